@@ -1,0 +1,259 @@
+"""ctypes binding of the CPU oracle (oracle/_build/liboracle.so).
+
+ORACLE — TEST INFRASTRUCTURE ONLY.  Import this from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg, never from rsba_amd/.  PARITY UNPINNED beyond the reference's mat_test.cc cases
+(see rsba_oracle_math.hpp).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+
+
+def build(force: bool = False) -> str:
+    srcs = [os.path.join(_HERE, f) for f in ("rsba_oracle.cpp", "rsba_oracle.h", "rsba_oracle_math.hpp", "Makefile")]
+    stale = (not os.path.exists(_LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.run(["make", "-C", _HERE] + (["-B"] if force else []), check=True, capture_output=True)
+    return _LIB_PATH
+
+
+class OrcProblem(C.Structure):
+    _fields_ = [
+        ("shutter", C.c_int32), ("scanlines", C.c_int32 * 2), ("interpolate_rotation", C.c_int32),
+        ("calibrated", C.c_int32), ("poses_per_frame", C.c_int32),
+        ("num_frames", C.c_int32), ("num_points", C.c_int32), ("num_intrinsics", C.c_int32),
+        ("num_observations", C.c_int64),
+        ("poses", C.c_void_p), ("points", C.c_void_p), ("intrinsics", C.c_void_p),
+        ("frame_intrinsics", C.c_void_p), ("obs_xy", C.c_void_p), ("obs_frame", C.c_void_p),
+        ("obs_point", C.c_void_p), ("pose_fixed_mask", C.c_void_p), ("point_constant", C.c_void_p),
+        ("intrinsics_constant", C.c_void_p), ("huber_a", C.c_double),
+    ]
+
+
+class OrcOptions(C.Structure):
+    _fields_ = [
+        ("max_num_iterations", C.c_int32), ("jacobi_scaling", C.c_int32),
+        ("max_num_consecutive_invalid_steps", C.c_int32), ("num_threads", C.c_int32),
+        ("initial_trust_region_radius", C.c_double), ("max_trust_region_radius", C.c_double),
+        ("min_trust_region_radius", C.c_double), ("min_relative_decrease", C.c_double),
+        ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
+        ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
+    ]
+
+
+class OrcIteration(C.Structure):
+    _fields_ = [
+        ("iteration", C.c_int32), ("step_is_valid", C.c_int32), ("step_is_successful", C.c_int32), ("pad", C.c_int32),
+        ("cost", C.c_double), ("cost_change", C.c_double), ("gradient_max_norm", C.c_double), ("step_norm", C.c_double),
+        ("relative_decrease", C.c_double), ("trust_region_radius", C.c_double), ("model_cost_change", C.c_double),
+    ]
+
+
+class OrcSummary(C.Structure):
+    _fields_ = [
+        ("termination_type", C.c_int32), ("num_successful_steps", C.c_int32), ("num_unsuccessful_steps", C.c_int32),
+        ("num_iterations", C.c_int32), ("num_residual_blocks", C.c_int32), ("num_residual_blocks_reduced", C.c_int32),
+        ("num_parameters_reduced", C.c_int32), ("pad", C.c_int32),
+        ("initial_cost", C.c_double), ("final_cost", C.c_double), ("fixed_cost", C.c_double),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.orc_evaluate_blocks.restype = C.c_int64
+        _lib.orc_evaluate_blocks_ceres_style.restype = C.c_int64
+        _lib.orc_evaluate_residuals.restype = C.c_int64
+        _lib.orc_norm3.restype = C.c_double
+        _lib.orc_huber.argtypes = [C.c_double, C.c_double, C.c_void_p]
+    return _lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def desc(prob) -> OrcProblem:
+    """Build the C descriptor over the problem's own numpy arrays (no copies: solves write in place)."""
+    d = OrcProblem()
+    d.shutter = int(prob.shutter)
+    d.scanlines[0], d.scanlines[1] = int(prob.scanlines[0]), int(prob.scanlines[1])
+    d.interpolate_rotation = int(bool(prob.interpolate_rotation))
+    d.calibrated = int(bool(prob.calibrated))
+    d.poses_per_frame = prob.poses_per_frame
+    d.num_frames, d.num_points, d.num_intrinsics = prob.num_frames, prob.num_points, prob.num_intrinsics
+    d.num_observations = prob.num_observations
+    d.poses, d.points, d.intrinsics = _ptr(prob.poses), _ptr(prob.points), _ptr(prob.intrinsics)
+    d.frame_intrinsics = _ptr(prob.frame_intrinsics)
+    d.obs_xy, d.obs_frame, d.obs_point = _ptr(prob.obs_xy), _ptr(prob.obs_frame), _ptr(prob.obs_point)
+    d.pose_fixed_mask = _ptr(prob.pose_fixed_mask)
+    d.point_constant = _ptr(prob.point_constant)
+    d.intrinsics_constant = _ptr(prob.intrinsics_constant)
+    d.huber_a = float(prob.huber_a)
+    d._keep = prob  # keep arrays alive
+    return d
+
+
+def evaluate_blocks(prob, jac: bool = True, threads: int = 0, d: OrcProblem | None = None):
+    """-> residuals [N,2], jacobians [N,2,K] (or None), ok [N] bool"""
+    d = d or desc(prob)
+    n, k = prob.num_observations, prob.jacobian_cols
+    r = np.zeros((n, 2))
+    J = np.zeros((n, 2, k)) if jac else None
+    ok = np.zeros(n, dtype=np.uint8)
+    if jac:
+        lib().orc_evaluate_blocks(C.byref(d), _ptr(r), _ptr(J), _ptr(ok), C.c_int32(threads))
+    else:
+        lib().orc_evaluate_residuals(C.byref(d), _ptr(r), _ptr(ok), C.c_int32(threads))
+    return r, J, ok.astype(bool)
+
+
+def evaluate(prob, gradient: bool = True):
+    """Problem::Evaluate -> (ok, cost, gradient dict or None)"""
+    d = desc(prob)
+    cost = C.c_double(0.0)
+    npose = prob.num_frames * prob.poses_per_frame * 6
+    g = np.zeros(npose + 3 * prob.num_points + 9 * prob.num_intrinsics) if gradient else None
+    rc = lib().orc_evaluate(C.byref(d), C.byref(cost), _ptr(g))
+    gd = None
+    if gradient:
+        gd = dict(poses=g[:npose].reshape(prob.poses.shape), points=g[npose:npose + 3 * prob.num_points].reshape(-1, 3),
+                  intrinsics=g[npose + 3 * prob.num_points:].reshape(-1, 9))
+    return rc == 0, cost.value, gd
+
+
+def normal_equations(prob):
+    d = desc(prob)
+    cd = 6 * prob.poses_per_frame
+    U = np.zeros((prob.num_frames, cd, cd)); gc = np.zeros((prob.num_frames, cd))
+    V = np.zeros((prob.num_points, 3, 3)); gp = np.zeros((prob.num_points, 3))
+    rc = lib().orc_normal_equations(C.byref(d), _ptr(U), _ptr(gc), _ptr(V), _ptr(gp))
+    assert rc == 0, rc
+    return U, gc, V, gp
+
+
+def default_options(**kw) -> OrcOptions:
+    o = OrcOptions()
+    lib().orc_default_options(C.byref(o))
+    for k, v in kw.items():
+        assert hasattr(o, k), k
+        setattr(o, k, v)
+    return o
+
+
+def solve(prob, options: OrcOptions | None = None, trace_cap: int = 256):
+    """ceres::Solve restated; prob's parameter arrays are overwritten.  -> (summary, [iteration records])"""
+    d = desc(prob)
+    o = options or default_options()
+    s = OrcSummary()
+    tr = (OrcIteration * trace_cap)()
+    lib().orc_solve(C.byref(d), C.byref(o), C.byref(s), tr, C.c_int32(trace_cap))
+    n = min(s.num_iterations, trace_cap)
+    return s, [tr[i] for i in range(n)]
+
+
+# ---- scalar helpers for the known-answer tests -------------------------------------------------
+def _v(x):
+    return np.ascontiguousarray(x, dtype=np.float64)
+
+
+def angle_axis_rotate(w, p):
+    out = np.zeros(3); lib().orc_angle_axis_rotate(_ptr(_v(w)), _ptr(_v(p)), _ptr(out)); return out
+
+
+def angle_axis_rotate_inplace(w, p):
+    """Rotate p in place (mat_test.cc:52 uses the aliasing form)."""
+    lib().orc_angle_axis_rotate(_ptr(_v(w)), _ptr(p), _ptr(p)); return p
+
+
+def lerp_rotation(r0, r1, tau):
+    out = np.zeros(3); lib().orc_lerp_rotation(_ptr(_v(r0)), _ptr(_v(r1)), C.c_double(tau), _ptr(out)); return out
+
+
+def distort(cam, img):
+    out = np.zeros(2); lib().orc_distort(_ptr(_v(cam)), _ptr(_v(img)), _ptr(out)); return out
+
+
+def undistort(cam, img):
+    out = np.zeros(2); ok = lib().orc_undistort(_ptr(_v(cam)), _ptr(_v(img)), _ptr(out)); return bool(ok), out
+
+
+def w2c(pose, X):
+    out = np.zeros(3); lib().orc_w2c(_ptr(_v(pose)), _ptr(_v(X)), _ptr(out)); return out
+
+
+def c2w(pose, pt):
+    out = np.zeros(3); lib().orc_c2w(_ptr(_v(pose)), _ptr(_v(pt)), _ptr(out)); return out
+
+
+def w2i(cam, pose, X, validate=True):
+    out = np.zeros(2); ok = lib().orc_w2i(_ptr(_v(cam)), _ptr(_v(pose)), _ptr(_v(X)), _ptr(out), C.c_int32(int(validate))); return bool(ok), out
+
+
+def direction_world(pose, X):
+    out = np.zeros(3); ok = lib().orc_direction_world(_ptr(_v(pose)), _ptr(_v(X)), _ptr(out)); return bool(ok), out
+
+
+def c2direction(pose, pt):
+    out = np.zeros(3); ok = lib().orc_c2direction(_ptr(_v(pose)), _ptr(_v(pt)), _ptr(out)); return bool(ok), out
+
+
+def direction_pixel(cam, pose, xy):
+    out = np.zeros(3); ok = lib().orc_direction_pixel(_ptr(_v(cam)), _ptr(_v(pose)), _ptr(_v(xy)), _ptr(out)); return bool(ok), out
+
+
+def ray_intersect(p2, d1, d2):
+    out = np.zeros(3); ok = lib().orc_ray_intersect(_ptr(_v(p2)), _ptr(_v(d1)), _ptr(_v(d2)), _ptr(out)); return bool(ok), out
+
+
+def triangulate(c1, d1, c2, d2):
+    out = np.zeros(3); ok = lib().orc_triangulate(_ptr(_v(c1)), _ptr(_v(d1)), _ptr(_v(c2)), _ptr(_v(d2)), _ptr(out)); return bool(ok), out
+
+
+def validate(cam, pose, xy, X, thr):
+    return bool(lib().orc_validate(_ptr(_v(cam)), _ptr(_v(pose)), _ptr(_v(xy)), _ptr(_v(X)), C.c_double(thr)))
+
+
+def ray_dist(cam, pose, obs, cam2, pose2, obs2):
+    out = np.zeros(3)
+    ok = lib().orc_ray_dist(_ptr(_v(cam)), _ptr(_v(pose)), _ptr(_v(obs)), _ptr(_v(cam2)), _ptr(_v(pose2)), _ptr(_v(obs2)), _ptr(out))
+    return bool(ok), out
+
+
+def norm3(v):
+    return lib().orc_norm3(_ptr(_v(v)))
+
+
+def interpolate_rs(p0, p1, shutter, scan, obs, interp_rotation=True):
+    out = np.zeros(6); sc = np.asarray(scan, dtype=np.int32)
+    lib().orc_interpolate_rs(_ptr(_v(p0)), _ptr(_v(p1)), C.c_int32(shutter), _ptr(sc), _ptr(_v(obs)), C.c_int32(int(interp_rotation)), _ptr(out))
+    return out
+
+
+def huber(a, s):
+    out = np.zeros(3); lib().orc_huber(C.c_double(a), C.c_double(s), _ptr(out)); return out
+
+
+def reproject(cam, poses, shutter, scan, X, sq_threshold, interp_rotation=True):
+    poses = _v(poses).reshape(-1, 6); out = np.zeros(2); sc = np.asarray(scan, dtype=np.int32)
+    ok = lib().orc_reproject(_ptr(_v(cam)), _ptr(poses), C.c_int32(len(poses)), C.c_int32(shutter), _ptr(sc),
+                             C.c_int32(int(interp_rotation)), _ptr(_v(X)), C.c_double(sq_threshold), _ptr(out))
+    return bool(ok), out
+
+
+def validate_obs(cam, poses, shutter, scan, X, obs, sq_threshold, min_dist, interp_rotation=True):
+    poses = _v(poses).reshape(-1, 6); sc = np.asarray(scan, dtype=np.int32)
+    return bool(lib().orc_validate_obs(_ptr(_v(cam)), _ptr(poses), C.c_int32(len(poses)), C.c_int32(shutter), _ptr(sc),
+                                       C.c_int32(int(interp_rotation)), _ptr(_v(X)), _ptr(_v(obs)), C.c_double(sq_threshold), C.c_double(min_dist)))

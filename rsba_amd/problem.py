@@ -1,0 +1,134 @@
+"""Flat (SoA) description of one bundle-adjustment problem — the host-side data model.
+
+This is what the reference's ``CeresHandler::Add`` loop (src/rsba/CeresHandler.h:94-390) produces
+when it walks a ``Session`` (src/rsba/sfm.thrift:13-74): one residual block per observation over
+user-owned parameter arrays, plus constness / subset masks.  The arrays here are handed to the
+C-ABI (include/rsba_amd.h) unchanged; nothing in this module computes.
+"""
+from __future__ import annotations
+
+import dataclasses
+from typing import Optional
+
+import numpy as np
+
+# src/rsba/mat/cam.h:37-41
+GLOBAL, HORIZONTAL, VERTICAL = 0, 1, 2
+# src/rsba/mat/cam.h:23-34
+FX, FY, K1, K2, P1, P2, K3, CX, CY = range(9)
+
+
+@dataclasses.dataclass
+class BAProblem:
+    """Parameter arrays are modified in place by solves, exactly like ceres::Problem blocks."""
+
+    poses: np.ndarray            # [F, P, 6] float64   (angle-axis world->camera, camera centre)
+    points: np.ndarray           # [M, 3]
+    intrinsics: np.ndarray       # [NI, 9]  {fx,fy,k1,k2,p1,p2,k3,cx,cy}
+    obs_xy: np.ndarray           # [N, 2]
+    obs_frame: np.ndarray        # [N] int32
+    obs_point: np.ndarray        # [N] int32
+    shutter: int = HORIZONTAL    # sess.rs
+    scanlines: tuple = (0, 1280)  # sess.scanlines
+    interpolate_rotation: bool = True   # opt.model.interpolateRotation
+    calibrated: bool = True             # opt.model.calibrated
+    frame_intrinsics: Optional[np.ndarray] = None   # [F] int32, None = every frame uses intrinsics[0]
+    pose_fixed_mask: Optional[np.ndarray] = None    # [F, P] uint8, bit i = coordinate i fixed
+    point_constant: Optional[np.ndarray] = None     # [M] uint8
+    intrinsics_constant: Optional[np.ndarray] = None  # [NI] uint8
+    huber_a: float = 0.0                # opt.ceres.huberLoss
+
+    def __post_init__(self):
+        self.poses = np.ascontiguousarray(self.poses, dtype=np.float64)
+        assert self.poses.ndim == 3 and self.poses.shape[2] == 6 and self.poses.shape[1] in (1, 2)
+        self.points = np.ascontiguousarray(self.points, dtype=np.float64).reshape(-1, 3)
+        self.intrinsics = np.ascontiguousarray(self.intrinsics, dtype=np.float64).reshape(-1, 9)
+        self.obs_xy = np.ascontiguousarray(self.obs_xy, dtype=np.float64).reshape(-1, 2)
+        self.obs_frame = np.ascontiguousarray(self.obs_frame, dtype=np.int32).reshape(-1)
+        self.obs_point = np.ascontiguousarray(self.obs_point, dtype=np.int32).reshape(-1)
+        assert len(self.obs_frame) == len(self.obs_point) == len(self.obs_xy)
+        for name, dt in (("frame_intrinsics", np.int32), ("pose_fixed_mask", np.uint8),
+                         ("point_constant", np.uint8), ("intrinsics_constant", np.uint8)):
+            v = getattr(self, name)
+            if v is not None:
+                setattr(self, name, np.ascontiguousarray(v, dtype=dt))
+        if self.pose_fixed_mask is not None:
+            self.pose_fixed_mask = self.pose_fixed_mask.reshape(self.num_frames, self.poses_per_frame)
+
+    @property
+    def num_frames(self) -> int:
+        return self.poses.shape[0]
+
+    @property
+    def poses_per_frame(self) -> int:
+        return self.poses.shape[1]
+
+    @property
+    def num_points(self) -> int:
+        return self.points.shape[0]
+
+    @property
+    def num_intrinsics(self) -> int:
+        return self.intrinsics.shape[0]
+
+    @property
+    def num_observations(self) -> int:
+        return self.obs_xy.shape[0]
+
+    @property
+    def jacobian_cols(self) -> int:
+        """Columns of one residual block: [cam 9]? [pose0 6] [pose1 6]? [point 3]."""
+        return (0 if self.calibrated else 9) + 6 * self.poses_per_frame + 3
+
+    def copy(self) -> "BAProblem":
+        kw = {}
+        for f in dataclasses.fields(self):
+            v = getattr(self, f.name)
+            kw[f.name] = v.copy() if isinstance(v, np.ndarray) else v
+        return BAProblem(**kw)
+
+    def shard(self, rank: int, world: int) -> "BAProblem":
+        """Point-partitioned shard for multi-GPU runs: rank r keeps every observation of
+        the points j with j % world == r; frames / intrinsics are replicated; points keep their global
+        numbering so parameter arrays stay comparable across ranks."""
+        keep = (self.obs_point % world) == rank
+        p = self.copy()
+        p.obs_xy = np.ascontiguousarray(self.obs_xy[keep])
+        p.obs_frame = np.ascontiguousarray(self.obs_frame[keep])
+        p.obs_point = np.ascontiguousarray(self.obs_point[keep])
+        return p
+
+
+def apply_gauge_masks(prob: BAProblem, *, fix_first_n_cameras: int = 0, fix_scale: bool = False,
+                      fix_rotation: bool = False, fix_position: bool = False, const3d: bool = False,
+                      start_frame: int = 0) -> BAProblem:
+    """Constness rules of CeresHandler::Add, applied to a problem whose every frame has observations.
+
+    src/rsba/CeresHandler.h:342-348 first-N cameras constant; :350-360 fixScale -> translation
+    {3,4,5} fixed on the first frame's poses[0] and the last frame's poses.back(); :361-371
+    fixRotation -> {0,1,2} on every pose; :372-382 fixPosition -> {3,4,5} on every pose (first
+    matching rule wins, per frame); :288-300 const3d / window BA freezes points.
+    """
+    F, P = prob.num_frames, prob.poses_per_frame
+    mask = np.zeros((F, P), dtype=np.uint8)
+    for f in range(F):
+        if f < fix_first_n_cameras:
+            mask[f, :] = 0x3F
+        elif fix_scale and (f == 0 or f == F - 1):
+            if f == 0:
+                mask[f, 0] |= 0b111000
+            else:
+                mask[f, P - 1] |= 0b111000
+        elif fix_rotation:
+            mask[f, :] |= 0b000111
+        elif fix_position:
+            mask[f, :] |= 0b111000
+    prob.pose_fixed_mask = mask
+    pc = np.zeros(prob.num_points, dtype=np.uint8)
+    if const3d:
+        pc[:] = 1
+    if start_frame > 0:
+        old = np.unique(prob.obs_point[prob.obs_frame < start_frame])
+        pc[old] = 1
+    prob.point_constant = pc
+    return prob
