@@ -1,0 +1,163 @@
+/* rsba_amd — C ABI of the MI355X-native bundle-adjustment hot path.
+ *
+ * Drop-in boundary for the path rsba runs through Ceres-Solver today.  Every entry
+ * point cites the reference interface it replaces; paths are relative to /root/reference/src/rsba/.
+ * Plain pointers and sizes only; no C++ / torch types.  All functions return an rsba_status (0 = OK),
+ * never throw, and — like ceres::Problem — are not re-entrant on one handle.
+ *
+ * The C++ facade in include/rsba/ceres_facade.hpp maps rsba's CostFunction / Problem / Solve usage
+ * onto these calls; INTEGRATION.md shows the reference-side binding.
+ */
+#ifndef RSBA_AMD_H_
+#define RSBA_AMD_H_
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RSBA_AMD_ABI_VERSION 1
+
+typedef enum rsba_status {
+  RSBA_OK = 0,
+  RSBA_ERR_INVALID_ARGUMENT = 1,
+  RSBA_ERR_NO_DEVICE = 2,        /* no gfx950 device / HIP runtime unusable: there is NO CPU fallback */
+  RSBA_ERR_HIP = 3,              /* a HIP call failed: see rsba_last_error() */
+  RSBA_ERR_EVALUATION_FAILED = 4,/* some functor returned false (point behind camera, mat/cam.h:410-412) */
+  RSBA_ERR_OUT_OF_MEMORY = 5,
+  RSBA_ERR_UNSUPPORTED = 6,
+  RSBA_ERR_COMM = 7
+} rsba_status;
+
+/* mat/cam.h:37-41 */
+enum { RSBA_SHUTTER_GLOBAL = 0, RSBA_SHUTTER_HORIZONTAL = 1, RSBA_SHUTTER_VERTICAL = 2 };
+
+/* The residual blocks CeresHandler::Add (CeresHandler.h:94-390) creates from a Session
+ * (sfm.thrift:13-74), flattened: one block per observation over caller-owned parameter arrays.
+ *   poses_per_frame == 2 -> RsBundleAdjustment (VideoSfmBaRs.h:15-84; CeresHandler.h:245-265)
+ *   poses_per_frame == 1 -> ReprojectionError  (video_bundler_free.h:17-101; CeresHandler.h:266-280)
+ *   calibrated != 0      -> intrinsics are data (Create(cam,obs) / Create(sess,opt,obs))
+ *   calibrated == 0      -> intrinsics are a parameter block (CreateWithCam / Create(obs)),
+ *                           shared sess.cam or per frame f.cam via frame_intrinsics (CeresHandler.h:260,277)
+ * Parameter arrays are written back by rsba_solve / rsba_download_parameters, as ceres::Solve
+ * mutates the blocks it was given (CeresHandler.h:253-255). */
+typedef struct rsba_problem_desc {
+  int32_t shutter;               /* sess.rs */
+  int32_t scanlines[2];          /* sess.scanlines */
+  int32_t interpolate_rotation;  /* opt.model.interpolateRotation (SfmOptions.h:25) */
+  int32_t calibrated;            /* opt.model.calibrated (SfmOptions.h:27) */
+  int32_t poses_per_frame;       /* f.poses.size(): 1 or 2 */
+  int32_t num_frames, num_points, num_intrinsics;
+  int64_t num_observations;
+  double* poses;                 /* [F][P][6]  angle-axis world->camera, camera centre (mat/cam.h:354-366) */
+  double* points;                /* [M][3] */
+  double* intrinsics;            /* [NI][9] {fx,fy,k1,k2,p1,p2,k3,cx,cy} (mat/cam.h:23-34) */
+  const int32_t* frame_intrinsics; /* [F] or NULL (= every frame uses intrinsics[0]) */
+  const double* obs_xy;          /* [N][2] */
+  const int32_t* obs_frame;      /* [N] */
+  const int32_t* obs_point;      /* [N] */
+  const uint8_t* pose_fixed_mask;   /* [F][P]: bit i set = coordinate i held fixed (SubsetParameterization,
+                                       CeresHandler.h:350-382); 0x3f = SetParameterBlockConstant (:342-348); NULL = free */
+  const uint8_t* point_constant;    /* [M] SetParameterBlockConstant on points (CeresHandler.h:288-300); NULL = free */
+  const uint8_t* intrinsics_constant; /* [NI] (CeresHandler.h:284,347); NULL = free */
+  double huber_a;                /* opt.ceres.huberLoss: > 0 -> one shared ceres::HuberLoss(a) (CeresHandler.h:85-90) */
+} rsba_problem_desc;
+
+typedef struct rsba_handle rsba_handle;   /* stands for the ceres::Problem member of CeresHandler (CeresHandler.h:78) */
+
+/* ceres::Solver::Options fields rsba writes (CeresHandler.h:403-412, VideoSfMHandler.cc:579-583)
+ * plus the Ceres 1.9 defaults the LM loop depends on. */
+typedef struct rsba_solver_options {
+  int32_t max_num_iterations;               /* 50 (CeresHandler.h:405) / 20 (VideoSfMHandler.h:63) */
+  int32_t jacobi_scaling;                   /* 1 */
+  int32_t max_num_consecutive_invalid_steps;/* 5 */
+  int32_t minimizer_progress_to_stdout;     /* CeresHandler.h:404 */
+  double initial_trust_region_radius;       /* 1e4 */
+  double max_trust_region_radius;           /* 1e16 */
+  double min_trust_region_radius;           /* 1e-32 */
+  double min_relative_decrease;             /* 1e-3 */
+  double min_lm_diagonal, max_lm_diagonal;  /* 1e-6, 1e32 */
+  double function_tolerance;                /* 1e-6 */
+  double gradient_tolerance;                /* 1e-10 */
+  double parameter_tolerance;               /* 1e-8 */
+} rsba_solver_options;
+
+enum { RSBA_CONVERGENCE = 0, RSBA_NO_CONVERGENCE = 1, RSBA_FAILURE = 2 };   /* ceres::TerminationType subset */
+
+/* ceres::IterationSummary subset (what minimizer_progress_to_stdout prints) */
+typedef struct rsba_iteration {
+  int32_t iteration, step_is_valid, step_is_successful, reserved;
+  double cost, cost_change, gradient_max_norm, step_norm, relative_decrease, trust_region_radius, model_cost_change;
+} rsba_iteration;
+
+/* ceres::Solver::Summary subset rsba reads (VideoSfMHandler.cc:593-596,627-630) + phase times that
+ * FullReport() prints */
+typedef struct rsba_solver_summary {
+  int32_t termination_type, num_successful_steps, num_unsuccessful_steps, num_iterations;
+  int32_t num_residual_blocks, num_residual_blocks_reduced, num_parameters_reduced, is_solution_usable;
+  double initial_cost, final_cost, fixed_cost;
+  double total_time_s, residual_jacobian_time_s, linear_solver_time_s;
+} rsba_solver_summary;
+
+/* Pointers into HBM for callers that keep results on the device (all fp64, component-major:
+ * component c of observation i at base[c * ld + i], observations in INTERNAL (frame-major) order;
+ * order[i] is the caller's index of internal observation i). */
+typedef struct rsba_device_view {
+  double* residuals;        /* [2][ld] */
+  double* jacobians;        /* [2*K][ld], row r column c at component r*K + c; columns [cam 9]?[pose0 6][pose1 6]?[point 3] */
+  int64_t ld;
+  int32_t jacobian_cols;    /* K */
+  int32_t reserved;
+  const int64_t* order_host;/* host array [N] */
+  double* poses; double* points; double* intrinsics;   /* device parameter arrays */
+} rsba_device_view;
+
+int32_t rsba_abi_version(void);
+const char* rsba_status_string(int32_t status);
+const char* rsba_last_error(void);                 /* thread-local detail for the last non-OK status */
+int32_t rsba_device_count(int32_t* count);         /* RSBA_ERR_NO_DEVICE when none: callers must fail, not fall back */
+
+/* == ceres::Problem construction + the AddResidualBlock loop (CeresHandler.h:78, 208-301): uploads the
+ * flat problem once; `device` is the HIP device ordinal (one process per GPU). */
+int32_t rsba_create(const rsba_problem_desc* desc, int32_t device, rsba_handle** out);
+void rsba_destroy(rsba_handle* h);                 /* == ~Problem: frees every device buffer exactly once */
+
+/* Run on a caller-owned HIP stream (hipStream_t as void*), e.g. torch's current stream; NULL = the
+ * handle's own stream. */
+int32_t rsba_set_stream(rsba_handle* h, void* hip_stream);
+
+/* Parameter blocks are caller-owned in Ceres; these move them between the caller's arrays and HBM. */
+int32_t rsba_upload_parameters(rsba_handle* h, const double* poses, const double* points, const double* intrinsics);
+int32_t rsba_download_parameters(rsba_handle* h, double* poses, double* points, double* intrinsics);
+
+/* The metric's "residual + Jacobian evaluation": == CostFunction::Evaluate over every residual block
+ * (VideoSfmBaRs.h:53-80 / video_bundler_free.h:70-91 through AutoDiffCostFunction).  Asynchronous on the
+ * handle's stream; results stay in HBM (rsba_get_device_view).  with_jacobians == 0 is the T=double path. */
+int32_t rsba_evaluate_device(rsba_handle* h, int32_t with_jacobians);
+
+/* == ceres::Problem::Evaluate(EvaluateOptions(), &cost, &residuals, &gradient, &jacobian)
+ * (CeresHandler.h:386-387 uses the cost-only form).  Host outputs in the CALLER's observation order:
+ * residuals [N][2]; jacobians [N][2][K] raw CostFunction blocks (no loss, no masks); gradient
+ * [F*P*6 | M*3 | NI*9] = loss-corrected J^T r with zeros at fixed coordinates; cost = 1/2 sum rho(|r|^2).
+ * Any output may be NULL.  num_failed receives the number of blocks whose functor returned false;
+ * the status is then RSBA_ERR_EVALUATION_FAILED. */
+int32_t rsba_evaluate(rsba_handle* h, double* cost, double* residuals, double* jacobians, double* gradient, int64_t* num_failed);
+
+int32_t rsba_get_device_view(rsba_handle* h, rsba_device_view* view);
+
+/* Average device time of one evaluation launch, measured with hipEvents on the handle's stream
+ * around `iters` back-to-back launches (after `warmup` untimed ones). */
+int32_t rsba_time_evaluate(rsba_handle* h, int32_t with_jacobians, int32_t warmup, int32_t iters, double* avg_ms);
+
+/* == ceres::Solve(options, &problem, &summary) with linear_solver_type = SPARSE_SCHUR
+ * (CeresHandler.h:394-426): LM trust region, Schur elimination of the points, Cholesky of the reduced
+ * camera system, all on the device; parameters are written back to the arrays given to rsba_create.
+ * trace (may be NULL) receives up to trace_capacity iteration records. */
+void rsba_default_solver_options(rsba_solver_options* opt);
+int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rsba_solver_summary* summary,
+                   rsba_iteration* trace, int32_t trace_capacity);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RSBA_AMD_H_ */

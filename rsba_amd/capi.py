@@ -1,0 +1,234 @@
+"""ctypes binding of the C ABI in include/rsba_amd.h (rsba_amd/_lib/librsba_amd.so).
+
+There is no CPU fallback: if the library is missing, fails to load, or no HIP device is present,
+everything here raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from .problem import BAProblem
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "librsba_amd.so")
+
+EXPORTS = [
+    "rsba_abi_version", "rsba_status_string", "rsba_last_error", "rsba_device_count", "rsba_create", "rsba_destroy",
+    "rsba_set_stream", "rsba_upload_parameters", "rsba_download_parameters", "rsba_evaluate_device", "rsba_evaluate",
+    "rsba_get_device_view", "rsba_time_evaluate", "rsba_default_solver_options", "rsba_solve",
+]
+
+
+class RsbaError(RuntimeError):
+    def __init__(self, status: int, detail: str):
+        super().__init__(f"rsba_amd status {status}: {detail}")
+        self.status = status
+
+
+class ProblemDesc(C.Structure):
+    _fields_ = [
+        ("shutter", C.c_int32), ("scanlines", C.c_int32 * 2), ("interpolate_rotation", C.c_int32),
+        ("calibrated", C.c_int32), ("poses_per_frame", C.c_int32),
+        ("num_frames", C.c_int32), ("num_points", C.c_int32), ("num_intrinsics", C.c_int32),
+        ("num_observations", C.c_int64),
+        ("poses", C.c_void_p), ("points", C.c_void_p), ("intrinsics", C.c_void_p),
+        ("frame_intrinsics", C.c_void_p), ("obs_xy", C.c_void_p), ("obs_frame", C.c_void_p),
+        ("obs_point", C.c_void_p), ("pose_fixed_mask", C.c_void_p), ("point_constant", C.c_void_p),
+        ("intrinsics_constant", C.c_void_p), ("huber_a", C.c_double),
+    ]
+
+
+class SolverOptions(C.Structure):
+    _fields_ = [
+        ("max_num_iterations", C.c_int32), ("jacobi_scaling", C.c_int32),
+        ("max_num_consecutive_invalid_steps", C.c_int32), ("minimizer_progress_to_stdout", C.c_int32),
+        ("initial_trust_region_radius", C.c_double), ("max_trust_region_radius", C.c_double),
+        ("min_trust_region_radius", C.c_double), ("min_relative_decrease", C.c_double),
+        ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
+        ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
+    ]
+
+
+class Iteration(C.Structure):
+    _fields_ = [
+        ("iteration", C.c_int32), ("step_is_valid", C.c_int32), ("step_is_successful", C.c_int32), ("reserved", C.c_int32),
+        ("cost", C.c_double), ("cost_change", C.c_double), ("gradient_max_norm", C.c_double), ("step_norm", C.c_double),
+        ("relative_decrease", C.c_double), ("trust_region_radius", C.c_double), ("model_cost_change", C.c_double),
+    ]
+
+
+class SolverSummary(C.Structure):
+    _fields_ = [
+        ("termination_type", C.c_int32), ("num_successful_steps", C.c_int32), ("num_unsuccessful_steps", C.c_int32),
+        ("num_iterations", C.c_int32), ("num_residual_blocks", C.c_int32), ("num_residual_blocks_reduced", C.c_int32),
+        ("num_parameters_reduced", C.c_int32), ("is_solution_usable", C.c_int32),
+        ("initial_cost", C.c_double), ("final_cost", C.c_double), ("fixed_cost", C.c_double),
+        ("total_time_s", C.c_double), ("residual_jacobian_time_s", C.c_double), ("linear_solver_time_s", C.c_double),
+    ]
+
+
+class DeviceView(C.Structure):
+    _fields_ = [
+        ("residuals", C.c_void_p), ("jacobians", C.c_void_p), ("ld", C.c_int64), ("jacobian_cols", C.c_int32),
+        ("reserved", C.c_int32), ("order_host", C.c_void_p), ("poses", C.c_void_p), ("points", C.c_void_p),
+        ("intrinsics", C.c_void_p),
+    ]
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    src = os.path.join(_HERE, "csrc")
+    subprocess.run(["make", "-C", src, "-j4"] + (["-B"] if force else []), check=True, capture_output=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RsbaError(-1, f"{LIB_PATH} is missing: run __graft_entry__.build() (no CPU fallback exists)")
+        try:
+            # torch ships its own libamdhip64 with the same SONAME; importing it first makes this
+            # library share that runtime, so device pointers / streams are interchangeable with torch.
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover - torch is optional for the C ABI itself
+            pass
+        _lib = C.CDLL(LIB_PATH)
+        _lib.rsba_status_string.restype = C.c_char_p
+        _lib.rsba_last_error.restype = C.c_char_p
+        _lib.rsba_destroy.restype = None
+        _lib.rsba_default_solver_options.restype = None
+        _lib.rsba_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.rsba_destroy.argtypes = [C.c_void_p]
+    return _lib
+
+
+def _check(status: int):
+    if status != 0:
+        L = lib()
+        raise RsbaError(status, f"{L.rsba_status_string(status).decode()} — {L.rsba_last_error().decode()}")
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def device_count() -> int:
+    n = C.c_int32(0)
+    _check(lib().rsba_device_count(C.byref(n)))
+    return n.value
+
+
+def make_desc(prob: BAProblem) -> ProblemDesc:
+    d = ProblemDesc()
+    d.shutter = int(prob.shutter)
+    d.scanlines[0], d.scanlines[1] = int(prob.scanlines[0]), int(prob.scanlines[1])
+    d.interpolate_rotation = int(bool(prob.interpolate_rotation))
+    d.calibrated = int(bool(prob.calibrated))
+    d.poses_per_frame = prob.poses_per_frame
+    d.num_frames, d.num_points, d.num_intrinsics = prob.num_frames, prob.num_points, prob.num_intrinsics
+    d.num_observations = prob.num_observations
+    d.poses, d.points, d.intrinsics = _ptr(prob.poses), _ptr(prob.points), _ptr(prob.intrinsics)
+    d.frame_intrinsics = _ptr(prob.frame_intrinsics)
+    d.obs_xy, d.obs_frame, d.obs_point = _ptr(prob.obs_xy), _ptr(prob.obs_frame), _ptr(prob.obs_point)
+    d.pose_fixed_mask = _ptr(prob.pose_fixed_mask)
+    d.point_constant = _ptr(prob.point_constant)
+    d.intrinsics_constant = _ptr(prob.intrinsics_constant)
+    d.huber_a = float(prob.huber_a)
+    return d
+
+
+class DeviceProblem:
+    """A problem resident in HBM (the ceres::Problem of CeresHandler, src/rsba/CeresHandler.h:78)."""
+
+    def __init__(self, prob: BAProblem, device: int = 0):
+        self.prob = prob
+        self._desc = make_desc(prob)
+        self._h = C.c_void_p()
+        _check(lib().rsba_create(C.byref(self._desc), C.c_int32(device), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib().rsba_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_stream(self, raw_stream: int | None):
+        _check(lib().rsba_set_stream(self._h, C.c_void_p(raw_stream or 0)))
+
+    def upload_parameters(self):
+        p = self.prob
+        _check(lib().rsba_upload_parameters(self._h, _ptr(p.poses), _ptr(p.points), _ptr(p.intrinsics)))
+
+    def download_parameters(self):
+        p = self.prob
+        _check(lib().rsba_download_parameters(self._h, _ptr(p.poses), _ptr(p.points), _ptr(p.intrinsics)))
+
+    def evaluate_device(self, with_jacobians: bool = True):
+        """One residual(+Jacobian) evaluation of every observation; asynchronous, results stay in HBM."""
+        _check(lib().rsba_evaluate_device(self._h, C.c_int32(int(with_jacobians))))
+
+    def time_evaluate(self, with_jacobians: bool = True, warmup: int = 2, iters: int = 10) -> float:
+        ms = C.c_double(0.0)
+        _check(lib().rsba_time_evaluate(self._h, C.c_int32(int(with_jacobians)), C.c_int32(warmup), C.c_int32(iters), C.byref(ms)))
+        return ms.value
+
+    def evaluate(self, residuals: bool = True, jacobians: bool = True, gradient: bool = False, allow_failed: bool = True):
+        """Problem::Evaluate -> dict(cost, residuals [N,2], jacobians [N,2,K], gradient{...}, num_failed)"""
+        p = self.prob
+        n, k = p.num_observations, p.jacobian_cols
+        cost = C.c_double(0.0)
+        nf = C.c_int64(0)
+        r = np.zeros((n, 2)) if residuals else None
+        J = np.zeros((n, 2, k)) if jacobians else None
+        npose = p.num_frames * p.poses_per_frame * 6
+        g = np.zeros(npose + 3 * p.num_points + 9 * p.num_intrinsics) if gradient else None
+        st = lib().rsba_evaluate(self._h, C.byref(cost), _ptr(r), _ptr(J), _ptr(g), C.byref(nf))
+        if st != 0 and not (allow_failed and st == 4):
+            _check(st)
+        out = dict(cost=cost.value, residuals=r, jacobians=J, num_failed=nf.value)
+        if gradient:
+            out["gradient"] = dict(poses=g[:npose].reshape(p.poses.shape), points=g[npose:npose + 3 * p.num_points].reshape(-1, 3),
+                                   intrinsics=g[npose + 3 * p.num_points:].reshape(-1, 9))
+        return out
+
+    def device_view(self) -> DeviceView:
+        v = DeviceView()
+        _check(lib().rsba_get_device_view(self._h, C.byref(v)))
+        return v
+
+    def solve(self, options: SolverOptions | None = None, trace_cap: int = 256):
+        """ceres::Solve; the BAProblem's parameter arrays are overwritten.  -> (summary, [iterations])"""
+        o = options or default_options()
+        s = SolverSummary()
+        tr = (Iteration * trace_cap)()
+        st = lib().rsba_solve(self._h, C.byref(o), C.byref(s), tr, C.c_int32(trace_cap))
+        _check(st)
+        return s, [tr[i] for i in range(min(s.num_iterations, trace_cap))]
+
+
+def default_options(**kw) -> SolverOptions:
+    o = SolverOptions()
+    lib().rsba_default_solver_options(C.byref(o))
+    for k, v in kw.items():
+        assert hasattr(o, k), k
+        setattr(o, k, v)
+    return o

@@ -1,0 +1,272 @@
+// C-ABI implementation (include/rsba_amd.h).  Host-side glue only: every number on the path is
+// produced by the HIP kernels; there is no CPU evaluation path in this library.
+#include "../../include/rsba_amd.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "handle.hpp"
+
+using namespace rsba;
+
+namespace {
+thread_local std::string g_last_error;
+int32_t fail(int32_t code, const std::string& msg) { g_last_error = msg; return code; }
+}  // namespace
+
+int32_t rsba_set_error(int32_t code, const char* msg) { return fail(code, msg); }
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess) return fail(e_ == hipErrorOutOfMemory ? RSBA_ERR_OUT_OF_MEMORY : RSBA_ERR_HIP, \
+                                      std::string(#expr) + ": " + hipGetErrorString(e_));          \
+  } while (0)
+
+template <class T>
+static int32_t dev_alloc(rsba_handle* h, T** p, size_t count) {
+  void* q = nullptr;
+  HIP_TRY(hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)));
+  h->allocs.push_back(q);
+  *p = static_cast<T*>(q);
+  return RSBA_OK;
+}
+template <class T>
+static int32_t dev_upload(rsba_handle* h, T** p, const T* src, size_t count) {
+  int32_t rc = dev_alloc(h, p, count);
+  if (rc) return rc;
+  if (count) HIP_TRY(hipMemcpy(*p, src, count * sizeof(T), hipMemcpyHostToDevice));
+  return RSBA_OK;
+}
+
+extern "C" {
+
+int32_t rsba_abi_version(void) { return RSBA_AMD_ABI_VERSION; }
+
+const char* rsba_status_string(int32_t s) {
+  switch (s) {
+    case RSBA_OK: return "ok";
+    case RSBA_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case RSBA_ERR_NO_DEVICE: return "no HIP device (this library has no CPU fallback)";
+    case RSBA_ERR_HIP: return "HIP error";
+    case RSBA_ERR_EVALUATION_FAILED: return "evaluation failed (a residual functor returned false)";
+    case RSBA_ERR_OUT_OF_MEMORY: return "out of device memory";
+    case RSBA_ERR_UNSUPPORTED: return "unsupported configuration";
+    case RSBA_ERR_COMM: return "collective exchange failed";
+  }
+  return "unknown status";
+}
+
+const char* rsba_last_error(void) { return g_last_error.c_str(); }
+
+int32_t rsba_device_count(int32_t* count) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (count) *count = (e == hipSuccess) ? n : 0;
+  if (e != hipSuccess || n <= 0) return fail(RSBA_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+  return RSBA_OK;
+}
+
+int32_t rsba_create(const rsba_problem_desc* d, int32_t device, rsba_handle** out) {
+  if (!d || !out) return fail(RSBA_ERR_INVALID_ARGUMENT, "null argument");
+  *out = nullptr;
+  if (d->poses_per_frame != 1 && d->poses_per_frame != 2) return fail(RSBA_ERR_INVALID_ARGUMENT, "poses_per_frame must be 1 or 2");
+  if (d->num_frames <= 0 || d->num_points <= 0 || d->num_intrinsics <= 0 || d->num_observations < 0)
+    return fail(RSBA_ERR_INVALID_ARGUMENT, "empty frames / points / intrinsics");
+  if (!d->poses || !d->points || !d->intrinsics || (d->num_observations && (!d->obs_xy || !d->obs_frame || !d->obs_point)))
+    return fail(RSBA_ERR_INVALID_ARGUMENT, "null array");
+  if (d->shutter < 0 || d->shutter > 2) return fail(RSBA_ERR_INVALID_ARGUMENT, "shutter");
+  if (d->shutter != RSBA_SHUTTER_GLOBAL && d->poses_per_frame == 2 && d->scanlines[0] == d->scanlines[1])
+    return fail(RSBA_ERR_INVALID_ARGUMENT, "scanlines[0] == scanlines[1]");
+  if (d->num_intrinsics > 1 && !d->frame_intrinsics) return fail(RSBA_ERR_INVALID_ARGUMENT, "frame_intrinsics required when num_intrinsics > 1");
+  const int64_t N = d->num_observations;
+  for (int64_t i = 0; i < N; ++i) {
+    if (d->obs_frame[i] < 0 || d->obs_frame[i] >= d->num_frames || d->obs_point[i] < 0 || d->obs_point[i] >= d->num_points)
+      return fail(RSBA_ERR_INVALID_ARGUMENT, "observation index out of range");
+  }
+  if (d->frame_intrinsics) for (int f = 0; f < d->num_frames; ++f)
+    if (d->frame_intrinsics[f] < 0 || d->frame_intrinsics[f] >= d->num_intrinsics) return fail(RSBA_ERR_INVALID_ARGUMENT, "frame_intrinsics out of range");
+
+  int32_t ndev = 0;
+  int32_t rc = rsba_device_count(&ndev);
+  if (rc) return rc;
+  if (device < 0 || device >= ndev) return fail(RSBA_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+  HIP_TRY(hipSetDevice(device));
+
+  rsba_handle* h = new rsba_handle();
+  h->device = device;
+  h->desc = *d;
+  auto bail = [&](int32_t code) { rsba_destroy(h); return code; };
+  if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) { delete h; return fail(RSBA_ERR_HIP, "hipStreamCreate"); }
+  h->stream = h->own_stream;
+
+  // frame-major order: the order CeresHandler::Add produces is already frame-major
+  // (VideoSfMHandler.cc:587-590); anything else is stably sorted once here.
+  h->order.resize(N);
+  std::iota(h->order.begin(), h->order.end(), (int64_t)0);
+  h->identity_order = std::is_sorted(d->obs_frame, d->obs_frame + N);
+  if (!h->identity_order)
+    std::stable_sort(h->order.begin(), h->order.end(), [&](int64_t a, int64_t b) { return d->obs_frame[a] < d->obs_frame[b]; });
+  std::vector<double> xy(2 * (size_t)N);
+  std::vector<int32_t> of(N), op(N);
+  for (int64_t i = 0; i < N; ++i) {
+    const int64_t u = h->order[i];
+    xy[2 * i] = d->obs_xy[2 * u]; xy[2 * i + 1] = d->obs_xy[2 * u + 1];
+    of[i] = d->obs_frame[u]; op[i] = d->obs_point[u];
+  }
+
+  DeviceProblem& dp = h->dp;
+  std::memset(&dp, 0, sizeof dp);
+  dp.shutter = d->shutter; dp.scan0 = d->scanlines[0]; dp.scan1 = d->scanlines[1];
+  dp.interp_rotation = d->interpolate_rotation != 0; dp.calibrated = d->calibrated != 0; dp.P = d->poses_per_frame;
+  dp.F = d->num_frames; dp.M = d->num_points; dp.NI = d->num_intrinsics; dp.N = N;
+  dp.ld = (N + 63) / 64 * 64; if (dp.ld == 0) dp.ld = 64;
+  dp.K = (dp.calibrated ? 0 : 9) + 6 * dp.P + 3;
+  dp.huber_a = d->huber_a;
+  const size_t npose = (size_t)dp.F * dp.P * 6;
+
+  double2* dxy = nullptr; int32_t *dof = nullptr, *dop = nullptr, *dfi = nullptr;
+  if ((rc = dev_upload(h, reinterpret_cast<double**>(&dxy), xy.data(), 2 * (size_t)N))) return bail(rc);
+  if ((rc = dev_upload(h, &dof, of.data(), (size_t)N))) return bail(rc);
+  if ((rc = dev_upload(h, &dop, op.data(), (size_t)N))) return bail(rc);
+  std::vector<int32_t> fi(dp.F, 0);
+  if (d->frame_intrinsics) std::copy(d->frame_intrinsics, d->frame_intrinsics + dp.F, fi.begin());
+  if ((rc = dev_upload(h, &dfi, fi.data(), (size_t)dp.F))) return bail(rc);
+  dp.xy = dxy; dp.obs_frame = dof; dp.obs_point = dop; dp.frame_intr = dfi;
+  if ((rc = dev_upload(h, &dp.poses, d->poses, npose))) return bail(rc);
+  if ((rc = dev_upload(h, &dp.points, d->points, (size_t)dp.M * 3))) return bail(rc);
+  if ((rc = dev_upload(h, &dp.intr, d->intrinsics, (size_t)dp.NI * 9))) return bail(rc);
+
+  // column scales: 0 at fixed coordinates, 1 elsewhere until the Jacobi scale is estimated
+  h->mask_pose.assign(npose, 1.0); h->mask_point.assign((size_t)dp.M * 3, 1.0); h->mask_intr.assign((size_t)dp.NI * 9, 1.0);
+  if (d->pose_fixed_mask) for (size_t b = 0; b < (size_t)dp.F * dp.P; ++b) for (int k = 0; k < 6; ++k)
+    if (d->pose_fixed_mask[b] & (1u << k)) h->mask_pose[6 * b + k] = 0.0;
+  if (d->point_constant) for (int j = 0; j < dp.M; ++j) if (d->point_constant[j]) for (int k = 0; k < 3; ++k) h->mask_point[3 * (size_t)j + k] = 0.0;
+  if (d->intrinsics_constant) for (int c = 0; c < dp.NI; ++c) if (d->intrinsics_constant[c]) for (int k = 0; k < 9; ++k) h->mask_intr[9 * (size_t)c + k] = 0.0;
+  if ((rc = dev_upload(h, &dp.scale_pose, h->mask_pose.data(), npose))) return bail(rc);
+  if ((rc = dev_upload(h, &dp.scale_point, h->mask_point.data(), (size_t)dp.M * 3))) return bail(rc);
+  if ((rc = dev_upload(h, &dp.scale_intr, h->mask_intr.data(), (size_t)dp.NI * 9))) return bail(rc);
+
+  if ((rc = dev_alloc(h, &dp.res, 2 * (size_t)dp.ld))) return bail(rc);
+  if ((rc = dev_alloc(h, &dp.jac, 2 * (size_t)dp.K * dp.ld))) return bail(rc);
+  const int nb = std::max(eval_num_blocks(N), 1);
+  if ((rc = dev_alloc(h, &dp.cost_partial, (size_t)nb))) return bail(rc);
+  if ((rc = dev_alloc(h, &dp.fixed_partial, (size_t)nb))) return bail(rc);
+  if ((rc = dev_alloc(h, &dp.fail_count, 1))) return bail(rc);
+  if ((rc = dev_alloc(h, &h->d_cost2, 2))) return bail(rc);
+  if (hipMemset(dp.fail_count, 0, sizeof(int)) != hipSuccess) return bail(fail(RSBA_ERR_HIP, "hipMemset"));
+  if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) return bail(fail(RSBA_ERR_HIP, "hipEventCreate"));
+  *out = h;
+  return RSBA_OK;
+}
+
+void rsba_destroy(rsba_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  rsba_destroy_solver(h);
+  for (void* p : h->allocs) (void)hipFree(p);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  delete h;
+}
+
+int32_t rsba_set_stream(rsba_handle* h, void* s) {
+  if (!h) return fail(RSBA_ERR_INVALID_ARGUMENT, "null handle");
+  h->stream = s ? static_cast<hipStream_t>(s) : h->own_stream;
+  return RSBA_OK;
+}
+
+int32_t rsba_upload_parameters(rsba_handle* h, const double* poses, const double* points, const double* intr) {
+  if (!h) return fail(RSBA_ERR_INVALID_ARGUMENT, "null handle");
+  HIP_TRY(hipSetDevice(h->device));
+  const DeviceProblem& dp = h->dp;
+  if (poses) HIP_TRY(hipMemcpyAsync(dp.poses, poses, (size_t)dp.F * dp.P * 6 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (points) HIP_TRY(hipMemcpyAsync(dp.points, points, (size_t)dp.M * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (intr) HIP_TRY(hipMemcpyAsync(dp.intr, intr, (size_t)dp.NI * 9 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return RSBA_OK;
+}
+
+int32_t rsba_download_parameters(rsba_handle* h, double* poses, double* points, double* intr) {
+  if (!h) return fail(RSBA_ERR_INVALID_ARGUMENT, "null handle");
+  HIP_TRY(hipSetDevice(h->device));
+  const DeviceProblem& dp = h->dp;
+  if (poses) HIP_TRY(hipMemcpyAsync(poses, dp.poses, (size_t)dp.F * dp.P * 6 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (points) HIP_TRY(hipMemcpyAsync(points, dp.points, (size_t)dp.M * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (intr) HIP_TRY(hipMemcpyAsync(intr, dp.intr, (size_t)dp.NI * 9 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return RSBA_OK;
+}
+
+int32_t rsba_evaluate_device(rsba_handle* h, int32_t with_jacobians) {
+  if (!h) return fail(RSBA_ERR_INVALID_ARGUMENT, "null handle");
+  HIP_TRY(launch_eval(h->dp, with_jacobians ? kRawJacobian : kResidualOnly, h->stream));
+  return RSBA_OK;
+}
+
+int32_t rsba_get_device_view(rsba_handle* h, rsba_device_view* v) {
+  if (!h || !v) return fail(RSBA_ERR_INVALID_ARGUMENT, "null argument");
+  std::memset(v, 0, sizeof *v);
+  v->residuals = h->dp.res; v->jacobians = h->dp.jac; v->ld = h->dp.ld; v->jacobian_cols = h->dp.K;
+  v->order_host = h->order.data(); v->poses = h->dp.poses; v->points = h->dp.points; v->intrinsics = h->dp.intr;
+  return RSBA_OK;
+}
+
+int32_t rsba_time_evaluate(rsba_handle* h, int32_t with_jacobians, int32_t warmup, int32_t iters, double* avg_ms) {
+  if (!h || !avg_ms || iters <= 0) return fail(RSBA_ERR_INVALID_ARGUMENT, "bad argument");
+  HIP_TRY(hipSetDevice(h->device));
+  const EvalMode mode = with_jacobians ? kRawJacobian : kResidualOnly;
+  for (int i = 0; i < warmup; ++i) HIP_TRY(launch_eval(h->dp, mode, h->stream));
+  HIP_TRY(hipEventRecord(h->ev0, h->stream));
+  for (int i = 0; i < iters; ++i) HIP_TRY(launch_eval(h->dp, mode, h->stream));
+  HIP_TRY(hipEventRecord(h->ev1, h->stream));
+  HIP_TRY(hipEventSynchronize(h->ev1));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  *avg_ms = (double)ms / iters;
+  return RSBA_OK;
+}
+
+int32_t rsba_evaluate(rsba_handle* h, double* cost, double* residuals, double* jacobians, double* gradient, int64_t* num_failed) {
+  if (!h) return fail(RSBA_ERR_INVALID_ARGUMENT, "null handle");
+  HIP_TRY(hipSetDevice(h->device));
+  DeviceProblem& dp = h->dp;
+  const int64_t N = dp.N, ld = dp.ld; const int K = dp.K;
+  HIP_TRY(hipMemsetAsync(dp.fail_count, 0, sizeof(int), h->stream));
+  HIP_TRY(launch_eval(dp, jacobians ? kRawJacobian : kResidualOnly, h->stream));
+  HIP_TRY(launch_cost_reduce(dp, h->d_cost2, h->stream));
+  double c2[2] = {0, 0}; int nfail = 0;
+  HIP_TRY(hipMemcpyAsync(c2, h->d_cost2, sizeof c2, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(&nfail, dp.fail_count, sizeof nfail, hipMemcpyDeviceToHost, h->stream));
+  std::vector<double> hr, hj;
+  if (residuals) { hr.resize(2 * (size_t)ld); HIP_TRY(hipMemcpyAsync(hr.data(), dp.res, hr.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream)); }
+  if (jacobians) { hj.resize(2 * (size_t)K * ld); HIP_TRY(hipMemcpyAsync(hj.data(), dp.jac, hj.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream)); }
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (cost) *cost = c2[0] + c2[1];
+  if (num_failed) *num_failed = nfail;
+  // component-major device layout -> caller's [N][2] / [N][2][K] in the caller's observation order
+  if (residuals) for (int64_t i = 0; i < N; ++i) { const int64_t u = h->order[i]; residuals[2 * u] = hr[i]; residuals[2 * u + 1] = hr[ld + i]; }
+  if (jacobians) for (int c = 0; c < 2 * K; ++c) { const double* src = &hj[(size_t)c * ld]; for (int64_t i = 0; i < N; ++i) jacobians[(size_t)h->order[i] * 2 * K + c] = src[i]; }
+  if (gradient) {
+    int32_t rc = rsba_gradient(h, gradient);
+    if (rc) return rc;
+  }
+  if (nfail) return fail(RSBA_ERR_EVALUATION_FAILED, std::to_string(nfail) + " residual blocks failed to evaluate");
+  return RSBA_OK;
+}
+
+void rsba_default_solver_options(rsba_solver_options* o) {
+  if (!o) return;
+  // Ceres 1.9 Solver::Options defaults; iteration cap as CeresHandler.h:405
+  o->max_num_iterations = 50; o->jacobi_scaling = 1; o->max_num_consecutive_invalid_steps = 5; o->minimizer_progress_to_stdout = 0;
+  o->initial_trust_region_radius = 1e4; o->max_trust_region_radius = 1e16; o->min_trust_region_radius = 1e-32;
+  o->min_relative_decrease = 1e-3; o->min_lm_diagonal = 1e-6; o->max_lm_diagonal = 1e32;
+  o->function_tolerance = 1e-6; o->gradient_tolerance = 1e-10; o->parameter_tolerance = 1e-8;
+}
+
+}  // extern "C"

@@ -1,0 +1,55 @@
+// Device-resident problem state shared by the kernels and the C-ABI implementation.
+//
+// HBM layout (everything fp64 / int32, struct-of-arrays, rows padded to 64 elements = 512 B):
+//   observations, frame-major (sorted by frame, stable):  xy[N] (double2), frame[N], point[N]
+//   parameters:  poses[F][P][6], points[M][3], intr[NI][9], frame_intr[F]
+//   evaluation:  res[2][ld], jac[2K][ld]   (component-major: one coalesced 512-B store per wave per
+//                component; row r, column c of observation i lives at jac[(r*K + c) * ld + i])
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace rsba {
+
+struct DeviceProblem {
+  // model
+  int shutter, scan0, scan1, interp_rotation, calibrated, P;
+  int F, M, NI;
+  int64_t N, ld;                 // observations, padded row length
+  int K;                         // Jacobian columns per observation
+  double huber_a;
+  // observations (frame-major)
+  const double2* xy;
+  const int32_t* obs_frame;
+  const int32_t* obs_point;
+  // parameters
+  double* poses;
+  double* points;
+  double* intr;
+  const int32_t* frame_intr;     // [F]
+  // column scales: 0 for a fixed coordinate, otherwise the Jacobi scale (1 before it is estimated)
+  double* scale_pose;            // [F][P][6]
+  double* scale_point;           // [M][3]
+  double* scale_intr;            // [NI][9]
+  // evaluation outputs
+  double* res;                   // [2][ld]
+  double* jac;                   // [2K][ld]
+  double* cost_partial;          // [nblocks] 1/2 sum rho0 over non-dropped blocks of each workgroup
+  double* fixed_partial;         // [nblocks] same over dropped (all-constant) blocks
+  int* fail_count;               // number of observations whose functor returned false
+};
+
+constexpr int kEvalBlock = 256;
+constexpr int kStageFrames = 16;   // camera blocks staged through LDS per workgroup
+
+enum EvalMode : int {
+  kResidualOnly = 0,   // T=double path: residuals + cost (trial point of the trust-region loop)
+  kRawJacobian = 1,    // what CostFunction::Evaluate returns: r and J, no loss, no masks (the metric)
+  kLmJacobian = 2,     // loss-corrected, masked, column-scaled r and J for the normal equations
+};
+
+hipError_t launch_eval(const DeviceProblem& dp, EvalMode mode, hipStream_t stream);
+int eval_num_blocks(int64_t n);
+hipError_t launch_cost_reduce(const DeviceProblem& dp, double* out2, hipStream_t stream);
+
+}  // namespace rsba

@@ -1,0 +1,30 @@
+// The object behind rsba_handle (include/rsba_amd.h): owns every device allocation of one problem.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <vector>
+
+#include "../../include/rsba_amd.h"
+#include "device_state.hpp"
+
+namespace rsba { struct Solver; }
+
+struct rsba_handle {
+  int device = 0;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  rsba_problem_desc desc;              // caller's descriptor (parameter pointers are written back by solve)
+  rsba::DeviceProblem dp;
+  std::vector<int64_t> order;          // internal (frame-major) index -> caller's observation index
+  bool identity_order = true;
+  std::vector<double> mask_pose, mask_point, mask_intr;   // 0 = fixed coordinate, 1 = free
+  std::vector<void*> allocs;
+  double* d_cost2 = nullptr;           // {cost, fixed cost}
+  rsba::Solver* solver = nullptr;      // normal-equation / Schur / LM state, built on first use
+};
+
+// internal (not exported through the C header)
+int32_t rsba_set_error(int32_t code, const char* msg);
+int32_t rsba_gradient(rsba_handle* h, double* gradient_host);
+void rsba_destroy_solver(rsba_handle* h);

@@ -1,0 +1,168 @@
+// K1  rs_residual_jacobian — the metric's "residual + Jacobian evaluation" (SURVEY §2.1 K1/K3/K8).
+//
+// One lane per observation over the frame-major observation list.  A 256-lane workgroup touches
+// 1-2 camera blocks, so their 6P pose doubles (and column scales) are staged once through LDS;
+// observation records (24 B) are coalesced reads, points are a 24-B gather that hits L2 (the point
+// array of the 1k-camera scene is 2.4 MB), and every output component is one coalesced 512-B store
+// per wave into the component-major res/jac arrays.  HBM-bound: 280 B/observation, ~0.6 kflop.
+#include "device_state.hpp"
+#include "obs_math.hpp"
+
+namespace rsba {
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+template <bool CAL, int P, int MODE>
+__global__ __launch_bounds__(kEvalBlock) void eval_kernel(const DeviceProblem dp) {
+  constexpr int CD = 6 * P;
+  constexpr int K = ObsOut<CAL, P>::K;
+  constexpr int OFF_POSE = CAL ? 0 : 9;
+  constexpr int OFF_PT = OFF_POSE + CD;
+  __shared__ double s_pose[kStageFrames * CD];
+  __shared__ double s_scale[MODE == kLmJacobian ? kStageFrames * CD : 1];
+  __shared__ double s_red[2][kEvalBlock / 64];
+
+  const int tid = threadIdx.x;
+  const int64_t base = (int64_t)blockIdx.x * kEvalBlock;
+  const int64_t i = base + tid;
+  const int64_t last = (base + kEvalBlock - 1 < dp.N) ? base + kEvalBlock - 1 : dp.N - 1;
+  const int f_lo = dp.obs_frame[base];
+  const int f_hi = dp.obs_frame[last];
+  const bool staged = (f_hi - f_lo) < kStageFrames;
+  if (staged) {
+    const int nvals = (f_hi - f_lo + 1) * CD;
+    for (int k = tid; k < nvals; k += kEvalBlock) {
+      s_pose[k] = dp.poses[(size_t)f_lo * CD + k];
+      if (MODE == kLmJacobian) s_scale[k] = dp.scale_pose[(size_t)f_lo * CD + k];
+    }
+    __syncthreads();
+  }
+
+  double cost = 0.0, fixed = 0.0;
+  if (i < dp.N) {
+    const double2 xy = dp.xy[i];
+    const int f = dp.obs_frame[i];
+    const int j = dp.obs_point[i];
+    double pose[CD], X[3], cam[9];
+    if (staged) {
+#pragma unroll
+      for (int k = 0; k < CD; ++k) pose[k] = s_pose[(f - f_lo) * CD + k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < CD; ++k) pose[k] = dp.poses[(size_t)f * CD + k];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) X[k] = dp.points[(size_t)j * 3 + k];
+    const int ci = (dp.NI == 1) ? 0 : dp.frame_intr[f];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) cam[k] = dp.intr[(size_t)ci * 9 + k];
+
+    const Model m = {dp.shutter, dp.scan0, dp.scan1, dp.interp_rotation};
+    ObsOut<CAL, P> o;
+    eval_observation<CAL, P, MODE != kResidualOnly>(m, cam, pose, X, xy.x, xy.y, o);
+
+    if (!o.ok) atomicAdd(dp.fail_count, 1);
+    // Ceres 1.9 ResidualBlock::Evaluate: cost = rho0/2 from the uncorrected residual
+    const double s = o.r[0] * o.r[0] + o.r[1] * o.r[1];
+    double rho[3] = {s, 1.0, 0.0};
+    if (dp.huber_a > 0.0) huber_rho(dp.huber_a, s, rho);
+    double half_rho = o.ok ? 0.5 * rho[0] : 0.0;
+
+    if (MODE == kLmJacobian) {
+      double sc[K];
+      if (!CAL) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) sc[k] = dp.scale_intr[(size_t)ci * 9 + k];
+      }
+      if (staged) {
+#pragma unroll
+        for (int k = 0; k < CD; ++k) sc[OFF_POSE + k] = s_scale[(f - f_lo) * CD + k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < CD; ++k) sc[OFF_POSE + k] = dp.scale_pose[(size_t)f * CD + k];
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) sc[OFF_PT + k] = dp.scale_point[(size_t)j * 3 + k];
+      // a residual block whose parameter blocks are all constant leaves the reduced program; its
+      // cost is carried as fixed_cost.  Column scale 0 <=> fixed coordinate.
+      bool dropped = true;
+#pragma unroll
+      for (int k = 0; k < K; ++k) dropped = dropped && (sc[k] == 0.0);
+      // Corrector (Ceres 1.9 corrector.cc) for rho'' <= 0, which always holds for Huber: residual
+      // and Jacobian rows are scaled by sqrt(rho').
+      const double sr1 = sqrt(rho[1]);
+      o.r[0] *= sr1; o.r[1] *= sr1;
+#pragma unroll
+      for (int k = 0; k < K; ++k) { const double c = sr1 * sc[k]; o.J[0][k] *= c; o.J[1][k] *= c; }
+      if (dropped) { fixed = half_rho; half_rho = 0.0; }
+    }
+    cost = half_rho;
+
+    dp.res[i] = o.ok ? o.r[0] : 0.0;
+    dp.res[dp.ld + i] = o.ok ? o.r[1] : 0.0;
+    if (MODE != kResidualOnly) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int k = 0; k < K; ++k) dp.jac[(size_t)(r * K + k) * dp.ld + i] = o.ok ? o.J[r][k] : 0.0;
+    }
+  }
+
+  // deterministic cost: fixed-order wave and workgroup sums, one partial per workgroup
+  cost = wave_sum(cost);
+  if (MODE == kLmJacobian) fixed = wave_sum(fixed);
+  if ((tid & 63) == 0) { s_red[0][tid >> 6] = cost; s_red[1][tid >> 6] = fixed; }
+  __syncthreads();
+  if (tid == 0) {
+    double c = 0.0, fx = 0.0;
+#pragma unroll
+    for (int w = 0; w < kEvalBlock / 64; ++w) { c += s_red[0][w]; fx += s_red[1][w]; }
+    dp.cost_partial[blockIdx.x] = c;
+    dp.fixed_partial[blockIdx.x] = (MODE == kLmJacobian) ? fx : 0.0;
+  }
+}
+
+// Fixed-order reduction of the per-workgroup partials: out[0] = cost, out[1] = fixed cost.
+__global__ __launch_bounds__(256) void reduce_cost_kernel(const double* __restrict__ cost_partial,
+                                                          const double* __restrict__ fixed_partial, int n, double* out) {
+  __shared__ double s_red[2][4];
+  double c = 0.0, f = 0.0;
+  for (int k = threadIdx.x; k < n; k += 256) { c += cost_partial[k]; f += fixed_partial[k]; }
+  c = wave_sum(c); f = wave_sum(f);
+  if ((threadIdx.x & 63) == 0) { s_red[0][threadIdx.x >> 6] = c; s_red[1][threadIdx.x >> 6] = f; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out[0] = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+    out[1] = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
+  }
+}
+
+hipError_t launch_cost_reduce(const DeviceProblem& dp, double* out2, hipStream_t st) {
+  hipLaunchKernelGGL(reduce_cost_kernel, dim3(1), dim3(256), 0, st, dp.cost_partial, dp.fixed_partial, eval_num_blocks(dp.N), out2);
+  return hipGetLastError();
+}
+
+int eval_num_blocks(int64_t n) { return (int)((n + kEvalBlock - 1) / kEvalBlock); }
+
+template <bool CAL, int P>
+static hipError_t launch_mode(const DeviceProblem& dp, EvalMode mode, hipStream_t st) {
+  const dim3 grid(eval_num_blocks(dp.N)), block(kEvalBlock);
+  switch (mode) {
+    case kResidualOnly: hipLaunchKernelGGL((eval_kernel<CAL, P, kResidualOnly>), grid, block, 0, st, dp); break;
+    case kRawJacobian: hipLaunchKernelGGL((eval_kernel<CAL, P, kRawJacobian>), grid, block, 0, st, dp); break;
+    case kLmJacobian: hipLaunchKernelGGL((eval_kernel<CAL, P, kLmJacobian>), grid, block, 0, st, dp); break;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_eval(const DeviceProblem& dp, EvalMode mode, hipStream_t st) {
+  if (dp.N <= 0) return hipSuccess;
+  if (dp.calibrated) return dp.P == 2 ? launch_mode<true, 2>(dp, mode, st) : launch_mode<true, 1>(dp, mode, st);
+  return dp.P == 2 ? launch_mode<false, 2>(dp, mode, st) : launch_mode<false, 1>(dp, mode, st);
+}
+
+}  // namespace rsba
