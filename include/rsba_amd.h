@@ -99,13 +99,16 @@ typedef struct rsba_solver_summary {
   double total_time_s, residual_jacobian_time_s, linear_solver_time_s;
 } rsba_solver_summary;
 
-/* Pointers into HBM for callers that keep results on the device (all fp64, component-major:
- * component c of observation i at base[c * ld + i], observations in INTERNAL (frame-major) order;
- * order[i] is the caller's index of internal observation i). */
+/* Pointers into HBM for callers that keep results on the device.  All fp64, tiled component-major:
+ * observations (INTERNAL frame-major order; order_host[i] = caller's index of internal observation i)
+ * are grouped in tiles of `tile` = 256; component c of observation i lives at
+ *   base[(i / tile) * ncomp * tile + c * tile + (i % tile)]
+ * with ncomp = 2 for residuals and 2*K for jacobians (component r*K + c = row r, column c; columns
+ * ordered [cam 9]? [pose0 6] [pose1 6]? [point 3]). */
 typedef struct rsba_device_view {
-  double* residuals;        /* [2][ld] */
-  double* jacobians;        /* [2*K][ld], row r column c at component r*K + c; columns [cam 9]?[pose0 6][pose1 6]?[point 3] */
-  int64_t ld;
+  double* residuals;
+  double* jacobians;
+  int64_t tile;
   int32_t jacobian_cols;    /* K */
   int32_t reserved;
   const int64_t* order_host;/* host array [N] */

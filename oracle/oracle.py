@@ -257,3 +257,20 @@ def validate_obs(cam, poses, shutter, scan, X, obs, sq_threshold, min_dist, inte
     poses = _v(poses).reshape(-1, 6); sc = np.asarray(scan, dtype=np.int32)
     return bool(lib().orc_validate_obs(_ptr(_v(cam)), _ptr(poses), C.c_int32(len(poses)), C.c_int32(shutter), _ptr(sc),
                                        C.c_int32(int(interp_rotation)), _ptr(_v(X)), _ptr(_v(obs)), C.c_double(sq_threshold), C.c_double(min_dist)))
+
+
+class CeresStyleEvaluator:
+    """CPU baseline: one heap-allocated cost object per observation, evaluated through Dual<K> by an
+    OpenMP parallel-for over residual blocks — how Ceres' evaluator runs rsba's functors
+    (src/rsba/CeresHandler.h:408-415 sets num_threads = hardware_concurrency)."""
+
+    def __init__(self, prob, threads: int = 0):
+        self.prob, self.threads = prob, threads
+        self.d = desc(prob)
+        n, k = prob.num_observations, prob.jacobian_cols
+        self.r = np.zeros((n, 2))
+        self.J = np.zeros((n, 2 * k))   # per block: [block0 2xN0 row-major | block1 2xN1 | ...]
+        lib().orc_evaluate_blocks_ceres_style(C.byref(self.d), None, None, C.c_int32(threads))   # build cost objects
+
+    def run(self) -> int:
+        return lib().orc_evaluate_blocks_ceres_style(C.byref(self.d), _ptr(self.r), _ptr(self.J), C.c_int32(self.threads))

@@ -73,7 +73,7 @@ class SolverSummary(C.Structure):
 
 class DeviceView(C.Structure):
     _fields_ = [
-        ("residuals", C.c_void_p), ("jacobians", C.c_void_p), ("ld", C.c_int64), ("jacobian_cols", C.c_int32),
+        ("residuals", C.c_void_p), ("jacobians", C.c_void_p), ("tile", C.c_int64), ("jacobian_cols", C.c_int32),
         ("reserved", C.c_int32), ("order_host", C.c_void_p), ("poses", C.c_void_p), ("points", C.c_void_p),
         ("intrinsics", C.c_void_p),
     ]

@@ -124,7 +124,7 @@ int32_t rsba_create(const rsba_problem_desc* d, int32_t device, rsba_handle** ou
   dp.shutter = d->shutter; dp.scan0 = d->scanlines[0]; dp.scan1 = d->scanlines[1];
   dp.interp_rotation = d->interpolate_rotation != 0; dp.calibrated = d->calibrated != 0; dp.P = d->poses_per_frame;
   dp.F = d->num_frames; dp.M = d->num_points; dp.NI = d->num_intrinsics; dp.N = N;
-  dp.ld = (N + 63) / 64 * 64; if (dp.ld == 0) dp.ld = 64;
+  dp.ntiles = std::max<int64_t>((N + kEvalBlock - 1) / kEvalBlock, 1);
   dp.K = (dp.calibrated ? 0 : 9) + 6 * dp.P + 3;
   dp.huber_a = d->huber_a;
   const size_t npose = (size_t)dp.F * dp.P * 6;
@@ -151,8 +151,8 @@ int32_t rsba_create(const rsba_problem_desc* d, int32_t device, rsba_handle** ou
   if ((rc = dev_upload(h, &dp.scale_point, h->mask_point.data(), (size_t)dp.M * 3))) return bail(rc);
   if ((rc = dev_upload(h, &dp.scale_intr, h->mask_intr.data(), (size_t)dp.NI * 9))) return bail(rc);
 
-  if ((rc = dev_alloc(h, &dp.res, 2 * (size_t)dp.ld))) return bail(rc);
-  if ((rc = dev_alloc(h, &dp.jac, 2 * (size_t)dp.K * dp.ld))) return bail(rc);
+  if ((rc = dev_alloc(h, &dp.res, 2 * (size_t)kEvalBlock * dp.ntiles))) return bail(rc);
+  if ((rc = dev_alloc(h, &dp.jac, 2 * (size_t)dp.K * kEvalBlock * dp.ntiles))) return bail(rc);
   const int nb = std::max(eval_num_blocks(N), 1);
   if ((rc = dev_alloc(h, &dp.cost_partial, (size_t)nb))) return bail(rc);
   if ((rc = dev_alloc(h, &dp.fixed_partial, (size_t)nb))) return bail(rc);
@@ -212,7 +212,7 @@ int32_t rsba_evaluate_device(rsba_handle* h, int32_t with_jacobians) {
 int32_t rsba_get_device_view(rsba_handle* h, rsba_device_view* v) {
   if (!h || !v) return fail(RSBA_ERR_INVALID_ARGUMENT, "null argument");
   std::memset(v, 0, sizeof *v);
-  v->residuals = h->dp.res; v->jacobians = h->dp.jac; v->ld = h->dp.ld; v->jacobian_cols = h->dp.K;
+  v->residuals = h->dp.res; v->jacobians = h->dp.jac; v->tile = kEvalBlock; v->jacobian_cols = h->dp.K;
   v->order_host = h->order.data(); v->poses = h->dp.poses; v->points = h->dp.points; v->intrinsics = h->dp.intr;
   return RSBA_OK;
 }
@@ -236,7 +236,7 @@ int32_t rsba_evaluate(rsba_handle* h, double* cost, double* residuals, double* j
   if (!h) return fail(RSBA_ERR_INVALID_ARGUMENT, "null handle");
   HIP_TRY(hipSetDevice(h->device));
   DeviceProblem& dp = h->dp;
-  const int64_t N = dp.N, ld = dp.ld; const int K = dp.K;
+  const int64_t N = dp.N, T = kEvalBlock; const int K = dp.K;
   HIP_TRY(hipMemsetAsync(dp.fail_count, 0, sizeof(int), h->stream));
   HIP_TRY(launch_eval(dp, jacobians ? kRawJacobian : kResidualOnly, h->stream));
   HIP_TRY(launch_cost_reduce(dp, h->d_cost2, h->stream));
@@ -244,14 +244,20 @@ int32_t rsba_evaluate(rsba_handle* h, double* cost, double* residuals, double* j
   HIP_TRY(hipMemcpyAsync(c2, h->d_cost2, sizeof c2, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipMemcpyAsync(&nfail, dp.fail_count, sizeof nfail, hipMemcpyDeviceToHost, h->stream));
   std::vector<double> hr, hj;
-  if (residuals) { hr.resize(2 * (size_t)ld); HIP_TRY(hipMemcpyAsync(hr.data(), dp.res, hr.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream)); }
-  if (jacobians) { hj.resize(2 * (size_t)K * ld); HIP_TRY(hipMemcpyAsync(hj.data(), dp.jac, hj.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream)); }
+  if (residuals) { hr.resize(2 * (size_t)T * dp.ntiles); HIP_TRY(hipMemcpyAsync(hr.data(), dp.res, hr.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream)); }
+  if (jacobians) { hj.resize(2 * (size_t)K * T * dp.ntiles); HIP_TRY(hipMemcpyAsync(hj.data(), dp.jac, hj.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream)); }
   HIP_TRY(hipStreamSynchronize(h->stream));
   if (cost) *cost = c2[0] + c2[1];
   if (num_failed) *num_failed = nfail;
-  // component-major device layout -> caller's [N][2] / [N][2][K] in the caller's observation order
-  if (residuals) for (int64_t i = 0; i < N; ++i) { const int64_t u = h->order[i]; residuals[2 * u] = hr[i]; residuals[2 * u + 1] = hr[ld + i]; }
-  if (jacobians) for (int c = 0; c < 2 * K; ++c) { const double* src = &hj[(size_t)c * ld]; for (int64_t i = 0; i < N; ++i) jacobians[(size_t)h->order[i] * 2 * K + c] = src[i]; }
+  // tiled component-major device layout -> caller's [N][2] / [N][2][K] in the caller's observation order
+  if (residuals) for (int64_t i = 0; i < N; ++i) {
+    const int64_t u = h->order[i]; const double* src = &hr[(size_t)(i / T) * 2 * T + (i % T)];
+    residuals[2 * u] = src[0]; residuals[2 * u + 1] = src[T];
+  }
+  if (jacobians) for (int64_t i = 0; i < N; ++i) {
+    const double* src = &hj[(size_t)(i / T) * 2 * K * T + (i % T)]; double* dst = &jacobians[(size_t)h->order[i] * 2 * K];
+    for (int c = 0; c < 2 * K; ++c) dst[c] = src[(size_t)c * T];
+  }
   if (gradient) {
     int32_t rc = rsba_gradient(h, gradient);
     if (rc) return rc;

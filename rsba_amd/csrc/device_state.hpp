@@ -3,8 +3,12 @@
 // HBM layout (everything fp64 / int32, struct-of-arrays, rows padded to 64 elements = 512 B):
 //   observations, frame-major (sorted by frame, stable):  xy[N] (double2), frame[N], point[N]
 //   parameters:  poses[F][P][6], points[M][3], intr[NI][9], frame_intr[F]
-//   evaluation:  res[2][ld], jac[2K][ld]   (component-major: one coalesced 512-B store per wave per
-//                component; row r, column c of observation i lives at jac[(r*K + c) * ld + i])
+//   evaluation:  res / jac in TILED component-major order: observations are grouped in tiles of 256 (one
+//                workgroup); inside a tile every component is a contiguous run of 256 doubles, so each
+//                store is one coalesced 512-B line per wave AND a workgroup's whole output is one
+//                contiguous block (2 KB x components) — DRAM-page friendly.  Component c of observation i:
+//                  base[(i / 256) * tile_stride + c * 256 + (i % 256)],  tile_stride = ncomp * 256
+//                jac component = r*K + c (row r, column c); res component = r.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -15,7 +19,7 @@ struct DeviceProblem {
   // model
   int shutter, scan0, scan1, interp_rotation, calibrated, P;
   int F, M, NI;
-  int64_t N, ld;                 // observations, padded row length
+  int64_t N, ntiles;             // observations, number of 256-observation tiles
   int K;                         // Jacobian columns per observation
   double huber_a;
   // observations (frame-major)

@@ -102,13 +102,15 @@ __global__ __launch_bounds__(kEvalBlock) void eval_kernel(const DeviceProblem dp
     }
     cost = half_rho;
 
-    dp.res[i] = o.ok ? o.r[0] : 0.0;
-    dp.res[dp.ld + i] = o.ok ? o.r[1] : 0.0;
+    double* rt = dp.res + (size_t)blockIdx.x * (2 * kEvalBlock) + tid;
+    rt[0] = o.ok ? o.r[0] : 0.0;
+    rt[kEvalBlock] = o.ok ? o.r[1] : 0.0;
     if (MODE != kResidualOnly) {
+      double* jt = dp.jac + (size_t)blockIdx.x * (2 * K * kEvalBlock) + tid;
 #pragma unroll
       for (int r = 0; r < 2; ++r)
 #pragma unroll
-        for (int k = 0; k < K; ++k) dp.jac[(size_t)(r * K + k) * dp.ld + i] = o.ok ? o.J[r][k] : 0.0;
+        for (int k = 0; k < K; ++k) jt[(r * K + k) * kEvalBlock] = o.ok ? o.J[r][k] : 0.0;
     }
   }
 

@@ -102,7 +102,6 @@ template <bool CAL, int P, bool WANT_J>
 __device__ __forceinline__ void eval_observation(const Model& m, const double* __restrict__ cam,
                                                  const double* __restrict__ pose, const double* __restrict__ X,
                                                  double ox, double oy, ObsOut<CAL, P>& o) {
-  constexpr int K = ObsOut<CAL, P>::K;
   constexpr int OFF_POSE = CAL ? 0 : 9;
   constexpr int OFF_PT = OFF_POSE + 6 * P;
   double w[3], t[3], tau = 0.0;
