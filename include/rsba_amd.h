@@ -146,6 +146,12 @@ int32_t rsba_evaluate_device(rsba_handle* h, int32_t with_jacobians);
  * the status is then RSBA_ERR_EVALUATION_FAILED. */
 int32_t rsba_evaluate(rsba_handle* h, double* cost, double* residuals, double* jacobians, double* gradient, int64_t* num_failed);
 
+/* Loss-corrected, masked normal-equation blocks at the current parameters (no damping, no Jacobi
+ * scaling) — what Ceres' SchurEliminator consumes: U [F][CD][CD], gc [F][CD] with
+ * CD = 6*poses_per_frame, V [M][3][3], gp [M][3]; host arrays, any may be NULL.  These per-camera blocks
+ * are also the payload of the multi-GPU exchange.  Calibrated problems only. */
+int32_t rsba_normal_equations(rsba_handle* h, double* U, double* gc, double* V, double* gp);
+
 int32_t rsba_get_device_view(rsba_handle* h, rsba_device_view* view);
 
 /* Average device time of one evaluation launch, measured with hipEvents on the handle's stream

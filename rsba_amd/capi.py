@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "_lib", "librsba_amd.so")
 EXPORTS = [
     "rsba_abi_version", "rsba_status_string", "rsba_last_error", "rsba_device_count", "rsba_create", "rsba_destroy",
     "rsba_set_stream", "rsba_upload_parameters", "rsba_download_parameters", "rsba_evaluate_device", "rsba_evaluate",
-    "rsba_get_device_view", "rsba_time_evaluate", "rsba_default_solver_options", "rsba_solve",
+    "rsba_get_device_view", "rsba_time_evaluate", "rsba_default_solver_options", "rsba_solve", "rsba_normal_equations",
 ]
 
 
@@ -209,6 +209,15 @@ class DeviceProblem:
             out["gradient"] = dict(poses=g[:npose].reshape(p.poses.shape), points=g[npose:npose + 3 * p.num_points].reshape(-1, 3),
                                    intrinsics=g[npose + 3 * p.num_points:].reshape(-1, 9))
         return out
+
+    def normal_equations(self):
+        """-> U [F,CD,CD], gc [F,CD], V [M,3,3], gp [M,3] (loss-corrected, masked, undamped)"""
+        p = self.prob
+        cd = 6 * p.poses_per_frame
+        U = np.zeros((p.num_frames, cd, cd)); gc = np.zeros((p.num_frames, cd))
+        V = np.zeros((p.num_points, 3, 3)); gp = np.zeros((p.num_points, 3))
+        _check(lib().rsba_normal_equations(self._h, _ptr(U), _ptr(gc), _ptr(V), _ptr(gp)))
+        return U, gc, V, gp
 
     def device_view(self) -> DeviceView:
         v = DeviceView()

@@ -137,6 +137,7 @@ int32_t rsba_create(const rsba_problem_desc* d, int32_t device, rsba_handle** ou
   if (d->frame_intrinsics) std::copy(d->frame_intrinsics, d->frame_intrinsics + dp.F, fi.begin());
   if ((rc = dev_upload(h, &dfi, fi.data(), (size_t)dp.F))) return bail(rc);
   dp.xy = dxy; dp.obs_frame = dof; dp.obs_point = dop; dp.frame_intr = dfi;
+  h->obs_frame = std::move(of); h->obs_point = std::move(op);
   if ((rc = dev_upload(h, &dp.poses, d->poses, npose))) return bail(rc);
   if ((rc = dev_upload(h, &dp.points, d->points, (size_t)dp.M * 3))) return bail(rc);
   if ((rc = dev_upload(h, &dp.intr, d->intrinsics, (size_t)dp.NI * 9))) return bail(rc);

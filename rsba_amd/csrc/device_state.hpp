@@ -36,8 +36,14 @@ struct DeviceProblem {
   double* scale_point;           // [M][3]
   double* scale_intr;            // [NI][9]
   // evaluation outputs
-  double* res;                   // [2][ld]
-  double* jac;                   // [2K][ld]
+  double* res;                   // tiled component-major, 2 components
+  double* jac;                   // tiled component-major, 2K components
+  // LM mode only: a second, POINT-major copy of every observation's corrected record, one contiguous
+  // run of rec_len = 2 + 2K doubles at slot obs_slot[i] (slots are sorted by point, then frame):
+  //   [r0 r1 | Jp row0 (3) Jp row1 (3) | Jc row0 (K-3) Jc row1 (K-3)]
+  // so that everything the point elimination needs about one point is contiguous in HBM.
+  double* rec;                   // [N][rec_len]
+  const int32_t* obs_slot;       // [N]
   double* cost_partial;          // [nblocks] 1/2 sum rho0 over non-dropped blocks of each workgroup
   double* fixed_partial;         // [nblocks] same over dropped (all-constant) blocks
   int* fail_count;               // number of observations whose functor returned false

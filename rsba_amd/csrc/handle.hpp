@@ -19,6 +19,7 @@ struct rsba_handle {
   std::vector<int64_t> order;          // internal (frame-major) index -> caller's observation index
   bool identity_order = true;
   std::vector<double> mask_pose, mask_point, mask_intr;   // 0 = fixed coordinate, 1 = free
+  std::vector<int32_t> obs_frame, obs_point;            // host copies, internal (frame-major) order
   std::vector<void*> allocs;
   double* d_cost2 = nullptr;           // {cost, fixed cost}
   rsba::Solver* solver = nullptr;      // normal-equation / Schur / LM state, built on first use

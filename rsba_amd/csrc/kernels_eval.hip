@@ -99,6 +99,21 @@ __global__ __launch_bounds__(kEvalBlock) void eval_kernel(const DeviceProblem dp
 #pragma unroll
       for (int k = 0; k < K; ++k) { const double c = sr1 * sc[k]; o.J[0][k] *= c; o.J[1][k] *= c; }
       if (dropped) { fixed = half_rho; half_rho = 0.0; }
+      // point-major copy of the corrected record (see device_state.hpp)
+      constexpr int REC = 2 + 2 * K;
+      constexpr int KC = K - 3;
+      double2* rp = reinterpret_cast<double2*>(dp.rec + (size_t)dp.obs_slot[i] * REC);
+      double rv[REC];
+      rv[0] = o.ok ? o.r[0] : 0.0; rv[1] = o.ok ? o.r[1] : 0.0;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) rv[2 + 3 * r + k] = o.ok ? o.J[r][OFF_PT + k] : 0.0;
+#pragma unroll
+        for (int k = 0; k < KC; ++k) rv[8 + KC * r + k] = o.ok ? o.J[r][k] : 0.0;
+      }
+#pragma unroll
+      for (int k = 0; k < REC / 2; ++k) rp[k] = make_double2(rv[2 * k], rv[2 * k + 1]);
     }
     cost = half_rho;
 

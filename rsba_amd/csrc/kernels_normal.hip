@@ -1,0 +1,429 @@
+// K2-K9 of SURVEY §2.1: normal-equation blocks, point elimination (Schur complement), back-substitution
+// and the scalar reductions of the trust-region loop.  All fp64; all sums are taken in a fixed order
+// (no floating-point atomics), so a solve is bit-reproducible from run to run.
+//
+// These replace, for rsba's BA problems, what Ceres-Solver 1.9's SchurEliminator / SchurComplementSolver
+// and TrustRegionMinimizer compute on the CPU (call site
+// /root/reference/src/rsba/CeresHandler.h:419).  They are HBM/latency-bound block operations on 12x12,
+// 12x3 and 3x3 blocks — deliberately NOT reshaped into MFMA GEMMs: on gfx950 the fp64 MFMA rate equals
+// the fp64 VALU rate, and padding 12 -> 16 would waste 44 % of it.
+#include "obs_math.hpp"
+#include "solver_state.hpp"
+
+namespace rsba {
+
+namespace {
+
+__device__ __forceinline__ double wsum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ double wmax(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2a  per-frame camera block  U_f = sum Jc^T Jc,  g_f = sum Jc^T r   (frame-major tiles, coalesced)
+// One workgroup per frame; every lane keeps the CD(CD+1)/2 + CD running sums of its strided
+// observations in registers, then a fixed-order wave / workgroup reduction.
+// ---------------------------------------------------------------------------------------------
+template <int CD>
+__global__ __launch_bounds__(256) void camera_blocks_kernel(const DeviceProblem dp, const SolverDev sv) {
+  constexpr int NU = CD * (CD + 1) / 2, NE = NU + CD;
+  __shared__ double s_red[4][NE];
+  const int f = blockIdx.x, tid = threadIdx.x;
+  const int K = dp.K, off_pose = K - 3 - CD;
+  const int64_t s = sv.frame_ptr[f], e = sv.frame_ptr[f + 1];
+  double acc[NE];
+#pragma unroll
+  for (int k = 0; k < NE; ++k) acc[k] = 0.0;
+  for (int64_t i = s + tid; i < e; i += 256) {
+    const double* jt = dp.jac + (size_t)(i >> 8) * (2 * K * kEvalBlock) + (i & 255);
+    const double* rt = dp.res + (size_t)(i >> 8) * (2 * kEvalBlock) + (i & 255);
+    double j0[CD], j1[CD];
+#pragma unroll
+    for (int c = 0; c < CD; ++c) { j0[c] = jt[(off_pose + c) * kEvalBlock]; j1[c] = jt[(K + off_pose + c) * kEvalBlock]; }
+    const double r0 = rt[0], r1 = rt[kEvalBlock];
+    int idx = 0;
+#pragma unroll
+    for (int a = 0; a < CD; ++a)
+#pragma unroll
+      for (int b = a; b < CD; ++b) { acc[idx] += j0[a] * j0[b] + j1[a] * j1[b]; ++idx; }
+#pragma unroll
+    for (int a = 0; a < CD; ++a) acc[NU + a] += j0[a] * r0 + j1[a] * r1;
+  }
+#pragma unroll
+  for (int k = 0; k < NE; ++k) {
+    const double v = wsum(acc[k]);
+    if ((tid & 63) == 0) s_red[tid >> 6][k] = v;
+  }
+  __syncthreads();
+  if (tid < NE) {
+    const double v = s_red[0][tid] + s_red[1][tid] + s_red[2][tid] + s_red[3][tid];
+    if (tid >= NU) sv.gc[(size_t)f * CD + (tid - NU)] = v;
+    else {
+      // unpack the upper-triangular index
+      int a = 0, rem = tid;
+      while (rem >= CD - a) { rem -= CD - a; ++a; }
+      const int b = a + rem;
+      sv.U[((size_t)f * CD + a) * CD + b] = v;
+      sv.U[((size_t)f * CD + b) * CD + a] = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2b  per-point block  V_j = sum Jp^T Jp (6 unique),  g_p,j = sum Jp^T r   (point-major records)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void point_blocks_kernel(const DeviceProblem dp, const SolverDev sv) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= dp.M) return;
+  const int REC = 2 + 2 * dp.K;
+  double v[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+  for (int64_t s = sv.point_ptr[j]; s < sv.point_ptr[j + 1]; ++s) {
+    const double2* rp = reinterpret_cast<const double2*>(dp.rec + (size_t)s * REC);
+    const double2 a = rp[0], b = rp[1], c = rp[2], d = rp[3];   // r0 r1 | p00 p01 | p02 p10 | p11 p12
+    const double r0 = a.x, r1 = a.y, p0[3] = {b.x, b.y, c.x}, p1[3] = {c.y, d.x, d.y};
+    v[0] += p0[0] * p0[0] + p1[0] * p1[0]; v[1] += p0[0] * p0[1] + p1[0] * p1[1]; v[2] += p0[0] * p0[2] + p1[0] * p1[2];
+    v[3] += p0[1] * p0[1] + p1[1] * p1[1]; v[4] += p0[1] * p0[2] + p1[1] * p1[2]; v[5] += p0[2] * p0[2] + p1[2] * p1[2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) g[k] += p0[k] * r0 + p1[k] * r1;
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) sv.V[(size_t)j * 6 + k] = v[k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) sv.gp[(size_t)j * 3 + k] = g[k];
+}
+
+// Ceres 1.9 TrustRegionMinimizer: EstimateScale  scale_i = 1 / (1 + sqrt(|J_i|^2)), once, from the first
+// Jacobian.  dp.scale_* holds the 0/1 mask at that moment.
+__global__ void jacobi_scale_kernel(const DeviceProblem dp, const SolverDev sv) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x, nc = sv.n;
+  if (t < nc) {
+    const int f = (int)(t / sv.CD), a = (int)(t % sv.CD);
+    dp.scale_pose[t] *= 1.0 / (1.0 + sqrt(sv.U[((size_t)f * sv.CD + a) * sv.CD + a]));
+  } else if (t < nc + 3 * (int64_t)dp.M) {
+    const int64_t u = t - nc; const int j = (int)(u / 3), a = (int)(u % 3);
+    const int dg = (a == 0) ? 0 : (a == 1 ? 3 : 5);
+    dp.scale_point[u] *= 1.0 / (1.0 + sqrt(sv.V[(size_t)j * 6 + dg]));
+  }
+}
+
+// LevenbergMarquardtStrategy::ComputeStep: diagonal_ = clamp(|J_i|^2, min_lm_diagonal, max_lm_diagonal)
+__global__ void clamp_diagonal_kernel(const DeviceProblem dp, const SolverDev sv, double lo, double hi) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x, nc = sv.n;
+  if (t < nc) {
+    const int f = (int)(t / sv.CD), a = (int)(t % sv.CD);
+    sv.diag_c[t] = fmin(fmax(sv.U[((size_t)f * sv.CD + a) * sv.CD + a], lo), hi);
+  } else if (t < nc + 3 * (int64_t)dp.M) {
+    const int64_t u = t - nc; const int j = (int)(u / 3), a = (int)(u % 3);
+    const int dg = (a == 0) ? 0 : (a == 1 ? 3 : 5);
+    sv.diag_p[u] = fmin(fmax(sv.V[(size_t)j * 6 + dg], lo), hi);
+  }
+}
+
+// max |g_i| of the UNSCALED gradient (Ceres evaluates the gradient before ScaleColumns): g = g_scaled / scale
+__global__ __launch_bounds__(1024) void gradient_max_kernel(const DeviceProblem dp, const SolverDev sv) {
+  __shared__ double s_red[16];
+  double m = 0.0;
+  const int64_t nc = sv.n, np = 3 * (int64_t)dp.M;
+  for (int64_t t = threadIdx.x; t < nc + np; t += 1024) {
+    const double sc = (t < nc) ? dp.scale_pose[t] : dp.scale_point[t - nc];
+    const double g = (t < nc) ? sv.gc[t] : sv.gp[t - nc];
+    if (sc > 0.0) m = fmax(m, fabs(g / sc));
+  }
+  m = wmax(m);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) { double r = 0.0; for (int w = 0; w < 16; ++w) r = fmax(r, s_red[w]); sv.scalars[kGradMax] = r; }
+}
+
+__global__ void unscaled_gradient_kernel(const DeviceProblem dp, const SolverDev sv, double* g_pose, double* g_point) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x, nc = sv.n;
+  if (t < nc) { const double sc = dp.scale_pose[t]; g_pose[t] = sc > 0.0 ? sv.gc[t] / sc : 0.0; }
+  else if (t < nc + 3 * (int64_t)dp.M) { const int64_t u = t - nc; const double sc = dp.scale_point[u]; g_point[u] = sc > 0.0 ? sv.gp[u] / sc : 0.0; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K5a  per point: V' = V + D_p^2 (D^2 = diagonal_/radius), 3x3 Cholesky, L^-1, z = L^-1 g_p
+// (SchurEliminator::Eliminate inverts each e-block)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void point_factor_kernel(const DeviceProblem dp, const SolverDev sv, double inv_radius) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= dp.M) return;
+  const double* v = sv.V + (size_t)j * 6;
+  const double* dg = sv.diag_p + (size_t)j * 3;
+  const double a00 = v[0] + dg[0] * inv_radius, a10 = v[1], a20 = v[2], a11 = v[3] + dg[1] * inv_radius, a21 = v[4], a22 = v[5] + dg[2] * inv_radius;
+  const double l00 = sqrt(a00), l10 = a10 / l00, l20 = a20 / l00;
+  const double d11 = a11 - l10 * l10, l11 = sqrt(d11), l21 = (a21 - l20 * l10) / l11;
+  const double d22 = a22 - l20 * l20 - l21 * l21, l22 = sqrt(d22);
+  if (!(a00 > 0.0) || !(d11 > 0.0) || !(d22 > 0.0) || !isfinite(l22)) atomicExch(sv.chol_fail, 1);
+  const double i00 = 1.0 / l00, i11 = 1.0 / l11, i22 = 1.0 / l22;
+  const double i10 = -l10 * i00 * i11, i21 = -l21 * i11 * i22, i20 = -(l20 * i00 + l21 * i10) * i22;
+  double* li = sv.Linv + (size_t)j * 6;
+  li[0] = i00; li[1] = i10; li[2] = i11; li[3] = i20; li[4] = i21; li[5] = i22;
+  const double* g = sv.gp + (size_t)j * 3;
+  double* z = sv.z + (size_t)j * 3;
+  z[0] = i00 * g[0]; z[1] = i10 * g[0] + i11 * g[1]; z[2] = i20 * g[0] + i21 * g[1] + i22 * g[2];
+}
+
+// K5b  per observation (point-major): P = Jc^T (Jp L^-T)   (CD x 3)
+template <int CD>
+__global__ __launch_bounds__(256) void project_kernel(const DeviceProblem dp, const SolverDev sv) {
+  const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (s >= dp.N) return;
+  const int REC = 2 + 2 * dp.K, KC = dp.K - 3, off = KC - CD;   // off = 9 when intrinsics columns precede the pose
+  const double* rec = dp.rec + (size_t)s * REC;
+  const double* li = sv.Linv + (size_t)sv.slot_point[s] * 6;
+  const double i00 = li[0], i10 = li[1], i11 = li[2], i20 = li[3], i21 = li[4], i22 = li[5];
+  double B[2][3];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const double p0 = rec[2 + 3 * r], p1 = rec[3 + 3 * r], p2 = rec[4 + 3 * r];
+    B[r][0] = p0 * i00; B[r][1] = p0 * i10 + p1 * i11; B[r][2] = p0 * i20 + p1 * i21 + p2 * i22;
+  }
+  double* out = sv.Pm + (size_t)s * (CD * 3);
+#pragma unroll
+  for (int a = 0; a < CD; ++a) {
+    const double c0 = rec[8 + off + a], c1 = rec[8 + KC + off + a];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) out[a * 3 + k] = c0 * B[0][k] + c1 * B[1][k];
+  }
+}
+
+__global__ __launch_bounds__(256) void zero_tiles_kernel(const SolverDev sv, const int32_t* ti, const int32_t* tj) {
+  double* t = sv.S + ((size_t)ti[blockIdx.x] * kTile) * sv.ld + (size_t)tj[blockIdx.x] * kTile;
+  const bool diag = ti[blockIdx.x] == tj[blockIdx.x];
+  const int64_t row0 = (int64_t)ti[blockIdx.x] * kTile;
+  for (int e = threadIdx.x; e < kTile * kTile; e += 256) {
+    const int r = e / kTile, c = e % kTile;
+    // rows beyond the real system are identity padding
+    t[(size_t)r * sv.ld + c] = (diag && r == c && row0 + r >= sv.n) ? 1.0 : 0.0;
+  }
+  if (diag) for (int r = threadIdx.x; r < kTile; r += 256) if (row0 + r >= sv.n) sv.rhs[row0 + r] = 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K5c  reduced camera system, one wave per structurally non-zero CDxCD block (a >= b):
+//   S_ab = [a==b](U_a + D_c^2) - sum_{pairs (o in a, o' in b) of one point} P_o P_o'^T ;  rhs_a = g_a - sum_{o in a} P_o z
+// 60/CD pair slots per wave step: lane = (slot q, row r) owns row r of the block for its slot's pair;
+// P_o' is read with wave-wide broadcast addresses (12 lanes share each address).  The per-block pair
+// lists come from the symbolic phase, so there are no atomics and the summation order is fixed.
+// ---------------------------------------------------------------------------------------------
+template <int CD>
+__global__ __launch_bounds__(256) void schur_blocks_kernel(const DeviceProblem dp, const SolverDev sv, double inv_radius) {
+  constexpr int NG = 60 / CD;
+  const int lane = threadIdx.x & 63;
+  const int blk = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (blk >= sv.nblk) return;
+  const int q = lane / CD, r = lane % CD;
+  const bool active = q < NG;
+  const int a = sv.blk_a[blk], b = sv.blk_b[blk];
+  const bool diag = a == b;
+  const int64_t p0 = sv.blk_ptr[blk], p1 = sv.blk_ptr[blk + 1];
+  double acc[CD], racc = 0.0;
+#pragma unroll
+  for (int c = 0; c < CD; ++c) acc[c] = 0.0;
+  for (int64_t base = p0; base < p1; base += NG) {
+    const int64_t p = base + q;
+    if (active && p < p1) {
+      const int sa = sv.pair_a[p], sb = sv.pair_b[p];
+      const double* pa = sv.Pm + (size_t)sa * (CD * 3) + r * 3;
+      const double* pb = sv.Pm + (size_t)sb * (CD * 3);
+      const double x0 = pa[0], x1 = pa[1], x2 = pa[2];
+#pragma unroll
+      for (int c = 0; c < CD; ++c) acc[c] += x0 * pb[c * 3] + x1 * pb[c * 3 + 1] + x2 * pb[c * 3 + 2];
+      if (diag && sa == sb) {
+        const double* z = sv.z + (size_t)sv.slot_point[sa] * 3;
+        racc += x0 * z[0] + x1 * z[1] + x2 * z[2];
+      }
+    }
+  }
+  // fold the NG pair slots onto slot 0 in a fixed order
+#pragma unroll
+  for (int c = 0; c < CD; ++c) {
+    double t = acc[c];
+#pragma unroll
+    for (int g = 1; g < NG; ++g) t += __shfl(acc[c], r + CD * g, 64);
+    acc[c] = t;
+  }
+  {
+    double t = racc;
+#pragma unroll
+    for (int g = 1; g < NG; ++g) t += __shfl(racc, r + CD * g, 64);
+    racc = t;
+  }
+  if (q == 0) {
+    double* srow = sv.S + ((size_t)a * CD + r) * sv.ld + (size_t)b * CD;
+    if (diag) {
+      const double* urow = sv.U + ((size_t)a * CD + r) * CD;
+#pragma unroll
+      for (int c = 0; c < CD; ++c) srow[c] = urow[c] + (c == r ? sv.diag_c[(size_t)a * CD + r] * inv_radius : 0.0) - acc[c];
+      sv.rhs[(size_t)a * CD + r] = sv.gc[(size_t)a * CD + r] - racc;
+    } else {
+#pragma unroll
+      for (int c = 0; c < CD; ++c) srow[c] = -acc[c];
+    }
+  }
+}
+
+// K7  back-substitution  y_p = L^-T ( z - sum_o P_o^T y_c(frame(o)) )
+template <int CD>
+__global__ __launch_bounds__(256) void back_substitute_kernel(const DeviceProblem dp, const SolverDev sv) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= dp.M) return;
+  double t0 = sv.z[(size_t)j * 3], t1 = sv.z[(size_t)j * 3 + 1], t2 = sv.z[(size_t)j * 3 + 2];
+  for (int64_t s = sv.point_ptr[j]; s < sv.point_ptr[j + 1]; ++s) {
+    const double* pm = sv.Pm + (size_t)s * (CD * 3);
+    const double* yc = sv.rhs + (size_t)sv.slot_frame[s] * CD;
+#pragma unroll
+    for (int a = 0; a < CD; ++a) { const double y = yc[a]; t0 -= pm[a * 3] * y; t1 -= pm[a * 3 + 1] * y; t2 -= pm[a * 3 + 2] * y; }
+  }
+  const double* li = sv.Linv + (size_t)j * 6;
+  double* yp = sv.yp + (size_t)j * 3;
+  yp[0] = li[0] * t0 + li[1] * t1 + li[3] * t2;
+  yp[1] = li[2] * t1 + li[4] * t2;
+  yp[2] = li[5] * t2;
+}
+
+// model_cost_change = -(J step).(r + J step / 2), step = -y   (TrustRegionMinimizer)
+template <int CD>
+__global__ __launch_bounds__(256) void model_cost_kernel(const DeviceProblem dp, const SolverDev sv) {
+  __shared__ double s_red[4];
+  const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  double v = 0.0;
+  if (s < dp.N) {
+    const int REC = 2 + 2 * dp.K, KC = dp.K - 3, off = KC - CD;
+    const double* rec = dp.rec + (size_t)s * REC;
+    const double* yc = sv.rhs + (size_t)sv.slot_frame[s] * CD;
+    const double* yp = sv.yp + (size_t)sv.slot_point[s] * 3;
+    double m0 = 0.0, m1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { m0 -= rec[2 + k] * yp[k]; m1 -= rec[5 + k] * yp[k]; }
+#pragma unroll
+    for (int a = 0; a < CD; ++a) { m0 -= rec[8 + off + a] * yc[a]; m1 -= rec[8 + KC + off + a] * yc[a]; }
+    v = m0 * (rec[0] + 0.5 * m0) + m1 * (rec[1] + 0.5 * m1);
+  }
+  v = wsum(v);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) sv.partial[blockIdx.x] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+}
+
+__global__ __launch_bounds__(256) void reduce_sum_kernel(const double* partial, int n, double* out, double sign) {
+  __shared__ double s_red[4];
+  double v = 0.0;
+  for (int k = threadIdx.x; k < n; k += 256) v += partial[k];
+  v = wsum(v);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) *out = sign * (s_red[0] + s_red[1] + s_red[2] + s_red[3]);
+}
+
+// x_plus_delta = x + scale .* step; |x - x_plus_delta|^2 and |x|^2 over the reduced program's blocks
+__global__ __launch_bounds__(256) void candidate_kernel(const DeviceProblem dp, const SolverDev sv) {
+  __shared__ double s_red[2][4];
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x, nc = sv.n, np = 3 * (int64_t)dp.M;
+  double st = 0.0, xx = 0.0;
+  if (t < nc + np) {
+    const bool cam = t < nc;
+    const int64_t u = cam ? t : t - nc;
+    const double x = cam ? dp.poses[u] : dp.points[u];
+    const double sc = cam ? dp.scale_pose[u] : dp.scale_point[u];
+    const double y = cam ? sv.rhs[u] : sv.yp[u];
+    const double in = cam ? sv.inprog_pose[u] : sv.inprog_point[u];
+    const double xn = (sc > 0.0) ? x + (-y * sc) : x;
+    if (cam) sv.trial_poses[u] = xn; else sv.trial_points[u] = xn;
+    if (in > 0.0) { const double e = x - xn; st = e * e; xx = x * x; }
+  }
+  st = wsum(st); xx = wsum(xx);
+  if ((threadIdx.x & 63) == 0) { s_red[0][threadIdx.x >> 6] = st; s_red[1][threadIdx.x >> 6] = xx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    sv.partial[blockIdx.x] = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+    sv.partial[gridDim.x + blockIdx.x] = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
+  }
+}
+
+inline int nblocks256(int64_t n) { return (int)((n + 255) / 256); }
+
+}  // namespace
+
+#define LAUNCH(kernel, grid, block, st, ...)                       \
+  do {                                                             \
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, st, __VA_ARGS__); \
+    hipError_t e_ = hipGetLastError();                             \
+    if (e_ != hipSuccess) return e_;                               \
+  } while (0)
+
+hipError_t launch_camera_blocks(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {
+  if (sv.CD == 12) LAUNCH(camera_blocks_kernel<12>, dp.F, 256, st, dp, sv);
+  else LAUNCH(camera_blocks_kernel<6>, dp.F, 256, st, dp, sv);
+  return hipSuccess;
+}
+hipError_t launch_point_blocks(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {
+  LAUNCH(point_blocks_kernel, nblocks256(dp.M), 256, st, dp, sv);
+  return hipSuccess;
+}
+hipError_t launch_jacobi_scale(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {
+  LAUNCH(jacobi_scale_kernel, nblocks256(sv.n + 3 * (int64_t)dp.M), 256, st, dp, sv);
+  return hipSuccess;
+}
+hipError_t launch_clamp_diagonal(const DeviceProblem& dp, const SolverDev& sv, double lo, double hi, hipStream_t st) {
+  LAUNCH(clamp_diagonal_kernel, nblocks256(sv.n + 3 * (int64_t)dp.M), 256, st, dp, sv, lo, hi);
+  return hipSuccess;
+}
+hipError_t launch_gradient_max(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {
+  LAUNCH(gradient_max_kernel, 1, 1024, st, dp, sv);
+  return hipSuccess;
+}
+hipError_t launch_unscaled_gradient(const DeviceProblem& dp, const SolverDev& sv, double* g_pose, double* g_point, hipStream_t st) {
+  LAUNCH(unscaled_gradient_kernel, nblocks256(sv.n + 3 * (int64_t)dp.M), 256, st, dp, sv, g_pose, g_point);
+  return hipSuccess;
+}
+hipError_t launch_point_factor(const DeviceProblem& dp, const SolverDev& sv, double radius, hipStream_t st) {
+  LAUNCH(point_factor_kernel, nblocks256(dp.M), 256, st, dp, sv, 1.0 / radius);
+  return hipSuccess;
+}
+hipError_t launch_project(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {
+  if (dp.N == 0) return hipSuccess;
+  if (sv.CD == 12) LAUNCH(project_kernel<12>, nblocks256(dp.N), 256, st, dp, sv);
+  else LAUNCH(project_kernel<6>, nblocks256(dp.N), 256, st, dp, sv);
+  return hipSuccess;
+}
+hipError_t launch_zero_tiles(const SolverDev& sv, const int32_t* ti, const int32_t* tj, int ntiles, hipStream_t st) {
+  if (ntiles > 0) LAUNCH(zero_tiles_kernel, ntiles, 256, st, sv, ti, tj);
+  return hipSuccess;
+}
+hipError_t launch_schur_blocks(const DeviceProblem& dp, const SolverDev& sv, double radius, hipStream_t st) {
+  const int grid = (sv.nblk + 3) / 4;
+  if (sv.CD == 12) LAUNCH(schur_blocks_kernel<12>, grid, 256, st, dp, sv, 1.0 / radius);
+  else LAUNCH(schur_blocks_kernel<6>, grid, 256, st, dp, sv, 1.0 / radius);
+  return hipSuccess;
+}
+hipError_t launch_back_substitute(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {
+  if (sv.CD == 12) LAUNCH(back_substitute_kernel<12>, nblocks256(dp.M), 256, st, dp, sv);
+  else LAUNCH(back_substitute_kernel<6>, nblocks256(dp.M), 256, st, dp, sv);
+  return hipSuccess;
+}
+hipError_t launch_model_cost_change(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {
+  const int nb = nblocks256(dp.N);
+  if (nb > 0) {
+    if (sv.CD == 12) LAUNCH(model_cost_kernel<12>, nb, 256, st, dp, sv);
+    else LAUNCH(model_cost_kernel<6>, nb, 256, st, dp, sv);
+  }
+  LAUNCH(reduce_sum_kernel, 1, 256, st, sv.partial, nb, sv.scalars + kModelCostChange, -1.0);
+  return hipSuccess;
+}
+hipError_t launch_candidate(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {
+  const int nb = nblocks256(sv.n + 3 * (int64_t)dp.M);
+  LAUNCH(candidate_kernel, nb, 256, st, dp, sv);
+  LAUNCH(reduce_sum_kernel, 1, 256, st, sv.partial, nb, sv.scalars + kStepSq, 1.0);
+  LAUNCH(reduce_sum_kernel, 1, 256, st, sv.partial + nb, nb, sv.scalars + kXSq, 1.0);
+  return hipSuccess;
+}
+
+}  // namespace rsba

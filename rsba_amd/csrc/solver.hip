@@ -1,9 +1,461 @@
-// LM / Schur solver state (placeholder until the normal-equation kernels land).
+// Host side of rsba_solve: the symbolic phase (once per problem) and the trust-region loop.
+//
+// The loop is a rule-for-rule restatement of Ceres-Solver 1.9's TrustRegionMinimizer +
+// LevenbergMarquardtStrategy with an exact Schur-complement linear solve — what
+// ceres::Solve(SPARSE_SCHUR) runs for /root/reference/src/rsba/CeresHandler.h:394-426 (SURVEY
+// Appendix C.5).  Every array lives on the device; per iteration the host reads back a few scalars
+// (costs, model decrease, step / parameter norms, gradient max-norm, failure flags) and decides.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
 #include "handle.hpp"
+#include "solver_state.hpp"
 
-int32_t rsba_gradient(rsba_handle*, double*) { return rsba_set_error(RSBA_ERR_UNSUPPORTED, "gradient: not built yet"); }
-void rsba_destroy_solver(rsba_handle*) {}
+namespace rsba {
 
-extern "C" int32_t rsba_solve(rsba_handle*, const rsba_solver_options*, rsba_solver_summary*, rsba_iteration*, int32_t) {
-  return rsba_set_error(RSBA_ERR_UNSUPPORTED, "solve: not built yet");
+hipError_t launch_chol_panel(const SolverDev& sv, int k, const int32_t* trsm_i, int ntrsm, hipStream_t st);
+hipError_t launch_chol_update(const SolverDev& sv, int k, const int32_t* upd_i, const int32_t* upd_j, int nupd, hipStream_t st);
+hipError_t launch_chol_backsolve(const SolverDev& sv, const int32_t* col_ptr, const int32_t* col_i, hipStream_t st);
+
+struct Solver {
+  SolverDev sv{};
+  std::vector<void*> allocs;
+  // Cholesky plan: per tile column k, the sub-diagonal tiles (panel) and the tile pairs to update
+  std::vector<int32_t> col_ptr, col_i, upd_ptr, upd_i, upd_j;
+  int32_t *d_col_ptr = nullptr, *d_col_i = nullptr, *d_upd_i = nullptr, *d_upd_j = nullptr;
+  int32_t *d_tile_i = nullptr, *d_tile_j = nullptr;
+  int ntiles = 0;
+  int32_t* d_obs_slot = nullptr;
+  double *d_gpose = nullptr, *d_gpoint = nullptr;
+  int64_t num_pairs = 0;
+  int num_reduced_blocks = 0, num_reduced_params = 0;
+};
+
+}  // namespace rsba
+
+using namespace rsba;
+
+#define HIP_TRY(expr)                                                                                 \
+  do {                                                                                                \
+    hipError_t e_ = (expr);                                                                           \
+    if (e_ != hipSuccess)                                                                             \
+      return rsba_set_error(e_ == hipErrorOutOfMemory ? RSBA_ERR_OUT_OF_MEMORY : RSBA_ERR_HIP,        \
+                            (std::string(#expr) + ": " + hipGetErrorString(e_)).c_str());             \
+  } while (0)
+
+namespace {
+
+template <class T>
+int32_t s_alloc(Solver* s, T** p, size_t count) {
+  void* q = nullptr;
+  HIP_TRY(hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)));
+  s->allocs.push_back(q);
+  *p = static_cast<T*>(q);
+  return RSBA_OK;
+}
+template <class T>
+int32_t s_upload(Solver* s, T** p, const std::vector<T>& v) {
+  int32_t rc = s_alloc(s, p, v.size());
+  if (rc) return rc;
+  if (!v.empty()) HIP_TRY(hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  return RSBA_OK;
+}
+template <class T>
+int32_t s_upload_const(Solver* s, const T** p, const std::vector<T>& v) {
+  T* q = nullptr;
+  int32_t rc = s_upload(s, &q, v);
+  *p = q;
+  return rc;
+}
+
+// Symbolic phase: frame / point adjacency, the per-block pair lists of the reduced camera system and
+// the tile-level fill pattern of its Cholesky factor.  Ceres does the equivalent in its preprocessor
+// (block structure detection, Schur ordering, CHOLMOD analyse) — SURVEY Appendix C.4.
+int32_t build_solver(rsba_handle* h) {
+  if (h->solver) return RSBA_OK;
+  const DeviceProblem& dp = h->dp;
+  if (!dp.calibrated) return rsba_set_error(RSBA_ERR_UNSUPPORTED, "solve with intrinsics as parameter blocks is not built yet");
+  Solver* s = new Solver();
+  h->solver = s;   // owned by the handle from here on (freed by rsba_destroy_solver)
+  SolverDev& sv = s->sv;
+  const int F = dp.F, M = dp.M, CD = 6 * dp.P;
+  const int64_t N = dp.N;
+  sv.CD = CD; sv.n = (int64_t)F * CD;
+  const int FT = kTile / CD;
+  sv.nt = (F + FT - 1) / FT; sv.npad = (int64_t)sv.nt * kTile; sv.ld = sv.npad;
+  const std::vector<int32_t>& of = h->obs_frame; const std::vector<int32_t>& op = h->obs_point;
+
+  std::vector<int64_t> frame_ptr(F + 1, 0), point_ptr(M + 1, 0);
+  for (int64_t i = 0; i < N; ++i) { frame_ptr[of[i] + 1]++; point_ptr[op[i] + 1]++; }
+  for (int f = 0; f < F; ++f) frame_ptr[f + 1] += frame_ptr[f];
+  for (int j = 0; j < M; ++j) point_ptr[j + 1] += point_ptr[j];
+  // slots: stable counting sort of the frame-major list by point -> ascending frame inside a point
+  std::vector<int32_t> obs_slot(N), slot_frame(N), slot_point(N);
+  {
+    std::vector<int64_t> fill(point_ptr.begin(), point_ptr.end() - 1);
+    for (int64_t i = 0; i < N; ++i) { const int64_t sl = fill[op[i]]++; obs_slot[i] = (int32_t)sl; slot_frame[sl] = of[i]; slot_point[sl] = op[i]; }
+  }
+  // blocks (a >= b) and their pair lists
+  const bool dense_keys = (int64_t)F * F <= (int64_t)1 << 26;
+  std::vector<int64_t> dense_cnt; std::unordered_map<int64_t, int64_t> sparse_cnt;
+  if (dense_keys) dense_cnt.assign((size_t)F * F, -1);
+  auto bump = [&](int a, int b, int64_t by) {
+    const int64_t key = (int64_t)a * F + b;
+    if (dense_keys) { int64_t& c = dense_cnt[key]; c = (c < 0 ? 0 : c) + by; }
+    else sparse_cnt[key] += by;
+  };
+  for (int f = 0; f < F; ++f) bump(f, f, 0);   // every frame owns a diagonal block (it carries U_f + D^2 and rhs_f)
+  for (int j = 0; j < M; ++j)
+    for (int64_t x = point_ptr[j]; x < point_ptr[j + 1]; ++x)
+      for (int64_t y = point_ptr[j]; y <= x; ++y) {
+        const int a = slot_frame[x], b = slot_frame[y];
+        if (a == b) bump(a, a, x == y ? 1 : 2); else bump(a, b, 1);
+      }
+  std::vector<int32_t> blk_a, blk_b; std::vector<int64_t> blk_ptr(1, 0);
+  std::unordered_map<int64_t, int32_t> blk_index;
+  std::vector<int32_t> dense_index;
+  if (dense_keys) {
+    dense_index.assign((size_t)F * F, -1);
+    for (int a = 0; a < F; ++a) for (int b = 0; b <= a; ++b) {
+      const int64_t c = dense_cnt[(size_t)a * F + b];
+      if (c >= 0) { dense_index[(size_t)a * F + b] = (int32_t)blk_a.size(); blk_a.push_back(a); blk_b.push_back(b); blk_ptr.push_back(blk_ptr.back() + c); }
+    }
+    std::vector<int64_t>().swap(dense_cnt);
+  } else {
+    std::vector<int64_t> keys; keys.reserve(sparse_cnt.size());
+    for (auto& kv : sparse_cnt) keys.push_back(kv.first);
+    std::sort(keys.begin(), keys.end());
+    for (int64_t key : keys) { blk_index[key] = (int32_t)blk_a.size(); blk_a.push_back((int32_t)(key / F)); blk_b.push_back((int32_t)(key % F)); blk_ptr.push_back(blk_ptr.back() + sparse_cnt[key]); }
+  }
+  auto index_of = [&](int a, int b) -> int32_t { return dense_keys ? dense_index[(size_t)a * F + b] : blk_index[(int64_t)a * F + b]; };
+  const int64_t npairs = blk_ptr.back();
+  std::vector<int32_t> pair_a(npairs), pair_b(npairs);
+  {
+    std::vector<int64_t> fill(blk_ptr.begin(), blk_ptr.end() - 1);
+    for (int j = 0; j < M; ++j)
+      for (int64_t x = point_ptr[j]; x < point_ptr[j + 1]; ++x)
+        for (int64_t y = point_ptr[j]; y <= x; ++y) {
+          const int a = slot_frame[x], b = slot_frame[y];
+          const int32_t bi = index_of(a, b);
+          int64_t& w = fill[bi];
+          pair_a[w] = (int32_t)x; pair_b[w] = (int32_t)y; ++w;
+          if (a == b && x != y) { pair_a[w] = (int32_t)y; pair_b[w] = (int32_t)x; ++w; }
+        }
+  }
+  std::vector<int32_t>().swap(dense_index);
+  sv.nblk = (int)blk_a.size();
+  s->num_pairs = npairs;
+
+  // tile pattern of S and symbolic fill of its factor
+  const int nt = sv.nt;
+  std::vector<std::vector<int32_t>> col(nt);
+  {
+    std::vector<std::vector<uint8_t>> mark(nt);
+    for (int k = 0; k < nt; ++k) mark[k].assign(nt - k, 0);       // mark[k][i-k] for i >= k
+    for (size_t bidx = 0; bidx < blk_a.size(); ++bidx) { const int ti = blk_a[bidx] / FT, tj = blk_b[bidx] / FT; mark[tj][ti - tj] = 1; }
+    for (int k = 0; k < nt; ++k) {
+      mark[k][0] = 1;
+      for (int i = k + 1; i < nt; ++i) if (mark[k][i - k]) col[k].push_back(i);
+      for (size_t u = 0; u < col[k].size(); ++u) for (size_t v = u; v < col[k].size(); ++v) mark[col[k][u]][col[k][v] - col[k][u]] = 1;
+    }
+  }
+  std::vector<int32_t> tile_i, tile_j;
+  s->col_ptr.assign(1, 0); s->upd_ptr.assign(1, 0);
+  for (int k = 0; k < nt; ++k) {
+    tile_i.push_back(k); tile_j.push_back(k);
+    for (int32_t i : col[k]) { s->col_i.push_back(i); tile_i.push_back(i); tile_j.push_back(k); }
+    s->col_ptr.push_back((int32_t)s->col_i.size());
+    for (size_t u = 0; u < col[k].size(); ++u) for (size_t v = u; v < col[k].size(); ++v) { s->upd_i.push_back(col[k][v]); s->upd_j.push_back(col[k][u]); }
+    s->upd_ptr.push_back((int32_t)s->upd_i.size());
+  }
+  s->ntiles = (int)tile_i.size();
+
+  // which coordinates belong to the reduced program (for |x| and |step|): blocks that are not constant
+  // and are touched by at least one residual block
+  std::vector<double> inprog_pose((size_t)F * CD, 0.0), inprog_point((size_t)M * 3, 0.0);
+  int nfree = 0;
+  for (int f = 0; f < F; ++f) for (int q = 0; q < dp.P; ++q) {
+    bool any_free = false;
+    for (int k = 0; k < 6; ++k) any_free = any_free || h->mask_pose[((size_t)f * dp.P + q) * 6 + k] != 0.0;
+    if (any_free && frame_ptr[f + 1] > frame_ptr[f]) for (int k = 0; k < 6; ++k) { inprog_pose[((size_t)f * dp.P + q) * 6 + k] = 1.0; nfree += h->mask_pose[((size_t)f * dp.P + q) * 6 + k] != 0.0; }
+  }
+  for (int j = 0; j < M; ++j) if (h->mask_point[(size_t)j * 3] != 0.0 && point_ptr[j + 1] > point_ptr[j]) { for (int k = 0; k < 3; ++k) inprog_point[(size_t)j * 3 + k] = 1.0; nfree += 3; }
+  s->num_reduced_params = nfree;
+  {
+    int64_t nred = 0;
+    for (int64_t i = 0; i < N; ++i) {
+      bool all_const = h->mask_point[(size_t)op[i] * 3] == 0.0;
+      for (int k = 0; k < CD && all_const; ++k) all_const = h->mask_pose[(size_t)of[i] * CD + k] == 0.0;
+      nred += !all_const;
+    }
+    s->num_reduced_blocks = (int)nred;
+  }
+
+  int32_t rc;
+  if ((rc = s_upload_const(s, &sv.frame_ptr, frame_ptr))) return rc;
+  if ((rc = s_upload_const(s, &sv.point_ptr, point_ptr))) return rc;
+  if ((rc = s_upload_const(s, &sv.slot_frame, slot_frame))) return rc;
+  if ((rc = s_upload_const(s, &sv.slot_point, slot_point))) return rc;
+  if ((rc = s_upload_const(s, &sv.blk_a, blk_a))) return rc;
+  if ((rc = s_upload_const(s, &sv.blk_b, blk_b))) return rc;
+  if ((rc = s_upload_const(s, &sv.blk_ptr, blk_ptr))) return rc;
+  if ((rc = s_upload_const(s, &sv.pair_a, pair_a))) return rc;
+  if ((rc = s_upload_const(s, &sv.pair_b, pair_b))) return rc;
+  if ((rc = s_upload_const(s, &sv.inprog_pose, inprog_pose))) return rc;
+  if ((rc = s_upload_const(s, &sv.inprog_point, inprog_point))) return rc;
+  if ((rc = s_upload(s, &s->d_obs_slot, obs_slot))) return rc;
+  if ((rc = s_upload(s, &s->d_col_ptr, s->col_ptr))) return rc;
+  if ((rc = s_upload(s, &s->d_col_i, s->col_i))) return rc;
+  if ((rc = s_upload(s, &s->d_upd_i, s->upd_i))) return rc;
+  if ((rc = s_upload(s, &s->d_upd_j, s->upd_j))) return rc;
+  if ((rc = s_upload(s, &s->d_tile_i, tile_i))) return rc;
+  if ((rc = s_upload(s, &s->d_tile_j, tile_j))) return rc;
+
+  const size_t REC = 2 + 2 * (size_t)dp.K;
+  if ((rc = s_alloc(s, &h->dp.rec, (size_t)N * REC))) return rc;
+  h->dp.obs_slot = s->d_obs_slot;
+  if ((rc = s_alloc(s, &sv.U, (size_t)F * CD * CD))) return rc;
+  if ((rc = s_alloc(s, &sv.gc, (size_t)F * CD))) return rc;
+  if ((rc = s_alloc(s, &sv.V, (size_t)M * 6))) return rc;
+  if ((rc = s_alloc(s, &sv.gp, (size_t)M * 3))) return rc;
+  if ((rc = s_alloc(s, &sv.diag_c, (size_t)F * CD))) return rc;
+  if ((rc = s_alloc(s, &sv.diag_p, (size_t)M * 3))) return rc;
+  if ((rc = s_alloc(s, &sv.Linv, (size_t)M * 6))) return rc;
+  if ((rc = s_alloc(s, &sv.z, (size_t)M * 3))) return rc;
+  if ((rc = s_alloc(s, &sv.Pm, (size_t)N * CD * 3))) return rc;
+  if ((rc = s_alloc(s, &sv.S, (size_t)sv.npad * sv.ld))) return rc;
+  if ((rc = s_alloc(s, &sv.rhs, (size_t)sv.npad))) return rc;
+  if ((rc = s_alloc(s, &sv.yp, (size_t)M * 3))) return rc;
+  if ((rc = s_alloc(s, &sv.trial_poses, (size_t)F * CD))) return rc;
+  if ((rc = s_alloc(s, &sv.trial_points, (size_t)M * 3))) return rc;
+  const size_t nb = std::max<size_t>((N + 255) / 256, ((size_t)sv.n + 3 * (size_t)M + 255) / 256);
+  if ((rc = s_alloc(s, &sv.partial, 2 * nb + 2))) return rc;
+  if ((rc = s_alloc(s, &sv.scalars, 16))) return rc;
+  if ((rc = s_alloc(s, &sv.chol_fail, 1))) return rc;
+  if ((rc = s_alloc(s, &s->d_gpose, (size_t)F * CD))) return rc;
+  if ((rc = s_alloc(s, &s->d_gpoint, (size_t)M * 3))) return rc;
+  HIP_TRY(hipMemset(sv.scalars, 0, 16 * sizeof(double)));
+  HIP_TRY(hipMemset(sv.chol_fail, 0, sizeof(int)));
+  return RSBA_OK;
+}
+
+int32_t reset_scales(rsba_handle* h) {
+  const DeviceProblem& dp = h->dp;
+  HIP_TRY(hipMemcpyAsync(dp.scale_pose, h->mask_pose.data(), h->mask_pose.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(dp.scale_point, h->mask_point.data(), h->mask_point.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(dp.scale_intr, h->mask_intr.data(), h->mask_intr.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  return RSBA_OK;
+}
+
+// r, J (loss-corrected, masked, scaled) and the normal-equation blocks at the current parameters
+int32_t linearize(rsba_handle* h) {
+  Solver* s = h->solver;
+  HIP_TRY(hipMemsetAsync(h->dp.fail_count, 0, sizeof(int), h->stream));
+  HIP_TRY(launch_eval(h->dp, kLmJacobian, h->stream));
+  HIP_TRY(launch_cost_reduce(h->dp, h->d_cost2, h->stream));
+  HIP_TRY(launch_camera_blocks(h->dp, s->sv, h->stream));
+  HIP_TRY(launch_point_blocks(h->dp, s->sv, h->stream));
+  return RSBA_OK;
+}
+
+int32_t factor_and_solve(rsba_handle* h, double radius) {
+  Solver* s = h->solver; const SolverDev& sv = s->sv; hipStream_t st = h->stream;
+  HIP_TRY(launch_point_factor(h->dp, sv, radius, st));
+  HIP_TRY(launch_project(h->dp, sv, st));
+  HIP_TRY(launch_zero_tiles(sv, s->d_tile_i, s->d_tile_j, s->ntiles, st));
+  HIP_TRY(launch_schur_blocks(h->dp, sv, radius, st));
+  for (int k = 0; k < sv.nt; ++k) {
+    const int c0 = s->col_ptr[k], c1 = s->col_ptr[k + 1], u0 = s->upd_ptr[k], u1 = s->upd_ptr[k + 1];
+    HIP_TRY(launch_chol_panel(sv, k, s->d_col_i + c0, c1 - c0, st));
+    HIP_TRY(launch_chol_update(sv, k, s->d_upd_i + u0, s->d_upd_j + u0, u1 - u0, st));
+  }
+  HIP_TRY(launch_chol_backsolve(sv, s->d_col_ptr, s->d_col_i, st));
+  HIP_TRY(launch_back_substitute(h->dp, sv, st));
+  return RSBA_OK;
+}
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+}  // namespace
+
+void rsba_destroy_solver(rsba_handle* h) {
+  if (!h || !h->solver) return;
+  for (void* p : h->solver->allocs) (void)hipFree(p);
+  delete h->solver;
+  h->solver = nullptr;
+  h->dp.rec = nullptr; h->dp.obs_slot = nullptr;
+}
+
+// gradient of Problem::Evaluate: loss-corrected J^T r on the masked tangent space, [F*P*6 | M*3 | NI*9]
+int32_t rsba_gradient(rsba_handle* h, double* g) {
+  int32_t rc = build_solver(h);
+  if (rc) return rc;
+  Solver* s = h->solver; const DeviceProblem& dp = h->dp;
+  if ((rc = reset_scales(h))) return rc;
+  if ((rc = linearize(h))) return rc;
+  HIP_TRY(launch_unscaled_gradient(dp, s->sv, s->d_gpose, s->d_gpoint, h->stream));
+  const size_t npose = (size_t)dp.F * dp.P * 6, npt = (size_t)dp.M * 3;
+  HIP_TRY(hipMemcpyAsync(g, s->d_gpose, npose * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(g + npose, s->d_gpoint, npt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  std::fill(g + npose + npt, g + npose + npt + (size_t)dp.NI * 9, 0.0);
+  return RSBA_OK;
+}
+
+extern "C" int32_t rsba_normal_equations(rsba_handle* h, double* U, double* gc, double* V, double* gp) {
+  if (!h) return rsba_set_error(RSBA_ERR_INVALID_ARGUMENT, "null handle");
+  HIP_TRY(hipSetDevice(h->device));
+  int32_t rc = build_solver(h);
+  if (rc) return rc;
+  Solver* s = h->solver; const DeviceProblem& dp = h->dp; const int CD = s->sv.CD;
+  if ((rc = reset_scales(h))) return rc;
+  if ((rc = linearize(h))) return rc;
+  if (U) HIP_TRY(hipMemcpyAsync(U, s->sv.U, (size_t)dp.F * CD * CD * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (gc) HIP_TRY(hipMemcpyAsync(gc, s->sv.gc, (size_t)dp.F * CD * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  std::vector<double> v6;
+  if (V) { v6.resize((size_t)dp.M * 6); HIP_TRY(hipMemcpyAsync(v6.data(), s->sv.V, v6.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream)); }
+  if (gp) HIP_TRY(hipMemcpyAsync(gp, s->sv.gp, (size_t)dp.M * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (V) for (int j = 0; j < dp.M; ++j) {
+    const double* v = &v6[(size_t)j * 6]; double* o = V + (size_t)j * 9;
+    o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[1]; o[4] = v[3]; o[5] = v[4]; o[6] = v[2]; o[7] = v[4]; o[8] = v[5];
+  }
+  return RSBA_OK;
+}
+
+extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rsba_solver_summary* sum, rsba_iteration* trace, int32_t trace_cap) {
+  if (!h || !opt || !sum) return rsba_set_error(RSBA_ERR_INVALID_ARGUMENT, "null argument");
+  HIP_TRY(hipSetDevice(h->device));
+  const double t_start = now_s();
+  std::memset(sum, 0, sizeof *sum);
+  int32_t rc = build_solver(h);
+  if (rc) return rc;
+  Solver* s = h->solver; SolverDev& sv = s->sv; DeviceProblem& dp = h->dp; hipStream_t st = h->stream;
+  sum->termination_type = RSBA_NO_CONVERGENCE;
+  sum->num_residual_blocks = (int32_t)dp.N;
+  sum->num_residual_blocks_reduced = s->num_reduced_blocks;
+  sum->num_parameters_reduced = s->num_reduced_params;
+  int ntrace = 0;
+  auto push = [&](const rsba_iteration& it) {
+    if (trace && ntrace < trace_cap) trace[ntrace] = it;
+    ++ntrace; sum->num_iterations = ntrace;
+    if (opt->minimizer_progress_to_stdout)
+      std::printf("%4d  cost % .6e  change % .3e  |grad| %.3e  |step| %.3e  rho % .3e  radius %.3e  %s\n", it.iteration, it.cost, it.cost_change,
+                  it.gradient_max_norm, it.step_norm, it.relative_decrease, it.trust_region_radius, it.step_is_successful ? "ok" : (it.iteration ? "rejected" : ""));
+  };
+  double host_sc[16]; double cost2[2]; int nfail = 0, cfail = 0;
+  auto read_back = [&]() -> int32_t {
+    HIP_TRY(hipMemcpyAsync(host_sc, sv.scalars, sizeof host_sc, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(cost2, h->d_cost2, sizeof cost2, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&nfail, dp.fail_count, sizeof nfail, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&cfail, sv.chol_fail, sizeof cfail, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return RSBA_OK;
+  };
+  auto finish = [&](int32_t term) -> int32_t {
+    sum->termination_type = term;
+    sum->is_solution_usable = term != RSBA_FAILURE;
+    (void)reset_scales(h);
+    const size_t npose = (size_t)dp.F * dp.P * 6, npt = (size_t)dp.M * 3;
+    HIP_TRY(hipMemcpyAsync(h->desc.poses, dp.poses, npose * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(h->desc.points, dp.points, npt * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    sum->total_time_s = now_s() - t_start;
+    return RSBA_OK;
+  };
+
+  // ---- iteration 0: initial evaluation ----
+  double t0 = now_s();
+  if ((rc = reset_scales(h))) return rc;
+  if ((rc = linearize(h))) return rc;
+  HIP_TRY(launch_gradient_max(dp, sv, st));
+  if ((rc = read_back())) return rc;
+  sum->residual_jacobian_time_s += now_s() - t0;
+  if (nfail) { sum->termination_type = RSBA_FAILURE; (void)finish(RSBA_FAILURE); return rsba_set_error(RSBA_ERR_EVALUATION_FAILED, "initial residual and Jacobian evaluation failed"); }
+  double cost = cost2[0]; const double fixed = cost2[1];
+  double gmax = host_sc[kGradMax];
+  sum->fixed_cost = fixed; sum->initial_cost = cost + fixed; sum->final_cost = cost + fixed;
+  double radius = opt->initial_trust_region_radius, decrease_factor = 2.0; bool reuse_diagonal = false;
+  rsba_iteration it; std::memset(&it, 0, sizeof it);
+  it.cost = cost + fixed; it.gradient_max_norm = gmax; it.trust_region_radius = radius;
+  if (gmax <= opt->gradient_tolerance) { push(it); return finish(RSBA_CONVERGENCE); }
+  if (opt->jacobi_scaling) {
+    // EstimateScale from the first Jacobian, then the Jacobian is column-scaled for good; here the
+    // scales feed the evaluation kernel, so re-linearise once with them
+    HIP_TRY(launch_jacobi_scale(dp, sv, st));
+    if ((rc = linearize(h))) return rc;
+  }
+  push(it);
+
+  int invalid_streak = 0, iteration = 0;
+  const size_t pose_bytes = (size_t)dp.F * dp.P * 6 * sizeof(double), point_bytes = (size_t)dp.M * 3 * sizeof(double);
+  (void)pose_bytes; (void)point_bytes;
+  while (true) {
+    if (iteration >= opt->max_num_iterations) return finish(RSBA_NO_CONVERGENCE);
+    t0 = now_s();
+    if (!reuse_diagonal) HIP_TRY(launch_clamp_diagonal(dp, sv, opt->min_lm_diagonal, opt->max_lm_diagonal, st));
+    HIP_TRY(hipMemsetAsync(sv.chol_fail, 0, sizeof(int), st));
+    if ((rc = factor_and_solve(h, radius))) return rc;
+    reuse_diagonal = true;
+    HIP_TRY(launch_model_cost_change(dp, sv, st));
+    HIP_TRY(launch_candidate(dp, sv, st));
+    // residuals only at the candidate (T = double path)
+    std::swap(dp.poses, sv.trial_poses); std::swap(dp.points, sv.trial_points);
+    HIP_TRY(hipMemsetAsync(dp.fail_count, 0, sizeof(int), st));
+    HIP_TRY(launch_eval(dp, kResidualOnly, st));
+    HIP_TRY(launch_cost_reduce(dp, h->d_cost2, st));
+    std::swap(dp.poses, sv.trial_poses); std::swap(dp.points, sv.trial_points);
+    if ((rc = read_back())) return rc;
+    sum->linear_solver_time_s += now_s() - t0;
+    ++iteration;
+    std::memset(&it, 0, sizeof it); it.iteration = iteration;
+    const double model_cost_change = host_sc[kModelCostChange];
+    const bool solved = !cfail && std::isfinite(model_cost_change) && std::isfinite(host_sc[kStepSq]);
+    const bool valid = solved && model_cost_change >= 0.0;
+    it.model_cost_change = solved ? model_cost_change : 0.0;
+    if (!valid) {
+      if (++invalid_streak >= opt->max_num_consecutive_invalid_steps) { it.cost = cost + fixed; it.trust_region_radius = radius; push(it); return finish(RSBA_FAILURE); }
+      radius /= decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;   // StepIsInvalid == StepRejected(0)
+      ++sum->num_unsuccessful_steps;
+      it.gradient_max_norm = gmax;
+    } else {
+      invalid_streak = 0; it.step_is_valid = 1;
+      const double new_cost = nfail ? std::numeric_limits<double>::max() : (cost2[0] + cost2[1]) - fixed;
+      it.step_norm = std::sqrt(host_sc[kStepSq]);
+      const double x_norm = std::sqrt(host_sc[kXSq]);
+      if (it.step_norm <= opt->parameter_tolerance * (x_norm + opt->parameter_tolerance)) { it.cost = cost + fixed; it.trust_region_radius = radius; push(it); return finish(RSBA_CONVERGENCE); }
+      it.cost_change = cost - new_cost;
+      if (std::fabs(it.cost_change) < opt->function_tolerance * cost) { it.cost = cost + fixed; it.trust_region_radius = radius; push(it); return finish(RSBA_CONVERGENCE); }
+      it.relative_decrease = it.cost_change / model_cost_change;
+      if (it.relative_decrease > opt->min_relative_decrease) {
+        it.step_is_successful = 1; ++sum->num_successful_steps;
+        radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * it.relative_decrease - 1.0, 3));
+        radius = std::min(opt->max_trust_region_radius, radius); decrease_factor = 2.0; reuse_diagonal = false;
+        std::swap(dp.poses, sv.trial_poses); std::swap(dp.points, sv.trial_points);   // x = x_plus_delta
+        t0 = now_s();
+        if ((rc = linearize(h))) return rc;
+        HIP_TRY(launch_gradient_max(dp, sv, st));
+        if ((rc = read_back())) return rc;
+        sum->residual_jacobian_time_s += now_s() - t0;
+        if (nfail) { push(it); (void)finish(RSBA_FAILURE); return rsba_set_error(RSBA_ERR_EVALUATION_FAILED, "residual and Jacobian evaluation failed"); }
+        cost = cost2[0]; gmax = host_sc[kGradMax];
+        it.gradient_max_norm = gmax;
+        sum->final_cost = std::min(sum->final_cost, cost + fixed);
+        if (gmax <= opt->gradient_tolerance) { it.cost = cost + fixed; it.trust_region_radius = radius; push(it); return finish(RSBA_CONVERGENCE); }
+      } else {
+        ++sum->num_unsuccessful_steps; it.gradient_max_norm = gmax;
+        radius /= decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;
+      }
+    }
+    it.cost = cost + fixed; it.trust_region_radius = radius;
+    push(it);
+    if (radius < opt->min_trust_region_radius) return finish(RSBA_CONVERGENCE);
+  }
 }

@@ -1,0 +1,76 @@
+// Device-side state of the LM / Schur solver (calibrated problems: camera blocks of CD = 6P unknowns,
+// point blocks of 3).  Everything lives in HBM for the whole solve; the host reads back a handful of
+// scalars per iteration to take the trust-region decisions.
+//
+//   J^T J = [ U  W ; W^T V ],  U = blockdiag(U_f) (CDxCD per frame),  V = blockdiag(V_j) (3x3 per point)
+//   with V'_j = V_j + D_p^2 = L_j L_j^T and  P_o = Jc_o^T Jp_o L_j^-T  (CD x 3 per observation):
+//     S   = U + D_c^2 - sum_o,o' in same point  P_o P_o'^T          (reduced camera system)
+//     rhs = g_c - sum_o P_o z_j,   z_j = L_j^-1 g_p,j
+//     y_p,j = L_j^-T ( z_j - sum_o P_o^T y_c(frame(o)) )            (back-substitution)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+#include "device_state.hpp"
+
+namespace rsba {
+
+constexpr int kTile = 48;   // Cholesky tile: 4 rolling-shutter frames (12 unknowns) or 8 global-shutter frames
+
+struct SolverDev {
+  int CD;                       // 6 * P
+  int64_t n, npad, ld;          // camera unknowns F*CD, padded to a multiple of kTile, leading dimension of S
+  int nt;                       // npad / kTile
+  // structure
+  const int64_t* frame_ptr;     // [F+1] frame-major observation ranges
+  const int64_t* point_ptr;     // [M+1] slot ranges per point
+  const int32_t* slot_frame;    // [N]
+  const int32_t* slot_point;    // [N]
+  int nblk;                     // structurally non-zero CDxCD blocks (a >= b) of S
+  const int32_t* blk_a;         // [nblk]
+  const int32_t* blk_b;
+  const int64_t* blk_ptr;       // [nblk+1] into the pair list
+  const int32_t* pair_a;        // slot in frame a
+  const int32_t* pair_b;        // slot in frame b (same point)
+  // numeric
+  double* U;                    // [F][CD][CD]
+  double* gc;                   // [F][CD]      (scaled) J_c^T r
+  double* V;                    // [M][6]  xx xy xz yy yz zz
+  double* gp;                   // [M][3]
+  double* diag_c;               // [F*CD]  clamped squared column norms (LM "diagonal_")
+  double* diag_p;               // [M*3]
+  double* Linv;                 // [M][6]  lower-triangular inverse of chol(V')
+  double* z;                    // [M][3]
+  double* Pm;                   // [N][CD*3]  point-major
+  double* S;                    // [npad][ld] lower triangle used
+  double* rhs;                  // [npad]  -> forward-solved in place -> y_c after the back solve
+  double* yp;                   // [M][3]
+  double* trial_poses;          // candidate x + delta
+  double* trial_points;
+  const double* inprog_pose;    // [F*CD] 1 if the coordinate's block is part of the reduced program
+  const double* inprog_point;   // [M*3]
+  double* partial;              // scratch for block partial sums
+  double* scalars;              // [16] results of reductions (see ScalarSlot)
+  int* chol_fail;               // set when a pivot is not positive / not finite
+};
+
+enum ScalarSlot : int {
+  kModelCostChange = 0, kStepSq = 1, kXSq = 2, kGradMax = 3, kCost = 4, kFixedCost = 5,
+};
+
+// kernels_normal.hip
+hipError_t launch_camera_blocks(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);
+hipError_t launch_point_blocks(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);
+hipError_t launch_jacobi_scale(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);           // scale = mask / (1 + sqrt(diag))
+hipError_t launch_clamp_diagonal(const DeviceProblem& dp, const SolverDev& sv, double lo, double hi, hipStream_t st);
+hipError_t launch_gradient_max(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);           // -> scalars[kGradMax]
+hipError_t launch_point_factor(const DeviceProblem& dp, const SolverDev& sv, double radius, hipStream_t st);
+hipError_t launch_project(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);
+hipError_t launch_zero_tiles(const SolverDev& sv, const int32_t* tile_i, const int32_t* tile_j, int ntiles, hipStream_t st);
+hipError_t launch_schur_blocks(const DeviceProblem& dp, const SolverDev& sv, double radius, hipStream_t st);
+hipError_t launch_back_substitute(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);
+hipError_t launch_model_cost_change(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);      // -> scalars[kModelCostChange]
+hipError_t launch_candidate(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);              // trial params, |step|^2, |x|^2
+hipError_t launch_unscaled_gradient(const DeviceProblem& dp, const SolverDev& sv, double* g_pose, double* g_point, hipStream_t st);
+
+}  // namespace rsba
