@@ -126,19 +126,29 @@ __global__ void clamp_diagonal_kernel(const DeviceProblem dp, const SolverDev sv
 }
 
 // max |g_i| of the UNSCALED gradient (Ceres evaluates the gradient before ScaleColumns): g = g_scaled / scale
-__global__ __launch_bounds__(1024) void gradient_max_kernel(const DeviceProblem dp, const SolverDev sv) {
-  __shared__ double s_red[16];
+__global__ __launch_bounds__(256) void gradient_max_kernel(const DeviceProblem dp, const SolverDev sv) {
+  __shared__ double s_red[4];
   double m = 0.0;
   const int64_t nc = sv.n, np = 3 * (int64_t)dp.M;
-  for (int64_t t = threadIdx.x; t < nc + np; t += 1024) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t < nc + np) {
     const double sc = (t < nc) ? dp.scale_pose[t] : dp.scale_point[t - nc];
     const double g = (t < nc) ? sv.gc[t] : sv.gp[t - nc];
-    if (sc > 0.0) m = fmax(m, fabs(g / sc));
+    if (sc > 0.0) m = fabs(g / sc);
   }
   m = wmax(m);
   if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = m;
   __syncthreads();
-  if (threadIdx.x == 0) { double r = 0.0; for (int w = 0; w < 16; ++w) r = fmax(r, s_red[w]); sv.scalars[kGradMax] = r; }
+  if (threadIdx.x == 0) sv.partial[blockIdx.x] = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
+}
+__global__ __launch_bounds__(256) void reduce_max_kernel(const double* partial, int n, double* out) {
+  __shared__ double s_red[4];
+  double v = 0.0;
+  for (int k = threadIdx.x; k < n; k += 256) v = fmax(v, partial[k]);
+  v = wmax(v);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) *out = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
 }
 
 __global__ void unscaled_gradient_kernel(const DeviceProblem dp, const SolverDev sv, double* g_pose, double* g_point) {
@@ -377,7 +387,9 @@ hipError_t launch_clamp_diagonal(const DeviceProblem& dp, const SolverDev& sv, d
   return hipSuccess;
 }
 hipError_t launch_gradient_max(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {
-  LAUNCH(gradient_max_kernel, 1, 1024, st, dp, sv);
+  const int nb = nblocks256(sv.n + 3 * (int64_t)dp.M);
+  LAUNCH(gradient_max_kernel, nb, 256, st, dp, sv);
+  LAUNCH(reduce_max_kernel, 1, 256, st, sv.partial, nb, sv.scalars + kGradMax);
   return hipSuccess;
 }
 hipError_t launch_unscaled_gradient(const DeviceProblem& dp, const SolverDev& sv, double* g_pose, double* g_point, hipStream_t st) {

