@@ -1,0 +1,426 @@
+// Header-only C++ facade: the subset of the Ceres-Solver API that rsba programs against
+// (SURVEY.md §8b lists every call site), mapped onto the C ABI in include/rsba_amd.h.
+//
+//   namespace ceres = rsba_amd::ceres;      // a CeresHandler-shaped program then compiles unchanged
+//
+// What is mapped (reference call sites, paths relative to /root/reference/src/rsba/):
+//   ceres::CostFunction / AddResidualBlock / SetParameterBlockConstant / SetParameterization +
+//   SubsetParameterization / HuberLoss / Problem::Evaluate / Solver::Options / Solve / Summary
+//     — CeresHandler.h:78-90, 208-301, 335-382, 386-387, 394-426; VideoSfMHandler.cc:579-596, 627-630.
+//
+// Only rsba's two hot-path functors are accepted: the typed cost objects of reprojection_costs.hpp
+// (RsBundleAdjustment / ReprojectionError factories).  There is NO host-side evaluation: every
+// residual, Jacobian and solve goes through librsba_amd's HIP kernels; a cost function of any other type
+// (rsba's priors — SURVEY §8f row f1) is rejected with an error, not evaluated on the CPU.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <memory>
+#include <set>
+#include <sstream>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../rsba_amd.h"
+#include "session.hpp"
+
+namespace rsba_amd {
+namespace ceres {
+
+enum LinearSolverType { DENSE_NORMAL_CHOLESKY, DENSE_QR, SPARSE_NORMAL_CHOLESKY, DENSE_SCHUR, SPARSE_SCHUR, ITERATIVE_SCHUR, CGNR };
+enum TerminationType { CONVERGENCE, NO_CONVERGENCE, FAILURE, USER_SUCCESS, USER_FAILURE };
+enum Ownership { DO_NOT_TAKE_OWNERSHIP, TAKE_OWNERSHIP };
+
+// ceres::LossFunction / ceres::HuberLoss (CeresHandler.h:80,88)
+class LossFunction {
+ public:
+  virtual ~LossFunction() {}
+  virtual void Evaluate(double sq_norm, double out[3]) const = 0;
+};
+class HuberLoss : public LossFunction {
+ public:
+  explicit HuberLoss(double a) : a_(a), b_(a * a) {}
+  // rho(s) = s for s <= a^2, 2 a sqrt(s) - a^2 beyond (closed form; the solve applies it on the device)
+  void Evaluate(double s, double rho[3]) const override {
+    if (s > b_) { const double r = std::sqrt(s); rho[0] = 2.0 * a_ * r - b_; rho[1] = std::max(std::numeric_limits<double>::min(), a_ / r); rho[2] = -rho[1] / (2.0 * s); }
+    else { rho[0] = s; rho[1] = 1.0; rho[2] = 0.0; }
+  }
+  double a() const { return a_; }
+ private:
+  double a_, b_;
+};
+
+// ceres::LocalParameterization / ceres::SubsetParameterization (CeresHandler.h:355,367,378)
+class LocalParameterization {
+ public:
+  virtual ~LocalParameterization() {}
+  virtual int GlobalSize() const = 0;
+  virtual int LocalSize() const = 0;
+};
+class SubsetParameterization : public LocalParameterization {
+ public:
+  SubsetParameterization(int size, const std::vector<int>& constant_parameters) : size_(size), mask_(0) {
+    for (int c : constant_parameters) if (c >= 0 && c < 32) mask_ |= (1u << c);
+    local_ = size_;
+    for (int c = 0; c < size_ && c < 32; ++c) if (mask_ & (1u << c)) --local_;
+  }
+  int GlobalSize() const override { return size_; }
+  int LocalSize() const override { return local_; }
+  unsigned constancy_mask() const { return mask_; }
+ private:
+  int size_, local_;
+  unsigned mask_;
+};
+
+// ceres::CostFunction (virtual Evaluate, row-major num_residuals x block_size Jacobians, false = failed)
+class CostFunction {
+ public:
+  virtual ~CostFunction() {}
+  virtual bool Evaluate(double const* const* parameters, double* residuals, double** jacobians) const = 0;
+  const std::vector<int32_t>& parameter_block_sizes() const { return sizes_; }
+  int num_residuals() const { return num_residuals_; }
+ protected:
+  std::vector<int32_t> sizes_;
+  int num_residuals_ = 0;
+};
+
+// The one family of cost functions this library accelerates.  Created by the factories in
+// reprojection_costs.hpp, which keep the reference's names and argument lists.
+class ReprojectionCost : public CostFunction {
+ public:
+  // blocks: [cam 9]? pose0 [pose1]? point
+  ReprojectionCost(bool rolling, bool with_cam, const double observed[2], const double* fixed_cam,
+                   const Session* sess, const SfmOptions* opt)
+      : rolling_(rolling), with_cam_(with_cam), sess_(sess), opt_(opt) {
+    obs_[0] = observed[0]; obs_[1] = observed[1];
+    if (fixed_cam) std::memcpy(cam_, fixed_cam, sizeof cam_); else std::memset(cam_, 0, sizeof cam_);
+    num_residuals_ = 2;
+    if (with_cam) sizes_.push_back(NUM_CAM_PARAMS);
+    sizes_.push_back(NUM_POSE_PARAMS);
+    if (rolling) sizes_.push_back(NUM_POSE_PARAMS);
+    sizes_.push_back(NUM_POINT_PARAMS);
+  }
+  bool rolling() const { return rolling_; }
+  bool with_cam() const { return with_cam_; }
+  const double* observed() const { return obs_; }
+  const double* fixed_cam() const { return cam_; }
+  // the RS functor reads session / option fields through references at evaluation time (VideoSfmBaRs.h:82-83)
+  int shutter() const { return rolling_ && sess_ ? sess_->rs : GLOBAL; }
+  void scanlines(int32_t out[2]) const { out[0] = (rolling_ && sess_ && sess_->scanlines.size() >= 2) ? sess_->scanlines[0] : 0; out[1] = (rolling_ && sess_ && sess_->scanlines.size() >= 2) ? sess_->scanlines[1] : 1; }
+  bool interpolate_rotation() const { return opt_ ? opt_->model.interpolateRotation : true; }
+
+  // CostFunction::Evaluate for one block: a one-observation problem through the same HIP kernel
+  bool Evaluate(double const* const* parameters, double* residuals, double** jacobians) const override {
+    rsba_problem_desc d; std::memset(&d, 0, sizeof d);
+    int b = 0;
+    double cam[NUM_CAM_PARAMS], poses[2 * NUM_POSE_PARAMS], point[NUM_POINT_PARAMS];
+    std::memcpy(cam, with_cam_ ? parameters[b++] : cam_, sizeof cam);
+    std::memcpy(poses, parameters[b++], NUM_POSE_PARAMS * sizeof(double));
+    if (rolling_) std::memcpy(poses + NUM_POSE_PARAMS, parameters[b++], NUM_POSE_PARAMS * sizeof(double));
+    std::memcpy(point, parameters[b++], sizeof point);
+    const int32_t zero = 0;
+    d.shutter = shutter(); scanlines(d.scanlines); d.interpolate_rotation = interpolate_rotation();
+    d.calibrated = !with_cam_; d.poses_per_frame = rolling_ ? 2 : 1;
+    d.num_frames = d.num_points = d.num_intrinsics = 1; d.num_observations = 1;
+    d.poses = poses; d.points = point; d.intrinsics = cam; d.obs_xy = obs_; d.obs_frame = &zero; d.obs_point = &zero;
+    rsba_handle* h = nullptr;
+    if (rsba_create(&d, 0, &h) != RSBA_OK) return false;
+    const int K = (with_cam_ ? 9 : 0) + (rolling_ ? 12 : 6) + 3;
+    std::vector<double> J(2 * (size_t)K);
+    int64_t nfail = 0; double cost = 0;
+    const int32_t st = rsba_evaluate(h, &cost, residuals, jacobians ? J.data() : nullptr, nullptr, &nfail);
+    rsba_destroy(h);
+    if (st != RSBA_OK) return false;
+    if (jacobians) {
+      int col = 0;
+      for (size_t blk = 0; blk < sizes_.size(); ++blk) {
+        const int n = sizes_[blk];
+        if (jacobians[blk]) for (int r = 0; r < 2; ++r) for (int c = 0; c < n; ++c) jacobians[blk][r * n + c] = J[(size_t)r * K + col + c];
+        col += n;
+      }
+    }
+    return true;
+  }
+
+ private:
+  bool rolling_, with_cam_;
+  double obs_[2], cam_[NUM_CAM_PARAMS];
+  const Session* sess_;
+  const SfmOptions* opt_;
+};
+
+struct CRSMatrix {
+  int num_rows = 0, num_cols = 0;
+  std::vector<int> cols, rows;
+  std::vector<double> values;
+};
+
+class Problem;
+struct Solver {
+  struct Options {
+    LinearSolverType linear_solver_type = SPARSE_NORMAL_CHOLESKY;
+    bool minimizer_progress_to_stdout = false;
+    int max_num_iterations = 50;
+    int min_linear_solver_iterations = 1;
+    int num_threads = 1, num_linear_solver_threads = 1;
+    bool jacobi_scaling = true;
+    bool use_nonmonotonic_steps = false;
+    int max_num_consecutive_invalid_steps = 5;
+    double initial_trust_region_radius = 1e4, max_trust_region_radius = 1e16, min_trust_region_radius = 1e-32;
+    double min_relative_decrease = 1e-3, min_lm_diagonal = 1e-6, max_lm_diagonal = 1e32;
+    double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
+    int device = 0;   // extension: HIP device ordinal (one process per GPU)
+  };
+  struct Summary {
+    TerminationType termination_type = FAILURE;
+    std::string message;
+    double initial_cost = 0, final_cost = 0, fixed_cost = 0;
+    int num_successful_steps = 0, num_unsuccessful_steps = 0;
+    int num_residual_blocks = 0, num_residual_blocks_reduced = 0, num_parameters_reduced = 0;
+    double total_time_in_seconds = 0, jacobian_evaluation_time_in_seconds = 0, linear_solver_time_in_seconds = 0;
+    std::vector<rsba_iteration> iterations;
+    bool IsSolutionUsable() const { return termination_type == CONVERGENCE || termination_type == NO_CONVERGENCE || termination_type == USER_SUCCESS; }
+    std::string BriefReport() const {
+      std::ostringstream o;
+      o << "rsba_amd report: iterations: " << iterations.size() << ", initial cost: " << initial_cost << ", final cost: " << final_cost
+        << ", termination: " << (termination_type == CONVERGENCE ? "CONVERGENCE" : termination_type == NO_CONVERGENCE ? "NO_CONVERGENCE" : "FAILURE");
+      return o.str();
+    }
+    std::string FullReport() const {
+      std::ostringstream o;
+      o << "Solver Summary (rsba_amd, MI355X)\n"
+        << "Residual blocks      " << num_residual_blocks << " (reduced " << num_residual_blocks_reduced << ")\n"
+        << "Effective parameters " << num_parameters_reduced << "\n"
+        << "Linear solver        SPARSE_SCHUR (on-device point elimination + tile-sparse Cholesky)\n"
+        << "Cost: initial " << initial_cost << "  final " << final_cost << "  change " << (initial_cost - final_cost) << "\n"
+        << "Minimizer iterations " << iterations.size() << " (successful " << num_successful_steps << ", unsuccessful " << num_unsuccessful_steps << ")\n"
+        << "Time (s): residual+jacobian " << jacobian_evaluation_time_in_seconds << "  linear solver " << linear_solver_time_in_seconds
+        << "  total " << total_time_in_seconds << "\n"
+        << "Termination: " << (termination_type == CONVERGENCE ? "CONVERGENCE" : termination_type == NO_CONVERGENCE ? "NO_CONVERGENCE" : "FAILURE")
+        << (message.empty() ? "" : " (" + message + ")") << "\n";
+      return o.str();
+    }
+  };
+};
+
+// ceres::Problem with default options: takes ownership of cost / loss / parameterization objects; the
+// same HuberLoss* may be passed many times and is freed once (CeresHandler.h:252,259,270,276).
+class Problem {
+ public:
+  struct EvaluateOptions {};
+  Problem() {}
+  Problem(const Problem&) = delete;
+  Problem& operator=(const Problem&) = delete;
+  ~Problem() {
+    for (CostFunction* c : costs_) delete c;
+    for (LossFunction* l : losses_) delete l;
+    for (LocalParameterization* p : params_) delete p;
+  }
+
+  void AddResidualBlock(CostFunction* cost, LossFunction* loss, double* x0) { add(cost, loss, {x0}); }
+  void AddResidualBlock(CostFunction* cost, LossFunction* loss, double* x0, double* x1) { add(cost, loss, {x0, x1}); }
+  void AddResidualBlock(CostFunction* cost, LossFunction* loss, double* x0, double* x1, double* x2) { add(cost, loss, {x0, x1, x2}); }
+  void AddResidualBlock(CostFunction* cost, LossFunction* loss, double* x0, double* x1, double* x2, double* x3) { add(cost, loss, {x0, x1, x2, x3}); }
+  void AddResidualBlock(CostFunction* cost, LossFunction* loss, double* x0, double* x1, double* x2, double* x3, double* x4) { add(cost, loss, {x0, x1, x2, x3, x4}); }
+
+  void SetParameterBlockConstant(double* values) { constant_.insert(values); }
+  void SetParameterBlockVariable(double* values) { constant_.erase(values); }
+  void SetParameterization(double* values, LocalParameterization* p) { if (p) params_.insert(p); parameterization_[values] = p; }
+  void SetParameterLowerBound(double* values, int index, double bound) { lower_bounds_[std::make_pair(values, index)] = bound; }
+  int NumParameterBlocks() const { return (int)block_sizes_.size(); }
+  int NumResidualBlocks() const { return (int)blocks_.size(); }
+  int NumResiduals() const { int n = 0; for (const Block& b : blocks_) n += b.cost->num_residuals(); return n; }
+
+  // Problem::Evaluate (CeresHandler.h:386-387): cost = 1/2 sum rho(|r|^2); residuals in block order;
+  // gradient over the parameter blocks in order of first appearance (full ambient size, zeros at fixed
+  // coordinates).  The CRS Jacobian output is not provided.
+  bool Evaluate(const EvaluateOptions&, double* cost, std::vector<double>* residuals, std::vector<double>* gradient, CRSMatrix* jacobian) {
+    if (jacobian) return false;
+    Flat f;
+    if (!flatten(&f, nullptr)) return false;
+    rsba_handle* h = nullptr;
+    if (rsba_create(&f.desc, 0, &h) != RSBA_OK) return false;
+    std::vector<double> g;
+    if (gradient) g.resize(f.poses.size() + f.points.size() + f.intr.size());
+    if (residuals) residuals->assign(2 * blocks_.size(), 0.0);
+    int64_t nfail = 0;
+    const int32_t st = rsba_evaluate(h, cost, residuals ? residuals->data() : nullptr, nullptr, gradient ? g.data() : nullptr, &nfail);
+    rsba_destroy(h);
+    if (st != RSBA_OK) return false;
+    if (gradient) {
+      gradient->clear();
+      for (double* p : block_order_) {
+        const Slot s = f.slot_of[p];
+        const double* src = s.kind == 0 ? &g[(size_t)s.index * 6] : s.kind == 1 ? &g[f.poses.size() + (size_t)s.index * 3] : &g[f.poses.size() + f.points.size() + (size_t)s.index * 9];
+        gradient->insert(gradient->end(), src, src + block_sizes_[p]);
+      }
+    }
+    return true;
+  }
+
+ private:
+  friend void Solve(const Solver::Options&, Problem*, Solver::Summary*);
+  struct Block { CostFunction* cost; LossFunction* loss; std::vector<double*> x; };
+  struct Slot { int kind; int index; };   // kind 0 pose block, 1 point, 2 intrinsics
+  struct Flat {
+    rsba_problem_desc desc;
+    std::vector<double> poses, points, intr, xy;
+    std::vector<int32_t> obs_frame, obs_point, frame_intr;
+    std::vector<uint8_t> pose_mask, point_const, intr_const;
+    std::vector<double*> pose_ptr, point_ptr, intr_ptr;   // where each flat block came from (nullptr: data, not a block)
+    std::map<double*, Slot> slot_of;
+  };
+
+  void add(CostFunction* cost, LossFunction* loss, std::vector<double*> x) {
+    costs_.insert(cost);
+    if (loss) losses_.insert(loss);
+    const std::vector<int32_t>& sz = cost->parameter_block_sizes();
+    for (size_t i = 0; i < x.size() && i < sz.size(); ++i)
+      if (!block_sizes_.count(x[i])) { block_sizes_[x[i]] = sz[i]; block_order_.push_back(x[i]); }
+    blocks_.push_back(Block{cost, loss, std::move(x)});
+  }
+
+  unsigned mask_of(double* p, int size) const {
+    if (constant_.count(p)) return size >= 32 ? 0xffffffffu : ((1u << size) - 1u);
+    auto it = parameterization_.find(p);
+    if (it != parameterization_.end()) if (auto* s = dynamic_cast<SubsetParameterization*>(it->second)) return s->constancy_mask();
+    return 0;
+  }
+
+  // AoS pointer graph -> the flat SoA description of include/rsba_amd.h.  Returns false (with a
+  // message) for anything outside the accelerated path.
+  bool flatten(Flat* f, std::string* why) {
+    auto fail = [&](const char* m) { if (why) *why = m; return false; };
+    if (blocks_.empty()) return fail("no residual blocks");
+    const ReprojectionCost* first = dynamic_cast<const ReprojectionCost*>(blocks_[0].cost);
+    if (!first) return fail("only rsba's reprojection cost functions are accelerated (priors: SURVEY §8f f1)");
+    const bool rolling = first->rolling(), with_cam = first->with_cam();
+    const int P = rolling ? 2 : 1;
+    LossFunction* loss0 = blocks_[0].loss;
+    std::map<std::pair<double*, double*>, int> frame_of;
+    std::map<double*, int> point_of, intr_of;
+    std::map<std::vector<double>, int> intr_by_value;
+    int32_t sl[2]; first->scanlines(sl);
+    for (const Block& b : blocks_) {
+      const ReprojectionCost* c = dynamic_cast<const ReprojectionCost*>(b.cost);
+      if (!c) return fail("only rsba's reprojection cost functions are accelerated (priors: SURVEY §8f f1)");
+      if (c->rolling() != rolling || c->with_cam() != with_cam) return fail("mixed functor shapes in one problem are not supported");
+      if (b.loss != loss0) return fail("all residual blocks must share one loss function (as CeresHandler does)");
+      if (b.x.size() != c->parameter_block_sizes().size()) return fail("wrong number of parameter blocks");
+      int32_t s2[2]; c->scanlines(s2);
+      if (c->shutter() != first->shutter() || s2[0] != sl[0] || s2[1] != sl[1] || c->interpolate_rotation() != first->interpolate_rotation())
+        return fail("residual blocks disagree on shutter / scanlines / interpolateRotation");
+      size_t k = 0;
+      double* camp = with_cam ? b.x[k++] : nullptr;
+      double* p0 = b.x[k++];
+      double* p1 = rolling ? b.x[k++] : nullptr;
+      double* pt = b.x[k++];
+      int ci;
+      if (with_cam) {
+        auto it = intr_of.find(camp);
+        if (it == intr_of.end()) { ci = (int)f->intr_ptr.size(); intr_of[camp] = ci; f->intr_ptr.push_back(camp); f->intr.insert(f->intr.end(), camp, camp + 9); f->slot_of[camp] = Slot{2, ci}; }
+        else ci = it->second;
+      } else {
+        std::vector<double> v(c->fixed_cam(), c->fixed_cam() + 9);
+        auto it = intr_by_value.find(v);
+        if (it == intr_by_value.end()) { ci = (int)f->intr_ptr.size(); intr_by_value[v] = ci; f->intr_ptr.push_back(nullptr); f->intr.insert(f->intr.end(), v.begin(), v.end()); }
+        else ci = it->second;
+      }
+      const auto key = std::make_pair(p0, p1);
+      int fi;
+      auto itf = frame_of.find(key);
+      if (itf == frame_of.end()) {
+        fi = (int)f->frame_intr.size(); frame_of[key] = fi; f->frame_intr.push_back(ci);
+        f->pose_ptr.push_back(p0); f->poses.insert(f->poses.end(), p0, p0 + 6); f->slot_of[p0] = Slot{0, fi * P};
+        if (rolling) { f->pose_ptr.push_back(p1); f->poses.insert(f->poses.end(), p1, p1 + 6); f->slot_of[p1] = Slot{0, fi * P + 1}; }
+      } else { fi = itf->second; if (f->frame_intr[fi] != ci) return fail("one frame observed through two different intrinsics"); }
+      int pi;
+      auto itp = point_of.find(pt);
+      if (itp == point_of.end()) { pi = (int)f->point_ptr.size(); point_of[pt] = pi; f->point_ptr.push_back(pt); f->points.insert(f->points.end(), pt, pt + 3); f->slot_of[pt] = Slot{1, pi}; }
+      else pi = itp->second;
+      f->xy.push_back(c->observed()[0]); f->xy.push_back(c->observed()[1]);
+      f->obs_frame.push_back(fi); f->obs_point.push_back(pi);
+    }
+    // a pose pointer may not serve as pose0 of one frame and pose1 of another
+    if ((int)f->slot_of.size() != (int)f->pose_ptr.size() + (int)f->point_ptr.size() + (with_cam ? (int)f->intr_ptr.size() : 0))
+      return fail("a parameter block is used in two different roles");
+    for (double* p : f->pose_ptr) f->pose_mask.push_back((uint8_t)(mask_of(p, 6) & 0x3f));
+    for (double* p : f->point_ptr) f->point_const.push_back(constant_.count(p) ? 1 : 0);
+    for (double* p : f->intr_ptr) f->intr_const.push_back(p && constant_.count(p) ? 1 : 0);
+    for (const auto& lb : lower_bounds_) if (f->slot_of.count(lb.first.first)) return fail("bounds on pose / point / intrinsics blocks are not supported");
+    rsba_problem_desc& d = f->desc; std::memset(&d, 0, sizeof d);
+    d.shutter = first->shutter(); d.scanlines[0] = sl[0]; d.scanlines[1] = sl[1];
+    d.interpolate_rotation = first->interpolate_rotation(); d.calibrated = !with_cam; d.poses_per_frame = P;
+    d.num_frames = (int32_t)f->frame_intr.size(); d.num_points = (int32_t)f->point_ptr.size(); d.num_intrinsics = (int32_t)f->intr_ptr.size();
+    d.num_observations = (int64_t)f->obs_frame.size();
+    d.poses = f->poses.data(); d.points = f->points.data(); d.intrinsics = f->intr.data(); d.frame_intrinsics = f->frame_intr.data();
+    d.obs_xy = f->xy.data(); d.obs_frame = f->obs_frame.data(); d.obs_point = f->obs_point.data();
+    d.pose_fixed_mask = f->pose_mask.data(); d.point_constant = f->point_const.data(); d.intrinsics_constant = f->intr_const.data();
+    const HuberLoss* hl = dynamic_cast<const HuberLoss*>(loss0);
+    if (loss0 && !hl) return fail("only ceres::HuberLoss is supported");
+    d.huber_a = hl ? hl->a() : 0.0;
+    return true;
+  }
+
+  // results of a solve go back into the caller's blocks, as ceres::Solve mutates them in place
+  void scatter(const Flat& f) {
+    const int nposeblk = (int)f.pose_ptr.size();
+    for (int b = 0; b < nposeblk; ++b) std::memcpy(f.pose_ptr[b], &f.poses[(size_t)b * 6], 6 * sizeof(double));
+    for (size_t j = 0; j < f.point_ptr.size(); ++j) std::memcpy(f.point_ptr[j], &f.points[j * 3], 3 * sizeof(double));
+    for (size_t c = 0; c < f.intr_ptr.size(); ++c) if (f.intr_ptr[c]) std::memcpy(f.intr_ptr[c], &f.intr[c * 9], 9 * sizeof(double));
+  }
+
+  std::vector<Block> blocks_;
+  std::set<CostFunction*> costs_;
+  std::set<LossFunction*> losses_;
+  std::set<LocalParameterization*> params_;
+  std::set<double*> constant_;
+  std::map<double*, LocalParameterization*> parameterization_;
+  std::map<std::pair<double*, int>, double> lower_bounds_;
+  std::map<double*, int> block_sizes_;
+  std::vector<double*> block_order_;
+};
+
+// ceres::Solve(options, &problem, &summary) (CeresHandler.h:419).  Synchronous; never throws; status in
+// the summary.  Any linear_solver_type is served by the one exact Schur-complement solver.
+inline void Solve(const Solver::Options& options, Problem* problem, Solver::Summary* summary) {
+  *summary = Solver::Summary();
+  Problem::Flat f;
+  std::string why;
+  if (!problem->flatten(&f, &why)) { summary->termination_type = FAILURE; summary->message = why; return; }
+  rsba_handle* h = nullptr;
+  int32_t st = rsba_create(&f.desc, options.device, &h);
+  if (st != RSBA_OK) { summary->termination_type = FAILURE; summary->message = std::string(rsba_status_string(st)) + ": " + rsba_last_error(); return; }
+  rsba_solver_options o; rsba_default_solver_options(&o);
+  o.max_num_iterations = options.max_num_iterations; o.jacobi_scaling = options.jacobi_scaling;
+  o.max_num_consecutive_invalid_steps = options.max_num_consecutive_invalid_steps;
+  o.minimizer_progress_to_stdout = options.minimizer_progress_to_stdout;
+  o.initial_trust_region_radius = options.initial_trust_region_radius; o.max_trust_region_radius = options.max_trust_region_radius;
+  o.min_trust_region_radius = options.min_trust_region_radius; o.min_relative_decrease = options.min_relative_decrease;
+  o.min_lm_diagonal = options.min_lm_diagonal; o.max_lm_diagonal = options.max_lm_diagonal;
+  o.function_tolerance = options.function_tolerance; o.gradient_tolerance = options.gradient_tolerance; o.parameter_tolerance = options.parameter_tolerance;
+  rsba_solver_summary s;
+  std::vector<rsba_iteration> trace((size_t)options.max_num_iterations + 2);
+  st = rsba_solve(h, &o, &s, trace.data(), (int32_t)trace.size());
+  rsba_destroy(h);
+  summary->termination_type = s.termination_type == RSBA_CONVERGENCE ? CONVERGENCE : s.termination_type == RSBA_NO_CONVERGENCE ? NO_CONVERGENCE : FAILURE;
+  if (st != RSBA_OK) { summary->termination_type = FAILURE; summary->message = std::string(rsba_status_string(st)) + ": " + rsba_last_error(); }
+  summary->initial_cost = s.initial_cost; summary->final_cost = s.final_cost; summary->fixed_cost = s.fixed_cost;
+  summary->num_successful_steps = s.num_successful_steps; summary->num_unsuccessful_steps = s.num_unsuccessful_steps;
+  summary->num_residual_blocks = s.num_residual_blocks; summary->num_residual_blocks_reduced = s.num_residual_blocks_reduced;
+  summary->num_parameters_reduced = s.num_parameters_reduced;
+  summary->total_time_in_seconds = s.total_time_s; summary->jacobian_evaluation_time_in_seconds = s.residual_jacobian_time_s;
+  summary->linear_solver_time_in_seconds = s.linear_solver_time_s;
+  trace.resize(std::min<size_t>(trace.size(), (size_t)std::max(0, s.num_iterations)));
+  summary->iterations = trace;
+  if (summary->IsSolutionUsable()) problem->scatter(f);
+}
+
+}  // namespace ceres
+}  // namespace rsba_amd

@@ -1,0 +1,145 @@
+// Host-side mirror of rsba's problem assembly and BA entry point, over the facade:
+//   CeresHandler::CeresHandler / Add / solve   /root/reference/src/rsba/CeresHandler.h:76-427
+//   VideoSfMHandler::BA                        /root/reference/src/rsba/VideoSfMHandler.cc:574-631
+// Same names, argument meaning and error behaviour for the per-observation path (SURVEY Appendix D
+// steps 3-4).  Not built (they are "next" rows): pose initialisation of frames without poses
+// (Appendix D step 1), motion / pose priors (step 2), the structure-less ray costs, match-based track
+// lookup and revalidateReprojections — reaching one of them throws std::runtime_error.
+#pragma once
+#include <cmath>
+#include <iostream>
+#include <stdexcept>
+#include <thread>
+
+#include "reprojection_costs.hpp"
+
+namespace rsba_amd {
+
+// struct/VideoSfM.cc:75-99 getPose (pointer-returning overload), 1-pose and "one pose per scan-line" cases
+inline double* getPose(const Session& sess, Frame& f, const SfmOptions&, const double obs[2]) {
+  switch (f.poses.size()) {
+    case 0: throw std::runtime_error("empty frame");
+    case 1: return f.poses[0].data();
+    case 2: throw std::runtime_error("not possible to get a pose reference on linear RS");
+    default: {
+      double line = (sess.rs == HORIZONTAL) ? obs[0] : obs[1];
+      if (line < 0) line = 0; else if (line > f.poses.size() - 1) line = (double)(f.poses.size() - 1);
+      return f.poses[(size_t)std::round(line)].data();
+    }
+  }
+}
+
+class CeresHandler {
+ public:
+  ceres::Problem problem;
+  SfmOptions opt;
+  ceres::LossFunction* lossFunction = nullptr;
+  size_t startFrame;
+
+  // CeresHandler.h:85-90: one shared HuberLoss when opt.ceres.huberLoss > 0
+  CeresHandler(const SfmOptions& o, size_t start = 0) : problem(), opt(o), startFrame(start) {
+    if (opt.ceres.huberLoss > 0) lossFunction = new ceres::HuberLoss(opt.ceres.huberLoss);
+  }
+
+  // CeresHandler.h:94-390, per-observation path
+  void Add(const size_t frameKey, Session& sess, bool uninitialized = false) {
+    Frame& f = sess.frames[frameKey];
+    const int formerParamNum = problem.NumParameterBlocks();
+    if (!f.__isset.poses) throw std::runtime_error("pose initialisation (CeresHandler.h:99-144) is not built: set Frame::poses");
+    if (frameKey >= opt.ceres.fixFirstNCameras) {
+      if (frameKey > 0 && (opt.ceres.constFrameVelocity != 0 || opt.ceres.constFrameAcceleration != 0))
+        throw std::runtime_error("motion priors (CeresHandler.h:148-186) are not built");
+      if ((opt.ceres.trustPriorCamRotation != 0 || opt.ceres.trustPriorCamPosition != 0) && f.__isset.priorPoses && !f.priorPoses.empty())
+        throw std::runtime_error("pose priors (CeresHandler.h:188-204) are not built");
+    }
+    if (!opt.model.use3Dpoints) throw std::runtime_error("structure-less costs (CeresHandler.h:303-332) are not built");
+    (void)uninitialized;
+    for (Observation& o : f.obs) {
+      double obs[2] = {o.x, o.y};
+      Track* t = nullptr;
+      if (o.__isset.track) {                                           // :215-218
+        t = &sess.getTrack((size_t)o.track);
+        if (!t->__isset.pt || (opt.ceres.useOnlyValidMatches && !t->valid)) t = nullptr;
+      }
+      if (!t || !(t->valid || !opt.ceres.useOnlyValidMatches)) continue;   // :238 (match-based lookup :220-236 not built)
+      if (opt.ceres.revalidateReprojections) throw std::runtime_error("revalidateReprojections (CeresHandler.h:239-243) is not built");
+      if (f.poses.size() == 2) {                                       // :245-265 rolling shutter, two poses
+        if (opt.model.constVelocity) throw std::runtime_error("constVelocity");   // the reference aborts (:246-247)
+        if (opt.model.calibrated) {
+          problem.AddResidualBlock(RsBundleAdjustment::Create(sess, opt, obs), lossFunction, f.poses[0].data(), f.poses[1].data(), t->pt.data());
+        } else {
+          problem.AddResidualBlock(RsBundleAdjustment::CreateWithCam(sess, opt, obs), lossFunction,
+                                   f.__isset.cam ? f.cam.data() : sess.cam.data(), f.poses[0].data(), f.poses[1].data(), t->pt.data());
+        }
+      } else {                                                         // :266-286 one pose per observation
+        if (opt.model.calibrated) {
+          problem.AddResidualBlock(ReprojectionError::Create(f.__isset.cam ? f.cam.data() : sess.cam.data(), obs), lossFunction,
+                                   getPose(sess, f, opt, obs), t->pt.data());
+        } else {
+          problem.AddResidualBlock(ReprojectionError::Create(obs), lossFunction, f.__isset.cam ? f.cam.data() : sess.cam.data(),
+                                   getPose(sess, f, opt, obs), t->pt.data());
+        }
+        if (frameKey < opt.ceres.fixFirstNCameras) {
+          problem.SetParameterBlockConstant(getPose(sess, f, opt, obs));
+          if (!opt.model.calibrated && f.__isset.cam) problem.SetParameterBlockConstant(f.cam.data());
+        }
+      }
+      bool fixedOldTrack = false;                                      // :288-300 window BA freezes old tracks
+      if (startFrame > 0)
+        for (const ObservationRef& ref : t->obs) if ((size_t)ref.frame < startFrame) { fixedOldTrack = true; break; }
+      if (fixedOldTrack || opt.ceres.const3d) problem.SetParameterBlockConstant(t->pt.data());
+    }
+    if (problem.NumParameterBlocks() > formerParamNum) {               // :335-382, first matching rule wins
+      if (frameKey < opt.ceres.fixFirstNCameras) {
+        if (f.poses.size() == 2) { problem.SetParameterBlockConstant(f.poses[0].data()); problem.SetParameterBlockConstant(f.poses[1].data()); }
+        if (!opt.model.calibrated && f.__isset.cam) problem.SetParameterBlockConstant(f.cam.data());
+      } else if (opt.ceres.fixScale && (frameKey == 0 || frameKey == sess.frames.size() - 1)) {
+        ceres::LocalParameterization* p = new ceres::SubsetParameterization(NUM_POSE_PARAMS, std::vector<int>{3, 4, 5});
+        if (frameKey == 0) problem.SetParameterization(f.poses[0].data(), p); else problem.SetParameterization(f.poses.back().data(), p);
+      } else if (opt.ceres.fixRotation) {
+        for (auto& pose : f.poses) problem.SetParameterization(pose.data(), new ceres::SubsetParameterization(NUM_POSE_PARAMS, std::vector<int>{0, 1, 2}));
+      } else if (opt.ceres.fixPosition) {
+        for (auto& pose : f.poses) problem.SetParameterization(pose.data(), new ceres::SubsetParameterization(NUM_POSE_PARAMS, std::vector<int>{3, 4, 5}));
+      }
+    }
+  }
+
+  // CeresHandler.h:394-426
+  ceres::Solver::Summary solve(ceres::Solver::Options* options = nullptr) {
+    ceres::Solver::Options tmp;
+    if (options == nullptr) {
+      options = &tmp;
+      options->linear_solver_type = ceres::SPARSE_SCHUR;
+      options->minimizer_progress_to_stdout = true;
+      options->max_num_iterations = 50;
+    }
+    const unsigned n = std::thread::hardware_concurrency();   // :408-415 (the device path ignores host threads)
+    if (n > 0) options->num_linear_solver_threads = options->num_threads = (int)n;
+    ceres::Solver::Summary summary;
+    ceres::Solve(*options, &problem, &summary);
+    return summary;
+  }
+};
+
+// VideoSfMHandler::BA (VideoSfMHandler.cc:574-631) without the service bookkeeping: options as :579-583,
+// Add frames [startFrame, endFrame], solve, print the report and the "average reprojection error"
+// sqrt(final_cost / num_residual_blocks_reduced) (:627-628), return IsSolutionUsable() (:630).
+inline bool BA(Session& sess, const int32_t startFrame, const int32_t endFrame, const SfmOptions& opt, const int32_t maxIter,
+               ceres::Solver::Summary* out = nullptr, bool progress = true) {
+  ceres::Solver::Options cOpt;
+  cOpt.linear_solver_type = ceres::SPARSE_SCHUR;
+  cOpt.minimizer_progress_to_stdout = progress;
+  cOpt.max_num_iterations = maxIter;
+  cOpt.min_linear_solver_iterations = 3;
+  CeresHandler cs(opt, (size_t)startFrame);
+  for (int32_t fi = startFrame; fi <= endFrame; fi++) cs.Add((size_t)fi, sess);
+  ceres::Solver::Summary summary = cs.solve(&cOpt);
+  if (progress) std::cout << summary.FullReport() << std::endl;
+  if (!summary.IsSolutionUsable()) std::cerr << summary.message << std::endl;
+  if (progress)
+    std::cout << "average reprojection error: " << std::sqrt(summary.final_cost / summary.num_residual_blocks_reduced) << std::endl;
+  if (out) *out = summary;
+  return summary.IsSolutionUsable();
+}
+
+}  // namespace rsba_amd
