@@ -1,9 +1,10 @@
 // K6  reduced camera system  S y = rhs  by a tile-sparse Cholesky factorisation, fp64.
 //
 // Replaces the CHOLMOD sparse Cholesky behind Ceres' SPARSE_SCHUR (reference call site
-// /root/reference/src/rsba/CeresHandler.h:403,419).  S (npad x npad, lower triangle, row-major, ld)
-// is treated as a grid of 48x48 tiles; the symbolic phase (host, once per problem) marks the tiles that
-// are structurally non-zero after fill-in, and only those are touched.  rsba's problems are video:
+// /root/reference/src/rsba/CeresHandler.h:403,419).  S (lower triangle) is a grid of 48x48 tiles; the
+// symbolic phase (host, once per problem) finds the tiles that are structurally non-zero after fill-in
+// and only those are stored — packed back to back in HBM (tile slot s at S + s*48*48, row-major), which is
+// also the buffer the multi-GPU exchange all-reduces.  rsba's problems are video:
 // frames only share points with frames a few dozen positions away, so S is block-banded, fill stays
 // inside the band, and the factorisation is O(n b^2) instead of O(n^3).
 //
@@ -40,11 +41,16 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
   return y;
 }
 
-__device__ __forceinline__ void load_tile(double* dst, const double* src, int64_t ld, int tid, bool lower_only) {
+__device__ __forceinline__ double* tile_ptr(const SolverDev& sv, int slot) { return sv.S + (size_t)slot * (T * T); }
+
+__device__ __forceinline__ void load_tile(double* dst, const double* src, int tid, bool lower_only) {
   for (int e = tid; e < T * T; e += 256) {
     const int r = e / T, c = e % T;
-    dst[r * TP + c] = (!lower_only || c <= r) ? src[(size_t)r * ld + c] : 0.0;
+    dst[r * TP + c] = (!lower_only || c <= r) ? src[e] : 0.0;
   }
+}
+__device__ __forceinline__ void store_tile(double* dst, const double* src, int tid) {
+  for (int e = tid; e < T * T; e += 256) dst[e] = src[(e / T) * TP + e % T];
 }
 
 // C -= A B^T on T x T tiles in LDS; 256 threads as 16 x 16, each a 3 x 3 micro-tile over K = 48
@@ -163,36 +169,33 @@ __device__ __forceinline__ void trsm_blocked(double* X, const double* L, const d
 
 struct StepArgs {
   int k;
-  int npanel;               // 1 + number of sub-diagonal tiles of column k
-  const int32_t* panel_i;   // [npanel-1] tile rows i > k of column k
-  const uint8_t* panel_prev;// [npanel]  1 if the tile (row k itself for entry 0) also exists in column k-1
-  const int32_t* trail_i;   // trailing pairs of step k-1 with j > k
-  const int32_t* trail_j;
+  int npanel;                 // 1 + number of sub-diagonal tiles of column k
+  const int32_t* panel_slot;  // [npanel] slot of tile (i,k); entry 0 is the diagonal tile (k,k)
+  const int32_t* prev_slot;   // [npanel] slot of tile (i,k-1) if it exists (pending update), else -1; entry 0 is (k,k-1)
+  const int32_t* trail;       // [ntrail][4]: slots of (i,k-1), (j,k-1), (i,j) and the tile row i if i == j else -1
 };
 
 __global__ __launch_bounds__(256) void chol_step_kernel(const SolverDev sv, const StepArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x, k = a.k;
-  const int64_t ld = sv.ld;
   if ((int)blockIdx.x >= a.npanel) {
     // ---- trailing update of step k-1 ----
     double* A = smem; double* B = smem + T * TP; double* C = smem + 2 * T * TP;
-    const int t = blockIdx.x - a.npanel;
-    const int i = a.trail_i[t], j = a.trail_j[t];
-    load_tile(A, sv.S + ((size_t)i * T) * ld + (size_t)(k - 1) * T, ld, tid, false);
-    load_tile(B, sv.S + ((size_t)j * T) * ld + (size_t)(k - 1) * T, ld, tid, false);
-    double* sij = sv.S + ((size_t)i * T) * ld + (size_t)j * T;
-    load_tile(C, sij, ld, tid, false);
+    const int32_t* t4 = a.trail + 4 * (blockIdx.x - a.npanel);
+    double* sij = tile_ptr(sv, t4[2]);
+    load_tile(A, tile_ptr(sv, t4[0]), tid, false);
+    load_tile(B, tile_ptr(sv, t4[1]), tid, false);
+    load_tile(C, sij, tid, false);
     __syncthreads();
     tile_gemm_sub(C, A, B, tid);
     __syncthreads();
-    for (int e = tid; e < T * T; e += 256) { const int r = e / T, c = e % T; sij[(size_t)r * ld + c] = C[r * TP + c]; }
-    if (i == j && tid < T) {
+    store_tile(sij, C, tid);
+    if (t4[3] >= 0 && tid < T) {
       const double* z = sv.rhs + (size_t)(k - 1) * T;
       double s0 = 0.0, s1 = 0.0;
 #pragma unroll 8
       for (int m = 0; m < T; m += 2) { s0 += A[tid * TP + m] * z[m]; s1 += A[tid * TP + m + 1] * z[m + 1]; }
-      sv.rhs[(size_t)i * T + tid] -= s0 + s1;
+      sv.rhs[(size_t)t4[3] * T + tid] -= s0 + s1;
     }
     return;
   }
@@ -200,16 +203,15 @@ __global__ __launch_bounds__(256) void chol_step_kernel(const SolverDev sv, cons
   double* D = smem;                 // diagonal tile S_kk -> L_kk
   double* X = smem + T * TP;        // own tile S_ik
   double* Lp = smem + 2 * T * TP;   // L_k,k-1
-  double* Lq = smem + 3 * T * TP;   // L_i,k-1
+  double* Lq = smem + 3 * T * TP;   // L_i,k-1, later the pivot reciprocals
   int* s_okp = reinterpret_cast<int*>(smem + 4 * T * TP);   // all LDS in the one dynamic region (16-B aligned base)
 #define s_ok (*s_okp)
   const int b = blockIdx.x;
-  const int i = b == 0 ? k : a.panel_i[b - 1];
-  const bool prev_k = a.panel_prev[0] != 0, prev_i = b > 0 && a.panel_prev[b] != 0;
-  load_tile(D, sv.S + ((size_t)k * T) * ld + (size_t)k * T, ld, tid, true);
-  if (b > 0) load_tile(X, sv.S + ((size_t)i * T) * ld + (size_t)k * T, ld, tid, false);
-  if (prev_k) load_tile(Lp, sv.S + ((size_t)k * T) * ld + (size_t)(k - 1) * T, ld, tid, false);
-  if (prev_i) load_tile(Lq, sv.S + ((size_t)i * T) * ld + (size_t)(k - 1) * T, ld, tid, false);
+  const bool prev_k = a.prev_slot[0] >= 0, prev_i = b > 0 && prev_k && a.prev_slot[b] >= 0;
+  load_tile(D, tile_ptr(sv, a.panel_slot[0]), tid, true);
+  if (b > 0) load_tile(X, tile_ptr(sv, a.panel_slot[b]), tid, false);
+  if (prev_k) load_tile(Lp, tile_ptr(sv, a.prev_slot[0]), tid, false);
+  if (prev_i) load_tile(Lq, tile_ptr(sv, a.prev_slot[b]), tid, false);
   if (tid == 0) s_ok = 1;
   __syncthreads();
   if (prev_k) {
@@ -223,8 +225,8 @@ __global__ __launch_bounds__(256) void chol_step_kernel(const SolverDev sv, cons
   __syncthreads();
   if (b == 0) {
     if (!s_ok && tid == 0) atomicExch(sv.chol_fail, 1);
-    double* out = sv.S + ((size_t)k * T) * ld + (size_t)k * T;
-    for (int e = tid; e < T * T; e += 256) { const int r = e / T, c = e % T; if (c <= r) out[(size_t)r * ld + c] = D[r * TP + c]; }
+    double* out = tile_ptr(sv, a.panel_slot[0]);
+    for (int e = tid; e < T * T; e += 256) { const int r = e / T, c = e % T; if (c <= r) out[e] = D[r * TP + c]; }
     // forward substitution of the right-hand-side tile, first wave, lane r owns b_r:
     //   b_k -= L_k,k-1 z_k-1 (pending),  z_k = L_kk^-1 b_k
     if (tid < 64) {
@@ -240,44 +242,41 @@ __global__ __launch_bounds__(256) void chol_step_kernel(const SolverDev sv, cons
       double col[T];
 #pragma unroll
       for (int c = 0; c < T; ++c) col[c] = D[r * TP + c];     // row r of L_kk
-      const double dinv = 1.0 / D[r * TP + r];                 // every lane inverts its own pivot, once
+      const double dinv = Lq[r];
 #pragma unroll
       for (int c = 0; c < T; ++c) {
-        // z_c = b_c / L_cc, broadcast from lane c
-        const double zc = __shfl(bb * dinv, c, 64);
+        const double zc = __shfl(bb * dinv, c, 64);             // z_c = b_c / L_cc, broadcast from lane c
         if (tid == c) bb = zc; else if (tid > c) bb -= col[c] * zc;
       }
       if (tid < T) sv.rhs[(size_t)k * T + tid] = bb;
     }
   } else {
-    // L_ik = S_ik L_kk^-T
-    trsm_blocked(X, D, Lq, tid);
-    double* sik = sv.S + ((size_t)i * T) * ld + (size_t)k * T;
-    for (int e = tid; e < T * T; e += 256) { const int r = e / T, c = e % T; sik[(size_t)r * ld + c] = X[r * TP + c]; }
+    trsm_blocked(X, D, Lq, tid);                   // L_ik = S_ik L_kk^-T
+    store_tile(tile_ptr(sv, a.panel_slot[b]), X, tid);
   }
 #undef s_ok
 }
 
 // L^T y = z, one persistent workgroup: for k = nt-1 .. 0:  t = z_k - sum_{i>k} L_ik^T y_i ; solve L_kk^T y_k = t
-__global__ __launch_bounds__(256) void chol_backsolve_kernel(const SolverDev sv, const int32_t* col_ptr, const int32_t* col_i) {
+// col_ptr / col_slot / col_row list, per tile column k, the diagonal tile first and then the tiles (i,k).
+__global__ __launch_bounds__(256) void chol_backsolve_kernel(const SolverDev sv, const int32_t* col_ptr, const int32_t* col_slot, const int32_t* col_row) {
   __shared__ double A[T * TP];
   __shared__ double part[10][T];
   const int tid = threadIdx.x;
   const int c2 = tid % 24, rg = tid / 24;   // column pair, row group (rg < 10 for tid < 240)
-  const int64_t ld = sv.ld;
   for (int k = sv.nt - 1; k >= 0; --k) {
-    load_tile(A, sv.S + ((size_t)k * T) * ld + (size_t)k * T, ld, tid, true);
+    const int p0 = col_ptr[k], p1 = col_ptr[k + 1];
+    load_tile(A, tile_ptr(sv, col_slot[p0]), tid, true);
     double s0 = 0.0, s1 = 0.0;
     if (rg < 10) {
-      for (int p = col_ptr[k]; p < col_ptr[k + 1]; ++p) {
-        const int i = col_i[p];
-        const double* lik = sv.S + ((size_t)i * T) * ld + (size_t)k * T + 2 * c2;
-        const double* yi = sv.rhs + (size_t)i * T;
+      for (int p = p0 + 1; p < p1; ++p) {
+        const double* lik = tile_ptr(sv, col_slot[p]) + 2 * c2;
+        const double* yi = sv.rhs + (size_t)col_row[p] * T;
 #pragma unroll
         for (int u = 0; u < 5; ++u) {
           const int r = rg + 10 * u;
           if (r < T) {
-            const double2 v = *reinterpret_cast<const double2*>(lik + (size_t)r * ld);
+            const double2 v = *reinterpret_cast<const double2*>(lik + (size_t)r * T);
             const double y = yi[r];
             s0 += v.x * y; s1 += v.y * y;
           }
@@ -309,9 +308,9 @@ __global__ __launch_bounds__(256) void chol_backsolve_kernel(const SolverDev sv,
 
 }  // namespace
 
-hipError_t launch_chol_step(const SolverDev& sv, int k, int npanel, const int32_t* panel_i, const uint8_t* panel_prev,
-                            const int32_t* trail_i, const int32_t* trail_j, int ntrail, hipStream_t st) {
-  StepArgs a{k, npanel, panel_i, panel_prev, trail_i, trail_j};
+hipError_t launch_chol_step(const SolverDev& sv, int k, int npanel, const int32_t* panel_slot, const int32_t* prev_slot,
+                            const int32_t* trail, int ntrail, hipStream_t st) {
+  StepArgs a{k, npanel, panel_slot, prev_slot, trail};
   const size_t lds = (size_t)4 * T * TP * sizeof(double) + 16;   // 75 KB of the CU's 160 KB
   static bool configured = false;
   if (!configured) {
@@ -322,8 +321,8 @@ hipError_t launch_chol_step(const SolverDev& sv, int k, int npanel, const int32_
   hipLaunchKernelGGL(chol_step_kernel, dim3(npanel + ntrail), dim3(256), lds, st, sv, a);
   return hipGetLastError();
 }
-hipError_t launch_chol_backsolve(const SolverDev& sv, const int32_t* col_ptr, const int32_t* col_i, hipStream_t st) {
-  hipLaunchKernelGGL(chol_backsolve_kernel, dim3(1), dim3(256), 0, st, sv, col_ptr, col_i);
+hipError_t launch_chol_backsolve(const SolverDev& sv, const int32_t* col_ptr, const int32_t* col_slot, const int32_t* col_row, hipStream_t st) {
+  hipLaunchKernelGGL(chol_backsolve_kernel, dim3(1), dim3(256), 0, st, sv, col_ptr, col_slot, col_row);
   return hipGetLastError();
 }
 

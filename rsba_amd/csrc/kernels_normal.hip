@@ -204,16 +204,11 @@ __global__ __launch_bounds__(256) void project_kernel(const DeviceProblem dp, co
   }
 }
 
-__global__ __launch_bounds__(256) void zero_tiles_kernel(const SolverDev sv, const int32_t* ti, const int32_t* tj) {
-  double* t = sv.S + ((size_t)ti[blockIdx.x] * kTile) * sv.ld + (size_t)tj[blockIdx.x] * kTile;
-  const bool diag = ti[blockIdx.x] == tj[blockIdx.x];
-  const int64_t row0 = (int64_t)ti[blockIdx.x] * kTile;
-  for (int e = threadIdx.x; e < kTile * kTile; e += 256) {
-    const int r = e / kTile, c = e % kTile;
-    // rows beyond the real system are identity padding
-    t[(size_t)r * sv.ld + c] = (diag && r == c && row0 + r >= sv.n) ? 1.0 : 0.0;
-  }
-  if (diag) for (int r = threadIdx.x; r < kTile; r += 256) if (row0 + r >= sv.n) sv.rhs[row0 + r] = 0.0;
+// rows beyond the real system (npad > n) are identity padding inside the last diagonal tile
+__global__ void pad_system_kernel(const SolverDev sv, int last_diag_slot) {
+  const int r = threadIdx.x;
+  const int64_t row = (int64_t)(sv.nt - 1) * kTile + r;
+  if (r < kTile && row >= sv.n) { sv.S[(size_t)last_diag_slot * (kTile * kTile) + r * kTile + r] = 1.0; sv.rhs[row] = 0.0; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -267,7 +262,7 @@ __global__ __launch_bounds__(256) void schur_blocks_kernel(const DeviceProblem d
     racc = t;
   }
   if (q == 0) {
-    double* srow = sv.S + ((size_t)a * CD + r) * sv.ld + (size_t)b * CD;
+    double* srow = sv.S + sv.blk_dst[blk] + (size_t)r * kTile;
     if (diag) {
       const double* urow = sv.U + ((size_t)a * CD + r) * CD;
 #pragma unroll
@@ -406,8 +401,10 @@ hipError_t launch_project(const DeviceProblem& dp, const SolverDev& sv, hipStrea
   else LAUNCH(project_kernel<6>, nblocks256(dp.N), 256, st, dp, sv);
   return hipSuccess;
 }
-hipError_t launch_zero_tiles(const SolverDev& sv, const int32_t* ti, const int32_t* tj, int ntiles, hipStream_t st) {
-  if (ntiles > 0) LAUNCH(zero_tiles_kernel, ntiles, 256, st, sv, ti, tj);
+hipError_t launch_clear_system(const SolverDev& sv, int last_diag_slot, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(sv.S, 0, (size_t)sv.nslots * kTile * kTile * sizeof(double), st);
+  if (e != hipSuccess) return e;
+  if (sv.npad > sv.n) LAUNCH(pad_system_kernel, 1, 64, st, sv, last_diag_slot);
   return hipSuccess;
 }
 hipError_t launch_schur_blocks(const DeviceProblem& dp, const SolverDev& sv, double radius, hipStream_t st) {

@@ -20,21 +20,18 @@
 
 namespace rsba {
 
-hipError_t launch_chol_step(const SolverDev& sv, int k, int npanel, const int32_t* panel_i, const uint8_t* panel_prev,
-                            const int32_t* trail_i, const int32_t* trail_j, int ntrail, hipStream_t st);
-hipError_t launch_chol_backsolve(const SolverDev& sv, const int32_t* col_ptr, const int32_t* col_i, hipStream_t st);
+hipError_t launch_chol_step(const SolverDev& sv, int k, int npanel, const int32_t* panel_slot, const int32_t* prev_slot,
+                            const int32_t* trail, int ntrail, hipStream_t st);
+hipError_t launch_chol_backsolve(const SolverDev& sv, const int32_t* col_ptr, const int32_t* col_slot, const int32_t* col_row, hipStream_t st);
 
 struct Solver {
   SolverDev sv{};
   std::vector<void*> allocs;
-  // Cholesky plan: per tile column k, the sub-diagonal tiles (panel), whether each panel tile also exists
-  // in column k-1 (pending update), and the trailing tile pairs (i >= j > k) of step k-1
-  std::vector<int32_t> col_ptr, col_i, trail_ptr, trail_i, trail_j, prev_ptr;
-  std::vector<uint8_t> prev_flag;
-  int32_t *d_col_ptr = nullptr, *d_col_i = nullptr, *d_trail_i = nullptr, *d_trail_j = nullptr;
-  uint8_t* d_prev_flag = nullptr;
-  int32_t *d_tile_i = nullptr, *d_tile_j = nullptr;
-  int ntiles = 0;
+  // Cholesky plan over the packed tile slots: per tile column k the panel tiles (diagonal first), the slot
+  // of the same tile row in column k-1 (pending update, -1 if none), and the trailing updates of step k-1
+  std::vector<int32_t> panel_ptr, panel_slot, panel_row, prev_slot, trail_ptr, trail;
+  int32_t *d_panel_ptr = nullptr, *d_panel_slot = nullptr, *d_panel_row = nullptr, *d_prev_slot = nullptr, *d_trail = nullptr;
+  int last_diag_slot = 0;
   int32_t* d_obs_slot = nullptr;
   double *d_gpose = nullptr, *d_gpoint = nullptr;
   int64_t num_pairs = 0;
@@ -92,7 +89,7 @@ int32_t build_solver(rsba_handle* h) {
   const int64_t N = dp.N;
   sv.CD = CD; sv.n = (int64_t)F * CD;
   const int FT = kTile / CD;
-  sv.nt = (F + FT - 1) / FT; sv.npad = (int64_t)sv.nt * kTile; sv.ld = sv.npad;
+  sv.nt = (F + FT - 1) / FT; sv.npad = (int64_t)sv.nt * kTile;
   const std::vector<int32_t>& of = h->obs_frame; const std::vector<int32_t>& op = h->obs_point;
 
   std::vector<int64_t> frame_ptr(F + 1, 0), point_ptr(M + 1, 0);
@@ -169,24 +166,37 @@ int32_t build_solver(rsba_handle* h) {
       for (size_t u = 0; u < col[k].size(); ++u) for (size_t v = u; v < col[k].size(); ++v) mark[col[k][u]][col[k][v] - col[k][u]] = 1;
     }
   }
-  std::vector<int32_t> tile_i, tile_j;
-  s->col_ptr.assign(1, 0); s->trail_ptr.assign(1, 0); s->prev_ptr.assign(1, 0);
+  // packed tile slots, column by column: (k,k) first, then the sub-diagonal tiles of column k
+  std::vector<int32_t> slot_base(nt + 1, 0);
+  for (int k = 0; k < nt; ++k) slot_base[k + 1] = slot_base[k] + 1 + (int32_t)col[k].size();
+  sv.nslots = slot_base[nt];
+  auto slot_of = [&](int i, int k) -> int32_t {   // -1 if tile (i,k) is structurally zero
+    if (i == k) return slot_base[k];
+    auto it = std::lower_bound(col[k].begin(), col[k].end(), i);
+    return (it != col[k].end() && *it == i) ? slot_base[k] + 1 + (int32_t)(it - col[k].begin()) : -1;
+  };
+  s->last_diag_slot = slot_base[nt - 1];
+  s->panel_ptr.assign(1, 0); s->trail_ptr.assign(1, 0);
   for (int k = 0; k < nt; ++k) {
-    tile_i.push_back(k); tile_j.push_back(k);
-    for (int32_t i : col[k]) { s->col_i.push_back(i); tile_i.push_back(i); tile_j.push_back(k); }
-    s->col_ptr.push_back((int32_t)s->col_i.size());
-    // pending updates from step k-1: tile (i,k) is touched iff both i and k are rows of column k-1
-    auto in_prev = [&](int32_t i) { return k > 0 && std::binary_search(col[k - 1].begin(), col[k - 1].end(), i); };
-    const bool prev_k = in_prev(k);
-    s->prev_flag.push_back(prev_k);
-    for (int32_t i : col[k]) s->prev_flag.push_back(prev_k && in_prev(i));
-    s->prev_ptr.push_back((int32_t)s->prev_flag.size());
+    s->panel_slot.push_back(slot_base[k]); s->panel_row.push_back(k);
+    s->prev_slot.push_back(k > 0 ? slot_of(k, k - 1) : -1);
+    for (int32_t i : col[k]) {
+      s->panel_slot.push_back(slot_of(i, k)); s->panel_row.push_back(i);
+      s->prev_slot.push_back(k > 0 ? slot_of(i, k - 1) : -1);
+    }
+    s->panel_ptr.push_back((int32_t)s->panel_slot.size());
     if (k > 0)
-      for (size_t u = 0; u < col[k - 1].size(); ++u) for (size_t v = u; v < col[k - 1].size(); ++v)
-        if (col[k - 1][u] > k) { s->trail_i.push_back(col[k - 1][v]); s->trail_j.push_back(col[k - 1][u]); }
-    s->trail_ptr.push_back((int32_t)s->trail_i.size());
+      for (size_t u = 0; u < col[k - 1].size(); ++u) for (size_t v = u; v < col[k - 1].size(); ++v) {
+        const int32_t j = col[k - 1][u], i = col[k - 1][v];
+        if (j > k) { s->trail.push_back(slot_of(i, k - 1)); s->trail.push_back(slot_of(j, k - 1)); s->trail.push_back(slot_of(i, j)); s->trail.push_back(i == j ? i : -1); }
+      }
+    s->trail_ptr.push_back((int32_t)(s->trail.size() / 4));
   }
-  s->ntiles = (int)tile_i.size();
+  std::vector<int64_t> blk_dst(blk_a.size());
+  for (size_t bidx = 0; bidx < blk_a.size(); ++bidx) {
+    const int a = blk_a[bidx], b = blk_b[bidx];
+    blk_dst[bidx] = (int64_t)slot_of(a / FT, b / FT) * (kTile * kTile) + (int64_t)(a % FT) * CD * kTile + (int64_t)(b % FT) * CD;
+  }
 
   // which coordinates belong to the reduced program (for |x| and |step|): blocks that are not constant
   // and are touched by at least one residual block
@@ -222,13 +232,12 @@ int32_t build_solver(rsba_handle* h) {
   if ((rc = s_upload_const(s, &sv.inprog_pose, inprog_pose))) return rc;
   if ((rc = s_upload_const(s, &sv.inprog_point, inprog_point))) return rc;
   if ((rc = s_upload(s, &s->d_obs_slot, obs_slot))) return rc;
-  if ((rc = s_upload(s, &s->d_col_ptr, s->col_ptr))) return rc;
-  if ((rc = s_upload(s, &s->d_col_i, s->col_i))) return rc;
-  if ((rc = s_upload(s, &s->d_trail_i, s->trail_i))) return rc;
-  if ((rc = s_upload(s, &s->d_trail_j, s->trail_j))) return rc;
-  if ((rc = s_upload(s, &s->d_prev_flag, s->prev_flag))) return rc;
-  if ((rc = s_upload(s, &s->d_tile_i, tile_i))) return rc;
-  if ((rc = s_upload(s, &s->d_tile_j, tile_j))) return rc;
+  if ((rc = s_upload_const(s, &sv.blk_dst, blk_dst))) return rc;
+  if ((rc = s_upload(s, &s->d_panel_ptr, s->panel_ptr))) return rc;
+  if ((rc = s_upload(s, &s->d_panel_slot, s->panel_slot))) return rc;
+  if ((rc = s_upload(s, &s->d_panel_row, s->panel_row))) return rc;
+  if ((rc = s_upload(s, &s->d_prev_slot, s->prev_slot))) return rc;
+  if ((rc = s_upload(s, &s->d_trail, s->trail))) return rc;
 
   const size_t REC = 2 + 2 * (size_t)dp.K;
   if ((rc = s_alloc(s, &h->dp.rec, (size_t)N * REC))) return rc;
@@ -242,7 +251,7 @@ int32_t build_solver(rsba_handle* h) {
   if ((rc = s_alloc(s, &sv.Linv, (size_t)M * 6))) return rc;
   if ((rc = s_alloc(s, &sv.z, (size_t)M * 3))) return rc;
   if ((rc = s_alloc(s, &sv.Pm, (size_t)N * CD * 3))) return rc;
-  if ((rc = s_alloc(s, &sv.S, (size_t)sv.npad * sv.ld))) return rc;
+  if ((rc = s_alloc(s, &sv.S, (size_t)sv.nslots * kTile * kTile))) return rc;
   if ((rc = s_alloc(s, &sv.rhs, (size_t)sv.npad))) return rc;
   if ((rc = s_alloc(s, &sv.yp, (size_t)M * 3))) return rc;
   if ((rc = s_alloc(s, &sv.trial_poses, (size_t)F * CD))) return rc;
@@ -281,13 +290,13 @@ int32_t factor_and_solve(rsba_handle* h, double radius) {
   Solver* s = h->solver; const SolverDev& sv = s->sv; hipStream_t st = h->stream;
   HIP_TRY(launch_point_factor(h->dp, sv, radius, st));
   HIP_TRY(launch_project(h->dp, sv, st));
-  HIP_TRY(launch_zero_tiles(sv, s->d_tile_i, s->d_tile_j, s->ntiles, st));
+  HIP_TRY(launch_clear_system(sv, s->last_diag_slot, st));
   HIP_TRY(launch_schur_blocks(h->dp, sv, radius, st));
   for (int k = 0; k < sv.nt; ++k) {
-    const int c0 = s->col_ptr[k], c1 = s->col_ptr[k + 1], u0 = s->trail_ptr[k], u1 = s->trail_ptr[k + 1];
-    HIP_TRY(launch_chol_step(sv, k, 1 + c1 - c0, s->d_col_i + c0, s->d_prev_flag + s->prev_ptr[k], s->d_trail_i + u0, s->d_trail_j + u0, u1 - u0, st));
+    const int p0 = s->panel_ptr[k], p1 = s->panel_ptr[k + 1], u0 = s->trail_ptr[k], u1 = s->trail_ptr[k + 1];
+    HIP_TRY(launch_chol_step(sv, k, p1 - p0, s->d_panel_slot + p0, s->d_prev_slot + p0, s->d_trail + 4 * (size_t)u0, u1 - u0, st));
   }
-  HIP_TRY(launch_chol_backsolve(sv, s->d_col_ptr, s->d_col_i, st));
+  HIP_TRY(launch_chol_backsolve(sv, s->d_panel_ptr, s->d_panel_slot, s->d_panel_row, st));
   HIP_TRY(launch_back_substitute(h->dp, sv, st));
   return RSBA_OK;
 }

@@ -19,8 +19,9 @@ constexpr int kTile = 48;   // Cholesky tile: 4 rolling-shutter frames (12 unkno
 
 struct SolverDev {
   int CD;                       // 6 * P
-  int64_t n, npad, ld;          // camera unknowns F*CD, padded to a multiple of kTile, leading dimension of S
+  int64_t n, npad;              // camera unknowns F*CD, padded to a multiple of kTile
   int nt;                       // npad / kTile
+  int nslots;                   // structurally non-zero tiles of the factor (each kTile*kTile doubles)
   // structure
   const int64_t* frame_ptr;     // [F+1] frame-major observation ranges
   const int64_t* point_ptr;     // [M+1] slot ranges per point
@@ -32,6 +33,7 @@ struct SolverDev {
   const int64_t* blk_ptr;       // [nblk+1] into the pair list
   const int32_t* pair_a;        // slot in frame a
   const int32_t* pair_b;        // slot in frame b (same point)
+  const int64_t* blk_dst;       // [nblk] offset of the block's (0,0) entry inside the packed tile array S
   // numeric
   double* U;                    // [F][CD][CD]
   double* gc;                   // [F][CD]      (scaled) J_c^T r
@@ -42,7 +44,7 @@ struct SolverDev {
   double* Linv;                 // [M][6]  lower-triangular inverse of chol(V')
   double* z;                    // [M][3]
   double* Pm;                   // [N][CD*3]  point-major
-  double* S;                    // [npad][ld] lower triangle used
+  double* S;                    // [nslots][kTile][kTile] packed tiles of the reduced camera system / its factor
   double* rhs;                  // [npad]  -> forward-solved in place -> y_c after the back solve
   double* yp;                   // [M][3]
   double* trial_poses;          // candidate x + delta
@@ -66,7 +68,7 @@ hipError_t launch_clamp_diagonal(const DeviceProblem& dp, const SolverDev& sv, d
 hipError_t launch_gradient_max(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);           // -> scalars[kGradMax]
 hipError_t launch_point_factor(const DeviceProblem& dp, const SolverDev& sv, double radius, hipStream_t st);
 hipError_t launch_project(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);
-hipError_t launch_zero_tiles(const SolverDev& sv, const int32_t* tile_i, const int32_t* tile_j, int ntiles, hipStream_t st);
+hipError_t launch_clear_system(const SolverDev& sv, int last_diag_slot, hipStream_t st);   // S = 0 (+ identity padding), rhs padding = 0
 hipError_t launch_schur_blocks(const DeviceProblem& dp, const SolverDev& sv, double radius, hipStream_t st);
 hipError_t launch_back_substitute(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);
 hipError_t launch_model_cost_change(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);      // -> scalars[kModelCostChange]
