@@ -72,8 +72,15 @@ def main():
 
     sc = make_config(args.config, seed=SEED + rank)      # same cameras on every rank, its own points
     prob = sc.problem
+    if world > 1:
+        # cameras are replicated: every rank starts from rank 0's (perturbed) poses
+        t = torch.from_numpy(prob.poses).cuda()
+        dist.broadcast(t, src=0)
+        prob.poses[:] = t.cpu().numpy()
     dp = capi.DeviceProblem(prob, device=local_rank)
-    dp.set_stream(torch.cuda.current_stream().cuda_stream)
+    if world > 1 and not args.no_lm:
+        from rsba_amd.distributed import attach
+        attach(dp)                                        # RCCL all-reduce exchange for the LM iterations
 
     def barrier():
         if world > 1:

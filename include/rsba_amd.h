@@ -166,6 +166,26 @@ void rsba_default_solver_options(rsba_solver_options* opt);
 int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rsba_solver_summary* summary,
                    rsba_iteration* trace, int32_t trace_capacity);
 
+/* ---- multi-GPU: one process per GPU, observations partitioned BY POINT, cameras replicated ----
+ * (the reference is single-process; this is the exchange step SURVEY §8e derives for the path).
+ * Every rank creates a handle over its own observations (all frames / points arrays are full size, a rank
+ * simply holds no observations of the points it does not own).  Per LM iteration the solver all-reduces
+ *   (1) the per-camera gradient blocks g_c and diag(U)  + cost / failure scalars      [2*F*CD + 3 doubles]
+ *   (2) the packed non-zero tiles of its partial reduced camera system S and its rhs  [nslots*48*48 + F*CD]
+ *   (3) eight step scalars (model decrease, |step|^2, |x|^2, trial cost, failure flags)
+ * through the callback below, which the host implements with RCCL (torch.distributed "nccl" over xGMI).
+ * op: 0 = sum, 1 = max.  The buffer is device memory; the collective must be ordered after prior work
+ * on `hip_stream` and complete (or be stream-ordered) before the callback returns.  Return 0 on success. */
+typedef int32_t (*rsba_allreduce_fn)(void* ctx, double* device_buffer, int64_t count, int32_t op, void* hip_stream);
+int32_t rsba_set_exchange(rsba_handle* h, rsba_allreduce_fn fn, void* ctx, int32_t rank, int32_t world);
+
+/* Structure of the reduced camera system: mask[a*F + b] != 0 (a >= b) iff frames a and b share a point in
+ * THIS rank's observations.  All ranks must install the same (union) structure before the first solve so
+ * that their tile layouts — and therefore exchange buffer (2) — coincide; frame_obs_count [F] likewise
+ * carries the per-frame observation count (summed over ranks before it is set back). */
+int32_t rsba_get_block_structure(rsba_handle* h, uint8_t* mask, int64_t* frame_obs_count);
+int32_t rsba_set_block_structure(rsba_handle* h, const uint8_t* mask, const int64_t* frame_obs_count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,6 +20,7 @@ EXPORTS = [
     "rsba_abi_version", "rsba_status_string", "rsba_last_error", "rsba_device_count", "rsba_create", "rsba_destroy",
     "rsba_set_stream", "rsba_upload_parameters", "rsba_download_parameters", "rsba_evaluate_device", "rsba_evaluate",
     "rsba_get_device_view", "rsba_time_evaluate", "rsba_default_solver_options", "rsba_solve", "rsba_normal_equations",
+    "rsba_set_exchange", "rsba_get_block_structure", "rsba_set_block_structure",
 ]
 
 

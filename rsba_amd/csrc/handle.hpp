@@ -23,6 +23,12 @@ struct rsba_handle {
   std::vector<void*> allocs;
   double* d_cost2 = nullptr;           // {cost, fixed cost}
   rsba::Solver* solver = nullptr;      // normal-equation / Schur / LM state, built on first use
+  // multi-GPU exchange (rsba_set_exchange / rsba_set_block_structure)
+  rsba_allreduce_fn allreduce = nullptr;
+  void* allreduce_ctx = nullptr;
+  int rank = 0, world = 1;
+  std::vector<uint8_t> union_mask;     // [F*F] structure installed by the host, empty = local structure
+  std::vector<int64_t> frame_obs_total;// [F] global observation count per frame
 };
 
 // internal (not exported through the C header)

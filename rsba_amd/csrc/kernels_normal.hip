@@ -103,8 +103,7 @@ __global__ __launch_bounds__(256) void point_blocks_kernel(const DeviceProblem d
 __global__ void jacobi_scale_kernel(const DeviceProblem dp, const SolverDev sv) {
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x, nc = sv.n;
   if (t < nc) {
-    const int f = (int)(t / sv.CD), a = (int)(t % sv.CD);
-    dp.scale_pose[t] *= 1.0 / (1.0 + sqrt(sv.U[((size_t)f * sv.CD + a) * sv.CD + a]));
+    dp.scale_pose[t] *= 1.0 / (1.0 + sqrt(sv.udiag[t]));
   } else if (t < nc + 3 * (int64_t)dp.M) {
     const int64_t u = t - nc; const int j = (int)(u / 3), a = (int)(u % 3);
     const int dg = (a == 0) ? 0 : (a == 1 ? 3 : 5);
@@ -116,8 +115,7 @@ __global__ void jacobi_scale_kernel(const DeviceProblem dp, const SolverDev sv) 
 __global__ void clamp_diagonal_kernel(const DeviceProblem dp, const SolverDev sv, double lo, double hi) {
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x, nc = sv.n;
   if (t < nc) {
-    const int f = (int)(t / sv.CD), a = (int)(t % sv.CD);
-    sv.diag_c[t] = fmin(fmax(sv.U[((size_t)f * sv.CD + a) * sv.CD + a], lo), hi);
+    sv.diag_c[t] = fmin(fmax(sv.udiag[t], lo), hi);
   } else if (t < nc + 3 * (int64_t)dp.M) {
     const int64_t u = t - nc; const int j = (int)(u / 3), a = (int)(u % 3);
     const int dg = (a == 0) ? 0 : (a == 1 ? 3 : 5);
@@ -208,7 +206,7 @@ __global__ __launch_bounds__(256) void project_kernel(const DeviceProblem dp, co
 __global__ void pad_system_kernel(const SolverDev sv, int last_diag_slot) {
   const int r = threadIdx.x;
   const int64_t row = (int64_t)(sv.nt - 1) * kTile + r;
-  if (r < kTile && row >= sv.n) { sv.S[(size_t)last_diag_slot * (kTile * kTile) + r * kTile + r] = 1.0; sv.rhs[row] = 0.0; }
+  if (r < kTile && row >= sv.n) { sv.S[(size_t)last_diag_slot * (kTile * kTile) + r * kTile + r] = sv.lead ? 1.0 : 0.0; sv.rhs[row] = 0.0; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -266,8 +264,8 @@ __global__ __launch_bounds__(256) void schur_blocks_kernel(const DeviceProblem d
     if (diag) {
       const double* urow = sv.U + ((size_t)a * CD + r) * CD;
 #pragma unroll
-      for (int c = 0; c < CD; ++c) srow[c] = urow[c] + (c == r ? sv.diag_c[(size_t)a * CD + r] * inv_radius : 0.0) - acc[c];
-      sv.rhs[(size_t)a * CD + r] = sv.gc[(size_t)a * CD + r] - racc;
+      for (int c = 0; c < CD; ++c) srow[c] = urow[c] + ((c == r && sv.lead) ? sv.diag_c[(size_t)a * CD + r] * inv_radius : 0.0) - acc[c];
+      sv.rhs[(size_t)a * CD + r] = (sv.lead ? sv.gc[(size_t)a * CD + r] : 0.0) - racc;
     } else {
 #pragma unroll
       for (int c = 0; c < CD; ++c) srow[c] = -acc[c];
@@ -353,6 +351,28 @@ __global__ __launch_bounds__(256) void candidate_kernel(const DeviceProblem dp, 
   }
 }
 
+// exchange buffer (1): g_c | diag(U) | cost, fixed cost, failed blocks
+__global__ void pack_linearize_kernel(const DeviceProblem dp, const SolverDev sv, const double* cost2) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t < sv.n) {
+    const int f = (int)(t / sv.CD), a = (int)(t % sv.CD);
+    sv.xbuf[t] = sv.gc[t];
+    sv.xbuf[sv.n + t] = sv.U[((size_t)f * sv.CD + a) * sv.CD + a];
+  }
+  if (t == 0) { sv.xbuf[2 * sv.n] = cost2[0]; sv.xbuf[2 * sv.n + 1] = cost2[1]; sv.xbuf[2 * sv.n + 2] = (double)*dp.fail_count; }
+}
+__global__ void unpack_linearize_kernel(const DeviceProblem dp, const SolverDev sv) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t < sv.n) { sv.gc[t] = sv.xbuf[t]; sv.udiag[t] = sv.xbuf[sv.n + t]; }
+  if (t == 0) { sv.scalars[kCost] = sv.xbuf[2 * sv.n]; sv.scalars[kFixedCost] = sv.xbuf[2 * sv.n + 1]; sv.scalars[kEvalFailed] = sv.xbuf[2 * sv.n + 2]; }
+}
+__global__ void pack_trial_kernel(const DeviceProblem dp, const SolverDev sv, const double* cost2) {
+  sv.scalars[kCost] = cost2[0] + cost2[1];
+  sv.scalars[kFixedCost] = 0.0;
+  sv.scalars[kEvalFailed] = (double)*dp.fail_count;
+  sv.scalars[kSolveFailed] = (double)*sv.chol_fail;
+}
+
 inline int nblocks256(int64_t n) { return (int)((n + 255) / 256); }
 
 }  // namespace
@@ -385,6 +405,18 @@ hipError_t launch_gradient_max(const DeviceProblem& dp, const SolverDev& sv, hip
   const int nb = nblocks256(sv.n + 3 * (int64_t)dp.M);
   LAUNCH(gradient_max_kernel, nb, 256, st, dp, sv);
   LAUNCH(reduce_max_kernel, 1, 256, st, sv.partial, nb, sv.scalars + kGradMax);
+  return hipSuccess;
+}
+hipError_t launch_pack_linearize(const DeviceProblem& dp, const SolverDev& sv, const double* cost2, hipStream_t st) {
+  LAUNCH(pack_linearize_kernel, nblocks256(sv.n), 256, st, dp, sv, cost2);
+  return hipSuccess;
+}
+hipError_t launch_unpack_linearize(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {
+  LAUNCH(unpack_linearize_kernel, nblocks256(sv.n), 256, st, dp, sv);
+  return hipSuccess;
+}
+hipError_t launch_pack_trial(const DeviceProblem& dp, const SolverDev& sv, const double* cost2, hipStream_t st) {
+  LAUNCH(pack_trial_kernel, 1, 1, st, dp, sv, cost2);
   return hipSuccess;
 }
 hipError_t launch_unscaled_gradient(const DeviceProblem& dp, const SolverDev& sv, double* g_pose, double* g_point, hipStream_t st) {

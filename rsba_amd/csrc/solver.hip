@@ -112,6 +112,8 @@ int32_t build_solver(rsba_handle* h) {
     else sparse_cnt[key] += by;
   };
   for (int f = 0; f < F; ++f) bump(f, f, 0);   // every frame owns a diagonal block (it carries U_f + D^2 and rhs_f)
+  if (!h->union_mask.empty())                    // multi-GPU: blocks other ranks fill, so every rank shares one tile layout
+    for (int a = 0; a < F; ++a) for (int b = 0; b <= a; ++b) if (h->union_mask[(size_t)a * F + b]) bump(a, b, 0);
   for (int j = 0; j < M; ++j)
     for (int64_t x = point_ptr[j]; x < point_ptr[j + 1]; ++x)
       for (int64_t y = point_ptr[j]; y <= x; ++y) {
@@ -202,10 +204,13 @@ int32_t build_solver(rsba_handle* h) {
   // and are touched by at least one residual block
   std::vector<double> inprog_pose((size_t)F * CD, 0.0), inprog_point((size_t)M * 3, 0.0);
   int nfree = 0;
+  const bool lead = h->rank == 0;
+  sv.lead = lead;
+  auto frame_has_obs = [&](int f) { return h->frame_obs_total.empty() ? frame_ptr[f + 1] > frame_ptr[f] : h->frame_obs_total[f] > 0; };
   for (int f = 0; f < F; ++f) for (int q = 0; q < dp.P; ++q) {
     bool any_free = false;
     for (int k = 0; k < 6; ++k) any_free = any_free || h->mask_pose[((size_t)f * dp.P + q) * 6 + k] != 0.0;
-    if (any_free && frame_ptr[f + 1] > frame_ptr[f]) for (int k = 0; k < 6; ++k) { inprog_pose[((size_t)f * dp.P + q) * 6 + k] = 1.0; nfree += h->mask_pose[((size_t)f * dp.P + q) * 6 + k] != 0.0; }
+    if (lead && any_free && frame_has_obs(f)) for (int k = 0; k < 6; ++k) { inprog_pose[((size_t)f * dp.P + q) * 6 + k] = 1.0; nfree += h->mask_pose[((size_t)f * dp.P + q) * 6 + k] != 0.0; }
   }
   for (int j = 0; j < M; ++j) if (h->mask_point[(size_t)j * 3] != 0.0 && point_ptr[j + 1] > point_ptr[j]) { for (int k = 0; k < 3; ++k) inprog_point[(size_t)j * 3 + k] = 1.0; nfree += 3; }
   s->num_reduced_params = nfree;
@@ -251,8 +256,10 @@ int32_t build_solver(rsba_handle* h) {
   if ((rc = s_alloc(s, &sv.Linv, (size_t)M * 6))) return rc;
   if ((rc = s_alloc(s, &sv.z, (size_t)M * 3))) return rc;
   if ((rc = s_alloc(s, &sv.Pm, (size_t)N * CD * 3))) return rc;
-  if ((rc = s_alloc(s, &sv.S, (size_t)sv.nslots * kTile * kTile))) return rc;
-  if ((rc = s_alloc(s, &sv.rhs, (size_t)sv.npad))) return rc;
+  if ((rc = s_alloc(s, &sv.S, (size_t)sv.nslots * kTile * kTile + (size_t)sv.npad))) return rc;
+  sv.rhs = sv.S + (size_t)sv.nslots * kTile * kTile;   // one buffer = exchange payload (2)
+  if ((rc = s_alloc(s, &sv.udiag, (size_t)F * CD))) return rc;
+  if ((rc = s_alloc(s, &sv.xbuf, 2 * (size_t)F * CD + 3))) return rc;
   if ((rc = s_alloc(s, &sv.yp, (size_t)M * 3))) return rc;
   if ((rc = s_alloc(s, &sv.trial_poses, (size_t)F * CD))) return rc;
   if ((rc = s_alloc(s, &sv.trial_points, (size_t)M * 3))) return rc;
@@ -275,7 +282,16 @@ int32_t reset_scales(rsba_handle* h) {
   return RSBA_OK;
 }
 
-// r, J (loss-corrected, masked, scaled) and the normal-equation blocks at the current parameters
+// all-reduce across the ranks of a point-partitioned solve (no-op for a single GPU)
+int32_t exchange(rsba_handle* h, double* buf, int64_t count, int op) {
+  if (h->world <= 1 || !h->allreduce) return RSBA_OK;
+  if (h->allreduce(h->allreduce_ctx, buf, count, op, h->stream) != 0) return rsba_set_error(RSBA_ERR_COMM, "all-reduce callback failed");
+  return RSBA_OK;
+}
+
+// r, J (loss-corrected, masked, scaled) and the normal-equation blocks at the current parameters;
+// exchange (1): per-camera gradient blocks + diag(U) + cost scalars.  Results: sv.gc / sv.udiag global,
+// scalars[kCost, kFixedCost, kEvalFailed].
 int32_t linearize(rsba_handle* h) {
   Solver* s = h->solver;
   HIP_TRY(hipMemsetAsync(h->dp.fail_count, 0, sizeof(int), h->stream));
@@ -283,7 +299,17 @@ int32_t linearize(rsba_handle* h) {
   HIP_TRY(launch_cost_reduce(h->dp, h->d_cost2, h->stream));
   HIP_TRY(launch_camera_blocks(h->dp, s->sv, h->stream));
   HIP_TRY(launch_point_blocks(h->dp, s->sv, h->stream));
+  HIP_TRY(launch_pack_linearize(h->dp, s->sv, h->d_cost2, h->stream));
+  int32_t rc = exchange(h, s->sv.xbuf, 2 * s->sv.n + 3, 0);
+  if (rc) return rc;
+  HIP_TRY(launch_unpack_linearize(h->dp, s->sv, h->stream));
   return RSBA_OK;
+}
+
+int32_t gradient_max(rsba_handle* h) {
+  Solver* s = h->solver;
+  HIP_TRY(launch_gradient_max(h->dp, s->sv, h->stream));
+  return exchange(h, s->sv.scalars + kGradMax, 1, 1);
 }
 
 int32_t factor_and_solve(rsba_handle* h, double radius) {
@@ -292,6 +318,8 @@ int32_t factor_and_solve(rsba_handle* h, double radius) {
   HIP_TRY(launch_project(h->dp, sv, st));
   HIP_TRY(launch_clear_system(sv, s->last_diag_slot, st));
   HIP_TRY(launch_schur_blocks(h->dp, sv, radius, st));
+  // exchange (2): partial reduced camera systems -> the full one on every rank (then factored redundantly)
+  { int32_t rc = exchange(h, sv.S, (int64_t)sv.nslots * kTile * kTile + sv.npad, 0); if (rc) return rc; }
   for (int k = 0; k < sv.nt; ++k) {
     const int p0 = s->panel_ptr[k], p1 = s->panel_ptr[k + 1], u0 = s->trail_ptr[k], u1 = s->trail_ptr[k + 1];
     HIP_TRY(launch_chol_step(sv, k, p1 - p0, s->d_panel_slot + p0, s->d_prev_slot + p0, s->d_trail + 4 * (size_t)u0, u1 - u0, st));
@@ -329,6 +357,42 @@ int32_t rsba_gradient(rsba_handle* h, double* g) {
   return RSBA_OK;
 }
 
+extern "C" int32_t rsba_set_exchange(rsba_handle* h, rsba_allreduce_fn fn, void* ctx, int32_t rank, int32_t world) {
+  if (!h || world < 1 || rank < 0 || rank >= world || (world > 1 && !fn)) return rsba_set_error(RSBA_ERR_INVALID_ARGUMENT, "bad exchange arguments");
+  if (h->solver) return rsba_set_error(RSBA_ERR_INVALID_ARGUMENT, "rsba_set_exchange must precede the first solve / gradient call");
+  h->allreduce = fn; h->allreduce_ctx = ctx; h->rank = rank; h->world = world;
+  return RSBA_OK;
+}
+
+extern "C" int32_t rsba_get_block_structure(rsba_handle* h, uint8_t* mask, int64_t* frame_obs_count) {
+  if (!h || !mask) return rsba_set_error(RSBA_ERR_INVALID_ARGUMENT, "null argument");
+  const int F = h->dp.F; const int64_t N = h->dp.N;
+  std::fill(mask, mask + (size_t)F * F, (uint8_t)0);
+  if (frame_obs_count) std::fill(frame_obs_count, frame_obs_count + F, (int64_t)0);
+  // observations grouped by point: frames of one point pairwise share it
+  std::vector<int64_t> ptr((size_t)h->dp.M + 1, 0);
+  for (int64_t i = 0; i < N; ++i) ptr[h->obs_point[i] + 1]++;
+  for (int j = 0; j < h->dp.M; ++j) ptr[j + 1] += ptr[j];
+  std::vector<int32_t> fr(N);
+  { std::vector<int64_t> fill(ptr.begin(), ptr.end() - 1); for (int64_t i = 0; i < N; ++i) fr[fill[h->obs_point[i]]++] = h->obs_frame[i]; }
+  for (int j = 0; j < h->dp.M; ++j)
+    for (int64_t x = ptr[j]; x < ptr[j + 1]; ++x) for (int64_t y = ptr[j]; y <= x; ++y) {
+      const int a = std::max(fr[x], fr[y]), b = std::min(fr[x], fr[y]);
+      mask[(size_t)a * F + b] = 1;
+    }
+  if (frame_obs_count) for (int64_t i = 0; i < N; ++i) frame_obs_count[h->obs_frame[i]]++;
+  return RSBA_OK;
+}
+
+extern "C" int32_t rsba_set_block_structure(rsba_handle* h, const uint8_t* mask, const int64_t* frame_obs_count) {
+  if (!h || !mask) return rsba_set_error(RSBA_ERR_INVALID_ARGUMENT, "null argument");
+  if (h->solver) return rsba_set_error(RSBA_ERR_INVALID_ARGUMENT, "rsba_set_block_structure must precede the first solve / gradient call");
+  const int F = h->dp.F;
+  h->union_mask.assign(mask, mask + (size_t)F * F);
+  if (frame_obs_count) h->frame_obs_total.assign(frame_obs_count, frame_obs_count + F); else h->frame_obs_total.clear();
+  return RSBA_OK;
+}
+
 extern "C" int32_t rsba_normal_equations(rsba_handle* h, double* U, double* gc, double* V, double* gp) {
   if (!h) return rsba_set_error(RSBA_ERR_INVALID_ARGUMENT, "null handle");
   HIP_TRY(hipSetDevice(h->device));
@@ -359,9 +423,17 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
   if (rc) return rc;
   Solver* s = h->solver; SolverDev& sv = s->sv; DeviceProblem& dp = h->dp; hipStream_t st = h->stream;
   sum->termination_type = RSBA_NO_CONVERGENCE;
-  sum->num_residual_blocks = (int32_t)dp.N;
-  sum->num_residual_blocks_reduced = s->num_reduced_blocks;
-  sum->num_parameters_reduced = s->num_reduced_params;
+  {
+    // problem-size figures of the whole (all-rank) problem
+    double cnt[3] = {(double)dp.N, (double)s->num_reduced_blocks, (double)s->num_reduced_params};
+    if (h->world > 1) {
+      HIP_TRY(hipMemcpyAsync(sv.scalars + 8, cnt, sizeof cnt, hipMemcpyHostToDevice, st));
+      if ((rc = exchange(h, sv.scalars + 8, 3, 0))) return rc;
+      HIP_TRY(hipMemcpyAsync(cnt, sv.scalars + 8, sizeof cnt, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+    }
+    sum->num_residual_blocks = (int32_t)cnt[0]; sum->num_residual_blocks_reduced = (int32_t)cnt[1]; sum->num_parameters_reduced = (int32_t)cnt[2];
+  }
   int ntrace = 0;
   auto push = [&](const rsba_iteration& it) {
     if (trace && ntrace < trace_cap) trace[ntrace] = it;
@@ -373,10 +445,9 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
   double host_sc[16]; double cost2[2]; int nfail = 0, cfail = 0;
   auto read_back = [&]() -> int32_t {
     HIP_TRY(hipMemcpyAsync(host_sc, sv.scalars, sizeof host_sc, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(cost2, h->d_cost2, sizeof cost2, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(&nfail, dp.fail_count, sizeof nfail, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(&cfail, sv.chol_fail, sizeof cfail, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    cost2[0] = host_sc[kCost]; cost2[1] = host_sc[kFixedCost];
+    nfail = host_sc[kEvalFailed] != 0.0; cfail = host_sc[kSolveFailed] != 0.0;
     return RSBA_OK;
   };
   auto finish = [&](int32_t term) -> int32_t {
@@ -395,7 +466,7 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
   double t0 = now_s();
   if ((rc = reset_scales(h))) return rc;
   if ((rc = linearize(h))) return rc;
-  HIP_TRY(launch_gradient_max(dp, sv, st));
+  if ((rc = gradient_max(h))) return rc;
   if ((rc = read_back())) return rc;
   sum->residual_jacobian_time_s += now_s() - t0;
   if (nfail) { sum->termination_type = RSBA_FAILURE; (void)finish(RSBA_FAILURE); return rsba_set_error(RSBA_ERR_EVALUATION_FAILED, "initial residual and Jacobian evaluation failed"); }
@@ -432,7 +503,12 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
     HIP_TRY(launch_eval(dp, kResidualOnly, st));
     HIP_TRY(launch_cost_reduce(dp, h->d_cost2, st));
     std::swap(dp.poses, sv.trial_poses); std::swap(dp.points, sv.trial_points);
+    // exchange (3): model decrease, |step|^2, |x|^2, (skip the max slot), trial cost, -, failure flags
+    HIP_TRY(launch_pack_trial(dp, sv, h->d_cost2, st));
+    if ((rc = exchange(h, sv.scalars, 3, 0))) return rc;
+    if ((rc = exchange(h, sv.scalars + kCost, 4, 0))) return rc;
     if ((rc = read_back())) return rc;
+    cost2[1] = 0.0;   // the trial evaluation reports the total in kCost
     sum->linear_solver_time_s += now_s() - t0;
     ++iteration;
     std::memset(&it, 0, sizeof it); it.iteration = iteration;
@@ -461,7 +537,7 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
         std::swap(dp.poses, sv.trial_poses); std::swap(dp.points, sv.trial_points);   // x = x_plus_delta
         t0 = now_s();
         if ((rc = linearize(h))) return rc;
-        HIP_TRY(launch_gradient_max(dp, sv, st));
+        if ((rc = gradient_max(h))) return rc;
         if ((rc = read_back())) return rc;
         sum->residual_jacobian_time_s += now_s() - t0;
         if (nfail) { push(it); (void)finish(RSBA_FAILURE); return rsba_set_error(RSBA_ERR_EVALUATION_FAILED, "residual and Jacobian evaluation failed"); }

@@ -45,7 +45,10 @@ struct SolverDev {
   double* z;                    // [M][3]
   double* Pm;                   // [N][CD*3]  point-major
   double* S;                    // [nslots][kTile][kTile] packed tiles of the reduced camera system / its factor
-  double* rhs;                  // [npad]  -> forward-solved in place -> y_c after the back solve
+  double* rhs;                  // [npad] directly behind S (one exchange buffer) -> z (forward) -> y_c (backward)
+  double* udiag;                // [F*CD] diag(U), global after the exchange
+  double* xbuf;                 // [2*F*CD + 3] exchange buffer: g_c | diag(U) | cost, fixed cost, failed blocks
+  int lead;                     // 1 on the rank that contributes the replicated terms (D_c^2, g_c, camera norms)
   double* yp;                   // [M][3]
   double* trial_poses;          // candidate x + delta
   double* trial_points;
@@ -57,7 +60,7 @@ struct SolverDev {
 };
 
 enum ScalarSlot : int {
-  kModelCostChange = 0, kStepSq = 1, kXSq = 2, kGradMax = 3, kCost = 4, kFixedCost = 5,
+  kModelCostChange = 0, kStepSq = 1, kXSq = 2, kGradMax = 3, kCost = 4, kFixedCost = 5, kEvalFailed = 6, kSolveFailed = 7,
 };
 
 // kernels_normal.hip
@@ -73,6 +76,9 @@ hipError_t launch_schur_blocks(const DeviceProblem& dp, const SolverDev& sv, dou
 hipError_t launch_back_substitute(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);
 hipError_t launch_model_cost_change(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);      // -> scalars[kModelCostChange]
 hipError_t launch_candidate(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);              // trial params, |step|^2, |x|^2
+hipError_t launch_pack_linearize(const DeviceProblem& dp, const SolverDev& sv, const double* cost2, hipStream_t st);
+hipError_t launch_unpack_linearize(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);
+hipError_t launch_pack_trial(const DeviceProblem& dp, const SolverDev& sv, const double* cost2, hipStream_t st);
 hipError_t launch_unscaled_gradient(const DeviceProblem& dp, const SolverDev& sv, double* g_pose, double* g_point, hipStream_t st);
 
 }  // namespace rsba

@@ -1,11 +1,91 @@
 """Multi-GPU driver for the LM solve: one process per GPU, torch.distributed over RCCL.
 
-Observations are partitioned by point (BAProblem.shard); cameras are replicated.  [single-GPU timing
-helper only for now — the exchange step lands with the sharded solve]
+Observations are partitioned BY POINT (BAProblem.shard): every observation of a point lives on one rank,
+so V_j, g_p,j and the point elimination are rank-local; camera parameters are replicated.  Per LM
+iteration the ranks all-reduce (include/rsba_amd.h, "multi-GPU"):
+  (1) per-camera gradient blocks g_c + diag(U) + cost scalars         2*F*CD + 3 doubles
+  (2) the packed non-zero tiles of the partial reduced camera system  nslots*48*48 + F*CD doubles
+  (3) eight step scalars
+and then factor the (identical) reduced system redundantly.  The collective itself is torch.distributed
+("nccl" = RCCL over xGMI on the GPU box); a "gloo" process group is served by staging through the host,
+which is how the exchange logic is tested without several GPUs.
 """
 from __future__ import annotations
 
+import ctypes as C
 import time
+
+import numpy as np
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p)
+
+
+class _DevicePtr:
+    """Minimal __cuda_array_interface__ carrier so torch can view library-owned HBM without a copy."""
+
+    def __init__(self, ptr: int, count: int):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+
+def make_allreduce(group=None):
+    """Build the rsba_allreduce_fn callback over a torch.distributed process group."""
+    import torch
+    import torch.distributed as dist
+
+    backend = dist.get_backend(group)
+
+    def _cb(_ctx, ptr, count, op, _stream):
+        try:
+            # run the collective in the context of the solver's own HIP stream, so it is ordered after the
+            # kernels that produced the buffer and before the ones that consume it
+            with torch.cuda.stream(torch.cuda.ExternalStream(int(_stream))):
+                t = torch.as_tensor(_DevicePtr(int(ptr), int(count)), device="cuda")
+                red = dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX
+                if backend == "nccl":
+                    dist.all_reduce(t, op=red, group=group)      # RCCL over xGMI
+                else:
+                    host = t.cpu()                               # gloo: stage through the host (tests)
+                    dist.all_reduce(host, op=red, group=group)
+                    t.copy_(host)
+                    torch.cuda.current_stream().synchronize()
+            return 0
+        except Exception as e:  # never let an exception cross the C boundary
+            print(f"rsba_amd exchange failed: {e!r}", flush=True)
+            return 1
+
+    return ALLREDUCE_FN(_cb)
+
+
+def union_structure(mask: np.ndarray, counts: np.ndarray, group=None):
+    """All ranks must share one tile layout: OR the per-rank co-visibility masks, sum the frame counts."""
+    import torch
+    import torch.distributed as dist
+
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    m = torch.from_numpy(mask.astype(np.int32)).to(dev)
+    c = torch.from_numpy(counts.astype(np.int64)).to(dev)
+    dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)
+    dist.all_reduce(c, op=dist.ReduceOp.SUM, group=group)
+    return m.cpu().numpy().astype(np.uint8), c.cpu().numpy().astype(np.int64)
+
+
+def attach(dp, group=None):
+    """Install the exchange on a DeviceProblem holding this rank's shard.  Call before the first solve."""
+    import torch
+    import torch.distributed as dist
+    from . import capi
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    F = dp.prob.num_frames
+    mask = np.zeros((F, F), dtype=np.uint8)
+    counts = np.zeros(F, dtype=np.int64)
+    capi._check(capi.lib().rsba_get_block_structure(dp._h, mask.ctypes.data_as(C.c_void_p), counts.ctypes.data_as(C.c_void_p)))
+    mask, counts = union_structure(mask, counts, group)
+    mask, counts = np.ascontiguousarray(mask), np.ascontiguousarray(counts)
+    capi._check(capi.lib().rsba_set_block_structure(dp._h, mask.ctypes.data_as(C.c_void_p), counts.ctypes.data_as(C.c_void_p)))
+    dp._exchange_cb = make_allreduce(group)       # keep the callback object alive as long as the handle
+    capi._check(capi.lib().rsba_set_exchange(dp._h, dp._exchange_cb, None, C.c_int32(rank), C.c_int32(world)))
+    return dp
 
 
 def solve_timed(dp, prob, world: int, iters: int):
@@ -15,11 +95,31 @@ def solve_timed(dp, prob, world: int, iters: int):
     saved = (prob.poses.copy(), prob.points.copy())
     t0 = time.perf_counter()
     s, trace = dp.solve(capi.default_options(max_num_iterations=iters, function_tolerance=0.0, parameter_tolerance=0.0, gradient_tolerance=0.0))
+    wall_first = time.perf_counter() - t0
+    prob.poses[:], prob.points[:] = saved
+    dp.upload_parameters()
+    t0 = time.perf_counter()
+    s, trace = dp.solve(capi.default_options(max_num_iterations=iters, function_tolerance=0.0, parameter_tolerance=0.0, gradient_tolerance=0.0))
     wall = time.perf_counter() - t0
     prob.poses[:], prob.points[:] = saved
     dp.upload_parameters()
     n_it = max(1, s.num_iterations - 1)
-    return {"iterations": n_it, "ms_per_lm_iteration": s.total_time_s / n_it * 1e3, "wall_s": wall,
+    return {"iterations": n_it, "ms_per_lm_iteration": s.total_time_s / n_it * 1e3, "wall_s": wall, "first_solve_wall_s": wall_first,
             "initial_cost": s.initial_cost, "final_cost": s.final_cost,
             "residual_jacobian_s": s.residual_jacobian_time_s, "linear_solver_s": s.linear_solver_time_s,
-            "n_gpus": world, "note": "first solve includes the one-off symbolic phase"}
+            "n_gpus": world, "note": "second solve on the same handle (symbolic phase already done); the first took first_solve_wall_s"}
+
+
+def gather_points(prob, group=None):
+    """After a sharded solve every rank holds the adjusted values of the points it owns (j % world == rank);
+    merge them so each rank ends with the full point array (poses are already identical everywhere)."""
+    import torch
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    owned = (np.arange(prob.num_points) % world) == rank
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    t = torch.from_numpy(np.where(owned[:, None], prob.points, 0.0)).to(dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    prob.points[:] = t.cpu().numpy()
+    return prob

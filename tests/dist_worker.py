@@ -1,0 +1,92 @@
+"""Worker for tests/test_distributed.py, launched by torch.distributed.run with 2 ranks.
+   python -m torch.distributed.run --nproc-per-node 2 ... tests/dist_worker.py <mode> <outdir>
+mode "cpu": host-side exchange logic over gloo, partial blocks from the oracle (no GPU needed)
+mode "gpu": the sharded on-device LM solve, both ranks on GPU 0, exchange staged through gloo"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def scene():
+    from rsba_amd.problem import apply_gauge_masks
+    from rsba_amd.scene import make_scene
+    p = make_scene(16, 700, seed=77).problem
+    apply_gauge_masks(p, fix_first_n_cameras=1)
+    p.pose_fixed_mask[-1, -1] |= 0b111000
+    return p
+
+
+def main():
+    mode, outdir = sys.argv[1], sys.argv[2]
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    full = scene()
+    shard = full.shard(rank, world)
+    out = {"rank": rank, "world": world, "n_full": full.num_observations, "n_shard": shard.num_observations}
+    if mode == "cpu":
+        from oracle import oracle as O
+        from rsba_amd.distributed import union_structure
+        # every observation on exactly one rank; a point's observations never split
+        n = torch.tensor([shard.num_observations]); dist.all_reduce(n); out["n_sum"] = int(n.item())
+        owners = np.zeros(full.num_points, dtype=np.int64); owners[np.unique(shard.obs_point)] = 1
+        t = torch.from_numpy(owners); dist.all_reduce(t); out["max_owners_per_point"] = int(t.max().item())
+        # exchange (1): partial camera blocks add up to the full ones; point blocks are complete on the owner
+        U, gc, V, gp = O.normal_equations(shard)
+        Uf, gcf, Vf, gpf = O.normal_equations(full)
+        tU, tg = torch.from_numpy(U.copy()), torch.from_numpy(gc.copy())
+        dist.all_reduce(tU); dist.all_reduce(tg)
+        out["U_err"] = float(np.abs(tU.numpy() - Uf).max() / np.abs(Uf).max())
+        out["gc_err"] = float(np.abs(tg.numpy() - gcf).max() / np.abs(gcf).max())
+        own = (np.arange(full.num_points) % world) == rank
+        out["V_err"] = float(np.abs(V[own] - Vf[own]).max() / np.abs(Vf).max())
+        out["V_foreign"] = float(np.abs(V[~own]).max())
+        # cost is additive over shards
+        c = torch.tensor([O.evaluate(shard, gradient=False)[1]], dtype=torch.float64); dist.all_reduce(c)
+        out["cost_err"] = abs(float(c.item()) - O.evaluate(full, gradient=False)[1]) / O.evaluate(full, gradient=False)[1]
+        # structure union == structure of the whole problem
+        def structure(p):
+            F = p.num_frames; m = np.zeros((F, F), dtype=np.uint8); cnt = np.bincount(p.obs_frame, minlength=F).astype(np.int64)
+            for j in np.unique(p.obs_point):
+                fr = p.obs_frame[p.obs_point == j]
+                a, b = np.meshgrid(fr, fr, indexing="ij"); m[np.maximum(a, b), np.minimum(a, b)] = 1
+            return m, cnt
+        m, cnt = structure(shard)
+        mu, cu = union_structure(m, cnt)
+        mf, cf = structure(full)
+        out["mask_equal"] = bool(np.array_equal(mu, mf)); out["count_equal"] = bool(np.array_equal(cu, cf))
+    else:
+        from rsba_amd import capi
+        from rsba_amd.distributed import attach, gather_points
+        torch.cuda.set_device(0)
+        opts = dict(max_num_iterations=15)
+        dp = capi.DeviceProblem(shard, device=0)
+        attach(dp)
+        s, tr = dp.solve(capi.default_options(**opts))
+        dp.close()
+        gather_points(shard)
+        out.update(final_cost=s.final_cost, initial_cost=s.initial_cost, iters=s.num_iterations, reduced=s.num_residual_blocks_reduced,
+                   params=s.num_parameters_reduced, term=s.termination_type)
+        if rank == 0:
+            ref = full.copy()
+            with capi.DeviceProblem(ref) as d1:
+                s1, tr1 = d1.solve(capi.default_options(**opts))
+            out.update(ref_final=s1.final_cost, ref_initial=s1.initial_cost, ref_iters=s1.num_iterations, ref_reduced=s1.num_residual_blocks_reduced,
+                       ref_params=s1.num_parameters_reduced, pose_err=float(np.abs(ref.poses - shard.poses).max()),
+                       point_err=float(np.abs(ref.points - shard.points).max()),
+                       traj_err=float(max(abs(a.cost - b.cost) / b.cost for a, b in zip(tr, tr1))))
+    with open(os.path.join(outdir, f"rank{rank}.json"), "w") as f:
+        json.dump(out, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
