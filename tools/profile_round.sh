@@ -1,0 +1,36 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): collects this round's evidence into gpurun_out/$1/ (default r01).
+#   kernel-trace stats of the bench command, FETCH_SIZE and WRITE_SIZE in separate --pmc passes
+#   (never combined with tracing), the HBM stream calibration, and the bench line itself.
+R=${1:-r01}
+OUT=gpurun_out/$R
+mkdir -p $OUT
+export TMPDIR=/tmp
+B="python bench.py --steps 30 --warmup 5 --no-cpu-baseline --lm-iters 6"
+python bench.py --steps 50 --warmup 5 --lm-iters 8 > $OUT/bench.json 2> $OUT/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $B > $OUT/trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o f -- $B --no-lm > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o w -- $B --no-lm > $OUT/pmc_write.log 2>&1
+./tools/hbm_calib > $OUT/hbm_calib.txt 2>&1
+python - "$OUT" <<'PY'
+import collections, csv, json, sys
+out = sys.argv[1]
+def mean_counter(path, counter, kernel_sub):
+    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter and kernel_sub in r["Kernel_Name"]]
+    return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
+k = "eval_kernel<true, 2, 1>"
+f, nf = mean_counter(f"{out}/pmc_fetch/f_counter_collection.csv", "FETCH_SIZE", k)
+w, nw = mean_counter(f"{out}/pmc_write/w_counter_collection.csv", "WRITE_SIZE", k)
+stats = {r["Name"]: r for r in csv.DictReader(open(f"{out}/trace/t_kernel_stats.csv"))}
+avg_ns = next((float(v["AverageNs"]) for n, v in stats.items() if k in n), None)
+summary = {"kernel": "rsba::" + k, "launches_fetch": nf, "launches_write": nw,
+           "FETCH_SIZE_KB_per_launch": f, "WRITE_SIZE_KB_per_launch": w,
+           "note": "gfx950 calibration (tools/hbm_calib.hip under the same counters): FETCH_SIZE reads 0.500x of coalesced read streams, WRITE_SIZE 1.000x",
+           "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0 if f and w else None,
+           "rocprof_avg_kernel_ns": avg_ns}
+json.dump(summary, open(f"{out}/pmc_summary.json", "w"), indent=1)
+print(json.dumps(summary))
+PY
+cp $OUT/trace/t_kernel_stats.csv $OUT/kernel_stats.csv
+rm -rf $OUT/trace/t_kernel_trace.csv
+cat $OUT/bench.json
