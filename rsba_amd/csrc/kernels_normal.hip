@@ -179,26 +179,57 @@ __global__ __launch_bounds__(256) void point_factor_kernel(const DeviceProblem d
 }
 
 // K5b  per observation (point-major): P = Jc^T (Jp L^-T)   (CD x 3)
-template <int CD>
+// One wave = 64 consecutive slots.  Records and results are moved between HBM and LDS with fully
+// coalesced 512-B wave accesses (a lane-per-record global access pattern touches 64 cache lines per
+// instruction and ran 4x slower); each lane then works on its own record out of LDS (odd pitch: no
+// bank conflicts).
+template <int CD, int KC>
 __global__ __launch_bounds__(256) void project_kernel(const DeviceProblem dp, const SolverDev sv) {
-  const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (s >= dp.N) return;
-  const int REC = 2 + 2 * dp.K, KC = dp.K - 3, off = KC - CD;   // off = 9 when intrinsics columns precede the pose
-  const double* rec = dp.rec + (size_t)s * REC;
-  const double* li = sv.Linv + (size_t)sv.slot_point[s] * 6;
-  const double i00 = li[0], i10 = li[1], i11 = li[2], i20 = li[3], i21 = li[4], i22 = li[5];
-  double B[2][3];
-#pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const double p0 = rec[2 + 3 * r], p1 = rec[3 + 3 * r], p2 = rec[4 + 3 * r];
-    B[r][0] = p0 * i00; B[r][1] = p0 * i10 + p1 * i11; B[r][2] = p0 * i20 + p1 * i21 + p2 * i22;
+  constexpr int REC = 8 + 2 * KC, OUT = CD * 3;
+  constexpr int PITCH = (REC > OUT ? REC : OUT) | 1;          // odd
+  constexpr int off = KC - CD;                                  // 9 when intrinsics columns precede the pose
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* buf = smem + (size_t)wave * 64 * PITCH;
+  const int64_t s0 = ((int64_t)blockIdx.x * 4 + wave) * 64;
+  if (s0 >= dp.N) return;
+  const int64_t nslot = (dp.N - s0 < 64) ? dp.N - s0 : 64;
+  const double* src = dp.rec + (size_t)s0 * REC;
+#pragma unroll 4
+  for (int k = 0; k < REC; ++k) {
+    const int idx = k * 64 + lane;
+    if (idx < nslot * REC) buf[(idx / REC) * PITCH + idx % REC] = src[idx];
   }
-  double* out = sv.Pm + (size_t)s * (CD * 3);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  double out[OUT];
+  if (lane < nslot) {
+    const double* rec = buf + lane * PITCH;
+    const double* li = sv.Linv + (size_t)sv.slot_point[s0 + lane] * 6;
+    const double i00 = li[0], i10 = li[1], i11 = li[2], i20 = li[3], i21 = li[4], i22 = li[5];
+    double B[2][3];
 #pragma unroll
-  for (int a = 0; a < CD; ++a) {
-    const double c0 = rec[8 + off + a], c1 = rec[8 + KC + off + a];
+    for (int r = 0; r < 2; ++r) {
+      const double p0 = rec[2 + 3 * r], p1 = rec[3 + 3 * r], p2 = rec[4 + 3 * r];
+      B[r][0] = p0 * i00; B[r][1] = p0 * i10 + p1 * i11; B[r][2] = p0 * i20 + p1 * i21 + p2 * i22;
+    }
 #pragma unroll
-    for (int k = 0; k < 3; ++k) out[a * 3 + k] = c0 * B[0][k] + c1 * B[1][k];
+    for (int a = 0; a < CD; ++a) {
+      const double c0 = rec[8 + off + a], c1 = rec[8 + KC + off + a];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) out[a * 3 + k] = c0 * B[0][k] + c1 * B[1][k];
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (lane < nslot) {
+#pragma unroll
+    for (int e = 0; e < OUT; ++e) buf[lane * PITCH + e] = out[e];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  double* dst = sv.Pm + (size_t)s0 * OUT;
+#pragma unroll 4
+  for (int k = 0; k < OUT; ++k) {
+    const int idx = k * 64 + lane;
+    if (idx < nslot * OUT) dst[idx] = buf[(idx / OUT) * PITCH + idx % OUT];
   }
 }
 
@@ -216,17 +247,35 @@ __global__ void pad_system_kernel(const SolverDev sv, int last_diag_slot) {
 // P_o' is read with wave-wide broadcast addresses (12 lanes share each address).  The per-block pair
 // lists come from the symbolic phase, so there are no atomics and the summation order is fixed.
 // ---------------------------------------------------------------------------------------------
+// final value of row r of block blk:  S_ab = [a==b](U_a + D_c^2) - acc ;  rhs_a = g_a - racc
+template <int CD>
+__device__ __forceinline__ void schur_store_row(const SolverDev& sv, int blk, int r, const double* acc, double racc, double inv_radius) {
+  const int a = sv.blk_a[blk], b = sv.blk_b[blk];
+  double* srow = sv.S + sv.blk_dst[blk] + (size_t)r * kTile;
+  if (a == b) {
+    const double* urow = sv.U + ((size_t)a * CD + r) * CD;
+#pragma unroll
+    for (int c = 0; c < CD; ++c) srow[c] = urow[c] + ((c == r && sv.lead) ? sv.diag_c[(size_t)a * CD + r] * inv_radius : 0.0) - acc[c];
+    sv.rhs[(size_t)a * CD + r] = (sv.lead ? sv.gc[(size_t)a * CD + r] : 0.0) - racc;
+  } else {
+#pragma unroll
+    for (int c = 0; c < CD; ++c) srow[c] = -acc[c];
+  }
+}
+
 template <int CD>
 __global__ __launch_bounds__(256) void schur_blocks_kernel(const DeviceProblem dp, const SolverDev sv, double inv_radius) {
   constexpr int NG = 60 / CD;
   const int lane = threadIdx.x & 63;
-  const int blk = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (blk >= sv.nblk) return;
+  const int chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (chunk >= sv.nchunk) return;
   const int q = lane / CD, r = lane % CD;
   const bool active = q < NG;
-  const int a = sv.blk_a[blk], b = sv.blk_b[blk];
-  const bool diag = a == b;
-  const int64_t p0 = sv.blk_ptr[blk], p1 = sv.blk_ptr[blk + 1];
+  const int blk = sv.chunk_blk[chunk];
+  const bool diag = sv.blk_a[blk] == sv.blk_b[blk];
+  const int64_t p0 = sv.chunk_p0[chunk];
+  const int64_t pend = sv.blk_ptr[blk + 1];
+  const int64_t p1 = (p0 + kSchurChunk < pend) ? p0 + kSchurChunk : pend;
   double acc[CD], racc = 0.0;
 #pragma unroll
   for (int c = 0; c < CD; ++c) acc[c] = 0.0;
@@ -235,10 +284,13 @@ __global__ __launch_bounds__(256) void schur_blocks_kernel(const DeviceProblem d
     if (active && p < p1) {
       const int sa = sv.pair_a[p], sb = sv.pair_b[p];
       const double* pa = sv.Pm + (size_t)sa * (CD * 3) + r * 3;
-      const double* pb = sv.Pm + (size_t)sb * (CD * 3);
+      const double2* pb = reinterpret_cast<const double2*>(sv.Pm + (size_t)sb * (CD * 3));   // records are 16-B aligned
       const double x0 = pa[0], x1 = pa[1], x2 = pa[2];
+      double w[CD * 3];
 #pragma unroll
-      for (int c = 0; c < CD; ++c) acc[c] += x0 * pb[c * 3] + x1 * pb[c * 3 + 1] + x2 * pb[c * 3 + 2];
+      for (int k = 0; k < CD * 3 / 2; ++k) { const double2 v = pb[k]; w[2 * k] = v.x; w[2 * k + 1] = v.y; }
+#pragma unroll
+      for (int c = 0; c < CD; ++c) acc[c] += x0 * w[c * 3] + x1 * w[c * 3 + 1] + x2 * w[c * 3 + 2];
       if (diag && sa == sb) {
         const double* z = sv.z + (size_t)sv.slot_point[sa] * 3;
         racc += x0 * z[0] + x1 * z[1] + x2 * z[2];
@@ -260,17 +312,36 @@ __global__ __launch_bounds__(256) void schur_blocks_kernel(const DeviceProblem d
     racc = t;
   }
   if (q == 0) {
-    double* srow = sv.S + sv.blk_dst[blk] + (size_t)r * kTile;
-    if (diag) {
-      const double* urow = sv.U + ((size_t)a * CD + r) * CD;
+    const bool single = p0 == sv.blk_ptr[blk] && p1 == pend;
+    if (single) schur_store_row<CD>(sv, blk, r, acc, racc, inv_radius);
+    else {
+      // a block split over several chunks: partial rows to scratch, summed in order by schur_merge_kernel
+      double* part = sv.schur_part + (size_t)chunk * (CD * (CD + 1)) + (size_t)r * (CD + 1);
 #pragma unroll
-      for (int c = 0; c < CD; ++c) srow[c] = urow[c] + ((c == r && sv.lead) ? sv.diag_c[(size_t)a * CD + r] * inv_radius : 0.0) - acc[c];
-      sv.rhs[(size_t)a * CD + r] = (sv.lead ? sv.gc[(size_t)a * CD + r] : 0.0) - racc;
-    } else {
-#pragma unroll
-      for (int c = 0; c < CD; ++c) srow[c] = -acc[c];
+      for (int c = 0; c < CD; ++c) part[c] = acc[c];
+      part[CD] = racc;
     }
   }
+}
+
+// blocks whose pair list was split: sum the chunk partials in chunk order (fixed), then the final store
+template <int CD>
+__global__ __launch_bounds__(256) void schur_merge_kernel(const DeviceProblem dp, const SolverDev sv, double inv_radius) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int m = t / CD, r = t % CD;
+  if (m >= sv.nmulti) return;
+  const int c0 = sv.multi_first[2 * m], c1 = sv.multi_first[2 * m + 1];
+  const int blk = sv.chunk_blk[c0];
+  double acc[CD], racc = 0.0;
+#pragma unroll
+  for (int c = 0; c < CD; ++c) acc[c] = 0.0;
+  for (int ch = c0; ch < c1; ++ch) {
+    const double* part = sv.schur_part + (size_t)ch * (CD * (CD + 1)) + (size_t)r * (CD + 1);
+#pragma unroll
+    for (int c = 0; c < CD; ++c) acc[c] += part[c];
+    racc += part[CD];
+  }
+  schur_store_row<CD>(sv, blk, r, acc, racc, inv_radius);
 }
 
 // K7  back-substitution  y_p = L^-T ( z - sum_o P_o^T y_c(frame(o)) )
@@ -429,9 +500,21 @@ hipError_t launch_point_factor(const DeviceProblem& dp, const SolverDev& sv, dou
 }
 hipError_t launch_project(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {
   if (dp.N == 0) return hipSuccess;
-  if (sv.CD == 12) LAUNCH(project_kernel<12>, nblocks256(dp.N), 256, st, dp, sv);
-  else LAUNCH(project_kernel<6>, nblocks256(dp.N), 256, st, dp, sv);
-  return hipSuccess;
+  const int grid = (int)((dp.N + 255) / 256);
+  const int KC = dp.K - 3;
+  auto lds_of = [](int rec, int out) { return (size_t)4 * 64 * (((rec > out ? rec : out)) | 1) * sizeof(double); };
+  if (sv.CD == 12 && KC == 12) {
+    static bool configured = false;   // 74 KB of dynamic LDS: above the 64 KB default cap
+    if (!configured) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(project_kernel<12, 12>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(32, 36));
+      if (e != hipSuccess) return e;
+      configured = true;
+    }
+    hipLaunchKernelGGL((project_kernel<12, 12>), dim3(grid), dim3(256), lds_of(32, 36), st, dp, sv);
+  }
+  else if (sv.CD == 6 && KC == 6) hipLaunchKernelGGL((project_kernel<6, 6>), dim3(grid), dim3(256), lds_of(20, 18), st, dp, sv);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
 }
 hipError_t launch_clear_system(const SolverDev& sv, int last_diag_slot, hipStream_t st) {
   hipError_t e = hipMemsetAsync(sv.S, 0, (size_t)sv.nslots * kTile * kTile * sizeof(double), st);
@@ -440,9 +523,14 @@ hipError_t launch_clear_system(const SolverDev& sv, int last_diag_slot, hipStrea
   return hipSuccess;
 }
 hipError_t launch_schur_blocks(const DeviceProblem& dp, const SolverDev& sv, double radius, hipStream_t st) {
-  const int grid = (sv.nblk + 3) / 4;
+  const int grid = (sv.nchunk + 3) / 4;
   if (sv.CD == 12) LAUNCH(schur_blocks_kernel<12>, grid, 256, st, dp, sv, 1.0 / radius);
   else LAUNCH(schur_blocks_kernel<6>, grid, 256, st, dp, sv, 1.0 / radius);
+  if (sv.nmulti > 0) {
+    const int g2 = nblocks256((int64_t)sv.nmulti * sv.CD);
+    if (sv.CD == 12) LAUNCH(schur_merge_kernel<12>, g2, 256, st, dp, sv, 1.0 / radius);
+    else LAUNCH(schur_merge_kernel<6>, g2, 256, st, dp, sv, 1.0 / radius);
+  }
   return hipSuccess;
 }
 hipError_t launch_back_substitute(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {

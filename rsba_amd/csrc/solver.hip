@@ -194,6 +194,17 @@ int32_t build_solver(rsba_handle* h) {
       }
     s->trail_ptr.push_back((int32_t)(s->trail.size() / 4));
   }
+  // chunks of the pair lists; blocks cut into more than one chunk are merged in a second pass
+  std::vector<int32_t> chunk_blk, multi_first; std::vector<int64_t> chunk_p0;
+  for (size_t bidx = 0; bidx < blk_a.size(); ++bidx) {
+    const int64_t b0 = blk_ptr[bidx], b1 = blk_ptr[bidx + 1];
+    const int32_t first = (int32_t)chunk_blk.size();
+    int64_t q0 = b0;
+    do { chunk_blk.push_back((int32_t)bidx); chunk_p0.push_back(q0); q0 += kSchurChunk; } while (q0 < b1);
+    const int32_t end_ = (int32_t)chunk_blk.size();
+    if (end_ - first > 1) { multi_first.push_back(first); multi_first.push_back(end_); }
+  }
+  sv.nchunk = (int)chunk_blk.size(); sv.nmulti = (int)(multi_first.size() / 2);
   std::vector<int64_t> blk_dst(blk_a.size());
   for (size_t bidx = 0; bidx < blk_a.size(); ++bidx) {
     const int a = blk_a[bidx], b = blk_b[bidx];
@@ -238,6 +249,10 @@ int32_t build_solver(rsba_handle* h) {
   if ((rc = s_upload_const(s, &sv.inprog_point, inprog_point))) return rc;
   if ((rc = s_upload(s, &s->d_obs_slot, obs_slot))) return rc;
   if ((rc = s_upload_const(s, &sv.blk_dst, blk_dst))) return rc;
+  if ((rc = s_upload_const(s, &sv.chunk_blk, chunk_blk))) return rc;
+  if ((rc = s_upload_const(s, &sv.chunk_p0, chunk_p0))) return rc;
+  if ((rc = s_upload_const(s, &sv.multi_first, multi_first))) return rc;
+  if ((rc = s_alloc(s, &sv.schur_part, (size_t)sv.nchunk * CD * (CD + 1)))) return rc;
   if ((rc = s_upload(s, &s->d_panel_ptr, s->panel_ptr))) return rc;
   if ((rc = s_upload(s, &s->d_panel_slot, s->panel_slot))) return rc;
   if ((rc = s_upload(s, &s->d_panel_row, s->panel_row))) return rc;

@@ -15,6 +15,7 @@
 
 namespace rsba {
 
+constexpr int kSchurChunk = 240;   // pairs per wave of the Schur kernel (multiple of the 5 / 10 pair slots)
 constexpr int kTile = 48;   // Cholesky tile: 4 rolling-shutter frames (12 unknowns) or 8 global-shutter frames
 
 struct SolverDev {
@@ -34,6 +35,13 @@ struct SolverDev {
   const int32_t* pair_a;        // slot in frame a
   const int32_t* pair_b;        // slot in frame b (same point)
   const int64_t* blk_dst;       // [nblk] offset of the block's (0,0) entry inside the packed tile array S
+  // pair lists cut into chunks of kSchurChunk so no wave walks a 2000-pair diagonal block alone
+  int nchunk;
+  const int32_t* chunk_blk;     // [nchunk]
+  const int64_t* chunk_p0;      // [nchunk] first pair of the chunk
+  int nmulti;                   // blocks split over >1 chunk
+  const int32_t* multi_first;   // [nmulti][2] first / end chunk of each such block (its chunks are consecutive)
+  double* schur_part;           // [nchunk][CD][CD+1] partial rows of split blocks
   // numeric
   double* U;                    // [F][CD][CD]
   double* gc;                   // [F][CD]      (scaled) J_c^T r
