@@ -25,6 +25,25 @@ __device__ __forceinline__ double wmax(double v) {
   return v;
 }
 
+// Camera-side coordinate t in [0, Fx*CD): the real pose coordinates, then the intrinsics pseudo frames
+// (9 coordinates + zero-scaled padding) when the intrinsics are a parameter block.
+__device__ __forceinline__ double* cam_scale_ptr(const DeviceProblem& dp, const SolverDev& sv, int64_t t) {
+  const int64_t npose = (int64_t)sv.F * sv.CD;
+  if (t < npose) return dp.scale_pose + t;
+  return (t - npose < 9) ? dp.scale_intr + (t - npose) : nullptr;
+}
+__device__ __forceinline__ double cam_scale(const DeviceProblem& dp, const SolverDev& sv, int64_t t) {
+  const double* p = cam_scale_ptr(dp, sv, t);
+  return p ? *p : 0.0;
+}
+__device__ __forceinline__ size_t u_cross_off(const SolverDev& sv, int v, int f) { return ((size_t)sv.F + (size_t)v * sv.F + f) * sv.CD * sv.CD; }
+__device__ __forceinline__ size_t u_self_off(const SolverDev& sv, int v, int w) { return ((size_t)sv.F + (size_t)sv.NPF * sv.F + (size_t)v * sv.NPF + w) * sv.CD * sv.CD; }
+__device__ __forceinline__ double u_diag(const SolverDev& sv, int64_t t) {
+  const int f = (int)(t / sv.CD), a = (int)(t % sv.CD);
+  const size_t base = f < sv.F ? (size_t)f * sv.CD * sv.CD : u_self_off(sv, f - sv.F, f - sv.F);
+  return sv.U[base + (size_t)a * sv.CD + a];
+}
+
 // ---------------------------------------------------------------------------------------------
 // K2a  per-frame camera block  U_f = sum Jc^T Jc,  g_f = sum Jc^T r   (frame-major tiles, coalesced)
 // One workgroup per frame; every lane keeps the CD(CD+1)/2 + CD running sums of its strided
@@ -76,6 +95,135 @@ __global__ __launch_bounds__(256) void camera_blocks_kernel(const DeviceProblem 
 }
 
 // ---------------------------------------------------------------------------------------------
+// K2a' intrinsics as a parameter block: the J^T J blocks that are NOT block-diagonal.
+//   cross: U[F+v][f] rows = intrinsics coordinates of pseudo frame v, cols = pose coordinates of frame f
+//   self : per-frame partials of Ji^T Ji (45 unique) and Ji^T r (9), summed over frames in order
+// Same register-accumulate + fixed-order reduction scheme as camera_blocks_kernel; the 9 x CD cross block
+// is produced NR intrinsics rows at a time to stay inside the register file.
+// ---------------------------------------------------------------------------------------------
+template <int CD, int R0, int NR>
+__global__ __launch_bounds__(256) void intr_cross_kernel(const DeviceProblem dp, const SolverDev sv) {
+  constexpr int NE = NR * CD;
+  __shared__ double s_red[4][NE];
+  const int f = blockIdx.x, tid = threadIdx.x;
+  const int K = dp.K;
+  const int64_t s = sv.frame_ptr[f], e = sv.frame_ptr[f + 1];
+  double acc[NE];
+#pragma unroll
+  for (int k = 0; k < NE; ++k) acc[k] = 0.0;
+  for (int64_t i = s + tid; i < e; i += 256) {
+    const double* jt = dp.jac + (size_t)(i >> 8) * (2 * K * kEvalBlock) + (i & 255);
+    double i0[NR], i1[NR], c0[CD], c1[CD];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) { i0[k] = jt[(R0 + k) * kEvalBlock]; i1[k] = jt[(K + R0 + k) * kEvalBlock]; }
+#pragma unroll
+    for (int c = 0; c < CD; ++c) { c0[c] = jt[(9 + c) * kEvalBlock]; c1[c] = jt[(K + 9 + c) * kEvalBlock]; }
+#pragma unroll
+    for (int k = 0; k < NR; ++k)
+#pragma unroll
+      for (int c = 0; c < CD; ++c) acc[k * CD + c] += i0[k] * c0[c] + i1[k] * c1[c];
+  }
+#pragma unroll
+  for (int k = 0; k < NE; ++k) {
+    const double v = wsum(acc[k]);
+    if ((tid & 63) == 0) s_red[tid >> 6][k] = v;
+  }
+  __syncthreads();
+  if (tid < NE) {
+    const int kk = R0 + tid / CD, c = tid % CD;
+    sv.U[u_cross_off(sv, kk / CD, f) + (size_t)(kk % CD) * CD + c] = s_red[0][tid] + s_red[1][tid] + s_red[2][tid] + s_red[3][tid];
+  }
+}
+
+__global__ __launch_bounds__(256) void intr_self_kernel(const DeviceProblem dp, const SolverDev sv) {
+  constexpr int NE = 45 + 9;
+  __shared__ double s_red[4][NE];
+  const int f = blockIdx.x, tid = threadIdx.x;
+  const int K = dp.K;
+  const int64_t s = sv.frame_ptr[f], e = sv.frame_ptr[f + 1];
+  double acc[NE];
+#pragma unroll
+  for (int k = 0; k < NE; ++k) acc[k] = 0.0;
+  for (int64_t i = s + tid; i < e; i += 256) {
+    const double* jt = dp.jac + (size_t)(i >> 8) * (2 * K * kEvalBlock) + (i & 255);
+    const double* rt = dp.res + (size_t)(i >> 8) * (2 * kEvalBlock) + (i & 255);
+    double i0[9], i1[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { i0[k] = jt[k * kEvalBlock]; i1[k] = jt[(K + k) * kEvalBlock]; }
+    const double r0 = rt[0], r1 = rt[kEvalBlock];
+    int idx = 0;
+#pragma unroll
+    for (int a = 0; a < 9; ++a)
+#pragma unroll
+      for (int b = a; b < 9; ++b) { acc[idx] += i0[a] * i0[b] + i1[a] * i1[b]; ++idx; }
+#pragma unroll
+    for (int a = 0; a < 9; ++a) acc[45 + a] += i0[a] * r0 + i1[a] * r1;
+  }
+#pragma unroll
+  for (int k = 0; k < NE; ++k) {
+    const double v = wsum(acc[k]);
+    if ((tid & 63) == 0) s_red[tid >> 6][k] = v;
+  }
+  __syncthreads();
+  if (tid < NE) sv.intr_part[(size_t)f * NE + tid] = s_red[0][tid] + s_red[1][tid] + s_red[2][tid] + s_red[3][tid];
+}
+
+__global__ void intr_reduce_kernel(const DeviceProblem dp, const SolverDev sv) {
+  const int t = threadIdx.x;
+  if (t >= 54) return;
+  double v = 0.0;
+  for (int f = 0; f < sv.F; ++f) v += sv.intr_part[(size_t)f * 54 + t];
+  const int CD = sv.CD;
+  if (t >= 45) { sv.gc[(size_t)sv.F * CD + (t - 45)] = v; return; }
+  int a = 0, rem = t;
+  while (rem >= 9 - a) { rem -= 9 - a; ++a; }
+  const int b = a + rem;
+  sv.U[u_self_off(sv, a / CD, b / CD) + (size_t)(a % CD) * CD + (b % CD)] = v;
+  sv.U[u_self_off(sv, b / CD, a / CD) + (size_t)(b % CD) * CD + (a % CD)] = v;
+}
+
+// virtual observation records of the pseudo frames: Q_j = sum_o Ji_o^T (Jp_o L_j^-T)   (9 x 3 per point)
+template <int CD>
+__global__ __launch_bounds__(256) void virtual_records_kernel(const DeviceProblem dp, const SolverDev sv) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= dp.M) return;
+  const int REC = 2 + 2 * dp.K, KC = dp.K - 3;
+  const double* li = sv.Linv + (size_t)j * 6;
+  const double i00 = li[0], i10 = li[1], i11 = li[2], i20 = li[3], i21 = li[4], i22 = li[5];
+  double Q[9][3];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { Q[k][0] = 0.0; Q[k][1] = 0.0; Q[k][2] = 0.0; }
+  for (int64_t s = sv.point_ptr[j]; s < sv.point_ptr[j + 1]; ++s) {
+    const double* rec = dp.rec + (size_t)s * REC;
+    double B[2][3];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const double p0 = rec[2 + 3 * r], p1 = rec[3 + 3 * r], p2 = rec[4 + 3 * r];
+      B[r][0] = p0 * i00; B[r][1] = p0 * i10 + p1 * i11; B[r][2] = p0 * i20 + p1 * i21 + p2 * i22;
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const double a0 = rec[8 + k], a1 = rec[8 + KC + k];
+#pragma unroll
+      for (int m = 0; m < 3; ++m) Q[k][m] += a0 * B[0][m] + a1 * B[1][m];
+    }
+  }
+  double* out = sv.Pm + ((size_t)dp.N + (size_t)j * sv.NPF) * (CD * 3);
+  for (int v = 0; v < sv.NPF; ++v)
+#pragma unroll
+    for (int rl = 0; rl < CD; ++rl) {
+      const int k = v * CD + rl;
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        double q = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < 9; ++kk) if (kk == k) q = Q[kk][m];
+        out[(size_t)v * (CD * 3) + rl * 3 + m] = q;
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // K2b  per-point block  V_j = sum Jp^T Jp (6 unique),  g_p,j = sum Jp^T r   (point-major records)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void point_blocks_kernel(const DeviceProblem dp, const SolverDev sv) {
@@ -103,7 +251,8 @@ __global__ __launch_bounds__(256) void point_blocks_kernel(const DeviceProblem d
 __global__ void jacobi_scale_kernel(const DeviceProblem dp, const SolverDev sv) {
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x, nc = sv.n;
   if (t < nc) {
-    dp.scale_pose[t] *= 1.0 / (1.0 + sqrt(sv.udiag[t]));
+    double* sp = cam_scale_ptr(dp, sv, t);
+    if (sp) *sp *= 1.0 / (1.0 + sqrt(sv.udiag[t]));
   } else if (t < nc + 3 * (int64_t)dp.M) {
     const int64_t u = t - nc; const int j = (int)(u / 3), a = (int)(u % 3);
     const int dg = (a == 0) ? 0 : (a == 1 ? 3 : 5);
@@ -130,7 +279,7 @@ __global__ __launch_bounds__(256) void gradient_max_kernel(const DeviceProblem d
   const int64_t nc = sv.n, np = 3 * (int64_t)dp.M;
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (t < nc + np) {
-    const double sc = (t < nc) ? dp.scale_pose[t] : dp.scale_point[t - nc];
+    const double sc = (t < nc) ? cam_scale(dp, sv, t) : dp.scale_point[t - nc];
     const double g = (t < nc) ? sv.gc[t] : sv.gp[t - nc];
     if (sc > 0.0) m = fabs(g / sc);
   }
@@ -151,7 +300,7 @@ __global__ __launch_bounds__(256) void reduce_max_kernel(const double* partial, 
 
 __global__ void unscaled_gradient_kernel(const DeviceProblem dp, const SolverDev sv, double* g_pose, double* g_point) {
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x, nc = sv.n;
-  if (t < nc) { const double sc = dp.scale_pose[t]; g_pose[t] = sc > 0.0 ? sv.gc[t] / sc : 0.0; }
+  if (t < nc) { const double sc = cam_scale(dp, sv, t); g_pose[t] = sc > 0.0 ? sv.gc[t] / sc : 0.0; }
   else if (t < nc + 3 * (int64_t)dp.M) { const int64_t u = t - nc; const double sc = dp.scale_point[u]; g_point[u] = sc > 0.0 ? sv.gp[u] / sc : 0.0; }
 }
 
@@ -252,11 +401,16 @@ template <int CD>
 __device__ __forceinline__ void schur_store_row(const SolverDev& sv, int blk, int r, const double* acc, double racc, double inv_radius) {
   const int a = sv.blk_a[blk], b = sv.blk_b[blk];
   double* srow = sv.S + sv.blk_dst[blk] + (size_t)r * kTile;
+  const int64_t add = sv.blk_add[blk];
   if (a == b) {
-    const double* urow = sv.U + ((size_t)a * CD + r) * CD;
+    const double* urow = sv.U + add + (size_t)r * CD;
 #pragma unroll
     for (int c = 0; c < CD; ++c) srow[c] = urow[c] + ((c == r && sv.lead) ? sv.diag_c[(size_t)a * CD + r] * inv_radius : 0.0) - acc[c];
     sv.rhs[(size_t)a * CD + r] = (sv.lead ? sv.gc[(size_t)a * CD + r] : 0.0) - racc;
+  } else if (add >= 0) {
+    const double* urow = sv.U + add + (size_t)r * CD;     // intrinsics x frame border block
+#pragma unroll
+    for (int c = 0; c < CD; ++c) srow[c] = urow[c] - acc[c];
   } else {
 #pragma unroll
     for (int c = 0; c < CD; ++c) srow[c] = -acc[c];
@@ -356,6 +510,12 @@ __global__ __launch_bounds__(256) void back_substitute_kernel(const DeviceProble
 #pragma unroll
     for (int a = 0; a < CD; ++a) { const double y = yc[a]; t0 -= pm[a * 3] * y; t1 -= pm[a * 3 + 1] * y; t2 -= pm[a * 3 + 2] * y; }
   }
+  for (int v = 0; v < sv.NPF; ++v) {   // the point's virtual observations of the intrinsics pseudo frames
+    const double* pm = sv.Pm + ((size_t)dp.N + (size_t)j * sv.NPF + v) * (CD * 3);
+    const double* yc = sv.rhs + (size_t)(sv.F + v) * CD;
+#pragma unroll
+    for (int a = 0; a < CD; ++a) { const double y = yc[a]; t0 -= pm[a * 3] * y; t1 -= pm[a * 3 + 1] * y; t2 -= pm[a * 3 + 2] * y; }
+  }
   const double* li = sv.Linv + (size_t)j * 6;
   double* yp = sv.yp + (size_t)j * 3;
   yp[0] = li[0] * t0 + li[1] * t1 + li[3] * t2;
@@ -379,6 +539,10 @@ __global__ __launch_bounds__(256) void model_cost_kernel(const DeviceProblem dp,
     for (int k = 0; k < 3; ++k) { m0 -= rec[2 + k] * yp[k]; m1 -= rec[5 + k] * yp[k]; }
 #pragma unroll
     for (int a = 0; a < CD; ++a) { m0 -= rec[8 + off + a] * yc[a]; m1 -= rec[8 + KC + off + a] * yc[a]; }
+    if (off > 0) {
+      const double* yi = sv.rhs + (size_t)sv.F * CD;   // intrinsics step: 9 coordinates across the pseudo frames
+      for (int k = 0; k < 9; ++k) { m0 -= rec[8 + k] * yi[k]; m1 -= rec[8 + KC + k] * yi[k]; }
+    }
     v = m0 * (rec[0] + 0.5 * m0) + m1 * (rec[1] + 0.5 * m1);
   }
   v = wsum(v);
@@ -404,14 +568,19 @@ __global__ __launch_bounds__(256) void candidate_kernel(const DeviceProblem dp, 
   double st = 0.0, xx = 0.0;
   if (t < nc + np) {
     const bool cam = t < nc;
-    const int64_t u = cam ? t : t - nc;
-    const double x = cam ? dp.poses[u] : dp.points[u];
-    const double sc = cam ? dp.scale_pose[u] : dp.scale_point[u];
-    const double y = cam ? sv.rhs[u] : sv.yp[u];
-    const double in = cam ? sv.inprog_pose[u] : sv.inprog_point[u];
+    const int64_t npose = (int64_t)sv.F * sv.CD;
+    const bool intr = cam && t >= npose;
+    const int64_t u = cam ? (intr ? t - npose : t) : t - nc;
+    if (intr && u >= 9) { st = 0.0; xx = 0.0; }   // padding coordinate of the last pseudo frame
+    else {
+    const double x = cam ? (intr ? dp.intr[u] : dp.poses[u]) : dp.points[u];
+    const double sc = cam ? cam_scale(dp, sv, t) : dp.scale_point[u];
+    const double y = cam ? sv.rhs[t] : sv.yp[u];
+    const double in = cam ? (intr ? sv.inprog_intr[u] : sv.inprog_pose[u]) : sv.inprog_point[u];
     const double xn = (sc > 0.0) ? x + (-y * sc) : x;
-    if (cam) sv.trial_poses[u] = xn; else sv.trial_points[u] = xn;
+    if (intr) sv.trial_intr[u] = xn; else if (cam) sv.trial_poses[u] = xn; else sv.trial_points[u] = xn;
     if (in > 0.0) { const double e = x - xn; st = e * e; xx = x * x; }
+    }
   }
   st = wsum(st); xx = wsum(xx);
   if ((threadIdx.x & 63) == 0) { s_red[0][threadIdx.x >> 6] = st; s_red[1][threadIdx.x >> 6] = xx; }
@@ -426,9 +595,8 @@ __global__ __launch_bounds__(256) void candidate_kernel(const DeviceProblem dp, 
 __global__ void pack_linearize_kernel(const DeviceProblem dp, const SolverDev sv, const double* cost2) {
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (t < sv.n) {
-    const int f = (int)(t / sv.CD), a = (int)(t % sv.CD);
     sv.xbuf[t] = sv.gc[t];
-    sv.xbuf[sv.n + t] = sv.U[((size_t)f * sv.CD + a) * sv.CD + a];
+    sv.xbuf[sv.n + t] = u_diag(sv, t);
   }
   if (t == 0) { sv.xbuf[2 * sv.n] = cost2[0]; sv.xbuf[2 * sv.n + 1] = cost2[1]; sv.xbuf[2 * sv.n + 2] = (double)*dp.fail_count; }
 }
@@ -513,8 +681,48 @@ hipError_t launch_project(const DeviceProblem& dp, const SolverDev& sv, hipStrea
     hipLaunchKernelGGL((project_kernel<12, 12>), dim3(grid), dim3(256), lds_of(32, 36), st, dp, sv);
   }
   else if (sv.CD == 6 && KC == 6) hipLaunchKernelGGL((project_kernel<6, 6>), dim3(grid), dim3(256), lds_of(20, 18), st, dp, sv);
-  else return hipErrorInvalidValue;
+  else if (sv.CD == 12 && KC == 21) {
+    static bool configured = false;
+    if (!configured) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(project_kernel<12, 21>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(50, 36));
+      if (e != hipSuccess) return e;
+      configured = true;
+    }
+    hipLaunchKernelGGL((project_kernel<12, 21>), dim3(grid), dim3(256), lds_of(50, 36), st, dp, sv);
+  } else if (sv.CD == 6 && KC == 15) {
+    static bool configured = false;
+    if (!configured) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(project_kernel<6, 15>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(38, 18));
+      if (e != hipSuccess) return e;
+      configured = true;
+    }
+    hipLaunchKernelGGL((project_kernel<6, 15>), dim3(grid), dim3(256), lds_of(38, 18), st, dp, sv);
+  } else return hipErrorInvalidValue;
   return hipGetLastError();
+}
+// intrinsics as a parameter block: border blocks of J^T J and the intrinsics gradient
+hipError_t launch_intr_blocks(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {
+  if (sv.NPF == 0) return hipSuccess;
+  const size_t CD2 = (size_t)sv.CD * sv.CD;
+  hipError_t e = hipMemsetAsync(sv.U + (size_t)sv.F * CD2, 0, ((size_t)sv.NPF * sv.F + (size_t)sv.NPF * sv.NPF) * CD2 * sizeof(double), st);
+  if (e != hipSuccess) return e;
+  e = hipMemsetAsync(sv.gc + (size_t)sv.F * sv.CD, 0, (size_t)sv.NPF * sv.CD * sizeof(double), st);
+  if (e != hipSuccess) return e;
+  if (sv.CD == 12) {
+    LAUNCH((intr_cross_kernel<12, 0, 5>), dp.F, 256, st, dp, sv);
+    LAUNCH((intr_cross_kernel<12, 5, 4>), dp.F, 256, st, dp, sv);
+  } else {
+    LAUNCH((intr_cross_kernel<6, 0, 9>), dp.F, 256, st, dp, sv);
+  }
+  LAUNCH(intr_self_kernel, dp.F, 256, st, dp, sv);
+  LAUNCH(intr_reduce_kernel, 1, 64, st, dp, sv);
+  return hipSuccess;
+}
+hipError_t launch_virtual_records(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {
+  if (sv.NPF == 0) return hipSuccess;
+  if (sv.CD == 12) LAUNCH(virtual_records_kernel<12>, nblocks256(dp.M), 256, st, dp, sv);
+  else LAUNCH(virtual_records_kernel<6>, nblocks256(dp.M), 256, st, dp, sv);
+  return hipSuccess;
 }
 hipError_t launch_clear_system(const SolverDev& sv, int last_diag_slot, hipStream_t st) {
   hipError_t e = hipMemsetAsync(sv.S, 0, (size_t)sv.nslots * kTile * kTile * sizeof(double), st);

@@ -81,27 +81,41 @@ int32_t s_upload_const(Solver* s, const T** p, const std::vector<T>& v) {
 int32_t build_solver(rsba_handle* h) {
   if (h->solver) return RSBA_OK;
   const DeviceProblem& dp = h->dp;
-  if (!dp.calibrated) return rsba_set_error(RSBA_ERR_UNSUPPORTED, "solve with intrinsics as parameter blocks is not built yet");
+  if (!dp.calibrated && dp.NI != 1)
+    return rsba_set_error(RSBA_ERR_UNSUPPORTED, "solve with per-frame intrinsics parameter blocks is not built yet (shared sess.cam is)");
   Solver* s = new Solver();
   h->solver = s;   // owned by the handle from here on (freed by rsba_destroy_solver)
   SolverDev& sv = s->sv;
-  const int F = dp.F, M = dp.M, CD = 6 * dp.P;
+  const int FR = dp.F, M = dp.M, CD = 6 * dp.P;          // FR real frames
+  const int NPF = dp.calibrated ? 0 : (9 + CD - 1) / CD;   // intrinsics pseudo frames (solver_state.hpp)
+  const int F = FR + NPF;                                 // camera-side blocks of the reduced system
   const int64_t N = dp.N;
+  sv.F = FR; sv.Fx = F; sv.NPF = NPF;
   sv.CD = CD; sv.n = (int64_t)F * CD;
   const int FT = kTile / CD;
   sv.nt = (F + FT - 1) / FT; sv.npad = (int64_t)sv.nt * kTile;
   const std::vector<int32_t>& of = h->obs_frame; const std::vector<int32_t>& op = h->obs_point;
 
-  std::vector<int64_t> frame_ptr(F + 1, 0), point_ptr(M + 1, 0);
+  std::vector<int64_t> frame_ptr(FR + 1, 0), point_ptr(M + 1, 0);
   for (int64_t i = 0; i < N; ++i) { frame_ptr[of[i] + 1]++; point_ptr[op[i] + 1]++; }
-  for (int f = 0; f < F; ++f) frame_ptr[f + 1] += frame_ptr[f];
+  for (int f = 0; f < FR; ++f) frame_ptr[f + 1] += frame_ptr[f];
   for (int j = 0; j < M; ++j) point_ptr[j + 1] += point_ptr[j];
-  // slots: stable counting sort of the frame-major list by point -> ascending frame inside a point
-  std::vector<int32_t> obs_slot(N), slot_frame(N), slot_point(N);
+  // slots: stable counting sort of the frame-major list by point -> ascending frame inside a point;
+  // behind them one virtual slot per (point, pseudo frame)
+  const int64_t NS = N + (int64_t)M * NPF;
+  std::vector<int32_t> obs_slot(N), slot_frame(NS), slot_point(NS);
   {
     std::vector<int64_t> fill(point_ptr.begin(), point_ptr.end() - 1);
     for (int64_t i = 0; i < N; ++i) { const int64_t sl = fill[op[i]]++; obs_slot[i] = (int32_t)sl; slot_frame[sl] = of[i]; slot_point[sl] = op[i]; }
+    for (int j = 0; j < M; ++j) for (int v = 0; v < NPF; ++v) { slot_frame[N + (int64_t)j * NPF + v] = FR + v; slot_point[N + (int64_t)j * NPF + v] = j; }
   }
+  // the slots of point j in ascending frame order (virtual ones last; only for points that are observed)
+  auto slots_of = [&](int j, std::vector<int64_t>& out) {
+    out.clear();
+    for (int64_t x = point_ptr[j]; x < point_ptr[j + 1]; ++x) out.push_back(x);
+    if (!out.empty()) for (int v = 0; v < NPF; ++v) out.push_back(N + (int64_t)j * NPF + v);
+  };
+  std::vector<int64_t> pslots;
   // blocks (a >= b) and their pair lists
   const bool dense_keys = (int64_t)F * F <= (int64_t)1 << 26;
   std::vector<int64_t> dense_cnt; std::unordered_map<int64_t, int64_t> sparse_cnt;
@@ -113,13 +127,16 @@ int32_t build_solver(rsba_handle* h) {
   };
   for (int f = 0; f < F; ++f) bump(f, f, 0);   // every frame owns a diagonal block (it carries U_f + D^2 and rhs_f)
   if (!h->union_mask.empty())                    // multi-GPU: blocks other ranks fill, so every rank shares one tile layout
-    for (int a = 0; a < F; ++a) for (int b = 0; b <= a; ++b) if (h->union_mask[(size_t)a * F + b]) bump(a, b, 0);
-  for (int j = 0; j < M; ++j)
-    for (int64_t x = point_ptr[j]; x < point_ptr[j + 1]; ++x)
-      for (int64_t y = point_ptr[j]; y <= x; ++y) {
-        const int a = slot_frame[x], b = slot_frame[y];
-        if (a == b) bump(a, a, x == y ? 1 : 2); else bump(a, b, 1);
+    for (int a = 0; a < FR; ++a) for (int b = 0; b <= a; ++b) if (h->union_mask[(size_t)a * FR + b]) bump(a, b, 0);
+  for (int v = 0; v < NPF; ++v) for (int b = 0; b < FR + v; ++b) bump(FR + v, b, 0);   // the intrinsics border is dense
+  for (int j = 0; j < M; ++j) {
+    slots_of(j, pslots);
+    for (size_t xi = 0; xi < pslots.size(); ++xi)
+      for (size_t yi = 0; yi <= xi; ++yi) {
+        const int a = slot_frame[pslots[xi]], b = slot_frame[pslots[yi]];
+        if (a == b) bump(a, a, xi == yi ? 1 : 2); else bump(a, b, 1);
       }
+  }
   std::vector<int32_t> blk_a, blk_b; std::vector<int64_t> blk_ptr(1, 0);
   std::unordered_map<int64_t, int32_t> blk_index;
   std::vector<int32_t> dense_index;
@@ -141,15 +158,18 @@ int32_t build_solver(rsba_handle* h) {
   std::vector<int32_t> pair_a(npairs), pair_b(npairs);
   {
     std::vector<int64_t> fill(blk_ptr.begin(), blk_ptr.end() - 1);
-    for (int j = 0; j < M; ++j)
-      for (int64_t x = point_ptr[j]; x < point_ptr[j + 1]; ++x)
-        for (int64_t y = point_ptr[j]; y <= x; ++y) {
+    for (int j = 0; j < M; ++j) {
+      slots_of(j, pslots);
+      for (size_t xi = 0; xi < pslots.size(); ++xi)
+        for (size_t yi = 0; yi <= xi; ++yi) {
+          const int64_t x = pslots[xi], y = pslots[yi];
           const int a = slot_frame[x], b = slot_frame[y];
           const int32_t bi = index_of(a, b);
           int64_t& w = fill[bi];
           pair_a[w] = (int32_t)x; pair_b[w] = (int32_t)y; ++w;
           if (a == b && x != y) { pair_a[w] = (int32_t)y; pair_b[w] = (int32_t)x; ++w; }
         }
+    }
   }
   std::vector<int32_t>().swap(dense_index);
   sv.nblk = (int)blk_a.size();
@@ -205,20 +225,25 @@ int32_t build_solver(rsba_handle* h) {
     if (end_ - first > 1) { multi_first.push_back(first); multi_first.push_back(end_); }
   }
   sv.nchunk = (int)chunk_blk.size(); sv.nmulti = (int)(multi_first.size() / 2);
-  std::vector<int64_t> blk_dst(blk_a.size());
+  std::vector<int64_t> blk_dst(blk_a.size()), blk_add(blk_a.size(), -1);
   for (size_t bidx = 0; bidx < blk_a.size(); ++bidx) {
     const int a = blk_a[bidx], b = blk_b[bidx];
     blk_dst[bidx] = (int64_t)slot_of(a / FT, b / FT) * (kTile * kTile) + (int64_t)(a % FT) * CD * kTile + (int64_t)(b % FT) * CD;
+    // which J^T J block enters this block of S: U layout [frames][pseudo x frames][pseudo x pseudo]
+    if (a < FR) { if (a == b) blk_add[bidx] = (int64_t)a * CD * CD; }
+    else if (b < FR) blk_add[bidx] = ((int64_t)FR + (int64_t)(a - FR) * FR + b) * CD * CD;
+    else blk_add[bidx] = ((int64_t)FR + (int64_t)NPF * FR + (int64_t)(a - FR) * NPF + (b - FR)) * CD * CD;
   }
 
   // which coordinates belong to the reduced program (for |x| and |step|): blocks that are not constant
   // and are touched by at least one residual block
-  std::vector<double> inprog_pose((size_t)F * CD, 0.0), inprog_point((size_t)M * 3, 0.0);
+  std::vector<double> inprog_pose((size_t)FR * CD, 0.0), inprog_point((size_t)M * 3, 0.0), inprog_intr((size_t)std::max(NPF, 1) * CD, 0.0);
   int nfree = 0;
   const bool lead = h->rank == 0;
   sv.lead = lead;
   auto frame_has_obs = [&](int f) { return h->frame_obs_total.empty() ? frame_ptr[f + 1] > frame_ptr[f] : h->frame_obs_total[f] > 0; };
-  for (int f = 0; f < F; ++f) for (int q = 0; q < dp.P; ++q) {
+  if (NPF > 0 && lead && h->mask_intr[0] != 0.0 && N > 0) for (int k = 0; k < 9; ++k) { inprog_intr[k] = 1.0; ++nfree; }
+  for (int f = 0; f < FR; ++f) for (int q = 0; q < dp.P; ++q) {
     bool any_free = false;
     for (int k = 0; k < 6; ++k) any_free = any_free || h->mask_pose[((size_t)f * dp.P + q) * 6 + k] != 0.0;
     if (lead && any_free && frame_has_obs(f)) for (int k = 0; k < 6; ++k) { inprog_pose[((size_t)f * dp.P + q) * 6 + k] = 1.0; nfree += h->mask_pose[((size_t)f * dp.P + q) * 6 + k] != 0.0; }
@@ -228,7 +253,7 @@ int32_t build_solver(rsba_handle* h) {
   {
     int64_t nred = 0;
     for (int64_t i = 0; i < N; ++i) {
-      bool all_const = h->mask_point[(size_t)op[i] * 3] == 0.0;
+      bool all_const = h->mask_point[(size_t)op[i] * 3] == 0.0 && (NPF == 0 || h->mask_intr[0] == 0.0);
       for (int k = 0; k < CD && all_const; ++k) all_const = h->mask_pose[(size_t)of[i] * CD + k] == 0.0;
       nred += !all_const;
     }
@@ -247,8 +272,10 @@ int32_t build_solver(rsba_handle* h) {
   if ((rc = s_upload_const(s, &sv.pair_b, pair_b))) return rc;
   if ((rc = s_upload_const(s, &sv.inprog_pose, inprog_pose))) return rc;
   if ((rc = s_upload_const(s, &sv.inprog_point, inprog_point))) return rc;
+  if ((rc = s_upload_const(s, &sv.inprog_intr, inprog_intr))) return rc;
   if ((rc = s_upload(s, &s->d_obs_slot, obs_slot))) return rc;
   if ((rc = s_upload_const(s, &sv.blk_dst, blk_dst))) return rc;
+  if ((rc = s_upload_const(s, &sv.blk_add, blk_add))) return rc;
   if ((rc = s_upload_const(s, &sv.chunk_blk, chunk_blk))) return rc;
   if ((rc = s_upload_const(s, &sv.chunk_p0, chunk_p0))) return rc;
   if ((rc = s_upload_const(s, &sv.multi_first, multi_first))) return rc;
@@ -262,21 +289,24 @@ int32_t build_solver(rsba_handle* h) {
   const size_t REC = 2 + 2 * (size_t)dp.K;
   if ((rc = s_alloc(s, &h->dp.rec, (size_t)N * REC))) return rc;
   h->dp.obs_slot = s->d_obs_slot;
-  if ((rc = s_alloc(s, &sv.U, (size_t)F * CD * CD))) return rc;
+  if ((rc = s_alloc(s, &sv.U, ((size_t)FR + (size_t)NPF * FR + (size_t)NPF * NPF) * CD * CD))) return rc;
   if ((rc = s_alloc(s, &sv.gc, (size_t)F * CD))) return rc;
+  if ((rc = s_alloc(s, &sv.intr_part, (size_t)FR * 54))) return rc;
+  if ((rc = s_alloc(s, &sv.trial_intr, 9 * (size_t)std::max(dp.NI, 1)))) return rc;
+  HIP_TRY(hipMemcpy(sv.trial_intr, dp.intr, 9 * (size_t)dp.NI * sizeof(double), hipMemcpyDeviceToDevice));
   if ((rc = s_alloc(s, &sv.V, (size_t)M * 6))) return rc;
   if ((rc = s_alloc(s, &sv.gp, (size_t)M * 3))) return rc;
   if ((rc = s_alloc(s, &sv.diag_c, (size_t)F * CD))) return rc;
   if ((rc = s_alloc(s, &sv.diag_p, (size_t)M * 3))) return rc;
   if ((rc = s_alloc(s, &sv.Linv, (size_t)M * 6))) return rc;
   if ((rc = s_alloc(s, &sv.z, (size_t)M * 3))) return rc;
-  if ((rc = s_alloc(s, &sv.Pm, (size_t)N * CD * 3))) return rc;
+  if ((rc = s_alloc(s, &sv.Pm, (size_t)NS * CD * 3))) return rc;
   if ((rc = s_alloc(s, &sv.S, (size_t)sv.nslots * kTile * kTile + (size_t)sv.npad))) return rc;
   sv.rhs = sv.S + (size_t)sv.nslots * kTile * kTile;   // one buffer = exchange payload (2)
   if ((rc = s_alloc(s, &sv.udiag, (size_t)F * CD))) return rc;
   if ((rc = s_alloc(s, &sv.xbuf, 2 * (size_t)F * CD + 3))) return rc;
   if ((rc = s_alloc(s, &sv.yp, (size_t)M * 3))) return rc;
-  if ((rc = s_alloc(s, &sv.trial_poses, (size_t)F * CD))) return rc;
+  if ((rc = s_alloc(s, &sv.trial_poses, (size_t)FR * CD))) return rc;
   if ((rc = s_alloc(s, &sv.trial_points, (size_t)M * 3))) return rc;
   const size_t nb = std::max<size_t>((N + 255) / 256, ((size_t)sv.n + 3 * (size_t)M + 255) / 256);
   if ((rc = s_alloc(s, &sv.partial, 2 * nb + 2))) return rc;
@@ -313,6 +343,7 @@ int32_t linearize(rsba_handle* h) {
   HIP_TRY(launch_eval(h->dp, kLmJacobian, h->stream));
   HIP_TRY(launch_cost_reduce(h->dp, h->d_cost2, h->stream));
   HIP_TRY(launch_camera_blocks(h->dp, s->sv, h->stream));
+  HIP_TRY(launch_intr_blocks(h->dp, s->sv, h->stream));
   HIP_TRY(launch_point_blocks(h->dp, s->sv, h->stream));
   HIP_TRY(launch_pack_linearize(h->dp, s->sv, h->d_cost2, h->stream));
   int32_t rc = exchange(h, s->sv.xbuf, 2 * s->sv.n + 3, 0);
@@ -331,6 +362,7 @@ int32_t factor_and_solve(rsba_handle* h, double radius) {
   Solver* s = h->solver; const SolverDev& sv = s->sv; hipStream_t st = h->stream;
   HIP_TRY(launch_point_factor(h->dp, sv, radius, st));
   HIP_TRY(launch_project(h->dp, sv, st));
+  HIP_TRY(launch_virtual_records(h->dp, sv, st));
   HIP_TRY(launch_clear_system(sv, s->last_diag_slot, st));
   HIP_TRY(launch_schur_blocks(h->dp, sv, radius, st));
   // exchange (2): partial reduced camera systems -> the full one on every rank (then factored redundantly)
@@ -367,8 +399,9 @@ int32_t rsba_gradient(rsba_handle* h, double* g) {
   const size_t npose = (size_t)dp.F * dp.P * 6, npt = (size_t)dp.M * 3;
   HIP_TRY(hipMemcpyAsync(g, s->d_gpose, npose * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipMemcpyAsync(g + npose, s->d_gpoint, npt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
   std::fill(g + npose + npt, g + npose + npt + (size_t)dp.NI * 9, 0.0);
+  if (s->sv.NPF > 0) HIP_TRY(hipMemcpyAsync(g + npose + npt, s->d_gpose + npose, 9 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
   return RSBA_OK;
 }
 
@@ -472,6 +505,7 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
     const size_t npose = (size_t)dp.F * dp.P * 6, npt = (size_t)dp.M * 3;
     HIP_TRY(hipMemcpyAsync(h->desc.poses, dp.poses, npose * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(h->desc.points, dp.points, npt * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (!dp.calibrated) HIP_TRY(hipMemcpyAsync(h->desc.intrinsics, dp.intr, (size_t)dp.NI * 9 * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     sum->total_time_s = now_s() - t_start;
     return RSBA_OK;
@@ -500,6 +534,8 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
   }
   push(it);
 
+  // current <-> candidate parameter buffers (intrinsics only when they are a parameter block)
+  auto swap_params = [&]() { std::swap(dp.poses, sv.trial_poses); std::swap(dp.points, sv.trial_points); if (sv.NPF > 0) std::swap(dp.intr, sv.trial_intr); };
   int invalid_streak = 0, iteration = 0;
   const size_t pose_bytes = (size_t)dp.F * dp.P * 6 * sizeof(double), point_bytes = (size_t)dp.M * 3 * sizeof(double);
   (void)pose_bytes; (void)point_bytes;
@@ -513,11 +549,11 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
     HIP_TRY(launch_model_cost_change(dp, sv, st));
     HIP_TRY(launch_candidate(dp, sv, st));
     // residuals only at the candidate (T = double path)
-    std::swap(dp.poses, sv.trial_poses); std::swap(dp.points, sv.trial_points);
+    swap_params();
     HIP_TRY(hipMemsetAsync(dp.fail_count, 0, sizeof(int), st));
     HIP_TRY(launch_eval(dp, kResidualOnly, st));
     HIP_TRY(launch_cost_reduce(dp, h->d_cost2, st));
-    std::swap(dp.poses, sv.trial_poses); std::swap(dp.points, sv.trial_points);
+    swap_params();
     // exchange (3): model decrease, |step|^2, |x|^2, (skip the max slot), trial cost, -, failure flags
     HIP_TRY(launch_pack_trial(dp, sv, h->d_cost2, st));
     if ((rc = exchange(h, sv.scalars, 3, 0))) return rc;
@@ -549,7 +585,8 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
         it.step_is_successful = 1; ++sum->num_successful_steps;
         radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * it.relative_decrease - 1.0, 3));
         radius = std::min(opt->max_trust_region_radius, radius); decrease_factor = 2.0; reuse_diagonal = false;
-        std::swap(dp.poses, sv.trial_poses); std::swap(dp.points, sv.trial_points);   // x = x_plus_delta
+        swap_params();   // x = x_plus_delta
+        if (sv.NPF > 0) HIP_TRY(hipMemcpyAsync(sv.trial_intr, dp.intr, 9 * sizeof(double), hipMemcpyDeviceToDevice, st));   // constant coordinates stay in sync
         t0 = now_s();
         if ((rc = linearize(h))) return rc;
         if ((rc = gradient_max(h))) return rc;

@@ -18,7 +18,14 @@ namespace rsba {
 constexpr int kSchurChunk = 240;   // pairs per wave of the Schur kernel (multiple of the 5 / 10 pair slots)
 constexpr int kTile = 48;   // Cholesky tile: 4 rolling-shutter frames (12 unknowns) or 8 global-shutter frames
 
+// Intrinsics as a parameter block (opt.model.calibrated == false with the shared sess.cam,
+// CeresHandler.h:256-264,273-280): its 9 coordinates ride as NPF = ceil(9/CD) extra "pseudo frames" at the
+// end of the camera-side ordering (zero-scaled padding fills the last one), and every point gets one
+// VIRTUAL observation slot per pseudo frame whose P record is Q_j = sum_o Ji_o^T Jp_o L^-T.  The pair lists
+// of the symbolic phase then produce the 9-wide dense border of the reduced system with the same Schur and
+// Cholesky kernels; only the (non block-diagonal) U cross terms need their own reductions.
 struct SolverDev {
+  int F, Fx, NPF;               // real frames, frames + pseudo frames, pseudo frames (0 when calibrated)
   int CD;                       // 6 * P
   int64_t n, npad;              // camera unknowns F*CD, padded to a multiple of kTile
   int nt;                       // npad / kTile
@@ -26,8 +33,8 @@ struct SolverDev {
   // structure
   const int64_t* frame_ptr;     // [F+1] frame-major observation ranges
   const int64_t* point_ptr;     // [M+1] slot ranges per point
-  const int32_t* slot_frame;    // [N]
-  const int32_t* slot_point;    // [N]
+  const int32_t* slot_frame;    // [N + M*NPF]  (virtual slots behind the real ones: N + j*NPF + v)
+  const int32_t* slot_point;    // [N + M*NPF]
   int nblk;                     // structurally non-zero CDxCD blocks (a >= b) of S
   const int32_t* blk_a;         // [nblk]
   const int32_t* blk_b;
@@ -35,6 +42,7 @@ struct SolverDev {
   const int32_t* pair_a;        // slot in frame a
   const int32_t* pair_b;        // slot in frame b (same point)
   const int64_t* blk_dst;       // [nblk] offset of the block's (0,0) entry inside the packed tile array S
+  const int64_t* blk_add;       // [nblk] offset into U of the J^T J block to add (diagonal / border blocks), -1 = none
   // pair lists cut into chunks of kSchurChunk so no wave walks a 2000-pair diagonal block alone
   int nchunk;
   const int32_t* chunk_blk;     // [nchunk]
@@ -43,15 +51,18 @@ struct SolverDev {
   const int32_t* multi_first;   // [nmulti][2] first / end chunk of each such block (its chunks are consecutive)
   double* schur_part;           // [nchunk][CD][CD+1] partial rows of split blocks
   // numeric
-  double* U;                    // [F][CD][CD]
-  double* gc;                   // [F][CD]      (scaled) J_c^T r
+  double* U;                    // [F][CD][CD] frame blocks | [NPF][F][CD][CD] intrinsics x frame | [NPF][NPF][CD][CD]
+  double* gc;                   // [Fx][CD]     (scaled) J_c^T r, intrinsics gradient in the pseudo frames
+  double* intr_part;            // [F][9*10/2 + 9] per-frame partials of Ji^T Ji and Ji^T r
+  double* trial_intr;           // [9] candidate intrinsics
+  const double* inprog_intr;    // [NPF*CD]
   double* V;                    // [M][6]  xx xy xz yy yz zz
   double* gp;                   // [M][3]
   double* diag_c;               // [F*CD]  clamped squared column norms (LM "diagonal_")
   double* diag_p;               // [M*3]
   double* Linv;                 // [M][6]  lower-triangular inverse of chol(V')
   double* z;                    // [M][3]
-  double* Pm;                   // [N][CD*3]  point-major
+  double* Pm;                   // [N + M*NPF][CD*3]  point-major, virtual records behind the real ones
   double* S;                    // [nslots][kTile][kTile] packed tiles of the reduced camera system / its factor
   double* rhs;                  // [npad] directly behind S (one exchange buffer) -> z (forward) -> y_c (backward)
   double* udiag;                // [F*CD] diag(U), global after the exchange
@@ -84,6 +95,8 @@ hipError_t launch_schur_blocks(const DeviceProblem& dp, const SolverDev& sv, dou
 hipError_t launch_back_substitute(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);
 hipError_t launch_model_cost_change(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);      // -> scalars[kModelCostChange]
 hipError_t launch_candidate(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);              // trial params, |step|^2, |x|^2
+hipError_t launch_intr_blocks(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);
+hipError_t launch_virtual_records(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);
 hipError_t launch_pack_linearize(const DeviceProblem& dp, const SolverDev& sv, const double* cost2, hipStream_t st);
 hipError_t launch_unpack_linearize(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);
 hipError_t launch_pack_trial(const DeviceProblem& dp, const SolverDev& sv, const double* cost2, hipStream_t st);

@@ -130,6 +130,38 @@ def test_constness_rules(capi, oracle, variant):
     compare_solves(capi, oracle, p, iters=15, final_tol=1e-6, expect_same_path=(variant != "free_gauge"))
 
 
+@pytest.mark.parametrize("rolling", [True, False])
+@pytest.mark.parametrize("huber", [0.0, 2.0])
+def test_shared_intrinsics_as_parameter_block(capi, oracle, rolling, huber):
+    """opt.model.calibrated = false with the shared sess.cam block (CeresHandler.h:256-264, 273-280):
+    BASELINE config C5's model (Huber + shared intrinsics) at a size the oracle solves in seconds."""
+    p = small_scene(rolling=rolling, frames=18, points=800, seed=51, outlier_ratio=0.05 if huber else 0.0)
+    p.calibrated = False
+    p.huber_a = huber
+    p.intrinsics = p.intrinsics * (1.0 + 1e-3 * np.array([[1, -1, 20, -20, 10, 10, -10, 0.5, -0.5]]))   # start off the true calibration
+    check_normal_equations_uncalibrated(capi, oracle, p)
+    s, s_ref, p_dev, p_cpu = compare_solves(capi, oracle, p, iters=40)
+    assert np.max(np.abs(p_dev.intrinsics - p_cpu.intrinsics) / np.maximum(1.0, np.abs(p_cpu.intrinsics))) <= 1e-6
+    assert not np.array_equal(p_dev.intrinsics, p.intrinsics)
+
+
+def test_constant_shared_intrinsics_block(capi, oracle):
+    p = small_scene(frames=10, points=300, seed=52)
+    p.calibrated = False
+    p.intrinsics_constant = np.array([1], dtype=np.uint8)
+    s, s_ref, p_dev, p_cpu = compare_solves(capi, oracle, p, iters=20)
+    assert np.array_equal(p_dev.intrinsics, p.intrinsics)
+
+
+def check_normal_equations_uncalibrated(capi, oracle, p, tol=1e-11):
+    ok, cost_ref, g_ref = oracle.evaluate(p)
+    with capi.DeviceProblem(p) as dp:
+        out = dp.evaluate(residuals=False, jacobians=False, gradient=True)
+    assert abs(out["cost"] - cost_ref) <= 1e-12 * cost_ref
+    for k in ("poses", "points", "intrinsics"):
+        assert scaled_err(out["gradient"][k], g_ref[k]) <= tol, k
+
+
 def test_behind_camera_initial_failure(capi):
     p = small_scene(frames=6, points=100)
     p.points[3, 2] = -5.0
