@@ -78,6 +78,9 @@ def lib():
         _lib.orc_evaluate_residuals.restype = C.c_int64
         _lib.orc_norm3.restype = C.c_double
         _lib.orc_huber.argtypes = [C.c_double, C.c_double, C.c_void_p]
+        # the checker's many small parallel regions crawl with a 256-thread team on a 2-socket host:
+        # keep its default team small (the cpu_baseline leg passes its own thread count explicitly)
+        _lib.orc_set_num_threads(C.c_int32(int(os.environ.get("RSBA_ORACLE_THREADS", min(os.cpu_count() or 1, 16)))))
     return _lib
 
 

@@ -564,6 +564,14 @@ int32_t orc_solve(orc_problem* p, const orc_options* opt, orc_summary* sum, orc_
   return sum->termination_type;
 }
 
+void orc_set_num_threads(int32_t n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 void orc_angle_axis_rotate(const double w[3], const double p[3], double out[3]) { angle_axis_rotate(w, p, out); }
 void orc_lerp_rotation(const double r0[3], const double r1[3], double tau, double out[3]) { lerp_rotation(r0, r1, tau, out); }
 void orc_distort(const double cam[9], const double img[2], double out[2]) { distort(cam, img, out); }

@@ -59,6 +59,8 @@ typedef struct orc_summary {
 } orc_summary;
 
 void orc_default_options(orc_options* o);
+/* default OpenMP team size for the calls that do not take a thread count */
+void orc_set_num_threads(int32_t n);
 
 /* Number of Jacobian columns per observation: 9*(!calibrated) + 6*P + 3 */
 int32_t orc_jacobian_cols(const orc_problem* p);

@@ -16,6 +16,13 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// value held by the neighbouring lane (lane ^ 1), via DPP quad_perm [1,0,3,2]
+__device__ __forceinline__ double swap_pair(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0xB1, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0xB1, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
 template <bool CAL, int P, int MODE>
 __global__ __launch_bounds__(kEvalBlock) void eval_kernel(const DeviceProblem dp) {
   constexpr int CD = 6 * P;
@@ -43,10 +50,14 @@ __global__ __launch_bounds__(kEvalBlock) void eval_kernel(const DeviceProblem dp
   }
 
   double cost = 0.0, fixed = 0.0;
-  if (i < dp.N) {
-    const double2 xy = dp.xy[i];
-    const int f = dp.obs_frame[i];
-    const int j = dp.obs_point[i];
+  {
+    // lanes past the end of the list recompute the last observation (they must stay converged for the
+    // lane-pair exchange below); their results land in the tile padding and are not counted
+    const bool valid = i < dp.N;
+    const int64_t ic = valid ? i : dp.N - 1;
+    const double2 xy = dp.xy[ic];
+    const int f = dp.obs_frame[ic];
+    const int j = dp.obs_point[ic];
     double pose[CD], X[3], cam[9];
     if (staged) {
 #pragma unroll
@@ -65,12 +76,12 @@ __global__ __launch_bounds__(kEvalBlock) void eval_kernel(const DeviceProblem dp
     ObsOut<CAL, P> o;
     eval_observation<CAL, P, MODE != kResidualOnly>(m, cam, pose, X, xy.x, xy.y, o);
 
-    if (!o.ok) atomicAdd(dp.fail_count, 1);
+    if (valid && !o.ok) atomicAdd(dp.fail_count, 1);
     // Ceres 1.9 ResidualBlock::Evaluate: cost = rho0/2 from the uncorrected residual
     const double s = o.r[0] * o.r[0] + o.r[1] * o.r[1];
     double rho[3] = {s, 1.0, 0.0};
     if (dp.huber_a > 0.0) huber_rho(dp.huber_a, s, rho);
-    double half_rho = o.ok ? 0.5 * rho[0] : 0.0;
+    double half_rho = (o.ok && valid) ? 0.5 * rho[0] : 0.0;
 
     if (MODE == kLmJacobian) {
       double sc[K];
@@ -102,7 +113,7 @@ __global__ __launch_bounds__(kEvalBlock) void eval_kernel(const DeviceProblem dp
       // point-major copy of the corrected record (see device_state.hpp)
       constexpr int REC = 2 + 2 * K;
       constexpr int KC = K - 3;
-      double2* rp = reinterpret_cast<double2*>(dp.rec + (size_t)dp.obs_slot[i] * REC);
+      double2* rp = reinterpret_cast<double2*>(dp.rec + (size_t)dp.obs_slot[ic] * REC);
       double rv[REC];
       rv[0] = o.ok ? o.r[0] : 0.0; rv[1] = o.ok ? o.r[1] : 0.0;
 #pragma unroll
@@ -112,20 +123,32 @@ __global__ __launch_bounds__(kEvalBlock) void eval_kernel(const DeviceProblem dp
 #pragma unroll
         for (int k = 0; k < KC; ++k) rv[8 + KC * r + k] = o.ok ? o.J[r][k] : 0.0;
       }
+      if (valid) {
 #pragma unroll
-      for (int k = 0; k < REC / 2; ++k) rp[k] = make_double2(rv[2 * k], rv[2 * k + 1]);
+        for (int k = 0; k < REC / 2; ++k) rp[k] = make_double2(rv[2 * k], rv[2 * k + 1]);
+      }
     }
     cost = half_rho;
 
-    double* rt = dp.res + (size_t)blockIdx.x * (2 * kEvalBlock) + tid;
-    rt[0] = o.ok ? o.r[0] : 0.0;
-    rt[kEvalBlock] = o.ok ? o.r[1] : 0.0;
+    // Tiled component-major stores, 16 B per lane: lanes 2m / 2m+1 exchange one value per component
+    // pair (DPP quad_perm [1,0,3,2]); the even lane then stores component c of observations (2m, 2m+1)
+    // and the odd lane component c+1 of the same two — 16-B stores sustain ~6 % more of the HBM write
+    // stream than 8-B ones on this part (tools/hbm_calib.hip: tiled_x2 vs write_tiled).
+    const bool odd = tid & 1;
+    double* rt = dp.res + (size_t)blockIdx.x * (2 * kEvalBlock) + (tid & ~1) + (odd ? kEvalBlock : 0);
+    {
+      const double r0 = o.ok ? o.r[0] : 0.0, r1 = o.ok ? o.r[1] : 0.0;
+      const double got = swap_pair(odd ? r0 : r1);
+      *reinterpret_cast<double2*>(rt) = odd ? make_double2(got, r1) : make_double2(r0, got);
+    }
     if (MODE != kResidualOnly) {
-      double* jt = dp.jac + (size_t)blockIdx.x * (2 * K * kEvalBlock) + tid;
+      double* jt = dp.jac + (size_t)blockIdx.x * (2 * K * kEvalBlock) + (tid & ~1) + (odd ? kEvalBlock : 0);
 #pragma unroll
-      for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int k = 0; k < K; ++k) jt[(r * K + k) * kEvalBlock] = o.ok ? o.J[r][k] : 0.0;
+      for (int c = 0; c < 2 * K; c += 2) {
+        const double v0 = o.ok ? o.J[c / K][c % K] : 0.0, v1 = o.ok ? o.J[(c + 1) / K][(c + 1) % K] : 0.0;
+        const double got = swap_pair(odd ? v0 : v1);
+        *reinterpret_cast<double2*>(jt + (size_t)c * kEvalBlock) = odd ? make_double2(got, v1) : make_double2(v0, got);
+      }
     }
   }
 
