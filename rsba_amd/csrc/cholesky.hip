@@ -8,15 +8,12 @@
 // frames only share points with frames a few dozen positions away, so S is block-banded, fill stays
 // inside the band, and the factorisation is O(n b^2) instead of O(n^3).
 //
-// One launch per tile column k (right-looking with the trailing update of column k-1 deferred by one
-// step, so it overlaps the next panel instead of sitting on the critical path):
-//   panel workgroups (1 + sub-diagonal tiles of column k): apply the pending step-(k-1) update to the
-//     diagonal tile and to their own tile, factor S_kk = L L^T in LDS (redundantly — 48^3/3 flops — so
-//     no inter-workgroup hand-off is needed); workgroup 0 stores L_kk and forward-substitutes the
-//     right-hand-side tile, workgroup t>0 solves its tile  L_ik = S_ik L_kk^-T;
-//   trailing workgroups: the remaining step-(k-1) updates  S_ij -= L_i,k-1 L_j,k-1^T  (j > k), the (i,i)
-//     ones also carry  rhs_i -= L_i,k-1 z_k-1  (the forward solve rides along with the factorisation).
-// The backward solve L^T y = z is one persistent workgroup walking the tile columns in reverse.
+// A band factored column after column is a serial chain of ~n/48 dependent steps (250 at 1k cameras),
+// each a few tens of microseconds of latency: the GPU idles.  So the host reorders the tile columns by
+// nested dissection (BFS-level separators cut the band into independent segments), computes the levels of
+// the resulting elimination structure, and the factorisation runs level by level: two launches per level
+// (diagonal tiles, then sub-diagonal tiles), every tile of a level in its own workgroup; the forward solve
+// rides along, the backward solve walks the levels in reverse.  1k cameras: ~50 levels instead of 250 steps.
 #include "solver_state.hpp"
 
 namespace rsba {
@@ -167,162 +164,218 @@ __device__ __forceinline__ void trsm_blocked(double* X, const double* L, const d
   }
 }
 
-struct StepArgs {
-  int k;
-  int npanel;                 // 1 + number of sub-diagonal tiles of column k
-  const int32_t* panel_slot;  // [npanel] slot of tile (i,k); entry 0 is the diagonal tile (k,k)
-  const int32_t* prev_slot;   // [npanel] slot of tile (i,k-1) if it exists (pending update), else -1; entry 0 is (k,k-1)
-  const int32_t* trail;       // [ntrail][4]: slots of (i,k-1), (j,k-1), (i,j) and the tile row i if i == j else -1
-};
+// ---- level-scheduled left-looking kernels -----------------------------------------------------------
+// The host orders the tile columns by nested dissection and groups them into levels of the elimination
+// structure; all columns of a level are independent.  Left-looking: a tile pulls every update it needs
+// from finished columns (no two workgroups ever write the same tile, so no atomics and a fixed summation
+// order), then the diagonal tile is factored / the sub-diagonal tile is solved.
 
-__global__ __launch_bounds__(256) void chol_step_kernel(const SolverDev sv, const StepArgs a) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int tid = threadIdx.x, k = a.k;
-  if ((int)blockIdx.x >= a.npanel) {
-    // ---- trailing update of step k-1 ----
-    double* A = smem; double* B = smem + T * TP; double* C = smem + 2 * T * TP;
-    const int32_t* t4 = a.trail + 4 * (blockIdx.x - a.npanel);
-    double* sij = tile_ptr(sv, t4[2]);
-    load_tile(A, tile_ptr(sv, t4[0]), tid, false);
-    load_tile(B, tile_ptr(sv, t4[1]), tid, false);
-    load_tile(C, sij, tid, false);
+// one workgroup per chunk of a long contributor list: partial = sum_{k in chunk} L_ik L_jk^T (and, for a
+// diagonal tile, sum L_jk z_k) to scratch; upd item = {kind, list begin, list end, scratch slot}
+__global__ __launch_bounds__(256) void chol_update_kernel(const SolverDev sv, const int32_t* upd, const int32_t* diag_list, const int32_t* sub_list) {
+  __shared__ double A[T * TP], B[T * TP];
+  const int tid = threadIdx.x;
+  const int32_t* u = upd + 4 * blockIdx.x;
+  const bool diag = u[0] == 0;
+  const int32_t* list = diag ? diag_list : sub_list;
+  double* out = sv.chol_part + (size_t)u[3] * (T * T + T);
+  const int ty = tid >> 4, tx = tid & 15;
+  double acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  double bacc = 0.0;
+  for (int p = u[1]; p < u[2]; ++p) {
     __syncthreads();
-    tile_gemm_sub(C, A, B, tid);
+    load_tile(A, tile_ptr(sv, list[2 * p]), tid, false);
+    if (!diag) load_tile(B, tile_ptr(sv, list[2 * p + 1]), tid, false);
     __syncthreads();
-    store_tile(sij, C, tid);
-    if (t4[3] >= 0 && tid < T) {
-      const double* z = sv.rhs + (size_t)(k - 1) * T;
+    const double* Bm = diag ? A : B;
+#pragma unroll 4
+    for (int m = 0; m < T; ++m) {
+      double a[3], b[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) { a[q] = A[(ty * 3 + q) * TP + m]; b[q] = Bm[(tx * 3 + q) * TP + m]; }
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int v = 0; v < 3; ++v) acc[q][v] += a[q] * b[v];
+    }
+    if (diag && tid < T) {
+      const double* z = sv.rhs + (size_t)list[2 * p + 1] * T;
       double s0 = 0.0, s1 = 0.0;
 #pragma unroll 8
       for (int m = 0; m < T; m += 2) { s0 += A[tid * TP + m] * z[m]; s1 += A[tid * TP + m + 1] * z[m + 1]; }
-      sv.rhs[(size_t)t4[3] * T + tid] -= s0 + s1;
+      bacc += s0 + s1;
     }
-    return;
   }
-  // ---- panel of column k ----
-  double* D = smem;                 // diagonal tile S_kk -> L_kk
-  double* X = smem + T * TP;        // own tile S_ik
-  double* Lp = smem + 2 * T * TP;   // L_k,k-1
-  double* Lq = smem + 3 * T * TP;   // L_i,k-1, later the pivot reciprocals
-  int* s_okp = reinterpret_cast<int*>(smem + 4 * T * TP);   // all LDS in the one dynamic region (16-B aligned base)
-#define s_ok (*s_okp)
-  const int b = blockIdx.x;
-  const bool prev_k = a.prev_slot[0] >= 0, prev_i = b > 0 && prev_k && a.prev_slot[b] >= 0;
-  load_tile(D, tile_ptr(sv, a.panel_slot[0]), tid, true);
-  if (b > 0) load_tile(X, tile_ptr(sv, a.panel_slot[b]), tid, false);
-  if (prev_k) load_tile(Lp, tile_ptr(sv, a.prev_slot[0]), tid, false);
-  if (prev_i) load_tile(Lq, tile_ptr(sv, a.prev_slot[b]), tid, false);
-  if (tid == 0) s_ok = 1;
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+#pragma unroll
+    for (int v = 0; v < 3; ++v) out[(ty * 3 + q) * T + tx * 3 + v] = acc[q][v];
+  if (diag && tid < T) out[T * T + tid] = bacc;
+}
+
+// one workgroup per column j of the level:
+//   S_jj -= sum_k L_jk L_jk^T ;  b_j -= sum_k L_jk z_k ;  S_jj = L_jj L_jj^T ;  z_j = L_jj^-1 b_j
+__global__ __launch_bounds__(256) void chol_diag_kernel(const SolverDev sv, const int32_t* info, const int32_t* ptr, const int32_t* list) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* D = smem; double* A = smem + T * TP; double* bvec = smem + 2 * T * TP; int* s_okp = reinterpret_cast<int*>(bvec + T);
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int slot_jj = info[4 * b], tile_j = info[4 * b + 1], part0 = info[4 * b + 2], nparts = info[4 * b + 3];
+  load_tile(D, tile_ptr(sv, slot_jj), tid, true);
+  if (tid < T) bvec[tid] = sv.rhs[(size_t)tile_j * T + tid];
+  if (tid == 0) *s_okp = 1;
   __syncthreads();
-  if (prev_k) {
-    tile_gemm_sub(D, Lp, Lp, tid);                 // S_kk -= L_k,k-1 L_k,k-1^T
-    if (prev_i) tile_gemm_sub(X, Lq, Lp, tid);     // S_ik -= L_i,k-1 L_k,k-1^T
+  for (int c = 0; c < nparts; ++c) {   // long contributor lists arrive pre-reduced (chol_update_kernel)
+    const double* part = sv.chol_part + (size_t)(part0 + c) * (T * T + T);
+    for (int e = tid; e < T * T; e += 256) D[(e / T) * TP + e % T] -= part[e];
+    if (tid < T) bvec[tid] -= part[T * T + tid];
+  }
+  if (nparts > 0) __syncthreads();
+  for (int p = ptr[b]; nparts == 0 && p < ptr[b + 1]; ++p) {
+    load_tile(A, tile_ptr(sv, list[2 * p]), tid, false);
+    __syncthreads();
+    tile_gemm_sub(D, A, A, tid);
+    if (tid < T) {
+      const double* z = sv.rhs + (size_t)list[2 * p + 1] * T;
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll 8
+      for (int m = 0; m < T; m += 2) { s0 += A[tid * TP + m] * z[m]; s1 += A[tid * TP + m + 1] * z[m + 1]; }
+      bvec[tid] -= s0 + s1;
+    }
     __syncthreads();
   }
   const bool ok = potrf_blocked(D, tid);
-  if (tid < 64 && !ok) s_ok = 0;
-  if (tid < T) Lq[tid] = 1.0 / D[tid * TP + tid];   // pivot reciprocals (Lq is free after the pending update)
+  if (tid < 64 && !ok) *s_okp = 0;
   __syncthreads();
-  if (b == 0) {
-    if (!s_ok && tid == 0) atomicExch(sv.chol_fail, 1);
-    double* out = tile_ptr(sv, a.panel_slot[0]);
-    for (int e = tid; e < T * T; e += 256) { const int r = e / T, c = e % T; if (c <= r) out[e] = D[r * TP + c]; }
-    // forward substitution of the right-hand-side tile, first wave, lane r owns b_r:
-    //   b_k -= L_k,k-1 z_k-1 (pending),  z_k = L_kk^-1 b_k
-    if (tid < 64) {
-      const int r = tid < T ? tid : T - 1;
-      double bb = sv.rhs[(size_t)k * T + r];
-      if (prev_k) {
-        const double* z = sv.rhs + (size_t)(k - 1) * T;
-        double s0 = 0.0, s1 = 0.0;
-#pragma unroll 8
-        for (int m = 0; m < T; m += 2) { s0 += Lp[r * TP + m] * z[m]; s1 += Lp[r * TP + m + 1] * z[m + 1]; }
-        bb -= s0 + s1;
-      }
-      double col[T];
+  if (!*s_okp && tid == 0) atomicExch(sv.chol_fail, 1);
+  double* out = tile_ptr(sv, slot_jj);
+  for (int e = tid; e < T * T; e += 256) { const int r = e / T, c = e % T; if (c <= r) out[e] = D[r * TP + c]; }
+  if (tid < 64) {
+    const int r = tid < T ? tid : T - 1;
+    double bb = bvec[r];
+    double colv[T];
 #pragma unroll
-      for (int c = 0; c < T; ++c) col[c] = D[r * TP + c];     // row r of L_kk
-      const double dinv = Lq[r];
+    for (int c = 0; c < T; ++c) colv[c] = D[r * TP + c];     // row r of L_jj
+    const double dinv = 1.0 / D[r * TP + r];
 #pragma unroll
-      for (int c = 0; c < T; ++c) {
-        const double zc = __shfl(bb * dinv, c, 64);             // z_c = b_c / L_cc, broadcast from lane c
-        if (tid == c) bb = zc; else if (tid > c) bb -= col[c] * zc;
-      }
-      if (tid < T) sv.rhs[(size_t)k * T + tid] = bb;
+    for (int c = 0; c < T; ++c) {
+      const double zc = __shfl(bb * dinv, c, 64);               // z_c = b_c / L_cc, broadcast from lane c
+      if (tid == c) bb = zc; else if (tid > c) bb -= colv[c] * zc;
     }
-  } else {
-    trsm_blocked(X, D, Lq, tid);                   // L_ik = S_ik L_kk^-T
-    store_tile(tile_ptr(sv, a.panel_slot[b]), X, tid);
+    if (tid < T) sv.rhs[(size_t)tile_j * T + tid] = bb;
   }
-#undef s_ok
 }
 
-// L^T y = z, one persistent workgroup: for k = nt-1 .. 0:  t = z_k - sum_{i>k} L_ik^T y_i ; solve L_kk^T y_k = t
-// col_ptr / col_slot / col_row list, per tile column k, the diagonal tile first and then the tiles (i,k).
-__global__ __launch_bounds__(256) void chol_backsolve_kernel(const SolverDev sv, const int32_t* col_ptr, const int32_t* col_slot, const int32_t* col_row) {
+// one workgroup per sub-diagonal tile (i,j) of the level's columns:
+//   S_ij -= sum_k L_ik L_jk^T ;  L_ij = S_ij L_jj^-T
+__global__ __launch_bounds__(256) void chol_sub_kernel(const SolverDev sv, const int32_t* info, const int32_t* ptr, const int32_t* list) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* X = smem; double* A = smem + T * TP; double* B = smem + 2 * T * TP; double* dinv = smem + 3 * T * TP;
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int slot_ij = info[4 * b], slot_jj = info[4 * b + 1], part0 = info[4 * b + 2], nparts = info[4 * b + 3];
+  load_tile(X, tile_ptr(sv, slot_ij), tid, false);
+  __syncthreads();
+  for (int c = 0; c < nparts; ++c) {
+    const double* part = sv.chol_part + (size_t)(part0 + c) * (T * T + T);
+    for (int e = tid; e < T * T; e += 256) X[(e / T) * TP + e % T] -= part[e];
+  }
+  if (nparts > 0) __syncthreads();
+  for (int p = ptr[b]; nparts == 0 && p < ptr[b + 1]; ++p) {
+    load_tile(A, tile_ptr(sv, list[2 * p]), tid, false);
+    load_tile(B, tile_ptr(sv, list[2 * p + 1]), tid, false);
+    __syncthreads();
+    tile_gemm_sub(X, A, B, tid);
+    __syncthreads();
+  }
+  load_tile(A, tile_ptr(sv, slot_jj), tid, true);   // L_jj, finished by chol_diag_kernel of this level
+  __syncthreads();
+  if (tid < T) dinv[tid] = 1.0 / A[tid * TP + tid];
+  __syncthreads();
+  trsm_blocked(X, A, dinv, tid);
+  store_tile(tile_ptr(sv, slot_ij), X, tid);
+}
+
+// backward solve, levels in reverse; one workgroup per column j:  y_j = L_jj^-T ( z_j - sum_i L_ij^T y_i )
+__global__ __launch_bounds__(256) void chol_back_kernel(const SolverDev sv, const int32_t* info, const int32_t* ptr, const int32_t* list) {
   __shared__ double A[T * TP];
   __shared__ double part[10][T];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, b = blockIdx.x;
   const int c2 = tid % 24, rg = tid / 24;   // column pair, row group (rg < 10 for tid < 240)
-  for (int k = sv.nt - 1; k >= 0; --k) {
-    const int p0 = col_ptr[k], p1 = col_ptr[k + 1];
-    load_tile(A, tile_ptr(sv, col_slot[p0]), tid, true);
-    double s0 = 0.0, s1 = 0.0;
-    if (rg < 10) {
-      for (int p = p0 + 1; p < p1; ++p) {
-        const double* lik = tile_ptr(sv, col_slot[p]) + 2 * c2;
-        const double* yi = sv.rhs + (size_t)col_row[p] * T;
+  const int slot_jj = info[2 * b], tile_j = info[2 * b + 1];
+  load_tile(A, tile_ptr(sv, slot_jj), tid, true);
+  double s0 = 0.0, s1 = 0.0;
+  if (rg < 10) {
+    for (int p = ptr[b]; p < ptr[b + 1]; ++p) {
+      const double* lij = tile_ptr(sv, list[2 * p]) + 2 * c2;
+      const double* yi = sv.rhs + (size_t)list[2 * p + 1] * T;
 #pragma unroll
-        for (int u = 0; u < 5; ++u) {
-          const int r = rg + 10 * u;
-          if (r < T) {
-            const double2 v = *reinterpret_cast<const double2*>(lik + (size_t)r * T);
-            const double y = yi[r];
-            s0 += v.x * y; s1 += v.y * y;
-          }
+      for (int u = 0; u < 5; ++u) {
+        const int r = rg + 10 * u;
+        if (r < T) {
+          const double2 v = *reinterpret_cast<const double2*>(lij + (size_t)r * T);
+          const double y = yi[r];
+          s0 += v.x * y; s1 += v.y * y;
         }
       }
-      part[rg][2 * c2] = s0; part[rg][2 * c2 + 1] = s1;
     }
-    __syncthreads();
-    if (tid < 64) {
-      const int r = tid < T ? tid : T - 1;
-      double t = sv.rhs[(size_t)k * T + r];
+    part[rg][2 * c2] = s0; part[rg][2 * c2 + 1] = s1;
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const int r = tid < T ? tid : T - 1;
+    double t = sv.rhs[(size_t)tile_j * T + r];
 #pragma unroll
-      for (int g = 0; g < 10; ++g) t -= part[g][r];
-      double colr[T];   // column r of L_kk = row r of L_kk^T : L[cc][r] for cc >= r
+    for (int g = 0; g < 10; ++g) t -= part[g][r];
+    double colr[T];   // column r of L_jj = row r of L_jj^T
 #pragma unroll
-      for (int cc = 0; cc < T; ++cc) colr[cc] = A[cc * TP + r];
-      const double dinv = 1.0 / A[r * TP + r];
+    for (int cc = 0; cc < T; ++cc) colr[cc] = A[cc * TP + r];
+    const double dinv = 1.0 / A[r * TP + r];
 #pragma unroll
-      for (int cc = T - 1; cc >= 0; --cc) {
-        const double y = __shfl(t * dinv, cc, 64);
-        if (tid == cc) t = y; else if (tid < cc) t -= colr[cc] * y;
-      }
-      if (tid < T) sv.rhs[(size_t)k * T + tid] = t;
+    for (int cc = T - 1; cc >= 0; --cc) {
+      const double y = __shfl(t * dinv, cc, 64);
+      if (tid == cc) t = y; else if (tid < cc) t -= colr[cc] * y;
     }
-    __threadfence_block();
-    __syncthreads();
+    if (tid < T) sv.rhs[(size_t)tile_j * T + tid] = t;
   }
 }
 
 }  // namespace
 
-hipError_t launch_chol_step(const SolverDev& sv, int k, int npanel, const int32_t* panel_slot, const int32_t* prev_slot,
-                            const int32_t* trail, int ntrail, hipStream_t st) {
-  StepArgs a{k, npanel, panel_slot, prev_slot, trail};
-  const size_t lds = (size_t)4 * T * TP * sizeof(double) + 16;   // 75 KB of the CU's 160 KB
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chol_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    configured = true;
-  }
-  hipLaunchKernelGGL(chol_step_kernel, dim3(npanel + ntrail), dim3(256), lds, st, sv, a);
+namespace {
+template <class K>
+hipError_t set_lds(K kernel, size_t bytes, bool& configured) {
+  if (configured) return hipSuccess;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess) configured = true;
+  return e;
+}
+}  // namespace
+
+hipError_t launch_chol_update(const SolverDev& sv, int nitem, const int32_t* upd, const int32_t* diag_list, const int32_t* sub_list, hipStream_t st) {
+  if (nitem <= 0) return hipSuccess;
+  hipLaunchKernelGGL(chol_update_kernel, dim3(nitem), dim3(256), 0, st, sv, upd, diag_list, sub_list);
   return hipGetLastError();
 }
-hipError_t launch_chol_backsolve(const SolverDev& sv, const int32_t* col_ptr, const int32_t* col_slot, const int32_t* col_row, hipStream_t st) {
-  hipLaunchKernelGGL(chol_backsolve_kernel, dim3(1), dim3(256), 0, st, sv, col_ptr, col_slot, col_row);
+hipError_t launch_chol_diag(const SolverDev& sv, int ncol, const int32_t* info, const int32_t* ptr, const int32_t* list, hipStream_t st) {
+  if (ncol <= 0) return hipSuccess;
+  const size_t lds = (size_t)(2 * T * TP + T) * sizeof(double) + 16;
+  static bool configured = false;
+  hipError_t e = set_lds(chol_diag_kernel, lds, configured);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(chol_diag_kernel, dim3(ncol), dim3(256), lds, st, sv, info, ptr, list);
+  return hipGetLastError();
+}
+hipError_t launch_chol_sub(const SolverDev& sv, int ntile, const int32_t* info, const int32_t* ptr, const int32_t* list, hipStream_t st) {
+  if (ntile <= 0) return hipSuccess;
+  const size_t lds = (size_t)(3 * T * TP + T) * sizeof(double) + 16;
+  static bool configured = false;
+  hipError_t e = set_lds(chol_sub_kernel, lds, configured);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(chol_sub_kernel, dim3(ntile), dim3(256), lds, st, sv, info, ptr, list);
+  return hipGetLastError();
+}
+hipError_t launch_chol_back(const SolverDev& sv, int ncol, const int32_t* info, const int32_t* ptr, const int32_t* list, hipStream_t st) {
+  if (ncol <= 0) return hipSuccess;
+  hipLaunchKernelGGL(chol_back_kernel, dim3(ncol), dim3(256), 0, st, sv, info, ptr, list);
   return hipGetLastError();
 }
 

@@ -400,8 +400,16 @@ __global__ void pad_system_kernel(const SolverDev sv, int last_diag_slot) {
 template <int CD>
 __device__ __forceinline__ void schur_store_row(const SolverDev& sv, int blk, int r, const double* acc, double racc, double inv_radius) {
   const int a = sv.blk_a[blk], b = sv.blk_b[blk];
-  double* srow = sv.S + sv.blk_dst[blk] + (size_t)r * kTile;
   const int64_t add = sv.blk_add[blk];
+  if (sv.blk_trans[blk]) {
+    // the tile ordering put frame b's tile below frame a's: this block lives transposed in tile (tb, ta)
+    double* scol = sv.S + sv.blk_dst[blk] + r;
+    const double* urow = add >= 0 ? sv.U + add + (size_t)r * CD : nullptr;
+#pragma unroll
+    for (int c = 0; c < CD; ++c) scol[(size_t)c * kTile] = (urow ? urow[c] : 0.0) - acc[c];
+    return;
+  }
+  double* srow = sv.S + sv.blk_dst[blk] + (size_t)r * kTile;
   if (a == b) {
     const double* urow = sv.U + add + (size_t)r * CD;
 #pragma unroll

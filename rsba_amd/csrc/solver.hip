@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <string>
 #include <unordered_map>
@@ -20,17 +21,23 @@
 
 namespace rsba {
 
-hipError_t launch_chol_step(const SolverDev& sv, int k, int npanel, const int32_t* panel_slot, const int32_t* prev_slot,
-                            const int32_t* trail, int ntrail, hipStream_t st);
-hipError_t launch_chol_backsolve(const SolverDev& sv, const int32_t* col_ptr, const int32_t* col_slot, const int32_t* col_row, hipStream_t st);
+hipError_t launch_chol_update(const SolverDev& sv, int nitem, const int32_t* upd, const int32_t* diag_list, const int32_t* sub_list, hipStream_t st);
+hipError_t launch_chol_diag(const SolverDev& sv, int ncol, const int32_t* info, const int32_t* ptr, const int32_t* list, hipStream_t st);
+hipError_t launch_chol_sub(const SolverDev& sv, int ntile, const int32_t* info, const int32_t* ptr, const int32_t* list, hipStream_t st);
+hipError_t launch_chol_back(const SolverDev& sv, int ncol, const int32_t* info, const int32_t* ptr, const int32_t* list, hipStream_t st);
 
 struct Solver {
   SolverDev sv{};
   std::vector<void*> allocs;
-  // Cholesky plan over the packed tile slots: per tile column k the panel tiles (diagonal first), the slot
-  // of the same tile row in column k-1 (pending update, -1 if none), and the trailing updates of step k-1
-  std::vector<int32_t> panel_ptr, panel_slot, panel_row, prev_slot, trail_ptr, trail;
-  int32_t *d_panel_ptr = nullptr, *d_panel_slot = nullptr, *d_panel_row = nullptr, *d_prev_slot = nullptr, *d_trail = nullptr;
+  // Cholesky plan over the packed tile slots, level-scheduled on the elimination structure (see build_solver)
+  int nlev = 0;
+  std::vector<int32_t> lev_diag_ptr, lev_sub_ptr, lev_upd_ptr, upd;   // [nlev+1] ranges of diag / sub / update items per level
+  int32_t* d_upd = nullptr;
+  std::vector<int32_t> diag_info, diag_ptr, diag_list;                // per column: {slot_jj, old tile}; contributors {slot_jk, old tile k}
+  std::vector<int32_t> sub_info, sub_ptr, sub_list;                   // per tile (i,j): {slot_ij, slot_jj}; contributors {slot_ik, slot_jk}
+  std::vector<int32_t> back_info, back_ptr, back_list;                // per column: {slot_jj, old tile}; tiles {slot_ij, old tile i}
+  int32_t *d_diag_info = nullptr, *d_diag_ptr = nullptr, *d_diag_list = nullptr, *d_sub_info = nullptr, *d_sub_ptr = nullptr,
+          *d_sub_list = nullptr, *d_back_info = nullptr, *d_back_ptr = nullptr, *d_back_list = nullptr;
   int last_diag_slot = 0;
   int32_t* d_obs_slot = nullptr;
   double *d_gpose = nullptr, *d_gpoint = nullptr;
@@ -175,44 +182,139 @@ int32_t build_solver(rsba_handle* h) {
   sv.nblk = (int)blk_a.size();
   s->num_pairs = npairs;
 
-  // tile pattern of S and symbolic fill of its factor
+  // ---- tile graph of S, fill-reducing / parallelism-exposing ordering, symbolic factorisation ----
   const int nt = sv.nt;
-  std::vector<std::vector<int32_t>> col(nt);
+  std::vector<std::vector<int32_t>> adj(nt);
+  {
+    std::vector<std::pair<int32_t, int32_t>> edges;
+    for (size_t bidx = 0; bidx < blk_a.size(); ++bidx) { const int ti = blk_a[bidx] / FT, tj = blk_b[bidx] / FT; if (ti != tj) edges.emplace_back(ti, tj); }
+    std::sort(edges.begin(), edges.end()); edges.erase(std::unique(edges.begin(), edges.end()), edges.end());
+    for (auto& e : edges) { adj[e.first].push_back(e.second); adj[e.second].push_back(e.first); }
+  }
+  // Nested dissection by BFS level structures (George): a video's co-visibility graph is a band, whose BFS
+  // levels are band-wide separators; cutting it into independent segments turns the factorisation's
+  // serial tile chain into a shallow elimination tree that the level-scheduled kernels run in parallel.
+  // Tiles adjacent to (almost) everything — the intrinsics border — are ordered last.
+  std::vector<int32_t> perm; perm.reserve(nt);          // perm[new] = old tile
+  {
+    std::vector<uint8_t> dense(nt, 0), done(nt, 0);
+    for (int t = 0; t < nt; ++t) if (nt > 8 && (int)adj[t].size() > (3 * nt) / 4) dense[t] = 1;
+    std::vector<int32_t> tag(nt, -1);                   // membership of the subgraph being processed
+    int tagc = 0;
+    auto bfs_levels = [&](int root, int mytag, std::vector<std::vector<int32_t>>& lv) {
+      lv.clear(); std::vector<int32_t> cur{root}; std::vector<uint8_t> seen(nt, 0); seen[root] = 1;
+      while (!cur.empty()) { lv.push_back(cur); std::vector<int32_t> nxt; for (int u : cur) for (int v : adj[u]) if (tag[v] == mytag && !seen[v]) { seen[v] = 1; nxt.push_back(v); } std::sort(nxt.begin(), nxt.end()); cur.swap(nxt); }
+    };
+    const int kLeaf = 24;
+    std::function<void(std::vector<int32_t>)> nd = [&](std::vector<int32_t> nodes) {
+      if (nodes.empty()) return;
+      const int mytag = ++tagc;
+      for (int u : nodes) tag[u] = mytag;
+      // one connected component at a time
+      std::vector<std::vector<int32_t>> lv;
+      int root = nodes[0];
+      for (int u : nodes) if (adj[u].size() < adj[root].size()) root = u;
+      for (int it = 0; it < 2; ++it) { bfs_levels(root, mytag, lv); int best = lv.back()[0]; for (int u : lv.back()) if (adj[u].size() < adj[best].size()) best = u; root = best; }
+      bfs_levels(root, mytag, lv);
+      size_t reached = 0; for (auto& l : lv) reached += l.size();
+      if (reached < nodes.size()) {               // disconnected: split off this component and recurse on both
+        std::vector<uint8_t> in(nt, 0); std::vector<int32_t> comp, rest;
+        for (auto& l : lv) for (int u : l) { in[u] = 1; comp.push_back(u); }
+        for (int u : nodes) if (!in[u]) rest.push_back(u);
+        nd(comp); nd(rest); return;
+      }
+      if ((int)nodes.size() <= kLeaf || lv.size() < 3) { for (auto& l : lv) for (int u : l) perm.push_back(u); return; }
+      size_t half = nodes.size() / 2, acc = 0, cut = 1;
+      for (size_t l = 0; l < lv.size(); ++l) { acc += lv[l].size(); if (acc >= half) { cut = std::min(std::max<size_t>(l, 1), lv.size() - 2); break; } }
+      std::vector<int32_t> left, right;
+      for (size_t l = 0; l < cut; ++l) left.insert(left.end(), lv[l].begin(), lv[l].end());
+      for (size_t l = cut + 1; l < lv.size(); ++l) right.insert(right.end(), lv[l].begin(), lv[l].end());
+      const std::vector<int32_t> sep = lv[cut];
+      nd(left); nd(right);
+      for (int u : sep) perm.push_back(u);
+    };
+    std::vector<int32_t> sparse_nodes;
+    for (int t = 0; t < nt; ++t) if (!dense[t]) sparse_nodes.push_back(t);
+    // dense tiles are invisible to the dissection
+    for (int t = 0; t < nt; ++t) if (dense[t]) tag[t] = -2;
+    nd(sparse_nodes);
+    for (int t = 0; t < nt; ++t) if (dense[t]) perm.push_back(t);
+    (void)done;
+  }
+  std::vector<int32_t> iperm(nt);
+  for (int k = 0; k < nt; ++k) iperm[perm[k]] = k;
+  // symbolic factorisation in the new order: col[k] = rows i > k of column k (after fill), row[j] = columns k < j of row j
+  std::vector<std::vector<int32_t>> col(nt), row(nt);
   {
     std::vector<std::vector<uint8_t>> mark(nt);
     for (int k = 0; k < nt; ++k) mark[k].assign(nt - k, 0);       // mark[k][i-k] for i >= k
-    for (size_t bidx = 0; bidx < blk_a.size(); ++bidx) { const int ti = blk_a[bidx] / FT, tj = blk_b[bidx] / FT; mark[tj][ti - tj] = 1; }
+    for (int t = 0; t < nt; ++t) for (int u : adj[t]) { const int i = std::max(iperm[t], iperm[u]), k = std::min(iperm[t], iperm[u]); mark[k][i - k] = 1; }
     for (int k = 0; k < nt; ++k) {
-      mark[k][0] = 1;
       for (int i = k + 1; i < nt; ++i) if (mark[k][i - k]) col[k].push_back(i);
       for (size_t u = 0; u < col[k].size(); ++u) for (size_t v = u; v < col[k].size(); ++v) mark[col[k][u]][col[k][v] - col[k][u]] = 1;
+      for (int32_t i : col[k]) row[i].push_back(k);
     }
   }
   // packed tile slots, column by column: (k,k) first, then the sub-diagonal tiles of column k
   std::vector<int32_t> slot_base(nt + 1, 0);
   for (int k = 0; k < nt; ++k) slot_base[k + 1] = slot_base[k] + 1 + (int32_t)col[k].size();
   sv.nslots = slot_base[nt];
-  auto slot_of = [&](int i, int k) -> int32_t {   // -1 if tile (i,k) is structurally zero
+  auto slot_of = [&](int i, int k) -> int32_t {   // new indices, i >= k; -1 if the tile is structurally zero
     if (i == k) return slot_base[k];
     auto it = std::lower_bound(col[k].begin(), col[k].end(), i);
     return (it != col[k].end() && *it == i) ? slot_base[k] + 1 + (int32_t)(it - col[k].begin()) : -1;
   };
-  s->last_diag_slot = slot_base[nt - 1];
-  s->panel_ptr.assign(1, 0); s->trail_ptr.assign(1, 0);
-  for (int k = 0; k < nt; ++k) {
-    s->panel_slot.push_back(slot_base[k]); s->panel_row.push_back(k);
-    s->prev_slot.push_back(k > 0 ? slot_of(k, k - 1) : -1);
-    for (int32_t i : col[k]) {
-      s->panel_slot.push_back(slot_of(i, k)); s->panel_row.push_back(i);
-      s->prev_slot.push_back(k > 0 ? slot_of(i, k - 1) : -1);
-    }
-    s->panel_ptr.push_back((int32_t)s->panel_slot.size());
-    if (k > 0)
-      for (size_t u = 0; u < col[k - 1].size(); ++u) for (size_t v = u; v < col[k - 1].size(); ++v) {
-        const int32_t j = col[k - 1][u], i = col[k - 1][v];
-        if (j > k) { s->trail.push_back(slot_of(i, k - 1)); s->trail.push_back(slot_of(j, k - 1)); s->trail.push_back(slot_of(i, j)); s->trail.push_back(i == j ? i : -1); }
+  s->last_diag_slot = slot_base[iperm[nt - 1]];      // the (possibly padded) last tile of the natural order
+  // level schedule: column j is ready once every column of row[j] is done
+  std::vector<int32_t> level(nt, 0);
+  int nlev = 0;
+  for (int j = 0; j < nt; ++j) { int l = 0; for (int32_t k : row[j]) l = std::max(l, level[k] + 1); level[j] = l; nlev = std::max(nlev, l + 1); }
+  s->nlev = nlev;
+  std::vector<std::vector<int32_t>> lev_cols(nlev);
+  for (int j = 0; j < nt; ++j) lev_cols[level[j]].push_back(j);
+  // flattened work lists (device copies below)
+  //   diag item d: column j -> {slot_jj, old tile of j}, contributors k in row[j]: {slot_jk, old tile of k}
+  //   sub  item t: tile (i,j) -> {slot_ij, slot_jj}, contributors k in row[j] & row[i]: {slot_ik, slot_jk}
+  //   back item  : column j -> {slot_jj, old tile of j}, tiles i in col[j]: {slot_ij, old tile of i}
+  // A tile with many contributors (separator rows are dense across their segments) would serialise dozens
+  // of 48^3 products in one workgroup; its contributor list is cut into chunks of kChunk that separate
+  // workgroups reduce to partial tiles (fixed split, fixed order: still deterministic), summed by the
+  // factor kernels.  upd items: {kind 0 diag / 1 sub, list begin, list end, scratch slot}.
+  const int kChunk = 6;
+  s->lev_diag_ptr.assign(1, 0); s->lev_sub_ptr.assign(1, 0); s->lev_upd_ptr.assign(1, 0);
+  s->diag_ptr.assign(1, 0); s->sub_ptr.assign(1, 0); s->back_ptr.assign(1, 0);
+  int max_parts = 1;
+  for (int l = 0; l < nlev; ++l) {
+    int parts = 0;
+    auto chunk_it = [&](int kind, int32_t p0, int32_t p1, std::vector<int32_t>& info) {
+      if (p1 - p0 <= kChunk) { info.push_back(0); info.push_back(0); return; }
+      info.push_back(parts);
+      int cnt = 0;
+      for (int32_t q = p0; q < p1; q += kChunk) { s->upd.push_back(kind); s->upd.push_back(q); s->upd.push_back(std::min(q + kChunk, p1)); s->upd.push_back(parts++); ++cnt; }
+      info.push_back(cnt);
+    };
+    for (int32_t j : lev_cols[l]) {
+      s->diag_info.push_back(slot_base[j]); s->diag_info.push_back(perm[j]);
+      const int32_t dp0 = (int32_t)(s->diag_list.size() / 2);
+      for (int32_t k : row[j]) { s->diag_list.push_back(slot_of(j, k)); s->diag_list.push_back(perm[k]); }
+      s->diag_ptr.push_back((int32_t)(s->diag_list.size() / 2));
+      chunk_it(0, dp0, (int32_t)(s->diag_list.size() / 2), s->diag_info);
+      s->back_info.push_back(slot_base[j]); s->back_info.push_back(perm[j]);
+      for (int32_t i : col[j]) { s->back_list.push_back(slot_of(i, j)); s->back_list.push_back(perm[i]); }
+      s->back_ptr.push_back((int32_t)(s->back_list.size() / 2));
+      for (int32_t i : col[j]) {
+        s->sub_info.push_back(slot_of(i, j)); s->sub_info.push_back(slot_base[j]);
+        const int32_t sp0 = (int32_t)(s->sub_list.size() / 2);
+        // k in row[j] with tile (i,k) present
+        for (int32_t k : row[j]) { const int32_t sik = slot_of(i, k); if (sik >= 0) { s->sub_list.push_back(sik); s->sub_list.push_back(slot_of(j, k)); } }
+        s->sub_ptr.push_back((int32_t)(s->sub_list.size() / 2));
+        chunk_it(1, sp0, (int32_t)(s->sub_list.size() / 2), s->sub_info);
       }
-    s->trail_ptr.push_back((int32_t)(s->trail.size() / 4));
+    }
+    max_parts = std::max(max_parts, parts);
+    s->lev_diag_ptr.push_back((int32_t)(s->diag_info.size() / 4));
+    s->lev_sub_ptr.push_back((int32_t)(s->sub_info.size() / 4));
+    s->lev_upd_ptr.push_back((int32_t)(s->upd.size() / 4));
   }
   // chunks of the pair lists; blocks cut into more than one chunk are merged in a second pass
   std::vector<int32_t> chunk_blk, multi_first; std::vector<int64_t> chunk_p0;
@@ -226,9 +328,15 @@ int32_t build_solver(rsba_handle* h) {
   }
   sv.nchunk = (int)chunk_blk.size(); sv.nmulti = (int)(multi_first.size() / 2);
   std::vector<int64_t> blk_dst(blk_a.size()), blk_add(blk_a.size(), -1);
+  std::vector<uint8_t> blk_trans(blk_a.size(), 0);
   for (size_t bidx = 0; bidx < blk_a.size(); ++bidx) {
     const int a = blk_a[bidx], b = blk_b[bidx];
-    blk_dst[bidx] = (int64_t)slot_of(a / FT, b / FT) * (kTile * kTile) + (int64_t)(a % FT) * CD * kTile + (int64_t)(b % FT) * CD;
+    {
+      // tile of the block in the permuted order; if the permutation swaps the two tiles the block is stored transposed
+      const int pa = iperm[a / FT], pb = iperm[b / FT];
+      if (pa >= pb) { blk_dst[bidx] = (int64_t)slot_of(pa, pb) * (kTile * kTile) + (int64_t)(a % FT) * CD * kTile + (int64_t)(b % FT) * CD; blk_trans[bidx] = 0; }
+      else { blk_dst[bidx] = (int64_t)slot_of(pb, pa) * (kTile * kTile) + (int64_t)(b % FT) * CD * kTile + (int64_t)(a % FT) * CD; blk_trans[bidx] = 1; }
+    }
     // which J^T J block enters this block of S: U layout [frames][pseudo x frames][pseudo x pseudo]
     if (a < FR) { if (a == b) blk_add[bidx] = (int64_t)a * CD * CD; }
     else if (b < FR) blk_add[bidx] = ((int64_t)FR + (int64_t)(a - FR) * FR + b) * CD * CD;
@@ -276,15 +384,22 @@ int32_t build_solver(rsba_handle* h) {
   if ((rc = s_upload(s, &s->d_obs_slot, obs_slot))) return rc;
   if ((rc = s_upload_const(s, &sv.blk_dst, blk_dst))) return rc;
   if ((rc = s_upload_const(s, &sv.blk_add, blk_add))) return rc;
+  if ((rc = s_upload_const(s, &sv.blk_trans, blk_trans))) return rc;
   if ((rc = s_upload_const(s, &sv.chunk_blk, chunk_blk))) return rc;
   if ((rc = s_upload_const(s, &sv.chunk_p0, chunk_p0))) return rc;
   if ((rc = s_upload_const(s, &sv.multi_first, multi_first))) return rc;
   if ((rc = s_alloc(s, &sv.schur_part, (size_t)sv.nchunk * CD * (CD + 1)))) return rc;
-  if ((rc = s_upload(s, &s->d_panel_ptr, s->panel_ptr))) return rc;
-  if ((rc = s_upload(s, &s->d_panel_slot, s->panel_slot))) return rc;
-  if ((rc = s_upload(s, &s->d_panel_row, s->panel_row))) return rc;
-  if ((rc = s_upload(s, &s->d_prev_slot, s->prev_slot))) return rc;
-  if ((rc = s_upload(s, &s->d_trail, s->trail))) return rc;
+  if ((rc = s_upload(s, &s->d_upd, s->upd))) return rc;
+  if ((rc = s_alloc(s, &sv.chol_part, (size_t)max_parts * (kTile * kTile + kTile)))) return rc;
+  if ((rc = s_upload(s, &s->d_diag_info, s->diag_info))) return rc;
+  if ((rc = s_upload(s, &s->d_diag_ptr, s->diag_ptr))) return rc;
+  if ((rc = s_upload(s, &s->d_diag_list, s->diag_list))) return rc;
+  if ((rc = s_upload(s, &s->d_sub_info, s->sub_info))) return rc;
+  if ((rc = s_upload(s, &s->d_sub_ptr, s->sub_ptr))) return rc;
+  if ((rc = s_upload(s, &s->d_sub_list, s->sub_list))) return rc;
+  if ((rc = s_upload(s, &s->d_back_info, s->back_info))) return rc;
+  if ((rc = s_upload(s, &s->d_back_ptr, s->back_ptr))) return rc;
+  if ((rc = s_upload(s, &s->d_back_list, s->back_list))) return rc;
 
   const size_t REC = 2 + 2 * (size_t)dp.K;
   if ((rc = s_alloc(s, &h->dp.rec, (size_t)N * REC))) return rc;
@@ -367,11 +482,18 @@ int32_t factor_and_solve(rsba_handle* h, double radius) {
   HIP_TRY(launch_schur_blocks(h->dp, sv, radius, st));
   // exchange (2): partial reduced camera systems -> the full one on every rank (then factored redundantly)
   { int32_t rc = exchange(h, sv.S, (int64_t)sv.nslots * kTile * kTile + sv.npad, 0); if (rc) return rc; }
-  for (int k = 0; k < sv.nt; ++k) {
-    const int p0 = s->panel_ptr[k], p1 = s->panel_ptr[k + 1], u0 = s->trail_ptr[k], u1 = s->trail_ptr[k + 1];
-    HIP_TRY(launch_chol_step(sv, k, p1 - p0, s->d_panel_slot + p0, s->d_prev_slot + p0, s->d_trail + 4 * (size_t)u0, u1 - u0, st));
+  // level-scheduled left-looking tile Cholesky (forward solve rides along), then the backward solve
+  for (int l = 0; l < s->nlev; ++l) {
+    const int d0 = s->lev_diag_ptr[l], d1 = s->lev_diag_ptr[l + 1], t0 = s->lev_sub_ptr[l], t1 = s->lev_sub_ptr[l + 1];
+    const int u0 = s->lev_upd_ptr[l], u1 = s->lev_upd_ptr[l + 1];
+    if (u1 > u0) HIP_TRY(launch_chol_update(sv, u1 - u0, s->d_upd + 4 * (size_t)u0, s->d_diag_list, s->d_sub_list, st));
+    HIP_TRY(launch_chol_diag(sv, d1 - d0, s->d_diag_info + 4 * (size_t)d0, s->d_diag_ptr + d0, s->d_diag_list, st));
+    if (t1 > t0) HIP_TRY(launch_chol_sub(sv, t1 - t0, s->d_sub_info + 4 * (size_t)t0, s->d_sub_ptr + t0, s->d_sub_list, st));
   }
-  HIP_TRY(launch_chol_backsolve(sv, s->d_panel_ptr, s->d_panel_slot, s->d_panel_row, st));
+  for (int l = s->nlev - 1; l >= 0; --l) {
+    const int d0 = s->lev_diag_ptr[l], d1 = s->lev_diag_ptr[l + 1];
+    HIP_TRY(launch_chol_back(sv, d1 - d0, s->d_back_info + 2 * (size_t)d0, s->d_back_ptr + d0, s->d_back_list, st));
+  }
   HIP_TRY(launch_back_substitute(h->dp, sv, st));
   return RSBA_OK;
 }

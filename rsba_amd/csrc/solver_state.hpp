@@ -43,6 +43,7 @@ struct SolverDev {
   const int32_t* pair_b;        // slot in frame b (same point)
   const int64_t* blk_dst;       // [nblk] offset of the block's (0,0) entry inside the packed tile array S
   const int64_t* blk_add;       // [nblk] offset into U of the J^T J block to add (diagonal / border blocks), -1 = none
+  const uint8_t* blk_trans;     // [nblk] 1 = the tile ordering swapped the block's two tiles: store it transposed
   // pair lists cut into chunks of kSchurChunk so no wave walks a 2000-pair diagonal block alone
   int nchunk;
   const int32_t* chunk_blk;     // [nchunk]
@@ -64,6 +65,7 @@ struct SolverDev {
   double* z;                    // [M][3]
   double* Pm;                   // [N + M*NPF][CD*3]  point-major, virtual records behind the real ones
   double* S;                    // [nslots][kTile][kTile] packed tiles of the reduced camera system / its factor
+  double* chol_part;            // [max chunks per level][kTile*kTile + kTile] partial update tiles (+ rhs partials)
   double* rhs;                  // [npad] directly behind S (one exchange buffer) -> z (forward) -> y_c (backward)
   double* udiag;                // [F*CD] diag(U), global after the exchange
   double* xbuf;                 // [2*F*CD + 3] exchange buffer: g_c | diag(U) | cost, fixed cost, failed blocks
