@@ -49,6 +49,19 @@ __device__ __forceinline__ void load_tile(double* dst, const double* src, int ti
 __device__ __forceinline__ void store_tile(double* dst, const double* src, int tid) {
   for (int e = tid; e < T * T; e += 256) dst[e] = src[(e / T) * TP + e % T];
 }
+// A tile in flight: each of the 256 threads holds 9 of its 2304 doubles, so the HBM/L2 latency of the next
+// contributor overlaps the 48^3 product on the current one.
+struct TileRegs {
+  double v[9];
+  __device__ __forceinline__ void fetch(const double* src, int tid) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) v[k] = src[tid + 256 * k];
+  }
+  __device__ __forceinline__ void commit(double* lds, int tid) const {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { const int e = tid + 256 * k; lds[(e / T) * TP + e % T] = v[k]; }
+  }
+};
 
 // C -= A B^T on T x T tiles in LDS; 256 threads as 16 x 16, each a 3 x 3 micro-tile over K = 48
 __device__ __forceinline__ void tile_gemm_sub(double* C, const double* A, const double* B, int tid) {
@@ -182,11 +195,18 @@ __global__ __launch_bounds__(256) void chol_update_kernel(const SolverDev sv, co
   const int ty = tid >> 4, tx = tid & 15;
   double acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
   double bacc = 0.0;
+  TileRegs ra, rb;
+  ra.fetch(tile_ptr(sv, list[2 * u[1]]), tid);
+  if (!diag) rb.fetch(tile_ptr(sv, list[2 * u[1] + 1]), tid);
   for (int p = u[1]; p < u[2]; ++p) {
     __syncthreads();
-    load_tile(A, tile_ptr(sv, list[2 * p]), tid, false);
-    if (!diag) load_tile(B, tile_ptr(sv, list[2 * p + 1]), tid, false);
+    ra.commit(A, tid);
+    if (!diag) rb.commit(B, tid);
     __syncthreads();
+    if (p + 1 < u[2]) {   // next contributor's tiles travel while this one is multiplied
+      ra.fetch(tile_ptr(sv, list[2 * (p + 1)]), tid);
+      if (!diag) rb.fetch(tile_ptr(sv, list[2 * (p + 1) + 1]), tid);
+    }
     const double* Bm = diag ? A : B;
 #pragma unroll 4
     for (int m = 0; m < T; ++m) {
@@ -230,9 +250,12 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(const SolverDev sv, cons
     if (tid < T) bvec[tid] -= part[T * T + tid];
   }
   if (nparts > 0) __syncthreads();
+  TileRegs ra;
+  if (nparts == 0 && ptr[b] < ptr[b + 1]) ra.fetch(tile_ptr(sv, list[2 * ptr[b]]), tid);
   for (int p = ptr[b]; nparts == 0 && p < ptr[b + 1]; ++p) {
-    load_tile(A, tile_ptr(sv, list[2 * p]), tid, false);
+    ra.commit(A, tid);
     __syncthreads();
+    if (p + 1 < ptr[b + 1]) ra.fetch(tile_ptr(sv, list[2 * (p + 1)]), tid);
     tile_gemm_sub(D, A, A, tid);
     if (tid < T) {
       const double* z = sv.rhs + (size_t)list[2 * p + 1] * T;
@@ -279,10 +302,12 @@ __global__ __launch_bounds__(256) void chol_sub_kernel(const SolverDev sv, const
     for (int e = tid; e < T * T; e += 256) X[(e / T) * TP + e % T] -= part[e];
   }
   if (nparts > 0) __syncthreads();
+  TileRegs ra, rb;
+  if (nparts == 0 && ptr[b] < ptr[b + 1]) { ra.fetch(tile_ptr(sv, list[2 * ptr[b]]), tid); rb.fetch(tile_ptr(sv, list[2 * ptr[b] + 1]), tid); }
   for (int p = ptr[b]; nparts == 0 && p < ptr[b + 1]; ++p) {
-    load_tile(A, tile_ptr(sv, list[2 * p]), tid, false);
-    load_tile(B, tile_ptr(sv, list[2 * p + 1]), tid, false);
+    ra.commit(A, tid); rb.commit(B, tid);
     __syncthreads();
+    if (p + 1 < ptr[b + 1]) { ra.fetch(tile_ptr(sv, list[2 * (p + 1)]), tid); rb.fetch(tile_ptr(sv, list[2 * (p + 1) + 1]), tid); }
     tile_gemm_sub(X, A, B, tid);
     __syncthreads();
   }
