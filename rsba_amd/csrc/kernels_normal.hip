@@ -382,128 +382,126 @@ __global__ __launch_bounds__(256) void project_kernel(const DeviceProblem dp, co
   }
 }
 
-// rows beyond the real system (npad > n) are identity padding inside the last diagonal tile
-__global__ void pad_system_kernel(const SolverDev sv, int last_diag_slot) {
-  const int r = threadIdx.x;
-  const int64_t row = (int64_t)(sv.nt - 1) * kTile + r;
-  if (r < kTile && row >= sv.n) { sv.S[(size_t)last_diag_slot * (kTile * kTile) + r * kTile + r] = sv.lead ? 1.0 : 0.0; sv.rhs[row] = 0.0; }
-}
-
 // ---------------------------------------------------------------------------------------------
-// K5c  reduced camera system, one wave per structurally non-zero CDxCD block (a >= b):
-//   S_ab = [a==b](U_a + D_c^2) - sum_{pairs (o in a, o' in b) of one point} P_o P_o'^T ;  rhs_a = g_a - sum_{o in a} P_o z
-// 60/CD pair slots per wave step: lane = (slot q, row r) owns row r of the block for its slot's pair;
-// P_o' is read with wave-wide broadcast addresses (12 lanes share each address).  The per-block pair
-// lists come from the symbolic phase, so there are no atomics and the summation order is fixed.
+// K5c  reduced camera system  S = U + D_c^2 - sum_j (sum_a P_aj)(sum_b P_bj)^T ,  rhs = g_c - sum P z
+// Work unit = ENTRY (point j, frame tiles I >= J): the point's P records in the FT frames of I and of J.
+// One workgroup per chunk of kSchurChunk entries; its 4 waves split the b-frames, lane (ia, r) of a wave
+// owns row r of the blocks (I*FT+ia, J*FT+ib) for the wave's ib.  Its own P row is a per-lane load; the P record of each b-frame is addressed
+// uniformly across the wave (one record, broadcast), so per entry every P record is fetched once for
+// FT x FT block products: 4x less traffic than a per-block pair list.  Chunks write partial tiles; the
+// merge kernel sums them in chunk order (fixed order, no atomics) and adds U, D_c^2, g_c.
 // ---------------------------------------------------------------------------------------------
-// final value of row r of block blk:  S_ab = [a==b](U_a + D_c^2) - acc ;  rhs_a = g_a - racc
 template <int CD>
-__device__ __forceinline__ void schur_store_row(const SolverDev& sv, int blk, int r, const double* acc, double racc, double inv_radius) {
-  const int a = sv.blk_a[blk], b = sv.blk_b[blk];
-  const int64_t add = sv.blk_add[blk];
-  if (sv.blk_trans[blk]) {
-    // the tile ordering put frame b's tile below frame a's: this block lives transposed in tile (tb, ta)
-    double* scol = sv.S + sv.blk_dst[blk] + r;
-    const double* urow = add >= 0 ? sv.U + add + (size_t)r * CD : nullptr;
+__global__ __launch_bounds__(256) void schur_tile_kernel(const SolverDev sv, const double* __restrict__ Pm, const double* __restrict__ zz) {
+  constexpr int FT = kTile / CD, PW = CD * 3;          // frames per tile, doubles per P record
+  constexpr int NREC = 2 * FT, ENT = NREC * PW;         // records / doubles staged per entry (288 doubles = 2304 B)
+  constexpr int IBW = FT / 4;                           // b-frames per wave (the 4 waves split the block columns)
+  constexpr int DEPTH = 4;                              // entries in flight (register ring)
+  __shared__ __attribute__((aligned(16))) double s_buf[2][ENT];
+  __shared__ int32_t s_slot[kSchurChunk * NREC];
+  __shared__ int32_t s_pt[kSchurChunk];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int chunk = blockIdx.x;
+  const int ia = lane / CD, r = lane % CD;
+  const bool active = ia < FT;
+  const int tp = sv.chunk_tp[chunk];
+  const int64_t e0 = sv.chunk_e0[chunk];
+  const int64_t eend = sv.tp_ptr[tp + 1];
+  const int n = (int)((e0 + kSchurChunk < eend ? e0 + kSchurChunk : eend) - e0);
+  // the chunk's slot table goes to LDS once (coalesced), so the record loads below do not wait on it
+  for (int k = tid; k < n * NREC; k += 256) s_slot[k] = sv.ent_slots[(size_t)e0 * NREC + k];
+  for (int k = tid; k < n; k += 256) s_pt[k] = sv.ent_pt[e0 + k];
+  __syncthreads();
+  double acc[IBW][CD], racc = 0.0;
 #pragma unroll
-    for (int c = 0; c < CD; ++c) scol[(size_t)c * kTile] = (urow ? urow[c] : 0.0) - acc[c];
-    return;
-  }
-  double* srow = sv.S + sv.blk_dst[blk] + (size_t)r * kTile;
-  if (a == b) {
-    const double* urow = sv.U + add + (size_t)r * CD;
+  for (int u = 0; u < IBW; ++u)
 #pragma unroll
-    for (int c = 0; c < CD; ++c) srow[c] = urow[c] + ((c == r && sv.lead) ? sv.diag_c[(size_t)a * CD + r] * inv_radius : 0.0) - acc[c];
-    sv.rhs[(size_t)a * CD + r] = (sv.lead ? sv.gc[(size_t)a * CD + r] : 0.0) - racc;
-  } else if (add >= 0) {
-    const double* urow = sv.U + add + (size_t)r * CD;     // intrinsics x frame border block
-#pragma unroll
-    for (int c = 0; c < CD; ++c) srow[c] = urow[c] - acc[c];
-  } else {
-#pragma unroll
-    for (int c = 0; c < CD; ++c) srow[c] = -acc[c];
-  }
-}
+    for (int c = 0; c < CD; ++c) acc[u][c] = 0.0;
 
-template <int CD>
-__global__ __launch_bounds__(256) void schur_blocks_kernel(const DeviceProblem dp, const SolverDev sv, double inv_radius) {
-  constexpr int NG = 60 / CD;
-  const int lane = threadIdx.x & 63;
-  const int chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (chunk >= sv.nchunk) return;
-  const int q = lane / CD, r = lane % CD;
-  const bool active = q < NG;
-  const int blk = sv.chunk_blk[chunk];
-  const bool diag = sv.blk_a[blk] == sv.blk_b[blk];
-  const int64_t p0 = sv.chunk_p0[chunk];
-  const int64_t pend = sv.blk_ptr[blk + 1];
-  const int64_t p1 = (p0 + kSchurChunk < pend) ? p0 + kSchurChunk : pend;
-  double acc[CD], racc = 0.0;
+  // The workgroup stages the 2*FT P records of entry e+DEPTH (one coalesced 16-B load per thread; a point
+  // that is not observed in a frame points at an all-zero record) while it multiplies entry e out of LDS:
+  // the record loads are DEPTH entries ahead of their use and every record is fetched once per entry.
+  const bool loader = tid < ENT / 2;
+  const int lq = tid / (PW / 2), lw = tid % (PW / 2);
+  double2 st[DEPTH];
+  auto fetch = [&](int k) -> double2 {
+    if (!loader || k >= n) return make_double2(0.0, 0.0);
+    return *reinterpret_cast<const double2*>(Pm + (size_t)s_slot[k * NREC + lq] * PW + 2 * lw);
+  };
 #pragma unroll
-  for (int c = 0; c < CD; ++c) acc[c] = 0.0;
-  for (int64_t base = p0; base < p1; base += NG) {
-    const int64_t p = base + q;
-    if (active && p < p1) {
-      const int sa = sv.pair_a[p], sb = sv.pair_b[p];
-      const double* pa = sv.Pm + (size_t)sa * (CD * 3) + r * 3;
-      const double2* pb = reinterpret_cast<const double2*>(sv.Pm + (size_t)sb * (CD * 3));   // records are 16-B aligned
-      const double x0 = pa[0], x1 = pa[1], x2 = pa[2];
-      double w[CD * 3];
+  for (int d = 0; d < DEPTH; ++d) st[d] = fetch(d);
+  for (int base = 0; base < n; base += DEPTH) {
 #pragma unroll
-      for (int k = 0; k < CD * 3 / 2; ++k) { const double2 v = pb[k]; w[2 * k] = v.x; w[2 * k + 1] = v.y; }
+    for (int d = 0; d < DEPTH; ++d) {
+      const int k = base + d;
+      if (k < n) {                                       // n is uniform across the workgroup
+        const int cur = d & 1;
+        if (loader) *reinterpret_cast<double2*>(&s_buf[cur][2 * tid]) = st[d];
+        __syncthreads();
+        st[d] = fetch(k + DEPTH);
+        const double* buf = s_buf[cur];
+        double x0 = 0.0, x1 = 0.0, x2 = 0.0;
+        if (active) { const double* pa = buf + ia * PW + r * 3; x0 = pa[0]; x1 = pa[1]; x2 = pa[2]; }
 #pragma unroll
-      for (int c = 0; c < CD; ++c) acc[c] += x0 * w[c * 3] + x1 * w[c * 3 + 1] + x2 * w[c * 3 + 2];
-      if (diag && sa == sb) {
-        const double* z = sv.z + (size_t)sv.slot_point[sa] * 3;
-        racc += x0 * z[0] + x1 * z[1] + x2 * z[2];
+        for (int u = 0; u < IBW; ++u) {
+          const double2* pb = reinterpret_cast<const double2*>(buf + (FT + wave * IBW + u) * PW);   // one address per wave: LDS broadcast
+          double w[PW];
+#pragma unroll
+          for (int q = 0; q < PW / 2; ++q) { const double2 v = pb[q]; w[2 * q] = v.x; w[2 * q + 1] = v.y; }
+#pragma unroll
+          for (int c = 0; c < CD; ++c) acc[u][c] += x0 * w[c * 3] + x1 * w[c * 3 + 1] + x2 * w[c * 3 + 2];
+        }
+        if (wave == 0) {
+          const int pt = s_pt[k];
+          if (pt < 0) {   // top bit: diagonal entry of the point -> rhs term
+            const double* z = zz + (size_t)(pt & 0x7fffffff) * 3;
+            racc += x0 * z[0] + x1 * z[1] + x2 * z[2];
+          }
+        }
       }
     }
   }
-  // fold the NG pair slots onto slot 0 in a fixed order
+  if (active) {
+    double* part = sv.schur_part + (size_t)chunk * (kTile * kTile + kTile);
+    double* prow = part + (size_t)(ia * CD + r) * kTile;
 #pragma unroll
-  for (int c = 0; c < CD; ++c) {
-    double t = acc[c];
+    for (int u = 0; u < IBW; ++u)
 #pragma unroll
-    for (int g = 1; g < NG; ++g) t += __shfl(acc[c], r + CD * g, 64);
-    acc[c] = t;
-  }
-  {
-    double t = racc;
-#pragma unroll
-    for (int g = 1; g < NG; ++g) t += __shfl(racc, r + CD * g, 64);
-    racc = t;
-  }
-  if (q == 0) {
-    const bool single = p0 == sv.blk_ptr[blk] && p1 == pend;
-    if (single) schur_store_row<CD>(sv, blk, r, acc, racc, inv_radius);
-    else {
-      // a block split over several chunks: partial rows to scratch, summed in order by schur_merge_kernel
-      double* part = sv.schur_part + (size_t)chunk * (CD * (CD + 1)) + (size_t)r * (CD + 1);
-#pragma unroll
-      for (int c = 0; c < CD; ++c) part[c] = acc[c];
-      part[CD] = racc;
-    }
+      for (int c = 0; c < CD; ++c) prow[(wave * IBW + u) * CD + c] = acc[u][c];
+    if (wave == 0) part[kTile * kTile + ia * CD + r] = racc;
   }
 }
 
-// blocks whose pair list was split: sum the chunk partials in chunk order (fixed), then the final store
-template <int CD>
+// one workgroup per tile pair: sum the chunk partials in order, add U / D_c^2 / g_c, identity padding, and
+// store into the packed tile slot (transposed when the tile ordering swapped the pair)
 __global__ __launch_bounds__(256) void schur_merge_kernel(const DeviceProblem dp, const SolverDev sv, double inv_radius) {
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  const int m = t / CD, r = t % CD;
-  if (m >= sv.nmulti) return;
-  const int c0 = sv.multi_first[2 * m], c1 = sv.multi_first[2 * m + 1];
-  const int blk = sv.chunk_blk[c0];
-  double acc[CD], racc = 0.0;
-#pragma unroll
-  for (int c = 0; c < CD; ++c) acc[c] = 0.0;
-  for (int ch = c0; ch < c1; ++ch) {
-    const double* part = sv.schur_part + (size_t)ch * (CD * (CD + 1)) + (size_t)r * (CD + 1);
-#pragma unroll
-    for (int c = 0; c < CD; ++c) acc[c] += part[c];
-    racc += part[CD];
+  const int tp = blockIdx.x, tid = threadIdx.x;
+  const int I = sv.tp_I[tp], J = sv.tp_J[tp], CD = sv.CD, FT = sv.FT;
+  const int c0 = sv.tp_chunk0[tp], c1 = sv.tp_chunk0[tp + 1];
+  double* dst = sv.S + (size_t)sv.tp_dst[tp] * (kTile * kTile);
+  const bool trans = sv.tp_trans[tp] != 0;
+  const size_t pstride = kTile * kTile + kTile;
+  for (int e = tid; e < kTile * kTile; e += 256) {
+    const int rt = e / kTile, ct = e % kTile;
+    const int x = rt / CD, y = ct / CD, r = rt % CD, c = ct % CD;
+    const int a = I * FT + x, b = J * FT + y;
+    double sum = 0.0;
+    for (int ch = c0; ch < c1; ++ch) sum += sv.schur_part[(size_t)ch * pstride + e];
+    double val;
+    if (a >= sv.Fx || b >= sv.Fx) val = (a == b && r == c && sv.lead) ? 1.0 : 0.0;     // padding frames of the last tile
+    else {
+      const int64_t add = sv.tp_add[((size_t)tp * FT + x) * FT + y];
+      val = (add >= 0 ? sv.U[add + (size_t)r * CD + c] : 0.0) - sum;
+      if (a == b && r == c && sv.lead) val += sv.diag_c[(size_t)a * CD + r] * inv_radius;
+    }
+    if (trans) dst[(size_t)ct * kTile + rt] = val; else dst[e] = val;
   }
-  schur_store_row<CD>(sv, blk, r, acc, racc, inv_radius);
+  if (I == J && tid < kTile) {
+    const int a = I * FT + tid / CD;
+    double sum = 0.0;
+    for (int ch = c0; ch < c1; ++ch) sum += sv.schur_part[(size_t)ch * pstride + kTile * kTile + tid];
+    sv.rhs[(size_t)I * kTile + tid] = (a < sv.Fx) ? (sv.lead ? sv.gc[(size_t)I * kTile + tid] : 0.0) - sum : 0.0;
+  }
 }
 
 // K7  back-substitution  y_p = L^-T ( z - sum_o P_o^T y_c(frame(o)) )
@@ -732,21 +730,15 @@ hipError_t launch_virtual_records(const DeviceProblem& dp, const SolverDev& sv, 
   else LAUNCH(virtual_records_kernel<6>, nblocks256(dp.M), 256, st, dp, sv);
   return hipSuccess;
 }
-hipError_t launch_clear_system(const SolverDev& sv, int last_diag_slot, hipStream_t st) {
-  hipError_t e = hipMemsetAsync(sv.S, 0, (size_t)sv.nslots * kTile * kTile * sizeof(double), st);
-  if (e != hipSuccess) return e;
-  if (sv.npad > sv.n) LAUNCH(pad_system_kernel, 1, 64, st, sv, last_diag_slot);
-  return hipSuccess;
+hipError_t launch_clear_system(const SolverDev& sv, hipStream_t st) {
+  return hipMemsetAsync(sv.S, 0, (size_t)sv.nslots * kTile * kTile * sizeof(double), st);
 }
 hipError_t launch_schur_blocks(const DeviceProblem& dp, const SolverDev& sv, double radius, hipStream_t st) {
-  const int grid = (sv.nchunk + 3) / 4;
-  if (sv.CD == 12) LAUNCH(schur_blocks_kernel<12>, grid, 256, st, dp, sv, 1.0 / radius);
-  else LAUNCH(schur_blocks_kernel<6>, grid, 256, st, dp, sv, 1.0 / radius);
-  if (sv.nmulti > 0) {
-    const int g2 = nblocks256((int64_t)sv.nmulti * sv.CD);
-    if (sv.CD == 12) LAUNCH(schur_merge_kernel<12>, g2, 256, st, dp, sv, 1.0 / radius);
-    else LAUNCH(schur_merge_kernel<6>, g2, 256, st, dp, sv, 1.0 / radius);
+  if (sv.nchunk > 0) {
+    if (sv.CD == 12) LAUNCH(schur_tile_kernel<12>, sv.nchunk, 256, st, sv, sv.Pm, sv.z);
+    else LAUNCH(schur_tile_kernel<6>, sv.nchunk, 256, st, sv, sv.Pm, sv.z);
   }
+  LAUNCH(schur_merge_kernel, sv.ntp, 256, st, dp, sv, 1.0 / radius);
   return hipSuccess;
 }
 hipError_t launch_back_substitute(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {

@@ -123,74 +123,88 @@ int32_t build_solver(rsba_handle* h) {
     if (!out.empty()) for (int v = 0; v < NPF; ++v) out.push_back(N + (int64_t)j * NPF + v);
   };
   std::vector<int64_t> pslots;
-  // blocks (a >= b) and their pair lists
-  const bool dense_keys = (int64_t)F * F <= (int64_t)1 << 26;
+  // ---- work list of the point elimination: one ENTRY per (point, pair of frame tiles I >= J) ----
+  // An entry lists the point's observation slot in each of the FT frames of tile I (sa) and of tile J (sb),
+  // -1 where it is not observed.  One wave turns an entry into up to FT x FT block products P_a P_b^T with
+  // every P record loaded once (frame-pair-major accumulation, no atomics).  A point seen
+  // twice in one frame gets a second "layer" of slots and the cross-layer entries.
+  const int nt = sv.nt;
+  const int ES = 2 * FT;                                   // ints per entry
+  struct TileSlots { int tile; std::vector<std::vector<int32_t>> layers; };
+  auto tiles_of = [&](int j, std::vector<TileSlots>& out) {
+    out.clear();
+    slots_of(j, pslots);
+    int prev_frame = -1, layer = 0;
+    for (int64_t sl : pslots) {
+      const int f = slot_frame[sl], tile = f / FT, pos = f % FT;
+      layer = (f == prev_frame) ? layer + 1 : 0; prev_frame = f;
+      if (out.empty() || out.back().tile != tile) out.push_back(TileSlots{tile, {}});
+      auto& L = out.back().layers;
+      while ((int)L.size() <= layer) L.emplace_back(FT, -1);
+      L[layer][pos] = (int32_t)sl;
+    }
+  };
+  const bool dense_keys = (int64_t)nt * nt <= (int64_t)1 << 26;
   std::vector<int64_t> dense_cnt; std::unordered_map<int64_t, int64_t> sparse_cnt;
-  if (dense_keys) dense_cnt.assign((size_t)F * F, -1);
-  auto bump = [&](int a, int b, int64_t by) {
-    const int64_t key = (int64_t)a * F + b;
+  if (dense_keys) dense_cnt.assign((size_t)nt * nt, -1);
+  auto bump = [&](int I, int J, int64_t by) {
+    const int64_t key = (int64_t)I * nt + J;
     if (dense_keys) { int64_t& c = dense_cnt[key]; c = (c < 0 ? 0 : c) + by; }
     else sparse_cnt[key] += by;
   };
-  for (int f = 0; f < F; ++f) bump(f, f, 0);   // every frame owns a diagonal block (it carries U_f + D^2 and rhs_f)
-  if (!h->union_mask.empty())                    // multi-GPU: blocks other ranks fill, so every rank shares one tile layout
-    for (int a = 0; a < FR; ++a) for (int b = 0; b <= a; ++b) if (h->union_mask[(size_t)a * FR + b]) bump(a, b, 0);
-  for (int v = 0; v < NPF; ++v) for (int b = 0; b < FR + v; ++b) bump(FR + v, b, 0);   // the intrinsics border is dense
+  for (int I = 0; I < nt; ++I) bump(I, I, 0);                // every diagonal tile exists (U + D^2, rhs)
+  if (!h->union_mask.empty())                                  // multi-GPU: tiles other ranks fill, so all ranks share one layout
+    for (int a = 0; a < FR; ++a) for (int b = 0; b <= a; ++b) if (h->union_mask[(size_t)a * FR + b]) bump(a / FT, b / FT, 0);
+  for (int v = 0; v < NPF; ++v) for (int b = 0; b < FR + v; ++b) bump((FR + v) / FT, b / FT, 0);   // the intrinsics border is dense
+  std::vector<TileSlots> ptiles;
   for (int j = 0; j < M; ++j) {
-    slots_of(j, pslots);
-    for (size_t xi = 0; xi < pslots.size(); ++xi)
-      for (size_t yi = 0; yi <= xi; ++yi) {
-        const int a = slot_frame[pslots[xi]], b = slot_frame[pslots[yi]];
-        if (a == b) bump(a, a, xi == yi ? 1 : 2); else bump(a, b, 1);
-      }
+    tiles_of(j, ptiles);
+    for (size_t x = 0; x < ptiles.size(); ++x) for (size_t y = 0; y <= x; ++y)
+      bump(ptiles[x].tile, ptiles[y].tile, (int64_t)ptiles[x].layers.size() * ptiles[y].layers.size());
   }
-  std::vector<int32_t> blk_a, blk_b; std::vector<int64_t> blk_ptr(1, 0);
-  std::unordered_map<int64_t, int32_t> blk_index;
-  std::vector<int32_t> dense_index;
+  std::vector<int32_t> tp_I, tp_J; std::vector<int64_t> tp_ptr(1, 0);
+  std::unordered_map<int64_t, int32_t> tp_index; std::vector<int32_t> dense_index;
   if (dense_keys) {
-    dense_index.assign((size_t)F * F, -1);
-    for (int a = 0; a < F; ++a) for (int b = 0; b <= a; ++b) {
-      const int64_t c = dense_cnt[(size_t)a * F + b];
-      if (c >= 0) { dense_index[(size_t)a * F + b] = (int32_t)blk_a.size(); blk_a.push_back(a); blk_b.push_back(b); blk_ptr.push_back(blk_ptr.back() + c); }
+    dense_index.assign((size_t)nt * nt, -1);
+    for (int I = 0; I < nt; ++I) for (int J = 0; J <= I; ++J) {
+      const int64_t c = dense_cnt[(size_t)I * nt + J];
+      if (c >= 0) { dense_index[(size_t)I * nt + J] = (int32_t)tp_I.size(); tp_I.push_back(I); tp_J.push_back(J); tp_ptr.push_back(tp_ptr.back() + c); }
     }
     std::vector<int64_t>().swap(dense_cnt);
   } else {
     std::vector<int64_t> keys; keys.reserve(sparse_cnt.size());
     for (auto& kv : sparse_cnt) keys.push_back(kv.first);
     std::sort(keys.begin(), keys.end());
-    for (int64_t key : keys) { blk_index[key] = (int32_t)blk_a.size(); blk_a.push_back((int32_t)(key / F)); blk_b.push_back((int32_t)(key % F)); blk_ptr.push_back(blk_ptr.back() + sparse_cnt[key]); }
+    for (int64_t key : keys) { tp_index[key] = (int32_t)tp_I.size(); tp_I.push_back((int32_t)(key / nt)); tp_J.push_back((int32_t)(key % nt)); tp_ptr.push_back(tp_ptr.back() + sparse_cnt[key]); }
   }
-  auto index_of = [&](int a, int b) -> int32_t { return dense_keys ? dense_index[(size_t)a * F + b] : blk_index[(int64_t)a * F + b]; };
-  const int64_t npairs = blk_ptr.back();
-  std::vector<int32_t> pair_a(npairs), pair_b(npairs);
+  auto index_of = [&](int I, int J) -> int32_t { return dense_keys ? dense_index[(size_t)I * nt + J] : tp_index[(int64_t)I * nt + J]; };
+  const int64_t nent = tp_ptr.back();
+  std::vector<int32_t> ent_slots((size_t)nent * ES), ent_pt(nent);
   {
-    std::vector<int64_t> fill(blk_ptr.begin(), blk_ptr.end() - 1);
+    std::vector<int64_t> fill(tp_ptr.begin(), tp_ptr.end() - 1);
     for (int j = 0; j < M; ++j) {
-      slots_of(j, pslots);
-      for (size_t xi = 0; xi < pslots.size(); ++xi)
-        for (size_t yi = 0; yi <= xi; ++yi) {
-          const int64_t x = pslots[xi], y = pslots[yi];
-          const int a = slot_frame[x], b = slot_frame[y];
-          const int32_t bi = index_of(a, b);
-          int64_t& w = fill[bi];
-          pair_a[w] = (int32_t)x; pair_b[w] = (int32_t)y; ++w;
-          if (a == b && x != y) { pair_a[w] = (int32_t)y; pair_b[w] = (int32_t)x; ++w; }
+      tiles_of(j, ptiles);
+      for (size_t x = 0; x < ptiles.size(); ++x) for (size_t y = 0; y <= x; ++y) {
+        int64_t& w = fill[index_of(ptiles[x].tile, ptiles[y].tile)];
+        for (size_t lx = 0; lx < ptiles[x].layers.size(); ++lx) for (size_t ly = 0; ly < ptiles[y].layers.size(); ++ly) {
+          for (int q = 0; q < FT; ++q) {
+            const int32_t a_ = ptiles[x].layers[lx][q], b_ = ptiles[y].layers[ly][q];
+            ent_slots[(size_t)w * ES + q] = a_ >= 0 ? a_ : (int32_t)NS;          // NS = the all-zero record behind the last slot
+            ent_slots[(size_t)w * ES + FT + q] = b_ >= 0 ? b_ : (int32_t)NS;
+          }
+          ent_pt[w] = j | ((x == y && lx == ly) ? (int32_t)0x80000000 : 0);   // top bit: the entry carries the rhs term P z
+          ++w;
         }
+      }
     }
   }
   std::vector<int32_t>().swap(dense_index);
-  sv.nblk = (int)blk_a.size();
-  s->num_pairs = npairs;
+  const int ntp = (int)tp_I.size();
+  s->num_pairs = nent;
 
   // ---- tile graph of S, fill-reducing / parallelism-exposing ordering, symbolic factorisation ----
-  const int nt = sv.nt;
   std::vector<std::vector<int32_t>> adj(nt);
-  {
-    std::vector<std::pair<int32_t, int32_t>> edges;
-    for (size_t bidx = 0; bidx < blk_a.size(); ++bidx) { const int ti = blk_a[bidx] / FT, tj = blk_b[bidx] / FT; if (ti != tj) edges.emplace_back(ti, tj); }
-    std::sort(edges.begin(), edges.end()); edges.erase(std::unique(edges.begin(), edges.end()), edges.end());
-    for (auto& e : edges) { adj[e.first].push_back(e.second); adj[e.second].push_back(e.first); }
-  }
+  for (int t = 0; t < ntp; ++t) if (tp_I[t] != tp_J[t]) { adj[tp_I[t]].push_back(tp_J[t]); adj[tp_J[t]].push_back(tp_I[t]); }
   // Nested dissection by BFS level structures (George): a video's co-visibility graph is a band, whose BFS
   // levels are band-wide separators; cutting it into independent segments turns the factorisation's
   // serial tile chain into a shallow elimination tree that the level-scheduled kernels run in parallel.
@@ -316,31 +330,30 @@ int32_t build_solver(rsba_handle* h) {
     s->lev_sub_ptr.push_back((int32_t)(s->sub_info.size() / 4));
     s->lev_upd_ptr.push_back((int32_t)(s->upd.size() / 4));
   }
-  // chunks of the pair lists; blocks cut into more than one chunk are merged in a second pass
-  std::vector<int32_t> chunk_blk, multi_first; std::vector<int64_t> chunk_p0;
-  for (size_t bidx = 0; bidx < blk_a.size(); ++bidx) {
-    const int64_t b0 = blk_ptr[bidx], b1 = blk_ptr[bidx + 1];
-    const int32_t first = (int32_t)chunk_blk.size();
-    int64_t q0 = b0;
-    do { chunk_blk.push_back((int32_t)bidx); chunk_p0.push_back(q0); q0 += kSchurChunk; } while (q0 < b1);
-    const int32_t end_ = (int32_t)chunk_blk.size();
-    if (end_ - first > 1) { multi_first.push_back(first); multi_first.push_back(end_); }
+  // chunks of kSchurChunk entries (one wave each) and, per tile pair, where the merged tile goes
+  std::vector<int32_t> chunk_tp; std::vector<int64_t> chunk_e0; std::vector<int32_t> tp_chunk0(ntp + 1, 0);
+  for (int t = 0; t < ntp; ++t) {
+    tp_chunk0[t] = (int32_t)chunk_tp.size();
+    for (int64_t q0 = tp_ptr[t]; q0 < tp_ptr[t + 1]; q0 += kSchurChunk) { chunk_tp.push_back(t); chunk_e0.push_back(q0); }
   }
-  sv.nchunk = (int)chunk_blk.size(); sv.nmulti = (int)(multi_first.size() / 2);
-  std::vector<int64_t> blk_dst(blk_a.size()), blk_add(blk_a.size(), -1);
-  std::vector<uint8_t> blk_trans(blk_a.size(), 0);
-  for (size_t bidx = 0; bidx < blk_a.size(); ++bidx) {
-    const int a = blk_a[bidx], b = blk_b[bidx];
-    {
-      // tile of the block in the permuted order; if the permutation swaps the two tiles the block is stored transposed
-      const int pa = iperm[a / FT], pb = iperm[b / FT];
-      if (pa >= pb) { blk_dst[bidx] = (int64_t)slot_of(pa, pb) * (kTile * kTile) + (int64_t)(a % FT) * CD * kTile + (int64_t)(b % FT) * CD; blk_trans[bidx] = 0; }
-      else { blk_dst[bidx] = (int64_t)slot_of(pb, pa) * (kTile * kTile) + (int64_t)(b % FT) * CD * kTile + (int64_t)(a % FT) * CD; blk_trans[bidx] = 1; }
+  tp_chunk0[ntp] = (int32_t)chunk_tp.size();
+  sv.nchunk = (int)chunk_tp.size(); sv.ntp = ntp; sv.FT = FT;
+  std::vector<int32_t> tp_dst(ntp); std::vector<uint8_t> tp_trans(ntp, 0);
+  std::vector<int64_t> tp_add((size_t)ntp * FT * FT, -1);
+  for (int t = 0; t < ntp; ++t) {
+    const int I = tp_I[t], J = tp_J[t], pI = iperm[I], pJ = iperm[J];
+    // tile of the pair in the permuted order; if the ordering swapped the two tiles it is stored transposed
+    if (pI >= pJ) tp_dst[t] = slot_of(pI, pJ); else { tp_dst[t] = slot_of(pJ, pI); tp_trans[t] = 1; }
+    // which J^T J block enters block (a,b) of this tile: U layout [frames][pseudo x frames][pseudo x pseudo]
+    for (int x = 0; x < FT; ++x) for (int y = 0; y < FT; ++y) {
+      const int a = I * FT + x, b = J * FT + y;
+      if (a >= F || b >= F || a < b) continue;
+      int64_t add = -1;
+      if (a < FR) { if (a == b) add = (int64_t)a * CD * CD; }
+      else if (b < FR) add = ((int64_t)FR + (int64_t)(a - FR) * FR + b) * CD * CD;
+      else add = ((int64_t)FR + (int64_t)NPF * FR + (int64_t)(a - FR) * NPF + (b - FR)) * CD * CD;
+      tp_add[((size_t)t * FT + x) * FT + y] = add;
     }
-    // which J^T J block enters this block of S: U layout [frames][pseudo x frames][pseudo x pseudo]
-    if (a < FR) { if (a == b) blk_add[bidx] = (int64_t)a * CD * CD; }
-    else if (b < FR) blk_add[bidx] = ((int64_t)FR + (int64_t)(a - FR) * FR + b) * CD * CD;
-    else blk_add[bidx] = ((int64_t)FR + (int64_t)NPF * FR + (int64_t)(a - FR) * NPF + (b - FR)) * CD * CD;
   }
 
   // which coordinates belong to the reduced program (for |x| and |step|): blocks that are not constant
@@ -373,22 +386,22 @@ int32_t build_solver(rsba_handle* h) {
   if ((rc = s_upload_const(s, &sv.point_ptr, point_ptr))) return rc;
   if ((rc = s_upload_const(s, &sv.slot_frame, slot_frame))) return rc;
   if ((rc = s_upload_const(s, &sv.slot_point, slot_point))) return rc;
-  if ((rc = s_upload_const(s, &sv.blk_a, blk_a))) return rc;
-  if ((rc = s_upload_const(s, &sv.blk_b, blk_b))) return rc;
-  if ((rc = s_upload_const(s, &sv.blk_ptr, blk_ptr))) return rc;
-  if ((rc = s_upload_const(s, &sv.pair_a, pair_a))) return rc;
-  if ((rc = s_upload_const(s, &sv.pair_b, pair_b))) return rc;
+  if ((rc = s_upload_const(s, &sv.tp_I, tp_I))) return rc;
+  if ((rc = s_upload_const(s, &sv.tp_J, tp_J))) return rc;
+  if ((rc = s_upload_const(s, &sv.tp_ptr, tp_ptr))) return rc;
+  if ((rc = s_upload_const(s, &sv.ent_slots, ent_slots))) return rc;
+  if ((rc = s_upload_const(s, &sv.ent_pt, ent_pt))) return rc;
   if ((rc = s_upload_const(s, &sv.inprog_pose, inprog_pose))) return rc;
   if ((rc = s_upload_const(s, &sv.inprog_point, inprog_point))) return rc;
   if ((rc = s_upload_const(s, &sv.inprog_intr, inprog_intr))) return rc;
   if ((rc = s_upload(s, &s->d_obs_slot, obs_slot))) return rc;
-  if ((rc = s_upload_const(s, &sv.blk_dst, blk_dst))) return rc;
-  if ((rc = s_upload_const(s, &sv.blk_add, blk_add))) return rc;
-  if ((rc = s_upload_const(s, &sv.blk_trans, blk_trans))) return rc;
-  if ((rc = s_upload_const(s, &sv.chunk_blk, chunk_blk))) return rc;
-  if ((rc = s_upload_const(s, &sv.chunk_p0, chunk_p0))) return rc;
-  if ((rc = s_upload_const(s, &sv.multi_first, multi_first))) return rc;
-  if ((rc = s_alloc(s, &sv.schur_part, (size_t)sv.nchunk * CD * (CD + 1)))) return rc;
+  if ((rc = s_upload_const(s, &sv.chunk_tp, chunk_tp))) return rc;
+  if ((rc = s_upload_const(s, &sv.chunk_e0, chunk_e0))) return rc;
+  if ((rc = s_upload_const(s, &sv.tp_chunk0, tp_chunk0))) return rc;
+  if ((rc = s_upload_const(s, &sv.tp_dst, tp_dst))) return rc;
+  if ((rc = s_upload_const(s, &sv.tp_trans, tp_trans))) return rc;
+  if ((rc = s_upload_const(s, &sv.tp_add, tp_add))) return rc;
+  if ((rc = s_alloc(s, &sv.schur_part, (size_t)std::max(sv.nchunk, 1) * (kTile * kTile + kTile)))) return rc;
   if ((rc = s_upload(s, &s->d_upd, s->upd))) return rc;
   if ((rc = s_alloc(s, &sv.chol_part, (size_t)max_parts * (kTile * kTile + kTile)))) return rc;
   if ((rc = s_upload(s, &s->d_diag_info, s->diag_info))) return rc;
@@ -415,7 +428,9 @@ int32_t build_solver(rsba_handle* h) {
   if ((rc = s_alloc(s, &sv.diag_p, (size_t)M * 3))) return rc;
   if ((rc = s_alloc(s, &sv.Linv, (size_t)M * 6))) return rc;
   if ((rc = s_alloc(s, &sv.z, (size_t)M * 3))) return rc;
-  if ((rc = s_alloc(s, &sv.Pm, (size_t)NS * CD * 3))) return rc;
+  if ((rc = s_alloc(s, &sv.Pm, (size_t)(NS + 1) * CD * 3))) return rc;
+  HIP_TRY(hipMemset(sv.Pm + (size_t)NS * CD * 3, 0, (size_t)CD * 3 * sizeof(double)));   // record NS: "not observed"
+
   if ((rc = s_alloc(s, &sv.S, (size_t)sv.nslots * kTile * kTile + (size_t)sv.npad))) return rc;
   sv.rhs = sv.S + (size_t)sv.nslots * kTile * kTile;   // one buffer = exchange payload (2)
   if ((rc = s_alloc(s, &sv.udiag, (size_t)F * CD))) return rc;
@@ -478,7 +493,7 @@ int32_t factor_and_solve(rsba_handle* h, double radius) {
   HIP_TRY(launch_point_factor(h->dp, sv, radius, st));
   HIP_TRY(launch_project(h->dp, sv, st));
   HIP_TRY(launch_virtual_records(h->dp, sv, st));
-  HIP_TRY(launch_clear_system(sv, s->last_diag_slot, st));
+  HIP_TRY(launch_clear_system(sv, st));
   HIP_TRY(launch_schur_blocks(h->dp, sv, radius, st));
   // exchange (2): partial reduced camera systems -> the full one on every rank (then factored redundantly)
   { int32_t rc = exchange(h, sv.S, (int64_t)sv.nslots * kTile * kTile + sv.npad, 0); if (rc) return rc; }

@@ -15,7 +15,7 @@
 
 namespace rsba {
 
-constexpr int kSchurChunk = 240;   // pairs per wave of the Schur kernel (multiple of the 5 / 10 pair slots)
+constexpr int kSchurChunk = 128;   // entries per wave of the Schur kernel
 constexpr int kTile = 48;   // Cholesky tile: 4 rolling-shutter frames (12 unknowns) or 8 global-shutter frames
 
 // Intrinsics as a parameter block (opt.model.calibrated == false with the shared sess.cam,
@@ -35,22 +35,22 @@ struct SolverDev {
   const int64_t* point_ptr;     // [M+1] slot ranges per point
   const int32_t* slot_frame;    // [N + M*NPF]  (virtual slots behind the real ones: N + j*NPF + v)
   const int32_t* slot_point;    // [N + M*NPF]
-  int nblk;                     // structurally non-zero CDxCD blocks (a >= b) of S
-  const int32_t* blk_a;         // [nblk]
-  const int32_t* blk_b;
-  const int64_t* blk_ptr;       // [nblk+1] into the pair list
-  const int32_t* pair_a;        // slot in frame a
-  const int32_t* pair_b;        // slot in frame b (same point)
-  const int64_t* blk_dst;       // [nblk] offset of the block's (0,0) entry inside the packed tile array S
-  const int64_t* blk_add;       // [nblk] offset into U of the J^T J block to add (diagonal / border blocks), -1 = none
-  const uint8_t* blk_trans;     // [nblk] 1 = the tile ordering swapped the block's two tiles: store it transposed
-  // pair lists cut into chunks of kSchurChunk so no wave walks a 2000-pair diagonal block alone
-  int nchunk;
-  const int32_t* chunk_blk;     // [nchunk]
-  const int64_t* chunk_p0;      // [nchunk] first pair of the chunk
-  int nmulti;                   // blocks split over >1 chunk
-  const int32_t* multi_first;   // [nmulti][2] first / end chunk of each such block (its chunks are consecutive)
-  double* schur_part;           // [nchunk][CD][CD+1] partial rows of split blocks
+  // point-elimination work list (symbolic phase): entries = (point, pair of frame tiles I >= J)
+  int FT;                       // frames per tile = kTile / CD
+  int ntp;                      // structurally non-zero tile pairs of S (before fill), frame order
+  const int32_t* tp_I;          // [ntp]
+  const int32_t* tp_J;
+  const int64_t* tp_ptr;        // [ntp+1] into the entry list
+  const int32_t* ent_slots;     // [nent][2*FT] observation slot of the point in each frame of tile I, then of tile J (-1 none)
+  const int32_t* ent_pt;        // [nent] point index; top bit set = the entry carries the rhs term P z
+  int nchunk;                   // waves of the Schur kernel: kSchurChunk entries each
+  const int32_t* chunk_tp;      // [nchunk]
+  const int64_t* chunk_e0;      // [nchunk] first entry of the chunk
+  const int32_t* tp_chunk0;     // [ntp+1] chunk range of each tile pair
+  const int32_t* tp_dst;        // [ntp] packed tile slot that receives the pair
+  const uint8_t* tp_trans;      // [ntp] 1 = the tile ordering swapped I and J: store transposed
+  const int64_t* tp_add;        // [ntp][FT][FT] offset into U of the J^T J block to add, -1 none
+  double* schur_part;           // [nchunk][kTile*kTile + kTile] partial tiles (+ rhs partials) of the chunks
   // numeric
   double* U;                    // [F][CD][CD] frame blocks | [NPF][F][CD][CD] intrinsics x frame | [NPF][NPF][CD][CD]
   double* gc;                   // [Fx][CD]     (scaled) J_c^T r, intrinsics gradient in the pseudo frames
@@ -92,7 +92,7 @@ hipError_t launch_clamp_diagonal(const DeviceProblem& dp, const SolverDev& sv, d
 hipError_t launch_gradient_max(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);           // -> scalars[kGradMax]
 hipError_t launch_point_factor(const DeviceProblem& dp, const SolverDev& sv, double radius, hipStream_t st);
 hipError_t launch_project(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);
-hipError_t launch_clear_system(const SolverDev& sv, int last_diag_slot, hipStream_t st);   // S = 0 (+ identity padding), rhs padding = 0
+hipError_t launch_clear_system(const SolverDev& sv, hipStream_t st);   // S = 0 (fill tiles start from zero)
 hipError_t launch_schur_blocks(const DeviceProblem& dp, const SolverDev& sv, double radius, hipStream_t st);
 hipError_t launch_back_substitute(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);
 hipError_t launch_model_cost_change(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);      // -> scalars[kModelCostChange]

@@ -162,6 +162,18 @@ def check_normal_equations_uncalibrated(capi, oracle, p, tol=1e-11):
         assert scaled_err(out["gradient"][k], g_ref[k]) <= tol, k
 
 
+def test_point_observed_twice_in_one_frame(capi, oracle):
+    """Two residual blocks on the same (frame, point) pair: the elimination must carry the cross terms."""
+    p = small_scene(frames=12, points=300, seed=61)
+    rng = np.random.default_rng(3)
+    dup = rng.choice(p.num_observations, size=150, replace=False)
+    p.obs_xy = np.concatenate([p.obs_xy, p.obs_xy[dup] + rng.normal(0, 0.7, (len(dup), 2))])
+    p.obs_frame = np.concatenate([p.obs_frame, p.obs_frame[dup]])
+    p.obs_point = np.concatenate([p.obs_point, p.obs_point[dup]])
+    check_normal_equations(capi, oracle, p)
+    compare_solves(capi, oracle, p, iters=20)
+
+
 def test_behind_camera_initial_failure(capi):
     p = small_scene(frames=6, points=100)
     p.points[3, 2] = -5.0
