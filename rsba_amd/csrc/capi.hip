@@ -157,6 +157,7 @@ int32_t rsba_create(const rsba_problem_desc* d, int32_t device, rsba_handle** ou
   const int nb = std::max(eval_num_blocks(N), 1);
   if ((rc = dev_alloc(h, &dp.cost_partial, (size_t)nb))) return bail(rc);
   if ((rc = dev_alloc(h, &dp.fixed_partial, (size_t)nb))) return bail(rc);
+  if ((rc = dev_alloc(h, &dp.fail_partial, (size_t)nb))) return bail(rc);
   if ((rc = dev_alloc(h, &dp.fail_count, 1))) return bail(rc);
   if ((rc = dev_alloc(h, &h->d_cost2, 2))) return bail(rc);
   if (hipMemset(dp.fail_count, 0, sizeof(int)) != hipSuccess) return bail(fail(RSBA_ERR_HIP, "hipMemset"));

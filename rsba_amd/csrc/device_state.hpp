@@ -46,7 +46,8 @@ struct DeviceProblem {
   const int32_t* obs_slot;       // [N]
   double* cost_partial;          // [nblocks] 1/2 sum rho0 over non-dropped blocks of each workgroup
   double* fixed_partial;         // [nblocks] same over dropped (all-constant) blocks
-  int* fail_count;               // number of observations whose functor returned false
+  double* fail_partial;          // [nblocks] observations of each workgroup whose functor returned false
+  int* fail_count;               // their total, written by the cost reduction (no atomics on the hot path)
 };
 
 constexpr int kEvalBlock = 256;

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(kEvalBlock) void eval_kernel(const DeviceProblem dp
   constexpr int OFF_PT = OFF_POSE + CD;
   __shared__ double s_pose[kStageFrames * CD];
   __shared__ double s_scale[MODE == kLmJacobian ? kStageFrames * CD : 1];
-  __shared__ double s_red[2][kEvalBlock / 64];
+  __shared__ double s_red[3][kEvalBlock / 64];
 
   const int tid = threadIdx.x;
   const int64_t base = (int64_t)blockIdx.x * kEvalBlock;
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(kEvalBlock) void eval_kernel(const DeviceProblem dp
     __syncthreads();
   }
 
-  double cost = 0.0, fixed = 0.0;
+  double cost = 0.0, fixed = 0.0, nfail = 0.0;   // nfail: this lane's functor returned false (counted like the cost: no atomics)
   {
     // lanes past the end of the list recompute the last observation (they must stay converged for the
     // lane-pair exchange below); their results land in the tile padding and are not counted
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(kEvalBlock) void eval_kernel(const DeviceProblem dp
     ObsOut<CAL, P> o;
     eval_observation<CAL, P, MODE != kResidualOnly>(m, cam, pose, X, xy.x, xy.y, o);
 
-    if (valid && !o.ok) atomicAdd(dp.fail_count, 1);
+    if (valid && !o.ok) nfail = 1.0;
     // Ceres 1.9 ResidualBlock::Evaluate: cost = rho0/2 from the uncorrected residual
     const double s = o.r[0] * o.r[0] + o.r[1] * o.r[1];
     double rho[3] = {s, 1.0, 0.0};
@@ -154,35 +154,38 @@ __global__ __launch_bounds__(kEvalBlock) void eval_kernel(const DeviceProblem dp
 
   // deterministic cost: fixed-order wave and workgroup sums, one partial per workgroup
   cost = wave_sum(cost);
+  nfail = wave_sum(nfail);
   if (MODE == kLmJacobian) fixed = wave_sum(fixed);
-  if ((tid & 63) == 0) { s_red[0][tid >> 6] = cost; s_red[1][tid >> 6] = fixed; }
+  if ((tid & 63) == 0) { s_red[0][tid >> 6] = cost; s_red[1][tid >> 6] = fixed; s_red[2][tid >> 6] = nfail; }
   __syncthreads();
   if (tid == 0) {
-    double c = 0.0, fx = 0.0;
+    double c = 0.0, fx = 0.0, nf = 0.0;
 #pragma unroll
-    for (int w = 0; w < kEvalBlock / 64; ++w) { c += s_red[0][w]; fx += s_red[1][w]; }
+    for (int w = 0; w < kEvalBlock / 64; ++w) { c += s_red[0][w]; fx += s_red[1][w]; nf += s_red[2][w]; }
     dp.cost_partial[blockIdx.x] = c;
     dp.fixed_partial[blockIdx.x] = (MODE == kLmJacobian) ? fx : 0.0;
+    dp.fail_partial[blockIdx.x] = nf;
   }
 }
 
 // Fixed-order reduction of the per-workgroup partials: out[0] = cost, out[1] = fixed cost.
-__global__ __launch_bounds__(256) void reduce_cost_kernel(const double* __restrict__ cost_partial,
-                                                          const double* __restrict__ fixed_partial, int n, double* out) {
-  __shared__ double s_red[2][4];
-  double c = 0.0, f = 0.0;
-  for (int k = threadIdx.x; k < n; k += 256) { c += cost_partial[k]; f += fixed_partial[k]; }
-  c = wave_sum(c); f = wave_sum(f);
-  if ((threadIdx.x & 63) == 0) { s_red[0][threadIdx.x >> 6] = c; s_red[1][threadIdx.x >> 6] = f; }
+__global__ __launch_bounds__(256) void reduce_cost_kernel(const double* __restrict__ cost_partial, const double* __restrict__ fixed_partial,
+                                                          const double* __restrict__ fail_partial, int n, double* out, int* fail_count) {
+  __shared__ double s_red[3][4];
+  double c = 0.0, f = 0.0, nf = 0.0;
+  for (int k = threadIdx.x; k < n; k += 256) { c += cost_partial[k]; f += fixed_partial[k]; nf += fail_partial[k]; }
+  c = wave_sum(c); f = wave_sum(f); nf = wave_sum(nf);
+  if ((threadIdx.x & 63) == 0) { s_red[0][threadIdx.x >> 6] = c; s_red[1][threadIdx.x >> 6] = f; s_red[2][threadIdx.x >> 6] = nf; }
   __syncthreads();
   if (threadIdx.x == 0) {
     out[0] = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
     out[1] = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
+    *fail_count = (int)(s_red[2][0] + s_red[2][1] + s_red[2][2] + s_red[2][3]);
   }
 }
 
 hipError_t launch_cost_reduce(const DeviceProblem& dp, double* out2, hipStream_t st) {
-  hipLaunchKernelGGL(reduce_cost_kernel, dim3(1), dim3(256), 0, st, dp.cost_partial, dp.fixed_partial, eval_num_blocks(dp.N), out2);
+  hipLaunchKernelGGL(reduce_cost_kernel, dim3(1), dim3(256), 0, st, dp.cost_partial, dp.fixed_partial, dp.fail_partial, eval_num_blocks(dp.N), out2, dp.fail_count);
   return hipGetLastError();
 }
 

@@ -124,7 +124,13 @@ def make_scene(num_frames: int, num_points: int, *, rolling: bool = True, track_
     cnt = np.bincount(obs_p, minlength=M)
     keepo = cnt[obs_p] >= 2
     obs_f, obs_p, obs_xy = obs_f[keepo], obs_p[keepo], obs_xy[keepo]
+    # Points are numbered in the order the video first sees them, as rsba's createTracks appends tracks while
+    # frames arrive (src/rsba/VideoSfMHandler.cc:283-372): the points of one frame then sit next to each other
+    # in the point array instead of being scattered over all of it.
     used = np.unique(obs_p)
+    first_seen = np.full(M, np.iinfo(np.int64).max, dtype=np.int64)
+    np.minimum.at(first_seen, obs_p, obs_f)
+    used = used[np.lexsort((X[used, 0], first_seen[used]))]
     remap = np.full(M, -1, dtype=np.int64)
     remap[used] = np.arange(len(used))
     X = X[used]
