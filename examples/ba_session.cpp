@@ -1,10 +1,10 @@
 // A CeresHandler-shaped host program over the facade: loads a flat scene file, rebuilds the Session
 // pointer graph rsba works on, runs BA() (VideoSfMHandler.cc:574-631 mirror) and writes the adjusted
-// parameters back.  Used by tests/test_gpu_facade.py to check that the C++ host path produces the same
+// parameters back.  Used by tests/test_facade.py to check that the C++ host path produces the same
 // solve as the C ABI / oracle.
 //
 //   scene file (binary, little endian): int32 F,P,M,rs,scan0,scan1,calibrated,interp,fixFirstN,fixScale,maxIter, int64 N,
-//     double huber, double cam[9], poses[F*P*6], points[M*3], obs_xy[N*2], int32 obs_frame[N], obs_point[N]
+//     double huber, double revalidate (squared px threshold of revalidateReprojections, <= 0 = off), double cam[9], poses[F*P*6], points[M*3], obs_xy[N*2], int32 obs_frame[N], obs_point[N]
 //   g++ -std=c++17 -O2 -Iinclude examples/ba_session.cpp -Lrsba_amd/_lib -lrsba_amd -Wl,-rpath,... -o ba_session
 #include <cstdio>
 #include <cstdlib>
@@ -22,8 +22,8 @@ int main(int argc, char** argv) {
   if (argc < 3) { std::fprintf(stderr, "usage: %s scene.bin out.bin\n", argv[0]); return 2; }
   FILE* f = std::fopen(argv[1], "rb");
   if (!f) { std::perror("scene"); return 2; }
-  int32_t hd[11]; int64_t N; double huber, cam[9];
-  if (!rd(f, hd, 11) || !rd(f, &N, 1) || !rd(f, &huber, 1) || !rd(f, cam, 9)) return 2;
+  int32_t hd[11]; int64_t N; double huber, reval, cam[9];
+  if (!rd(f, hd, 11) || !rd(f, &N, 1) || !rd(f, &huber, 1) || !rd(f, &reval, 1) || !rd(f, cam, 9)) return 2;
   const int F = hd[0], P = hd[1], M = hd[2];
   std::vector<double> poses((size_t)F * P * 6), points((size_t)M * 3), xy((size_t)N * 2);
   std::vector<int32_t> of(N), op(N);
@@ -48,6 +48,7 @@ int main(int argc, char** argv) {
   SfmOptions opt;
   opt.model.rolling_shutter = P == 2; opt.model.calibrated = hd[6] != 0; opt.model.interpolateRotation = hd[7] != 0;
   opt.ceres.fixFirstNCameras = (unsigned)hd[8]; opt.ceres.fixScale = hd[9] != 0; opt.ceres.huberLoss = huber;
+  if (reval > 0) { opt.ceres.revalidateReprojections = true; opt.tracks.sqrdThreshold = reval; }
 
   ceres::Solver::Summary summary;
   const bool usable = BA(sess, 0, F - 1, opt, hd[10], &summary, true);

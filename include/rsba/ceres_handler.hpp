@@ -4,7 +4,8 @@
 // Same names, argument meaning and error behaviour for the per-observation path (SURVEY Appendix D
 // steps 3-4).  Not built (they are "next" rows): pose initialisation of frames without poses
 // (Appendix D step 1), motion / pose priors (step 2), the structure-less ray costs, match-based track
-// lookup and revalidateReprojections — reaching one of them throws std::runtime_error.
+// lookup — reaching one of them throws std::runtime_error.  revalidateReprojections (:239-243) runs as one
+// batched device validation per frame (video_sfm.hpp).
 #pragma once
 #include <cmath>
 #include <iostream>
@@ -12,6 +13,7 @@
 #include <thread>
 
 #include "reprojection_costs.hpp"
+#include "video_sfm.hpp"
 
 namespace rsba_amd {
 
@@ -54,15 +56,29 @@ class CeresHandler {
     }
     if (!opt.model.use3Dpoints) throw std::runtime_error("structure-less costs (CeresHandler.h:303-332) are not built");
     (void)uninitialized;
-    for (Observation& o : f.obs) {
-      double obs[2] = {o.x, o.y};
+    std::vector<Track*> track_of(f.obs.size(), nullptr);
+    for (size_t oi = 0; oi < f.obs.size(); ++oi) {
+      Observation& o = f.obs[oi];
       Track* t = nullptr;
       if (o.__isset.track) {                                           // :215-218
         t = &sess.getTrack((size_t)o.track);
         if (!t->__isset.pt || (opt.ceres.useOnlyValidMatches && !t->valid)) t = nullptr;
       }
       if (!t || !(t->valid || !opt.ceres.useOnlyValidMatches)) continue;   // :238 (match-based lookup :220-236 not built)
-      if (opt.ceres.revalidateReprojections) throw std::runtime_error("revalidateReprojections (CeresHandler.h:239-243) is not built");
+      track_of[oi] = t;
+    }
+    if (opt.ceres.revalidateReprojections) {                           // :239-243, all observations of the frame in one launch
+      std::vector<const double*> pts; std::vector<std::array<double, 2>> xy; std::vector<size_t> which;
+      for (size_t oi = 0; oi < f.obs.size(); ++oi)
+        if (track_of[oi]) { pts.push_back(track_of[oi]->pt.data()); xy.push_back({f.obs[oi].x, f.obs[oi].y}); which.push_back(oi); }
+      const std::vector<uint8_t> ok = validate(sess, f, opt, pts, xy);
+      for (size_t k = 0; k < which.size(); ++k) if (!ok[k]) track_of[which[k]] = nullptr;   // skip observation
+    }
+    for (size_t oi = 0; oi < f.obs.size(); ++oi) {
+      Observation& o = f.obs[oi];
+      double obs[2] = {o.x, o.y};
+      Track* t = track_of[oi];
+      if (!t) continue;
       if (f.poses.size() == 2) {                                       // :245-265 rolling shutter, two poses
         if (opt.model.constVelocity) throw std::runtime_error("constVelocity");   // the reference aborts (:246-247)
         if (opt.model.calibrated) {

@@ -166,6 +166,19 @@ void rsba_default_solver_options(rsba_solver_options* opt);
 int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rsba_solver_summary* summary,
                    rsba_iteration* trace, int32_t trace_capacity);
 
+/* ---- the steps either side of the solve: batched reprojection / validation filter ----
+ * == vision::sfm::validate(sess, f, opt, pt, obs) for every observation of the problem
+ * (struct/VideoSfM.cc:159-169 with getPose :103-133; callers: CeresHandler.h:239-243 revalidateReprojections,
+ * VideoSfMHandler.cc evalTracks / createTracks): valid[i] = 1 iff |camera centre at the observation's scan
+ * line - point| >= min_distance (opt.tracks.minDistanceToCamera) and the squared reprojection error <
+ * sq_threshold (opt.tracks.sqrdThreshold).  Unlike the cost functor, tau is taken from the TRUE observation
+ * (x for HORIZONTAL, y for VERTICAL).  valid is a host array [N] in the caller's observation order. */
+int32_t rsba_validate_observations(rsba_handle* h, double sq_threshold, double min_distance, uint8_t* valid);
+/* == vision::sfm::reproject(sess, f, opt, pt, obs) (struct/VideoSfM.cc:139-155) for n (frame, point) pairs:
+ * fixed point on the scan-line time from the principal point, at most 49 projections, converged when the
+ * projection moves <= 1e-3 px.  xy_out [n][2], ok_out [n] (host arrays). */
+int32_t rsba_reproject(rsba_handle* h, const int32_t* frames, const int32_t* points, int64_t n, double* xy_out, uint8_t* ok_out);
+
 /* ---- multi-GPU: one process per GPU, observations partitioned BY POINT, cameras replicated ----
  * (the reference is single-process; this is the exchange step SURVEY §8e derives for the path).
  * Every rank creates a handle over its own observations (all frames / points arrays are full size, a rank

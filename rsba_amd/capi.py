@@ -21,6 +21,7 @@ EXPORTS = [
     "rsba_set_stream", "rsba_upload_parameters", "rsba_download_parameters", "rsba_evaluate_device", "rsba_evaluate",
     "rsba_get_device_view", "rsba_time_evaluate", "rsba_default_solver_options", "rsba_solve", "rsba_normal_equations",
     "rsba_set_exchange", "rsba_get_block_structure", "rsba_set_block_structure",
+    "rsba_validate_observations", "rsba_reproject",
 ]
 
 
@@ -219,6 +220,19 @@ class DeviceProblem:
         V = np.zeros((p.num_points, 3, 3)); gp = np.zeros((p.num_points, 3))
         _check(lib().rsba_normal_equations(self._h, _ptr(U), _ptr(gc), _ptr(V), _ptr(gp)))
         return U, gc, V, gp
+
+    def validate_observations(self, sq_threshold: float, min_distance: float = 0.0) -> np.ndarray:
+        """vision::sfm::validate for every observation (struct/VideoSfM.cc:159-169) -> bool [N]"""
+        out = np.zeros(self.prob.num_observations, dtype=np.uint8)
+        _check(lib().rsba_validate_observations(self._h, C.c_double(sq_threshold), C.c_double(min_distance), _ptr(out)))
+        return out.astype(bool)
+
+    def reproject(self, frames, points):
+        """vision::sfm::reproject (struct/VideoSfM.cc:139-155) for (frame, point) pairs -> xy [n,2], ok [n]"""
+        fr = np.ascontiguousarray(frames, dtype=np.int32); pt = np.ascontiguousarray(points, dtype=np.int32)
+        xy = np.zeros((len(fr), 2)); ok = np.zeros(len(fr), dtype=np.uint8)
+        _check(lib().rsba_reproject(self._h, _ptr(fr), _ptr(pt), C.c_int64(len(fr)), _ptr(xy), _ptr(ok)))
+        return xy, ok.astype(bool)
 
     def device_view(self) -> DeviceView:
         v = DeviceView()

@@ -268,6 +268,45 @@ int32_t rsba_evaluate(rsba_handle* h, double* cost, double* residuals, double* j
   return RSBA_OK;
 }
 
+int32_t rsba_validate_observations(rsba_handle* h, double sq_threshold, double min_distance, uint8_t* valid) {
+  if (!h || !valid) return fail(RSBA_ERR_INVALID_ARGUMENT, "null argument");
+  HIP_TRY(hipSetDevice(h->device));
+  const int64_t N = h->dp.N;
+  if (N == 0) return RSBA_OK;
+  uint8_t* d = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), (size_t)N));
+  std::vector<uint8_t> tmp((size_t)N);
+  hipError_t e = launch_validate(h->dp, sq_threshold, min_distance, d, h->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(tmp.data(), d, (size_t)N, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail(RSBA_ERR_HIP, hipGetErrorString(e));
+  for (int64_t i = 0; i < N; ++i) valid[h->order[i]] = tmp[i];
+  return RSBA_OK;
+}
+
+int32_t rsba_reproject(rsba_handle* h, const int32_t* frames, const int32_t* points, int64_t n, double* xy_out, uint8_t* ok_out) {
+  if (!h || (n > 0 && (!frames || !points || !xy_out || !ok_out))) return fail(RSBA_ERR_INVALID_ARGUMENT, "null argument");
+  for (int64_t i = 0; i < n; ++i)
+    if (frames[i] < 0 || frames[i] >= h->dp.F || points[i] < 0 || points[i] >= h->dp.M) return fail(RSBA_ERR_INVALID_ARGUMENT, "index out of range");
+  if (n <= 0) return RSBA_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  int32_t *df = nullptr, *dq = nullptr; double* dxy = nullptr; uint8_t* dok = nullptr;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&df), (size_t)n * 4);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&dq), (size_t)n * 4);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&dxy), (size_t)n * 16);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&dok), (size_t)n);
+  if (e == hipSuccess) e = hipMemcpyAsync(df, frames, (size_t)n * 4, hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(dq, points, (size_t)n * 4, hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess) e = launch_reproject(h->dp, df, dq, n, dxy, dok, h->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(xy_out, dxy, (size_t)n * 16, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(ok_out, dok, (size_t)n, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  (void)hipFree(df); (void)hipFree(dq); (void)hipFree(dxy); (void)hipFree(dok);
+  if (e != hipSuccess) return fail(RSBA_ERR_HIP, hipGetErrorString(e));
+  return RSBA_OK;
+}
+
 void rsba_default_solver_options(rsba_solver_options* o) {
   if (!o) return;
   // Ceres 1.9 Solver::Options defaults; iteration cap as CeresHandler.h:405

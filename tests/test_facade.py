@@ -58,3 +58,29 @@ def test_ba_of_a_session_matches_the_oracle(exe, oracle, tmp_path, rolling, hube
     assert abs(out["initial_cost"] - s_ref.initial_cost) <= 1e-12 * s_ref.initial_cost
     assert abs(out["final_cost"] - s_ref.final_cost) <= 1e-6 * s_ref.final_cost
     assert np.max(np.abs(out["poses"] - q.poses)) <= 1e-5 and np.max(np.abs(out["points"] - q.points)) <= 1e-4
+
+
+@pytest.mark.gpu
+def test_revalidate_reprojections_drops_what_validate_rejects(exe, oracle, tmp_path):
+    """CeresHandler.h:239-243: with revalidateReprojections the observations failing validate() never become
+    residual blocks.  The oracle solves the problem with exactly those observations removed."""
+    from rsba_amd.problem import apply_gauge_masks
+    from rsba_amd.scene import make_scene
+    p = make_scene(14, 500, rolling=True, seed=43, outlier_ratio=0.1, rot_noise=0.002, pos_noise=0.01, pt_noise=0.01).problem
+    thr = 36.0
+    write_scene_file(tmp_path / "s.bin", p, fix_first_n=1, max_iter=15, revalidate=thr)
+    r = subprocess.run([exe, str(tmp_path / "s.bin"), str(tmp_path / "o.bin")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = read_result_file(tmp_path / "o.bin", p)
+    keep = np.array([oracle.validate_obs(p.intrinsics[0], p.poses[f], p.shutter, p.scanlines, p.points[j], xy, thr, 0.0, True)
+                     for f, j, xy in zip(p.obs_frame, p.obs_point, p.obs_xy)])
+    assert 0.5 < keep.mean() < 0.97
+    q = p.copy()
+    q.obs_xy, q.obs_frame, q.obs_point = p.obs_xy[keep], p.obs_frame[keep], p.obs_point[keep]
+    apply_gauge_masks(q, fix_first_n_cameras=1, fix_scale=False)
+    s_ref, _ = oracle.solve(q, oracle.default_options(max_num_iterations=15))
+    assert out["reduced"] == s_ref.num_residual_blocks_reduced
+    assert abs(out["initial_cost"] - s_ref.initial_cost) <= 1e-12 * s_ref.initial_cost
+    assert abs(out["final_cost"] - s_ref.final_cost) <= 1e-6 * s_ref.final_cost
+    # points that lost all their observations keep their input value on both sides
+    assert np.max(np.abs(out["poses"] - q.poses)) <= 1e-5 and np.max(np.abs(out["points"] - q.points)) <= 1e-4
