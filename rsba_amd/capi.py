@@ -14,7 +14,7 @@ import numpy as np
 from .problem import BAProblem
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_lib", "librsba_amd.so")
+LIB_PATH = os.environ.get("RSBA_AMD_LIB") or os.path.join(_HERE, "_lib", "librsba_amd.so")   # override: kernel experiments (tools/)
 
 EXPORTS = [
     "rsba_abi_version", "rsba_status_string", "rsba_last_error", "rsba_device_count", "rsba_create", "rsba_destroy",

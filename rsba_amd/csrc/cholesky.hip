@@ -11,9 +11,9 @@
 // A band factored column after column is a serial chain of ~n/48 dependent steps (250 at 1k cameras),
 // each a few tens of microseconds of latency: the GPU idles.  So the host reorders the tile columns by
 // nested dissection (BFS-level separators cut the band into independent segments), computes the levels of
-// the resulting elimination structure, and the factorisation runs level by level: two launches per level
-// (diagonal tiles, then sub-diagonal tiles), every tile of a level in its own workgroup; the forward solve
-// rides along, the backward solve walks the levels in reverse.  1k cameras: ~50 levels instead of 250 steps.
+// the resulting elimination structure, and the factorisation runs as a DAG of tile tasks in one persistent
+// kernel (below); the forward solve rides along, the backward solve walks the levels in reverse.
+// 1k cameras: ~42 levels instead of 250 steps.
 #include "solver_state.hpp"
 
 namespace rsba {
@@ -39,49 +39,6 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
 }
 
 __device__ __forceinline__ double* tile_ptr(const SolverDev& sv, int slot) { return sv.S + (size_t)slot * (T * T); }
-
-__device__ __forceinline__ void load_tile(double* dst, const double* src, int tid, bool lower_only) {
-  for (int e = tid; e < T * T; e += 256) {
-    const int r = e / T, c = e % T;
-    dst[r * TP + c] = (!lower_only || c <= r) ? src[e] : 0.0;
-  }
-}
-__device__ __forceinline__ void store_tile(double* dst, const double* src, int tid) {
-  for (int e = tid; e < T * T; e += 256) dst[e] = src[(e / T) * TP + e % T];
-}
-// A tile in flight: each of the 256 threads holds 9 of its 2304 doubles, so the HBM/L2 latency of the next
-// contributor overlaps the 48^3 product on the current one.
-struct TileRegs {
-  double v[9];
-  __device__ __forceinline__ void fetch(const double* src, int tid) {
-#pragma unroll
-    for (int k = 0; k < 9; ++k) v[k] = src[tid + 256 * k];
-  }
-  __device__ __forceinline__ void commit(double* lds, int tid) const {
-#pragma unroll
-    for (int k = 0; k < 9; ++k) { const int e = tid + 256 * k; lds[(e / T) * TP + e % T] = v[k]; }
-  }
-};
-
-// C -= A B^T on T x T tiles in LDS; 256 threads as 16 x 16, each a 3 x 3 micro-tile over K = 48
-__device__ __forceinline__ void tile_gemm_sub(double* C, const double* A, const double* B, int tid) {
-  const int ty = tid >> 4, tx = tid & 15;
-  double acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-#pragma unroll 4
-  for (int m = 0; m < T; ++m) {
-    double a[3], b[3];
-#pragma unroll
-    for (int u = 0; u < 3; ++u) { a[u] = A[(ty * 3 + u) * TP + m]; b[u] = B[(tx * 3 + u) * TP + m]; }
-#pragma unroll
-    for (int u = 0; u < 3; ++u)
-#pragma unroll
-      for (int v = 0; v < 3; ++v) acc[u][v] += a[u] * b[v];
-  }
-#pragma unroll
-  for (int u = 0; u < 3; ++u)
-#pragma unroll
-    for (int v = 0; v < 3; ++v) C[(ty * 3 + u) * TP + tx * 3 + v] -= acc[u][v];
-}
 
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
@@ -142,224 +99,578 @@ __device__ __forceinline__ bool potrf_blocked(double* A, int tid) {
   return ok;
 }
 
-// X <- X L^-T for the T x T tiles X and L (lower, factored) in LDS, dinv = 1 / diag(L): blocked forward
-// substitution along the rows; 12-column solves by one thread per row, rank-12 updates by all threads.
-__device__ __forceinline__ void trsm_blocked(double* X, const double* L, const double* dinv, int tid) {
+// ---- MFMA tile products ------------------------------------------------------------------------------------
+// C(48x48) += A B^T on v_mfma_f64_16x16x4_f64, operands straight from HBM/L2 into registers — no LDS, no
+// barrier in the accumulation loop.  The four waves of the workgroup split K: wave w owns columns
+// [12w, 12w+12) of both operand tiles, lane (r = lane & 15, g = lane >> 4) holds columns 12w + 3g + t (t < 3)
+// of rows 16I + r — for MFMA step t that is A[i = r][k = g] and B[k = g][j = r] of the 16x16x4 product over
+// the k values {12w + 3g' + t}.  Every wave therefore accumulates all nine 16x16 blocks over its quarter of
+// K (27 MFMAs, 64 cycles each: the fp64 matrix rate of gfx950 equals its vector rate, but the VALU form of
+// this product is bound by LDS operand reads at a third of it) and the four partial tiles meet once, in LDS,
+// when the task has gone through all its contributors.
+// Result layout of the instruction (measured, tools/mfma_f64_check.hip): lane holds rows g + 4v (v < 4), column r.
+typedef double dbl4 __attribute__((ext_vector_type(4)));
+
+struct Frag {
+  double v[3][3];   // [row block I][step t]
+  template <bool DAG>
+  __device__ __forceinline__ void load(const double* tile, int wave, int lane);
+};
+
+struct Acc {
+  dbl4 c[3][3];
+  __device__ __forceinline__ void clear() {
 #pragma unroll
-  for (int bc = 0; bc < T / NB; ++bc) {
-    const int c0 = NB * bc;
-    if (tid < T) {
-      double x[NB];
+    for (int I = 0; I < 3; ++I)
 #pragma unroll
-      for (int m = 0; m < NB; ++m) x[m] = X[tid * TP + c0 + m];
+      for (int J = 0; J < 3; ++J) c[I][J] = dbl4{0.0, 0.0, 0.0, 0.0};
+  }
+  template <bool LOWER>
+  __device__ __forceinline__ void mac(const Frag& a, const Frag& b) {
 #pragma unroll
-      for (int jj = 0; jj < NB; ++jj) {
-        double s = 0.0;
+    for (int t = 0; t < 3; ++t)
 #pragma unroll
-        for (int m = 0; m < jj; ++m) s += x[m] * L[(c0 + jj) * TP + c0 + m];
-        x[jj] = (x[jj] - s) * dinv[c0 + jj];
+      for (int I = 0; I < 3; ++I)
+#pragma unroll
+        for (int J = 0; J < 3; ++J)
+          if (!LOWER || J <= I) c[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.v[I][t], b.v[J][t], c[I][J], 0, 0, 0);
+  }
+  // this wave's partial tile -> its LDS buffer (row-major, pitch TP)
+  __device__ __forceinline__ void spill(double* buf, int lane) const {
+    const int r = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int I = 0; I < 3; ++I)
+#pragma unroll
+      for (int J = 0; J < 3; ++J)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) buf[(16 * I + g + 4 * v) * TP + 16 * J + r] = c[I][J][v];
+  }
+};
+
+// ---- left-looking tile tasks ----------------------------------------------------------------------------
+// The host orders the tile columns by nested dissection and lists, per tile of the factor, the finished tiles it
+// pulls its updates from (left-looking: no two workgroups ever write the same tile, so no fp atomics and a fixed
+// summation order).  Four task kinds, each run by one 256-thread workgroup:
+//   UPDATE  partial = sum_{k in chunk} L_ik L_jk^T (+ sum L_jk z_k for a diagonal tile) -> scratch
+//   DIAG    S_jj -= updates ; S_jj = L_jj L_jj^T ; W_j = L_jj^-1 ; z_j = W_j (b_j - updates)
+//   SUB     S_ij -= updates ; L_ij = S_ij W_j^T
+//   BACK    y_j = W_j^T ( z_j - sum_i L_ij^T y_i )
+// The explicit inverse of the 48x48 diagonal factor turns every triangular solve behind it (dozens of SUB tiles
+// per column, the forward and the backward substitution) into a product without a serial chain.
+// Two drivers run the same task bodies:
+//   * chol_dag_kernel — ONE persistent launch per solve.  Workgroups draw tickets from a global counter over the
+//     topologically sorted task list and wait on per-tile "done" flags (agent-scope release/acquire) instead of
+//     kernel boundaries.  A claimed task only waits for tasks with smaller tickets, which are claimed by running
+//     workgroups, so progress never depends on how many workgroups are resident.
+//   * chol_level_kernel — one launch per (level, kind), no flags: the reference schedule the DAG driver is
+//     tested against (RSBA_CHOL_LEVELS=1).
+
+__shared__ long long* s_trace_slot;   // RSBA_CHOL_TRACE: where the running task logs its time stamps (null = off)
+#define CHOL_STAMP(k) do { if (DAG && tid == 0 && s_trace_slot) s_trace_slot[k] = wall_clock64(); } while (0)
+
+// Cross-workgroup data of the DAG driver (tiles, partial tiles, W, z, y) moves through agent-coherent accesses:
+// relaxed agent-scope atomic loads / stores of the individual doubles, which gfx950 issues with sc1 (L2 of the
+// other XCDs is not coherent with ours; sc1 accesses go to the memory side).  Ordering against the "done" flag is
+// then a matter of completion, not of cache maintenance: a producer waits for its stores (s_waitcnt, workgroup
+// fence + barrier) before raising the flag, a consumer issues its loads after it has seen the flag.  That saves
+// the L2 write-back (buffer_wbl2) of an agent-scope release and the invalidate (buffer_inv) of an acquire on every
+// link of the dependency chain — measured 0.44 ms of 1.75 ms at 1k cameras.  -DRSBA_FORMAL_FENCES restores the
+// plain loads / stores with agent-scope fences (same results, checked by tests/test_gpu_solve.py).
+#ifdef RSBA_FORMAL_FENCES
+#define RSBA_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
+#define RSBA_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
+template <bool DAG> __device__ __forceinline__ double ld(const double* p) { return *p; }
+template <bool DAG> __device__ __forceinline__ void st(double* p, double v) { *p = v; }
+#else
+#define RSBA_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup")
+// every wave drains its own stores (vmcnt counts a store until the coherence point of its scope has taken it)
+#define RSBA_RELEASE() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
+template <bool DAG> __device__ __forceinline__ double ld(const double* p) {
+  if (DAG) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return *p;
+}
+template <bool DAG> __device__ __forceinline__ void st(double* p, double v) {
+  if (DAG) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+#endif
+
+__device__ __forceinline__ int flag_set(const CholPlan& pl, int index) {
+  return __hip_atomic_load(pl.flags + index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// In-order readiness of a task's inputs: items [.., upto) are finished and acquired.  A refresh reads the flags of
+// the next 64 items at once — lane l those of item upto + l, so the whole window costs ONE memory round trip
+// (a flag read is an L2-bypassing load of ~1.5 us; read one after the other they, not the tile products, were
+// the critical path) — and advances upto over the leading finished ones behind a single acquire fence.
+// Every lane of the calling wave takes part; waves do not synchronise here.
+template <bool DAG, class F>
+struct Ready {
+  const CholPlan& pl; F ok; int upto, end;
+  __device__ __forceinline__ Ready(const CholPlan& p, int begin, int e, F f) : pl(p), ok(f), upto(begin), end(e) {}
+  __device__ __forceinline__ void refresh() {
+    const int item = upto + (int)(threadIdx.x & 63);
+    const bool mine = item < end ? ok(item) != 0 : false;
+    const unsigned long long mask = __ballot(mine);
+    const int n = mask == ~0ull ? 64 : __builtin_ctzll(~mask);
+    if (n > 0) { RSBA_ACQUIRE(); upto += n; }
+  }
+  // non-blocking: true if item p is finished
+  __device__ __forceinline__ bool poll(int p) {
+    if (!DAG || p < upto) return true;
+    refresh();
+    return p < upto;
+  }
+  __device__ __forceinline__ void need(int p) {
+    if (!DAG || p < upto) return;
+    bool spun = false;
+    for (;;) {
+      refresh();
+      if (p < upto) break;
+      __builtin_amdgcn_s_sleep(1);
+      spun = true;
+    }
+    if (spun && threadIdx.x == 0 && s_trace_slot) { s_trace_slot[2] = wall_clock64(); s_trace_slot[6] = (long long)(end - p); }   // when the last late input arrived, and how much was left
+  }
+};
+template <bool DAG, class F>
+__device__ __forceinline__ Ready<DAG, F> make_ready(const CholPlan& pl, int begin, int end, F f) { return Ready<DAG, F>(pl, begin, end, f); }
+
+template <bool DAG>
+__device__ __forceinline__ void dag_publish(const CholPlan& pl, int index, int tid) {
+  if (!DAG) return;
+  RSBA_RELEASE();   // every wave's stores are written back before the barrier
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(pl.flags + index, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// LDS map (doubles): four partial-tile buffers, then small vectors
+constexpr int kBuf = T * TP;
+constexpr int kVecOff = 4 * kBuf;            // [4][T] per-wave rhs partials, [T] b, [T] 1/diag, flag word
+constexpr int kCholLds = kVecOff + 8 * T;
+
+template <bool DAG>
+__device__ __forceinline__ void Frag::load(const double* tile, int wave, int lane) {
+  const double* p = tile + (lane & 15) * T + 12 * wave + 3 * (lane >> 4);
+#pragma unroll
+  for (int I = 0; I < 3; ++I)
+#pragma unroll
+    for (int t = 0; t < 3; ++t) v[I][t] = ld<DAG>(p + 16 * I * T + t);
+}
+
+// sum_{p in [p0,p1)} L_a(p) L_b(p)^T into acc (K-split over the waves), and for DIAG lists sum L_jk z_k into
+// bz[I] (this lane's share of rows 16I + r).  DIAG list entries are {slot_jk, tile of z_k}: A = B = L_jk and only
+// the lower blocks are formed; SUB entries are {slot_ik, slot_jk}.
+template <bool DAG, bool DIAG>
+__device__ __forceinline__ void accumulate(const SolverDev& sv, const CholPlan& pl, const int32_t* list, int p0, int p1, Acc& acc, double bz[3],
+                                           int wave, int lane) {
+  if (p0 >= p1) return;
+  auto ready = make_ready<DAG>(pl, p0, p1, [&](int p) { return DIAG ? flag_set(pl, list[2 * p]) : (flag_set(pl, list[2 * p]) & flag_set(pl, list[2 * p + 1])); });
+  // Operands travel in groups of kGroup contributors, one group ahead of the MFMAs: the HBM/L2 round trip of a
+  // tile (~2 us behind an acquire) is several times the 0.7 us its product takes.  Loads are issued in straight
+  // lines (the tail of the list re-reads its last contributor rather than branch) and the two schedules —
+  // "next group is finished: fetch it, then multiply" / "multiply, then wait for it" — are separate code paths, so
+  // that the compiler's s_waitcnt placement can count the loads in flight instead of draining them at a join.
+  constexpr int kGroup = 2;
+  struct Group { Frag a[kGroup], b[kGroup]; double z[kGroup][3]; };
+  Group cur, nxt;
+  auto fetch_group = [&](Group& g, int p) {
+#pragma unroll
+    for (int u = 0; u < kGroup; ++u) {
+      const int q = min(p + u, p1 - 1);
+      g.a[u].template load<DAG>(tile_ptr(sv, list[2 * q]), wave, lane);
+      if (!DIAG) g.b[u].template load<DAG>(tile_ptr(sv, list[2 * q + 1]), wave, lane);
+      else {
+        const double* zk = sv.rhs + (size_t)list[2 * q + 1] * T + 12 * wave + 3 * (lane >> 4);
+        g.z[u][0] = ld<DAG>(zk); g.z[u][1] = ld<DAG>(zk + 1); g.z[u][2] = ld<DAG>(zk + 2);
       }
-#pragma unroll
-      for (int m = 0; m < NB; ++m) X[tid * TP + c0 + m] = x[m];
     }
-    __syncthreads();
-    const int n1 = T - (c0 + NB);
-    if (n1 > 0) {
-      for (int e = tid; e < T * n1; e += 256) {
-        const int r = e / n1, c = c0 + NB + e % n1;
-        double s0 = 0.0, s1 = 0.0;
+  };
+  auto mac_group = [&](const Group& g, int p) {
 #pragma unroll
-        for (int m = 0; m < NB; m += 2) { s0 += X[r * TP + c0 + m] * L[c * TP + c0 + m]; s1 += X[r * TP + c0 + m + 1] * L[c * TP + c0 + m + 1]; }
-        X[r * TP + c] -= s0 + s1;
-      }
-      __syncthreads();
-    }
-  }
-}
-
-// ---- level-scheduled left-looking kernels -----------------------------------------------------------
-// The host orders the tile columns by nested dissection and groups them into levels of the elimination
-// structure; all columns of a level are independent.  Left-looking: a tile pulls every update it needs
-// from finished columns (no two workgroups ever write the same tile, so no atomics and a fixed summation
-// order), then the diagonal tile is factored / the sub-diagonal tile is solved.
-
-// one workgroup per chunk of a long contributor list: partial = sum_{k in chunk} L_ik L_jk^T (and, for a
-// diagonal tile, sum L_jk z_k) to scratch; upd item = {kind, list begin, list end, scratch slot}
-__global__ __launch_bounds__(256) void chol_update_kernel(const SolverDev sv, const int32_t* upd, const int32_t* diag_list, const int32_t* sub_list) {
-  __shared__ double A[T * TP], B[T * TP];
-  const int tid = threadIdx.x;
-  const int32_t* u = upd + 4 * blockIdx.x;
-  const bool diag = u[0] == 0;
-  const int32_t* list = diag ? diag_list : sub_list;
-  double* out = sv.chol_part + (size_t)u[3] * (T * T + T);
-  const int ty = tid >> 4, tx = tid & 15;
-  double acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-  double bacc = 0.0;
-  TileRegs ra, rb;
-  ra.fetch(tile_ptr(sv, list[2 * u[1]]), tid);
-  if (!diag) rb.fetch(tile_ptr(sv, list[2 * u[1] + 1]), tid);
-  for (int p = u[1]; p < u[2]; ++p) {
-    __syncthreads();
-    ra.commit(A, tid);
-    if (!diag) rb.commit(B, tid);
-    __syncthreads();
-    if (p + 1 < u[2]) {   // next contributor's tiles travel while this one is multiplied
-      ra.fetch(tile_ptr(sv, list[2 * (p + 1)]), tid);
-      if (!diag) rb.fetch(tile_ptr(sv, list[2 * (p + 1) + 1]), tid);
-    }
-    const double* Bm = diag ? A : B;
-#pragma unroll 4
-    for (int m = 0; m < T; ++m) {
-      double a[3], b[3];
+    for (int u = 0; u < kGroup; ++u) {
+      if (p + u < p1) {
+        if (DIAG) {
+          acc.mac<true>(g.a[u], g.a[u]);
 #pragma unroll
-      for (int q = 0; q < 3; ++q) { a[q] = A[(ty * 3 + q) * TP + m]; b[q] = Bm[(tx * 3 + q) * TP + m]; }
+          for (int I = 0; I < 3; ++I)
 #pragma unroll
-      for (int q = 0; q < 3; ++q)
-#pragma unroll
-        for (int v = 0; v < 3; ++v) acc[q][v] += a[q] * b[v];
-    }
-    if (diag && tid < T) {
-      const double* z = sv.rhs + (size_t)list[2 * p + 1] * T;
-      double s0 = 0.0, s1 = 0.0;
-#pragma unroll 8
-      for (int m = 0; m < T; m += 2) { s0 += A[tid * TP + m] * z[m]; s1 += A[tid * TP + m + 1] * z[m + 1]; }
-      bacc += s0 + s1;
-    }
-  }
-#pragma unroll
-  for (int q = 0; q < 3; ++q)
-#pragma unroll
-    for (int v = 0; v < 3; ++v) out[(ty * 3 + q) * T + tx * 3 + v] = acc[q][v];
-  if (diag && tid < T) out[T * T + tid] = bacc;
-}
-
-// one workgroup per column j of the level:
-//   S_jj -= sum_k L_jk L_jk^T ;  b_j -= sum_k L_jk z_k ;  S_jj = L_jj L_jj^T ;  z_j = L_jj^-1 b_j
-__global__ __launch_bounds__(256) void chol_diag_kernel(const SolverDev sv, const int32_t* info, const int32_t* ptr, const int32_t* list) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  double* D = smem; double* A = smem + T * TP; double* bvec = smem + 2 * T * TP; int* s_okp = reinterpret_cast<int*>(bvec + T);
-  const int tid = threadIdx.x, b = blockIdx.x;
-  const int slot_jj = info[4 * b], tile_j = info[4 * b + 1], part0 = info[4 * b + 2], nparts = info[4 * b + 3];
-  load_tile(D, tile_ptr(sv, slot_jj), tid, true);
-  if (tid < T) bvec[tid] = sv.rhs[(size_t)tile_j * T + tid];
-  if (tid == 0) *s_okp = 1;
-  __syncthreads();
-  for (int c = 0; c < nparts; ++c) {   // long contributor lists arrive pre-reduced (chol_update_kernel)
-    const double* part = sv.chol_part + (size_t)(part0 + c) * (T * T + T);
-    for (int e = tid; e < T * T; e += 256) D[(e / T) * TP + e % T] -= part[e];
-    if (tid < T) bvec[tid] -= part[T * T + tid];
-  }
-  if (nparts > 0) __syncthreads();
-  TileRegs ra;
-  if (nparts == 0 && ptr[b] < ptr[b + 1]) ra.fetch(tile_ptr(sv, list[2 * ptr[b]]), tid);
-  for (int p = ptr[b]; nparts == 0 && p < ptr[b + 1]; ++p) {
-    ra.commit(A, tid);
-    __syncthreads();
-    if (p + 1 < ptr[b + 1]) ra.fetch(tile_ptr(sv, list[2 * (p + 1)]), tid);
-    tile_gemm_sub(D, A, A, tid);
-    if (tid < T) {
-      const double* z = sv.rhs + (size_t)list[2 * p + 1] * T;
-      double s0 = 0.0, s1 = 0.0;
-#pragma unroll 8
-      for (int m = 0; m < T; m += 2) { s0 += A[tid * TP + m] * z[m]; s1 += A[tid * TP + m + 1] * z[m + 1]; }
-      bvec[tid] -= s0 + s1;
-    }
-    __syncthreads();
-  }
-  const bool ok = potrf_blocked(D, tid);
-  if (tid < 64 && !ok) *s_okp = 0;
-  __syncthreads();
-  if (!*s_okp && tid == 0) atomicExch(sv.chol_fail, 1);
-  double* out = tile_ptr(sv, slot_jj);
-  for (int e = tid; e < T * T; e += 256) { const int r = e / T, c = e % T; if (c <= r) out[e] = D[r * TP + c]; }
-  if (tid < 64) {
-    const int r = tid < T ? tid : T - 1;
-    double bb = bvec[r];
-    double colv[T];
-#pragma unroll
-    for (int c = 0; c < T; ++c) colv[c] = D[r * TP + c];     // row r of L_jj
-    const double dinv = 1.0 / D[r * TP + r];
-#pragma unroll
-    for (int c = 0; c < T; ++c) {
-      const double zc = __shfl(bb * dinv, c, 64);               // z_c = b_c / L_cc, broadcast from lane c
-      if (tid == c) bb = zc; else if (tid > c) bb -= colv[c] * zc;
-    }
-    if (tid < T) sv.rhs[(size_t)tile_j * T + tid] = bb;
-  }
-}
-
-// one workgroup per sub-diagonal tile (i,j) of the level's columns:
-//   S_ij -= sum_k L_ik L_jk^T ;  L_ij = S_ij L_jj^-T
-__global__ __launch_bounds__(256) void chol_sub_kernel(const SolverDev sv, const int32_t* info, const int32_t* ptr, const int32_t* list) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  double* X = smem; double* A = smem + T * TP; double* B = smem + 2 * T * TP; double* dinv = smem + 3 * T * TP;
-  const int tid = threadIdx.x, b = blockIdx.x;
-  const int slot_ij = info[4 * b], slot_jj = info[4 * b + 1], part0 = info[4 * b + 2], nparts = info[4 * b + 3];
-  load_tile(X, tile_ptr(sv, slot_ij), tid, false);
-  __syncthreads();
-  for (int c = 0; c < nparts; ++c) {
-    const double* part = sv.chol_part + (size_t)(part0 + c) * (T * T + T);
-    for (int e = tid; e < T * T; e += 256) X[(e / T) * TP + e % T] -= part[e];
-  }
-  if (nparts > 0) __syncthreads();
-  TileRegs ra, rb;
-  if (nparts == 0 && ptr[b] < ptr[b + 1]) { ra.fetch(tile_ptr(sv, list[2 * ptr[b]]), tid); rb.fetch(tile_ptr(sv, list[2 * ptr[b] + 1]), tid); }
-  for (int p = ptr[b]; nparts == 0 && p < ptr[b + 1]; ++p) {
-    ra.commit(A, tid); rb.commit(B, tid);
-    __syncthreads();
-    if (p + 1 < ptr[b + 1]) { ra.fetch(tile_ptr(sv, list[2 * (p + 1)]), tid); rb.fetch(tile_ptr(sv, list[2 * (p + 1) + 1]), tid); }
-    tile_gemm_sub(X, A, B, tid);
-    __syncthreads();
-  }
-  load_tile(A, tile_ptr(sv, slot_jj), tid, true);   // L_jj, finished by chol_diag_kernel of this level
-  __syncthreads();
-  if (tid < T) dinv[tid] = 1.0 / A[tid * TP + tid];
-  __syncthreads();
-  trsm_blocked(X, A, dinv, tid);
-  store_tile(tile_ptr(sv, slot_ij), X, tid);
-}
-
-// backward solve, levels in reverse; one workgroup per column j:  y_j = L_jj^-T ( z_j - sum_i L_ij^T y_i )
-__global__ __launch_bounds__(256) void chol_back_kernel(const SolverDev sv, const int32_t* info, const int32_t* ptr, const int32_t* list) {
-  __shared__ double A[T * TP];
-  __shared__ double part[10][T];
-  const int tid = threadIdx.x, b = blockIdx.x;
-  const int c2 = tid % 24, rg = tid / 24;   // column pair, row group (rg < 10 for tid < 240)
-  const int slot_jj = info[2 * b], tile_j = info[2 * b + 1];
-  load_tile(A, tile_ptr(sv, slot_jj), tid, true);
-  double s0 = 0.0, s1 = 0.0;
-  if (rg < 10) {
-    for (int p = ptr[b]; p < ptr[b + 1]; ++p) {
-      const double* lij = tile_ptr(sv, list[2 * p]) + 2 * c2;
-      const double* yi = sv.rhs + (size_t)list[2 * p + 1] * T;
-#pragma unroll
-      for (int u = 0; u < 5; ++u) {
-        const int r = rg + 10 * u;
-        if (r < T) {
-          const double2 v = *reinterpret_cast<const double2*>(lij + (size_t)r * T);
-          const double y = yi[r];
-          s0 += v.x * y; s1 += v.y * y;
+            for (int t = 0; t < 3; ++t) bz[I] += g.a[u].v[I][t] * g.z[u][t];
+        } else {
+          acc.mac<false>(g.a[u], g.b[u]);
         }
       }
     }
-    part[rg][2 * c2] = s0; part[rg][2 * c2 + 1] = s1;
+  };
+  auto group_poll = [&](int p) { return ready.poll(min(p + kGroup, p1) - 1); };   // in order: the last one covers the group
+  auto group_need = [&](int p) { ready.need(min(p + kGroup, p1) - 1); };
+  group_need(p0);
+  if (DAG && threadIdx.x == 0 && s_trace_slot) s_trace_slot[5] = wall_clock64();
+  fetch_group(cur, p0);
+  for (int p = p0; p < p1; p += kGroup) {
+    const int pn = p + kGroup;
+    if (pn < p1) {
+      if (group_poll(pn)) { fetch_group(nxt, pn); mac_group(cur, p); }
+      else { mac_group(cur, p); group_need(pn); fetch_group(nxt, pn); }
+      cur = nxt;
+    } else {
+      if (DAG && threadIdx.x == 0 && s_trace_slot) { asm volatile("s_waitcnt vmcnt(0)"); s_trace_slot[6] = wall_clock64(); }
+      mac_group(cur, p);
+    }
+  }
+}
+
+// this wave's rhs partials: fold the four lane groups, lanes g == 0 write rows 16I + r of their wave's LDS vector
+__device__ __forceinline__ void spill_bz(double bz[3], double* vec, int lane) {
+#pragma unroll
+  for (int I = 0; I < 3; ++I) {
+    double x = bz[I];
+    x += __shfl_xor(x, 16, 64);
+    x += __shfl_xor(x, 32, 64);
+    if (lane < 16) vec[16 * I + lane] = x;
+  }
+}
+
+template <bool DAG>
+__device__ __forceinline__ void task_update(const SolverDev& sv, const CholPlan& pl, int item, double* smem, int tid) {
+  const int wave = tid >> 6, lane = tid & 63;
+  const int32_t* u = pl.upd + 4 * item;
+  const bool diag = u[0] == 0;
+  Acc acc; acc.clear();
+  double bz[3] = {0, 0, 0};
+  if (diag) accumulate<DAG, true>(sv, pl, pl.diag_list, u[1], u[2], acc, bz, wave, lane);
+  else accumulate<DAG, false>(sv, pl, pl.sub_list, u[1], u[2], acc, bz, wave, lane);
+  CHOL_STAMP(3);
+  acc.spill(smem + wave * kBuf, lane);
+  if (diag) spill_bz(bz, smem + kVecOff + wave * T, lane);
+  __syncthreads();
+  double* out = sv.chol_part + (size_t)u[3] * (T * T + T);
+  for (int e = tid; e < T * T; e += 256) {
+    const int o = (e / T) * TP + e % T;
+    st<DAG>(out + e, (smem[o] + smem[kBuf + o]) + (smem[2 * kBuf + o] + smem[3 * kBuf + o]));
+  }
+  if (diag && tid < T) { const double* v = smem + kVecOff; st<DAG>(out + T * T + tid, (v[tid] + v[T + tid]) + (v[2 * T + tid] + v[3 * T + tid])); }
+  CHOL_STAMP(4);
+  dag_publish<DAG>(pl, pl.nslots + u[3], tid);
+}
+
+// W = L^-1 for the factored lower-triangular tile L in LDS (pitch TP), into Wl (pitch TP; upper part left
+// untouched), by 12 x 12 blocks over all 256 threads: the four diagonal blocks are inverted by forward
+// substitution (one wave each, a lane per column), then block sub-diagonal d = 1, 2, 3 follows from the ones before:
+//   W_ab = -W_aa ( sum_{m=b}^{a-1} L_am W_mb ),  a - b = d.
+// Tm (pitch TP) is scratch for the inner sums.  All threads must call; ends with a barrier.
+__device__ __forceinline__ void invert_lower_blocked(const double* L, const double* dinv, double* Wl, double* Tm, int tid) {
+  const int wave = tid >> 6, lane = tid & 63;
+  {
+    const int o = NB * wave, c = lane < NB ? lane : NB - 1;
+    double w[NB];
+#pragma unroll
+    for (int r = 0; r < NB; ++r) {
+      double s = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+      for (int m = 0; m < r; ++m) s -= L[(o + r) * TP + o + m] * w[m];
+      w[r] = s * dinv[o + r];
+    }
+    if (lane < NB) {
+#pragma unroll
+      for (int r = 0; r < NB; ++r) Wl[(o + r) * TP + o + c] = w[r];
+    }
   }
   __syncthreads();
-  if (tid < 64) {
-    const int r = tid < T ? tid : T - 1;
-    double t = sv.rhs[(size_t)tile_j * T + r];
 #pragma unroll
-    for (int g = 0; g < 10; ++g) t -= part[g][r];
-    double colr[T];   // column r of L_jj = row r of L_jj^T
-#pragma unroll
-    for (int cc = 0; cc < T; ++cc) colr[cc] = A[cc * TP + r];
-    const double dinv = 1.0 / A[r * TP + r];
-#pragma unroll
-    for (int cc = T - 1; cc >= 0; --cc) {
-      const double y = __shfl(t * dinv, cc, 64);
-      if (tid == cc) t = y; else if (tid < cc) t -= colr[cc] * y;
+  for (int d = 1; d < T / NB; ++d) {
+    const int nblk = T / NB - d;
+    for (int e = tid; e < nblk * NB * NB; e += 256) {      // Tm_ab = sum_m L_am W_mb
+      const int blk = e / (NB * NB), r = (e / NB) % NB, c = e % NB, bb = blk, aa = blk + d;
+      double s0 = 0.0, s1 = 0.0;
+      for (int m = bb * NB; m < aa * NB; m += 2) { s0 += L[(aa * NB + r) * TP + m] * Wl[m * TP + bb * NB + c]; s1 += L[(aa * NB + r) * TP + m + 1] * Wl[(m + 1) * TP + bb * NB + c]; }
+      Tm[(aa * NB + r) * TP + bb * NB + c] = s0 + s1;
     }
-    if (tid < T) sv.rhs[(size_t)tile_j * T + tid] = t;
+    __syncthreads();
+    for (int e = tid; e < nblk * NB * NB; e += 256) {      // W_ab = -W_aa Tm_ab
+      const int blk = e / (NB * NB), r = (e / NB) % NB, c = e % NB, bb = blk, aa = blk + d;
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int m = 0; m < NB; m += 2) { s0 += Wl[(aa * NB + r) * TP + aa * NB + m] * Tm[(aa * NB + m) * TP + bb * NB + c]; s1 += Wl[(aa * NB + r) * TP + aa * NB + m + 1] * Tm[(aa * NB + m + 1) * TP + bb * NB + c]; }
+      Wl[(aa * NB + r) * TP + bb * NB + c] = -(s0 + s1);
+    }
+    __syncthreads();
+  }
+}
+
+template <bool DAG>
+__device__ __forceinline__ void task_diag(const SolverDev& sv, const CholPlan& pl, int b, double* smem, int tid) {
+  const int wave = tid >> 6, lane = tid & 63;
+  double* D = smem; double* Wl = smem + kBuf;
+  double* vec = smem + kVecOff; double* bvec = vec + 4 * T; double* dinv = vec + 5 * T; int* s_okp = reinterpret_cast<int*>(vec + 6 * T);
+  const int32_t* info = pl.diag_info + 4 * b;
+  const int slot_jj = info[0], tile_j = info[1], part0 = info[2], nparts = info[3];
+  const int p0 = pl.diag_own[b], p1 = pl.diag_ptr[b + 1];   // the owner's share of the contributor list
+  // the tile itself (left by the Schur kernels before this launch) travels while the updates are formed
+  double sreg[9];
+  const double* src = tile_ptr(sv, slot_jj);
+#pragma unroll
+  for (int q = 0; q < 9; ++q) sreg[q] = src[tid + 256 * q];
+  double breg = tid < T ? sv.rhs[(size_t)tile_j * T + tid] : 0.0;
+  if (nparts > 0) {   // the early part of a long contributor list arrives pre-reduced (UPDATE tasks), well before the owner's own share
+    auto ready = make_ready<DAG>(pl, 0, nparts, [&](int c) { return flag_set(pl, pl.nslots + part0 + c); });
+    ready.need(nparts - 1);
+    for (int c0 = 0; c0 < nparts; c0 += 4) {   // four partials' loads in flight together
+      double pv[4][9], pb[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double* part = sv.chol_part + (size_t)(part0 + min(c0 + u, nparts - 1)) * (T * T + T);
+#pragma unroll
+        for (int q = 0; q < 9; ++q) pv[u][q] = ld<DAG>(part + tid + 256 * q);
+        pb[u] = tid < T ? ld<DAG>(part + T * T + tid) : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (c0 + u < nparts) {
+#pragma unroll
+          for (int q = 0; q < 9; ++q) sreg[q] -= pv[u][q];
+          breg -= pb[u];
+        }
+    }
+  }
+  Acc acc; acc.clear();
+  double bz[3] = {0, 0, 0};
+  accumulate<DAG, true>(sv, pl, pl.diag_list, p0, p1, acc, bz, wave, lane);
+  CHOL_STAMP(3);
+  acc.spill(smem + wave * kBuf, lane);
+  spill_bz(bz, vec + wave * T, lane);
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 9; ++q) {
+    const int e = tid + 256 * q, r = e / T, c = e % T, o = r * TP + c;
+    const double upd = (smem[o] + smem[kBuf + o]) + (smem[2 * kBuf + o] + smem[3 * kBuf + o]);
+    sreg[q] = (c <= r) ? sreg[q] - upd : 0.0;
+  }
+  if (tid < T) bvec[tid] = breg - ((vec[tid] + vec[T + tid]) + (vec[2 * T + tid] + vec[3 * T + tid]));
+  if (tid == 0) *s_okp = 1;
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 9; ++q) { const int e = tid + 256 * q; D[(e / T) * TP + e % T] = sreg[q]; }
+  __syncthreads();
+  CHOL_STAMP(4);
+  const bool ok = potrf_blocked(D, tid);
+  if (tid < 64 && !ok) *s_okp = 0;
+  if (tid < T) dinv[tid] = 1.0 / D[tid * TP + tid];
+  __syncthreads();
+  CHOL_STAMP(5);
+  if (!*s_okp && tid == 0) atomicExch(sv.chol_fail, 1);
+  {
+    double* out = tile_ptr(sv, slot_jj);   // L_jj itself is only kept for inspection: everything downstream uses W_j
+    for (int e = tid; e < T * T; e += 256) { const int r = e / T, c = e % T; st<DAG>(out + e, (c <= r) ? D[r * TP + c] : 0.0); }
+  }
+  invert_lower_blocked(D, dinv, Wl, smem + 2 * kBuf, tid);
+  CHOL_STAMP(6);
+  double* wout = sv.Winv + (size_t)tile_j * (T * T);
+  for (int e = tid; e < T * T; e += 256) { const int r = e / T, c = e % T; st<DAG>(wout + e, (c <= r) ? Wl[r * TP + c] : 0.0); }
+  if (tid < T) {   // z_j = W b
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll 8
+    for (int m = 0; m < T; m += 2) { if (m <= tid) s0 += Wl[tid * TP + m] * bvec[m]; if (m + 1 <= tid) s1 += Wl[tid * TP + m + 1] * bvec[m + 1]; }
+    st<DAG>(sv.rhs + (size_t)tile_j * T + tid, s0 + s1);
+  }
+  dag_publish<DAG>(pl, slot_jj, tid);
+}
+
+template <bool DAG>
+__device__ __forceinline__ void task_sub(const SolverDev& sv, const CholPlan& pl, int b, double* smem, int tid) {
+  const int wave = tid >> 6, lane = tid & 63;
+  double* X = smem;
+  const int32_t* info = pl.sub_info + 4 * b;
+  const int slot_ij = info[0], slot_jj = info[1], part0 = info[2], nparts = info[3], tile_j = pl.sub_col[b];
+  const int p0 = pl.sub_own[b], p1 = pl.sub_ptr[b + 1];
+  double sreg[9];
+  const double* src = tile_ptr(sv, slot_ij);
+#pragma unroll
+  for (int q = 0; q < 9; ++q) sreg[q] = src[tid + 256 * q];
+  if (nparts > 0) {
+    auto ready = make_ready<DAG>(pl, 0, nparts, [&](int c) { return flag_set(pl, pl.nslots + part0 + c); });
+    ready.need(nparts - 1);
+    for (int c0 = 0; c0 < nparts; c0 += 4) {
+      double pv[4][9];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double* part = sv.chol_part + (size_t)(part0 + min(c0 + u, nparts - 1)) * (T * T + T);
+#pragma unroll
+        for (int q = 0; q < 9; ++q) pv[u][q] = ld<DAG>(part + tid + 256 * q);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (c0 + u < nparts) {
+#pragma unroll
+          for (int q = 0; q < 9; ++q) sreg[q] -= pv[u][q];
+        }
+    }
+  }
+  Acc acc; acc.clear();
+  double bz[3] = {0, 0, 0};
+  accumulate<DAG, false>(sv, pl, pl.sub_list, p0, p1, acc, bz, wave, lane);
+  CHOL_STAMP(3);
+  acc.spill(smem + wave * kBuf, lane);
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 9; ++q) {
+    const int e = tid + 256 * q, o = (e / T) * TP + e % T;
+    sreg[q] -= (smem[o] + smem[kBuf + o]) + (smem[2 * kBuf + o] + smem[3 * kBuf + o]);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 9; ++q) { const int e = tid + 256 * q; X[(e / T) * TP + e % T] = sreg[q]; }
+  CHOL_STAMP(4);
+  { auto ready = make_ready<DAG>(pl, 0, 1, [&](int) { return flag_set(pl, slot_jj); }); ready.need(0); }   // W_j, from the DIAG task of this column
+  __syncthreads();
+  CHOL_STAMP(5);
+  // L_ij = X W^T: wave I forms row block I; W is lower triangular, so column block J only needs k < 16 (J + 1)
+  if (wave < 3) {
+    const int I = wave, r = lane & 15, g = lane >> 4;
+    const double* Wg = sv.Winv + (size_t)tile_j * (T * T);
+    double* out = tile_ptr(sv, slot_ij);
+    double wv[3][12];   // B operand: W[16J + r][4kk + g]
+#pragma unroll
+    for (int J = 0; J < 3; ++J)
+#pragma unroll
+      for (int kk = 0; kk < 4 * (J + 1); ++kk) wv[J][kk] = ld<DAG>(Wg + (16 * J + r) * T + 4 * kk + g);
+    dbl4 c[3] = {dbl4{0, 0, 0, 0}, dbl4{0, 0, 0, 0}, dbl4{0, 0, 0, 0}};
+#pragma unroll
+    for (int kk = 0; kk < 12; ++kk) {
+      const double a = X[(16 * I + r) * TP + 4 * kk + g];
+#pragma unroll
+      for (int J = 0; J < 3; ++J)
+        if (kk < 4 * (J + 1)) c[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, wv[J][kk], c[J], 0, 0, 0);
+    }
+#pragma unroll
+    for (int J = 0; J < 3; ++J)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) st<DAG>(out + (16 * I + g + 4 * v) * T + 16 * J + r, c[J][v]);
+  }
+  CHOL_STAMP(6);
+  dag_publish<DAG>(pl, slot_ij, tid);
+}
+
+template <bool DAG>
+__device__ __forceinline__ void task_back(const SolverDev& sv, const CholPlan& pl, int b, double* smem, int tid) {
+  double* part = smem;            // [10][T]
+  double* tvec = smem + 10 * T;   // [T]
+  const int32_t* list = pl.back_list;
+  const int c2 = tid % 24, rg = tid / 24;   // column pair, row group (rg < 10 for tid < 240)
+  const int slot_jj = pl.back_info[2 * b], tile_j = pl.back_info[2 * b + 1];
+  const int p0 = pl.back_ptr[b], p1 = pl.back_ptr[b + 1];
+  const int ybase = pl.nslots + pl.nparts;
+  // rows of a 48 x 48 tile handled by this thread: rg, rg + 10, .. ; columns 2 c2, 2 c2 + 1
+  auto gather = [&](const double* tile, const double* y, double2 v[5], double yy[5], bool LDSY) {
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+      const int r = rg + 10 * u;
+      if (rg < 10 && r < T) { const double* q = tile + (size_t)r * T + 2 * c2; v[u] = make_double2(ld<DAG>(q), ld<DAG>(q + 1)); yy[u] = LDSY ? y[r] : ld<DAG>(y + r); }
+      else { v[u] = make_double2(0.0, 0.0); yy[u] = 0.0; }
+    }
+  };
+  double s0 = 0.0, s1 = 0.0;
+  if (p0 < p1) {
+    // L_ij (forward phase) is long finished; y_i is what the task waits for.  The host lists the tiles of the
+    // column bottom-up, the order in which the y_i become available; loads run one group of four tiles ahead.
+    auto ready = make_ready<DAG>(pl, p0, p1, [&](int p) { return flag_set(pl, list[2 * p]) & flag_set(pl, ybase + list[2 * p + 1]); });
+    constexpr int kGroup = 4;
+    struct Group { double2 v[kGroup][5]; double yy[kGroup][5]; };
+    Group cur, nxt;
+    auto fetch_group = [&](Group& g, int p) {
+#pragma unroll
+      for (int u = 0; u < kGroup; ++u) { const int q = min(p + u, p1 - 1); gather(tile_ptr(sv, list[2 * q]), sv.rhs + (size_t)list[2 * q + 1] * T, g.v[u], g.yy[u], false); }
+    };
+    auto mac_group = [&](const Group& g, int p) {
+#pragma unroll
+      for (int u = 0; u < kGroup; ++u)
+        if (p + u < p1) {
+#pragma unroll
+          for (int k = 0; k < 5; ++k) { s0 += g.v[u][k].x * g.yy[u][k]; s1 += g.v[u][k].y * g.yy[u][k]; }
+        }
+    };
+    auto group_poll = [&](int p) { return ready.poll(min(p + kGroup, p1) - 1); };
+    auto group_need = [&](int p) { ready.need(min(p + kGroup, p1) - 1); };
+    group_need(p0);
+    fetch_group(cur, p0);
+    for (int p = p0; p < p1; p += kGroup) {
+      const int pn = p + kGroup;
+      if (pn < p1) {
+        if (group_poll(pn)) { fetch_group(nxt, pn); mac_group(cur, p); }
+        else { mac_group(cur, p); group_need(pn); fetch_group(nxt, pn); }
+        cur = nxt;
+      } else {
+        mac_group(cur, p);
+      }
+    }
+  }
+  { auto ready = make_ready<DAG>(pl, 0, 1, [&](int) { return flag_set(pl, slot_jj); }); ready.need(0); }   // z_j and W_j
+  if (rg < 10) { part[rg * T + 2 * c2] = s0; part[rg * T + 2 * c2 + 1] = s1; }
+  __syncthreads();
+  CHOL_STAMP(3);
+  if (tid < T) {
+    double t = ld<DAG>(sv.rhs + (size_t)tile_j * T + tid);
+#pragma unroll
+    for (int g = 0; g < 10; ++g) t -= part[g * T + tid];
+    tvec[tid] = t;
+  }
+  __syncthreads();
+  // y = W^T t
+  {
+    const double* Wg = sv.Winv + (size_t)tile_j * (T * T);
+    double2 v[5]; double yy[5];
+    gather(Wg, tvec, v, yy, true);
+    s0 = 0.0; s1 = 0.0;
+#pragma unroll
+    for (int u = 0; u < 5; ++u) { s0 += v[u].x * yy[u]; s1 += v[u].y * yy[u]; }
+  }
+  __syncthreads();
+  if (rg < 10) { part[rg * T + 2 * c2] = s0; part[rg * T + 2 * c2 + 1] = s1; }
+  __syncthreads();
+  if (tid < T) {
+    double y = 0.0;
+#pragma unroll
+    for (int g = 0; g < 10; ++g) y += part[g * T + tid];
+    st<DAG>(sv.rhs + (size_t)tile_j * T + tid, y);
+  }
+  CHOL_STAMP(4);
+  dag_publish<DAG>(pl, ybase + tile_j, tid);
+}
+
+template <bool DAG>
+__device__ __forceinline__ void run_task(const SolverDev& sv, const CholPlan& pl, int kind, int item, double* smem, int tid) {
+  switch (kind) {
+    case kTaskUpdate: task_update<DAG>(sv, pl, item, smem, tid); break;
+    case kTaskDiag: task_diag<DAG>(sv, pl, item, smem, tid); break;
+    case kTaskSub: task_sub<DAG>(sv, pl, item, smem, tid); break;
+    default: task_back<DAG>(sv, pl, item, smem, tid); break;
+  }
+}
+
+// one launch per (level, kind): items first .. first + gridDim.x of one kind
+__global__ __launch_bounds__(256) void chol_level_kernel(const SolverDev sv, const CholPlan pl, int kind, int first) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  run_task<false>(sv, pl, kind, first + blockIdx.x, smem, threadIdx.x);
+}
+
+// the whole factorisation + both triangular solves in one persistent launch
+__global__ __launch_bounds__(256) void chol_dag_kernel(const SolverDev sv, const CholPlan pl) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  __shared__ int s_ticket;
+  const int tid = threadIdx.x;
+  for (;;) {
+    __syncthreads();   // the previous task's LDS is free, s_ticket has been read by everyone
+    if (tid == 0) {
+      const int tk = (int)__hip_atomic_fetch_add(pl.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_ticket = tk;
+      s_trace_slot = (pl.trace && tk < pl.ntasks) ? pl.trace + 8 * (size_t)tk : nullptr;
+      if (s_trace_slot) { s_trace_slot[0] = blockIdx.x; s_trace_slot[1] = s_trace_slot[2] = wall_clock64(); }
+    }
+    __syncthreads();
+    const int t = s_ticket;
+    if (t >= pl.ntasks) return;
+    run_task<true>(sv, pl, pl.tasks[2 * t], pl.tasks[2 * t + 1], smem, tid);
+    if (tid == 0 && s_trace_slot) s_trace_slot[7] = wall_clock64();
   }
 }
 
@@ -375,32 +686,24 @@ hipError_t set_lds(K kernel, size_t bytes, bool& configured) {
 }
 }  // namespace
 
-hipError_t launch_chol_update(const SolverDev& sv, int nitem, const int32_t* upd, const int32_t* diag_list, const int32_t* sub_list, hipStream_t st) {
-  if (nitem <= 0) return hipSuccess;
-  hipLaunchKernelGGL(chol_update_kernel, dim3(nitem), dim3(256), 0, st, sv, upd, diag_list, sub_list);
-  return hipGetLastError();
-}
-hipError_t launch_chol_diag(const SolverDev& sv, int ncol, const int32_t* info, const int32_t* ptr, const int32_t* list, hipStream_t st) {
-  if (ncol <= 0) return hipSuccess;
-  const size_t lds = (size_t)(2 * T * TP + T) * sizeof(double) + 16;
+hipError_t launch_chol_level(const SolverDev& sv, const CholPlan& pl, int kind, int first, int count, hipStream_t st) {
+  if (count <= 0) return hipSuccess;
   static bool configured = false;
-  hipError_t e = set_lds(chol_diag_kernel, lds, configured);
+  hipError_t e = set_lds(chol_level_kernel, kCholLds * sizeof(double), configured);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(chol_diag_kernel, dim3(ncol), dim3(256), lds, st, sv, info, ptr, list);
+  hipLaunchKernelGGL(chol_level_kernel, dim3(count), dim3(256), kCholLds * sizeof(double), st, sv, pl, kind, first);
   return hipGetLastError();
 }
-hipError_t launch_chol_sub(const SolverDev& sv, int ntile, const int32_t* info, const int32_t* ptr, const int32_t* list, hipStream_t st) {
-  if (ntile <= 0) return hipSuccess;
-  const size_t lds = (size_t)(3 * T * TP + T) * sizeof(double) + 16;
+
+hipError_t launch_chol_dag(const SolverDev& sv, const CholPlan& pl, int workgroups, hipStream_t st) {
+  if (pl.ntasks <= 0) return hipSuccess;
   static bool configured = false;
-  hipError_t e = set_lds(chol_sub_kernel, lds, configured);
+  hipError_t e = set_lds(chol_dag_kernel, kCholLds * sizeof(double), configured);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(chol_sub_kernel, dim3(ntile), dim3(256), lds, st, sv, info, ptr, list);
-  return hipGetLastError();
-}
-hipError_t launch_chol_back(const SolverDev& sv, int ncol, const int32_t* info, const int32_t* ptr, const int32_t* list, hipStream_t st) {
-  if (ncol <= 0) return hipSuccess;
-  hipLaunchKernelGGL(chol_back_kernel, dim3(ncol), dim3(256), 0, st, sv, info, ptr, list);
+  // ticket counter and flags sit in one allocation: [ticket (as 4 bytes, padded to 16) | flags]
+  e = hipMemsetAsync(pl.ticket, 0, 16 + sizeof(int32_t) * ((size_t)pl.nslots + pl.nparts + sv.nt), st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(chol_dag_kernel, dim3(workgroups), dim3(256), kCholLds * sizeof(double), st, sv, pl);
   return hipGetLastError();
 }
 

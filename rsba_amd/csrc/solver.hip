@@ -7,6 +7,7 @@
 // (costs, model decrease, step / parameter norms, gradient max-norm, failure flags) and decides.
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -21,10 +22,6 @@
 
 namespace rsba {
 
-hipError_t launch_chol_update(const SolverDev& sv, int nitem, const int32_t* upd, const int32_t* diag_list, const int32_t* sub_list, hipStream_t st);
-hipError_t launch_chol_diag(const SolverDev& sv, int ncol, const int32_t* info, const int32_t* ptr, const int32_t* list, hipStream_t st);
-hipError_t launch_chol_sub(const SolverDev& sv, int ntile, const int32_t* info, const int32_t* ptr, const int32_t* list, hipStream_t st);
-hipError_t launch_chol_back(const SolverDev& sv, int ncol, const int32_t* info, const int32_t* ptr, const int32_t* list, hipStream_t st);
 
 struct Solver {
   SolverDev sv{};
@@ -34,10 +31,19 @@ struct Solver {
   std::vector<int32_t> lev_diag_ptr, lev_sub_ptr, lev_upd_ptr, upd;   // [nlev+1] ranges of diag / sub / update items per level
   int32_t* d_upd = nullptr;
   std::vector<int32_t> diag_info, diag_ptr, diag_list;                // per column: {slot_jj, old tile}; contributors {slot_jk, old tile k}
+  std::vector<int32_t> diag_own, sub_own;                             // first contributor the owner multiplies itself (the ones before arrive as partial tiles)
+  std::vector<int32_t> sub_col;                                       // per sub tile: tile index of its column (W_j, z_j)
   std::vector<int32_t> sub_info, sub_ptr, sub_list;                   // per tile (i,j): {slot_ij, slot_jj}; contributors {slot_ik, slot_jk}
   std::vector<int32_t> back_info, back_ptr, back_list;                // per column: {slot_jj, old tile}; tiles {slot_ij, old tile i}
   int32_t *d_diag_info = nullptr, *d_diag_ptr = nullptr, *d_diag_list = nullptr, *d_sub_info = nullptr, *d_sub_ptr = nullptr,
-          *d_sub_list = nullptr, *d_back_info = nullptr, *d_back_ptr = nullptr, *d_back_list = nullptr;
+          *d_sub_list = nullptr, *d_sub_col = nullptr, *d_diag_own = nullptr, *d_sub_own = nullptr, *d_back_info = nullptr, *d_back_ptr = nullptr, *d_back_list = nullptr;
+  std::vector<int32_t> tasks;                                         // {kind, item} in level order, backward solve last
+  int32_t* d_tasks = nullptr;
+  unsigned int* d_dag_sync = nullptr;                                 // [ticket, pad x3 | flags]
+  long long* d_trace = nullptr;                                       // RSBA_CHOL_TRACE=<file>: task time stamps of the last factorisation
+  CholPlan plan{};
+  int dag_workgroups = 0;
+  bool use_levels = false;                                            // RSBA_CHOL_LEVELS=1: one launch per (level, kind)
   int last_diag_slot = 0;
   int32_t* d_obs_slot = nullptr;
   double *d_gpose = nullptr, *d_gpoint = nullptr;
@@ -294,42 +300,65 @@ int32_t build_solver(rsba_handle* h) {
   // of 48^3 products in one workgroup; its contributor list is cut into chunks of kChunk that separate
   // workgroups reduce to partial tiles (fixed split, fixed order: still deterministic), summed by the
   // factor kernels.  upd items: {kind 0 diag / 1 sub, list begin, list end, scratch slot}.
-  const int kChunk = 6;
+  // The owner of a tile keeps the last kTail contributors — the ones from the latest levels, the list being sorted by
+  // level — for itself: on the critical path a freshly finished tile is then multiplied by its consumer directly
+  // instead of passing through a partial tile in HBM (one publish and two memory round trips less per level).
+  // An UPDATE task becomes runnable one level after its last contributor, which is where it enters the ticket order.
+  const int kChunk = 6, kTail = 4;
   s->lev_diag_ptr.assign(1, 0); s->lev_sub_ptr.assign(1, 0); s->lev_upd_ptr.assign(1, 0);
   s->diag_ptr.assign(1, 0); s->sub_ptr.assign(1, 0); s->back_ptr.assign(1, 0);
-  int max_parts = 1;
+  int parts = 0;
+  std::vector<std::vector<int32_t>> upd_by_level(nlev);
+  std::vector<int32_t> klev;   // level of each contributor of the list being built
   for (int l = 0; l < nlev; ++l) {
-    int parts = 0;
-    auto chunk_it = [&](int kind, int32_t p0, int32_t p1, std::vector<int32_t>& info) {
-      if (p1 - p0 <= kChunk) { info.push_back(0); info.push_back(0); return; }
+    const size_t diag0 = s->diag_info.size() / 4, sub0 = s->sub_info.size() / 4;
+    auto chunk_it = [&](int kind, int32_t p0, int32_t p1, std::vector<int32_t>& info, std::vector<int32_t>& own) {
+      if (p1 - p0 <= kChunk) { info.push_back(0); info.push_back(0); own.push_back(p0); return; }
+      const int32_t own0 = p1 - kTail;
       info.push_back(parts);
       int cnt = 0;
-      for (int32_t q = p0; q < p1; q += kChunk) { s->upd.push_back(kind); s->upd.push_back(q); s->upd.push_back(std::min(q + kChunk, p1)); s->upd.push_back(parts++); ++cnt; }
+      for (int32_t q = p0; q < own0; q += kChunk) {
+        const int32_t q1 = std::min(q + kChunk, own0);
+        upd_by_level[klev[q1 - 1 - p0] + 1].push_back((int32_t)(s->upd.size() / 4));
+        s->upd.push_back(kind); s->upd.push_back(q); s->upd.push_back(q1); s->upd.push_back(parts++); ++cnt;
+      }
       info.push_back(cnt);
+      own.push_back(own0);
     };
     for (int32_t j : lev_cols[l]) {
+      std::vector<int32_t> rj(row[j]);   // contributors in the order they finish
+      std::stable_sort(rj.begin(), rj.end(), [&](int32_t x, int32_t y) { return level[x] < level[y]; });
       s->diag_info.push_back(slot_base[j]); s->diag_info.push_back(perm[j]);
       const int32_t dp0 = (int32_t)(s->diag_list.size() / 2);
-      for (int32_t k : row[j]) { s->diag_list.push_back(slot_of(j, k)); s->diag_list.push_back(perm[k]); }
+      klev.clear();
+      for (int32_t k : rj) { s->diag_list.push_back(slot_of(j, k)); s->diag_list.push_back(perm[k]); klev.push_back(level[k]); }
       s->diag_ptr.push_back((int32_t)(s->diag_list.size() / 2));
-      chunk_it(0, dp0, (int32_t)(s->diag_list.size() / 2), s->diag_info);
+      chunk_it(0, dp0, (int32_t)(s->diag_list.size() / 2), s->diag_info, s->diag_own);
       s->back_info.push_back(slot_base[j]); s->back_info.push_back(perm[j]);
-      for (int32_t i : col[j]) { s->back_list.push_back(slot_of(i, j)); s->back_list.push_back(perm[i]); }
+      for (auto it = col[j].rbegin(); it != col[j].rend(); ++it) { s->back_list.push_back(slot_of(*it, j)); s->back_list.push_back(perm[*it]); }   // bottom-up: the order the y_i arrive in
       s->back_ptr.push_back((int32_t)(s->back_list.size() / 2));
       for (int32_t i : col[j]) {
-        s->sub_info.push_back(slot_of(i, j)); s->sub_info.push_back(slot_base[j]);
+        s->sub_info.push_back(slot_of(i, j)); s->sub_info.push_back(slot_base[j]); s->sub_col.push_back(perm[j]);
         const int32_t sp0 = (int32_t)(s->sub_list.size() / 2);
         // k in row[j] with tile (i,k) present
-        for (int32_t k : row[j]) { const int32_t sik = slot_of(i, k); if (sik >= 0) { s->sub_list.push_back(sik); s->sub_list.push_back(slot_of(j, k)); } }
+        klev.clear();
+        for (int32_t k : rj) { const int32_t sik = slot_of(i, k); if (sik >= 0) { s->sub_list.push_back(sik); s->sub_list.push_back(slot_of(j, k)); klev.push_back(level[k]); } }
         s->sub_ptr.push_back((int32_t)(s->sub_list.size() / 2));
-        chunk_it(1, sp0, (int32_t)(s->sub_list.size() / 2), s->sub_info);
+        chunk_it(1, sp0, (int32_t)(s->sub_list.size() / 2), s->sub_info, s->sub_own);
       }
     }
-    max_parts = std::max(max_parts, parts);
     s->lev_diag_ptr.push_back((int32_t)(s->diag_info.size() / 4));
     s->lev_sub_ptr.push_back((int32_t)(s->sub_info.size() / 4));
     s->lev_upd_ptr.push_back((int32_t)(s->upd.size() / 4));
+    (void)diag0; (void)sub0;
   }
+  for (int l = 0; l < nlev; ++l) {
+    for (int32_t u : upd_by_level[l]) { s->tasks.push_back(kTaskUpdate); s->tasks.push_back(u); }
+    for (int d = s->lev_diag_ptr[l]; d < s->lev_diag_ptr[l + 1]; ++d) { s->tasks.push_back(kTaskDiag); s->tasks.push_back(d); }
+    for (int t = s->lev_sub_ptr[l]; t < s->lev_sub_ptr[l + 1]; ++t) { s->tasks.push_back(kTaskSub); s->tasks.push_back(t); }
+  }
+  for (int l = nlev - 1; l >= 0; --l)
+    for (int d = s->lev_diag_ptr[l]; d < s->lev_diag_ptr[l + 1]; ++d) { s->tasks.push_back(kTaskBack); s->tasks.push_back(d); }
   // chunks of kSchurChunk entries (one wave each) and, per tile pair, where the merged tile goes
   std::vector<int32_t> chunk_tp; std::vector<int64_t> chunk_e0; std::vector<int32_t> tp_chunk0(ntp + 1, 0);
   for (int t = 0; t < ntp; ++t) {
@@ -403,13 +432,19 @@ int32_t build_solver(rsba_handle* h) {
   if ((rc = s_upload_const(s, &sv.tp_add, tp_add))) return rc;
   if ((rc = s_alloc(s, &sv.schur_part, (size_t)std::max(sv.nchunk, 1) * (kTile * kTile + kTile)))) return rc;
   if ((rc = s_upload(s, &s->d_upd, s->upd))) return rc;
-  if ((rc = s_alloc(s, &sv.chol_part, (size_t)max_parts * (kTile * kTile + kTile)))) return rc;
+  if ((rc = s_alloc(s, &sv.chol_part, (size_t)std::max(parts, 1) * (kTile * kTile + kTile)))) return rc;
+  if ((rc = s_upload(s, &s->d_tasks, s->tasks))) return rc;
+  if ((rc = s_alloc(s, &s->d_dag_sync, 4 + (size_t)sv.nslots + parts + nt))) return rc;
   if ((rc = s_upload(s, &s->d_diag_info, s->diag_info))) return rc;
   if ((rc = s_upload(s, &s->d_diag_ptr, s->diag_ptr))) return rc;
   if ((rc = s_upload(s, &s->d_diag_list, s->diag_list))) return rc;
   if ((rc = s_upload(s, &s->d_sub_info, s->sub_info))) return rc;
   if ((rc = s_upload(s, &s->d_sub_ptr, s->sub_ptr))) return rc;
   if ((rc = s_upload(s, &s->d_sub_list, s->sub_list))) return rc;
+  if ((rc = s_upload(s, &s->d_sub_col, s->sub_col))) return rc;
+  if ((rc = s_upload(s, &s->d_diag_own, s->diag_own))) return rc;
+  if ((rc = s_upload(s, &s->d_sub_own, s->sub_own))) return rc;
+  if ((rc = s_alloc(s, &sv.Winv, (size_t)nt * kTile * kTile))) return rc;
   if ((rc = s_upload(s, &s->d_back_info, s->back_info))) return rc;
   if ((rc = s_upload(s, &s->d_back_ptr, s->back_ptr))) return rc;
   if ((rc = s_upload(s, &s->d_back_list, s->back_list))) return rc;
@@ -446,6 +481,20 @@ int32_t build_solver(rsba_handle* h) {
   if ((rc = s_alloc(s, &s->d_gpoint, (size_t)M * 3))) return rc;
   HIP_TRY(hipMemset(sv.scalars, 0, 16 * sizeof(double)));
   HIP_TRY(hipMemset(sv.chol_fail, 0, sizeof(int)));
+  CholPlan& pl = s->plan;
+  pl.upd = s->d_upd; pl.diag_info = s->d_diag_info; pl.diag_ptr = s->d_diag_ptr; pl.diag_list = s->d_diag_list;
+  pl.sub_info = s->d_sub_info; pl.sub_ptr = s->d_sub_ptr; pl.sub_list = s->d_sub_list; pl.sub_col = s->d_sub_col; pl.diag_own = s->d_diag_own; pl.sub_own = s->d_sub_own;
+  pl.back_info = s->d_back_info; pl.back_ptr = s->d_back_ptr; pl.back_list = s->d_back_list;
+  pl.tasks = s->d_tasks; pl.ntasks = (int)(s->tasks.size() / 2);
+  pl.ticket = s->d_dag_sync; pl.flags = reinterpret_cast<int32_t*>(s->d_dag_sync + 4);
+  pl.nslots = sv.nslots; pl.nparts = parts;
+  int cus = 0;
+  HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
+  s->dag_workgroups = std::max(1, std::min(pl.ntasks, std::max(cus, 1)));   // one 4-wave workgroup per CU (register budget)
+  if (std::getenv("RSBA_CHOL_TRACE")) { if ((rc = s_alloc(s, &s->d_trace, 8 * (size_t)pl.ntasks))) return rc; }
+  pl.trace = s->d_trace;
+  const char* lv = std::getenv("RSBA_CHOL_LEVELS");
+  s->use_levels = lv && lv[0] == '1';
   return RSBA_OK;
 }
 
@@ -497,17 +546,22 @@ int32_t factor_and_solve(rsba_handle* h, double radius) {
   HIP_TRY(launch_schur_blocks(h->dp, sv, radius, st));
   // exchange (2): partial reduced camera systems -> the full one on every rank (then factored redundantly)
   { int32_t rc = exchange(h, sv.S, (int64_t)sv.nslots * kTile * kTile + sv.npad, 0); if (rc) return rc; }
-  // level-scheduled left-looking tile Cholesky (forward solve rides along), then the backward solve
-  for (int l = 0; l < s->nlev; ++l) {
-    const int d0 = s->lev_diag_ptr[l], d1 = s->lev_diag_ptr[l + 1], t0 = s->lev_sub_ptr[l], t1 = s->lev_sub_ptr[l + 1];
-    const int u0 = s->lev_upd_ptr[l], u1 = s->lev_upd_ptr[l + 1];
-    if (u1 > u0) HIP_TRY(launch_chol_update(sv, u1 - u0, s->d_upd + 4 * (size_t)u0, s->d_diag_list, s->d_sub_list, st));
-    HIP_TRY(launch_chol_diag(sv, d1 - d0, s->d_diag_info + 4 * (size_t)d0, s->d_diag_ptr + d0, s->d_diag_list, st));
-    if (t1 > t0) HIP_TRY(launch_chol_sub(sv, t1 - t0, s->d_sub_info + 4 * (size_t)t0, s->d_sub_ptr + t0, s->d_sub_list, st));
-  }
-  for (int l = s->nlev - 1; l >= 0; --l) {
-    const int d0 = s->lev_diag_ptr[l], d1 = s->lev_diag_ptr[l + 1];
-    HIP_TRY(launch_chol_back(sv, d1 - d0, s->d_back_info + 2 * (size_t)d0, s->d_back_ptr + d0, s->d_back_list, st));
+  // left-looking tile Cholesky (forward solve rides along), then the backward solve: one persistent DAG
+  // launch, or — the schedule it is checked against — one launch per (level, kind)
+  if (!s->use_levels) {
+    HIP_TRY(launch_chol_dag(sv, s->plan, s->dag_workgroups, st));
+  } else {
+    for (int l = 0; l < s->nlev; ++l) {
+      const int d0 = s->lev_diag_ptr[l], d1 = s->lev_diag_ptr[l + 1], t0 = s->lev_sub_ptr[l], t1 = s->lev_sub_ptr[l + 1];
+      const int u0 = s->lev_upd_ptr[l], u1 = s->lev_upd_ptr[l + 1];
+      HIP_TRY(launch_chol_level(sv, s->plan, kTaskUpdate, u0, u1 - u0, st));
+      HIP_TRY(launch_chol_level(sv, s->plan, kTaskDiag, d0, d1 - d0, st));
+      HIP_TRY(launch_chol_level(sv, s->plan, kTaskSub, t0, t1 - t0, st));
+    }
+    for (int l = s->nlev - 1; l >= 0; --l) {
+      const int d0 = s->lev_diag_ptr[l], d1 = s->lev_diag_ptr[l + 1];
+      HIP_TRY(launch_chol_level(sv, s->plan, kTaskBack, d0, d1 - d0, st));
+    }
   }
   HIP_TRY(launch_back_substitute(h->dp, sv, st));
   return RSBA_OK;
@@ -645,6 +699,18 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
     if (!dp.calibrated) HIP_TRY(hipMemcpyAsync(h->desc.intrinsics, dp.intr, (size_t)dp.NI * 9 * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     sum->total_time_s = now_s() - t_start;
+    if (const char* path = h->solver->d_trace ? std::getenv("RSBA_CHOL_TRACE") : nullptr) {   // debugging aid, off by default
+      Solver* sl = h->solver;
+      std::vector<long long> tr(8 * (size_t)sl->plan.ntasks);
+      HIP_TRY(hipMemcpy(tr.data(), sl->d_trace, tr.size() * sizeof(long long), hipMemcpyDeviceToHost));
+      if (FILE* f = std::fopen(path, "wb")) {
+        const int32_t n = sl->plan.ntasks;
+        std::fwrite(&n, sizeof(n), 1, f);
+        std::fwrite(sl->tasks.data(), sizeof(int32_t), sl->tasks.size(), f);
+        std::fwrite(tr.data(), sizeof(long long), tr.size(), f);
+        std::fclose(f);
+      }
+    }
     return RSBA_OK;
   };
 

@@ -65,7 +65,8 @@ struct SolverDev {
   double* z;                    // [M][3]
   double* Pm;                   // [N + M*NPF][CD*3]  point-major, virtual records behind the real ones
   double* S;                    // [nslots][kTile][kTile] packed tiles of the reduced camera system / its factor
-  double* chol_part;            // [max chunks per level][kTile*kTile + kTile] partial update tiles (+ rhs partials)
+  double* Winv;                 // [nt][kTile][kTile] inverses of the factored diagonal tiles (by tile index)
+  double* chol_part;            // [all chunks][kTile*kTile + kTile] partial update tiles (+ rhs partials)
   double* rhs;                  // [npad] directly behind S (one exchange buffer) -> z (forward) -> y_c (backward)
   double* udiag;                // [F*CD] diag(U), global after the exchange
   double* xbuf;                 // [2*F*CD + 3] exchange buffer: g_c | diag(U) | cost, fixed cost, failed blocks
@@ -83,6 +84,23 @@ struct SolverDev {
 enum ScalarSlot : int {
   kModelCostChange = 0, kStepSq = 1, kXSq = 2, kGradMax = 3, kCost = 4, kFixedCost = 5, kEvalFailed = 6, kSolveFailed = 7,
 };
+
+// Cholesky task plan (cholesky.hip): flattened work lists of the symbolic phase, device pointers
+struct CholPlan {
+  const int32_t *upd, *diag_info, *diag_ptr, *diag_list, *sub_info, *sub_ptr, *sub_list, *sub_col, *diag_own, *sub_own, *back_info, *back_ptr, *back_list;
+  const int32_t* tasks;      // [ntasks][2] {kind, item} in a topological order
+  int ntasks;
+  int32_t* flags;            // [nslots tile done | nparts partial done | nt y done]
+  unsigned int* ticket;
+  long long* trace;          // debugging (RSBA_CHOL_TRACE): [ntasks][8] {workgroup, claimed, inputs ready, 4 task-specific stamps, done} in 10 ns ticks
+  int nslots, nparts;
+};
+
+enum : int { kTaskUpdate = 0, kTaskDiag = 1, kTaskSub = 2, kTaskBack = 3 };
+
+// cholesky.hip
+hipError_t launch_chol_level(const SolverDev& sv, const CholPlan& pl, int kind, int first, int count, hipStream_t st);
+hipError_t launch_chol_dag(const SolverDev& sv, const CholPlan& pl, int workgroups, hipStream_t st);
 
 // kernels_normal.hip
 hipError_t launch_camera_blocks(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);

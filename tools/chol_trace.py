@@ -1,0 +1,45 @@
+"""Timeline of the DAG Cholesky's tasks (RSBA_CHOL_TRACE): per kind, how long tasks waited for inputs and ran,
+and the end-to-end span.  usage: python tools/chol_trace.py [C4]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+path = "/tmp/chol_trace.bin"
+os.environ["RSBA_CHOL_TRACE"] = path
+from rsba_amd import capi
+from rsba_amd.scene import make_config
+name = sys.argv[1] if len(sys.argv) > 1 else "C4"
+prob = make_config(name).problem
+with capi.DeviceProblem(prob) as dp:
+    dp.solve(capi.default_options(max_num_iterations=4))
+raw = open(path, "rb").read()
+n = np.frombuffer(raw[:4], dtype=np.int32)[0]
+tasks = np.frombuffer(raw[4:4 + 8 * n], dtype=np.int32).reshape(n, 2)
+tr = np.frombuffer(raw[4 + 8 * n:], dtype=np.int64).reshape(n, 8).astype(np.float64)
+t0 = tr[:, 1].min()
+us = (tr[:, 1:] - t0) * 0.01
+us = np.concatenate([us[:, :2], us[:, 6:7], us[:, 2:6]], axis=1)   # claimed, ready, done, stamps 3..6
+print(f"{n} tasks, span {us[:, 2].max():.1f} us, workgroups {int(tr[:, 0].max()) + 1}")
+names = ["update", "diag", "sub", "back"]
+for k in range(4):
+    m = tasks[:, 0] == k
+    if not m.any(): continue
+    wait, run = us[m, 1] - us[m, 0], us[m, 2] - us[m, 1]
+    print(f"{names[k]:7s} n={m.sum():5d}  claimed->last late input: mean {wait.mean():8.1f} max {wait.max():8.1f}   after it: mean {run.mean():6.2f} p50 {np.median(run):6.2f} max {run.max():6.2f}   first start {us[m,0].min():8.1f} last end {us[m,2].max():8.1f}")
+    st = us[m][:, 3:7] - us[m][:, 1:2]
+    print("        stamps relative to the last late input (mean us):", np.round(np.nanmean(np.where(tr[m][:, 3:7] > 0, st, np.nan), axis=0), 2))
+m = tasks[:, 0] == 0
+left = tr[m, 6].astype(np.int64)
+after = (us[m, 3] - us[m, 1])
+for k in range(0, 8):
+    q = left == k
+    if q.any(): print(f"update tasks with {k} contributors left at the last late input: n={q.sum()}, accumulate end after it: mean {after[q].mean():.2f} us")
+m = (tasks[:, 0] == 0) & (tr[:, 2] == tr[:, 1])
+print('update tasks that never waited:', m.sum())
+t5 = (tr[m, 5] - tr[m, 1]) * 0.01; t6 = (tr[m, 6] - tr[m, 1]) * 0.01; t3 = (tr[m, 3] - tr[m, 1]) * 0.01; t7 = (tr[m, 7] - tr[m, 1]) * 0.01
+print("update tasks, since claim (median us): first group ready", np.median(t5), " last group's loads landed", np.median(t6), " accumulate end", np.median(t3), " done", np.median(t7))
+# critical chain: walk the diag tasks in order of completion
+d = np.where(tasks[:, 0] == 1)[0]
+order = d[np.argsort(us[d, 2])]
+ends = us[order, 2]
+print("diag completions (us), every 10th:", np.round(ends[::max(1, len(ends) // 25)], 1))
+np.save("/tmp/chol_trace.npy", np.concatenate([tasks, us], axis=1))

@@ -1,0 +1,29 @@
+"""LM iteration wall time of one configuration with the DAG Cholesky and with the per-level schedule (same task
+bodies), and the difference of the two solves.  usage: python tools/lm_time.py [C4] [iters]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from rsba_amd import capi
+from rsba_amd.scene import make_config
+
+name = sys.argv[1] if len(sys.argv) > 1 else "C4"
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+res = {}
+for mode in ("dag", "levels"):
+    os.environ["RSBA_CHOL_LEVELS"] = "1" if mode == "levels" else "0"
+    prob = make_config(name).problem
+    p0, x0 = prob.poses.copy(), prob.points.copy()
+    with capi.DeviceProblem(prob) as dp:
+        opt = capi.default_options(max_num_iterations=iters, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
+        for rep in range(2):
+            prob.poses[...] = p0; prob.points[...] = x0
+            dp.upload_parameters()
+            t0 = time.perf_counter()
+            summ, trace = dp.solve(opt)
+            dt = time.perf_counter() - t0
+        n = max(summ.num_iterations, 1)
+        print(f"{name} {mode}: {summ.num_iterations} iterations, {1e3 * dt / n:.3f} ms/iteration (wall {dt * 1e3:.1f} ms), "
+              f"cost {summ.initial_cost:.6e} -> {summ.final_cost:.9e}", flush=True)
+        res[mode] = (summ.final_cost, prob.poses.copy(), prob.points.copy())
+print("final cost rel diff", abs(res["dag"][0] - res["levels"][0]) / res["levels"][0],
+      "max pose diff", np.abs(res["dag"][1] - res["levels"][1]).max(), "max point diff", np.abs(res["dag"][2] - res["levels"][2]).max())
