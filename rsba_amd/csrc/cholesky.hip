@@ -354,48 +354,52 @@ __device__ __forceinline__ void task_update(const SolverDev& sv, const CholPlan&
   dag_publish<DAG>(pl, pl.nslots + u[3], tid);
 }
 
-// W = L^-1 for the factored lower-triangular tile L in LDS (pitch TP), into Wl (pitch TP; upper part left
-// untouched), by 12 x 12 blocks over all 256 threads: the four diagonal blocks are inverted by forward
-// substitution (one wave each, a lane per column), then block sub-diagonal d = 1, 2, 3 follows from the ones before:
-//   W_ab = -W_aa ( sum_{m=b}^{a-1} L_am W_mb ),  a - b = d.
-// Tm (pitch TP) is scratch for the inner sums.  All threads must call; ends with a barrier.
+// W = L^-1 for the factored lower-triangular tile L in LDS (pitch TP), into Wl (pitch TP; blocks above the
+// diagonal left untouched), by 16 x 16 blocks over all 256 threads — thread (r, c) = (tid >> 4, tid & 15) owns
+// element (r, c) of every block:
+//   W_bb = L_bb^-1 (forward substitution, one wave per block, a lane per column), then
+//   W_10 = -W_11 (L_10 W_00),  W_21 = -W_22 (L_21 W_11),  W_20 = -W_22 (L_20 W_00 + L_21 W_10).
+// Tm (pitch TP) is scratch for the inner products.  All threads must call; ends with a barrier.
 __device__ __forceinline__ void invert_lower_blocked(const double* L, const double* dinv, double* Wl, double* Tm, int tid) {
-  const int wave = tid >> 6, lane = tid & 63;
-  {
-    const int o = NB * wave, c = lane < NB ? lane : NB - 1;
-    double w[NB];
+  constexpr int B = 16;
+  const int wave = tid >> 6, lane = tid & 63, r = tid >> 4, c = tid & 15;
+  if (wave < 3) {
+    const int o = B * wave, cc = lane < B ? lane : B - 1;
+    double w[B];
 #pragma unroll
-    for (int r = 0; r < NB; ++r) {
-      double s = (r == c) ? 1.0 : 0.0;
+    for (int i = 0; i < B; ++i) {
+      double s = (i == cc) ? 1.0 : 0.0;
 #pragma unroll
-      for (int m = 0; m < r; ++m) s -= L[(o + r) * TP + o + m] * w[m];
-      w[r] = s * dinv[o + r];
+      for (int m = 0; m < i; ++m) s -= L[(o + i) * TP + o + m] * w[m];
+      w[i] = s * dinv[o + i];
     }
-    if (lane < NB) {
+    if (lane < B) {
 #pragma unroll
-      for (int r = 0; r < NB; ++r) Wl[(o + r) * TP + o + c] = w[r];
+      for (int i = 0; i < B; ++i) Wl[(o + i) * TP + o + cc] = w[i];
     }
   }
   __syncthreads();
+  // block (a, b) of X Y with X block row a from column xo, Y block column b from row yo
+  auto dot = [&](const double* X, int xr, int xo, const double* Y, int yo, int yc) {
+    double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-  for (int d = 1; d < T / NB; ++d) {
-    const int nblk = T / NB - d;
-    for (int e = tid; e < nblk * NB * NB; e += 256) {      // Tm_ab = sum_m L_am W_mb
-      const int blk = e / (NB * NB), r = (e / NB) % NB, c = e % NB, bb = blk, aa = blk + d;
-      double s0 = 0.0, s1 = 0.0;
-      for (int m = bb * NB; m < aa * NB; m += 2) { s0 += L[(aa * NB + r) * TP + m] * Wl[m * TP + bb * NB + c]; s1 += L[(aa * NB + r) * TP + m + 1] * Wl[(m + 1) * TP + bb * NB + c]; }
-      Tm[(aa * NB + r) * TP + bb * NB + c] = s0 + s1;
-    }
-    __syncthreads();
-    for (int e = tid; e < nblk * NB * NB; e += 256) {      // W_ab = -W_aa Tm_ab
-      const int blk = e / (NB * NB), r = (e / NB) % NB, c = e % NB, bb = blk, aa = blk + d;
-      double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-      for (int m = 0; m < NB; m += 2) { s0 += Wl[(aa * NB + r) * TP + aa * NB + m] * Tm[(aa * NB + m) * TP + bb * NB + c]; s1 += Wl[(aa * NB + r) * TP + aa * NB + m + 1] * Tm[(aa * NB + m + 1) * TP + bb * NB + c]; }
-      Wl[(aa * NB + r) * TP + bb * NB + c] = -(s0 + s1);
-    }
-    __syncthreads();
+    for (int m = 0; m < B; m += 2) { s0 += X[(xr + r) * TP + xo + m] * Y[(yo + m) * TP + yc + c]; s1 += X[(xr + r) * TP + xo + m + 1] * Y[(yo + m + 1) * TP + yc + c]; }
+    return s0 + s1;
+  };
+  {
+    const double t10 = dot(L, 16, 0, Wl, 0, 0), t21 = dot(L, 32, 16, Wl, 16, 16), t20 = dot(L, 32, 0, Wl, 0, 0);
+    Tm[(16 + r) * TP + c] = t10; Tm[(32 + r) * TP + 16 + c] = t21; Tm[(32 + r) * TP + c] = t20;
   }
+  __syncthreads();
+  {
+    const double w10 = -dot(Wl, 16, 16, Tm, 16, 0), w21 = -dot(Wl, 32, 32, Tm, 32, 16);
+    Wl[(16 + r) * TP + c] = w10; Wl[(32 + r) * TP + 16 + c] = w21;
+  }
+  __syncthreads();
+  Tm[(32 + r) * TP + c] += dot(L, 32, 16, Wl, 16, 0);
+  __syncthreads();
+  Wl[(32 + r) * TP + c] = -dot(Wl, 32, 32, Tm, 32, 0);
+  __syncthreads();
 }
 
 template <bool DAG>

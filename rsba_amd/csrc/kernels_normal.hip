@@ -384,92 +384,105 @@ __global__ __launch_bounds__(256) void project_kernel(const DeviceProblem dp, co
 
 // ---------------------------------------------------------------------------------------------
 // K5c  reduced camera system  S = U + D_c^2 - sum_j (sum_a P_aj)(sum_b P_bj)^T ,  rhs = g_c - sum P z
-// Work unit = ENTRY (point j, frame tiles I >= J): the point's P records in the FT frames of I and of J.
-// One workgroup per chunk of kSchurChunk entries; its 4 waves split the b-frames, lane (ia, r) of a wave
-// owns row r of the blocks (I*FT+ia, J*FT+ib) for the wave's ib.  Its own P row is a per-lane load; the P record of each b-frame is addressed
-// uniformly across the wave (one record, broadcast), so per entry every P record is fetched once for
-// FT x FT block products: 4x less traffic than a per-block pair list.  Chunks write partial tiles; the
-// merge kernel sums them in chunk order (fixed order, no atomics) and adds U, D_c^2, g_c.
+// Work unit = ENTRY (point j, frame tiles I >= J): the point's P records in the FT frames of I and of J, stacked
+// into A_j(I) and A_j(J) (48 x 3 each; a frame that does not see the point contributes the all-zero record).
+// The tile of the pair is the banded SYRK  S_IJ = sum_j A_j(I) A_j(J)^T  — GEMM-shaped, K = 3 per point — and runs
+// on v_mfma_f64_16x16x4_f64 with one point per MFMA step (k = the 3 coordinates + one zero column), operands
+// gathered from HBM/L2 straight into the instruction's register layout: lane (r = lane & 15, g = lane >> 4)
+// holds P[row 16 Ib + r][coordinate g] for the three 16-row blocks Ib of each side.  No LDS, no barrier in the
+// loop.  One workgroup per chunk of kSchurChunk entries; its four waves take every fourth entry and keep all
+// nine 16x16 blocks (loads run kDepth entries ahead of the MFMAs in a register ring), the four partial tiles meet
+// once in LDS.  The fp64 VALU form of this product was bound by LDS operand reads at 2.0 ms per 1k-camera
+// iteration.  Chunks write partial tiles; the merge kernel sums them in chunk order (fixed order, no atomics)
+// and adds U, D_c^2, g_c.
 // ---------------------------------------------------------------------------------------------
+typedef double dbl4 __attribute__((ext_vector_type(4)));
+
 template <int CD>
 __global__ __launch_bounds__(256) void schur_tile_kernel(const SolverDev sv, const double* __restrict__ Pm, const double* __restrict__ zz) {
   constexpr int FT = kTile / CD, PW = CD * 3;          // frames per tile, doubles per P record
-  constexpr int NREC = 2 * FT, ENT = NREC * PW;         // records / doubles staged per entry (288 doubles = 2304 B)
-  constexpr int IBW = FT / 4;                           // b-frames per wave (the 4 waves split the block columns)
-  constexpr int DEPTH = 4;                              // entries in flight (register ring)
-  __shared__ __attribute__((aligned(16))) double s_buf[2][ENT];
-  __shared__ int32_t s_slot[kSchurChunk * NREC];
-  __shared__ int32_t s_pt[kSchurChunk];
+  constexpr int NREC = 2 * FT;                         // records per entry
+  constexpr int TPITCH = kTile + 1;
+  constexpr int kDepth = 8;                            // entries in flight per wave
+  extern __shared__ __attribute__((aligned(16))) double smem[];   // slot table during the loop, partial tiles after it
+  int32_t* s_slot = reinterpret_cast<int32_t*>(smem);
+  int32_t* s_pt = s_slot + kSchurChunk * NREC;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4, gc = g < 3 ? g : 2;
   const int chunk = blockIdx.x;
-  const int ia = lane / CD, r = lane % CD;
-  const bool active = ia < FT;
   const int tp = sv.chunk_tp[chunk];
   const int64_t e0 = sv.chunk_e0[chunk];
   const int64_t eend = sv.tp_ptr[tp + 1];
   const int n = (int)((e0 + kSchurChunk < eend ? e0 + kSchurChunk : eend) - e0);
-  // the chunk's slot table goes to LDS once (coalesced), so the record loads below do not wait on it
   for (int k = tid; k < n * NREC; k += 256) s_slot[k] = sv.ent_slots[(size_t)e0 * NREC + k];
   for (int k = tid; k < n; k += 256) s_pt[k] = sv.ent_pt[e0 + k];
   __syncthreads();
-  double acc[IBW][CD], racc = 0.0;
+  // which record (frame of the tile) and which of its doubles this lane reads for block row Ib
+  int fa[3], off[3];
 #pragma unroll
-  for (int u = 0; u < IBW; ++u)
-#pragma unroll
-    for (int c = 0; c < CD; ++c) acc[u][c] = 0.0;
+  for (int Ib = 0; Ib < 3; ++Ib) { const int row = 16 * Ib + r; fa[Ib] = row / CD; off[Ib] = (row % CD) * 3 + gc; }
 
-  // The workgroup stages the 2*FT P records of entry e+DEPTH (one coalesced 16-B load per thread; a point
-  // that is not observed in a frame points at an all-zero record) while it multiplies entry e out of LDS:
-  // the record loads are DEPTH entries ahead of their use and every record is fetched once per entry.
-  const bool loader = tid < ENT / 2;
-  const int lq = tid / (PW / 2), lw = tid % (PW / 2);
-  double2 st[DEPTH];
-  auto fetch = [&](int k) -> double2 {
-    if (!loader || k >= n) return make_double2(0.0, 0.0);
-    return *reinterpret_cast<const double2*>(Pm + (size_t)s_slot[k * NREC + lq] * PW + 2 * lw);
+  dbl4 acc[3][3];
+#pragma unroll
+  for (int I = 0; I < 3; ++I)
+#pragma unroll
+    for (int J = 0; J < 3; ++J) acc[I][J] = dbl4{0.0, 0.0, 0.0, 0.0};
+  double racc[3] = {0.0, 0.0, 0.0};
+  double ra[kDepth][3], rb[kDepth][3], rz[kDepth];
+  // loads of entry k (clamped into the chunk: the tail re-reads its last entry instead of branching)
+  auto fetch = [&](int k, double a[3], double b[3], double& z) {
+    const int kk = k < n ? k : n - 1;
+    const int32_t* sl = s_slot + kk * NREC;
+#pragma unroll
+    for (int Ib = 0; Ib < 3; ++Ib) {
+      const double va = Pm[(size_t)sl[fa[Ib]] * PW + off[Ib]];
+      const double vb = Pm[(size_t)sl[FT + fa[Ib]] * PW + off[Ib]];
+      a[Ib] = g < 3 ? va : 0.0; b[Ib] = g < 3 ? vb : 0.0;
+    }
+    const int pt = s_pt[kk];
+    const double zv = zz[(size_t)(pt & 0x7fffffff) * 3 + gc];
+    z = (pt < 0 && g < 3) ? zv : 0.0;     // top bit: diagonal entry of the point -> rhs term P z
   };
 #pragma unroll
-  for (int d = 0; d < DEPTH; ++d) st[d] = fetch(d);
-  for (int base = 0; base < n; base += DEPTH) {
+  for (int d = 0; d < kDepth; ++d) fetch(wave + 4 * d, ra[d], rb[d], rz[d]);
+  for (int base = wave; base < n; base += 4 * kDepth) {
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) {
-      const int k = base + d;
-      if (k < n) {                                       // n is uniform across the workgroup
-        const int cur = d & 1;
-        if (loader) *reinterpret_cast<double2*>(&s_buf[cur][2 * tid]) = st[d];
-        __syncthreads();
-        st[d] = fetch(k + DEPTH);
-        const double* buf = s_buf[cur];
-        double x0 = 0.0, x1 = 0.0, x2 = 0.0;
-        if (active) { const double* pa = buf + ia * PW + r * 3; x0 = pa[0]; x1 = pa[1]; x2 = pa[2]; }
+    for (int d = 0; d < kDepth; ++d) {
+      const int k = base + 4 * d;
+      if (k < n) {
 #pragma unroll
-        for (int u = 0; u < IBW; ++u) {
-          const double2* pb = reinterpret_cast<const double2*>(buf + (FT + wave * IBW + u) * PW);   // one address per wave: LDS broadcast
-          double w[PW];
+        for (int I = 0; I < 3; ++I)
 #pragma unroll
-          for (int q = 0; q < PW / 2; ++q) { const double2 v = pb[q]; w[2 * q] = v.x; w[2 * q + 1] = v.y; }
+          for (int J = 0; J < 3; ++J) acc[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[d][I], rb[d][J], acc[I][J], 0, 0, 0);
 #pragma unroll
-          for (int c = 0; c < CD; ++c) acc[u][c] += x0 * w[c * 3] + x1 * w[c * 3 + 1] + x2 * w[c * 3 + 2];
-        }
-        if (wave == 0) {
-          const int pt = s_pt[k];
-          if (pt < 0) {   // top bit: diagonal entry of the point -> rhs term
-            const double* z = zz + (size_t)(pt & 0x7fffffff) * 3;
-            racc += x0 * z[0] + x1 * z[1] + x2 * z[2];
-          }
-        }
+        for (int I = 0; I < 3; ++I) racc[I] += ra[d][I] * rz[d];
       }
+      fetch(k + 4 * kDepth, ra[d], rb[d], rz[d]);
     }
   }
-  if (active) {
-    double* part = sv.schur_part + (size_t)chunk * (kTile * kTile + kTile);
-    double* prow = part + (size_t)(ia * CD + r) * kTile;
+  __syncthreads();   // everyone is done with the slot table: the same LDS now takes the four partial tiles
+  double* buf = smem + wave * (kTile * TPITCH);
 #pragma unroll
-    for (int u = 0; u < IBW; ++u)
+  for (int I = 0; I < 3; ++I)
 #pragma unroll
-      for (int c = 0; c < CD; ++c) prow[(wave * IBW + u) * CD + c] = acc[u][c];
-    if (wave == 0) part[kTile * kTile + ia * CD + r] = racc;
+    for (int J = 0; J < 3; ++J)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) buf[(16 * I + g + 4 * v) * TPITCH + 16 * J + r] = acc[I][J][v];
+  double* rvec = smem + 4 * kTile * TPITCH + wave * kTile;
+#pragma unroll
+  for (int I = 0; I < 3; ++I) {
+    double x = racc[I];
+    x += __shfl_xor(x, 16, 64);
+    x += __shfl_xor(x, 32, 64);
+    if (lane < 16) rvec[16 * I + lane] = x;
   }
+  __syncthreads();
+  double* part = sv.schur_part + (size_t)chunk * (kTile * kTile + kTile);
+  for (int e = tid; e < kTile * kTile; e += 256) {
+    const int o = (e / kTile) * TPITCH + e % kTile;
+    part[e] = (smem[o] + smem[kTile * TPITCH + o]) + (smem[2 * kTile * TPITCH + o] + smem[3 * kTile * TPITCH + o]);
+  }
+  if (tid < kTile) { const double* v = smem + 4 * kTile * TPITCH; part[kTile * kTile + tid] = (v[tid] + v[kTile + tid]) + (v[2 * kTile + tid] + v[3 * kTile + tid]); }
 }
 
 // one workgroup per tile pair: sum the chunk partials in order, add U / D_c^2 / g_c, identity padding, and
@@ -735,8 +748,19 @@ hipError_t launch_clear_system(const SolverDev& sv, hipStream_t st) {
 }
 hipError_t launch_schur_blocks(const DeviceProblem& dp, const SolverDev& sv, double radius, hipStream_t st) {
   if (sv.nchunk > 0) {
-    if (sv.CD == 12) LAUNCH(schur_tile_kernel<12>, sv.nchunk, 256, st, sv, sv.Pm, sv.z);
-    else LAUNCH(schur_tile_kernel<6>, sv.nchunk, 256, st, sv, sv.Pm, sv.z);
+    // dynamic LDS: max(slot table of a chunk, four partial tiles + rhs partials)
+    const size_t table = (size_t)kSchurChunk * (2 * (kTile / sv.CD) + 1) * sizeof(int32_t);
+    const size_t tiles = (size_t)(4 * kTile * (kTile + 1) + 4 * kTile) * sizeof(double);
+    const size_t lds = table > tiles ? table : tiles;
+    static bool configured12 = false, configured6 = false;
+    if (sv.CD == 12) {
+      if (!configured12) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(schur_tile_kernel<12>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; configured12 = true; }
+      hipLaunchKernelGGL(schur_tile_kernel<12>, dim3(sv.nchunk), dim3(256), lds, st, sv, sv.Pm, sv.z);
+    } else {
+      if (!configured6) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(schur_tile_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; configured6 = true; }
+      hipLaunchKernelGGL(schur_tile_kernel<6>, dim3(sv.nchunk), dim3(256), lds, st, sv, sv.Pm, sv.z);
+    }
+    { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; }
   }
   LAUNCH(schur_merge_kernel, sv.ntp, 256, st, dp, sv, 1.0 / radius);
   return hipSuccess;

@@ -15,7 +15,7 @@
 
 namespace rsba {
 
-constexpr int kSchurChunk = 128;   // entries per wave of the Schur kernel
+constexpr int kSchurChunk = 512;   // entries per workgroup of the Schur kernel (its four waves take every fourth)
 constexpr int kTile = 48;   // Cholesky tile: 4 rolling-shutter frames (12 unknowns) or 8 global-shutter frames
 
 // Intrinsics as a parameter block (opt.model.calibrated == false with the shared sess.cam,
@@ -43,7 +43,7 @@ struct SolverDev {
   const int64_t* tp_ptr;        // [ntp+1] into the entry list
   const int32_t* ent_slots;     // [nent][2*FT] observation slot of the point in each frame of tile I, then of tile J (-1 none)
   const int32_t* ent_pt;        // [nent] point index; top bit set = the entry carries the rhs term P z
-  int nchunk;                   // waves of the Schur kernel: kSchurChunk entries each
+  int nchunk;                   // workgroups of the Schur kernel: kSchurChunk entries each
   const int32_t* chunk_tp;      // [nchunk]
   const int64_t* chunk_e0;      // [nchunk] first entry of the chunk
   const int32_t* tp_chunk0;     // [ntp+1] chunk range of each tile pair
