@@ -387,11 +387,10 @@ __global__ __launch_bounds__(256) void project_kernel(const DeviceProblem dp, co
 // Work unit = ENTRY (point j, frame tiles I >= J): the point's P records in the FT frames of I and of J, stacked
 // into A_j(I) and A_j(J) (48 x 3 each; a frame that does not see the point contributes the all-zero record).
 // The tile of the pair is the banded SYRK  S_IJ = sum_j A_j(I) A_j(J)^T  — GEMM-shaped, K = 3 per point — and runs
-// on v_mfma_f64_16x16x4_f64 with one point per MFMA step (k = the 3 coordinates + one zero column), operands
-// gathered from HBM/L2 straight into the instruction's register layout: lane (r = lane & 15, g = lane >> 4)
-// holds P[row 16 Ib + r][coordinate g] for the three 16-row blocks Ib of each side.  No LDS, no barrier in the
-// loop.  One workgroup per chunk of kSchurChunk entries; its four waves take every fourth entry and keep all
-// nine 16x16 blocks (loads run kDepth entries ahead of the MFMAs in a register ring), the four partial tiles meet
+// on v_mfma_f64_16x16x4_f64 (four points fill three MFMA steps of k = 4), operands gathered from HBM/L2 straight
+// into the instruction's register layout: lane (r = lane & 15, g = lane >> 4) holds P[row 16 Ib + r][one
+// coordinate of one point] for the three 16-row blocks Ib of each side.  No LDS, no barrier in the loop.  One workgroup per chunk of kSchurChunk entries; its four waves take every fourth entry and keep all
+// nine 16x16 blocks (loads run kDepth groups ahead of the MFMAs in a register ring), the four partial tiles meet
 // once in LDS.  The fp64 VALU form of this product was bound by LDS operand reads at 2.0 ms per 1k-camera
 // iteration.  Chunks write partial tiles; the merge kernel sums them in chunk order (fixed order, no atomics)
 // and adds U, D_c^2, g_c.
@@ -403,24 +402,34 @@ __global__ __launch_bounds__(256) void schur_tile_kernel(const SolverDev sv, con
   constexpr int FT = kTile / CD, PW = CD * 3;          // frames per tile, doubles per P record
   constexpr int NREC = 2 * FT;                         // records per entry
   constexpr int TPITCH = kTile + 1;
-  constexpr int kDepth = 8;                            // entries in flight per wave
-  extern __shared__ __attribute__((aligned(16))) double smem[];   // slot table during the loop, partial tiles after it
-  int32_t* s_slot = reinterpret_cast<int32_t*>(smem);
-  int32_t* s_pt = s_slot + kSchurChunk * NREC;
+  constexpr int kDepth = 3;                            // groups of four entries in flight per wave (54 loads: vmcnt counts to 63)
+  extern __shared__ __attribute__((aligned(16))) double smem[];   // slot table + z during the loop, partial tiles after it
+  double* s_z = smem;                                              // [kSchurChunk][3], zero where the entry carries no rhs term
+  int32_t* s_slot = reinterpret_cast<int32_t*>(smem + 3 * kSchurChunk);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 15, g = lane >> 4, gc = g < 3 ? g : 2;
-  const int chunk = blockIdx.x;
-  const int tp = sv.chunk_tp[chunk];
+  const int r = lane & 15, g = lane >> 4;
+  // consecutive chunks share records (host: chunk numbering); workgroups go round-robin over the 8 XCDs, so XCD x
+  // walks the x-th eighth of the chunk list in order and its L2 sees the repeats
+  const int per_xcd = (sv.nchunk + 7) / 8;
+  const int chunk = sv.schur_linear ? (int)blockIdx.x : (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  if (chunk >= sv.nchunk) return;
   const int64_t e0 = sv.chunk_e0[chunk];
-  const int64_t eend = sv.tp_ptr[tp + 1];
-  const int n = (int)((e0 + kSchurChunk < eend ? e0 + kSchurChunk : eend) - e0);
+  const int n = sv.chunk_n[chunk];
   for (int k = tid; k < n * NREC; k += 256) s_slot[k] = sv.ent_slots[(size_t)e0 * NREC + k];
-  for (int k = tid; k < n; k += 256) s_pt[k] = sv.ent_pt[e0 + k];
+  for (int k = tid; k < n * 3; k += 256) {
+    const int32_t pt = sv.ent_pt[e0 + k / 3];
+    s_z[k] = pt < 0 ? zz[(size_t)(pt & 0x7fffffff) * 3 + k % 3] : 0.0;   // top bit: diagonal entry of the point -> rhs term P z
+  }
   __syncthreads();
-  // which record (frame of the tile) and which of its doubles this lane reads for block row Ib
+  // K = 3 per point against 4 per MFMA: four of the wave's entries share three MFMA steps, step t taking the
+  // coordinates k = 4t .. 4t+3 of the twelve — lane group g reads coordinate (4t + g) % 3 of entry (4t + g) / 3.
+  int pe[3], comp[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) { pe[t] = (4 * t + g) / 3; comp[t] = (4 * t + g) % 3; }
+  // which record (frame of the tile) and which of its rows this lane reads for block row Ib
   int fa[3], off[3];
 #pragma unroll
-  for (int Ib = 0; Ib < 3; ++Ib) { const int row = 16 * Ib + r; fa[Ib] = row / CD; off[Ib] = (row % CD) * 3 + gc; }
+  for (int Ib = 0; Ib < 3; ++Ib) { const int row = 16 * Ib + r; fa[Ib] = row / CD; off[Ib] = (row % CD) * 3; }
 
   dbl4 acc[3][3];
 #pragma unroll
@@ -428,36 +437,48 @@ __global__ __launch_bounds__(256) void schur_tile_kernel(const SolverDev sv, con
 #pragma unroll
     for (int J = 0; J < 3; ++J) acc[I][J] = dbl4{0.0, 0.0, 0.0, 0.0};
   double racc[3] = {0.0, 0.0, 0.0};
-  double ra[kDepth][3], rb[kDepth][3], rz[kDepth];
-  // loads of entry k (clamped into the chunk: the tail re-reads its last entry instead of branching)
-  auto fetch = [&](int k, double a[3], double b[3], double& z) {
-    const int kk = k < n ? k : n - 1;
-    const int32_t* sl = s_slot + kk * NREC;
+  struct Group { double a[3][3], b[3][3], z[3]; };   // [step][block row]
+  Group ring[kDepth];
+  const int nw = n > wave ? (n - wave + 3) / 4 : 0;   // this wave's entries: wave, wave + 4, ..
+  // loads of group q (entries clamped into the chunk: the tail re-reads its last entry instead of branching).
+  // The ring keeps the values as loaded; lanes whose entry does not exist are zeroed where the values are USED —
+  // a select next to the load would make the compiler wait for the load right there and undo the prefetch.
+  auto fetch = [&](int q, Group& G) {
 #pragma unroll
-    for (int Ib = 0; Ib < 3; ++Ib) {
-      const double va = Pm[(size_t)sl[fa[Ib]] * PW + off[Ib]];
-      const double vb = Pm[(size_t)sl[FT + fa[Ib]] * PW + off[Ib]];
-      a[Ib] = g < 3 ? va : 0.0; b[Ib] = g < 3 ? vb : 0.0;
+    for (int t = 0; t < 3; ++t) {
+      const int m = 4 * q + pe[t];
+      const int k = m < nw ? wave + 4 * m : (n > 0 ? n - 1 : 0);
+      const int32_t* sl = s_slot + k * NREC;
+#pragma unroll
+      for (int Ib = 0; Ib < 3; ++Ib) {
+        G.a[t][Ib] = Pm[(size_t)((uint32_t)sl[fa[Ib]] * (uint32_t)PW + (uint32_t)(off[Ib] + comp[t]))];
+        G.b[t][Ib] = Pm[(size_t)((uint32_t)sl[FT + fa[Ib]] * (uint32_t)PW + (uint32_t)(off[Ib] + comp[t]))];
+      }
+      G.z[t] = s_z[k * 3 + comp[t]];
     }
-    const int pt = s_pt[kk];
-    const double zv = zz[(size_t)(pt & 0x7fffffff) * 3 + gc];
-    z = (pt < 0 && g < 3) ? zv : 0.0;     // top bit: diagonal entry of the point -> rhs term P z
   };
+  const int ngroups = (nw + 3) / 4;
 #pragma unroll
-  for (int d = 0; d < kDepth; ++d) fetch(wave + 4 * d, ra[d], rb[d], rz[d]);
-  for (int base = wave; base < n; base += 4 * kDepth) {
+  for (int d = 0; d < kDepth; ++d) fetch(d, ring[d]);
+  for (int base = 0; base < ngroups; base += kDepth) {
 #pragma unroll
     for (int d = 0; d < kDepth; ++d) {
-      const int k = base + 4 * d;
-      if (k < n) {
+      if (base + d < ngroups) {
 #pragma unroll
-        for (int I = 0; I < 3; ++I)
+        for (int t = 0; t < 3; ++t) {
+          const bool live = 4 * (base + d) + pe[t] < nw;
+          double a[3], b[3];
 #pragma unroll
-          for (int J = 0; J < 3; ++J) acc[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[d][I], rb[d][J], acc[I][J], 0, 0, 0);
+          for (int I = 0; I < 3; ++I) { a[I] = live ? ring[d].a[t][I] : 0.0; b[I] = live ? ring[d].b[t][I] : 0.0; }
 #pragma unroll
-        for (int I = 0; I < 3; ++I) racc[I] += ra[d][I] * rz[d];
+          for (int I = 0; I < 3; ++I)
+#pragma unroll
+            for (int J = 0; J < 3; ++J) acc[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[I], b[J], acc[I][J], 0, 0, 0);
+#pragma unroll
+          for (int I = 0; I < 3; ++I) racc[I] += a[I] * ring[d].z[t];
+        }
       }
-      fetch(k + 4 * kDepth, ra[d], rb[d], rz[d]);
+      fetch(base + d + kDepth, ring[d]);
     }
   }
   __syncthreads();   // everyone is done with the slot table: the same LDS now takes the four partial tiles
@@ -499,7 +520,7 @@ __global__ __launch_bounds__(256) void schur_merge_kernel(const DeviceProblem dp
     const int x = rt / CD, y = ct / CD, r = rt % CD, c = ct % CD;
     const int a = I * FT + x, b = J * FT + y;
     double sum = 0.0;
-    for (int ch = c0; ch < c1; ++ch) sum += sv.schur_part[(size_t)ch * pstride + e];
+    for (int ch = c0; ch < c1; ++ch) sum += sv.schur_part[(size_t)sv.tp_chunk_list[ch] * pstride + e];
     double val;
     if (a >= sv.Fx || b >= sv.Fx) val = (a == b && r == c && sv.lead) ? 1.0 : 0.0;     // padding frames of the last tile
     else {
@@ -512,7 +533,7 @@ __global__ __launch_bounds__(256) void schur_merge_kernel(const DeviceProblem dp
   if (I == J && tid < kTile) {
     const int a = I * FT + tid / CD;
     double sum = 0.0;
-    for (int ch = c0; ch < c1; ++ch) sum += sv.schur_part[(size_t)ch * pstride + kTile * kTile + tid];
+    for (int ch = c0; ch < c1; ++ch) sum += sv.schur_part[(size_t)sv.tp_chunk_list[ch] * pstride + kTile * kTile + tid];
     sv.rhs[(size_t)I * kTile + tid] = (a < sv.Fx) ? (sv.lead ? sv.gc[(size_t)I * kTile + tid] : 0.0) - sum : 0.0;
   }
 }
@@ -749,16 +770,16 @@ hipError_t launch_clear_system(const SolverDev& sv, hipStream_t st) {
 hipError_t launch_schur_blocks(const DeviceProblem& dp, const SolverDev& sv, double radius, hipStream_t st) {
   if (sv.nchunk > 0) {
     // dynamic LDS: max(slot table of a chunk, four partial tiles + rhs partials)
-    const size_t table = (size_t)kSchurChunk * (2 * (kTile / sv.CD) + 1) * sizeof(int32_t);
+    const size_t table = (size_t)kSchurChunk * (2 * (kTile / sv.CD) * sizeof(int32_t) + 3 * sizeof(double));
     const size_t tiles = (size_t)(4 * kTile * (kTile + 1) + 4 * kTile) * sizeof(double);
     const size_t lds = table > tiles ? table : tiles;
     static bool configured12 = false, configured6 = false;
     if (sv.CD == 12) {
       if (!configured12) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(schur_tile_kernel<12>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; configured12 = true; }
-      hipLaunchKernelGGL(schur_tile_kernel<12>, dim3(sv.nchunk), dim3(256), lds, st, sv, sv.Pm, sv.z);
+      hipLaunchKernelGGL(schur_tile_kernel<12>, dim3(8 * ((sv.nchunk + 7) / 8)), dim3(256), lds, st, sv, sv.Pm, sv.z);
     } else {
       if (!configured6) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(schur_tile_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; configured6 = true; }
-      hipLaunchKernelGGL(schur_tile_kernel<6>, dim3(sv.nchunk), dim3(256), lds, st, sv, sv.Pm, sv.z);
+      hipLaunchKernelGGL(schur_tile_kernel<6>, dim3(8 * ((sv.nchunk + 7) / 8)), dim3(256), lds, st, sv, sv.Pm, sv.z);
     }
     { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; }
   }

@@ -116,6 +116,7 @@ int32_t build_solver(rsba_handle* h) {
   // slots: stable counting sort of the frame-major list by point -> ascending frame inside a point;
   // behind them one virtual slot per (point, pseudo frame)
   const int64_t NS = N + (int64_t)M * NPF;
+  if ((NS + 1) * (int64_t)CD * 3 >= ((int64_t)1 << 32)) return rsba_set_error(RSBA_ERR_UNSUPPORTED, "more than 2^32 doubles of P records: the Schur kernel indexes them with 32 bits");
   std::vector<int32_t> obs_slot(N), slot_frame(NS), slot_point(NS);
   {
     std::vector<int64_t> fill(point_ptr.begin(), point_ptr.end() - 1);
@@ -359,14 +360,51 @@ int32_t build_solver(rsba_handle* h) {
   }
   for (int l = nlev - 1; l >= 0; --l)
     for (int d = s->lev_diag_ptr[l]; d < s->lev_diag_ptr[l + 1]; ++d) { s->tasks.push_back(kTaskBack); s->tasks.push_back(d); }
-  // chunks of kSchurChunk entries (one wave each) and, per tile pair, where the merged tile goes
-  std::vector<int32_t> chunk_tp; std::vector<int64_t> chunk_e0; std::vector<int32_t> tp_chunk0(ntp + 1, 0);
-  for (int t = 0; t < ntp; ++t) {
-    tp_chunk0[t] = (int32_t)chunk_tp.size();
-    for (int64_t q0 = tp_ptr[t]; q0 < tp_ptr[t + 1]; q0 += kSchurChunk) { chunk_tp.push_back(t); chunk_e0.push_back(q0); }
+  // Chunks of the Schur kernel (one workgroup each): at most kSchurChunk consecutive entries of one tile pair.
+  // The points of tile row I are cut into blocks of kSchurChunk (the entry list of the diagonal pair (I, I) holds
+  // them all), every pair (I, J) of the row is cut at the same point boundaries, and the chunks are numbered
+  // row by row, block by block, J innermost: consecutive chunks then read the SAME A_j(I) records against
+  // different A_j(J), and the kernel's blockIdx -> chunk map keeps consecutive chunks on one XCD, whose L2 serves
+  // the repeats (each record is otherwise fetched once per tile pair it takes part in: 4.8 GB per 1k-camera
+  // iteration).  Per tile pair the chunk ids are listed in entry order for the merge kernel.
+  std::vector<int32_t> chunk_tp, chunk_n; std::vector<int64_t> chunk_e0;
+  std::vector<std::vector<int32_t>> pair_chunks(ntp);
+  {
+    std::vector<int32_t> row_pairs;
+    int t = 0;
+    while (t < ntp) {
+      const int I = tp_I[t];
+      row_pairs.clear();
+      int tdiag = -1;
+      for (; t < ntp && tp_I[t] == I; ++t) { row_pairs.push_back(t); if (tp_J[t] == I) tdiag = t; }
+      // point boundaries from the diagonal pair's entry list (every observed point of the row is in it)
+      std::vector<int32_t> bounds;   // first point index of each block
+      if (tdiag >= 0) for (int64_t q = tp_ptr[tdiag]; q < tp_ptr[tdiag + 1]; q += kSchurChunk) bounds.push_back(ent_pt[q] & 0x7fffffff);
+      if (bounds.empty()) bounds.push_back(0);
+      bounds[0] = 0;
+      std::vector<int64_t> cursor(row_pairs.size());
+      for (size_t x = 0; x < row_pairs.size(); ++x) cursor[x] = tp_ptr[row_pairs[x]];
+      for (size_t c = 0; c < bounds.size(); ++c) {
+        const int64_t next_point = c + 1 < bounds.size() ? bounds[c + 1] : std::numeric_limits<int64_t>::max();
+        for (size_t x = row_pairs.size(); x-- > 0;) {          // J descending: the diagonal pair first
+          const int tp_ = row_pairs[x];
+          int64_t q = cursor[x];
+          const int64_t qend = tp_ptr[tp_ + 1];
+          while (q < qend && (ent_pt[q] & 0x7fffffff) < next_point) ++q;
+          for (int64_t q0 = cursor[x]; q0 < q; q0 += kSchurChunk) {
+            pair_chunks[tp_].push_back((int32_t)chunk_tp.size());
+            chunk_tp.push_back(tp_); chunk_e0.push_back(q0); chunk_n.push_back((int32_t)std::min<int64_t>(kSchurChunk, q - q0));
+          }
+          cursor[x] = q;
+        }
+      }
+    }
   }
-  tp_chunk0[ntp] = (int32_t)chunk_tp.size();
+  std::vector<int32_t> tp_chunk0(ntp + 1, 0), tp_chunk_list;
+  for (int t = 0; t < ntp; ++t) { tp_chunk0[t] = (int32_t)tp_chunk_list.size(); tp_chunk_list.insert(tp_chunk_list.end(), pair_chunks[t].begin(), pair_chunks[t].end()); }
+  tp_chunk0[ntp] = (int32_t)tp_chunk_list.size();
   sv.nchunk = (int)chunk_tp.size(); sv.ntp = ntp; sv.FT = FT;
+  { const char* e = std::getenv("RSBA_SCHUR_LINEAR"); sv.schur_linear = e && e[0] == '1'; }
   std::vector<int32_t> tp_dst(ntp); std::vector<uint8_t> tp_trans(ntp, 0);
   std::vector<int64_t> tp_add((size_t)ntp * FT * FT, -1);
   for (int t = 0; t < ntp; ++t) {
@@ -427,6 +465,8 @@ int32_t build_solver(rsba_handle* h) {
   if ((rc = s_upload_const(s, &sv.chunk_tp, chunk_tp))) return rc;
   if ((rc = s_upload_const(s, &sv.chunk_e0, chunk_e0))) return rc;
   if ((rc = s_upload_const(s, &sv.tp_chunk0, tp_chunk0))) return rc;
+  if ((rc = s_upload_const(s, &sv.tp_chunk_list, tp_chunk_list))) return rc;
+  if ((rc = s_upload_const(s, &sv.chunk_n, chunk_n))) return rc;
   if ((rc = s_upload_const(s, &sv.tp_dst, tp_dst))) return rc;
   if ((rc = s_upload_const(s, &sv.tp_trans, tp_trans))) return rc;
   if ((rc = s_upload_const(s, &sv.tp_add, tp_add))) return rc;
@@ -493,6 +533,9 @@ int32_t build_solver(rsba_handle* h) {
   s->dag_workgroups = std::max(1, std::min(pl.ntasks, std::max(cus, 1)));   // one 4-wave workgroup per CU (register budget)
   if (std::getenv("RSBA_CHOL_TRACE")) { if ((rc = s_alloc(s, &s->d_trace, 8 * (size_t)pl.ntasks))) return rc; }
   pl.trace = s->d_trace;
+  if (std::getenv("RSBA_DEBUG_PLAN"))
+    std::fprintf(stderr, "[rsba plan] tiles %d, factor tiles %d, levels %d, tasks %d (partials %d); tile pairs %d, entries %lld, schur chunks %d\n", nt, sv.nslots,
+                 s->nlev, pl.ntasks, parts, sv.ntp, (long long)s->num_pairs, sv.nchunk);
   const char* lv = std::getenv("RSBA_CHOL_LEVELS");
   s->use_levels = lv && lv[0] == '1';
   return RSBA_OK;

@@ -43,10 +43,13 @@ struct SolverDev {
   const int64_t* tp_ptr;        // [ntp+1] into the entry list
   const int32_t* ent_slots;     // [nent][2*FT] observation slot of the point in each frame of tile I, then of tile J (-1 none)
   const int32_t* ent_pt;        // [nent] point index; top bit set = the entry carries the rhs term P z
+  int schur_linear;             // debugging (RSBA_SCHUR_LINEAR=1): blockIdx -> chunk without the XCD map
   int nchunk;                   // workgroups of the Schur kernel: kSchurChunk entries each
   const int32_t* chunk_tp;      // [nchunk]
   const int64_t* chunk_e0;      // [nchunk] first entry of the chunk
-  const int32_t* tp_chunk0;     // [ntp+1] chunk range of each tile pair
+  const int32_t* chunk_n;       // [nchunk] entries in the chunk (<= kSchurChunk)
+  const int32_t* tp_chunk0;     // [ntp+1] range of each tile pair in tp_chunk_list
+  const int32_t* tp_chunk_list; // chunk ids of each tile pair, in entry order
   const int32_t* tp_dst;        // [ntp] packed tile slot that receives the pair
   const uint8_t* tp_trans;      // [ntp] 1 = the tile ordering swapped I and J: store transposed
   const int64_t* tp_add;        // [ntp][FT][FT] offset into U of the J^T J block to add, -1 none
