@@ -538,55 +538,95 @@ __global__ __launch_bounds__(256) void schur_merge_kernel(const DeviceProblem dp
   }
 }
 
-// K7  back-substitution  y_p = L^-T ( z - sum_o P_o^T y_c(frame(o)) )
-template <int CD>
-__global__ __launch_bounds__(256) void back_substitute_kernel(const DeviceProblem dp, const SolverDev sv) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= dp.M) return;
-  double t0 = sv.z[(size_t)j * 3], t1 = sv.z[(size_t)j * 3 + 1], t2 = sv.z[(size_t)j * 3 + 2];
-  for (int64_t s = sv.point_ptr[j]; s < sv.point_ptr[j + 1]; ++s) {
-    const double* pm = sv.Pm + (size_t)s * (CD * 3);
-    const double* yc = sv.rhs + (size_t)sv.slot_frame[s] * CD;
-#pragma unroll
-    for (int a = 0; a < CD; ++a) { const double y = yc[a]; t0 -= pm[a * 3] * y; t1 -= pm[a * 3 + 1] * y; t2 -= pm[a * 3 + 2] * y; }
-  }
-  for (int v = 0; v < sv.NPF; ++v) {   // the point's virtual observations of the intrinsics pseudo frames
-    const double* pm = sv.Pm + ((size_t)dp.N + (size_t)j * sv.NPF + v) * (CD * 3);
-    const double* yc = sv.rhs + (size_t)(sv.F + v) * CD;
-#pragma unroll
-    for (int a = 0; a < CD; ++a) { const double y = yc[a]; t0 -= pm[a * 3] * y; t1 -= pm[a * 3 + 1] * y; t2 -= pm[a * 3 + 2] * y; }
-  }
-  const double* li = sv.Linv + (size_t)j * 6;
-  double* yp = sv.yp + (size_t)j * 3;
-  yp[0] = li[0] * t0 + li[1] * t1 + li[3] * t2;
-  yp[1] = li[2] * t1 + li[4] * t2;
-  yp[2] = li[5] * t2;
-}
-
-// model_cost_change = -(J step).(r + J step / 2), step = -y   (TrustRegionMinimizer)
-template <int CD>
-__global__ __launch_bounds__(256) void model_cost_kernel(const DeviceProblem dp, const SolverDev sv) {
+// K7 + K8  point steps and the model cost change in ONE pass over the point-major records:
+//   y_p,j = L_j^-T ( z_j - L_j^-1 u_j ),  u_j = sum_o Jp_o^T t_o,  t_o = Jc_o y_c(frame(o)) + Ji_o y_i
+// (the back-substitution y_p = L^-T (z - sum_o P_o^T y_c) with P_o = Jc_o^T Jp_o L^-T written out), and
+//   model_cost_change = -sum_o m_o.(r_o + m_o / 2),  m_o = -(t_o + Jp_o y_p)      (TrustRegionMinimizer)
+// expanded per point so that it needs nothing per observation beyond what the same pass accumulates:
+//   sum_o m.(r + m/2) = -sum r.t - y_p.g_p + 1/2 sum |t|^2 + y_p.u + 1/2 y_p^T V y_p      (V, g_p from K2b).
+// The records (256 B at 1k cameras) are read once — before, the P records (288 B) and then the Jacobian records
+// were each streamed by their own kernel.  One wave owns 64 consecutive points = one contiguous slot range, moves it
+// through LDS 64 records at a time with fully coalesced 512-B wave loads (the next 64 already in flight in
+// registers), every lane reduces ITS record to 5 numbers, and the lane that owns the point sums its records' numbers
+// in slot order (fixed order: deterministic).
+template <int CD, int KC>
+__global__ __launch_bounds__(256) void point_step_kernel(const DeviceProblem dp, const SolverDev sv) {
+  constexpr int REC = 8 + 2 * KC, PITCH = REC | 1, off = KC - CD, NC = 5;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
   __shared__ double s_red[4];
-  const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  double v = 0.0;
-  if (s < dp.N) {
-    const int REC = 2 + 2 * dp.K, KC = dp.K - 3, off = KC - CD;
-    const double* rec = dp.rec + (size_t)s * REC;
-    const double* yc = sv.rhs + (size_t)sv.slot_frame[s] * CD;
-    const double* yp = sv.yp + (size_t)sv.slot_point[s] * 3;
-    double m0 = 0.0, m1 = 0.0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* buf = smem + (size_t)wave * (64 * PITCH + 64 * NC);
+  double* cbuf = buf + 64 * PITCH;
+  const int64_t j0 = ((int64_t)blockIdx.x * 4 + wave) * 64;
+  double mc = 0.0;
+  if (j0 < dp.M) {   // wave-uniform
+    const int jn = (int)(dp.M - j0 < 64 ? dp.M - j0 : 64);
+    const bool mine = lane < jn;
+    const int64_t j = j0 + (mine ? lane : 0);
+    const int64_t lo = mine ? sv.point_ptr[j] : 0, hi = mine ? sv.point_ptr[j + 1] : 0;
+    const int64_t sb = sv.point_ptr[j0], se = sv.point_ptr[j0 + jn];
+    double acc[NC] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    double pre[REC];
+    int pre_frame = 0;
+    // loads of the chunk at c0; indices are clamped into the wave's range instead of predicated (the values of a
+    // clamped lane are never used), so nothing next to the load makes the compiler wait for it
+    auto issue = [&](int64_t c0) {
+      const int64_t last = (se - c0) * REC - 1;
+      const double* src = dp.rec + (size_t)c0 * REC;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { m0 -= rec[2 + k] * yp[k]; m1 -= rec[5 + k] * yp[k]; }
+      for (int k = 0; k < REC; ++k) { const int64_t idx = k * 64 + lane; pre[k] = src[idx < last ? idx : last]; }
+      pre_frame = sv.slot_frame[c0 + lane < se ? c0 + lane : se - 1];
+    };
+    if (sb < se) issue(sb);
+    for (int64_t c0 = sb; c0 < se; c0 += 64) {
+      const int nrec = (int)(se - c0 < 64 ? se - c0 : 64);
 #pragma unroll
-    for (int a = 0; a < CD; ++a) { m0 -= rec[8 + off + a] * yc[a]; m1 -= rec[8 + KC + off + a] * yc[a]; }
-    if (off > 0) {
-      const double* yi = sv.rhs + (size_t)sv.F * CD;   // intrinsics step: 9 coordinates across the pseudo frames
-      for (int k = 0; k < 9; ++k) { m0 -= rec[8 + k] * yi[k]; m1 -= rec[8 + KC + k] * yi[k]; }
+      for (int k = 0; k < REC; ++k) { const int idx = k * 64 + lane; buf[(idx / REC) * PITCH + idx % REC] = pre[k]; }
+      const int frame = pre_frame;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (c0 + 64 < se) issue(c0 + 64);
+      if (lane < nrec) {
+        const double* rec = buf + lane * PITCH;
+        const double* yc = sv.rhs + (size_t)frame * CD;
+        double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+        for (int a = 0; a < CD; ++a) { const double y = yc[a]; t0 += rec[8 + off + a] * y; t1 += rec[8 + KC + off + a] * y; }
+        if (off > 0) {
+          const double* yi = sv.rhs + (size_t)sv.F * CD;   // intrinsics step: 9 coordinates across the pseudo frames
+#pragma unroll
+          for (int k = 0; k < off; ++k) { const double y = yi[k]; t0 += rec[8 + k] * y; t1 += rec[8 + KC + k] * y; }
+        }
+        double* c = cbuf + lane * NC;
+        c[0] = rec[2] * t0 + rec[5] * t1; c[1] = rec[3] * t0 + rec[6] * t1; c[2] = rec[4] * t0 + rec[7] * t1;   // Jp^T t
+        c[3] = t0 * t0 + t1 * t1;
+        c[4] = rec[0] * t0 + rec[1] * t1;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int64_t s_lo = lo > c0 ? lo : c0, s_hi = hi < c0 + nrec ? hi : c0 + nrec;
+      for (int64_t sidx = s_lo; sidx < s_hi; ++sidx) {
+        const double* c = cbuf + (sidx - c0) * NC;
+#pragma unroll
+        for (int q = 0; q < NC; ++q) acc[q] += c[q];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    v = m0 * (rec[0] + 0.5 * m0) + m1 * (rec[1] + 0.5 * m1);
+    if (mine) {
+      const double* li = sv.Linv + (size_t)j * 6;
+      const double* z = sv.z + (size_t)j * 3;
+      const double i00 = li[0], i10 = li[1], i11 = li[2], i20 = li[3], i21 = li[4], i22 = li[5];
+      const double u0 = acc[0], u1 = acc[1], u2 = acc[2];
+      const double w0 = z[0] - i00 * u0, w1 = z[1] - (i10 * u0 + i11 * u1), w2 = z[2] - (i20 * u0 + i21 * u1 + i22 * u2);
+      const double y0 = i00 * w0 + i10 * w1 + i20 * w2, y1 = i11 * w1 + i21 * w2, y2 = i22 * w2;
+      double* yp = sv.yp + (size_t)j * 3;
+      yp[0] = y0; yp[1] = y1; yp[2] = y2;
+      const double* v = sv.V + (size_t)j * 6;   // xx xy xz yy yz zz
+      const double* g = sv.gp + (size_t)j * 3;
+      const double vy0 = v[0] * y0 + v[1] * y1 + v[2] * y2, vy1 = v[1] * y0 + v[3] * y1 + v[4] * y2, vy2 = v[2] * y0 + v[4] * y1 + v[5] * y2;
+      mc = -acc[4] - (y0 * g[0] + y1 * g[1] + y2 * g[2]) + 0.5 * acc[3] + (y0 * u0 + y1 * u1 + y2 * u2) + 0.5 * (y0 * vy0 + y1 * vy1 + y2 * vy2);
+    }
   }
-  v = wsum(v);
-  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+  mc = wsum(mc);
+  if (lane == 0) s_red[wave] = mc;
   __syncthreads();
   if (threadIdx.x == 0) sv.partial[blockIdx.x] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
 }
@@ -786,18 +826,30 @@ hipError_t launch_schur_blocks(const DeviceProblem& dp, const SolverDev& sv, dou
   LAUNCH(schur_merge_kernel, sv.ntp, 256, st, dp, sv, 1.0 / radius);
   return hipSuccess;
 }
-hipError_t launch_back_substitute(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {
-  if (sv.CD == 12) LAUNCH(back_substitute_kernel<12>, nblocks256(dp.M), 256, st, dp, sv);
-  else LAUNCH(back_substitute_kernel<6>, nblocks256(dp.M), 256, st, dp, sv);
-  return hipSuccess;
-}
-hipError_t launch_model_cost_change(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {
-  const int nb = nblocks256(dp.N);
-  if (nb > 0) {
-    if (sv.CD == 12) LAUNCH(model_cost_kernel<12>, nb, 256, st, dp, sv);
-    else LAUNCH(model_cost_kernel<6>, nb, 256, st, dp, sv);
+static int point_step_blocks(const DeviceProblem& dp) { return (int)((dp.M + 255) / 256); }
+template <int CD, int KC>
+static hipError_t launch_point_step(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {
+  constexpr int REC = 8 + 2 * KC, PITCH = REC | 1;
+  const size_t lds = (size_t)4 * (64 * PITCH + 64 * 5) * sizeof(double);
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(point_step_kernel<CD, KC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    configured = true;
   }
-  LAUNCH(reduce_sum_kernel, 1, 256, st, sv.partial, nb, sv.scalars + kModelCostChange, -1.0);
+  hipLaunchKernelGGL((point_step_kernel<CD, KC>), dim3(point_step_blocks(dp)), dim3(256), lds, st, dp, sv);
+  return hipGetLastError();
+}
+// point steps y_p and the per-workgroup partials of the model cost change (sv.partial)
+hipError_t launch_back_substitute(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {
+  if (dp.M <= 0) return hipSuccess;
+  const int KC = dp.K - 3;
+  if (sv.CD == 12) return KC == 12 ? launch_point_step<12, 12>(dp, sv, st) : launch_point_step<12, 21>(dp, sv, st);
+  return KC == 6 ? launch_point_step<6, 6>(dp, sv, st) : launch_point_step<6, 15>(dp, sv, st);
+}
+// -> scalars[kModelCostChange]; must follow launch_back_substitute directly (it reduces that kernel's partials)
+hipError_t launch_model_cost_change(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {
+  LAUNCH(reduce_sum_kernel, 1, 256, st, sv.partial, dp.M > 0 ? point_step_blocks(dp) : 0, sv.scalars + kModelCostChange, -1.0);
   return hipSuccess;
 }
 hipError_t launch_candidate(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {
