@@ -332,6 +332,8 @@ __global__ __launch_bounds__(256) void point_factor_kernel(const DeviceProblem d
 // coalesced 512-B wave accesses (a lane-per-record global access pattern touches 64 cache lines per
 // instruction and ran 4x slower); each lane then works on its own record out of LDS (odd pitch: no
 // bank conflicts).
+constexpr int kProjectChunks = 8;   // consecutive 64-slot chunks per wave of the projection kernel
+
 template <int CD, int KC>
 __global__ __launch_bounds__(256) void project_kernel(const DeviceProblem dp, const SolverDev sv) {
   constexpr int REC = 8 + 2 * KC, OUT = CD * 3;
@@ -340,45 +342,56 @@ __global__ __launch_bounds__(256) void project_kernel(const DeviceProblem dp, co
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double* buf = smem + (size_t)wave * 64 * PITCH;
-  const int64_t s0 = ((int64_t)blockIdx.x * 4 + wave) * 64;
-  if (s0 >= dp.N) return;
-  const int64_t nslot = (dp.N - s0 < 64) ? dp.N - s0 : 64;
-  const double* src = dp.rec + (size_t)s0 * REC;
-#pragma unroll 4
-  for (int k = 0; k < REC; ++k) {
-    const int idx = k * 64 + lane;
-    if (idx < nslot * REC) buf[(idx / REC) * PITCH + idx % REC] = src[idx];
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  double out[OUT];
-  if (lane < nslot) {
-    const double* rec = buf + lane * PITCH;
-    const double* li = sv.Linv + (size_t)sv.slot_point[s0 + lane] * 6;
+  const int64_t sb = ((int64_t)blockIdx.x * 4 + wave) * 64 * kProjectChunks;
+  if (sb >= dp.N) return;
+  const int64_t se = sb + 64 * kProjectChunks < dp.N ? sb + 64 * kProjectChunks : dp.N;
+  // the next chunk's records (and the point of each slot) travel in registers while this one is worked on; indices
+  // are clamped rather than predicated so that nothing next to the loads waits for them
+  double pre[REC];
+  int pre_point = 0;
+  auto issue = [&](int64_t c0) {
+    const int64_t last = (se - c0) * REC - 1;
+    const double* src = dp.rec + (size_t)c0 * REC;
+#pragma unroll
+    for (int k = 0; k < REC; ++k) { const int64_t idx = k * 64 + lane; pre[k] = src[idx < last ? idx : last]; }
+    pre_point = sv.slot_point[c0 + lane < se ? c0 + lane : se - 1];
+  };
+  issue(sb);
+  for (int64_t s0 = sb; s0 < se; s0 += 64) {
+    const int64_t nslot = se - s0 < 64 ? se - s0 : 64;
+#pragma unroll
+    for (int k = 0; k < REC; ++k) { const int idx = k * 64 + lane; buf[(idx / REC) * PITCH + idx % REC] = pre[k]; }
+    const double* li = sv.Linv + (size_t)pre_point * 6;
     const double i00 = li[0], i10 = li[1], i11 = li[2], i20 = li[3], i21 = li[4], i22 = li[5];
-    double B[2][3];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (s0 + 64 < se) issue(s0 + 64);
+    double out[OUT];
+    {
+      const double* rec = buf + lane * PITCH;   // lanes past nslot work on stale LDS; their results are not stored
+      double B[2][3];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const double p0 = rec[2 + 3 * r], p1 = rec[3 + 3 * r], p2 = rec[4 + 3 * r];
-      B[r][0] = p0 * i00; B[r][1] = p0 * i10 + p1 * i11; B[r][2] = p0 * i20 + p1 * i21 + p2 * i22;
+      for (int r = 0; r < 2; ++r) {
+        const double p0 = rec[2 + 3 * r], p1 = rec[3 + 3 * r], p2 = rec[4 + 3 * r];
+        B[r][0] = p0 * i00; B[r][1] = p0 * i10 + p1 * i11; B[r][2] = p0 * i20 + p1 * i21 + p2 * i22;
+      }
+#pragma unroll
+      for (int a = 0; a < CD; ++a) {
+        const double c0 = rec[8 + off + a], c1 = rec[8 + KC + off + a];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) out[a * 3 + k] = c0 * B[0][k] + c1 * B[1][k];
+      }
     }
-#pragma unroll
-    for (int a = 0; a < CD; ++a) {
-      const double c0 = rec[8 + off + a], c1 = rec[8 + KC + off + a];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) out[a * 3 + k] = c0 * B[0][k] + c1 * B[1][k];
-    }
-  }
-  __builtin_amdgcn_wave_barrier();
-  if (lane < nslot) {
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int e = 0; e < OUT; ++e) buf[lane * PITCH + e] = out[e];
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  double* dst = sv.Pm + (size_t)s0 * OUT;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double* dst = sv.Pm + (size_t)s0 * OUT;
 #pragma unroll 4
-  for (int k = 0; k < OUT; ++k) {
-    const int idx = k * 64 + lane;
-    if (idx < nslot * OUT) dst[idx] = buf[(idx / OUT) * PITCH + idx % OUT];
+    for (int k = 0; k < OUT; ++k) {
+      const int idx = k * 64 + lane;
+      if (idx < nslot * OUT) dst[idx] = buf[(idx / OUT) * PITCH + idx % OUT];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
 }
 
@@ -748,7 +761,7 @@ hipError_t launch_point_factor(const DeviceProblem& dp, const SolverDev& sv, dou
 }
 hipError_t launch_project(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {
   if (dp.N == 0) return hipSuccess;
-  const int grid = (int)((dp.N + 255) / 256);
+  const int grid = (int)((dp.N + 256 * kProjectChunks - 1) / (256 * kProjectChunks));
   const int KC = dp.K - 3;
   auto lds_of = [](int rec, int out) { return (size_t)4 * 64 * (((rec > out ? rec : out)) | 1) * sizeof(double); };
   if (sv.CD == 12 && KC == 12) {
