@@ -32,6 +32,11 @@ __global__ __launch_bounds__(kEvalBlock) void eval_kernel(const DeviceProblem dp
   __shared__ double s_pose[kStageFrames * CD];
   __shared__ double s_scale[MODE == kLmJacobian ? kStageFrames * CD : 1];
   __shared__ double s_red[3][kEvalBlock / 64];
+  constexpr bool CAMBLK = (MODE == kLmJacobian) && CAL;   // camera blocks formed here (dp.cam_part)
+  constexpr int TP = 17;                                   // pitch of the operand transposition buffer
+  constexpr int RECW = 2 + 2 * K, RPITCH = RECW | 1;       // point-major record, and its pitch in the staging buffer
+  constexpr int TRW = (MODE == kLmJacobian) ? ((64 * TP > 32 * RPITCH) ? 64 * TP : 32 * RPITCH) : 1;   // doubles per wave
+  __shared__ double s_tr[(MODE == kLmJacobian) ? (kEvalBlock / 64) * TRW : 1];
 
   const int tid = threadIdx.x;
   const int64_t base = (int64_t)blockIdx.x * kEvalBlock;
@@ -113,7 +118,6 @@ __global__ __launch_bounds__(kEvalBlock) void eval_kernel(const DeviceProblem dp
       // point-major copy of the corrected record (see device_state.hpp)
       constexpr int REC = 2 + 2 * K;
       constexpr int KC = K - 3;
-      double2* rp = reinterpret_cast<double2*>(dp.rec + (size_t)dp.obs_slot[ic] * REC);
       double rv[REC];
       rv[0] = o.ok ? o.r[0] : 0.0; rv[1] = o.ok ? o.r[1] : 0.0;
 #pragma unroll
@@ -123,17 +127,88 @@ __global__ __launch_bounds__(kEvalBlock) void eval_kernel(const DeviceProblem dp
 #pragma unroll
         for (int k = 0; k < KC; ++k) rv[8 + KC * r + k] = o.ok ? o.J[r][k] : 0.0;
       }
-      if (valid) {
+      // The records are scattered by slot.  Written one lane per record, every 16-B store of a wave hits 64
+      // different cache lines, an eighth of a line at a time; staged through LDS (half a wave at a time), each
+      // record leaves as one contiguous run written by REC/2 neighbouring lanes.
+      {
+        const int lane = tid & 63, wv = tid >> 6;
+        double* st = s_tr + wv * TRW;
+        const int my_slot = valid ? dp.obs_slot[ic] : -1;
 #pragma unroll
-        for (int k = 0; k < REC / 2; ++k) rp[k] = make_double2(rv[2 * k], rv[2 * k + 1]);
+        for (int h = 0; h < 2; ++h) {
+          if ((lane >> 5) == h) {
+#pragma unroll
+            for (int k = 0; k < REC; ++k) st[(lane & 31) * RPITCH + k] = rv[k];
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+          for (int q = 0; q < (16 * REC + 63) / 64; ++q) {
+            const int idx = lane + 64 * q;                       // double2 index within the half's 32 records
+            const int rcd = idx / (REC / 2), part = idx % (REC / 2);
+            const int slot = __shfl(my_slot, 32 * h + (rcd < 32 ? rcd : 31), 64);
+            if (idx < 16 * REC && slot >= 0)
+              *reinterpret_cast<double2*>(dp.rec + (size_t)slot * REC + 2 * part) = make_double2(st[rcd * RPITCH + 2 * part], st[rcd * RPITCH + 2 * part + 1]);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
       }
     }
     cost = half_rho;
+
+    if (CAMBLK && dp.cam_part) {
+      // K2a in place: D = [Jc | r]^T [Jc | r] over the observations of ONE frame = U_f (CD x CD), g_f (column CD).
+      // MFMA wants lane (i = lane & 15, g = lane >> 4) to hold coordinate i of Jacobian row k = 4 step + g, while
+      // the rows live one observation per lane: they change lanes through LDS, half a wave (64 rows) at a time.
+      // A wave that straddles frames does one pass per frame, rows of the other frames masked to zero.
+      typedef double dbl4 __attribute__((ext_vector_type(4)));
+      const int lane = tid & 63, wv = tid >> 6, ci = lane & 15, cg = lane >> 4;
+      double* tr = s_tr + wv * TRW;
+      const int my_frame = valid ? f : -1;
+      const int64_t wave_id = (base >> 6) + wv;
+      int seg = dp.wave_seg_base[wave_id];
+      int done = 0;
+      while (done < 64) {
+        const int fr = __builtin_amdgcn_readlane(my_frame, done);
+        if (fr < 0) break;
+        const unsigned long long in_seg = __ballot(my_frame == fr);
+        const int seg_end = done + __builtin_popcountll(in_seg);     // observations of a frame are consecutive
+        dbl4 d = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          if ((lane >> 5) == h) {
+            const bool keep = o.ok && valid && my_frame == fr;
+            double* row = tr + 2 * (lane & 31) * TP;
+#pragma unroll
+            for (int c = 0; c < CD; ++c) { row[c] = keep ? o.J[0][OFF_POSE + c] : 0.0; row[TP + c] = keep ? o.J[1][OFF_POSE + c] : 0.0; }
+            row[CD] = keep ? o.r[0] : 0.0; row[TP + CD] = keep ? o.r[1] : 0.0;
+#pragma unroll
+            for (int c = CD + 1; c < 16; ++c) { row[c] = 0.0; row[TP + c] = 0.0; }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          // rows of this half that belong to the segment: observations [max(done, 32h), min(seg_end, 32h + 32))
+          const int o_lo = done > 32 * h ? done : 32 * h, o_hi = seg_end < 32 * h + 32 ? seg_end : 32 * h + 32;
+          if (o_lo < o_hi) {
+            const int s_lo = (2 * (o_lo - 32 * h)) >> 2, s_hi = (2 * (o_hi - 32 * h) + 3) >> 2;
+            for (int step = s_lo; step < s_hi; ++step) {
+              const double a = tr[(4 * step + cg) * TP + ci];
+              d = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, d, 0, 0, 0);
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        double* part = dp.cam_part + (size_t)seg * 256;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) part[(cg + 4 * v) * 16 + ci] = d[v];
+        ++seg;
+        done = seg_end;
+      }
+    }
 
     // Tiled component-major stores, 16 B per lane: lanes 2m / 2m+1 exchange one value per component
     // pair (DPP quad_perm [1,0,3,2]); the even lane then stores component c of observations (2m, 2m+1)
     // and the odd lane component c+1 of the same two — 16-B stores sustain ~6 % more of the HBM write
     // stream than 8-B ones on this part (tools/hbm_calib.hip: tiled_x2 vs write_tiled).
+    if (!(CAMBLK && dp.cam_part)) {
     const bool odd = tid & 1;
     double* rt = dp.res + (size_t)blockIdx.x * (2 * kEvalBlock) + (tid & ~1) + (odd ? kEvalBlock : 0);
     {
@@ -149,6 +224,7 @@ __global__ __launch_bounds__(kEvalBlock) void eval_kernel(const DeviceProblem dp
         const double got = swap_pair(odd ? v0 : v1);
         *reinterpret_cast<double2*>(jt + (size_t)c * kEvalBlock) = odd ? make_double2(got, v1) : make_double2(v0, got);
       }
+    }
     }
   }
 

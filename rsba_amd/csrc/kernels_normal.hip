@@ -94,6 +94,24 @@ __global__ __launch_bounds__(256) void camera_blocks_kernel(const DeviceProblem 
   }
 }
 
+// K2a, calibrated problems: the evaluation kernel has left one 16 x 16 partial [Jc | r]^T [Jc | r] per (wave, frame)
+// (kernels_eval.hip); one workgroup per frame sums its waves' partials in wave order (fixed order: deterministic).
+template <int CD>
+__global__ __launch_bounds__(256) void camera_reduce_kernel(const DeviceProblem dp, const SolverDev sv) {
+  const int f = blockIdx.x, e = threadIdx.x, row = e >> 4, col = e & 15;
+  const int64_t s0 = sv.frame_ptr[f], s1 = sv.frame_ptr[f + 1];
+  double sum = 0.0;
+  if (s1 > s0) {
+    const int rk = dp.frame_rank[f];
+    for (int64_t w = s0 >> 6; w <= (s1 - 1) >> 6; ++w) {
+      const int seg = dp.wave_seg_base[w] + rk - dp.frame_rank[dp.obs_frame[w << 6]];
+      sum += dp.cam_part[(size_t)seg * 256 + e];
+    }
+  }
+  if (row < CD && col < CD) sv.U[((size_t)f * CD + row) * CD + col] = sum;
+  if (row < CD && col == CD) sv.gc[(size_t)f * CD + row] = sum;
+}
+
 // ---------------------------------------------------------------------------------------------
 // K2a' intrinsics as a parameter block: the J^T J blocks that are NOT block-diagonal.
 //   cross: U[F+v][f] rows = intrinsics coordinates of pseudo frame v, cols = pose coordinates of frame f
@@ -717,6 +735,11 @@ inline int nblocks256(int64_t n) { return (int)((n + 255) / 256); }
   } while (0)
 
 hipError_t launch_camera_blocks(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {
+  if (dp.cam_part) {   // calibrated: the blocks were formed by the evaluation kernel, only the per-frame sums are left
+    if (sv.CD == 12) LAUNCH(camera_reduce_kernel<12>, dp.F, 256, st, dp, sv);
+    else LAUNCH(camera_reduce_kernel<6>, dp.F, 256, st, dp, sv);
+    return hipSuccess;
+  }
   if (sv.CD == 12) LAUNCH(camera_blocks_kernel<12>, dp.F, 256, st, dp, sv);
   else LAUNCH(camera_blocks_kernel<6>, dp.F, 256, st, dp, sv);
   return hipSuccess;

@@ -492,6 +492,21 @@ int32_t build_solver(rsba_handle* h) {
   const size_t REC = 2 + 2 * (size_t)dp.K;
   if ((rc = s_alloc(s, &h->dp.rec, (size_t)N * REC))) return rc;
   h->dp.obs_slot = s->d_obs_slot;
+  if (dp.calibrated && N > 0) {
+    // camera blocks inside the evaluation kernel: one 16 x 16 partial per (64-observation wave, frame it touches)
+    const int64_t nwaves = (int64_t)eval_num_blocks(N) * (kEvalBlock / 64);
+    std::vector<int32_t> wave_seg_base((size_t)nwaves + 1, 0), frame_rank(F, 0);
+    { int rk = 0; for (int f = 0; f < F; ++f) { frame_rank[f] = rk; if (frame_ptr[f + 1] > frame_ptr[f]) ++rk; } }
+    for (int64_t w = 0; w < nwaves; ++w) {
+      const int64_t a = w * 64, b = std::min<int64_t>(a + 64, N);
+      wave_seg_base[w + 1] = wave_seg_base[w] + (a < N ? frame_rank[of[b - 1]] - frame_rank[of[a]] + 1 : 0);
+    }
+    int32_t *d_base = nullptr, *d_rank = nullptr;
+    if ((rc = s_upload(s, &d_base, wave_seg_base))) return rc;
+    if ((rc = s_upload(s, &d_rank, frame_rank))) return rc;
+    if ((rc = s_alloc(s, &h->dp.cam_part, (size_t)std::max(wave_seg_base[nwaves], 1) * 256))) return rc;
+    h->dp.wave_seg_base = d_base; h->dp.frame_rank = d_rank;
+  }
   if ((rc = s_alloc(s, &sv.U, ((size_t)FR + (size_t)NPF * FR + (size_t)NPF * NPF) * CD * CD))) return rc;
   if ((rc = s_alloc(s, &sv.gc, (size_t)F * CD))) return rc;
   if ((rc = s_alloc(s, &sv.intr_part, (size_t)FR * 54))) return rc;
@@ -619,7 +634,7 @@ void rsba_destroy_solver(rsba_handle* h) {
   for (void* p : h->solver->allocs) (void)hipFree(p);
   delete h->solver;
   h->solver = nullptr;
-  h->dp.rec = nullptr; h->dp.obs_slot = nullptr;
+  h->dp.rec = nullptr; h->dp.obs_slot = nullptr; h->dp.cam_part = nullptr; h->dp.wave_seg_base = nullptr; h->dp.frame_rank = nullptr;
 }
 
 // gradient of Problem::Evaluate: loss-corrected J^T r on the masked tangent space, [F*P*6 | M*3 | NI*9]
