@@ -357,7 +357,7 @@ __device__ __forceinline__ void task_update(const SolverDev& sv, const CholPlan&
 // W = L^-1 for the factored lower-triangular tile L in LDS (pitch TP), into Wl (pitch TP; blocks above the
 // diagonal left untouched), by 16 x 16 blocks over all 256 threads — thread (r, c) = (tid >> 4, tid & 15) owns
 // element (r, c) of every block:
-//   W_bb = L_bb^-1 (forward substitution, one wave per block, a lane per column), then
+//   W_bb = L_bb^-1 (forward substitution, one wave per block, a lane per column), then, as 16 x 16 MFMA products,
 //   W_10 = -W_11 (L_10 W_00),  W_21 = -W_22 (L_21 W_11),  W_20 = -W_22 (L_20 W_00 + L_21 W_10).
 // Tm (pitch TP) is scratch for the inner products.  All threads must call; ends with a barrier.
 __device__ __forceinline__ void invert_lower_blocked(const double* L, const double* dinv, double* Wl, double* Tm, int tid) {
@@ -379,26 +379,36 @@ __device__ __forceinline__ void invert_lower_blocked(const double* L, const doub
     }
   }
   __syncthreads();
-  // block (a, b) of X Y with X block row a from column xo, Y block column b from row yo
-  auto dot = [&](const double* X, int xr, int xo, const double* Y, int yo, int yc) {
-    double s0 = 0.0, s1 = 0.0;
+  // 16 x 16 block products on the matrix pipe, one wave each: (rows xr.., columns xo.. of X) times (rows yo.., columns
+  // yc.. of Y), result in the MFMA layout (this lane: column lane & 15, rows (lane >> 4) + 4v)
+  const int mi = lane & 15, mg = lane >> 4;
+  auto mm16 = [&](const double* X, int xr, int xo, const double* Y, int yo, int yc, dbl4 acc) {
 #pragma unroll
-    for (int m = 0; m < B; m += 2) { s0 += X[(xr + r) * TP + xo + m] * Y[(yo + m) * TP + yc + c]; s1 += X[(xr + r) * TP + xo + m + 1] * Y[(yo + m + 1) * TP + yc + c]; }
-    return s0 + s1;
+    for (int kk = 0; kk < 4; ++kk)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[(xr + mi) * TP + xo + 4 * kk + mg], Y[(yo + 4 * kk + mg) * TP + yc + mi], acc, 0, 0, 0);
+    return acc;
   };
-  {
-    const double t10 = dot(L, 16, 0, Wl, 0, 0), t21 = dot(L, 32, 16, Wl, 16, 16), t20 = dot(L, 32, 0, Wl, 0, 0);
-    Tm[(16 + r) * TP + c] = t10; Tm[(32 + r) * TP + 16 + c] = t21; Tm[(32 + r) * TP + c] = t20;
+  auto put = [&](double* M, int rb, int cb, dbl4 v, double sign) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) M[(rb + mg + 4 * q) * TP + cb + mi] = sign * v[q];
+  };
+  const dbl4 zero = {0.0, 0.0, 0.0, 0.0};
+  (void)r; (void)c;
+  if (wave == 0) put(Tm, 16, 0, mm16(L, 16, 0, Wl, 0, 0, zero), 1.0);          // T10 = L10 W00
+  else if (wave == 1) put(Tm, 32, 16, mm16(L, 32, 16, Wl, 16, 16, zero), 1.0);  // T21 = L21 W11
+  else if (wave == 2) put(Tm, 32, 0, mm16(L, 32, 0, Wl, 0, 0, zero), 1.0);      // T20 = L20 W00
+  __syncthreads();
+  if (wave == 0) put(Wl, 16, 0, mm16(Wl, 16, 16, Tm, 16, 0, zero), -1.0);       // W10 = -W11 T10
+  else if (wave == 1) put(Wl, 32, 16, mm16(Wl, 32, 32, Tm, 32, 16, zero), -1.0);   // W21 = -W22 T21
+  __syncthreads();
+  if (wave == 0) {                                                              // T20 += L21 W10 ; W20 = -W22 T20
+    dbl4 t;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t[q] = Tm[(32 + mg + 4 * q) * TP + mi];
+    put(Tm, 32, 0, mm16(L, 32, 16, Wl, 16, 0, t), 1.0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    put(Wl, 32, 0, mm16(Wl, 32, 32, Tm, 32, 0, zero), -1.0);
   }
-  __syncthreads();
-  {
-    const double w10 = -dot(Wl, 16, 16, Tm, 16, 0), w21 = -dot(Wl, 32, 32, Tm, 32, 16);
-    Wl[(16 + r) * TP + c] = w10; Wl[(32 + r) * TP + 16 + c] = w21;
-  }
-  __syncthreads();
-  Tm[(32 + r) * TP + c] += dot(L, 32, 16, Wl, 16, 0);
-  __syncthreads();
-  Wl[(32 + r) * TP + c] = -dot(Wl, 32, 32, Tm, 32, 0);
   __syncthreads();
 }
 
