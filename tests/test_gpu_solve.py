@@ -212,3 +212,24 @@ def test_config_c4_solve_properties(capi):
     assert all(b <= a for a, b in zip(costs, costs[1:]))
     assert np.sqrt(s1.final_cost / s1.num_residual_blocks_reduced) < 0.55
     assert s1.final_cost < 1e-2 * s1.initial_cost
+
+
+@pytest.mark.parametrize("config,shared_intrinsics", [("C2", False), ("C2", True), ("C4", False)])
+def test_dag_cholesky_equals_the_level_schedule(capi, monkeypatch, config, shared_intrinsics):
+    """The persistent task-DAG Cholesky (tickets + per-tile flags + agent-coherent loads/stores) runs the same task
+    bodies in the same summation order as one launch per (level, kind): the two solves must agree to the bit.  A
+    stale read or a flag raised before its data would show up here."""
+    from rsba_amd.scene import make_config
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("RSBA_CHOL_LEVELS", mode)
+        p = make_config(config).problem
+        if shared_intrinsics:
+            p.calibrated = False
+            p.huber_a = 2.0
+        with capi.DeviceProblem(p) as dp:
+            s, _ = dp.solve(capi.default_options(max_num_iterations=6))
+        out[mode] = (s.final_cost, s.num_iterations, p.poses.copy(), p.points.copy(), p.intrinsics.copy())
+    a, b = out["0"], out["1"]
+    assert a[0] == b[0] and a[1] == b[1]
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
