@@ -132,12 +132,25 @@ def main():
             traffic, traffic_src = pm.get("hbm_bytes_per_launch"), f"profiles/{prof[-1]}/pmc_summary.json (2*FETCH_SIZE + WRITE_SIZE, calibrated)"
 
     lm = None
+    lm_hung = False
     if not args.no_lm:
-        try:
-            from rsba_amd.distributed import solve_timed
-            lm = solve_timed(dp, prob, world, args.lm_iters)
-        except (ImportError, capi.RsbaError) as e:
-            lm = {"error": str(e)}
+        # The LM solve is the one part of this script with a collective on the data path (three all-reduces per
+        # iteration).  It runs under a watchdog so that a wedged exchange can never take the bench line with it.
+        import threading
+        box = {}
+
+        def run_lm():
+            try:
+                from rsba_amd.distributed import solve_timed
+                box["lm"] = solve_timed(dp, prob, world, args.lm_iters)
+            except Exception as e:  # noqa: BLE001 - reported in the JSON line
+                box["lm"] = {"error": repr(e)}
+
+        th = threading.Thread(target=run_lm, daemon=True)
+        th.start()
+        th.join(timeout=float(os.environ.get("RSBA_BENCH_LM_TIMEOUT_S", "180")))
+        lm_hung = th.is_alive()
+        lm = {"error": "LM solve did not finish inside the watchdog window"} if lm_hung else box.get("lm")
 
     out = None
     if rank == 0:
@@ -156,6 +169,10 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(prob)
+    if lm_hung:                      # do not touch the device or the process group again: report and leave
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        os._exit(0)
     dp.close()
     if world > 1:
         dist.barrier()
