@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <numeric>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -42,6 +43,27 @@ static int32_t dev_upload(rsba_handle* h, T** p, const T* src, size_t count) {
   if (count) HIP_TRY(hipMemcpy(*p, src, count * sizeof(T), hipMemcpyHostToDevice));
   return RSBA_OK;
 }
+
+namespace rsba {
+hipError_t allow_dynamic_lds_impl(const void* kernel, size_t bytes) {
+  struct Entry { const void* fn; unsigned long long devices; size_t bytes; };
+  static Entry table[64];
+  static int used = 0;
+  static std::mutex mu;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lock(mu);
+  Entry* ent = nullptr;
+  for (int i = 0; i < used; ++i) if (table[i].fn == kernel) { ent = &table[i]; break; }
+  if (ent && dev >= 0 && dev < 64 && (ent->devices >> dev & 1ull) && ent->bytes >= bytes) return hipSuccess;
+  e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return e;
+  if (!ent && used < 64) { ent = &table[used++]; ent->fn = kernel; ent->devices = 0; ent->bytes = 0; }
+  if (ent && dev >= 0 && dev < 64) { if (bytes > ent->bytes) { ent->bytes = bytes; ent->devices = 0; } ent->devices |= 1ull << dev; }
+  return hipSuccess;
+}
+}  // namespace rsba
 
 extern "C" {
 
@@ -238,28 +260,29 @@ int32_t rsba_evaluate(rsba_handle* h, double* cost, double* residuals, double* j
   if (!h) return fail(RSBA_ERR_INVALID_ARGUMENT, "null handle");
   HIP_TRY(hipSetDevice(h->device));
   DeviceProblem& dp = h->dp;
-  const int64_t N = dp.N, T = kEvalBlock; const int K = dp.K;
+  const int64_t N = dp.N; const int K = dp.K;
   HIP_TRY(hipMemsetAsync(dp.fail_count, 0, sizeof(int), h->stream));
   HIP_TRY(launch_eval(dp, jacobians ? kRawJacobian : kResidualOnly, h->stream));
   HIP_TRY(launch_cost_reduce(dp, h->d_cost2, h->stream));
   double c2[2] = {0, 0}; int nfail = 0;
   HIP_TRY(hipMemcpyAsync(c2, h->d_cost2, sizeof c2, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipMemcpyAsync(&nfail, dp.fail_count, sizeof nfail, hipMemcpyDeviceToHost, h->stream));
-  std::vector<double> hr, hj;
-  if (residuals) { hr.resize(2 * (size_t)T * dp.ntiles); HIP_TRY(hipMemcpyAsync(hr.data(), dp.res, hr.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream)); }
-  if (jacobians) { hj.resize(2 * (size_t)K * T * dp.ntiles); HIP_TRY(hipMemcpyAsync(hj.data(), dp.jac, hj.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream)); }
+  if ((residuals || jacobians) && N > 0) {
+    if (!h->d_order) {
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_order), (size_t)N * sizeof(int64_t)));
+      h->allocs.push_back(h->d_order);
+      HIP_TRY(hipMemcpyAsync(h->d_order, h->order.data(), (size_t)N * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_rows), (size_t)N * (2 + 2 * (size_t)K) * sizeof(double)));
+      h->allocs.push_back(h->d_rows);
+    }
+    double* d_res = h->d_rows; double* d_jac = h->d_rows + 2 * (size_t)N;
+    HIP_TRY(launch_untile(dp, h->d_order, jacobians != nullptr, d_res, d_jac, h->stream));
+    if (residuals) HIP_TRY(hipMemcpyAsync(residuals, d_res, 2 * (size_t)N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (jacobians) HIP_TRY(hipMemcpyAsync(jacobians, d_jac, 2 * (size_t)K * N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  }
   HIP_TRY(hipStreamSynchronize(h->stream));
   if (cost) *cost = c2[0] + c2[1];
   if (num_failed) *num_failed = nfail;
-  // tiled component-major device layout -> caller's [N][2] / [N][2][K] in the caller's observation order
-  if (residuals) for (int64_t i = 0; i < N; ++i) {
-    const int64_t u = h->order[i]; const double* src = &hr[(size_t)(i / T) * 2 * T + (i % T)];
-    residuals[2 * u] = src[0]; residuals[2 * u + 1] = src[T];
-  }
-  if (jacobians) for (int64_t i = 0; i < N; ++i) {
-    const double* src = &hj[(size_t)(i / T) * 2 * K * T + (i % T)]; double* dst = &jacobians[(size_t)h->order[i] * 2 * K];
-    for (int c = 0; c < 2 * K; ++c) dst[c] = src[(size_t)c * T];
-  }
   if (gradient) {
     int32_t rc = rsba_gradient(h, gradient);
     if (rc) return rc;

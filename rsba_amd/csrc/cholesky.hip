@@ -690,20 +690,9 @@ __global__ __launch_bounds__(256) void chol_dag_kernel(const SolverDev sv, const
 
 }  // namespace
 
-namespace {
-template <class K>
-hipError_t set_lds(K kernel, size_t bytes, bool& configured) {
-  if (configured) return hipSuccess;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-  if (e == hipSuccess) configured = true;
-  return e;
-}
-}  // namespace
-
 hipError_t launch_chol_level(const SolverDev& sv, const CholPlan& pl, int kind, int first, int count, hipStream_t st) {
   if (count <= 0) return hipSuccess;
-  static bool configured = false;
-  hipError_t e = set_lds(chol_level_kernel, kCholLds * sizeof(double), configured);
+  hipError_t e = allow_dynamic_lds(chol_level_kernel, kCholLds * sizeof(double));
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(chol_level_kernel, dim3(count), dim3(256), kCholLds * sizeof(double), st, sv, pl, kind, first);
   return hipGetLastError();
@@ -711,8 +700,7 @@ hipError_t launch_chol_level(const SolverDev& sv, const CholPlan& pl, int kind, 
 
 hipError_t launch_chol_dag(const SolverDev& sv, const CholPlan& pl, int workgroups, hipStream_t st) {
   if (pl.ntasks <= 0) return hipSuccess;
-  static bool configured = false;
-  hipError_t e = set_lds(chol_dag_kernel, kCholLds * sizeof(double), configured);
+  hipError_t e = allow_dynamic_lds(chol_dag_kernel, kCholLds * sizeof(double));
   if (e != hipSuccess) return e;
   // ticket counter and flags sit in one allocation: [ticket (as 4 bytes, padded to 16) | flags]
   e = hipMemsetAsync(pl.ticket, 0, 16 + sizeof(int32_t) * ((size_t)pl.nslots + pl.nparts + sv.nt), st);

@@ -68,6 +68,8 @@ enum EvalMode : int {
 hipError_t launch_eval(const DeviceProblem& dp, EvalMode mode, hipStream_t stream);
 int eval_num_blocks(int64_t n);
 hipError_t launch_cost_reduce(const DeviceProblem& dp, double* out2, hipStream_t stream);
+// tiled component-major res / jac -> rows[order[i]][..] in the caller's layout ([N][2] and [N][2][K], back to back)
+hipError_t launch_untile(const DeviceProblem& dp, const int64_t* order, bool with_jacobians, double* res_rows, double* jac_rows, hipStream_t st);
 hipError_t launch_validate(const DeviceProblem& dp, double sq_threshold, double min_distance, uint8_t* valid, hipStream_t st);
 hipError_t launch_reproject(const DeviceProblem& dp, const int32_t* frames, const int32_t* points, int64_t n, double* xy_out, uint8_t* ok_out, hipStream_t st);
 

@@ -22,6 +22,8 @@ struct rsba_handle {
   std::vector<int32_t> obs_frame, obs_point;            // host copies, internal (frame-major) order
   std::vector<void*> allocs;
   double* d_cost2 = nullptr;           // {cost, fixed cost}
+  int64_t* d_order = nullptr;          // device copy of `order`, made on the first host-returning evaluation
+  double* d_rows = nullptr;            // [N][2 + 2K] results in the caller's layout and order, staged for one D2H copy each
   rsba::Solver* solver = nullptr;      // normal-equation / Schur / LM state, built on first use
   // multi-GPU exchange (rsba_set_exchange / rsba_set_block_structure)
   rsba_allreduce_fn allreduce = nullptr;

@@ -260,6 +260,29 @@ __global__ __launch_bounds__(256) void reduce_cost_kernel(const double* __restri
   }
 }
 
+// Host-returning evaluations (rsba_evaluate): convert the device layout to the caller's on the device, so that the
+// results leave in one contiguous D2H copy each instead of being re-ordered element by element on the host.
+__global__ __launch_bounds__(256) void untile_kernel(const DeviceProblem dp, const int64_t* __restrict__ order, int with_jac,
+                                                     double* __restrict__ res_rows, double* __restrict__ jac_rows) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= dp.N) return;
+  const int64_t u = order[i];
+  const int K = dp.K;
+  const double* rt = dp.res + (size_t)(i >> 8) * (2 * kEvalBlock) + (i & 255);
+  res_rows[2 * u] = rt[0]; res_rows[2 * u + 1] = rt[kEvalBlock];
+  if (with_jac) {
+    const double* jt = dp.jac + (size_t)(i >> 8) * (2 * (size_t)K * kEvalBlock) + (i & 255);
+    double* dst = jac_rows + (size_t)u * 2 * K;
+    for (int c = 0; c < 2 * K; ++c) dst[c] = jt[(size_t)c * kEvalBlock];
+  }
+}
+
+hipError_t launch_untile(const DeviceProblem& dp, const int64_t* order, bool with_jacobians, double* res_rows, double* jac_rows, hipStream_t st) {
+  if (dp.N <= 0) return hipSuccess;
+  hipLaunchKernelGGL(untile_kernel, dim3((unsigned)((dp.N + 255) / 256)), dim3(256), 0, st, dp, order, with_jacobians ? 1 : 0, res_rows, jac_rows);
+  return hipGetLastError();
+}
+
 hipError_t launch_cost_reduce(const DeviceProblem& dp, double* out2, hipStream_t st) {
   hipLaunchKernelGGL(reduce_cost_kernel, dim3(1), dim3(256), 0, st, dp.cost_partial, dp.fixed_partial, dp.fail_partial, eval_num_blocks(dp.N), out2, dp.fail_count);
   return hipGetLastError();

@@ -782,39 +782,24 @@ hipError_t launch_point_factor(const DeviceProblem& dp, const SolverDev& sv, dou
   LAUNCH(point_factor_kernel, nblocks256(dp.M), 256, st, dp, sv, 1.0 / radius);
   return hipSuccess;
 }
+template <int CD, int KC>
+static hipError_t launch_project_as(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {
+  constexpr int REC = 8 + 2 * KC, OUT = CD * 3;
+  const size_t lds = (size_t)4 * 64 * ((REC > OUT ? REC : OUT) | 1) * sizeof(double);
+  const int grid = (int)((dp.N + 256 * kProjectChunks - 1) / (256 * kProjectChunks));
+  hipError_t e = allow_dynamic_lds(project_kernel<CD, KC>, lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((project_kernel<CD, KC>), dim3(grid), dim3(256), lds, st, dp, sv);
+  return hipGetLastError();
+}
 hipError_t launch_project(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {
   if (dp.N == 0) return hipSuccess;
-  const int grid = (int)((dp.N + 256 * kProjectChunks - 1) / (256 * kProjectChunks));
   const int KC = dp.K - 3;
-  auto lds_of = [](int rec, int out) { return (size_t)4 * 64 * (((rec > out ? rec : out)) | 1) * sizeof(double); };
-  if (sv.CD == 12 && KC == 12) {
-    static bool configured = false;   // 74 KB of dynamic LDS: above the 64 KB default cap
-    if (!configured) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(project_kernel<12, 12>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(32, 36));
-      if (e != hipSuccess) return e;
-      configured = true;
-    }
-    hipLaunchKernelGGL((project_kernel<12, 12>), dim3(grid), dim3(256), lds_of(32, 36), st, dp, sv);
-  }
-  else if (sv.CD == 6 && KC == 6) hipLaunchKernelGGL((project_kernel<6, 6>), dim3(grid), dim3(256), lds_of(20, 18), st, dp, sv);
-  else if (sv.CD == 12 && KC == 21) {
-    static bool configured = false;
-    if (!configured) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(project_kernel<12, 21>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(50, 36));
-      if (e != hipSuccess) return e;
-      configured = true;
-    }
-    hipLaunchKernelGGL((project_kernel<12, 21>), dim3(grid), dim3(256), lds_of(50, 36), st, dp, sv);
-  } else if (sv.CD == 6 && KC == 15) {
-    static bool configured = false;
-    if (!configured) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(project_kernel<6, 15>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(38, 18));
-      if (e != hipSuccess) return e;
-      configured = true;
-    }
-    hipLaunchKernelGGL((project_kernel<6, 15>), dim3(grid), dim3(256), lds_of(38, 18), st, dp, sv);
-  } else return hipErrorInvalidValue;
-  return hipGetLastError();
+  if (sv.CD == 12 && KC == 12) return launch_project_as<12, 12>(dp, sv, st);
+  if (sv.CD == 6 && KC == 6) return launch_project_as<6, 6>(dp, sv, st);
+  if (sv.CD == 12 && KC == 21) return launch_project_as<12, 21>(dp, sv, st);
+  if (sv.CD == 6 && KC == 15) return launch_project_as<6, 15>(dp, sv, st);
+  return hipErrorInvalidValue;
 }
 // intrinsics as a parameter block: border blocks of J^T J and the intrinsics gradient
 hipError_t launch_intr_blocks(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {
@@ -849,13 +834,13 @@ hipError_t launch_schur_blocks(const DeviceProblem& dp, const SolverDev& sv, dou
     const size_t table = (size_t)kSchurChunk * (2 * (kTile / sv.CD) * sizeof(int32_t) + 3 * sizeof(double));
     const size_t tiles = (size_t)(4 * kTile * (kTile + 1) + 4 * kTile) * sizeof(double);
     const size_t lds = table > tiles ? table : tiles;
-    static bool configured12 = false, configured6 = false;
+    const dim3 grid(8 * ((sv.nchunk + 7) / 8));
     if (sv.CD == 12) {
-      if (!configured12) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(schur_tile_kernel<12>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; configured12 = true; }
-      hipLaunchKernelGGL(schur_tile_kernel<12>, dim3(8 * ((sv.nchunk + 7) / 8)), dim3(256), lds, st, sv, sv.Pm, sv.z);
+      hipError_t e = allow_dynamic_lds(schur_tile_kernel<12>, lds); if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(schur_tile_kernel<12>, grid, dim3(256), lds, st, sv, sv.Pm, sv.z);
     } else {
-      if (!configured6) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(schur_tile_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; configured6 = true; }
-      hipLaunchKernelGGL(schur_tile_kernel<6>, dim3(8 * ((sv.nchunk + 7) / 8)), dim3(256), lds, st, sv, sv.Pm, sv.z);
+      hipError_t e = allow_dynamic_lds(schur_tile_kernel<6>, lds); if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(schur_tile_kernel<6>, grid, dim3(256), lds, st, sv, sv.Pm, sv.z);
     }
     { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; }
   }
@@ -867,12 +852,8 @@ template <int CD, int KC>
 static hipError_t launch_point_step(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {
   constexpr int REC = 8 + 2 * KC, PITCH = REC | 1;
   const size_t lds = (size_t)4 * (64 * PITCH + 64 * 5) * sizeof(double);
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(point_step_kernel<CD, KC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    configured = true;
-  }
+  hipError_t e = allow_dynamic_lds(point_step_kernel<CD, KC>, lds);
+  if (e != hipSuccess) return e;
   hipLaunchKernelGGL((point_step_kernel<CD, KC>), dim3(point_step_blocks(dp)), dim3(256), lds, st, dp, sv);
   return hipGetLastError();
 }

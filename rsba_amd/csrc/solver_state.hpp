@@ -88,6 +88,11 @@ enum ScalarSlot : int {
   kModelCostChange = 0, kStepSq = 1, kXSq = 2, kGradMax = 3, kCost = 4, kFixedCost = 5, kEvalFailed = 6, kSolveFailed = 7,
 };
 
+// Dynamic LDS above the 64 KB default needs the kernel's cap raised, once per (kernel, device).
+hipError_t allow_dynamic_lds_impl(const void* kernel, size_t bytes);   // capi.hip
+template <class K>
+inline hipError_t allow_dynamic_lds(K kernel, size_t bytes) { return allow_dynamic_lds_impl(reinterpret_cast<const void*>(kernel), bytes); }
+
 // Cholesky task plan (cholesky.hip): flattened work lists of the symbolic phase, device pointers
 struct CholPlan {
   const int32_t *upd, *diag_info, *diag_ptr, *diag_list, *sub_info, *sub_ptr, *sub_list, *sub_col, *diag_own, *sub_own, *back_info, *back_ptr, *back_list;
