@@ -186,11 +186,17 @@ __global__ __launch_bounds__(256) void intr_self_kernel(const DeviceProblem dp, 
   if (tid < NE) sv.intr_part[(size_t)f * NE + tid] = s_red[0][tid] + s_red[1][tid] + s_red[2][tid] + s_red[3][tid];
 }
 
-__global__ void intr_reduce_kernel(const DeviceProblem dp, const SolverDev sv) {
-  const int t = threadIdx.x;
-  if (t >= 54) return;
+// one workgroup per entry t of the 45 + 9 sums: lanes stride the frames, fixed-order wave / workgroup reduction
+__global__ __launch_bounds__(256) void intr_reduce_kernel(const DeviceProblem dp, const SolverDev sv) {
+  __shared__ double s_red[4];
+  const int t = blockIdx.x, tid = threadIdx.x;
   double v = 0.0;
-  for (int f = 0; f < sv.F; ++f) v += sv.intr_part[(size_t)f * 54 + t];
+  for (int f = tid; f < sv.F; f += 256) v += sv.intr_part[(size_t)f * 54 + t];
+  v = wsum(v);
+  if ((tid & 63) == 0) s_red[tid >> 6] = v;
+  __syncthreads();
+  if (tid != 0) return;
+  v = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
   const int CD = sv.CD;
   if (t >= 45) { sv.gc[(size_t)sv.F * CD + (t - 45)] = v; return; }
   int a = 0, rem = t;
@@ -537,6 +543,23 @@ __global__ __launch_bounds__(256) void schur_tile_kernel(const SolverDev sv, con
   if (tid < kTile) { const double* v = smem + 4 * kTile * TPITCH; part[kTile * kTile + tid] = (v[tid] + v[kTile + tid]) + (v[2 * kTile + tid] + v[3 * kTile + tid]); }
 }
 
+// one workgroup per group of a very long chunk list: partial[first] = sum of the group's partials, in list order
+__global__ __launch_bounds__(256) void schur_premerge_kernel(const SolverDev sv) {
+  const int g0 = sv.pm_ptr[blockIdx.x], g1 = sv.pm_ptr[blockIdx.x + 1], tid = threadIdx.x;
+  const size_t pstride = kTile * kTile + kTile;
+  double* dst = sv.schur_part + (size_t)sv.pm_list[g0] * pstride;
+  for (int e = tid; e < (int)pstride; e += 256) {
+    double ps[4] = {0, 0, 0, 0};
+    int c = g0;
+    for (; c + 4 <= g1; c += 4) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) ps[u] += sv.schur_part[(size_t)sv.pm_list[c + u] * pstride + e];
+    }
+    for (int u = 0; c < g1; ++c, ++u) ps[u] += sv.schur_part[(size_t)sv.pm_list[c] * pstride + e];
+    dst[e] = (ps[0] + ps[1]) + (ps[2] + ps[3]);
+  }
+}
+
 // one workgroup per tile pair: sum the chunk partials in order, add U / D_c^2 / g_c, identity padding, and
 // store into the packed tile slot (transposed when the tile ordering swapped the pair)
 __global__ __launch_bounds__(256) void schur_merge_kernel(const DeviceProblem dp, const SolverDev sv, double inv_radius) {
@@ -550,8 +573,16 @@ __global__ __launch_bounds__(256) void schur_merge_kernel(const DeviceProblem dp
     const int rt = e / kTile, ct = e % kTile;
     const int x = rt / CD, y = ct / CD, r = rt % CD, c = ct % CD;
     const int a = I * FT + x, b = J * FT + y;
-    double sum = 0.0;
-    for (int ch = c0; ch < c1; ++ch) sum += sv.schur_part[(size_t)sv.tp_chunk_list[ch] * pstride + e];
+    // eight interleaved running sums (chunk index mod 8) keep eight loads in flight; the diagonal pair of the
+    // intrinsics pseudo tile has one chunk per 512 points of the whole problem
+    double ps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int ch = c0;
+    for (; ch + 8 <= c1; ch += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) ps[u] += sv.schur_part[(size_t)sv.tp_chunk_list[ch + u] * pstride + e];
+    }
+    for (int u = 0; ch < c1; ++ch, ++u) ps[u] += sv.schur_part[(size_t)sv.tp_chunk_list[ch] * pstride + e];
+    const double sum = ((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7]));
     double val;
     if (a >= sv.Fx || b >= sv.Fx) val = (a == b && r == c && sv.lead) ? 1.0 : 0.0;     // padding frames of the last tile
     else {
@@ -563,8 +594,14 @@ __global__ __launch_bounds__(256) void schur_merge_kernel(const DeviceProblem dp
   }
   if (I == J && tid < kTile) {
     const int a = I * FT + tid / CD;
-    double sum = 0.0;
-    for (int ch = c0; ch < c1; ++ch) sum += sv.schur_part[(size_t)sv.tp_chunk_list[ch] * pstride + kTile * kTile + tid];
+    double ps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int ch = c0;
+    for (; ch + 8 <= c1; ch += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) ps[u] += sv.schur_part[(size_t)sv.tp_chunk_list[ch + u] * pstride + kTile * kTile + tid];
+    }
+    for (int u = 0; ch < c1; ++ch, ++u) ps[u] += sv.schur_part[(size_t)sv.tp_chunk_list[ch] * pstride + kTile * kTile + tid];
+    const double sum = ((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7]));
     sv.rhs[(size_t)I * kTile + tid] = (a < sv.Fx) ? (sv.lead ? sv.gc[(size_t)I * kTile + tid] : 0.0) - sum : 0.0;
   }
 }
@@ -816,7 +853,7 @@ hipError_t launch_intr_blocks(const DeviceProblem& dp, const SolverDev& sv, hipS
     LAUNCH((intr_cross_kernel<6, 0, 9>), dp.F, 256, st, dp, sv);
   }
   LAUNCH(intr_self_kernel, dp.F, 256, st, dp, sv);
-  LAUNCH(intr_reduce_kernel, 1, 64, st, dp, sv);
+  LAUNCH(intr_reduce_kernel, 54, 256, st, dp, sv);
   return hipSuccess;
 }
 hipError_t launch_virtual_records(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {
@@ -844,6 +881,7 @@ hipError_t launch_schur_blocks(const DeviceProblem& dp, const SolverDev& sv, dou
     }
     { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; }
   }
+  if (sv.npremerge > 0) LAUNCH(schur_premerge_kernel, sv.npremerge, 256, st, sv);
   LAUNCH(schur_merge_kernel, sv.ntp, 256, st, dp, sv, 1.0 / radius);
   return hipSuccess;
 }

@@ -400,9 +400,23 @@ int32_t build_solver(rsba_handle* h) {
       }
     }
   }
-  std::vector<int32_t> tp_chunk0(ntp + 1, 0), tp_chunk_list;
-  for (int t = 0; t < ntp; ++t) { tp_chunk0[t] = (int32_t)tp_chunk_list.size(); tp_chunk_list.insert(tp_chunk_list.end(), pair_chunks[t].begin(), pair_chunks[t].end()); }
+  // A pair with very many chunks (the diagonal pair of the intrinsics pseudo tile has one per 512 points of the whole
+  // problem) would be summed by a single workgroup of the merge kernel: its chunk list is pre-reduced in groups of
+  // kMergeGroup, one workgroup each, into the partial tile of the group's first chunk, and only those heads go to the merge.
+  const int kMergeGroup = 32;
+  std::vector<int32_t> tp_chunk0(ntp + 1, 0), tp_chunk_list, pm_ptr(1, 0), pm_list;
+  for (int t = 0; t < ntp; ++t) {
+    tp_chunk0[t] = (int32_t)tp_chunk_list.size();
+    const std::vector<int32_t>& pc = pair_chunks[t];
+    if ((int)pc.size() <= kMergeGroup) { tp_chunk_list.insert(tp_chunk_list.end(), pc.begin(), pc.end()); continue; }
+    for (size_t g = 0; g < pc.size(); g += kMergeGroup) {
+      const size_t g1 = std::min(pc.size(), g + kMergeGroup);
+      tp_chunk_list.push_back(pc[g]);
+      if (g1 - g > 1) { pm_list.insert(pm_list.end(), pc.begin() + g, pc.begin() + g1); pm_ptr.push_back((int32_t)pm_list.size()); }
+    }
+  }
   tp_chunk0[ntp] = (int32_t)tp_chunk_list.size();
+  sv.npremerge = (int)pm_ptr.size() - 1;
   sv.nchunk = (int)chunk_tp.size(); sv.ntp = ntp; sv.FT = FT;
   { const char* e = std::getenv("RSBA_SCHUR_LINEAR"); sv.schur_linear = e && e[0] == '1'; }
   std::vector<int32_t> tp_dst(ntp); std::vector<uint8_t> tp_trans(ntp, 0);
@@ -467,6 +481,8 @@ int32_t build_solver(rsba_handle* h) {
   if ((rc = s_upload_const(s, &sv.tp_chunk0, tp_chunk0))) return rc;
   if ((rc = s_upload_const(s, &sv.tp_chunk_list, tp_chunk_list))) return rc;
   if ((rc = s_upload_const(s, &sv.chunk_n, chunk_n))) return rc;
+  if ((rc = s_upload_const(s, &sv.pm_ptr, pm_ptr))) return rc;
+  if ((rc = s_upload_const(s, &sv.pm_list, pm_list))) return rc;
   if ((rc = s_upload_const(s, &sv.tp_dst, tp_dst))) return rc;
   if ((rc = s_upload_const(s, &sv.tp_trans, tp_trans))) return rc;
   if ((rc = s_upload_const(s, &sv.tp_add, tp_add))) return rc;

@@ -49,7 +49,10 @@ struct SolverDev {
   const int64_t* chunk_e0;      // [nchunk] first entry of the chunk
   const int32_t* chunk_n;       // [nchunk] entries in the chunk (<= kSchurChunk)
   const int32_t* tp_chunk0;     // [ntp+1] range of each tile pair in tp_chunk_list
-  const int32_t* tp_chunk_list; // chunk ids of each tile pair, in entry order
+  const int32_t* tp_chunk_list; // chunk ids of each tile pair, in entry order (heads of pre-merged groups for very long lists)
+  int npremerge;                // groups of chunks summed ahead of the merge
+  const int32_t* pm_ptr;        // [npremerge+1] into pm_list
+  const int32_t* pm_list;       // chunk ids of each group; the sum lands in the first one's partial tile
   const int32_t* tp_dst;        // [ntp] packed tile slot that receives the pair
   const uint8_t* tp_trans;      // [ntp] 1 = the tile ordering swapped I and J: store transposed
   const int64_t* tp_add;        // [ntp][FT][FT] offset into U of the J^T J block to add, -1 none

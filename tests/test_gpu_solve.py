@@ -233,3 +233,15 @@ def test_dag_cholesky_equals_the_level_schedule(capi, monkeypatch, config, share
     a, b = out["0"], out["1"]
     assert a[0] == b[0] and a[1] == b[1]
     assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+
+
+def test_shared_intrinsics_with_many_points(capi, oracle):
+    """The diagonal tile pair of the intrinsics pseudo tile has one Schur chunk per 512 points: above 32 chunks its
+    partial tiles are pre-reduced in groups before the merge.  20 000 points reach that path; the oracle still
+    solves the 40-frame reduced system densely in seconds."""
+    p = small_scene(rolling=True, frames=40, points=20000, seed=53, outlier_ratio=0.02)
+    p.calibrated = False
+    p.huber_a = 2.0
+    p.intrinsics = p.intrinsics * (1.0 + 1e-3 * np.array([[1, -1, 20, -20, 10, 10, -10, 0.5, -0.5]]))
+    s, s_ref, p_dev, p_cpu = compare_solves(capi, oracle, p, iters=8)
+    assert np.max(np.abs(p_dev.intrinsics - p_cpu.intrinsics) / np.maximum(1.0, np.abs(p_cpu.intrinsics))) <= 1e-6
