@@ -44,10 +44,11 @@ struct DeviceProblem {
   // so that everything the point elimination needs about one point is contiguous in HBM.
   double* rec;                   // [N][rec_len]
   const int32_t* obs_slot;       // [N]
-  // LM mode, calibrated problems: the per-frame camera blocks are formed inside the evaluation kernel (fp64 MFMA
+  // LM mode: the per-frame camera (and intrinsics border) blocks are formed inside the evaluation kernel (fp64 MFMA
   // over each wave's 64 observations) instead of from a second pass over the tiled Jacobian, which is then not
-  // written at all.  Every wave stores one 16 x 16 partial [Jc | r]^T [Jc | r] per frame it touches:
-  double* cam_part;              // [segments][256]; null = write the tiled Jacobian (K2a reads it)
+  // written at all.  Every wave stores the 16 x 16 blocks on and below the diagonal of [Ji | Jc | r]^T [Ji | Jc | r]
+  // (one block, or three with rolling shutter + intrinsics) per frame it touches:
+  double* cam_part;              // [segments][blocks][256]; null = write the tiled Jacobian
   const int32_t* wave_seg_base;  // [ceil(N / 64) + 1] first segment of each 64-observation wave
   const int32_t* frame_rank;     // [F] index of the frame among the frames that have observations
   double* cost_partial;          // [nblocks] 1/2 sum rho0 over non-dropped blocks of each workgroup

@@ -32,8 +32,10 @@ __global__ __launch_bounds__(kEvalBlock) void eval_kernel(const DeviceProblem dp
   __shared__ double s_pose[kStageFrames * CD];
   __shared__ double s_scale[MODE == kLmJacobian ? kStageFrames * CD : 1];
   __shared__ double s_red[3][kEvalBlock / 64];
-  constexpr bool CAMBLK = (MODE == kLmJacobian) && CAL;   // camera blocks formed here (dp.cam_part)
-  constexpr int TP = 17;                                   // pitch of the operand transposition buffer
+  constexpr bool CAMBLK = (MODE == kLmJacobian);          // camera (and intrinsics) blocks formed here (dp.cam_part)
+  constexpr int NCOL = (K - 3) + 1;                        // [Ji (9, uncalibrated only) | Jc (CD) | r]
+  constexpr int NCB = (NCOL + 15) / 16;                    // 16-column blocks of it: 1, or 2 for rolling shutter + intrinsics
+  constexpr int TP = 16 * NCB + 1;                         // pitch of the operand transposition buffer
   constexpr int RECW = 2 + 2 * K, RPITCH = RECW | 1;       // point-major record, and its pitch in the staging buffer
   constexpr int TRW = (MODE == kLmJacobian) ? ((64 * TP > 32 * RPITCH) ? 64 * TP : 32 * RPITCH) : 1;   // doubles per wave
   __shared__ double s_tr[(MODE == kLmJacobian) ? (kEvalBlock / 64) * TRW : 1];
@@ -156,11 +158,14 @@ __global__ __launch_bounds__(kEvalBlock) void eval_kernel(const DeviceProblem dp
     cost = half_rho;
 
     if (CAMBLK && dp.cam_part) {
-      // K2a in place: D = [Jc | r]^T [Jc | r] over the observations of ONE frame = U_f (CD x CD), g_f (column CD).
-      // MFMA wants lane (i = lane & 15, g = lane >> 4) to hold coordinate i of Jacobian row k = 4 step + g, while
-      // the rows live one observation per lane: they change lanes through LDS, half a wave (64 rows) at a time.
-      // A wave that straddles frames does one pass per frame, rows of the other frames masked to zero.
+      // K2a in place: G = [Ji | Jc | r]^T [Ji | Jc | r] over the observations of ONE frame holds U_f = Jc^T Jc, g_f = Jc^T r
+      // and, with intrinsics as a parameter block, the border blocks Ji^T Jc, Ji^T Ji, Ji^T r of the same frame.
+      // MFMA wants lane (i = lane & 15, g = lane >> 4) to hold column i of Jacobian row k = 4 step + g, while the rows
+      // live one observation per lane: they change lanes through LDS, half a wave (64 rows) at a time.  A wave
+      // that straddles frames does one pass per frame, rows of the other frames masked to zero.  Only the blocks
+      // on and below the diagonal of G are formed (NCB (NCB + 1) / 2 of 16 x 16).
       typedef double dbl4 __attribute__((ext_vector_type(4)));
+      constexpr int NBLK = NCB * (NCB + 1) / 2;
       const int lane = tid & 63, wv = tid >> 6, ci = lane & 15, cg = lane >> 4;
       double* tr = s_tr + wv * TRW;
       const int my_frame = valid ? f : -1;
@@ -172,17 +177,19 @@ __global__ __launch_bounds__(kEvalBlock) void eval_kernel(const DeviceProblem dp
         if (fr < 0) break;
         const unsigned long long in_seg = __ballot(my_frame == fr);
         const int seg_end = done + __builtin_popcountll(in_seg);     // observations of a frame are consecutive
-        dbl4 d = {0.0, 0.0, 0.0, 0.0};
+        dbl4 d[NBLK];
+#pragma unroll
+        for (int q = 0; q < NBLK; ++q) d[q] = dbl4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           if ((lane >> 5) == h) {
             const bool keep = o.ok && valid && my_frame == fr;
             double* row = tr + 2 * (lane & 31) * TP;
 #pragma unroll
-            for (int c = 0; c < CD; ++c) { row[c] = keep ? o.J[0][OFF_POSE + c] : 0.0; row[TP + c] = keep ? o.J[1][OFF_POSE + c] : 0.0; }
-            row[CD] = keep ? o.r[0] : 0.0; row[TP + CD] = keep ? o.r[1] : 0.0;
+            for (int c = 0; c < K - 3; ++c) { row[c] = keep ? o.J[0][c] : 0.0; row[TP + c] = keep ? o.J[1][c] : 0.0; }
+            row[K - 3] = keep ? o.r[0] : 0.0; row[TP + K - 3] = keep ? o.r[1] : 0.0;
 #pragma unroll
-            for (int c = CD + 1; c < 16; ++c) { row[c] = 0.0; row[TP + c] = 0.0; }
+            for (int c = NCOL; c < 16 * NCB; ++c) { row[c] = 0.0; row[TP + c] = 0.0; }
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
           // rows of this half that belong to the segment: observations [max(done, 32h), min(seg_end, 32h + 32))
@@ -190,15 +197,22 @@ __global__ __launch_bounds__(kEvalBlock) void eval_kernel(const DeviceProblem dp
           if (o_lo < o_hi) {
             const int s_lo = (2 * (o_lo - 32 * h)) >> 2, s_hi = (2 * (o_hi - 32 * h) + 3) >> 2;
             for (int step = s_lo; step < s_hi; ++step) {
-              const double a = tr[(4 * step + cg) * TP + ci];
-              d = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, d, 0, 0, 0);
+              double a[NCB];
+#pragma unroll
+              for (int q = 0; q < NCB; ++q) a[q] = tr[(4 * step + cg) * TP + 16 * q + ci];
+#pragma unroll
+              for (int qa = 0; qa < NCB; ++qa)
+#pragma unroll
+                for (int qb = 0; qb <= qa; ++qb) d[qa * (qa + 1) / 2 + qb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[qa], a[qb], d[qa * (qa + 1) / 2 + qb], 0, 0, 0);
             }
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        double* part = dp.cam_part + (size_t)seg * 256;
+        double* part = dp.cam_part + (size_t)seg * (NBLK * 256);
 #pragma unroll
-        for (int v = 0; v < 4; ++v) part[(cg + 4 * v) * 16 + ci] = d[v];
+        for (int q = 0; q < NBLK; ++q)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) part[q * 256 + (cg + 4 * v) * 16 + ci] = d[q][v];
         ++seg;
         done = seg_end;
       }

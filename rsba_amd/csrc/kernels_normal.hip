@@ -45,145 +45,53 @@ __device__ __forceinline__ double u_diag(const SolverDev& sv, int64_t t) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// K2a  per-frame camera block  U_f = sum Jc^T Jc,  g_f = sum Jc^T r   (frame-major tiles, coalesced)
-// One workgroup per frame; every lane keeps the CD(CD+1)/2 + CD running sums of its strided
-// observations in registers, then a fixed-order wave / workgroup reduction.
+// K2a  per-frame camera block  U_f = sum Jc^T Jc,  g_f = sum Jc^T r  and, with intrinsics as a parameter block
+// (opt.model.calibrated == false, shared sess.cam), the blocks of J^T J that are NOT block-diagonal:
+//   cross: U[F+v][f] rows = intrinsics coordinates of pseudo frame v, cols = pose coordinates of frame f
+//   self : per-frame partials of Ji^T Ji (45 unique) and Ji^T r (9), summed over frames by intr_reduce_kernel.
+// The products themselves are formed by the evaluation kernel (kernels_eval.hip): every wave leaves the 16 x 16
+// blocks on and below the diagonal of G = [Ji | Jc | r]^T [Ji | Jc | r] per frame it touches.  Here one workgroup
+// per frame sums its waves' partials in wave order (fixed order: deterministic) and files the entries of G.
 // ---------------------------------------------------------------------------------------------
-template <int CD>
-__global__ __launch_bounds__(256) void camera_blocks_kernel(const DeviceProblem dp, const SolverDev sv) {
-  constexpr int NU = CD * (CD + 1) / 2, NE = NU + CD;
-  __shared__ double s_red[4][NE];
-  const int f = blockIdx.x, tid = threadIdx.x;
-  const int K = dp.K, off_pose = K - 3 - CD;
-  const int64_t s = sv.frame_ptr[f], e = sv.frame_ptr[f + 1];
-  double acc[NE];
-#pragma unroll
-  for (int k = 0; k < NE; ++k) acc[k] = 0.0;
-  for (int64_t i = s + tid; i < e; i += 256) {
-    const double* jt = dp.jac + (size_t)(i >> 8) * (2 * K * kEvalBlock) + (i & 255);
-    const double* rt = dp.res + (size_t)(i >> 8) * (2 * kEvalBlock) + (i & 255);
-    double j0[CD], j1[CD];
-#pragma unroll
-    for (int c = 0; c < CD; ++c) { j0[c] = jt[(off_pose + c) * kEvalBlock]; j1[c] = jt[(K + off_pose + c) * kEvalBlock]; }
-    const double r0 = rt[0], r1 = rt[kEvalBlock];
-    int idx = 0;
-#pragma unroll
-    for (int a = 0; a < CD; ++a)
-#pragma unroll
-      for (int b = a; b < CD; ++b) { acc[idx] += j0[a] * j0[b] + j1[a] * j1[b]; ++idx; }
-#pragma unroll
-    for (int a = 0; a < CD; ++a) acc[NU + a] += j0[a] * r0 + j1[a] * r1;
-  }
-#pragma unroll
-  for (int k = 0; k < NE; ++k) {
-    const double v = wsum(acc[k]);
-    if ((tid & 63) == 0) s_red[tid >> 6][k] = v;
-  }
-  __syncthreads();
-  if (tid < NE) {
-    const double v = s_red[0][tid] + s_red[1][tid] + s_red[2][tid] + s_red[3][tid];
-    if (tid >= NU) sv.gc[(size_t)f * CD + (tid - NU)] = v;
-    else {
-      // unpack the upper-triangular index
-      int a = 0, rem = tid;
-      while (rem >= CD - a) { rem -= CD - a; ++a; }
-      const int b = a + rem;
-      sv.U[((size_t)f * CD + a) * CD + b] = v;
-      sv.U[((size_t)f * CD + b) * CD + a] = v;
-    }
-  }
-}
-
-// K2a, calibrated problems: the evaluation kernel has left one 16 x 16 partial [Jc | r]^T [Jc | r] per (wave, frame)
-// (kernels_eval.hip); one workgroup per frame sums its waves' partials in wave order (fixed order: deterministic).
-template <int CD>
+template <int CD, bool CAL>
 __global__ __launch_bounds__(256) void camera_reduce_kernel(const DeviceProblem dp, const SolverDev sv) {
-  const int f = blockIdx.x, e = threadIdx.x, row = e >> 4, col = e & 15;
+  constexpr int NI = CAL ? 0 : 9, NCOL = NI + CD + 1, NCB = (NCOL + 15) / 16, NBLK = NCB * (NCB + 1) / 2;
+  __shared__ double G[NBLK][256];
+  const int f = blockIdx.x, e = threadIdx.x;
   const int64_t s0 = sv.frame_ptr[f], s1 = sv.frame_ptr[f + 1];
-  double sum = 0.0;
+  double sum[NBLK];
+#pragma unroll
+  for (int q = 0; q < NBLK; ++q) sum[q] = 0.0;
   if (s1 > s0) {
     const int rk = dp.frame_rank[f];
     for (int64_t w = s0 >> 6; w <= (s1 - 1) >> 6; ++w) {
       const int seg = dp.wave_seg_base[w] + rk - dp.frame_rank[dp.obs_frame[w << 6]];
-      sum += dp.cam_part[(size_t)seg * 256 + e];
+#pragma unroll
+      for (int q = 0; q < NBLK; ++q) sum[q] += dp.cam_part[((size_t)seg * NBLK + q) * 256 + e];
     }
   }
-  if (row < CD && col < CD) sv.U[((size_t)f * CD + row) * CD + col] = sum;
-  if (row < CD && col == CD) sv.gc[(size_t)f * CD + row] = sum;
-}
-
-// ---------------------------------------------------------------------------------------------
-// K2a' intrinsics as a parameter block: the J^T J blocks that are NOT block-diagonal.
-//   cross: U[F+v][f] rows = intrinsics coordinates of pseudo frame v, cols = pose coordinates of frame f
-//   self : per-frame partials of Ji^T Ji (45 unique) and Ji^T r (9), summed over frames in order
-// Same register-accumulate + fixed-order reduction scheme as camera_blocks_kernel; the 9 x CD cross block
-// is produced NR intrinsics rows at a time to stay inside the register file.
-// ---------------------------------------------------------------------------------------------
-template <int CD, int R0, int NR>
-__global__ __launch_bounds__(256) void intr_cross_kernel(const DeviceProblem dp, const SolverDev sv) {
-  constexpr int NE = NR * CD;
-  __shared__ double s_red[4][NE];
-  const int f = blockIdx.x, tid = threadIdx.x;
-  const int K = dp.K;
-  const int64_t s = sv.frame_ptr[f], e = sv.frame_ptr[f + 1];
-  double acc[NE];
 #pragma unroll
-  for (int k = 0; k < NE; ++k) acc[k] = 0.0;
-  for (int64_t i = s + tid; i < e; i += 256) {
-    const double* jt = dp.jac + (size_t)(i >> 8) * (2 * K * kEvalBlock) + (i & 255);
-    double i0[NR], i1[NR], c0[CD], c1[CD];
-#pragma unroll
-    for (int k = 0; k < NR; ++k) { i0[k] = jt[(R0 + k) * kEvalBlock]; i1[k] = jt[(K + R0 + k) * kEvalBlock]; }
-#pragma unroll
-    for (int c = 0; c < CD; ++c) { c0[c] = jt[(9 + c) * kEvalBlock]; c1[c] = jt[(K + 9 + c) * kEvalBlock]; }
-#pragma unroll
-    for (int k = 0; k < NR; ++k)
-#pragma unroll
-      for (int c = 0; c < CD; ++c) acc[k * CD + c] += i0[k] * c0[c] + i1[k] * c1[c];
-  }
-#pragma unroll
-  for (int k = 0; k < NE; ++k) {
-    const double v = wsum(acc[k]);
-    if ((tid & 63) == 0) s_red[tid >> 6][k] = v;
-  }
+  for (int q = 0; q < NBLK; ++q) G[q][e] = sum[q];
   __syncthreads();
-  if (tid < NE) {
-    const int kk = R0 + tid / CD, c = tid % CD;
-    sv.U[u_cross_off(sv, kk / CD, f) + (size_t)(kk % CD) * CD + c] = s_red[0][tid] + s_red[1][tid] + s_red[2][tid] + s_red[3][tid];
+  auto g = [&](int a, int b) {   // entry (a, b) of the symmetric G
+    if (a < b) { const int t = a; a = b; b = t; }
+    const int qa = a >> 4, qb = b >> 4;
+    return G[qa * (qa + 1) / 2 + qb][(a & 15) * 16 + (b & 15)];
+  };
+  for (int idx = e; idx < CD * CD; idx += 256) sv.U[(size_t)f * CD * CD + idx] = g(NI + idx / CD, NI + idx % CD);
+  if (e < CD) sv.gc[(size_t)f * CD + e] = g(NI + CD, NI + e);
+  if (!CAL) {
+    for (int idx = e; idx < 9 * CD; idx += 256) {
+      const int kk = idx / CD, c = idx % CD;
+      sv.U[u_cross_off(sv, kk / CD, f) + (size_t)(kk % CD) * CD + c] = g(NI + c, kk);
+    }
+    if (e < 54) {
+      double v;
+      if (e >= 45) v = g(NI + CD, e - 45);
+      else { int a = 0, rem = e; while (rem >= 9 - a) { rem -= 9 - a; ++a; } v = g(a + rem, a); }
+      sv.intr_part[(size_t)f * 54 + e] = v;
+    }
   }
-}
-
-__global__ __launch_bounds__(256) void intr_self_kernel(const DeviceProblem dp, const SolverDev sv) {
-  constexpr int NE = 45 + 9;
-  __shared__ double s_red[4][NE];
-  const int f = blockIdx.x, tid = threadIdx.x;
-  const int K = dp.K;
-  const int64_t s = sv.frame_ptr[f], e = sv.frame_ptr[f + 1];
-  double acc[NE];
-#pragma unroll
-  for (int k = 0; k < NE; ++k) acc[k] = 0.0;
-  for (int64_t i = s + tid; i < e; i += 256) {
-    const double* jt = dp.jac + (size_t)(i >> 8) * (2 * K * kEvalBlock) + (i & 255);
-    const double* rt = dp.res + (size_t)(i >> 8) * (2 * kEvalBlock) + (i & 255);
-    double i0[9], i1[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) { i0[k] = jt[k * kEvalBlock]; i1[k] = jt[(K + k) * kEvalBlock]; }
-    const double r0 = rt[0], r1 = rt[kEvalBlock];
-    int idx = 0;
-#pragma unroll
-    for (int a = 0; a < 9; ++a)
-#pragma unroll
-      for (int b = a; b < 9; ++b) { acc[idx] += i0[a] * i0[b] + i1[a] * i1[b]; ++idx; }
-#pragma unroll
-    for (int a = 0; a < 9; ++a) acc[45 + a] += i0[a] * r0 + i1[a] * r1;
-  }
-#pragma unroll
-  for (int k = 0; k < NE; ++k) {
-    const double v = wsum(acc[k]);
-    if ((tid & 63) == 0) s_red[tid >> 6][k] = v;
-  }
-  __syncthreads();
-  if (tid < NE) sv.intr_part[(size_t)f * NE + tid] = s_red[0][tid] + s_red[1][tid] + s_red[2][tid] + s_red[3][tid];
 }
 
 // one workgroup per entry t of the 45 + 9 sums: lanes stride the frames, fixed-order wave / workgroup reduction
@@ -772,13 +680,21 @@ inline int nblocks256(int64_t n) { return (int)((n + 255) / 256); }
   } while (0)
 
 hipError_t launch_camera_blocks(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {
-  if (dp.cam_part) {   // calibrated: the blocks were formed by the evaluation kernel, only the per-frame sums are left
-    if (sv.CD == 12) LAUNCH(camera_reduce_kernel<12>, dp.F, 256, st, dp, sv);
-    else LAUNCH(camera_reduce_kernel<6>, dp.F, 256, st, dp, sv);
-    return hipSuccess;
+  const size_t CD2 = (size_t)sv.CD * sv.CD;
+  if (sv.NPF > 0) {   // the padding coordinates of the pseudo frames stay zero
+    hipError_t e = hipMemsetAsync(sv.U + (size_t)sv.F * CD2, 0, ((size_t)sv.NPF * sv.F + (size_t)sv.NPF * sv.NPF) * CD2 * sizeof(double), st);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(sv.gc + (size_t)sv.F * sv.CD, 0, (size_t)sv.NPF * sv.CD * sizeof(double), st);
+    if (e != hipSuccess) return e;
   }
-  if (sv.CD == 12) LAUNCH(camera_blocks_kernel<12>, dp.F, 256, st, dp, sv);
-  else LAUNCH(camera_blocks_kernel<6>, dp.F, 256, st, dp, sv);
+  if (!dp.cam_part) {   // no observations on this rank: nothing was accumulated
+    hipError_t e = hipMemsetAsync(sv.U, 0, (size_t)sv.F * CD2 * sizeof(double), st);
+    if (e == hipSuccess) e = hipMemsetAsync(sv.gc, 0, (size_t)sv.F * sv.CD * sizeof(double), st);
+    if (e == hipSuccess && sv.NPF > 0) e = hipMemsetAsync(sv.intr_part, 0, (size_t)sv.F * 54 * sizeof(double), st);
+    return e;
+  }
+  if (sv.CD == 12) { if (dp.calibrated) LAUNCH((camera_reduce_kernel<12, true>), dp.F, 256, st, dp, sv); else LAUNCH((camera_reduce_kernel<12, false>), dp.F, 256, st, dp, sv); }
+  else { if (dp.calibrated) LAUNCH((camera_reduce_kernel<6, true>), dp.F, 256, st, dp, sv); else LAUNCH((camera_reduce_kernel<6, false>), dp.F, 256, st, dp, sv); }
   return hipSuccess;
 }
 hipError_t launch_point_blocks(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {
@@ -838,21 +754,9 @@ hipError_t launch_project(const DeviceProblem& dp, const SolverDev& sv, hipStrea
   if (sv.CD == 6 && KC == 15) return launch_project_as<6, 15>(dp, sv, st);
   return hipErrorInvalidValue;
 }
-// intrinsics as a parameter block: border blocks of J^T J and the intrinsics gradient
+// intrinsics as a parameter block: the self block and the intrinsics gradient, summed over the frames
 hipError_t launch_intr_blocks(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {
   if (sv.NPF == 0) return hipSuccess;
-  const size_t CD2 = (size_t)sv.CD * sv.CD;
-  hipError_t e = hipMemsetAsync(sv.U + (size_t)sv.F * CD2, 0, ((size_t)sv.NPF * sv.F + (size_t)sv.NPF * sv.NPF) * CD2 * sizeof(double), st);
-  if (e != hipSuccess) return e;
-  e = hipMemsetAsync(sv.gc + (size_t)sv.F * sv.CD, 0, (size_t)sv.NPF * sv.CD * sizeof(double), st);
-  if (e != hipSuccess) return e;
-  if (sv.CD == 12) {
-    LAUNCH((intr_cross_kernel<12, 0, 5>), dp.F, 256, st, dp, sv);
-    LAUNCH((intr_cross_kernel<12, 5, 4>), dp.F, 256, st, dp, sv);
-  } else {
-    LAUNCH((intr_cross_kernel<6, 0, 9>), dp.F, 256, st, dp, sv);
-  }
-  LAUNCH(intr_self_kernel, dp.F, 256, st, dp, sv);
   LAUNCH(intr_reduce_kernel, 54, 256, st, dp, sv);
   return hipSuccess;
 }

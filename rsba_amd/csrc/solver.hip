@@ -508,8 +508,9 @@ int32_t build_solver(rsba_handle* h) {
   const size_t REC = 2 + 2 * (size_t)dp.K;
   if ((rc = s_alloc(s, &h->dp.rec, (size_t)N * REC))) return rc;
   h->dp.obs_slot = s->d_obs_slot;
-  if (dp.calibrated && N > 0) {
-    // camera blocks inside the evaluation kernel: one 16 x 16 partial per (64-observation wave, frame it touches)
+  if (N > 0) {
+    // camera (and intrinsics border) blocks inside the evaluation kernel: per (64-observation wave, frame it touches)
+    // the 16 x 16 blocks on and below the diagonal of [Ji | Jc | r]^T [Ji | Jc | r]
     const int64_t nwaves = (int64_t)eval_num_blocks(N) * (kEvalBlock / 64);
     std::vector<int32_t> wave_seg_base((size_t)nwaves + 1, 0), frame_rank(F, 0);
     { int rk = 0; for (int f = 0; f < F; ++f) { frame_rank[f] = rk; if (frame_ptr[f + 1] > frame_ptr[f]) ++rk; } }
@@ -520,7 +521,8 @@ int32_t build_solver(rsba_handle* h) {
     int32_t *d_base = nullptr, *d_rank = nullptr;
     if ((rc = s_upload(s, &d_base, wave_seg_base))) return rc;
     if ((rc = s_upload(s, &d_rank, frame_rank))) return rc;
-    if ((rc = s_alloc(s, &h->dp.cam_part, (size_t)std::max(wave_seg_base[nwaves], 1) * 256))) return rc;
+    const int ncb = ((dp.K - 3) + 1 + 15) / 16, nblk = ncb * (ncb + 1) / 2;
+    if ((rc = s_alloc(s, &h->dp.cam_part, (size_t)std::max(wave_seg_base[nwaves], 1) * nblk * 256))) return rc;
     h->dp.wave_seg_base = d_base; h->dp.frame_rank = d_rank;
   }
   if ((rc = s_alloc(s, &sv.U, ((size_t)FR + (size_t)NPF * FR + (size_t)NPF * NPF) * CD * CD))) return rc;
