@@ -159,32 +159,26 @@ struct Acc {
 // per column, the forward and the backward substitution) into a product without a serial chain.
 // Two drivers run the same task bodies:
 //   * chol_dag_kernel — ONE persistent launch per solve.  Workgroups draw tickets from a global counter over the
-//     topologically sorted task list and wait on per-tile "done" flags (agent-scope release/acquire) instead of
-//     kernel boundaries.  A claimed task only waits for tasks with smaller tickets, which are claimed by running
-//     workgroups, so progress never depends on how many workgroups are resident.
-//   * chol_level_kernel — one launch per (level, kind), no flags: the reference schedule the DAG driver is
-//     tested against (RSBA_CHOL_LEVELS=1).
+//     topologically sorted task list.  A claimed task only waits for tasks with smaller tickets, which are claimed by
+//     running workgroups, so progress never depends on how many workgroups are resident.  There are no flags:
+//     everything a task hands to another one (factor tiles, partial tiles, W, z, y) is a WRITE-ONCE CELL — its
+//     array is filled with an "empty" bit pattern before the launch, a producer stores each double exactly once,
+//     and a consumer that reads "empty" simply reads again.  Waiting for a tile therefore costs one memory
+//     round trip after it lands (the data is its own flag) instead of a flag round trip plus a data round trip,
+//     and a producer has nothing to wait for before it moves on: measured 9 us less per level of the dependency
+//     chain than release / flag / acquire hand-offs.
+//   * chol_level_kernel — one launch per (level, kind), no waiting at all: the reference schedule the DAG driver is
+//     tested against bit for bit (RSBA_CHOL_LEVELS=1).
 
 __shared__ long long* s_trace_slot;   // RSBA_CHOL_TRACE: where the running task logs its time stamps (null = off)
 #define CHOL_STAMP(k) do { if (DAG && tid == 0 && s_trace_slot) s_trace_slot[k] = wall_clock64(); } while (0)
 
-// Cross-workgroup data of the DAG driver (tiles, partial tiles, W, z, y) moves through agent-coherent accesses:
-// relaxed agent-scope atomic loads / stores of the individual doubles, which gfx950 issues with sc1 (L2 of the
-// other XCDs is not coherent with ours; sc1 accesses go to the memory side).  Ordering against the "done" flag is
-// then a matter of completion, not of cache maintenance: a producer waits for its stores (s_waitcnt, workgroup
-// fence + barrier) before raising the flag, a consumer issues its loads after it has seen the flag.  That saves
-// the L2 write-back (buffer_wbl2) of an agent-scope release and the invalidate (buffer_inv) of an acquire on every
-// link of the dependency chain — measured 0.44 ms of 1.75 ms at 1k cameras.  -DRSBA_FORMAL_FENCES restores the
-// plain loads / stores with agent-scope fences (same results, checked by tests/test_gpu_solve.py).
-#ifdef RSBA_FORMAL_FENCES
-#define RSBA_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
-#define RSBA_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
-template <bool DAG> __device__ __forceinline__ double ld(const double* p) { return *p; }
-template <bool DAG> __device__ __forceinline__ void st(double* p, double v) { *p = v; }
-#else
-#define RSBA_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup")
-// every wave drains its own stores (vmcnt counts a store until the coherence point of its scope has taken it)
-#define RSBA_RELEASE() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
+// Write-once cells.  "Empty" is all ones — what hipMemset(0xFF) leaves; as a double it is a NaN with a payload that
+// no arithmetic produces (a failed factorisation yields the canonical NaN, which counts as data: no task can hang).
+// Cells move through agent-coherent accesses: relaxed agent-scope atomic loads / stores of the individual doubles,
+// which gfx950 issues with sc1 (the L2 of the other XCDs is not coherent with ours; sc1 accesses go to the memory
+// side), so neither side needs cache maintenance.  The level driver (DAG = false) uses plain loads and stores.
+__device__ __forceinline__ bool filled(double v) { return __double_as_longlong(v) != -1ll; }
 template <bool DAG> __device__ __forceinline__ double ld(const double* p) {
   if (DAG) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return *p;
@@ -193,56 +187,18 @@ template <bool DAG> __device__ __forceinline__ void st(double* p, double v) {
   if (DAG) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   else *p = v;
 }
-#endif
-
-__device__ __forceinline__ int flag_set(const CholPlan& pl, int index) {
-  return __hip_atomic_load(pl.flags + index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// In-order readiness of a task's inputs: items [.., upto) are finished and acquired.  A refresh reads the flags of
-// the next 64 items at once — lane l those of item upto + l, so the whole window costs ONE memory round trip
-// (a flag read is an L2-bypassing load of ~1.5 us; read one after the other they, not the tile products, were
-// the critical path) — and advances upto over the leading finished ones behind a single acquire fence.
-// Every lane of the calling wave takes part; waves do not synchronise here.
-template <bool DAG, class F>
-struct Ready {
-  const CholPlan& pl; F ok; int upto, end;
-  __device__ __forceinline__ Ready(const CholPlan& p, int begin, int e, F f) : pl(p), ok(f), upto(begin), end(e) {}
-  __device__ __forceinline__ void refresh() {
-    const int item = upto + (int)(threadIdx.x & 63);
-    const bool mine = item < end ? ok(item) != 0 : false;
-    const unsigned long long mask = __ballot(mine);
-    const int n = mask == ~0ull ? 64 : __builtin_ctzll(~mask);
-    if (n > 0) { RSBA_ACQUIRE(); upto += n; }
-  }
-  // non-blocking: true if item p is finished
-  __device__ __forceinline__ bool poll(int p) {
-    if (!DAG || p < upto) return true;
-    refresh();
-    return p < upto;
-  }
-  __device__ __forceinline__ void need(int p) {
-    if (!DAG || p < upto) return;
-    bool spun = false;
-    for (;;) {
-      refresh();
-      if (p < upto) break;
-      __builtin_amdgcn_s_sleep(1);
-      spun = true;
-    }
-    if (spun && threadIdx.x == 0 && s_trace_slot) { s_trace_slot[2] = wall_clock64(); s_trace_slot[6] = (long long)(end - p); }   // when the last late input arrived, and how much was left
-  }
-};
-template <bool DAG, class F>
-__device__ __forceinline__ Ready<DAG, F> make_ready(const CholPlan& pl, int begin, int end, F f) { return Ready<DAG, F>(pl, begin, end, f); }
-
+// Waiting costs memory traffic: a task that found a group of cells incomplete does not keep re-reading the whole group
+// (hundreds of claimed-but-waiting tasks doing that saturate the memory system) — it watches ONE cell of the
+// missing input, with a pause between looks, and reads the group again once that cell has landed.
 template <bool DAG>
-__device__ __forceinline__ void dag_publish(const CholPlan& pl, int index, int tid) {
+__device__ __forceinline__ void watch_cell(const double* p) {
   if (!DAG) return;
-  RSBA_RELEASE();   // every wave's stores are written back before the barrier
-  __syncthreads();
-  if (tid == 0) __hip_atomic_store(pl.flags + index, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  while (!filled(ld<true>(p))) __builtin_amdgcn_s_sleep(8);
 }
+// a waiting task marks when its last late input arrived (RSBA_CHOL_TRACE)
+__device__ __forceinline__ void note_late_input() { if (threadIdx.x == 0 && s_trace_slot) s_trace_slot[2] = wall_clock64(); }
+
+__device__ __forceinline__ double* factor_ptr(const SolverDev& sv, int slot) { return sv.Lf + (size_t)slot * (T * T); }
 
 // LDS map (doubles): four partial-tile buffers, then small vectors
 constexpr int kBuf = T * TP;
@@ -265,12 +221,11 @@ template <bool DAG, bool DIAG>
 __device__ __forceinline__ void accumulate(const SolverDev& sv, const CholPlan& pl, const int32_t* list, int p0, int p1, Acc& acc, double bz[3],
                                            int wave, int lane) {
   if (p0 >= p1) return;
-  auto ready = make_ready<DAG>(pl, p0, p1, [&](int p) { return DIAG ? flag_set(pl, list[2 * p]) : (flag_set(pl, list[2 * p]) & flag_set(pl, list[2 * p + 1])); });
-  // Operands travel in groups of kGroup contributors, one group ahead of the MFMAs: the HBM/L2 round trip of a
-  // tile (~2 us behind an acquire) is several times the 0.7 us its product takes.  Loads are issued in straight
-  // lines (the tail of the list re-reads its last contributor rather than branch) and the two schedules —
-  // "next group is finished: fetch it, then multiply" / "multiply, then wait for it" — are separate code paths, so
-  // that the compiler's s_waitcnt placement can count the loads in flight instead of draining them at a join.
+  // Operands travel in groups of kGroup contributors, one group ahead of the MFMAs: the HBM round trip of a tile
+  // (~2 us) is several times the 0.7 us its product takes.  Loads are issued in straight lines (the tail of the list
+  // re-reads its last contributor rather than branch).  The prefetch is speculative — a tile that has not been
+  // produced yet reads as empty cells — and a group is checked when it is about to be multiplied: a wave whose
+  // share of it is incomplete reads it again until it is.
   constexpr int kGroup = 2;
   struct Group { Frag a[kGroup], b[kGroup]; double z[kGroup][3]; };
   Group cur, nxt;
@@ -278,13 +233,25 @@ __device__ __forceinline__ void accumulate(const SolverDev& sv, const CholPlan& 
 #pragma unroll
     for (int u = 0; u < kGroup; ++u) {
       const int q = min(p + u, p1 - 1);
-      g.a[u].template load<DAG>(tile_ptr(sv, list[2 * q]), wave, lane);
-      if (!DIAG) g.b[u].template load<DAG>(tile_ptr(sv, list[2 * q + 1]), wave, lane);
+      g.a[u].template load<DAG>(factor_ptr(sv, list[2 * q]), wave, lane);
+      if (!DIAG) g.b[u].template load<DAG>(factor_ptr(sv, list[2 * q + 1]), wave, lane);
       else {
-        const double* zk = sv.rhs + (size_t)list[2 * q + 1] * T + 12 * wave + 3 * (lane >> 4);
+        const double* zk = sv.zv + (size_t)list[2 * q + 1] * T + 12 * wave + 3 * (lane >> 4);
         g.z[u][0] = ld<DAG>(zk); g.z[u][1] = ld<DAG>(zk + 1); g.z[u][2] = ld<DAG>(zk + 2);
       }
     }
+  };
+  auto complete = [&](const Group& g) {
+    bool ok = true;
+#pragma unroll
+    for (int u = 0; u < kGroup; ++u) {
+#pragma unroll
+      for (int I = 0; I < 3; ++I)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) { ok = ok && filled(g.a[u].v[I][t]); if (!DIAG) ok = ok && filled(g.b[u].v[I][t]); }
+      if (DIAG) ok = ok && filled(g.z[u][0]) && filled(g.z[u][1]) && filled(g.z[u][2]);
+    }
+    return __ballot(!ok) == 0ull;
   };
   auto mac_group = [&](const Group& g, int p) {
 #pragma unroll
@@ -302,21 +269,24 @@ __device__ __forceinline__ void accumulate(const SolverDev& sv, const CholPlan& 
       }
     }
   };
-  auto group_poll = [&](int p) { return ready.poll(min(p + kGroup, p1) - 1); };   // in order: the last one covers the group
-  auto group_need = [&](int p) { ready.need(min(p + kGroup, p1) - 1); };
-  group_need(p0);
-  if (DAG && threadIdx.x == 0 && s_trace_slot) s_trace_slot[5] = wall_clock64();
   fetch_group(cur, p0);
   for (int p = p0; p < p1; p += kGroup) {
     const int pn = p + kGroup;
-    if (pn < p1) {
-      if (group_poll(pn)) { fetch_group(nxt, pn); mac_group(cur, p); }
-      else { mac_group(cur, p); group_need(pn); fetch_group(nxt, pn); }
-      cur = nxt;
-    } else {
-      if (DAG && threadIdx.x == 0 && s_trace_slot) { asm volatile("s_waitcnt vmcnt(0)"); s_trace_slot[6] = wall_clock64(); }
-      mac_group(cur, p);
+    if (pn < p1) fetch_group(nxt, pn);
+    if (DAG) {
+      bool late = false;
+      while (!complete(cur)) {
+        // the list is in the order the contributors finish: watch the last one of the group
+        const int q = min(p + kGroup, p1) - 1;
+        watch_cell<DAG>(factor_ptr(sv, list[2 * q]) + 12 * wave);
+        if (!DIAG) watch_cell<DAG>(factor_ptr(sv, list[2 * q + 1]) + 12 * wave);
+        fetch_group(cur, p);
+        late = true;
+      }
+      if (late) note_late_input();
     }
+    mac_group(cur, p);
+    if (pn < p1) cur = nxt;
   }
 }
 
@@ -351,7 +321,44 @@ __device__ __forceinline__ void task_update(const SolverDev& sv, const CholPlan&
   }
   if (diag && tid < T) { const double* v = smem + kVecOff; st<DAG>(out + T * T + tid, (v[tid] + v[T + tid]) + (v[2 * T + tid] + v[3 * T + tid])); }
   CHOL_STAMP(4);
-  dag_publish<DAG>(pl, pl.nslots + u[3], tid);
+}
+
+// the partial tiles (and, WITH_B, rhs partials) of UPDATE tasks, four at a time: each thread re-reads its own nine
+// cells of a partial until they are all there
+template <bool DAG, bool WITH_B>
+__device__ __forceinline__ void subtract_partials(const SolverDev& sv, int part0, int nparts, double sreg[9], double& breg, int tid) {
+  for (int c0 = 0; c0 < nparts; c0 += 4) {
+    double pv[4][9], pb[4] = {0.0, 0.0, 0.0, 0.0};
+    bool late = false;
+    for (;;) {
+      bool ok = true;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double* part = sv.chol_part + (size_t)(part0 + min(c0 + u, nparts - 1)) * (T * T + T);
+#pragma unroll
+        for (int q = 0; q < 9; ++q) pv[u][q] = ld<DAG>(part + tid + 256 * q);
+        if (WITH_B && tid < T) pb[u] = ld<DAG>(part + T * T + tid);
+      }
+      if (!DAG) break;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) ok = ok && filled(pv[u][q]);
+        ok = ok && filled(pb[u]);
+      }
+      if (ok) break;
+      late = true;
+      watch_cell<DAG>(sv.chol_part + (size_t)(part0 + min(c0 + 3, nparts - 1)) * (T * T + T) + tid);
+    }
+    if (late) note_late_input();
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (c0 + u < nparts) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) sreg[q] -= pv[u][q];
+        breg -= pb[u];
+      }
+  }
 }
 
 // W = L^-1 for the factored lower-triangular tile L in LDS (pitch TP), into Wl (pitch TP; blocks above the
@@ -426,27 +433,8 @@ __device__ __forceinline__ void task_diag(const SolverDev& sv, const CholPlan& p
 #pragma unroll
   for (int q = 0; q < 9; ++q) sreg[q] = src[tid + 256 * q];
   double breg = tid < T ? sv.rhs[(size_t)tile_j * T + tid] : 0.0;
-  if (nparts > 0) {   // the early part of a long contributor list arrives pre-reduced (UPDATE tasks), well before the owner's own share
-    auto ready = make_ready<DAG>(pl, 0, nparts, [&](int c) { return flag_set(pl, pl.nslots + part0 + c); });
-    ready.need(nparts - 1);
-    for (int c0 = 0; c0 < nparts; c0 += 4) {   // four partials' loads in flight together
-      double pv[4][9], pb[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const double* part = sv.chol_part + (size_t)(part0 + min(c0 + u, nparts - 1)) * (T * T + T);
-#pragma unroll
-        for (int q = 0; q < 9; ++q) pv[u][q] = ld<DAG>(part + tid + 256 * q);
-        pb[u] = tid < T ? ld<DAG>(part + T * T + tid) : 0.0;
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (c0 + u < nparts) {
-#pragma unroll
-          for (int q = 0; q < 9; ++q) sreg[q] -= pv[u][q];
-          breg -= pb[u];
-        }
-    }
-  }
+  // the early part of a long contributor list arrives pre-reduced (UPDATE tasks), well before the owner's own share
+  subtract_partials<DAG, true>(sv, part0, nparts, sreg, breg, tid);
   Acc acc; acc.clear();
   double bz[3] = {0, 0, 0};
   accumulate<DAG, true>(sv, pl, pl.diag_list, p0, p1, acc, bz, wave, lane);
@@ -473,10 +461,7 @@ __device__ __forceinline__ void task_diag(const SolverDev& sv, const CholPlan& p
   __syncthreads();
   CHOL_STAMP(5);
   if (!*s_okp && tid == 0) atomicExch(sv.chol_fail, 1);
-  {
-    double* out = tile_ptr(sv, slot_jj);   // L_jj itself is only kept for inspection: everything downstream uses W_j
-    for (int e = tid; e < T * T; e += 256) { const int r = e / T, c = e % T; st<DAG>(out + e, (c <= r) ? D[r * TP + c] : 0.0); }
-  }
+  (void)slot_jj;   // L_jj itself is not stored: everything downstream uses W_j
   invert_lower_blocked(D, dinv, Wl, smem + 2 * kBuf, tid);
   CHOL_STAMP(6);
   double* wout = sv.Winv + (size_t)tile_j * (T * T);
@@ -485,9 +470,8 @@ __device__ __forceinline__ void task_diag(const SolverDev& sv, const CholPlan& p
     double s0 = 0.0, s1 = 0.0;
 #pragma unroll 8
     for (int m = 0; m < T; m += 2) { if (m <= tid) s0 += Wl[tid * TP + m] * bvec[m]; if (m + 1 <= tid) s1 += Wl[tid * TP + m + 1] * bvec[m + 1]; }
-    st<DAG>(sv.rhs + (size_t)tile_j * T + tid, s0 + s1);
+    st<DAG>(sv.zv + (size_t)tile_j * T + tid, s0 + s1);
   }
-  dag_publish<DAG>(pl, slot_jj, tid);
 }
 
 template <bool DAG>
@@ -501,25 +485,7 @@ __device__ __forceinline__ void task_sub(const SolverDev& sv, const CholPlan& pl
   const double* src = tile_ptr(sv, slot_ij);
 #pragma unroll
   for (int q = 0; q < 9; ++q) sreg[q] = src[tid + 256 * q];
-  if (nparts > 0) {
-    auto ready = make_ready<DAG>(pl, 0, nparts, [&](int c) { return flag_set(pl, pl.nslots + part0 + c); });
-    ready.need(nparts - 1);
-    for (int c0 = 0; c0 < nparts; c0 += 4) {
-      double pv[4][9];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const double* part = sv.chol_part + (size_t)(part0 + min(c0 + u, nparts - 1)) * (T * T + T);
-#pragma unroll
-        for (int q = 0; q < 9; ++q) pv[u][q] = ld<DAG>(part + tid + 256 * q);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (c0 + u < nparts) {
-#pragma unroll
-          for (int q = 0; q < 9; ++q) sreg[q] -= pv[u][q];
-        }
-    }
-  }
+  { double none = 0.0; subtract_partials<DAG, false>(sv, part0, nparts, sreg, none, tid); }
   Acc acc; acc.clear();
   double bz[3] = {0, 0, 0};
   accumulate<DAG, false>(sv, pl, pl.sub_list, p0, p1, acc, bz, wave, lane);
@@ -535,19 +501,27 @@ __device__ __forceinline__ void task_sub(const SolverDev& sv, const CholPlan& pl
 #pragma unroll
   for (int q = 0; q < 9; ++q) { const int e = tid + 256 * q; X[(e / T) * TP + e % T] = sreg[q]; }
   CHOL_STAMP(4);
-  { auto ready = make_ready<DAG>(pl, 0, 1, [&](int) { return flag_set(pl, slot_jj); }); ready.need(0); }   // W_j, from the DIAG task of this column
   __syncthreads();
   CHOL_STAMP(5);
-  // L_ij = X W^T: wave I forms row block I; W is lower triangular, so column block J only needs k < 16 (J + 1)
+  // L_ij = X W_j^T: wave I forms row block I; W is lower triangular, so column block J only needs k < 16 (J + 1).
+  // W_j comes from the DIAG task of this column: its cells are read until they are all there.
   if (wave < 3) {
     const int I = wave, r = lane & 15, g = lane >> 4;
     const double* Wg = sv.Winv + (size_t)tile_j * (T * T);
-    double* out = tile_ptr(sv, slot_ij);
+    double* out = factor_ptr(sv, slot_ij);
     double wv[3][12];   // B operand: W[16J + r][4kk + g]
+    bool late = false;
+    for (;;) {
+      bool ok = true;
 #pragma unroll
-    for (int J = 0; J < 3; ++J)
+      for (int J = 0; J < 3; ++J)
 #pragma unroll
-      for (int kk = 0; kk < 4 * (J + 1); ++kk) wv[J][kk] = ld<DAG>(Wg + (16 * J + r) * T + 4 * kk + g);
+        for (int kk = 0; kk < 4 * (J + 1); ++kk) { wv[J][kk] = ld<DAG>(Wg + (16 * J + r) * T + 4 * kk + g); ok = ok && filled(wv[J][kk]); }
+      if (!DAG || __ballot(!ok) == 0ull) break;
+      late = true;
+      watch_cell<DAG>(Wg + (T * T - 1));   // the corner of the inverse
+    }
+    if (late) note_late_input();
     dbl4 c[3] = {dbl4{0, 0, 0, 0}, dbl4{0, 0, 0, 0}, dbl4{0, 0, 0, 0}};
 #pragma unroll
     for (int kk = 0; kk < 12; ++kk) {
@@ -562,7 +536,7 @@ __device__ __forceinline__ void task_sub(const SolverDev& sv, const CholPlan& pl
       for (int v = 0; v < 4; ++v) st<DAG>(out + (16 * I + g + 4 * v) * T + 16 * J + r, c[J][v]);
   }
   CHOL_STAMP(6);
-  dag_publish<DAG>(pl, slot_ij, tid);
+  (void)slot_jj;
 }
 
 template <bool DAG>
@@ -571,29 +545,46 @@ __device__ __forceinline__ void task_back(const SolverDev& sv, const CholPlan& p
   double* tvec = smem + 10 * T;   // [T]
   const int32_t* list = pl.back_list;
   const int c2 = tid % 24, rg = tid / 24;   // column pair, row group (rg < 10 for tid < 240)
-  const int slot_jj = pl.back_info[2 * b], tile_j = pl.back_info[2 * b + 1];
+  const int tile_j = pl.back_info[2 * b + 1];
   const int p0 = pl.back_ptr[b], p1 = pl.back_ptr[b + 1];
-  const int ybase = pl.nslots + pl.nparts;
-  // rows of a 48 x 48 tile handled by this thread: rg, rg + 10, .. ; columns 2 c2, 2 c2 + 1
+  const bool worker = rg < 10;
+  // rows of a 48 x 48 tile handled by this thread: rg, rg + 10, .. ; columns 2 c2, 2 c2 + 1 (threads without work
+  // read nothing).  Whether the cells were all there is asked where the values are USED (gathered_ok), never next to
+  // the loads: a test there would make the compiler wait for them on the spot and undo the prefetch.
   auto gather = [&](const double* tile, const double* y, double2 v[5], double yy[5], bool LDSY) {
 #pragma unroll
     for (int u = 0; u < 5; ++u) {
       const int r = rg + 10 * u;
-      if (rg < 10 && r < T) { const double* q = tile + (size_t)r * T + 2 * c2; v[u] = make_double2(ld<DAG>(q), ld<DAG>(q + 1)); yy[u] = LDSY ? y[r] : ld<DAG>(y + r); }
-      else { v[u] = make_double2(0.0, 0.0); yy[u] = 0.0; }
+      if (worker && r < T) {
+        const double* q = tile + (size_t)r * T + 2 * c2;
+        v[u] = make_double2(ld<DAG>(q), ld<DAG>(q + 1));
+        yy[u] = LDSY ? y[r] : ld<DAG>(y + r);
+      } else { v[u] = make_double2(0.0, 0.0); yy[u] = 0.0; }
     }
+  };
+  auto gathered_ok = [&](const double2 v[5], const double yy[5]) {
+    bool ok = true;
+#pragma unroll
+    for (int u = 0; u < 5; ++u) ok = ok && filled(v[u].x) && filled(v[u].y) && filled(yy[u]);
+    return ok;
   };
   double s0 = 0.0, s1 = 0.0;
   if (p0 < p1) {
     // L_ij (forward phase) is long finished; y_i is what the task waits for.  The host lists the tiles of the
-    // column bottom-up, the order in which the y_i become available; loads run one group of four tiles ahead.
-    auto ready = make_ready<DAG>(pl, p0, p1, [&](int p) { return flag_set(pl, list[2 * p]) & flag_set(pl, ybase + list[2 * p + 1]); });
-    constexpr int kGroup = 4;
+    // column bottom-up, the order in which the y_i become available; loads run one group of two tiles ahead and a
+    // thread whose cells of a group are not all there yet reads the group again.
+    constexpr int kGroup = 2;
     struct Group { double2 v[kGroup][5]; double yy[kGroup][5]; };
     Group cur, nxt;
     auto fetch_group = [&](Group& g, int p) {
 #pragma unroll
-      for (int u = 0; u < kGroup; ++u) { const int q = min(p + u, p1 - 1); gather(tile_ptr(sv, list[2 * q]), sv.rhs + (size_t)list[2 * q + 1] * T, g.v[u], g.yy[u], false); }
+      for (int u = 0; u < kGroup; ++u) { const int q = min(p + u, p1 - 1); gather(factor_ptr(sv, list[2 * q]), sv.yv + (size_t)list[2 * q + 1] * T, g.v[u], g.yy[u], false); }
+    };
+    auto group_ok = [&](const Group& g) {
+      bool ok = true;
+#pragma unroll
+      for (int u = 0; u < kGroup; ++u) ok = ok && gathered_ok(g.v[u], g.yy[u]);
+      return ok;
     };
     auto mac_group = [&](const Group& g, int p) {
 #pragma unroll
@@ -603,27 +594,29 @@ __device__ __forceinline__ void task_back(const SolverDev& sv, const CholPlan& p
           for (int k = 0; k < 5; ++k) { s0 += g.v[u][k].x * g.yy[u][k]; s1 += g.v[u][k].y * g.yy[u][k]; }
         }
     };
-    auto group_poll = [&](int p) { return ready.poll(min(p + kGroup, p1) - 1); };
-    auto group_need = [&](int p) { ready.need(min(p + kGroup, p1) - 1); };
-    group_need(p0);
     fetch_group(cur, p0);
     for (int p = p0; p < p1; p += kGroup) {
       const int pn = p + kGroup;
-      if (pn < p1) {
-        if (group_poll(pn)) { fetch_group(nxt, pn); mac_group(cur, p); }
-        else { mac_group(cur, p); group_need(pn); fetch_group(nxt, pn); }
-        cur = nxt;
-      } else {
-        mac_group(cur, p);
+      if (pn < p1) fetch_group(nxt, pn);
+      if (DAG) {
+        bool late = false;
+        while (!group_ok(cur)) {
+          watch_cell<DAG>(sv.yv + (size_t)list[2 * (min(p + kGroup, p1) - 1) + 1] * T);   // y of the last tile of the group
+          fetch_group(cur, p);
+          late = true;
+        }
+        if (late) note_late_input();
       }
+      mac_group(cur, p);
+      if (pn < p1) cur = nxt;
     }
   }
-  { auto ready = make_ready<DAG>(pl, 0, 1, [&](int) { return flag_set(pl, slot_jj); }); ready.need(0); }   // z_j and W_j
-  if (rg < 10) { part[rg * T + 2 * c2] = s0; part[rg * T + 2 * c2 + 1] = s1; }
+  if (worker) { part[rg * T + 2 * c2] = s0; part[rg * T + 2 * c2 + 1] = s1; }
   __syncthreads();
   CHOL_STAMP(3);
   if (tid < T) {
-    double t = ld<DAG>(sv.rhs + (size_t)tile_j * T + tid);
+    double t = ld<DAG>(sv.zv + (size_t)tile_j * T + tid);   // z_j, from the DIAG task of this column
+    while (DAG && !filled(t)) { __builtin_amdgcn_s_sleep(8); t = ld<DAG>(sv.zv + (size_t)tile_j * T + tid); }
 #pragma unroll
     for (int g = 0; g < 10; ++g) t -= part[g * T + tid];
     tvec[tid] = t;
@@ -634,21 +627,21 @@ __device__ __forceinline__ void task_back(const SolverDev& sv, const CholPlan& p
     const double* Wg = sv.Winv + (size_t)tile_j * (T * T);
     double2 v[5]; double yy[5];
     gather(Wg, tvec, v, yy, true);
+    while (DAG && !gathered_ok(v, yy)) { __builtin_amdgcn_s_sleep(8); gather(Wg, tvec, v, yy, true); }
     s0 = 0.0; s1 = 0.0;
 #pragma unroll
     for (int u = 0; u < 5; ++u) { s0 += v[u].x * yy[u]; s1 += v[u].y * yy[u]; }
   }
   __syncthreads();
-  if (rg < 10) { part[rg * T + 2 * c2] = s0; part[rg * T + 2 * c2 + 1] = s1; }
+  if (worker) { part[rg * T + 2 * c2] = s0; part[rg * T + 2 * c2 + 1] = s1; }
   __syncthreads();
   if (tid < T) {
     double y = 0.0;
 #pragma unroll
     for (int g = 0; g < 10; ++g) y += part[g * T + tid];
-    st<DAG>(sv.rhs + (size_t)tile_j * T + tid, y);
+    st<DAG>(sv.yv + (size_t)tile_j * T + tid, y);
   }
   CHOL_STAMP(4);
-  dag_publish<DAG>(pl, ybase + tile_j, tid);
 }
 
 template <bool DAG>
@@ -702,8 +695,12 @@ hipError_t launch_chol_dag(const SolverDev& sv, const CholPlan& pl, int workgrou
   if (pl.ntasks <= 0) return hipSuccess;
   hipError_t e = allow_dynamic_lds(chol_dag_kernel, kCholLds * sizeof(double));
   if (e != hipSuccess) return e;
-  // ticket counter and flags sit in one allocation: [ticket (as 4 bytes, padded to 16) | flags]
-  e = hipMemsetAsync(pl.ticket, 0, 16 + sizeof(int32_t) * ((size_t)pl.nslots + pl.nparts + sv.nt), st);
+  e = hipMemsetAsync(pl.ticket, 0, 16, st);
+  // every write-once cell starts out empty (all ones): factor tiles, partial tiles, W, z | y
+  if (e == hipSuccess) e = hipMemsetAsync(sv.Lf, 0xFF, (size_t)sv.nslots * T * T * sizeof(double), st);
+  if (e == hipSuccess) e = hipMemsetAsync(sv.chol_part, 0xFF, (size_t)(pl.nparts > 0 ? pl.nparts : 1) * (T * T + T) * sizeof(double), st);
+  if (e == hipSuccess) e = hipMemsetAsync(sv.Winv, 0xFF, (size_t)sv.nt * T * T * sizeof(double), st);
+  if (e == hipSuccess) e = hipMemsetAsync(sv.zv, 0xFF, 2 * (size_t)sv.npad * sizeof(double), st);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(chol_dag_kernel, dim3(workgroups), dim3(256), kCholLds * sizeof(double), st, sv, pl);
   return hipGetLastError();

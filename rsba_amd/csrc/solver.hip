@@ -39,7 +39,7 @@ struct Solver {
           *d_sub_list = nullptr, *d_sub_col = nullptr, *d_diag_own = nullptr, *d_sub_own = nullptr, *d_back_info = nullptr, *d_back_ptr = nullptr, *d_back_list = nullptr;
   std::vector<int32_t> tasks;                                         // {kind, item} in level order, backward solve last
   int32_t* d_tasks = nullptr;
-  unsigned int* d_dag_sync = nullptr;                                 // [ticket, pad x3 | flags]
+  unsigned int* d_dag_sync = nullptr;                                 // [ticket, pad x3]
   long long* d_trace = nullptr;                                       // RSBA_CHOL_TRACE=<file>: task time stamps of the last factorisation
   CholPlan plan{};
   int dag_workgroups = 0;
@@ -490,7 +490,10 @@ int32_t build_solver(rsba_handle* h) {
   if ((rc = s_upload(s, &s->d_upd, s->upd))) return rc;
   if ((rc = s_alloc(s, &sv.chol_part, (size_t)std::max(parts, 1) * (kTile * kTile + kTile)))) return rc;
   if ((rc = s_upload(s, &s->d_tasks, s->tasks))) return rc;
-  if ((rc = s_alloc(s, &s->d_dag_sync, 4 + (size_t)sv.nslots + parts + nt))) return rc;
+  if ((rc = s_alloc(s, &s->d_dag_sync, 4))) return rc;
+  if ((rc = s_alloc(s, &sv.Lf, (size_t)sv.nslots * kTile * kTile))) return rc;
+  if ((rc = s_alloc(s, &sv.zv, 2 * (size_t)sv.npad))) return rc;
+  sv.yv = sv.zv + sv.npad;
   if ((rc = s_upload(s, &s->d_diag_info, s->diag_info))) return rc;
   if ((rc = s_upload(s, &s->d_diag_ptr, s->diag_ptr))) return rc;
   if ((rc = s_upload(s, &s->d_diag_list, s->diag_list))) return rc;
@@ -559,7 +562,7 @@ int32_t build_solver(rsba_handle* h) {
   pl.sub_info = s->d_sub_info; pl.sub_ptr = s->d_sub_ptr; pl.sub_list = s->d_sub_list; pl.sub_col = s->d_sub_col; pl.diag_own = s->d_diag_own; pl.sub_own = s->d_sub_own;
   pl.back_info = s->d_back_info; pl.back_ptr = s->d_back_ptr; pl.back_list = s->d_back_list;
   pl.tasks = s->d_tasks; pl.ntasks = (int)(s->tasks.size() / 2);
-  pl.ticket = s->d_dag_sync; pl.flags = reinterpret_cast<int32_t*>(s->d_dag_sync + 4);
+  pl.ticket = s->d_dag_sync;
   pl.nslots = sv.nslots; pl.nparts = parts;
   int cus = 0;
   HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
@@ -639,6 +642,7 @@ int32_t factor_and_solve(rsba_handle* h, double radius) {
       HIP_TRY(launch_chol_level(sv, s->plan, kTaskBack, d0, d1 - d0, st));
     }
   }
+  HIP_TRY(hipMemcpyAsync(sv.rhs, sv.yv, (size_t)sv.npad * sizeof(double), hipMemcpyDeviceToDevice, st));   // camera step
   HIP_TRY(launch_back_substitute(h->dp, sv, st));
   return RSBA_OK;
 }

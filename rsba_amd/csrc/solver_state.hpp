@@ -71,6 +71,9 @@ struct SolverDev {
   double* z;                    // [M][3]
   double* Pm;                   // [N + M*NPF][CD*3]  point-major, virtual records behind the real ones
   double* S;                    // [nslots][kTile][kTile] packed tiles of the reduced camera system / its factor
+  double* Lf;                   // [nslots][kTile][kTile] the factor's sub-diagonal tiles (S keeps the reduced system itself)
+  double* zv;                   // [npad] forward solve z, directly followed by
+  double* yv;                   // [npad] the camera step y (copied to rhs when the solve is done)
   double* Winv;                 // [nt][kTile][kTile] inverses of the factored diagonal tiles (by tile index)
   double* chol_part;            // [all chunks][kTile*kTile + kTile] partial update tiles (+ rhs partials)
   double* rhs;                  // [npad] directly behind S (one exchange buffer) -> z (forward) -> y_c (backward)
@@ -101,7 +104,6 @@ struct CholPlan {
   const int32_t *upd, *diag_info, *diag_ptr, *diag_list, *sub_info, *sub_ptr, *sub_list, *sub_col, *diag_own, *sub_own, *back_info, *back_ptr, *back_list;
   const int32_t* tasks;      // [ntasks][2] {kind, item} in a topological order
   int ntasks;
-  int32_t* flags;            // [nslots tile done | nparts partial done | nt y done]
   unsigned int* ticket;
   long long* trace;          // debugging (RSBA_CHOL_TRACE): [ntasks][8] {workgroup, claimed, inputs ready, 4 task-specific stamps, done} in 10 ns ticks
   int nslots, nparts;

@@ -42,4 +42,7 @@ d = np.where(tasks[:, 0] == 1)[0]
 order = d[np.argsort(us[d, 2])]
 ends = us[order, 2]
 print("diag completions (us), every 10th:", np.round(ends[::max(1, len(ends) // 25)], 1))
+bk = np.where(tasks[:, 0] == 3)[0]
+print("back completions (us), every 10th:", np.round(np.sort(us[bk, 2])[::10], 1))
+print("back: claimed->late input / late input->done for the last 12 finishing:", np.round(us[bk[np.argsort(us[bk, 2])][-12:], 1] - us[bk[np.argsort(us[bk, 2])][-12:], 0], 1), np.round(us[bk[np.argsort(us[bk, 2])][-12:], 2] - us[bk[np.argsort(us[bk, 2])][-12:], 1], 1))
 np.save("/tmp/chol_trace.npy", np.concatenate([tasks, us], axis=1))
