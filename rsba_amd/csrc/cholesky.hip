@@ -47,11 +47,13 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 }
 
 constexpr int NB = 12;   // inner block: one rolling-shutter camera block
+typedef double dbl4_t __attribute__((ext_vector_type(4)));
 
 // Factor the T x T tile held in LDS (lower triangle, pitch TP) in place: blocked right-looking Cholesky.
 // Each 12-column panel is factored by the first wave entirely in registers (lane = row, pivot rows
 // broadcast with v_readlane, 1/sqrt instead of sqrt + divide: no LDS round trips or barriers on the
-// serial chain); the rank-12 trailing update is spread over all 256 threads.  All threads must call.
+// serial chain); the rank-12 trailing update runs on the matrix pipe, its blocks dealt to the four waves.
+// All threads must call.
 // Returns false (in the first wave) on a non-positive pivot.
 __device__ __forceinline__ bool potrf_blocked(double* A, int tid) {
   bool ok = true;
@@ -65,16 +67,16 @@ __device__ __forceinline__ bool potrf_blocked(double* A, int tid) {
       double a[NB];
 #pragma unroll
       for (int m = 0; m < NB; ++m) a[m] = A[rr * TP + c0 + m];
+      // right-looking inside the panel: once column jj is scaled, the columns behind it are updated by independent
+      // FMAs (the next pivot first), which fill the latency of the next 1/sqrt instead of forming one long sum
 #pragma unroll
       for (int jj = 0; jj < NB; ++jj) {
-        double s = 0.0;
-#pragma unroll
-        for (int m = 0; m < jj; ++m) s += a[m] * readlane_f64(a[m], jj);
-        const double t = a[jj] - s;
-        const double djj = readlane_f64(t, jj);
+        const double djj = readlane_f64(a[jj], jj);
         ok = ok && (djj > 0.0) && isfinite(djj);
         const double rinv = rsqrt_nr(djj);
-        a[jj] = (tid == jj) ? djj * rinv : t * rinv;
+        a[jj] = (tid == jj) ? djj * rinv : a[jj] * rinv;
+#pragma unroll
+        for (int m = jj + 1; m < NB; ++m) a[m] -= a[jj] * readlane_f64(a[jj], m);
       }
       if (live) {
 #pragma unroll
@@ -82,17 +84,29 @@ __device__ __forceinline__ bool potrf_blocked(double* A, int tid) {
       }
     }
     __syncthreads();
-    const int n1 = T - (c0 + NB);
-    if (n1 > 0) {
-      for (int e = tid; e < n1 * n1; e += 256) {
-        const int r = c0 + NB + e / n1, c = c0 + NB + e % n1;
-        if (c <= r) {
-          double s0 = 0.0, s1 = 0.0;
+    // rank-12 trailing update A[r][c] -= sum_m L[r][c0 + m] L[c][c0 + m] for c0 + 12 <= c <= r on the matrix pipe
+    // (K = 12 = three MFMA steps): the 16 x 16 blocks of the tile grid that reach into the trailing part are
+    // dealt to the waves, products formed in full and subtracted under a mask.
+    if (c0 + NB < T) {
+      const int wave = tid >> 6, lane = tid & 63, mi = lane & 15, mg = lane >> 4;
+      const int first = (c0 + NB) >> 4;                        // first block row / column that has trailing entries
+      int blk = 0;
 #pragma unroll
-          for (int m = 0; m < NB; m += 2) { s0 += A[r * TP + c0 + m] * A[c * TP + c0 + m]; s1 += A[r * TP + c0 + m + 1] * A[c * TP + c0 + m + 1]; }
-          A[r * TP + c] -= s0 + s1;
+      for (int I = 0; I < 3; ++I)
+#pragma unroll
+        for (int J = 0; J <= I; ++J) {
+          if (J < first) continue;                             // I >= J >= first
+          if ((blk++ & 3) != wave) continue;
+          dbl4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int kk = 0; kk < NB / 4; ++kk)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[(16 * I + mi) * TP + c0 + 4 * kk + mg], A[(16 * J + mi) * TP + c0 + 4 * kk + mg], acc, 0, 0, 0);
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int r = 16 * I + mg + 4 * v, c = 16 * J + mi;
+            if (c >= c0 + NB && c <= r) A[r * TP + c] -= acc[v];
+          }
         }
-      }
       __syncthreads();
     }
   }
