@@ -120,15 +120,18 @@ __global__ __launch_bounds__(kEvalBlock) void eval_kernel(const DeviceProblem dp
       // point-major copy of the corrected record (see device_state.hpp)
       constexpr int REC = 2 + 2 * K;
       constexpr int KC = K - 3;
-      double rv[REC];
-      rv[0] = o.ok ? o.r[0] : 0.0; rv[1] = o.ok ? o.r[1] : 0.0;
+      // a failed block contributes zeros everywhere below (record, camera blocks, tiled output)
+      if (!o.ok) {
+        o.r[0] = 0.0; o.r[1] = 0.0;
 #pragma unroll
-      for (int r = 0; r < 2; ++r) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) rv[2 + 3 * r + k] = o.ok ? o.J[r][OFF_PT + k] : 0.0;
-#pragma unroll
-        for (int k = 0; k < KC; ++k) rv[8 + KC * r + k] = o.ok ? o.J[r][k] : 0.0;
+        for (int k = 0; k < K; ++k) { o.J[0][k] = 0.0; o.J[1][k] = 0.0; }
       }
+      // record layout [r0 r1 | Jp row0 (3) Jp row1 (3) | Jc row0 (KC) Jc row1 (KC)]: entry k of the record
+      auto rec_entry = [&](int k) -> double {
+        if (k < 2) return o.r[k];
+        if (k < 8) return o.J[(k - 2) / 3][OFF_PT + (k - 2) % 3];
+        return o.J[(k - 8) / KC][(k - 8) % KC];
+      };
       // The records are scattered by slot.  Written one lane per record, every 16-B store of a wave hits 64
       // different cache lines, an eighth of a line at a time; staged through LDS (half a wave at a time), each
       // record leaves as one contiguous run written by REC/2 neighbouring lanes.
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(kEvalBlock) void eval_kernel(const DeviceProblem dp
         for (int h = 0; h < 2; ++h) {
           if ((lane >> 5) == h) {
 #pragma unroll
-            for (int k = 0; k < REC; ++k) st[(lane & 31) * RPITCH + k] = rv[k];
+            for (int k = 0; k < REC; ++k) st[(lane & 31) * RPITCH + k] = rec_entry(k);
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
