@@ -141,6 +141,7 @@ def main():
 
         def run_lm():
             try:
+                torch.cuda.set_device(local_rank)          # the current device is per thread
                 from rsba_amd.distributed import solve_timed
                 box["lm"] = solve_timed(dp, prob, world, args.lm_iters)
             except Exception as e:  # noqa: BLE001 - reported in the JSON line

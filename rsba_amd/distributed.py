@@ -33,13 +33,17 @@ def make_allreduce(group=None):
     import torch.distributed as dist
 
     backend = dist.get_backend(group)
+    # the device of the process at attach time; the callback may run on another thread (bench.py's watchdog), whose
+    # "current device" would otherwise default to 0
+    dev = torch.device("cuda", torch.cuda.current_device())
 
     def _cb(_ctx, ptr, count, op, _stream):
         try:
+            torch.cuda.set_device(dev)
             # run the collective in the context of the solver's own HIP stream, so it is ordered after the
             # kernels that produced the buffer and before the ones that consume it
-            with torch.cuda.stream(torch.cuda.ExternalStream(int(_stream))):
-                t = torch.as_tensor(_DevicePtr(int(ptr), int(count)), device="cuda")
+            with torch.cuda.stream(torch.cuda.ExternalStream(int(_stream), device=dev)):
+                t = torch.as_tensor(_DevicePtr(int(ptr), int(count)), device=dev)
                 red = dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX
                 if backend == "nccl":
                     dist.all_reduce(t, op=red, group=group)      # RCCL over xGMI
