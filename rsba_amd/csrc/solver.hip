@@ -303,7 +303,7 @@ int32_t build_solver(rsba_handle* h) {
   // factor kernels.  upd items: {kind 0 diag / 1 sub, list begin, list end, scratch slot}.
   // The owner of a tile keeps the last kTail contributors — the ones from the latest levels, the list being sorted by
   // level — for itself: on the critical path a freshly finished tile is then multiplied by its consumer directly
-  // instead of passing through a partial tile in HBM (one publish and two memory round trips less per level).
+  // instead of passing through a partial tile in HBM (two memory round trips less per level).
   // An UPDATE task becomes runnable one level after its last contributor, which is where it enters the ticket order.
   const int kChunk = 6, kTail = 4;
   s->lev_diag_ptr.assign(1, 0); s->lev_sub_ptr.assign(1, 0); s->lev_upd_ptr.assign(1, 0);

@@ -86,8 +86,10 @@ def test_tiny_solves_reach_the_independent_minimum(capi, oracle, idx):
     assert abs(s.final_cost - c["expected"]["final_cost"]) <= 1e-8 * c["expected"]["final_cost"]
     ptol = 1e-3 if c["huber_a"] > 0 else 1e-5
     assert np.max(np.abs(p_dev.poses - np.array(c["expected"]["poses"]))) <= ptol
-    # (parameters agree as far as the flat directions of the cost allow; the Huber scene is flatter)
-    qtol = 1e-5 if c["huber_a"] > 0 else 1e-7
+    # (parameters agree as far as the flat directions of the cost allow; the Huber scene is flatter.  Both solves stop on
+    # their tolerances somewhere along those directions: the distance was observed at 0.9-1.1e-7 from run to run — the
+    # oracle's OpenMP reductions are not order-deterministic — so the bound leaves a factor of a few)
+    qtol = 1e-5 if c["huber_a"] > 0 else 5e-7
     assert np.max(np.abs(p_dev.poses - p_cpu.poses)) <= qtol and np.max(np.abs(p_dev.points - p_cpu.points)) <= 10 * qtol
     # default Ceres tolerances: within the 1e-6 contract of the minimum
     p2 = problem_from_solve_case(c)
