@@ -4,7 +4,8 @@
 // solve as the C ABI / oracle.
 //
 //   scene file (binary, little endian): int32 F,P,M,rs,scan0,scan1,calibrated,interp,fixFirstN,fixScale,maxIter, int64 N,
-//     double huber, double revalidate (squared px threshold of revalidateReprojections, <= 0 = off), double cam[9], poses[F*P*6], points[M*3], obs_xy[N*2], int32 obs_frame[N], obs_point[N]
+//     double huber, double revalidate (squared px threshold of revalidateReprojections, <= 0 = off), double covFrame (>= 0:
+//     calcCovariances, the pp | pe | ee blocks of that frame are appended to the result file), double cam[9], poses[F*P*6], points[M*3], obs_xy[N*2], int32 obs_frame[N], obs_point[N]
 //   g++ -std=c++17 -O2 -Iinclude examples/ba_session.cpp -Lrsba_amd/_lib -lrsba_amd -Wl,-rpath,... -o ba_session
 #include <cstdio>
 #include <cstdlib>
@@ -22,8 +23,8 @@ int main(int argc, char** argv) {
   if (argc < 3) { std::fprintf(stderr, "usage: %s scene.bin out.bin\n", argv[0]); return 2; }
   FILE* f = std::fopen(argv[1], "rb");
   if (!f) { std::perror("scene"); return 2; }
-  int32_t hd[11]; int64_t N; double huber, reval, cam[9];
-  if (!rd(f, hd, 11) || !rd(f, &N, 1) || !rd(f, &huber, 1) || !rd(f, &reval, 1) || !rd(f, cam, 9)) return 2;
+  int32_t hd[11]; int64_t N; double huber, reval, covf, cam[9];
+  if (!rd(f, hd, 11) || !rd(f, &N, 1) || !rd(f, &huber, 1) || !rd(f, &reval, 1) || !rd(f, &covf, 1) || !rd(f, cam, 9)) return 2;
   const int F = hd[0], P = hd[1], M = hd[2];
   std::vector<double> poses((size_t)F * P * 6), points((size_t)M * 3), xy((size_t)N * 2);
   std::vector<int32_t> of(N), op(N);
@@ -49,9 +50,11 @@ int main(int argc, char** argv) {
   opt.model.rolling_shutter = P == 2; opt.model.calibrated = hd[6] != 0; opt.model.interpolateRotation = hd[7] != 0;
   opt.ceres.fixFirstNCameras = (unsigned)hd[8]; opt.ceres.fixScale = hd[9] != 0; opt.ceres.huberLoss = huber;
   if (reval > 0) { opt.ceres.revalidateReprojections = true; opt.tracks.sqrdThreshold = reval; }
+  opt.debug.calcCovariances = covf >= 0;
 
   ceres::Solver::Summary summary;
-  const bool usable = BA(sess, 0, F - 1, opt, hd[10], &summary, true);
+  std::vector<std::vector<double>> covs;
+  const bool usable = BA(sess, 0, F - 1, opt, hd[10], &summary, true, &covs);
 
   FILE* g = std::fopen(argv[2], "wb");
   if (!g) { std::perror("out"); return 2; }
@@ -60,6 +63,7 @@ int main(int argc, char** argv) {
   std::fwrite(head, sizeof(double), 6, g);
   for (int i = 0; i < F; ++i) for (int q = 0; q < P; ++q) std::fwrite(sess.frames[i].poses[q].data(), sizeof(double), 6, g);
   for (int j = 0; j < M; ++j) std::fwrite(sess.tracks[j].pt.data(), sizeof(double), 3, g);
+  if (covf >= 0 && (size_t)covf < covs.size() && covs[(size_t)covf].size() == 108) std::fwrite(covs[(size_t)covf].data(), sizeof(double), 108, g);
   std::fclose(g);
   return usable ? 0 : 1;
 }

@@ -266,6 +266,7 @@ class Problem {
 
  private:
   friend void Solve(const Solver::Options&, Problem*, Solver::Summary*);
+  friend class Covariance;
   struct Block { CostFunction* cost; LossFunction* loss; std::vector<double*> x; };
   struct Slot { int kind; int index; };   // kind 0 pose block, 1 point, 2 intrinsics
   struct Flat {
@@ -421,6 +422,61 @@ inline void Solve(const Solver::Options& options, Problem* problem, Solver::Summ
   summary->iterations = trace;
   if (summary->IsSolutionUsable()) problem->scatter(f);
 }
+
+// ceres::Covariance for pose blocks (the use rsba makes of it, VideoSfMHandler.cc:602-621): Compute() takes pairs of
+// pose blocks of the problem, GetCovarianceBlock() returns the row-major 6 x 6 block between two poses of ONE
+// frame.  Each frame asked for costs one call of rsba_pose_covariance (CD solves through the device factorisation).
+// Compute() returns false — like Ceres — when J^T J is rank deficient, and for blocks outside the accelerated
+// path (points, intrinsics, poses of two different frames).
+class Covariance {
+ public:
+  struct Options { int device = 0; };
+  Covariance() {}
+  explicit Covariance(const Options& o) : options_(o) {}
+
+  bool Compute(const std::vector<std::pair<const double*, const double*>>& blocks, Problem* problem) {
+    ready_.clear();
+    Problem::Flat f;
+    if (!problem->flatten(&f, nullptr)) return false;
+    const int P = f.desc.poses_per_frame, CD = 6 * P;
+    std::set<int> frames;
+    for (const auto& b : blocks) {
+      auto i0 = f.slot_of.find(const_cast<double*>(b.first)), i1 = f.slot_of.find(const_cast<double*>(b.second));
+      if (i0 == f.slot_of.end() || i1 == f.slot_of.end() || i0->second.kind != 0 || i1->second.kind != 0) return false;
+      if (i0->second.index / P != i1->second.index / P) return false;
+      frames.insert(i0->second.index / P);
+    }
+    rsba_handle* h = nullptr;
+    if (rsba_create(&f.desc, options_.device, &h) != RSBA_OK) return false;
+    bool ok = true;
+    for (int fr : frames) {
+      std::vector<double> cov((size_t)CD * CD);
+      if (rsba_pose_covariance(h, fr, cov.data()) != RSBA_OK) { ok = false; break; }
+      for (int q = 0; q < P; ++q) index_[f.pose_ptr[(size_t)fr * P + q]] = std::make_pair(fr, q);
+      ready_[fr] = std::move(cov);
+    }
+    rsba_destroy(h);
+    poses_per_frame_ = P;
+    if (!ok) ready_.clear();
+    return ok;
+  }
+
+  bool GetCovarianceBlock(const double* p0, const double* p1, double* out) const {
+    auto i0 = index_.find(p0), i1 = index_.find(p1);
+    if (i0 == index_.end() || i1 == index_.end() || i0->second.first != i1->second.first) return false;
+    auto it = ready_.find(i0->second.first);
+    if (it == ready_.end()) return false;
+    const int CD = 6 * poses_per_frame_, r0 = 6 * i0->second.second, c0 = 6 * i1->second.second;
+    for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) out[a * 6 + b] = it->second[(size_t)(r0 + a) * CD + c0 + b];
+    return true;
+  }
+
+ private:
+  Options options_;
+  int poses_per_frame_ = 1;
+  std::map<const double*, std::pair<int, int>> index_;   // pose block -> (frame, pose within the frame)
+  std::map<int, std::vector<double>> ready_;             // frame -> [CD][CD]
+};
 
 }  // namespace ceres
 }  // namespace rsba_amd

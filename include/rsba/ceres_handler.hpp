@@ -4,7 +4,7 @@
 // Same names, argument meaning and error behaviour for the per-observation path (SURVEY Appendix D
 // steps 3-4).  Not built (they are "next" rows): pose initialisation of frames without poses
 // (Appendix D step 1), motion / pose priors (step 2), the structure-less ray costs, match-based track
-// lookup — reaching one of them throws std::runtime_error.  revalidateReprojections (:239-243) runs as one
+// lookup — reaching one of them throws std::runtime_error.  opt.debug.calcCovariances (VideoSfMHandler.cc:599-621) is built.  revalidateReprojections (:239-243) runs as one
 // batched device validation per frame (video_sfm.hpp).
 #pragma once
 #include <cmath>
@@ -141,7 +141,7 @@ class CeresHandler {
 // Add frames [startFrame, endFrame], solve, print the report and the "average reprojection error"
 // sqrt(final_cost / num_residual_blocks_reduced) (:627-628), return IsSolutionUsable() (:630).
 inline bool BA(Session& sess, const int32_t startFrame, const int32_t endFrame, const SfmOptions& opt, const int32_t maxIter,
-               ceres::Solver::Summary* out = nullptr, bool progress = true) {
+               ceres::Solver::Summary* out = nullptr, bool progress = true, std::vector<std::vector<double>>* covariances = nullptr) {
   ceres::Solver::Options cOpt;
   cOpt.linear_solver_type = ceres::SPARSE_SCHUR;
   cOpt.minimizer_progress_to_stdout = progress;
@@ -152,6 +152,32 @@ inline bool BA(Session& sess, const int32_t startFrame, const int32_t endFrame, 
   ceres::Solver::Summary summary = cs.solve(&cOpt);
   if (progress) std::cout << summary.FullReport() << std::endl;
   if (!summary.IsSolutionUsable()) std::cerr << summary.message << std::endl;
+  if (opt.debug.calcCovariances) {                                   // :599-621 (rolling-shutter frames: two poses)
+    for (int32_t fi = startFrame; fi <= endFrame; fi++) {
+      const Frame& f = sess.frames[(size_t)fi];
+      if (f.poses.size() != 2) continue;
+      ceres::Covariance::Options options;
+      ceres::Covariance covariance(options);
+      std::vector<std::pair<const double*, const double*>> covariance_blocks;
+      covariance_blocks.push_back(std::make_pair(f.poses[0].data(), f.poses[0].data()));
+      covariance_blocks.push_back(std::make_pair(f.poses[0].data(), f.poses[1].data()));
+      covariance_blocks.push_back(std::make_pair(f.poses[1].data(), f.poses[1].data()));
+      if (covariance.Compute(covariance_blocks, &cs.problem)) {
+        std::vector<double> ppe(3 * 36);
+        covariance.GetCovarianceBlock(f.poses[0].data(), f.poses[0].data(), &ppe[0]);
+        covariance.GetCovarianceBlock(f.poses[0].data(), f.poses[1].data(), &ppe[36]);
+        covariance.GetCovarianceBlock(f.poses[1].data(), f.poses[1].data(), &ppe[72]);
+        if (progress) {
+          const char* names[3] = {"pp:", "pe:", "ee:"};
+          for (int b = 0; b < 3; ++b) {
+            std::cout << names[b] << std::endl;
+            for (int r = 0; r < 6; ++r) { for (int c = 0; c < 6; ++c) std::cout << ppe[(size_t)b * 36 + r * 6 + c] << (c < 5 ? " " : ""); std::cout << std::endl; }
+          }
+        }
+        if (covariances) { covariances->resize(sess.frames.size()); (*covariances)[(size_t)fi] = ppe; }
+      }
+    }
+  }
   if (progress)
     std::cout << "average reprojection error: " << std::sqrt(summary.final_cost / summary.num_residual_blocks_reduced) << std::endl;
   if (out) *out = summary;

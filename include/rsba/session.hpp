@@ -82,6 +82,9 @@ struct SfmOptions {
     double trustPriorCamRotation = 0;
     bool revalidateReprojections = false;
   } ceres;
+  struct Debug {
+    bool calcCovariances = false;   // VideoSfMHandler.cc:599-621
+  } debug;
 };
 
 }  // namespace rsba_amd

@@ -179,6 +179,12 @@ int32_t rsba_validate_observations(rsba_handle* h, double sq_threshold, double m
  * projection moves <= 1e-3 px.  xy_out [n][2], ok_out [n] (host arrays). */
 int32_t rsba_reproject(rsba_handle* h, const int32_t* frames, const int32_t* points, int64_t n, double* xy_out, uint8_t* ok_out);
 
+/* == the covariance blocks VideoSfMHandler::BA prints with opt.debug.calcCovariances (VideoSfMHandler.cc:602-621:
+ * ceres::Covariance::Compute on (p0,p0), (p0,p1), (p1,p1) of a frame): cov [CD][CD] row-major,
+ * CD = 6 * poses_per_frame, = the (frame, frame) block of (J^T J)^-1 at the current parameters, loss function applied,
+ * zero rows / columns at fixed coordinates.  RSBA_ERR_UNSUPPORTED when J^T J is rank deficient (Compute returns false). */
+int32_t rsba_pose_covariance(rsba_handle* h, int32_t frame, double* cov);
+
 /* ---- multi-GPU: one process per GPU, observations partitioned BY POINT, cameras replicated ----
  * (the reference is single-process; this is the exchange step SURVEY §8e derives for the path).
  * Every rank creates a handle over its own observations (all frames / points arrays are full size, a rank

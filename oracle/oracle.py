@@ -147,6 +147,15 @@ def normal_equations(prob):
     return U, gc, V, gp
 
 
+def pose_covariance(prob, frame: int):
+    """ceres::Covariance blocks of one frame -> ([CD, CD] array, ok)"""
+    d = desc(prob)
+    cd = 6 * prob.poses_per_frame
+    cov = np.zeros((cd, cd))
+    ok = lib().orc_pose_covariance(C.byref(d), C.c_int32(frame), _ptr(cov))
+    return cov, bool(ok)
+
+
 def default_options(**kw) -> OrcOptions:
     o = OrcOptions()
     lib().orc_default_options(C.byref(o))

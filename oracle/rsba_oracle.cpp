@@ -245,12 +245,14 @@ PointCsr point_csr(const orc_problem* p) {
 // SchurComplementSolver restated (Ceres 1.9 schur_complement_solver.cc / schur_eliminator_impl.h):
 // solve (J^T J + D^2) y = J^T r exactly by eliminating the point blocks, dense Cholesky on the
 // reduced camera system, back-substitution.  J is the (already column-scaled) corrected Jacobian.
-bool schur_solve(const Eval& E, const PointCsr& pc, const std::vector<double>& J, const std::vector<double>& r,
-                 const std::vector<double>& D2, std::vector<double>& y) {
+// reduced camera system S = U + D_c^2 - sum_j W_j (V_j + D_p^2)^-1 W_j^T and its right-hand side (dense), with the
+// inverted point blocks and point gradients the back-substitution needs
+bool reduced_system(const Eval& E, const PointCsr& pc, const std::vector<double>& J, const std::vector<double>& r,
+                    const std::vector<double>& D2, std::vector<double>& S, std::vector<double>& rhs,
+                    std::vector<double>& Vinv, std::vector<double>& bp) {
   const Layout& L = E.L; const int K = L.K; const int KC = K - 3;   // camera-side columns of one block
   const int64_t nc = E.ncam, N = E.N; const int M = E.M;
-  std::vector<double> S((size_t)nc * nc, 0.0), rhs(nc, 0.0);
-  y.assign(E.nparam, 0.0);
+  S.assign((size_t)nc * nc, 0.0); rhs.assign(nc, 0.0);
   // camera-side Hessian and gradient
   for (int64_t i = 0; i < N; ++i) {
     const double* Ji = &J[(size_t)2 * K * i];
@@ -261,7 +263,7 @@ bool schur_solve(const Eval& E, const PointCsr& pc, const std::vector<double>& J
     }
   }
   for (int64_t a = 0; a < nc; ++a) S[a * nc + a] += D2[a];
-  std::vector<double> Vinv((size_t)9 * M), bp((size_t)3 * M, 0.0);
+  Vinv.assign((size_t)9 * M, 0.0); bp.assign((size_t)3 * M, 0.0);
   bool ok = true;
   for (int j = 0; j < M; ++j) {
     double V[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
@@ -302,7 +304,16 @@ bool schur_solve(const Eval& E, const PointCsr& pc, const std::vector<double>& J
       }
     }
   }
-  if (!ok) return false;
+  return ok;
+}
+
+bool schur_solve(const Eval& E, const PointCsr& pc, const std::vector<double>& J, const std::vector<double>& r,
+                 const std::vector<double>& D2, std::vector<double>& y) {
+  const Layout& L = E.L; const int K = L.K; const int KC = K - 3;
+  const int64_t nc = E.ncam; const int M = E.M;
+  std::vector<double> S, rhs, Vinv, bp;
+  y.assign(E.nparam, 0.0);
+  if (!reduced_system(E, pc, J, r, D2, S, rhs, Vinv, bp)) return false;
   if (!cholesky(S, nc)) return false;
   chol_solve(S, nc, rhs);
   for (int64_t a = 0; a < nc; ++a) y[a] = rhs[a];
@@ -562,6 +573,46 @@ int32_t orc_solve(orc_problem* p, const orc_options* opt, orc_summary* sum, orc_
     push(it);
   }
   return sum->termination_type;
+}
+
+// ceres::Covariance::Compute + GetCovarianceBlock for the pose block(s) of one frame (reference call site
+// VideoSfMHandler.cc:602-621; Ceres 1.9 covariance_impl.cc restated): the (frame, frame) block of (J^T J)^-1 with the
+// loss function applied, on the tangent space — constant blocks and the fixed coordinates of a SubsetParameterization
+// are removed before the inversion and come back as zero rows / columns.  The point blocks are eliminated first
+// (same inverse, by the block-inverse formula).  Returns 0 if J^T J is rank deficient or the evaluation fails.
+int32_t orc_pose_covariance(const orc_problem* p, int32_t frame, double* cov) {
+  Eval E(p);
+  if (!E.run(true, nullptr, nullptr)) return 0;
+  const int CD = E.L.CD; const int64_t nc = E.ncam;
+  PointCsr pc = point_csr(p);
+  std::vector<double> D2(E.nparam, 0.0), S, rhs, Vinv, bp;
+  // fixed point coordinates: keep their (decoupled, otherwise singular) 3x3 blocks invertible
+  for (int64_t a = nc; a < E.nparam; ++a) if (E.colmask[a]) D2[a] = 1.0;
+  // a point that nobody observes has an all-zero block as well
+  for (int j = 0; j < E.M; ++j) if (pc.ptr[j + 1] == pc.ptr[j]) for (int k = 0; k < 3; ++k) D2[nc + 3 * (int64_t)j + k] = 1.0;
+  if (!reduced_system(E, pc, E.J, E.r, D2, S, rhs, Vinv, bp)) return 0;
+  // free camera-side coordinates
+  std::vector<int64_t> freec;
+  for (int64_t a = 0; a < nc; ++a) if (!E.colmask[a]) freec.push_back(a);
+  const int64_t nf = (int64_t)freec.size();
+  std::vector<double> A((size_t)nf * nf);
+  for (int64_t a = 0; a < nf; ++a) for (int64_t b = 0; b < nf; ++b) A[a * nf + b] = S[freec[a] * nc + freec[b]];
+  if (!cholesky(A, nf)) return 0;
+  for (int a = 0; a < CD * CD; ++a) cov[a] = 0.0;
+  for (int k = 0; k < CD; ++k) {
+    const int64_t g = (int64_t)frame * CD + k;
+    const auto it = std::lower_bound(freec.begin(), freec.end(), g);
+    if (it == freec.end() || *it != g) continue;
+    std::vector<double> e(nf, 0.0);
+    e[it - freec.begin()] = 1.0;
+    chol_solve(A, nf, e);
+    for (int a = 0; a < CD; ++a) {
+      const int64_t ga = (int64_t)frame * CD + a;
+      const auto ia = std::lower_bound(freec.begin(), freec.end(), ga);
+      if (ia != freec.end() && *ia == ga) cov[a * CD + k] = e[ia - freec.begin()];
+    }
+  }
+  return 1;
 }
 
 void orc_set_num_threads(int32_t n) {

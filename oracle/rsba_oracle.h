@@ -90,6 +90,10 @@ int32_t orc_normal_equations(const orc_problem* p, double* U, double* gc, double
  * Parameters are overwritten in place.  trace (may be NULL) receives up to trace_cap iteration records. */
 int32_t orc_solve(orc_problem* p, const orc_options* opt, orc_summary* summary, orc_iteration* trace, int32_t trace_cap);
 
+/* ceres::Covariance blocks of one frame's poses (VideoSfMHandler.cc:602-621): cov [CD][CD], CD = 6 * poses_per_frame;
+ * returns 1 on success, 0 if J^T J is rank deficient or a functor fails. */
+int32_t orc_pose_covariance(const orc_problem* p, int32_t frame, double* cov);
+
 /* Scalar entry points for the known-answer tests (mat_test.cc) */
 void orc_angle_axis_rotate(const double w[3], const double p[3], double out[3]);
 void orc_lerp_rotation(const double r0[3], const double r1[3], double tau, double out[3]);

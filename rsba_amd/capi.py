@@ -21,7 +21,7 @@ EXPORTS = [
     "rsba_set_stream", "rsba_upload_parameters", "rsba_download_parameters", "rsba_evaluate_device", "rsba_evaluate",
     "rsba_get_device_view", "rsba_time_evaluate", "rsba_default_solver_options", "rsba_solve", "rsba_normal_equations",
     "rsba_set_exchange", "rsba_get_block_structure", "rsba_set_block_structure",
-    "rsba_validate_observations", "rsba_reproject",
+    "rsba_validate_observations", "rsba_reproject", "rsba_pose_covariance",
 ]
 
 
@@ -233,6 +233,13 @@ class DeviceProblem:
         xy = np.zeros((len(fr), 2)); ok = np.zeros(len(fr), dtype=np.uint8)
         _check(lib().rsba_reproject(self._h, _ptr(fr), _ptr(pt), C.c_int64(len(fr)), _ptr(xy), _ptr(ok)))
         return xy, ok.astype(bool)
+
+    def pose_covariance(self, frame: int) -> np.ndarray:
+        """ceres::Covariance blocks of one frame (VideoSfMHandler.cc:602-621) -> [CD, CD]"""
+        cd = 6 * self.prob.poses_per_frame
+        out = np.zeros((cd, cd))
+        _check(lib().rsba_pose_covariance(self._h, C.c_int32(frame), _ptr(out)))
+        return out
 
     def device_view(self) -> DeviceView:
         v = DeviceView()

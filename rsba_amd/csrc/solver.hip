@@ -616,7 +616,8 @@ int32_t gradient_max(rsba_handle* h) {
   return exchange(h, s->sv.scalars + kGradMax, 1, 1);
 }
 
-int32_t factor_and_solve(rsba_handle* h, double radius) {
+// reduced camera system S and rhs at the given trust-region radius (point elimination), summed over the ranks
+int32_t reduce_system(rsba_handle* h, double radius) {
   Solver* s = h->solver; const SolverDev& sv = s->sv; hipStream_t st = h->stream;
   HIP_TRY(launch_point_factor(h->dp, sv, radius, st));
   HIP_TRY(launch_project(h->dp, sv, st));
@@ -624,9 +625,14 @@ int32_t factor_and_solve(rsba_handle* h, double radius) {
   HIP_TRY(launch_clear_system(sv, st));
   HIP_TRY(launch_schur_blocks(h->dp, sv, radius, st));
   // exchange (2): partial reduced camera systems -> the full one on every rank (then factored redundantly)
-  { int32_t rc = exchange(h, sv.S, (int64_t)sv.nslots * kTile * kTile + sv.npad, 0); if (rc) return rc; }
-  // left-looking tile Cholesky (forward solve rides along), then the backward solve: one persistent DAG
-  // launch, or — the schedule it is checked against — one launch per (level, kind)
+  return exchange(h, sv.S, (int64_t)sv.nslots * kTile * kTile + sv.npad, 0);
+}
+
+// S y = rhs: left-looking tile Cholesky (forward solve rides along), then the backward solve: one persistent DAG
+// launch, or — the schedule it is checked against — one launch per (level, kind).  S and rhs are left as they are
+// (the factor has its own tiles); y lands in sv.yv.
+int32_t solve_reduced_system(rsba_handle* h) {
+  Solver* s = h->solver; const SolverDev& sv = s->sv; hipStream_t st = h->stream;
   if (!s->use_levels) {
     HIP_TRY(launch_chol_dag(sv, s->plan, s->dag_workgroups, st));
   } else {
@@ -642,6 +648,14 @@ int32_t factor_and_solve(rsba_handle* h, double radius) {
       HIP_TRY(launch_chol_level(sv, s->plan, kTaskBack, d0, d1 - d0, st));
     }
   }
+  return RSBA_OK;
+}
+
+int32_t factor_and_solve(rsba_handle* h, double radius) {
+  Solver* s = h->solver; const SolverDev& sv = s->sv; hipStream_t st = h->stream;
+  int32_t rc = reduce_system(h, radius);
+  if (rc) return rc;
+  if ((rc = solve_reduced_system(h))) return rc;
   HIP_TRY(hipMemcpyAsync(sv.rhs, sv.yv, (size_t)sv.npad * sizeof(double), hipMemcpyDeviceToDevice, st));   // camera step
   HIP_TRY(launch_back_substitute(h->dp, sv, st));
   return RSBA_OK;
@@ -729,6 +743,45 @@ extern "C" int32_t rsba_normal_equations(rsba_handle* h, double* U, double* gc, 
   if (V) for (int j = 0; j < dp.M; ++j) {
     const double* v = &v6[(size_t)j * 6]; double* o = V + (size_t)j * 9;
     o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[1]; o[4] = v[3]; o[5] = v[4]; o[6] = v[2]; o[7] = v[4]; o[8] = v[5];
+  }
+  return RSBA_OK;
+}
+
+// Covariance of one frame's pose block(s): the (frame, frame) block of (J^T J)^-1, J = loss-corrected Jacobian of the
+// problem at the current parameters on the tangent space of its parameterizations — what ceres::Covariance returns
+// for the blocks (p0,p0), (p0,p1), (p1,p1) that VideoSfMHandler::BA asks for (VideoSfMHandler.cc:602-621).
+// It is the same block of the inverse of the reduced camera system: S without damping and without Jacobi scaling
+// (radius 1e300: fixed coordinates keep a vanishing, decoupled diagonal instead of an exact zero), one solve per
+// unit vector through the factorisation.  Fixed coordinates have zero covariance.
+extern "C" int32_t rsba_pose_covariance(rsba_handle* h, int32_t frame, double* cov) {
+  if (!h || !cov) return rsba_set_error(RSBA_ERR_INVALID_ARGUMENT, "null argument");
+  if (frame < 0 || frame >= h->dp.F) return rsba_set_error(RSBA_ERR_INVALID_ARGUMENT, "frame out of range");
+  HIP_TRY(hipSetDevice(h->device));
+  int32_t rc = build_solver(h);
+  if (rc) return rc;
+  Solver* s = h->solver; SolverDev& sv = s->sv; hipStream_t st = h->stream; const int CD = sv.CD;
+  if ((rc = reset_scales(h))) return rc;
+  if ((rc = linearize(h))) return rc;
+  HIP_TRY(launch_clamp_diagonal(h->dp, sv, 1e-6, 1e32, st));   // only its floor matters: the decoupled diagonal of fixed coordinates
+  HIP_TRY(hipMemsetAsync(sv.chol_fail, 0, sizeof(int), st));
+  if ((rc = reduce_system(h, 1e300))) return rc;
+  std::vector<double> col((size_t)CD * CD, 0.0);
+  const double one = 1.0;
+  for (int k = 0; k < CD; ++k) {
+    HIP_TRY(hipMemsetAsync(sv.rhs, 0, (size_t)sv.npad * sizeof(double), st));
+    HIP_TRY(hipMemcpyAsync(sv.rhs + (size_t)frame * CD + k, &one, sizeof(double), hipMemcpyHostToDevice, st));
+    if ((rc = solve_reduced_system(h))) return rc;
+    HIP_TRY(hipMemcpyAsync(&col[(size_t)k * CD], sv.yv + (size_t)frame * CD, (size_t)CD * sizeof(double), hipMemcpyDeviceToHost, st));
+  }
+  int fail = 0, nfail = 0;
+  HIP_TRY(hipMemcpyAsync(&fail, sv.chol_fail, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(&nfail, h->dp.fail_count, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (nfail) return rsba_set_error(RSBA_ERR_EVALUATION_FAILED, "residual and Jacobian evaluation failed");
+  if (fail) return rsba_set_error(RSBA_ERR_UNSUPPORTED, "J^T J is rank deficient (fix the gauge): no covariance, as ceres::Covariance::Compute returns false");
+  for (int a = 0; a < CD; ++a) for (int b = 0; b < CD; ++b) {
+    const double ma = h->mask_pose[(size_t)frame * CD + a], mb = h->mask_pose[(size_t)frame * CD + b];
+    cov[(size_t)a * CD + b] = (ma != 0.0 && mb != 0.0) ? col[(size_t)b * CD + a] : 0.0;
   }
   return RSBA_OK;
 }

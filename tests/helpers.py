@@ -59,14 +59,14 @@ def rel_err(a, b):
     return float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b)))) if a.size else 0.0
 
 
-def write_scene_file(path, prob, *, fix_first_n=1, fix_scale=False, max_iter=20, revalidate=0.0):
+def write_scene_file(path, prob, *, fix_first_n=1, fix_scale=False, max_iter=20, revalidate=0.0, cov_frame=-1):
     """Binary scene file read by examples/ba_session.cpp (layout documented there)."""
     import struct
     with open(path, "wb") as f:
         f.write(struct.pack("<11i", prob.num_frames, prob.poses_per_frame, prob.num_points, int(prob.shutter), int(prob.scanlines[0]),
                             int(prob.scanlines[1]), int(prob.calibrated), int(prob.interpolate_rotation), fix_first_n, int(fix_scale), max_iter))
         f.write(struct.pack("<q", prob.num_observations))
-        f.write(struct.pack("<dd", float(prob.huber_a), float(revalidate)))
+        f.write(struct.pack("<ddd", float(prob.huber_a), float(revalidate), float(cov_frame)))
         f.write(prob.intrinsics[0].astype("<f8").tobytes())
         f.write(prob.poses.astype("<f8").tobytes())
         f.write(prob.points.astype("<f8").tobytes())
@@ -81,5 +81,6 @@ def read_result_file(path, prob):
     npose = prob.poses.size
     poses = raw[6:6 + npose].reshape(prob.poses.shape)
     points = raw[6 + npose:6 + npose + prob.points.size].reshape(-1, 3)
+    rest = raw[6 + npose + prob.points.size:]
     return dict(initial_cost=head[0], final_cost=head[1], iterations=int(head[2]), reduced=int(head[3]), termination=int(head[4]),
-                usable=bool(head[5]), poses=poses, points=points)
+                usable=bool(head[5]), poses=poses, points=points, covariance=rest[:108].reshape(3, 6, 6) if rest.size >= 108 else None)

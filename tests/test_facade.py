@@ -84,3 +84,25 @@ def test_revalidate_reprojections_drops_what_validate_rejects(exe, oracle, tmp_p
     assert abs(out["final_cost"] - s_ref.final_cost) <= 1e-6 * s_ref.final_cost
     # points that lost all their observations keep their input value on both sides
     assert np.max(np.abs(out["poses"] - q.poses)) <= 1e-5 and np.max(np.abs(out["points"] - q.points)) <= 1e-4
+
+
+@pytest.mark.gpu
+def test_calc_covariances_prints_what_the_oracle_computes(exe, oracle, tmp_path):
+    """opt.debug.calcCovariances (VideoSfMHandler.cc:599-621): after the solve, ceres::Covariance on (p0,p0), (p0,p1),
+    (p1,p1) of every frame.  The facade's blocks of one frame equal the oracle's at the adjusted parameters."""
+    from rsba_amd.problem import apply_gauge_masks
+    p = small_problem(True, 0.0)
+    write_scene_file(tmp_path / "s.bin", p, fix_first_n=1, fix_scale=True, max_iter=15, cov_frame=6)
+    r = subprocess.run([exe, str(tmp_path / "s.bin"), str(tmp_path / "o.bin")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "pp:" in r.stdout and "pe:" in r.stdout and "ee:" in r.stdout
+    out = read_result_file(tmp_path / "o.bin", p)
+    q = p.copy()
+    q.poses[...] = out["poses"]; q.points[...] = out["points"]
+    apply_gauge_masks(q, fix_first_n_cameras=1, fix_scale=True)
+    ref, ok = oracle.pose_covariance(q, 6)
+    assert ok and out["covariance"] is not None
+    scale = np.abs(ref).max()
+    assert np.abs(out["covariance"][0] - ref[:6, :6]).max() <= 1e-7 * scale
+    assert np.abs(out["covariance"][1] - ref[:6, 6:]).max() <= 1e-7 * scale
+    assert np.abs(out["covariance"][2] - ref[6:, 6:]).max() <= 1e-7 * scale
