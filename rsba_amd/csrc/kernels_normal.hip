@@ -360,7 +360,10 @@ __global__ __launch_bounds__(256) void schur_tile_kernel(const SolverDev sv, con
   if (chunk >= sv.nchunk) return;
   const int64_t e0 = sv.chunk_e0[chunk];
   const int n = sv.chunk_n[chunk];
-  for (int k = tid; k < n * NREC; k += 256) s_slot[k] = sv.ent_slots[(size_t)e0 * NREC + k];
+  for (int k = tid; k < n * NREC; k += 256) {
+    const int e = k / NREC, q = k % NREC;   // slot q of entry e: frame q % FT of its I-side (q < FT) or J-side group
+    s_slot[k] = sv.group_slots[(size_t)sv.ent_groups[2 * (e0 + e) + q / FT] * FT + q % FT];
+  }
   for (int k = tid; k < n * 3; k += 256) {
     const int32_t pt = sv.ent_pt[e0 + k / 3];
     s_z[k] = pt < 0 ? zz[(size_t)(pt & 0x7fffffff) * 3 + k % 3] : 0.0;   // top bit: diagonal entry of the point -> rhs term P z

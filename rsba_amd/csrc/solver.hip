@@ -98,6 +98,13 @@ int32_t build_solver(rsba_handle* h) {
     return rsba_set_error(RSBA_ERR_UNSUPPORTED, "solve with per-frame intrinsics parameter blocks is not built yet (shared sess.cam is)");
   Solver* s = new Solver();
   h->solver = s;   // owned by the handle from here on (freed by rsba_destroy_solver)
+  const bool dbg_plan = std::getenv("RSBA_DEBUG_PLAN") != nullptr;
+  std::string phases; double t_phase = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  auto tick = [&](const char* name) {
+    if (!dbg_plan) return;
+    const double t = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    char b[64]; std::snprintf(b, sizeof b, " %s %.1f ms;", name, (t - t_phase) * 1e3); phases += b; t_phase = t;
+  };
   SolverDev& sv = s->sv;
   const int FR = dp.F, M = dp.M, CD = 6 * dp.P;          // FR real frames
   const int NPF = dp.calibrated ? 0 : (9 + CD - 1) / CD;   // intrinsics pseudo frames (solver_state.hpp)
@@ -130,27 +137,34 @@ int32_t build_solver(rsba_handle* h) {
     if (!out.empty()) for (int v = 0; v < NPF; ++v) out.push_back(N + (int64_t)j * NPF + v);
   };
   std::vector<int64_t> pslots;
+  tick("slots");
   // ---- work list of the point elimination: one ENTRY per (point, pair of frame tiles I >= J) ----
   // An entry lists the point's observation slot in each of the FT frames of tile I (sa) and of tile J (sb),
   // -1 where it is not observed.  One wave turns an entry into up to FT x FT block products P_a P_b^T with
   // every P record loaded once (frame-pair-major accumulation, no atomics).  A point seen
   // twice in one frame gets a second "layer" of slots and the cross-layer entries.
   const int nt = sv.nt;
-  const int ES = 2 * FT;                                   // ints per entry
-  struct TileSlots { int tile; std::vector<std::vector<int32_t>> layers; };
-  auto tiles_of = [&](int j, std::vector<TileSlots>& out) {
-    out.clear();
+  // Per point, the (tile, layer) groups of its slots — computed once, flat (no per-point allocations: this pass used
+  // to be 85 % of the symbolic phase): group g of point j covers one tile and one layer and owns FT slot entries.
+  std::vector<int64_t> pt_group(M + 1, 0);     // groups of point j: [pt_group[j], pt_group[j+1])
+  std::vector<int32_t> g_tile, g_rows;          // tile of each group; FT slots per group (NS = not observed)
+  g_tile.reserve((size_t)N / 2); g_rows.reserve((size_t)N * 2);
+  for (int j = 0; j < M; ++j) {
     slots_of(j, pslots);
-    int prev_frame = -1, layer = 0;
+    int prev_frame = -1, layer = 0, cur_tile = -1;
+    size_t tile_first = g_tile.size();          // first group (layer 0) of the current tile
     for (int64_t sl : pslots) {
       const int f = slot_frame[sl], tile = f / FT, pos = f % FT;
       layer = (f == prev_frame) ? layer + 1 : 0; prev_frame = f;
-      if (out.empty() || out.back().tile != tile) out.push_back(TileSlots{tile, {}});
-      auto& L = out.back().layers;
-      while ((int)L.size() <= layer) L.emplace_back(FT, -1);
-      L[layer][pos] = (int32_t)sl;
+      if (tile != cur_tile) { cur_tile = tile; tile_first = g_tile.size(); }
+      while (g_tile.size() - tile_first <= (size_t)layer) {    // a new layer of this tile
+        g_tile.push_back(tile);
+        g_rows.insert(g_rows.end(), FT, (int32_t)NS);   // NS = the all-zero record behind the last slot: "not observed"
+      }
+      g_rows[(tile_first + layer) * FT + pos] = (int32_t)sl;
     }
-  };
+    pt_group[j + 1] = (int64_t)g_tile.size();
+  }
   const bool dense_keys = (int64_t)nt * nt <= (int64_t)1 << 26;
   std::vector<int64_t> dense_cnt; std::unordered_map<int64_t, int64_t> sparse_cnt;
   if (dense_keys) dense_cnt.assign((size_t)nt * nt, -1);
@@ -163,12 +177,20 @@ int32_t build_solver(rsba_handle* h) {
   if (!h->union_mask.empty())                                  // multi-GPU: tiles other ranks fill, so all ranks share one layout
     for (int a = 0; a < FR; ++a) for (int b = 0; b <= a; ++b) if (h->union_mask[(size_t)a * FR + b]) bump(a / FT, b / FT, 0);
   for (int v = 0; v < NPF; ++v) for (int b = 0; b < FR + v; ++b) bump((FR + v) / FT, b / FT, 0);   // the intrinsics border is dense
-  std::vector<TileSlots> ptiles;
-  for (int j = 0; j < M; ++j) {
-    tiles_of(j, ptiles);
-    for (size_t x = 0; x < ptiles.size(); ++x) for (size_t y = 0; y <= x; ++y)
-      bump(ptiles[x].tile, ptiles[y].tile, (int64_t)ptiles[x].layers.size() * ptiles[y].layers.size());
-  }
+  // entries of point j: every pair of its tiles (X >= Y) times every combination of their layers — for X == Y both
+  // orders of two different layers (the diagonal tile pair is stored in full)
+  auto for_each_entry = [&](int j, auto&& fn) {
+    for (int64_t xa = pt_group[j]; xa < pt_group[j + 1];) {
+      int64_t xb = xa; while (xb < pt_group[j + 1] && g_tile[xb] == g_tile[xa]) ++xb;
+      for (int64_t ya = pt_group[j]; ya < xb;) {
+        int64_t yb = ya; while (yb < pt_group[j + 1] && g_tile[yb] == g_tile[ya]) ++yb;
+        for (int64_t gx = xa; gx < xb; ++gx) for (int64_t gy = ya; gy < yb; ++gy) fn(gx, gy);
+        ya = yb;
+      }
+      xa = xb;
+    }
+  };
+  for (int j = 0; j < M; ++j) for_each_entry(j, [&](int64_t gx, int64_t gy) { bump(g_tile[gx], g_tile[gy], 1); });
   std::vector<int32_t> tp_I, tp_J; std::vector<int64_t> tp_ptr(1, 0);
   std::unordered_map<int64_t, int32_t> tp_index; std::vector<int32_t> dense_index;
   if (dense_keys) {
@@ -186,24 +208,16 @@ int32_t build_solver(rsba_handle* h) {
   }
   auto index_of = [&](int I, int J) -> int32_t { return dense_keys ? dense_index[(size_t)I * nt + J] : tp_index[(int64_t)I * nt + J]; };
   const int64_t nent = tp_ptr.back();
-  std::vector<int32_t> ent_slots((size_t)nent * ES), ent_pt(nent);
+  // an entry is the pair of groups (of tile I, of tile J) plus its point: the kernel looks the slots up in g_rows
+  std::vector<int32_t> ent_groups((size_t)nent * 2), ent_pt(nent);
   {
     std::vector<int64_t> fill(tp_ptr.begin(), tp_ptr.end() - 1);
-    for (int j = 0; j < M; ++j) {
-      tiles_of(j, ptiles);
-      for (size_t x = 0; x < ptiles.size(); ++x) for (size_t y = 0; y <= x; ++y) {
-        int64_t& w = fill[index_of(ptiles[x].tile, ptiles[y].tile)];
-        for (size_t lx = 0; lx < ptiles[x].layers.size(); ++lx) for (size_t ly = 0; ly < ptiles[y].layers.size(); ++ly) {
-          for (int q = 0; q < FT; ++q) {
-            const int32_t a_ = ptiles[x].layers[lx][q], b_ = ptiles[y].layers[ly][q];
-            ent_slots[(size_t)w * ES + q] = a_ >= 0 ? a_ : (int32_t)NS;          // NS = the all-zero record behind the last slot
-            ent_slots[(size_t)w * ES + FT + q] = b_ >= 0 ? b_ : (int32_t)NS;
-          }
-          ent_pt[w] = j | ((x == y && lx == ly) ? (int32_t)0x80000000 : 0);   // top bit: the entry carries the rhs term P z
-          ++w;
-        }
-      }
-    }
+    for (int j = 0; j < M; ++j)
+      for_each_entry(j, [&](int64_t gx, int64_t gy) {
+        const int64_t w = fill[index_of(g_tile[gx], g_tile[gy])]++;
+        ent_groups[2 * (size_t)w] = (int32_t)gx; ent_groups[2 * (size_t)w + 1] = (int32_t)gy;
+        ent_pt[w] = j | (gx == gy ? (int32_t)0x80000000 : 0);   // top bit: the entry carries the rhs term P z
+      });
   }
   std::vector<int32_t>().swap(dense_index);
   const int ntp = (int)tp_I.size();
@@ -212,6 +226,7 @@ int32_t build_solver(rsba_handle* h) {
   // ---- tile graph of S, fill-reducing / parallelism-exposing ordering, symbolic factorisation ----
   std::vector<std::vector<int32_t>> adj(nt);
   for (int t = 0; t < ntp; ++t) if (tp_I[t] != tp_J[t]) { adj[tp_I[t]].push_back(tp_J[t]); adj[tp_J[t]].push_back(tp_I[t]); }
+  tick("entries");
   // Nested dissection by BFS level structures (George): a video's co-visibility graph is a band, whose BFS
   // levels are band-wide separators; cutting it into independent segments turns the factorisation's
   // serial tile chain into a shallow elimination tree that the level-scheduled kernels run in parallel.
@@ -264,6 +279,7 @@ int32_t build_solver(rsba_handle* h) {
   }
   std::vector<int32_t> iperm(nt);
   for (int k = 0; k < nt; ++k) iperm[perm[k]] = k;
+  tick("ordering");
   // symbolic factorisation in the new order: col[k] = rows i > k of column k (after fill), row[j] = columns k < j of row j
   std::vector<std::vector<int32_t>> col(nt), row(nt);
   {
@@ -286,6 +302,7 @@ int32_t build_solver(rsba_handle* h) {
     return (it != col[k].end() && *it == i) ? slot_base[k] + 1 + (int32_t)(it - col[k].begin()) : -1;
   };
   s->last_diag_slot = slot_base[iperm[nt - 1]];      // the (possibly padded) last tile of the natural order
+  tick("symbolic");
   // level schedule: column j is ready once every column of row[j] is done
   std::vector<int32_t> level(nt, 0);
   int nlev = 0;
@@ -360,6 +377,7 @@ int32_t build_solver(rsba_handle* h) {
   }
   for (int l = nlev - 1; l >= 0; --l)
     for (int d = s->lev_diag_ptr[l]; d < s->lev_diag_ptr[l + 1]; ++d) { s->tasks.push_back(kTaskBack); s->tasks.push_back(d); }
+  tick("tasks");
   // Chunks of the Schur kernel (one workgroup each): at most kSchurChunk consecutive entries of one tile pair.
   // The points of tile row I are cut into blocks of kSchurChunk (the entry list of the diagonal pair (I, I) holds
   // them all), every pair (I, J) of the row is cut at the same point boundaries, and the chunks are numbered
@@ -437,6 +455,7 @@ int32_t build_solver(rsba_handle* h) {
     }
   }
 
+  tick("chunks");
   // which coordinates belong to the reduced program (for |x| and |step|): blocks that are not constant
   // and are touched by at least one residual block
   std::vector<double> inprog_pose((size_t)FR * CD, 0.0), inprog_point((size_t)M * 3, 0.0), inprog_intr((size_t)std::max(NPF, 1) * CD, 0.0);
@@ -470,7 +489,8 @@ int32_t build_solver(rsba_handle* h) {
   if ((rc = s_upload_const(s, &sv.tp_I, tp_I))) return rc;
   if ((rc = s_upload_const(s, &sv.tp_J, tp_J))) return rc;
   if ((rc = s_upload_const(s, &sv.tp_ptr, tp_ptr))) return rc;
-  if ((rc = s_upload_const(s, &sv.ent_slots, ent_slots))) return rc;
+  if ((rc = s_upload_const(s, &sv.ent_groups, ent_groups))) return rc;
+  if ((rc = s_upload_const(s, &sv.group_slots, g_rows))) return rc;
   if ((rc = s_upload_const(s, &sv.ent_pt, ent_pt))) return rc;
   if ((rc = s_upload_const(s, &sv.inprog_pose, inprog_pose))) return rc;
   if ((rc = s_upload_const(s, &sv.inprog_point, inprog_point))) return rc;
@@ -508,6 +528,7 @@ int32_t build_solver(rsba_handle* h) {
   if ((rc = s_upload(s, &s->d_back_ptr, s->back_ptr))) return rc;
   if ((rc = s_upload(s, &s->d_back_list, s->back_list))) return rc;
 
+  tick("uploads");
   const size_t REC = 2 + 2 * (size_t)dp.K;
   if ((rc = s_alloc(s, &h->dp.rec, (size_t)N * REC))) return rc;
   h->dp.obs_slot = s->d_obs_slot;
@@ -570,6 +591,10 @@ int32_t build_solver(rsba_handle* h) {
   if (std::getenv("RSBA_CHOL_TRACE")) { if ((rc = s_alloc(s, &s->d_trace, 8 * (size_t)pl.ntasks))) return rc; }
   pl.trace = s->d_trace;
   if (std::getenv("RSBA_DEBUG_PLAN"))
+    tick("allocations");
+  if (dbg_plan)
+    std::fprintf(stderr, "[rsba plan] host phases:%s\n", phases.c_str());
+  if (dbg_plan)
     std::fprintf(stderr, "[rsba plan] tiles %d, factor tiles %d, levels %d, tasks %d (partials %d); tile pairs %d, entries %lld, schur chunks %d\n", nt, sv.nslots,
                  s->nlev, pl.ntasks, parts, sv.ntp, (long long)s->num_pairs, sv.nchunk);
   const char* lv = std::getenv("RSBA_CHOL_LEVELS");

@@ -41,7 +41,8 @@ struct SolverDev {
   const int32_t* tp_I;          // [ntp]
   const int32_t* tp_J;
   const int64_t* tp_ptr;        // [ntp+1] into the entry list
-  const int32_t* ent_slots;     // [nent][2*FT] observation slot of the point in each frame of tile I, then of tile J (-1 none)
+  const int32_t* ent_groups;    // [nent][2] the point's (tile, layer) group on the I side and on the J side
+  const int32_t* group_slots;   // [groups][FT] observation slot of the point in each frame of the group's tile (the zero record if none)
   const int32_t* ent_pt;        // [nent] point index; top bit set = the entry carries the rhs term P z
   int schur_linear;             // debugging (RSBA_SCHUR_LINEAR=1): blockIdx -> chunk without the XCD map
   int nchunk;                   // workgroups of the Schur kernel: kSchurChunk entries each
