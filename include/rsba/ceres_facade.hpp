@@ -176,6 +176,7 @@ struct Solver {
     double min_relative_decrease = 1e-3, min_lm_diagonal = 1e-6, max_lm_diagonal = 1e32;
     double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
     int device = 0;   // extension: HIP device ordinal (one process per GPU)
+    bool level_scheduled_cholesky = false;   // extension: see rsba_solver_options
   };
   struct Summary {
     TerminationType termination_type = FAILURE;
@@ -406,6 +407,7 @@ inline void Solve(const Solver::Options& options, Problem* problem, Solver::Summ
   o.min_trust_region_radius = options.min_trust_region_radius; o.min_relative_decrease = options.min_relative_decrease;
   o.min_lm_diagonal = options.min_lm_diagonal; o.max_lm_diagonal = options.max_lm_diagonal;
   o.function_tolerance = options.function_tolerance; o.gradient_tolerance = options.gradient_tolerance; o.parameter_tolerance = options.parameter_tolerance;
+  o.level_scheduled_cholesky = options.level_scheduled_cholesky ? 1 : 0;
   rsba_solver_summary s;
   std::vector<rsba_iteration> trace((size_t)options.max_num_iterations + 2);
   st = rsba_solve(h, &o, &s, trace.data(), (int32_t)trace.size());

@@ -80,6 +80,10 @@ typedef struct rsba_solver_options {
   double function_tolerance;                /* 1e-6 */
   double gradient_tolerance;                /* 1e-10 */
   double parameter_tolerance;               /* 1e-8 */
+  int32_t level_scheduled_cholesky;         /* 0.  1 = factor the reduced camera system with one launch per elimination
+                                             * level instead of the persistent task-DAG kernel (same arithmetic, same results,
+                                             * no communication between workgroups inside a launch; slower) */
+  int32_t reserved;
 } rsba_solver_options;
 
 enum { RSBA_CONVERGENCE = 0, RSBA_NO_CONVERGENCE = 1, RSBA_FAILURE = 2 };   /* ceres::TerminationType subset */

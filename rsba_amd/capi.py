@@ -52,6 +52,7 @@ class SolverOptions(C.Structure):
         ("min_trust_region_radius", C.c_double), ("min_relative_decrease", C.c_double),
         ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
         ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
+        ("level_scheduled_cholesky", C.c_int32), ("reserved", C.c_int32),
     ]
 
 

@@ -337,6 +337,7 @@ void rsba_default_solver_options(rsba_solver_options* o) {
   o->initial_trust_region_radius = 1e4; o->max_trust_region_radius = 1e16; o->min_trust_region_radius = 1e-32;
   o->min_relative_decrease = 1e-3; o->min_lm_diagonal = 1e-6; o->max_lm_diagonal = 1e32;
   o->function_tolerance = 1e-6; o->gradient_tolerance = 1e-10; o->parameter_tolerance = 1e-8;
+  o->level_scheduled_cholesky = 0; o->reserved = 0;
 }
 
 }  // extern "C"

@@ -820,6 +820,7 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
   if (rc) return rc;
   Solver* s = h->solver; SolverDev& sv = s->sv; DeviceProblem& dp = h->dp; hipStream_t st = h->stream;
   sum->termination_type = RSBA_NO_CONVERGENCE;
+  { const char* lv = std::getenv("RSBA_CHOL_LEVELS"); s->use_levels = opt->level_scheduled_cholesky != 0 || (lv && lv[0] == '1'); }
   {
     // problem-size figures of the whole (all-rank) problem
     double cnt[3] = {(double)dp.N, (double)s->num_reduced_blocks, (double)s->num_reduced_params};

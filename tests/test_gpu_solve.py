@@ -223,14 +223,14 @@ def test_dag_cholesky_equals_the_level_schedule(capi, monkeypatch, config, share
     stale read or a flag raised before its data would show up here."""
     from rsba_amd.scene import make_config
     out = {}
+    monkeypatch.delenv("RSBA_CHOL_LEVELS", raising=False)
     for mode in ("0", "1"):
-        monkeypatch.setenv("RSBA_CHOL_LEVELS", mode)
         p = make_config(config).problem
         if shared_intrinsics:
             p.calibrated = False
             p.huber_a = 2.0
         with capi.DeviceProblem(p) as dp:
-            s, _ = dp.solve(capi.default_options(max_num_iterations=6))
+            s, _ = dp.solve(capi.default_options(max_num_iterations=6, level_scheduled_cholesky=int(mode)))
         out[mode] = (s.final_cost, s.num_iterations, p.poses.copy(), p.points.copy(), p.intrinsics.copy())
     a, b = out["0"], out["1"]
     assert a[0] == b[0] and a[1] == b[1]
