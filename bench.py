@@ -64,7 +64,7 @@ def main():
     ap.add_argument("--config", default="C4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lm", action="store_true")
-    ap.add_argument("--lm-iters", type=int, default=6)
+    ap.add_argument("--lm-iters", type=int, default=12)
     args = ap.parse_args()
 
     import torch

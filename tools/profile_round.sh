@@ -6,8 +6,8 @@ R=${1:-r01}
 OUT=gpurun_out/$R
 mkdir -p $OUT
 export TMPDIR=/tmp
-B="python bench.py --steps 30 --warmup 5 --no-cpu-baseline --lm-iters 6"
-python bench.py --steps 50 --warmup 5 --lm-iters 8 > $OUT/bench.json 2> $OUT/bench.err
+B="python bench.py --steps 30 --warmup 5 --no-cpu-baseline --lm-iters 12"
+python bench.py --steps 50 --warmup 5 --lm-iters 12 > $OUT/bench.json 2> $OUT/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $B > $OUT/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o f -- $B --no-lm > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o w -- $B --no-lm > $OUT/pmc_write.log 2>&1
