@@ -73,9 +73,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # test hook (one-GPU boxes): RSBA_BENCH_TEST_ONE_GPU=1 runs every rank on device 0 over gloo, which exercises the
+    # whole multi-rank flow of this script (sharded scenes, exchange callback, watchdog) without several GPUs
+    one_gpu = os.environ.get("RSBA_BENCH_TEST_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from rsba_amd import capi
     from rsba_amd.scene import SEED, make_config
@@ -84,7 +92,7 @@ def main():
     prob = sc.problem
     if world > 1:
         # cameras are replicated: every rank starts from rank 0's (perturbed) poses
-        t = torch.from_numpy(prob.poses).cuda()
+        t = torch.from_numpy(prob.poses).to("cpu" if one_gpu else "cuda")
         dist.broadcast(t, src=0)
         prob.poses[:] = t.cpu().numpy()
     dp = capi.DeviceProblem(prob, device=local_rank)
@@ -109,8 +117,9 @@ def main():
         dp.evaluate_device(True)
     barrier()
     elapsed = time.perf_counter() - t0
-    n_obs = torch.tensor([float(prob.num_observations)], device="cuda")
-    t_max = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+    cdev = "cpu" if one_gpu else "cuda"
+    n_obs = torch.tensor([float(prob.num_observations)], device=cdev)
+    t_max = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(n_obs, op=dist.ReduceOp.SUM)
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
