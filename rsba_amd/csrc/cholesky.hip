@@ -41,13 +41,13 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
-constexpr int NB = 12;   // inner block: one rolling-shutter camera block
+constexpr int NB = 16;   // panel width of the tile factorisation: one MFMA block column
 typedef double dbl4_t __attribute__((ext_vector_type(4)));
 
 // Factor the T x T tile held in LDS (lower triangle, pitch TP) in place: blocked right-looking Cholesky.
-// Each 12-column panel is factored by the first wave entirely in registers (lane = row, pivot rows
+// Each 16-column panel is factored by the first wave entirely in registers (lane = row, pivot rows
 // broadcast with v_readlane, 1/sqrt instead of sqrt + divide: no LDS round trips or barriers on the
-// serial chain); the rank-12 trailing update runs on the matrix pipe, its blocks dealt to the four waves.
+// serial chain); the rank-16 trailing update runs on the matrix pipe, its blocks dealt to the four waves.
 // All threads must call.
 // Returns false (in the first wave) on a non-positive pivot.
 __device__ __forceinline__ bool potrf_blocked(double* A, int tid) {
@@ -79,8 +79,8 @@ __device__ __forceinline__ bool potrf_blocked(double* A, int tid) {
       }
     }
     __syncthreads();
-    // rank-12 trailing update A[r][c] -= sum_m L[r][c0 + m] L[c][c0 + m] for c0 + 12 <= c <= r on the matrix pipe
-    // (K = 12 = three MFMA steps): the 16 x 16 blocks of the tile grid that reach into the trailing part are
+    // rank-16 trailing update A[r][c] -= sum_m L[r][c0 + m] L[c][c0 + m] for c0 + 12 <= c <= r on the matrix pipe
+    // (K = 16 = four MFMA steps): the 16 x 16 blocks of the tile grid that reach into the trailing part are
     // dealt to the waves, products formed in full and subtracted under a mask.
     if (c0 + NB < T) {
       const int wave = tid >> 6, lane = tid & 63, mi = lane & 15, mg = lane >> 4;
