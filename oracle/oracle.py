@@ -34,6 +34,8 @@ class OrcProblem(C.Structure):
         ("frame_intrinsics", C.c_void_p), ("obs_xy", C.c_void_p), ("obs_frame", C.c_void_p),
         ("obs_point", C.c_void_p), ("pose_fixed_mask", C.c_void_p), ("point_constant", C.c_void_p),
         ("intrinsics_constant", C.c_void_p), ("huber_a", C.c_double),
+        ("prior_kind", C.c_int32), ("num_priors", C.c_int32), ("prior_frames", C.c_void_p),
+        ("prior_scale", C.c_double), ("inter_frame_ratio", C.c_double),
     ]
 
 
@@ -105,6 +107,10 @@ def desc(prob) -> OrcProblem:
     d.point_constant = _ptr(prob.point_constant)
     d.intrinsics_constant = _ptr(prob.intrinsics_constant)
     d.huber_a = float(prob.huber_a)
+    d.prior_kind = int(prob.prior_kind) if prob.prior_frames is not None and len(prob.prior_frames) else 0
+    d.num_priors = 0 if d.prior_kind == 0 else len(prob.prior_frames)
+    d.prior_frames = _ptr(prob.prior_frames) if d.prior_kind else None
+    d.prior_scale, d.inter_frame_ratio = float(prob.prior_scale), float(prob.inter_frame_ratio)
     d._keep = prob  # keep arrays alive
     return d
 

@@ -64,6 +64,59 @@ bool block_eval(const orc_problem* p, int64_t i, double* r, double* J /* [2][K] 
   return true;
 }
 
+// RsConstVeloPrior::operator() (video_bundler_rs_inter.h:63-93) and RsConstAccelerationPrior::operator()
+// (:121-158) restated, coordinate by coordinate in the reference's order of operations.  cur0/cur1 = the two poses
+// of frame f, prev0/prev1 = those of frame f-1.  Returns the functor's validity flag.
+template <class T>
+bool motion_prior(int kind, const T& ratio, double scale, const T* cur0, const T* cur1, const T* prev0, const T* prev1, T* res) {
+  for (int i = 0; i < 6; ++i) {
+    if (kind == 1) {
+      // constant velocity: frame start against prev1 + ratio (prev1 - prev0) ...
+      T d = prev1[i] - prev0[i];
+      d = d * ratio;
+      d = prev1[i] + d;
+      res[i] = cur0[i] - d;
+      // ... and frame end against cur0 + (cur0 - prev1) / ratio (ratio > eps), else cur0 + (prev1 - prev0)
+      T e;
+      if (ratio > kEps) { e = cur0[i] - prev1[i]; e = e * (T(1.0) / ratio); }
+      else e = prev1[i] - prev0[i];
+      e = cur0[i] + e;
+      res[6 + i] = cur1[i] - e;
+    } else {
+      // constant acceleration: x' = x_-1 + v_-1 t + a t^2 / 2 with a t^2 = v t - v_-1 t
+      T vt = cur0[i] - prev1[i];
+      T v1t = (prev1[i] - prev0[i]) * ratio;
+      T h = (vt - v1t) * T(0.5);
+      h = v1t + h;
+      h = prev1[i] + h;
+      res[i] = cur0[i] - h;
+      T v = cur1[i] - cur0[i];
+      T w = (cur0[i] - prev1[i]) * (T(1.0) / ratio);
+      T g = (v - w) * T(0.5);
+      g = w + g;
+      g = cur0[i] + g;
+      res[6 + i] = cur1[i] - g;
+    }
+  }
+  for (int i = 0; i < 12; ++i) res[i] = res[i] * T(scale);
+  for (int i = 0; i < 3; ++i) { res[i] = res[i] * T(0.01); res[6 + i] = res[6 + i] * T(0.01); }   // down-scaled rotation rows
+  return kind == 1 ? !(ratio < 0.0) : !(ratio < kEps);
+}
+
+// AutoDiffCostFunction<Rs...Prior,12,1,6,6,6,6>::Evaluate with the ratio block constant (null Jacobian):
+// r[12], J[12][24] over the columns [f.poses[0] | f.poses[1] | f-1.poses[0] | f-1.poses[1]]
+bool prior_eval(const orc_problem* p, int k, double* r, double* J) {
+  const int f = p->prior_frames[k];
+  const double* cur = p->poses + (size_t)f * 12; const double* prev = p->poses + (size_t)(f - 1) * 12;
+  if (!J) return motion_prior<double>(p->prior_kind, p->inter_frame_ratio, p->prior_scale, cur, cur + 6, prev, prev + 6, r);
+  typedef Dual<24> D;
+  D x[24], res[12];
+  for (int c = 0; c < 12; ++c) { x[c] = D(cur[c], c); x[12 + c] = D(prev[c], 12 + c); }
+  if (!motion_prior<D>(p->prior_kind, D(p->inter_frame_ratio), p->prior_scale, x, x + 6, x + 12, x + 18, res)) return false;
+  for (int i = 0; i < 12; ++i) { r[i] = res[i].a; for (int c = 0; c < 24; ++c) J[i * 24 + c] = res[i].v[c]; }
+  return true;
+}
+
 typedef bool (*block_fn)(const orc_problem*, int64_t, double*, double*);
 block_fn pick_block_fn(const Layout& L) {
   if (L.cal) return L.P == 2 ? block_eval<true, 2> : block_eval<true, 1>;
@@ -125,6 +178,10 @@ struct Eval {
   std::vector<uint8_t> dropped;       // residual block with every parameter block constant
   std::vector<uint8_t> colmask;       // per parameter column (global numbering) 1 = fixed
   int64_t ncam, nparam;               // camera-side unknowns (poses + intrinsics), all unknowns
+  // motion-prior blocks: corrected residuals [NP][12], Jacobian [NP][12][24], dropped flags
+  int NP = 0; std::vector<double> pr, pJ; std::vector<uint8_t> pdropped;
+  // global column of local column c of prior k
+  inline int64_t pcol(int k, int c) const { const int f = p->prior_frames[k]; return c < 12 ? (int64_t)f * 12 + c : (int64_t)(f - 1) * 12 + (c - 12); }
   Eval(const orc_problem* pp) : p(pp), L(layout_of(pp)) {
     N = p->num_observations; F = p->num_frames; M = p->num_points; NI = p->num_intrinsics;
     ncam = (int64_t)F * L.CD + (L.cal ? 0 : (int64_t)NI * 9);
@@ -145,6 +202,9 @@ struct Eval {
       // a block is constant only if all 6 coordinates are fixed; a partially fixed pose keeps the residual
       dropped[i] = all_const;
     }
+    NP = (p->prior_kind != 0 && L.P == 2) ? p->num_priors : 0;
+    pdropped.assign(NP, 0);
+    for (int k = 0; k < NP; ++k) { bool all_const = true; for (int c = 0; c < 24 && all_const; ++c) if (!colmask[pcol(k, c)]) all_const = false; pdropped[k] = all_const; }
   }
   // global column of local column k of observation i
   inline int64_t gcol(int64_t i, int k) const {
@@ -190,9 +250,40 @@ struct Eval {
       }
       if (Ji) for (int k = 0; k < K; ++k) if (colmask[gcol(i, k)]) { Ji[k] = 0.0; Ji[K + k] = 0.0; }
     }
+    pr.resize((size_t)12 * NP); if (want_jac) pJ.resize((size_t)12 * 24 * NP);
+    for (int k = 0; k < NP; ++k) {
+      double* rk = &pr[(size_t)12 * k]; double* Jk = want_jac ? &pJ[(size_t)288 * k] : nullptr;
+      if (!prior_eval(p, k, rk, Jk)) { ++bad; continue; }
+      double s = 0.0; for (int i = 0; i < 12; ++i) s += rk[i] * rk[i];
+      double rho[3] = {s, 1.0, 0.0};
+      if (p->huber_a > 0.0) huber(p->huber_a, s, rho);
+      if (pdropped[k]) cf += 0.5 * rho[0]; else c += 0.5 * rho[0];
+      if (p->huber_a > 0.0) {   // the same corrector, 12 rows
+        const double sr1 = std::sqrt(rho[1]);
+        double rscale = sr1, alpha_sq = 0.0;
+        if (!(s == 0.0 || rho[2] <= 0.0)) { const double alpha = 1.0 - std::sqrt(1.0 + 2.0 * s * rho[2] / rho[1]); rscale = sr1 / (1.0 - alpha); alpha_sq = alpha / s; }
+        if (Jk) for (int cc = 0; cc < 24; ++cc) {
+          double rtj = 0.0; for (int i = 0; i < 12; ++i) rtj += Jk[i * 24 + cc] * rk[i];
+          for (int i = 0; i < 12; ++i) Jk[i * 24 + cc] = sr1 * (Jk[i * 24 + cc] - alpha_sq * rk[i] * rtj);
+        }
+        for (int i = 0; i < 12; ++i) rk[i] *= rscale;
+      }
+      if (Jk) for (int cc = 0; cc < 24; ++cc) if (colmask[pcol(k, cc)]) for (int i = 0; i < 12; ++i) Jk[i * 24 + cc] = 0.0;
+    }
     if (cost) *cost = c;
     if (fixed) *fixed = cf;
     return bad == 0;
+  }
+  // J^T r and J^T J contributions of the prior blocks, entry by entry
+  template <class FG, class FH> void prior_normal(FG&& g, FH&& h) const {
+    for (int k = 0; k < NP; ++k) {
+      const double* Jk = &pJ[(size_t)288 * k]; const double* rk = &pr[(size_t)12 * k];
+      for (int a = 0; a < 24; ++a) {
+        double ga = 0.0; for (int i = 0; i < 12; ++i) ga += Jk[i * 24 + a] * rk[i];
+        g(pcol(k, a), ga);
+        for (int b = 0; b < 24; ++b) { double hab = 0.0; for (int i = 0; i < 12; ++i) hab += Jk[i * 24 + a] * Jk[i * 24 + b]; if (hab != 0.0) h(pcol(k, a), pcol(k, b), hab); }
+      }
+    }
   }
 };
 
@@ -262,6 +353,7 @@ bool reduced_system(const Eval& E, const PointCsr& pc, const std::vector<double>
       for (int b = 0; b < KC; ++b) S[ga * nc + E.gcol(i, b)] += Ji[a] * Ji[b] + Ji[K + a] * Ji[K + b];
     }
   }
+  E.prior_normal([&](int64_t a, double v) { rhs[a] += v; }, [&](int64_t a, int64_t b, double v) { S[a * nc + b] += v; });
   for (int64_t a = 0; a < nc; ++a) S[a * nc + a] += D2[a];
   Vinv.assign((size_t)9 * M, 0.0); bp.assign((size_t)3 * M, 0.0);
   bool ok = true;
@@ -408,6 +500,7 @@ int32_t orc_evaluate(const orc_problem* p, double* cost, double* gradient) {
     std::vector<double> g(E.nparam, 0.0);
     for (int64_t i = 0; i < E.N; ++i) for (int k = 0; k < E.L.K; ++k)
       g[E.gcol(i, k)] += E.J[(size_t)2 * E.L.K * i + k] * E.r[2 * i] + E.J[(size_t)2 * E.L.K * i + E.L.K + k] * E.r[2 * i + 1];
+    E.prior_normal([&](int64_t a, double v) { g[a] += v; }, [](int64_t, int64_t, double) {});
     for (int64_t a = 0; a < npose; ++a) gradient[a] = g[a];
     for (int64_t a = 0; a < 3 * (int64_t)E.M; ++a) gradient[npose + a] = g[E.ncam + a];
     if (!E.L.cal) for (int64_t a = 0; a < 9 * (int64_t)E.NI; ++a) gradient[npose + 3 * (int64_t)E.M + a] = g[npose + a];
@@ -433,6 +526,9 @@ int32_t orc_normal_equations(const orc_problem* p, double* U, double* gc, double
       for (int b = 0; b < 3; ++b) V[(size_t)j * 9 + 3 * a + b] += Ji[CD + a] * Ji[CD + b] + Ji[K + CD + a] * Ji[K + CD + b];
     }
   }
+  // motion priors: their share of the block diagonal (the frame-to-frame cross blocks are not part of this output)
+  E.prior_normal([&](int64_t a, double v) { gc[a] += v; },
+                 [&](int64_t a, int64_t b, double v) { if (a / CD == b / CD) U[(size_t)(a / CD) * CD * CD + (a % CD) * CD + (b % CD)] += v; });
   return 0;
 }
 
@@ -445,8 +541,9 @@ int32_t orc_solve(orc_problem* p, const orc_options* opt, orc_summary* sum, orc_
   const PointCsr pc = point_csr(p);
   std::memset(sum, 0, sizeof *sum);
   sum->termination_type = ORC_NO_CONVERGENCE;
-  sum->num_residual_blocks = (int32_t)N;
+  sum->num_residual_blocks = (int32_t)(N + E.NP);
   int64_t nred = 0; for (int64_t i = 0; i < N; ++i) nred += !E.dropped[i];
+  for (int k = 0; k < E.NP; ++k) nred += !E.pdropped[k];
   sum->num_residual_blocks_reduced = (int32_t)nred;
   // which parameter BLOCKS are in the reduced program (non-constant): used for |x| and |step|
   std::vector<uint8_t> in_program(np, 0);
@@ -461,6 +558,7 @@ int32_t orc_solve(orc_problem* p, const orc_options* opt, orc_summary* sum, orc_
     // pose blocks / intrinsics that no residual touches are not part of the problem
     std::vector<uint8_t> touched(np, 0);
     for (int64_t i = 0; i < N; ++i) for (int k = 0; k < K; ++k) touched[E.gcol(i, k)] = 1;
+    for (int k = 0; k < E.NP; ++k) for (int c = 0; c < 24; ++c) touched[E.pcol(k, c)] = 1;
     for (int64_t a = 0; a < np; ++a) if (!touched[a]) in_program[a] = 0;
   }
   int64_t nfree = 0; for (int64_t a = 0; a < np; ++a) nfree += (in_program[a] && !E.colmask[a]);
@@ -477,14 +575,17 @@ int32_t orc_solve(orc_problem* p, const orc_options* opt, orc_summary* sum, orc_
     g.assign(np, 0.0);
     for (int64_t i = 0; i < N; ++i) for (int k = 0; k < K; ++k)
       g[E.gcol(i, k)] += E.J[(size_t)2 * K * i + k] * E.r[2 * i] + E.J[(size_t)2 * K * i + K + k] * E.r[2 * i + 1];
+    E.prior_normal([&](int64_t a, double v) { g[a] += v; }, [](int64_t, int64_t, double) {});
   };
   auto scale_cols = [&](const std::vector<double>& sc) {
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < N; ++i) for (int k = 0; k < K; ++k) { const double s = sc[E.gcol(i, k)]; E.J[(size_t)2 * K * i + k] *= s; E.J[(size_t)2 * K * i + K + k] *= s; }
+    for (int k = 0; k < E.NP; ++k) for (int c = 0; c < 24; ++c) { const double s = sc[E.pcol(k, c)]; for (int i = 0; i < 12; ++i) E.pJ[(size_t)288 * k + i * 24 + c] *= s; }
   };
   auto col_sq_norms = [&](std::vector<double>& d) {
     d.assign(np, 0.0);
     for (int64_t i = 0; i < N; ++i) for (int k = 0; k < K; ++k) { const double a = E.J[(size_t)2 * K * i + k], b = E.J[(size_t)2 * K * i + K + k]; d[E.gcol(i, k)] += a * a + b * b; }
+    for (int k = 0; k < E.NP; ++k) for (int c = 0; c < 24; ++c) for (int i = 0; i < 12; ++i) { const double a = E.pJ[(size_t)288 * k + i * 24 + c]; d[E.pcol(k, c)] += a * a; }
   };
   int ntrace = 0;
   auto push = [&](const orc_iteration& it) { if (trace && ntrace < trace_cap) trace[ntrace] = it; ++ntrace; sum->num_iterations = ntrace; };
@@ -503,7 +604,7 @@ int32_t orc_solve(orc_problem* p, const orc_options* opt, orc_summary* sum, orc_
   if (opt->jacobi_scaling) { std::vector<double> d; col_sq_norms(d); for (int64_t a = 0; a < np; ++a) scale[a] = 1.0 / (1.0 + std::sqrt(d[a])); scale_cols(scale); }
   push(it);
 
-  std::vector<double> diagonal, D2(np), y, x_save(np), r_cur, J_cur;
+  std::vector<double> diagonal, D2(np), y, x_save(np), r_cur, J_cur, pr_cur;
   int invalid_streak = 0; int iteration = 0;
   while (true) {
     if (iteration >= opt->max_num_iterations) { sum->termination_type = ORC_NO_CONVERGENCE; break; }
@@ -523,6 +624,11 @@ int32_t orc_solve(orc_problem* p, const orc_options* opt, orc_summary* sum, orc_
         for (int k = 0; k < K; ++k) { const double s = -y[E.gcol(i, k)]; m0 += E.J[(size_t)2 * K * i + k] * s; m1 += E.J[(size_t)2 * K * i + K + k] * s; }
         acc += m0 * (E.r[2 * i] + 0.5 * m0) + m1 * (E.r[2 * i + 1] + 0.5 * m1);
       }
+      for (int k = 0; k < E.NP; ++k) for (int i = 0; i < 12; ++i) {
+        double m = 0.0;
+        for (int c = 0; c < 24; ++c) m += E.pJ[(size_t)288 * k + i * 24 + c] * -y[E.pcol(k, c)];
+        acc += m * (E.pr[(size_t)12 * k + i] + 0.5 * m);
+      }
       model_cost_change = -acc;
       valid = model_cost_change >= 0.0;   // Ceres: invalid iff model_cost_change < 0
     }
@@ -538,10 +644,10 @@ int32_t orc_solve(orc_problem* p, const orc_options* opt, orc_summary* sum, orc_
       double step_sq = 0.0;
       for (int64_t a = 0; a < np; ++a) { x_save[a] = *param_ptr(a); const double d = -y[a] * scale[a]; if (in_program[a] && !E.colmask[a]) { *param_ptr(a) = x_save[a] + d; const double e = x_save[a] - *param_ptr(a); step_sq += e * e; } }
       // keep the current linearisation; evaluate residuals only at the candidate
-      r_cur.swap(E.r); J_cur.swap(E.J);
+      r_cur.swap(E.r); J_cur.swap(E.J); pr_cur.swap(E.pr);
       double new_cost = 0, new_fixed = 0;
       const bool ev_ok = E.run(false, &new_cost, &new_fixed);
-      E.r.swap(r_cur); E.J.swap(J_cur);
+      E.r.swap(r_cur); E.J.swap(J_cur); E.pr.swap(pr_cur);
       if (!ev_ok) new_cost = std::numeric_limits<double>::max();
       it.step_norm = std::sqrt(step_sq);
       const double step_tol = opt->parameter_tolerance * (x_norm + opt->parameter_tolerance);

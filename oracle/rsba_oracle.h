@@ -32,6 +32,14 @@ typedef struct orc_problem {
   const uint8_t* point_constant;    /* [M] */
   const uint8_t* intrinsics_constant; /* [NI] */
   double huber_a;                /* opt.ceres.huberLoss; <= 0 = no loss (CeresHandler.h:87-89) */
+  /* Frame-to-frame motion priors (CeresHandler.h:147-185) with opt.ceres.interFrameRatio != 1, i.e. the ratio block
+   * set constant (CeresHandler.h:175-177).  One 12-residual block per listed frame f >= 1 over the blocks
+   * (f.poses[0], f.poses[1], f-1.poses[0], f-1.poses[1]); the shared loss function applies to it (:155,:166). */
+  int32_t prior_kind;            /* 0 none, 1 RsConstVeloPrior, 2 RsConstAccelerationPrior (video_bundler_rs_inter.h:55-173) */
+  int32_t num_priors;
+  const int32_t* prior_frames;   /* [num_priors], strictly increasing, each >= 1 */
+  double prior_scale;            /* opt.ceres.constFrameVelocity / constFrameAcceleration */
+  double inter_frame_ratio;      /* opt.ceres.interFrameRatio */
 } orc_problem;
 
 /* Ceres 1.9 Solver::Options subset (defaults: SURVEY Appendix C.5) */

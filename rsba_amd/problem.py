@@ -37,6 +37,11 @@ class BAProblem:
     point_constant: Optional[np.ndarray] = None     # [M] uint8
     intrinsics_constant: Optional[np.ndarray] = None  # [NI] uint8
     huber_a: float = 0.0                # opt.ceres.huberLoss
+    # frame-to-frame motion priors with a constant interFrameRatio (CeresHandler.h:147-185)
+    prior_kind: int = 0                 # 0 none, 1 constFrameVelocity, 2 constFrameAcceleration
+    prior_frames: Optional[np.ndarray] = None   # [NP] int32, frames f >= 1 that carry a prior against frame f - 1
+    prior_scale: float = 0.0            # opt.ceres.constFrameVelocity / constFrameAcceleration
+    inter_frame_ratio: float = 1.0      # opt.ceres.interFrameRatio
 
     def __post_init__(self):
         self.poses = np.ascontiguousarray(self.poses, dtype=np.float64)
@@ -47,7 +52,7 @@ class BAProblem:
         self.obs_frame = np.ascontiguousarray(self.obs_frame, dtype=np.int32).reshape(-1)
         self.obs_point = np.ascontiguousarray(self.obs_point, dtype=np.int32).reshape(-1)
         assert len(self.obs_frame) == len(self.obs_point) == len(self.obs_xy)
-        for name, dt in (("frame_intrinsics", np.int32), ("pose_fixed_mask", np.uint8),
+        for name, dt in (("frame_intrinsics", np.int32), ("prior_frames", np.int32), ("pose_fixed_mask", np.uint8),
                          ("point_constant", np.uint8), ("intrinsics_constant", np.uint8)):
             v = getattr(self, name)
             if v is not None:

@@ -249,6 +249,27 @@ def tiny_scene(seed, F, M, rolling, huber_a, outliers):
                 obs_xy=xy, obs_frame=of.astype(np.int32), obs_point=op.astype(np.int32), huber_a=huber_a, rolling=rolling)
 
 
+def np_prior_residuals(poses, kind, scale, ratio, frames):
+    """Frame-to-frame motion priors (video_bundler_rs_inter.h:55-173) from their physical meaning:
+    the frame's first pose against the previous frame's last pose extrapolated over the inter-frame gap
+    (ratio = gap / exposure), the frame's last pose against its first pose extrapolated over the exposure —
+    with the previous velocity (kind 1) or with the mean of the previous and the current velocity (kind 2)."""
+    out = []
+    w = scale * np.array([0.01] * 3 + [1.0] * 3)
+    for f in frames:
+        start, end, pstart, pend = poses[f, 0], poses[f, 1], poses[f - 1, 0], poses[f - 1, 1]
+        if kind == 1:
+            r1 = start - (pend + ratio * (pend - pstart))
+            r2 = end - (start + (start - pend) / ratio)
+        else:
+            gap_prev, gap_now = ratio * (pend - pstart), start - pend          # displacement over the gap at either velocity
+            r1 = start - (pend + 0.5 * (gap_prev + gap_now))
+            exp_prev, exp_now = (start - pend) / ratio, end - start            # displacement over the exposure
+            r2 = end - (start + 0.5 * (exp_prev + exp_now))
+        out.append(np.concatenate([w * r1, w * r2]))
+    return np.array(out)
+
+
 def minimise(sc):
     """Gauge: frame 0 constant, translation of the last frame's last pose fixed.  Robust cost enters as
     r~ = r * sqrt(rho(s)/s) per 2-D block, so that 1/2 |r~|^2 = 1/2 rho(s) (Ceres' block-wise loss)."""
@@ -271,7 +292,15 @@ def minimise(sc):
             s = np.sum(r * r, axis=1)
             rho = np.where(s <= a * a, s, 2 * a * np.sqrt(np.maximum(s, 1e-300)) - a * a)
             r = r * np.sqrt(rho / np.maximum(s, 1e-300))[:, None]
-        return r.reshape(-1)
+        r = r.reshape(-1)
+        if sc.get("prior"):
+            pr = np_prior_residuals(poses, *sc["prior"])
+            if a > 0:   # the shared loss function acts on the 12-D block as a whole
+                s = np.sum(pr * pr, axis=1)
+                rho = np.where(s <= a * a, s, 2 * a * np.sqrt(np.maximum(s, 1e-300)) - a * a)
+                pr = pr * np.sqrt(rho / np.maximum(s, 1e-300))[:, None]
+            r = np.concatenate([r, pr.reshape(-1)])
+        return r
 
     x0 = np.concatenate([sc["poses"][free], sc["points"].reshape(-1)])
     sol = least_squares(fun, x0, method="trf", x_scale="jac", ftol=1e-15, xtol=1e-15, gtol=1e-15, max_nfev=400)
@@ -294,7 +323,28 @@ def solve_cases():
     return out
 
 
+def prior_solve_cases():
+    out = []
+    for name, seed, F, M, a, outl, kind, scale, ratio in (("rs_velocity", 21, 6, 60, 0.0, False, 1, 6.0, 0.8),
+                                                         ("rs_acceleration_huber", 22, 7, 70, 2.0, True, 2, 25.0, 1.25)):
+        sc = tiny_scene(seed, F, M, True, a, outl)
+        frames = list(range(1, F))
+        sc["prior"] = (kind, scale, ratio, frames)
+        res = minimise(sc)
+        res["prior_residuals_at_start"] = np_prior_residuals(sc["poses"], kind, scale, ratio, frames).tolist()
+        out.append(dict(name=name, rolling=True, huber_a=a, cam=sc["cam"].tolist(), scanlines=list(sc["scan"]), shutter=sc["shutter"],
+                        poses=sc["poses"].tolist(), points=sc["points"].tolist(), obs_xy=sc["obs_xy"].tolist(),
+                        obs_frame=sc["obs_frame"].tolist(), obs_point=sc["obs_point"].tolist(),
+                        prior_kind=kind, prior_scale=scale, inter_frame_ratio=ratio, prior_frames=frames, expected=res))
+        print(name, "obs", len(sc["obs_frame"]), "cost", res["initial_cost"], "->", res["final_cost"], "|g|inf", res["grad_inf"], file=sys.stderr)
+    return out
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "priors":   # only the motion-prior cases (added after the others were committed)
+        with open(os.path.join(HERE, "prior_solves.json"), "w") as f:
+            json.dump(prior_solve_cases(), f)
+        return
     with open(os.path.join(HERE, "per_observation.json"), "w") as f:
         json.dump(per_observation_cases(), f, indent=0)
     with open(os.path.join(HERE, "huber.json"), "w") as f:

@@ -51,6 +51,9 @@ def problem_from_solve_case(c) -> BAProblem:
     mask[0, :] = 0x3F
     mask[-1, -1] |= 0b111000
     prob.pose_fixed_mask = mask
+    if c.get("prior_kind"):
+        prob.prior_kind, prob.prior_scale, prob.inter_frame_ratio = c["prior_kind"], c["prior_scale"], c["inter_frame_ratio"]
+        prob.prior_frames = np.array(c["prior_frames"], dtype=np.int32)
     return prob
 
 

@@ -97,6 +97,37 @@ def test_tiny_solve_reaches_independent_minimum(oracle, idx):
     assert abs(s2.final_cost - c["expected"]["final_cost"]) <= 2e-6 * c["expected"]["final_cost"]
 
 
+@pytest.mark.parametrize("idx", [0, 1])
+def test_motion_prior_solve_reaches_independent_minimum(oracle, idx):
+    """Frame-to-frame motion priors (constant interFrameRatio): the restated functors + the LM restatement
+    against an independent numpy model of the priors minimised by scipy (tests/golden/make_golden.py priors)."""
+    c = load_golden("prior_solves.json")[idx]
+    prob = problem_from_solve_case(c)
+    ok, cost0, g = oracle.evaluate(prob)
+    assert ok and abs(cost0 - c["expected"]["initial_cost"]) <= 1e-9 * cost0
+    # gradient incl. the prior blocks against central differences of the cost
+    rng = np.random.default_rng(1)
+    for _ in range(6):
+        f, q, k = rng.integers(1, prob.num_frames - 1), rng.integers(0, 2), rng.integers(0, 6)
+        h = 1e-6
+        p1 = prob.copy(); p1.poses[f, q, k] += h
+        p2 = prob.copy(); p2.poses[f, q, k] -= h
+        fd = (oracle.evaluate(p1, gradient=False)[1] - oracle.evaluate(p2, gradient=False)[1]) / (2 * h)
+        assert abs(fd - g["poses"][f, q, k]) <= 1e-5 * max(1.0, abs(fd))
+    opts = oracle.default_options(max_num_iterations=200, function_tolerance=1e-14, parameter_tolerance=1e-14, gradient_tolerance=1e-12)
+    s, trace = oracle.solve(prob, opts)
+    assert s.termination_type in (0, 1)
+    assert s.num_residual_blocks == prob.num_observations + len(c["prior_frames"])
+    assert abs(s.final_cost - c["expected"]["final_cost"]) <= 1e-8 * c["expected"]["final_cost"], (s.final_cost, c["expected"]["final_cost"])
+    ptol = 1e-3 if c["huber_a"] > 0 else 1e-5
+    assert np.max(np.abs(prob.poses - np.array(c["expected"]["poses"]))) <= ptol
+    assert np.max(np.abs(prob.points - np.array(c["expected"]["points"]))) <= 10 * ptol
+    # the priors matter: without them the same scene ends at a different (lower) cost
+    prob0 = problem_from_solve_case(c); prob0.prior_kind = 0; prob0.prior_frames = None
+    s0, _ = oracle.solve(prob0, opts)
+    assert s0.final_cost < (1 - 1e-4) * s.final_cost
+
+
 def test_gradient_matches_finite_differences(oracle):
     c = load_golden("tiny_solves.json")[2]   # Huber case
     prob = problem_from_solve_case(c)
