@@ -189,6 +189,19 @@ int32_t rsba_reproject(rsba_handle* h, const int32_t* frames, const int32_t* poi
  * zero rows / columns at fixed coordinates.  RSBA_ERR_UNSUPPORTED when J^T J is rank deficient (Compute returns false). */
 int32_t rsba_pose_covariance(rsba_handle* h, int32_t frame, double* cov);
 
+/* == the frame-to-frame motion priors CeresHandler::Add attaches to a rolling-shutter frame (CeresHandler.h:147-185;
+ * SURVEY §8f row f1): one 12-residual block per listed frame f >= 1 over (f.poses[0], f.poses[1], f-1.poses[0],
+ * f-1.poses[1]) — RsConstVeloPrior (kind 1, video_bundler_rs_inter.h:55-108) or RsConstAccelerationPrior (kind 2,
+ * :113-173) with weight `scale` (opt.ceres.constFrameVelocity / constFrameAcceleration), rotation rows down-scaled
+ * by 0.01, under the problem's loss function (huber_a).  inter_frame_ratio is opt.ceres.interFrameRatio as a CONSTANT
+ * block — the case the reference takes when the option is != 1 (CeresHandler.h:175-177); a free, lower-bounded ratio
+ * (the option left at 1) needs bounded LM and is not built: RSBA_ERR_UNSUPPORTED is the caller's cue.
+ * The blocks count in cost, gradient, num_residual_blocks and the solve; their validity flag (ratio >= 0 resp.
+ * >= DBL_EPSILON) fails the evaluation like any functor returning false.  Needs poses_per_frame == 2 and a calibrated
+ * or shared-intrinsics problem.  frames strictly increasing; must precede the first solve / gradient call;
+ * kind 0 or count 0 removes them.  With rsba_set_exchange every rank passes the same list (rank 0 contributes them). */
+int32_t rsba_set_motion_priors(rsba_handle* h, int32_t kind, double scale, double inter_frame_ratio, const int32_t* frames, int32_t count);
+
 /* ---- multi-GPU: one process per GPU, observations partitioned BY POINT, cameras replicated ----
  * (the reference is single-process; this is the exchange step SURVEY §8e derives for the path).
  * Every rank creates a handle over its own observations (all frames / points arrays are full size, a rank

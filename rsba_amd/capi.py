@@ -21,7 +21,7 @@ EXPORTS = [
     "rsba_set_stream", "rsba_upload_parameters", "rsba_download_parameters", "rsba_evaluate_device", "rsba_evaluate",
     "rsba_get_device_view", "rsba_time_evaluate", "rsba_default_solver_options", "rsba_solve", "rsba_normal_equations",
     "rsba_set_exchange", "rsba_get_block_structure", "rsba_set_block_structure",
-    "rsba_validate_observations", "rsba_reproject", "rsba_pose_covariance",
+    "rsba_validate_observations", "rsba_reproject", "rsba_pose_covariance", "rsba_set_motion_priors",
 ]
 
 
@@ -156,6 +156,8 @@ class DeviceProblem:
         self._desc = make_desc(prob)
         self._h = C.c_void_p()
         _check(lib().rsba_create(C.byref(self._desc), C.c_int32(device), C.byref(self._h)))
+        if prob.prior_kind and prob.prior_frames is not None and len(prob.prior_frames):
+            self.set_motion_priors(prob.prior_kind, prob.prior_scale, prob.inter_frame_ratio, prob.prior_frames)
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
@@ -173,6 +175,12 @@ class DeviceProblem:
 
     def __exit__(self, *a):
         self.close()
+
+    def set_motion_priors(self, kind: int, scale: float, inter_frame_ratio: float, frames):
+        """Frame-to-frame motion priors with a constant interFrameRatio (CeresHandler.h:147-185; rsba_amd.h)."""
+        fr = np.ascontiguousarray(frames, dtype=np.int32)
+        _check(lib().rsba_set_motion_priors(self._h, C.c_int32(int(kind)), C.c_double(float(scale)), C.c_double(float(inter_frame_ratio)),
+                                            fr.ctypes.data_as(C.c_void_p), C.c_int32(len(fr))))
 
     def set_stream(self, raw_stream: int | None):
         _check(lib().rsba_set_stream(self._h, C.c_void_p(raw_stream or 0)))

@@ -256,6 +256,30 @@ int32_t rsba_time_evaluate(rsba_handle* h, int32_t with_jacobians, int32_t warmu
   return RSBA_OK;
 }
 
+int32_t rsba_set_motion_priors(rsba_handle* h, int32_t kind, double scale, double inter_frame_ratio, const int32_t* frames, int32_t count) {
+  if (!h || kind < 0 || kind > 2 || count < 0 || (count > 0 && !frames)) return fail(RSBA_ERR_INVALID_ARGUMENT, "bad motion prior arguments");
+  if (h->solver) return fail(RSBA_ERR_INVALID_ARGUMENT, "rsba_set_motion_priors must precede the first solve / gradient call");
+  HIP_TRY(hipSetDevice(h->device));
+  DeviceProblem& dp = h->dp;
+  if (kind == 0 || count == 0) { dp.prior_of = nullptr; dp.prior_kind = 0; h->prior_frames.clear(); h->prior_invalid = 0; return RSBA_OK; }
+  if (dp.P != 2) return fail(RSBA_ERR_INVALID_ARGUMENT, "motion priors need two poses per frame (CeresHandler.h:151)");
+  std::vector<int32_t> flags((size_t)dp.F + 1, 0);
+  for (int32_t k = 0; k < count; ++k) {
+    if (frames[k] < 1 || frames[k] >= dp.F || (k > 0 && frames[k] <= frames[k - 1])) return fail(RSBA_ERR_INVALID_ARGUMENT, "prior frames must be strictly increasing in [1, F)");
+    flags[frames[k]] = 1;
+  }
+  int32_t* d = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), flags.size() * sizeof(int32_t)));
+  h->allocs.push_back(d);
+  HIP_TRY(hipMemcpy(d, flags.data(), flags.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  dp.prior_of = d; dp.prior_kind = kind; dp.prior_scale = scale; dp.prior_ratio = inter_frame_ratio;
+  h->prior_frames.assign(frames, frames + count);
+  // RsConstVeloPrior returns ratio >= 0, RsConstAccelerationPrior ratio >= _EPS (video_bundler_rs_inter.h:92,:157)
+  const bool valid = kind == 1 ? inter_frame_ratio >= 0.0 : inter_frame_ratio >= 2.220446049250313e-16;
+  h->prior_invalid = valid ? 0 : count;
+  return RSBA_OK;
+}
+
 int32_t rsba_evaluate(rsba_handle* h, double* cost, double* residuals, double* jacobians, double* gradient, int64_t* num_failed) {
   if (!h) return fail(RSBA_ERR_INVALID_ARGUMENT, "null handle");
   HIP_TRY(hipSetDevice(h->device));
@@ -264,6 +288,7 @@ int32_t rsba_evaluate(rsba_handle* h, double* cost, double* residuals, double* j
   HIP_TRY(hipMemsetAsync(dp.fail_count, 0, sizeof(int), h->stream));
   HIP_TRY(launch_eval(dp, jacobians ? kRawJacobian : kResidualOnly, h->stream));
   HIP_TRY(launch_cost_reduce(dp, h->d_cost2, h->stream));
+  if (dp.prior_of && h->rank == 0) HIP_TRY(launch_prior_cost(dp, h->d_cost2, h->prior_invalid, h->stream));
   double c2[2] = {0, 0}; int nfail = 0;
   HIP_TRY(hipMemcpyAsync(c2, h->d_cost2, sizeof c2, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipMemcpyAsync(&nfail, dp.fail_count, sizeof nfail, hipMemcpyDeviceToHost, h->stream));

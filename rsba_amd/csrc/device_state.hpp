@@ -55,6 +55,10 @@ struct DeviceProblem {
   double* fixed_partial;         // [nblocks] same over dropped (all-constant) blocks
   double* fail_partial;          // [nblocks] observations of each workgroup whose functor returned false
   int* fail_count;               // their total, written by the cost reduction (no atomics on the hot path)
+  // frame-to-frame motion priors with a constant interFrameRatio (kernels_prior.hip); null = none
+  const int32_t* prior_of;       // [F + 1] 1 = frame f carries a prior against frame f - 1 (entry F is 0)
+  int prior_kind;                // 1 RsConstVeloPrior, 2 RsConstAccelerationPrior
+  double prior_scale, prior_ratio;
 };
 
 constexpr int kEvalBlock = 256;
@@ -71,6 +75,8 @@ int eval_num_blocks(int64_t n);
 hipError_t launch_cost_reduce(const DeviceProblem& dp, double* out2, hipStream_t stream);
 // tiled component-major res / jac -> rows[order[i]][..] in the caller's layout ([N][2] and [N][2][K], back to back)
 hipError_t launch_untile(const DeviceProblem& dp, const int64_t* order, bool with_jacobians, double* res_rows, double* jac_rows, hipStream_t st);
+// motion priors: cost2 += {cost, fixed cost} of the prior blocks at dp.poses (fail_count += invalid_blocks)
+hipError_t launch_prior_cost(const DeviceProblem& dp, double* cost2, int invalid_blocks, hipStream_t st);
 hipError_t launch_validate(const DeviceProblem& dp, double sq_threshold, double min_distance, uint8_t* valid, hipStream_t st);
 hipError_t launch_reproject(const DeviceProblem& dp, const int32_t* frames, const int32_t* points, int64_t n, double* xy_out, uint8_t* ok_out, hipStream_t st);
 

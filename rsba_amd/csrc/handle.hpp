@@ -24,6 +24,9 @@ struct rsba_handle {
   double* d_cost2 = nullptr;           // {cost, fixed cost}
   int64_t* d_order = nullptr;          // device copy of `order`, made on the first host-returning evaluation
   double* d_rows = nullptr;            // [N][2 + 2K] results in the caller's layout and order, staged for one D2H copy each
+  // motion priors (rsba_set_motion_priors): frames that carry one, device flags live in dp.prior_of
+  std::vector<int32_t> prior_frames;
+  int prior_invalid = 0;               // blocks whose functor returns false for the given interFrameRatio
   rsba::Solver* solver = nullptr;      // normal-equation / Schur / LM state, built on first use
   // multi-GPU exchange (rsba_set_exchange / rsba_set_block_structure)
   rsba_allreduce_fn allreduce = nullptr;

@@ -1,0 +1,174 @@
+// Frame-to-frame motion priors: RsConstVeloPrior / RsConstAccelerationPrior
+// (/root/reference/src/rsba/video_bundler_rs_inter.h:55-108, :113-173) as CeresHandler::Add creates them
+// (CeresHandler.h:147-185), for the case the reference takes when opt.ceres.interFrameRatio != 1: the ratio block is
+// constant (:175-177), so a prior is a 12-residual block over the four pose blocks of frames f and f-1 that is LINEAR
+// in them.  Per pose coordinate i the two residuals
+//     r[i]     = s_i * (Ca . x_i),     r[6 + i] = s_i * (Cb . x_i),     x_i = (f.p0[i], f.p1[i], (f-1).p0[i], (f-1).p1[i])
+// touch only that coordinate of the four poses (s_i = scale * 0.01 for the rotation rows, scale otherwise), so a
+// prior adds 2 x 2 blocks per coordinate to U_f, U_{f-1} and to the (f, f-1) block of the reduced camera system —
+// the block-tridiagonal fill SURVEY names.  The shared loss function acts on the 12-vector as a whole (:155,:166).
+//
+// O(F) work per LM iteration: one thread per frame gathers the prior it heads and the one that refers back to it
+// (no atomics, fixed order), single-workgroup reductions for the cost and the model cost change.
+#include "obs_math.hpp"
+#include "solver_state.hpp"
+
+namespace rsba {
+
+namespace {
+
+__device__ __forceinline__ double wsum64(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// Jacobian coefficients of the two residual rows with respect to x_i (what Jet arithmetic leaves in the functors)
+__device__ __forceinline__ void prior_coefficients(const DeviceProblem& dp, double Ca[4], double Cb[4]) {
+  const double q = dp.prior_ratio, inv = 1.0 / q;
+  if (dp.prior_kind == 1) {
+    Ca[0] = 1.0; Ca[1] = 0.0; Ca[2] = q; Ca[3] = -(1.0 + q);
+    if (q > 2.220446049250313e-16) { Cb[0] = -(1.0 + inv); Cb[1] = 1.0; Cb[2] = 0.0; Cb[3] = inv; }
+    else { Cb[0] = -1.0; Cb[1] = 1.0; Cb[2] = 1.0; Cb[3] = -1.0; }
+  } else {
+    Ca[0] = 0.5; Ca[1] = 0.0; Ca[2] = 0.5 * q; Ca[3] = -0.5 * (1.0 + q);
+    Cb[0] = -0.5 * (1.0 + inv); Cb[1] = 0.5; Cb[2] = 0.0; Cb[3] = 0.5 * inv;
+  }
+}
+
+// the functors' residuals in their own order of operations (T = double path); loss weight rho' and cost rho / 2
+struct PriorValue { double r[12]; double weight, cost; };
+__device__ __forceinline__ PriorValue prior_value(const DeviceProblem& dp, int f) {
+  PriorValue v;
+  const double* cur = dp.poses + (size_t)f * 12; const double* prev = cur - 12;
+  const double q = dp.prior_ratio;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const double c0 = cur[i], c1 = cur[6 + i], p0 = prev[i], p1 = prev[6 + i];
+    double a, b;
+    if (dp.prior_kind == 1) {
+      a = c0 - (p1 + (p1 - p0) * q);
+      const double d = (q > 2.220446049250313e-16) ? (c0 - p1) * (1.0 / q) : (p1 - p0);
+      b = c1 - (c0 + d);
+    } else {
+      const double vt = c0 - p1, v1t = (p1 - p0) * q;
+      a = c0 - (p1 + (v1t + (vt - v1t) * 0.5));
+      const double vv = c1 - c0, w = (c0 - p1) * (1.0 / q);
+      b = c1 - (c0 + (w + (vv - w) * 0.5));
+    }
+    const double down = i < 3 ? 0.01 : 1.0;
+    v.r[i] = a * dp.prior_scale * down; v.r[6 + i] = b * dp.prior_scale * down;
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) s += v.r[i] * v.r[i];
+  double rho[3] = {s, 1.0, 0.0};
+  if (dp.huber_a > 0.0) huber_rho(dp.huber_a, s, rho);
+  v.weight = rho[1]; v.cost = 0.5 * rho[0];
+  return v;
+}
+
+// U_f, g_f and the (f, f-1) cross block: one thread per frame
+__global__ __launch_bounds__(64) void prior_blocks_kernel(const DeviceProblem dp, const SolverDev sv, double* __restrict__ ucross) {
+  const int f = blockIdx.x * 64 + threadIdx.x;
+  if (f >= dp.F) return;
+  const bool heads = dp.prior_of[f] != 0, referred = dp.prior_of[f + 1] != 0;
+  if (!heads && !referred) return;
+  double Ca[4], Cb[4];
+  prior_coefficients(dp, Ca, Cb);
+  PriorValue mine, next;
+  if (heads) mine = prior_value(dp, f);
+  if (referred) next = prior_value(dp, f + 1);
+  const double* sc = dp.scale_pose + (size_t)f * 12;
+  double* U = sv.U + (size_t)f * 144; double* g = sv.gc + (size_t)f * 12;
+  for (int i = 0; i < 6; ++i) {
+    const double si = dp.prior_scale * (i < 3 ? 0.01 : 1.0), s2 = si * si;
+    double H[2][2] = {{0.0, 0.0}, {0.0, 0.0}}, gv[2] = {0.0, 0.0};
+    if (heads)
+      for (int p = 0; p < 2; ++p) {
+        gv[p] += mine.weight * si * (Ca[p] * mine.r[i] + Cb[p] * mine.r[6 + i]);
+        for (int q = 0; q < 2; ++q) H[p][q] += mine.weight * s2 * (Ca[p] * Ca[q] + Cb[p] * Cb[q]);
+      }
+    if (referred)
+      for (int p = 0; p < 2; ++p) {
+        gv[p] += next.weight * si * (Ca[2 + p] * next.r[i] + Cb[2 + p] * next.r[6 + i]);
+        for (int q = 0; q < 2; ++q) H[p][q] += next.weight * s2 * (Ca[2 + p] * Ca[2 + q] + Cb[2 + p] * Cb[2 + q]);
+      }
+    for (int p = 0; p < 2; ++p) {
+      const int a = 6 * p + i;
+      g[a] += gv[p] * sc[a];
+      for (int q = 0; q < 2; ++q) { const int b = 6 * q + i; U[a * 12 + b] += H[p][q] * sc[a] * sc[b]; }
+    }
+    if (heads) {
+      const double* scp = sc - 12;   // frame f - 1
+      for (int p = 0; p < 2; ++p) for (int q = 0; q < 2; ++q) {
+        const int a = 6 * p + i, b = 6 * q + i;
+        ucross[(size_t)f * 144 + a * 12 + b] = mine.weight * s2 * (Ca[p] * Ca[2 + q] + Cb[p] * Cb[2 + q]) * sc[a] * scp[b];
+      }
+    }
+  }
+}
+
+// cost of the prior blocks at dp.poses, added to {cost, fixed cost}; a block whose four poses are all constant is not
+// part of the reduced program and its cost is "fixed" (Ceres: Program::RemoveFixedBlocks)
+__global__ __launch_bounds__(256) void prior_cost_kernel(const DeviceProblem dp, double* cost2, int invalid) {
+  __shared__ double s_red[2][4];
+  double c = 0.0, cf = 0.0;
+  for (int f = threadIdx.x; f < dp.F; f += 256) {
+    if (!dp.prior_of[f]) continue;
+    const PriorValue v = prior_value(dp, f);
+    bool all_const = true;
+    for (int k = 0; k < 24; ++k) all_const = all_const && dp.scale_pose[(size_t)(f - 1) * 12 + k] == 0.0;
+    if (all_const) cf += v.cost; else c += v.cost;
+  }
+  c = wsum64(c); cf = wsum64(cf);
+  if ((threadIdx.x & 63) == 0) { s_red[0][threadIdx.x >> 6] = c; s_red[1][threadIdx.x >> 6] = cf; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    cost2[0] += (s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]);
+    cost2[1] += (s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]);
+    if (invalid) *dp.fail_count += invalid;   // the functors return false for this interFrameRatio
+  }
+}
+
+// model cost change of the prior blocks for the camera step in sv.rhs:  -sum m.(r~ + m/2),  m = -J~ y
+__global__ __launch_bounds__(256) void prior_model_kernel(const DeviceProblem dp, const SolverDev sv, double* out) {
+  __shared__ double s_red[4];
+  double Ca[4], Cb[4];
+  prior_coefficients(dp, Ca, Cb);
+  double acc = 0.0;
+  for (int f = threadIdx.x; f < dp.F; f += 256) {
+    if (!dp.prior_of[f]) continue;
+    const PriorValue v = prior_value(dp, f);
+    const double sw = sqrt(v.weight);
+    const double* y = sv.rhs + (size_t)(f - 1) * 12; const double* sc = dp.scale_pose + (size_t)(f - 1) * 12;   // [prev | cur]
+    for (int i = 0; i < 6; ++i) {
+      const double si = dp.prior_scale * (i < 3 ? 0.01 : 1.0);
+      const double x0 = sc[12 + i] * y[12 + i], x1 = sc[18 + i] * y[18 + i], x2 = sc[i] * y[i], x3 = sc[6 + i] * y[6 + i];
+      const double ma = -sw * si * (Ca[0] * x0 + Ca[1] * x1 + Ca[2] * x2 + Ca[3] * x3);
+      const double mb = -sw * si * (Cb[0] * x0 + Cb[1] * x1 + Cb[2] * x2 + Cb[3] * x3);
+      acc += ma * (sw * v.r[i] + 0.5 * ma) + mb * (sw * v.r[6 + i] + 0.5 * mb);
+    }
+  }
+  acc = wsum64(acc);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) *out += -((s_red[0] + s_red[1]) + (s_red[2] + s_red[3]));
+}
+
+}  // namespace
+
+hipError_t launch_prior_blocks(const DeviceProblem& dp, const SolverDev& sv, double* ucross, hipStream_t st) {
+  hipLaunchKernelGGL(prior_blocks_kernel, dim3((dp.F + 63) / 64), dim3(64), 0, st, dp, sv, ucross);
+  return hipGetLastError();
+}
+hipError_t launch_prior_cost(const DeviceProblem& dp, double* cost2, int invalid_blocks, hipStream_t st) {
+  hipLaunchKernelGGL(prior_cost_kernel, dim3(1), dim3(256), 0, st, dp, cost2, invalid_blocks);
+  return hipGetLastError();
+}
+hipError_t launch_prior_model(const DeviceProblem& dp, const SolverDev& sv, double* model_cost_change, hipStream_t st) {
+  hipLaunchKernelGGL(prior_model_kernel, dim3(1), dim3(256), 0, st, dp, sv, model_cost_change);
+  return hipGetLastError();
+}
+
+}  // namespace rsba

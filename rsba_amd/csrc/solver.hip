@@ -48,7 +48,8 @@ struct Solver {
   int32_t* d_obs_slot = nullptr;
   double *d_gpose = nullptr, *d_gpoint = nullptr;
   int64_t num_pairs = 0;
-  int num_reduced_blocks = 0, num_reduced_params = 0;
+  int num_reduced_blocks = 0, num_reduced_params = 0, num_priors_reduced = 0;
+  double* ucross = nullptr;                                           // [F][CD][CD] motion-prior blocks (f, f-1), behind sv.U's J^T J blocks
 };
 
 }  // namespace rsba
@@ -177,6 +178,7 @@ int32_t build_solver(rsba_handle* h) {
   if (!h->union_mask.empty())                                  // multi-GPU: tiles other ranks fill, so all ranks share one layout
     for (int a = 0; a < FR; ++a) for (int b = 0; b <= a; ++b) if (h->union_mask[(size_t)a * FR + b]) bump(a / FT, b / FT, 0);
   for (int v = 0; v < NPF; ++v) for (int b = 0; b < FR + v; ++b) bump((FR + v) / FT, b / FT, 0);   // the intrinsics border is dense
+  for (int32_t f : h->prior_frames) bump(f / FT, (f - 1) / FT, 0);   // motion priors couple frame f with f - 1 (every rank: one layout)
   // entries of point j: every pair of its tiles (X >= Y) times every combination of their layers — for X == Y both
   // orders of two different layers (the diagonal tile pair is stored in full)
   auto for_each_entry = [&](int j, auto&& fn) {
@@ -437,6 +439,9 @@ int32_t build_solver(rsba_handle* h) {
   sv.npremerge = (int)pm_ptr.size() - 1;
   sv.nchunk = (int)chunk_tp.size(); sv.ntp = ntp; sv.FT = FT;
   { const char* e = std::getenv("RSBA_SCHUR_LINEAR"); sv.schur_linear = e && e[0] == '1'; }
+  std::vector<uint8_t> has_prior((size_t)FR + 1, 0);
+  for (int32_t f : h->prior_frames) has_prior[f] = 1;
+  const int64_t ucross_base = ((int64_t)FR + (int64_t)NPF * FR + (int64_t)NPF * NPF) * CD * CD;   // behind the J^T J blocks in sv.U
   std::vector<int32_t> tp_dst(ntp); std::vector<uint8_t> tp_trans(ntp, 0);
   std::vector<int64_t> tp_add((size_t)ntp * FT * FT, -1);
   for (int t = 0; t < ntp; ++t) {
@@ -448,7 +453,10 @@ int32_t build_solver(rsba_handle* h) {
       const int a = I * FT + x, b = J * FT + y;
       if (a >= F || b >= F || a < b) continue;
       int64_t add = -1;
-      if (a < FR) { if (a == b) add = (int64_t)a * CD * CD; }
+      if (a < FR) {
+        if (a == b) add = (int64_t)a * CD * CD;
+        else if (b == a - 1 && has_prior[a]) add = ucross_base + (int64_t)a * CD * CD;   // motion prior block (a, a-1)
+      }
       else if (b < FR) add = ((int64_t)FR + (int64_t)(a - FR) * FR + b) * CD * CD;
       else add = ((int64_t)FR + (int64_t)NPF * FR + (int64_t)(a - FR) * NPF + (b - FR)) * CD * CD;
       tp_add[((size_t)t * FT + x) * FT + y] = add;
@@ -462,7 +470,10 @@ int32_t build_solver(rsba_handle* h) {
   int nfree = 0;
   const bool lead = h->rank == 0;
   sv.lead = lead;
-  auto frame_has_obs = [&](int f) { return h->frame_obs_total.empty() ? frame_ptr[f + 1] > frame_ptr[f] : h->frame_obs_total[f] > 0; };
+  auto frame_has_obs = [&](int f) {
+    if (has_prior[f] || has_prior[f + 1]) return true;   // touched by a motion prior block
+    return h->frame_obs_total.empty() ? frame_ptr[f + 1] > frame_ptr[f] : h->frame_obs_total[f] > 0;
+  };
   if (NPF > 0 && lead && h->mask_intr[0] != 0.0 && N > 0) for (int k = 0; k < 9; ++k) { inprog_intr[k] = 1.0; ++nfree; }
   for (int f = 0; f < FR; ++f) for (int q = 0; q < dp.P; ++q) {
     bool any_free = false;
@@ -477,6 +488,12 @@ int32_t build_solver(rsba_handle* h) {
       bool all_const = h->mask_point[(size_t)op[i] * 3] == 0.0 && (NPF == 0 || h->mask_intr[0] == 0.0);
       for (int k = 0; k < CD && all_const; ++k) all_const = h->mask_pose[(size_t)of[i] * CD + k] == 0.0;
       nred += !all_const;
+    }
+    s->num_priors_reduced = 0;
+    if (lead) for (int32_t f : h->prior_frames) {
+      bool all_const = true;
+      for (int k = 0; k < 24 && all_const; ++k) all_const = h->mask_pose[(size_t)(f - 1) * CD + k] == 0.0;
+      s->num_priors_reduced += !all_const;
     }
     s->num_reduced_blocks = (int)nred;
   }
@@ -549,7 +566,9 @@ int32_t build_solver(rsba_handle* h) {
     if ((rc = s_alloc(s, &h->dp.cam_part, (size_t)std::max(wave_seg_base[nwaves], 1) * nblk * 256))) return rc;
     h->dp.wave_seg_base = d_base; h->dp.frame_rank = d_rank;
   }
-  if ((rc = s_alloc(s, &sv.U, ((size_t)FR + (size_t)NPF * FR + (size_t)NPF * NPF) * CD * CD))) return rc;
+  const size_t ucross_len = h->prior_frames.empty() ? 0 : (size_t)FR * CD * CD;
+  if ((rc = s_alloc(s, &sv.U, (size_t)ucross_base + ucross_len))) return rc;
+  if (ucross_len) { s->ucross = sv.U + ucross_base; HIP_TRY(hipMemset(s->ucross, 0, ucross_len * sizeof(double))); }   // stays zero on the other ranks
   if ((rc = s_alloc(s, &sv.gc, (size_t)F * CD))) return rc;
   if ((rc = s_alloc(s, &sv.intr_part, (size_t)FR * 54))) return rc;
   if ((rc = s_alloc(s, &sv.trial_intr, 9 * (size_t)std::max(dp.NI, 1)))) return rc;
@@ -627,6 +646,10 @@ int32_t linearize(rsba_handle* h) {
   HIP_TRY(launch_cost_reduce(h->dp, h->d_cost2, h->stream));
   HIP_TRY(launch_camera_blocks(h->dp, s->sv, h->stream));
   HIP_TRY(launch_intr_blocks(h->dp, s->sv, h->stream));
+  if (s->ucross && s->sv.lead) {   // motion priors: replicated terms, contributed by the lead rank
+    HIP_TRY(launch_prior_cost(h->dp, h->d_cost2, h->prior_invalid, h->stream));
+    HIP_TRY(launch_prior_blocks(h->dp, s->sv, s->ucross, h->stream));
+  }
   HIP_TRY(launch_point_blocks(h->dp, s->sv, h->stream));
   HIP_TRY(launch_pack_linearize(h->dp, s->sv, h->d_cost2, h->stream));
   int32_t rc = exchange(h, s->sv.xbuf, 2 * s->sv.n + 3, 0);
@@ -823,7 +846,8 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
   { const char* lv = std::getenv("RSBA_CHOL_LEVELS"); s->use_levels = opt->level_scheduled_cholesky != 0 || (lv && lv[0] == '1'); }
   {
     // problem-size figures of the whole (all-rank) problem
-    double cnt[3] = {(double)dp.N, (double)s->num_reduced_blocks, (double)s->num_reduced_params};
+    const double npri = sv.lead ? (double)h->prior_frames.size() : 0.0;
+    double cnt[3] = {(double)dp.N + npri, (double)(s->num_reduced_blocks + s->num_priors_reduced), (double)s->num_reduced_params};
     if (h->world > 1) {
       HIP_TRY(hipMemcpyAsync(sv.scalars + 8, cnt, sizeof cnt, hipMemcpyHostToDevice, st));
       if ((rc = exchange(h, sv.scalars + 8, 3, 0))) return rc;
@@ -909,12 +933,14 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
     if ((rc = factor_and_solve(h, radius))) return rc;
     reuse_diagonal = true;
     HIP_TRY(launch_model_cost_change(dp, sv, st));
+    if (s->ucross && sv.lead) HIP_TRY(launch_prior_model(dp, sv, sv.scalars + kModelCostChange, st));
     HIP_TRY(launch_candidate(dp, sv, st));
     // residuals only at the candidate (T = double path)
     swap_params();
     HIP_TRY(hipMemsetAsync(dp.fail_count, 0, sizeof(int), st));
     HIP_TRY(launch_eval(dp, kResidualOnly, st));
     HIP_TRY(launch_cost_reduce(dp, h->d_cost2, st));
+    if (s->ucross && sv.lead) HIP_TRY(launch_prior_cost(dp, h->d_cost2, h->prior_invalid, st));
     swap_params();
     // exchange (3): model decrease, |step|^2, |x|^2, (skip the max slot), trial cost, -, failure flags
     HIP_TRY(launch_pack_trial(dp, sv, h->d_cost2, st));

@@ -129,6 +129,9 @@ hipError_t launch_schur_blocks(const DeviceProblem& dp, const SolverDev& sv, dou
 hipError_t launch_back_substitute(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);
 hipError_t launch_model_cost_change(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);      // -> scalars[kModelCostChange]
 hipError_t launch_candidate(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);              // trial params, |step|^2, |x|^2
+// motion priors (kernels_prior.hip): U_f, g_f += their J^T J / J^T r, ucross[f] = the (f, f-1) block; model cost change
+hipError_t launch_prior_blocks(const DeviceProblem& dp, const SolverDev& sv, double* ucross, hipStream_t st);
+hipError_t launch_prior_model(const DeviceProblem& dp, const SolverDev& sv, double* model_cost_change, hipStream_t st);
 hipError_t launch_intr_blocks(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);
 hipError_t launch_virtual_records(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);
 hipError_t launch_pack_linearize(const DeviceProblem& dp, const SolverDev& sv, const double* cost2, hipStream_t st);
