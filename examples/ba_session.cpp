@@ -5,7 +5,8 @@
 //
 //   scene file (binary, little endian): int32 F,P,M,rs,scan0,scan1,calibrated,interp,fixFirstN,fixScale,maxIter, int64 N,
 //     double huber, double revalidate (squared px threshold of revalidateReprojections, <= 0 = off), double covFrame (>= 0:
-//     calcCovariances, the pp | pe | ee blocks of that frame are appended to the result file), double cam[9], poses[F*P*6], points[M*3], obs_xy[N*2], int32 obs_frame[N], obs_point[N]
+//     calcCovariances, the pp | pe | ee blocks of that frame are appended to the result file), double constFrameVelocity,
+//     constFrameAcceleration, interFrameRatio (motion priors, CeresHandler.h:147-185), double cam[9], poses[F*P*6], points[M*3], obs_xy[N*2], int32 obs_frame[N], obs_point[N]
 //   g++ -std=c++17 -O2 -Iinclude examples/ba_session.cpp -Lrsba_amd/_lib -lrsba_amd -Wl,-rpath,... -o ba_session
 #include <cstdio>
 #include <cstdlib>
@@ -23,8 +24,8 @@ int main(int argc, char** argv) {
   if (argc < 3) { std::fprintf(stderr, "usage: %s scene.bin out.bin\n", argv[0]); return 2; }
   FILE* f = std::fopen(argv[1], "rb");
   if (!f) { std::perror("scene"); return 2; }
-  int32_t hd[11]; int64_t N; double huber, reval, covf, cam[9];
-  if (!rd(f, hd, 11) || !rd(f, &N, 1) || !rd(f, &huber, 1) || !rd(f, &reval, 1) || !rd(f, &covf, 1) || !rd(f, cam, 9)) return 2;
+  int32_t hd[11]; int64_t N; double huber, reval, covf, motion[3], cam[9];
+  if (!rd(f, hd, 11) || !rd(f, &N, 1) || !rd(f, &huber, 1) || !rd(f, &reval, 1) || !rd(f, &covf, 1) || !rd(f, motion, 3) || !rd(f, cam, 9)) return 2;
   const int F = hd[0], P = hd[1], M = hd[2];
   std::vector<double> poses((size_t)F * P * 6), points((size_t)M * 3), xy((size_t)N * 2);
   std::vector<int32_t> of(N), op(N);
@@ -51,6 +52,7 @@ int main(int argc, char** argv) {
   opt.ceres.fixFirstNCameras = (unsigned)hd[8]; opt.ceres.fixScale = hd[9] != 0; opt.ceres.huberLoss = huber;
   if (reval > 0) { opt.ceres.revalidateReprojections = true; opt.tracks.sqrdThreshold = reval; }
   opt.debug.calcCovariances = covf >= 0;
+  opt.ceres.constFrameVelocity = motion[0]; opt.ceres.constFrameAcceleration = motion[1]; opt.ceres.interFrameRatio = motion[2];
 
   ceres::Solver::Summary summary;
   std::vector<std::vector<double>> covs;

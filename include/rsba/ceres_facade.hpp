@@ -161,6 +161,23 @@ struct CRSMatrix {
   std::vector<double> values;
 };
 
+// Frame-to-frame motion prior blocks (video_bundler_rs_inter.h:55-173): typed handles like ReprojectionCost, created
+// by the factories in motion_priors.hpp.  Blocks: interFrameRatio[1], f.poses[0], f.poses[1], f-1.poses[0], f-1.poses[1];
+// 12 residuals.  They are evaluated inside a Problem (device path, rsba_set_motion_priors); a stand-alone Evaluate of
+// one block is not provided.
+class MotionPriorCost : public CostFunction {
+ public:
+  MotionPriorCost(int kind, double scale) : kind_(kind), scale_(scale) {
+    num_residuals_ = 12;
+    sizes_ = {1, NUM_POSE_PARAMS, NUM_POSE_PARAMS, NUM_POSE_PARAMS, NUM_POSE_PARAMS};
+  }
+  int kind() const { return kind_; }       // 1 RsConstVeloPrior, 2 RsConstAccelerationPrior
+  double scale() const { return scale_; }
+  bool Evaluate(double const* const*, double*, double**) const override { return false; }
+ private:
+  int kind_; double scale_;
+};
+
 class Problem;
 struct Solver {
   struct Options {
@@ -246,7 +263,8 @@ class Problem {
     Flat f;
     if (!flatten(&f, nullptr)) return false;
     rsba_handle* h = nullptr;
-    if (rsba_create(&f.desc, 0, &h) != RSBA_OK) return false;
+    if (residuals && !f.prior_frames.empty()) return false;   // per-block residual output covers the reprojection blocks only
+    if (create_handle(f, 0, &h) != RSBA_OK) return false;
     std::vector<double> g;
     if (gradient) g.resize(f.poses.size() + f.points.size() + f.intr.size());
     if (residuals) residuals->assign(2 * blocks_.size(), 0.0);
@@ -258,6 +276,7 @@ class Problem {
       gradient->clear();
       for (double* p : block_order_) {
         const Slot s = f.slot_of[p];
+        if (s.kind == 3) { gradient->insert(gradient->end(), (size_t)block_sizes_[p], 0.0); continue; }   // constant data block
         const double* src = s.kind == 0 ? &g[(size_t)s.index * 6] : s.kind == 1 ? &g[f.poses.size() + (size_t)s.index * 3] : &g[f.poses.size() + f.points.size() + (size_t)s.index * 9];
         gradient->insert(gradient->end(), src, src + block_sizes_[p]);
       }
@@ -269,7 +288,7 @@ class Problem {
   friend void Solve(const Solver::Options&, Problem*, Solver::Summary*);
   friend class Covariance;
   struct Block { CostFunction* cost; LossFunction* loss; std::vector<double*> x; };
-  struct Slot { int kind; int index; };   // kind 0 pose block, 1 point, 2 intrinsics
+  struct Slot { int kind; int index; };   // kind 0 pose block, 1 point, 2 intrinsics, 3 constant scalar data (interFrameRatio)
   struct Flat {
     rsba_problem_desc desc;
     std::vector<double> poses, points, intr, xy;
@@ -277,7 +296,20 @@ class Problem {
     std::vector<uint8_t> pose_mask, point_const, intr_const;
     std::vector<double*> pose_ptr, point_ptr, intr_ptr;   // where each flat block came from (nullptr: data, not a block)
     std::map<double*, Slot> slot_of;
+    // motion priors (constant interFrameRatio): lowered to rsba_set_motion_priors
+    int prior_kind = 0; double prior_scale = 0, prior_ratio = 1;
+    std::vector<int32_t> prior_frames;
   };
+  // device problem of a flattened graph: rsba_create + the prior blocks
+  static int32_t create_handle(const Flat& f, int device, rsba_handle** h) {
+    int32_t st = rsba_create(&f.desc, device, h);
+    if (st != RSBA_OK) return st;
+    if (!f.prior_frames.empty()) {
+      st = rsba_set_motion_priors(*h, f.prior_kind, f.prior_scale, f.prior_ratio, f.prior_frames.data(), (int32_t)f.prior_frames.size());
+      if (st != RSBA_OK) { rsba_destroy(*h); *h = nullptr; }
+    }
+    return st;
+  }
 
   void add(CostFunction* cost, LossFunction* loss, std::vector<double*> x) {
     costs_.insert(cost);
@@ -300,18 +332,19 @@ class Problem {
   bool flatten(Flat* f, std::string* why) {
     auto fail = [&](const char* m) { if (why) *why = m; return false; };
     if (blocks_.empty()) return fail("no residual blocks");
-    const ReprojectionCost* first = dynamic_cast<const ReprojectionCost*>(blocks_[0].cost);
-    if (!first) return fail("only rsba's reprojection cost functions are accelerated (priors: SURVEY §8f f1)");
+    const ReprojectionCost* first = nullptr; LossFunction* loss0 = nullptr;
+    for (const Block& b : blocks_) if ((first = dynamic_cast<const ReprojectionCost*>(b.cost))) { loss0 = b.loss; break; }
+    if (!first) return fail("only rsba's reprojection cost functions (plus motion priors between their frames) are accelerated");
     const bool rolling = first->rolling(), with_cam = first->with_cam();
     const int P = rolling ? 2 : 1;
-    LossFunction* loss0 = blocks_[0].loss;
     std::map<std::pair<double*, double*>, int> frame_of;
     std::map<double*, int> point_of, intr_of;
     std::map<std::vector<double>, int> intr_by_value;
     int32_t sl[2]; first->scanlines(sl);
     for (const Block& b : blocks_) {
+      if (dynamic_cast<const MotionPriorCost*>(b.cost)) continue;   // second pass below, once every frame has its number
       const ReprojectionCost* c = dynamic_cast<const ReprojectionCost*>(b.cost);
-      if (!c) return fail("only rsba's reprojection cost functions are accelerated (priors: SURVEY §8f f1)");
+      if (!c) return fail("only rsba's reprojection cost functions (plus motion priors between their frames) are accelerated");
       if (c->rolling() != rolling || c->with_cam() != with_cam) return fail("mixed functor shapes in one problem are not supported");
       if (b.loss != loss0) return fail("all residual blocks must share one loss function (as CeresHandler does)");
       if (b.x.size() != c->parameter_block_sizes().size()) return fail("wrong number of parameter blocks");
@@ -349,13 +382,31 @@ class Problem {
       f->xy.push_back(c->observed()[0]); f->xy.push_back(c->observed()[1]);
       f->obs_frame.push_back(fi); f->obs_point.push_back(pi);
     }
+    // motion priors (CeresHandler.h:147-185): blocks (ratio, f.p0, f.p1, f-1.p0, f-1.p1) between consecutive frames
+    for (const Block& b : blocks_) {
+      const MotionPriorCost* c = dynamic_cast<const MotionPriorCost*>(b.cost);
+      if (!c) continue;
+      if (!rolling || b.x.size() != 5) return fail("motion priors need rolling-shutter frames with two poses");
+      if (b.loss != loss0) return fail("all residual blocks must share one loss function (as CeresHandler does)");
+      if (!constant_.count(b.x[0])) return fail("a free interFrameRatio (opt.ceres.interFrameRatio == 1: lower-bounded parameter) is not built; set the option to the known ratio");
+      auto cur = frame_of.find(std::make_pair(b.x[1], b.x[2])), prev = frame_of.find(std::make_pair(b.x[3], b.x[4]));
+      if (cur == frame_of.end() || prev == frame_of.end()) return fail("motion prior on a frame without observations");
+      if (prev->second != cur->second - 1) return fail("motion priors must link consecutive frames");
+      if (f->prior_frames.empty()) { f->prior_kind = c->kind(); f->prior_scale = c->scale(); f->prior_ratio = *b.x[0]; }
+      else if (f->prior_kind != c->kind() || f->prior_scale != c->scale() || f->prior_ratio != *b.x[0]) return fail("motion priors of one problem must share kind, scale and ratio");
+      f->prior_frames.push_back(cur->second);
+      f->slot_of[b.x[0]] = Slot{3, 0};
+    }
+    std::sort(f->prior_frames.begin(), f->prior_frames.end());
+    if (std::adjacent_find(f->prior_frames.begin(), f->prior_frames.end()) != f->prior_frames.end()) return fail("two motion priors on one frame");
+    const int nscalar = f->prior_frames.empty() ? 0 : 1;
     // a pose pointer may not serve as pose0 of one frame and pose1 of another
-    if ((int)f->slot_of.size() != (int)f->pose_ptr.size() + (int)f->point_ptr.size() + (with_cam ? (int)f->intr_ptr.size() : 0))
+    if ((int)f->slot_of.size() - nscalar != (int)f->pose_ptr.size() + (int)f->point_ptr.size() + (with_cam ? (int)f->intr_ptr.size() : 0))
       return fail("a parameter block is used in two different roles");
     for (double* p : f->pose_ptr) f->pose_mask.push_back((uint8_t)(mask_of(p, 6) & 0x3f));
     for (double* p : f->point_ptr) f->point_const.push_back(constant_.count(p) ? 1 : 0);
     for (double* p : f->intr_ptr) f->intr_const.push_back(p && constant_.count(p) ? 1 : 0);
-    for (const auto& lb : lower_bounds_) if (f->slot_of.count(lb.first.first)) return fail("bounds on pose / point / intrinsics blocks are not supported");
+    for (const auto& lb : lower_bounds_) { auto it = f->slot_of.find(lb.first.first); if (it != f->slot_of.end() && it->second.kind != 3) return fail("bounds on pose / point / intrinsics blocks are not supported"); }
     rsba_problem_desc& d = f->desc; std::memset(&d, 0, sizeof d);
     d.shutter = first->shutter(); d.scanlines[0] = sl[0]; d.scanlines[1] = sl[1];
     d.interpolate_rotation = first->interpolate_rotation(); d.calibrated = !with_cam; d.poses_per_frame = P;
@@ -397,7 +448,7 @@ inline void Solve(const Solver::Options& options, Problem* problem, Solver::Summ
   std::string why;
   if (!problem->flatten(&f, &why)) { summary->termination_type = FAILURE; summary->message = why; return; }
   rsba_handle* h = nullptr;
-  int32_t st = rsba_create(&f.desc, options.device, &h);
+  int32_t st = Problem::create_handle(f, options.device, &h);
   if (st != RSBA_OK) { summary->termination_type = FAILURE; summary->message = std::string(rsba_status_string(st)) + ": " + rsba_last_error(); return; }
   rsba_solver_options o; rsba_default_solver_options(&o);
   o.max_num_iterations = options.max_num_iterations; o.jacobi_scaling = options.jacobi_scaling;
@@ -449,7 +500,7 @@ class Covariance {
       frames.insert(i0->second.index / P);
     }
     rsba_handle* h = nullptr;
-    if (rsba_create(&f.desc, options_.device, &h) != RSBA_OK) return false;
+    if (Problem::create_handle(f, options_.device, &h) != RSBA_OK) return false;
     bool ok = true;
     for (int fr : frames) {
       std::vector<double> cov((size_t)CD * CD);

@@ -3,15 +3,18 @@
 //   VideoSfMHandler::BA                        /root/reference/src/rsba/VideoSfMHandler.cc:574-631
 // Same names, argument meaning and error behaviour for the per-observation path (SURVEY Appendix D
 // steps 3-4).  Not built (they are "next" rows): pose initialisation of frames without poses
-// (Appendix D step 1), motion / pose priors (step 2), the structure-less ray costs, match-based track
-// lookup — reaching one of them throws std::runtime_error.  opt.debug.calcCovariances (VideoSfMHandler.cc:599-621) is built.  revalidateReprojections (:239-243) runs as one
+// (Appendix D step 1), pose priors (GoodPosePrior, step 2), the structure-less ray costs, match-based track
+// lookup — reaching one of them throws std::runtime_error.  Motion priors (:147-186) are built for a known
+// opt.ceres.interFrameRatio (!= 1: constant block); the free, lower-bounded ratio is reported by Solve, not silently fixed.  opt.debug.calcCovariances (VideoSfMHandler.cc:599-621) is built.  revalidateReprojections (:239-243) runs as one
 // batched device validation per frame (video_sfm.hpp).
 #pragma once
 #include <cmath>
 #include <iostream>
+#include <limits>
 #include <stdexcept>
 #include <thread>
 
+#include "motion_priors.hpp"
 #include "reprojection_costs.hpp"
 #include "video_sfm.hpp"
 
@@ -49,8 +52,27 @@ class CeresHandler {
     const int formerParamNum = problem.NumParameterBlocks();
     if (!f.__isset.poses) throw std::runtime_error("pose initialisation (CeresHandler.h:99-144) is not built: set Frame::poses");
     if (frameKey >= opt.ceres.fixFirstNCameras) {
-      if (frameKey > 0 && (opt.ceres.constFrameVelocity != 0 || opt.ceres.constFrameAcceleration != 0))
-        throw std::runtime_error("motion priors (CeresHandler.h:148-186) are not built");
+      if (frameKey > 0 && (opt.ceres.constFrameVelocity != 0 || opt.ceres.constFrameAcceleration != 0)) {   // :148-186
+        Frame& f_1 = sess.frames[frameKey - 1];
+        if (f.poses.size() == 2 && f_1.poses.size() == 2) {
+          if (opt.ceres.constFrameAcceleration != 0) {
+            problem.AddResidualBlock(RsConstAccelerationPrior::Create(opt.ceres.constFrameAcceleration), lossFunction, &opt.ceres.interFrameRatio,
+                                     f.poses[0].data(), f.poses[1].data(), f_1.poses[0].data(), f_1.poses[1].data());
+            problem.SetParameterLowerBound(&opt.ceres.interFrameRatio, 0, std::numeric_limits<double>::epsilon());   // _EPS
+          } else {
+            problem.AddResidualBlock(RsConstVeloPrior::Create(opt.ceres.constFrameVelocity), lossFunction, &opt.ceres.interFrameRatio,
+                                     f.poses[0].data(), f.poses[1].data(), f_1.poses[0].data(), f_1.poses[1].data());
+            problem.SetParameterLowerBound(&opt.ceres.interFrameRatio, 0, 0.0);
+          }
+          // :175-177.  With the option left at 1 the reference optimises the ratio as a lower-bounded parameter;
+          // that case is not built — Solve reports it (summary.message) instead of silently fixing the ratio.
+          if (opt.ceres.interFrameRatio != 1) problem.SetParameterBlockConstant(&opt.ceres.interFrameRatio);
+          if (frameKey - 1 < opt.ceres.fixFirstNCameras) {   // :179-184 the previous frame is one of the fixed cameras
+            for (auto& pose : f_1.poses) problem.SetParameterBlockConstant(pose.data());
+            if (f_1.__isset.cam) problem.SetParameterBlockConstant(f_1.cam.data());
+          }
+        }
+      }
       if ((opt.ceres.trustPriorCamRotation != 0 || opt.ceres.trustPriorCamPosition != 0) && f.__isset.priorPoses && !f.priorPoses.empty())
         throw std::runtime_error("pose priors (CeresHandler.h:188-204) are not built");
     }

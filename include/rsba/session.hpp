@@ -78,6 +78,7 @@ struct SfmOptions {
     bool fixPosition = false;
     double constFrameVelocity = 0;
     double constFrameAcceleration = 0;
+    double interFrameRatio = 1;       // SfmOptions.h:75; 1 = free (lower-bounded) parameter in the reference: not built here
     double trustPriorCamPosition = 0;
     double trustPriorCamRotation = 0;
     bool revalidateReprojections = false;

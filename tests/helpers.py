@@ -62,7 +62,8 @@ def rel_err(a, b):
     return float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b)))) if a.size else 0.0
 
 
-def write_scene_file(path, prob, *, fix_first_n=1, fix_scale=False, max_iter=20, revalidate=0.0, cov_frame=-1):
+def write_scene_file(path, prob, *, fix_first_n=1, fix_scale=False, max_iter=20, revalidate=0.0, cov_frame=-1,
+                     const_frame_velocity=0.0, const_frame_acceleration=0.0, inter_frame_ratio=1.0):
     """Binary scene file read by examples/ba_session.cpp (layout documented there)."""
     import struct
     with open(path, "wb") as f:
@@ -70,6 +71,7 @@ def write_scene_file(path, prob, *, fix_first_n=1, fix_scale=False, max_iter=20,
                             int(prob.scanlines[1]), int(prob.calibrated), int(prob.interpolate_rotation), fix_first_n, int(fix_scale), max_iter))
         f.write(struct.pack("<q", prob.num_observations))
         f.write(struct.pack("<ddd", float(prob.huber_a), float(revalidate), float(cov_frame)))
+        f.write(struct.pack("<ddd", float(const_frame_velocity), float(const_frame_acceleration), float(inter_frame_ratio)))
         f.write(prob.intrinsics[0].astype("<f8").tobytes())
         f.write(prob.poses.astype("<f8").tobytes())
         f.write(prob.points.astype("<f8").tobytes())

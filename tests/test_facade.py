@@ -61,6 +61,44 @@ def test_ba_of_a_session_matches_the_oracle(exe, oracle, tmp_path, rolling, hube
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind,huber", [(1, 0.0), (2, 2.0)])
+def test_ba_with_motion_priors_matches_the_oracle(exe, oracle, tmp_path, kind, huber):
+    """CeresHandler::Add's motion priors (CeresHandler.h:147-185) with a known interFrameRatio through the C++ host path."""
+    from rsba_amd.problem import apply_gauge_masks
+    p = small_problem(True, huber)
+    scale = 8.0 if kind == 1 else 20.0
+    write_scene_file(tmp_path / "s.bin", p, fix_first_n=1, max_iter=20, const_frame_velocity=scale if kind == 1 else 0.0,
+                     const_frame_acceleration=scale if kind == 2 else 0.0, inter_frame_ratio=0.8)
+    r = subprocess.run([exe, str(tmp_path / "s.bin"), str(tmp_path / "o.bin")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = read_result_file(tmp_path / "o.bin", p)
+    q = p.copy()
+    apply_gauge_masks(q, fix_first_n_cameras=1)
+    q.prior_kind, q.prior_scale, q.inter_frame_ratio = kind, scale, 0.8
+    q.prior_frames = np.arange(1, q.num_frames, dtype=np.int32)
+    s_ref, _ = oracle.solve(q, oracle.default_options(max_num_iterations=20))
+    assert out["usable"] and out["reduced"] == s_ref.num_residual_blocks_reduced
+    assert abs(out["initial_cost"] - s_ref.initial_cost) <= 1e-12 * s_ref.initial_cost
+    assert abs(out["final_cost"] - s_ref.final_cost) <= 1e-6 * s_ref.final_cost
+    assert np.max(np.abs(out["poses"] - q.poses)) <= 1e-5 and np.max(np.abs(out["points"] - q.points)) <= 1e-4
+    # and the priors did something: the plain solve ends elsewhere
+    q0 = p.copy(); apply_gauge_masks(q0, fix_first_n_cameras=1)
+    s0, _ = oracle.solve(q0, oracle.default_options(max_num_iterations=20))
+    assert s0.final_cost < s_ref.final_cost
+
+
+@pytest.mark.gpu
+def test_free_inter_frame_ratio_is_reported(exe, tmp_path):
+    """opt.ceres.interFrameRatio == 1 makes the ratio a free lower-bounded parameter in the reference: not built, said so."""
+    p = small_problem(True, 0.0)
+    write_scene_file(tmp_path / "s.bin", p, fix_first_n=1, max_iter=5, const_frame_velocity=5.0, inter_frame_ratio=1.0)
+    r = subprocess.run([exe, str(tmp_path / "s.bin"), str(tmp_path / "o.bin")], capture_output=True, text=True)
+    assert r.returncode == 1 and "interFrameRatio" in (r.stderr + r.stdout)
+    out = read_result_file(tmp_path / "o.bin", p)
+    assert not out["usable"] and np.array_equal(out["poses"], p.poses)
+
+
+@pytest.mark.gpu
 def test_revalidate_reprojections_drops_what_validate_rejects(exe, oracle, tmp_path):
     """CeresHandler.h:239-243: with revalidateReprojections the observations failing validate() never become
     residual blocks.  The oracle solves the problem with exactly those observations removed."""

@@ -62,7 +62,8 @@ def test_solve_trajectory_matches_oracle(capi, oracle, kind, scale, ratio, huber
         p.calibrated = False
     s, s_ref, p_dev, p_cpu = compare_solves(capi, oracle, p, iters=30)
     assert s.num_residual_blocks == s_ref.num_residual_blocks == p.num_observations + p.num_frames - 1
-    assert np.max(np.abs(p_dev.poses - p_cpu.poses)) <= 1e-6
+    # both stop at Ceres' default tolerances: the last step's size bounds how far apart they may end (as in test_gpu_solve.py)
+    assert np.max(np.abs(p_dev.poses - p_cpu.poses)) <= 1e-5
 
 
 def test_level_schedule_and_dag_agree_with_priors(capi):
