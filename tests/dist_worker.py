@@ -1,7 +1,7 @@
 """Worker for tests/test_distributed.py, launched by torch.distributed.run with 2 ranks.
    python -m torch.distributed.run --nproc-per-node 2 ... tests/dist_worker.py <mode> <outdir>
 mode "cpu": host-side exchange logic over gloo, partial blocks from the oracle (no GPU needed)
-mode "gpu": the sharded on-device LM solve, both ranks on GPU 0, exchange staged through gloo"""
+mode "gpu": the sharded on-device LM solve, both ranks on GPU 0, exchange staged through gloo ("gpu_priors": with motion priors)"""
 import json
 import os
 import sys
@@ -29,6 +29,9 @@ def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     full = scene()
+    if mode == "gpu_priors":   # motion priors are replicated terms: every rank lists them, rank 0 contributes them
+        full.prior_kind, full.prior_scale, full.inter_frame_ratio = 2, 25.0, 1.2
+        full.prior_frames = np.arange(1, full.num_frames, dtype=np.int32)
     shard = full.shard(rank, world)
     out = {"rank": rank, "world": world, "n_full": full.num_observations, "n_shard": shard.num_observations}
     if mode == "cpu":

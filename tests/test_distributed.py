@@ -36,8 +36,9 @@ def test_sharding_and_exchange_payloads_gloo(tmp_path, oracle):
 
 
 @pytest.mark.gpu
-def test_sharded_solve_equals_single_gpu_solve(tmp_path):
-    res = run_two_ranks("gpu", tmp_path)
+@pytest.mark.parametrize("mode", ["gpu", "gpu_priors"])
+def test_sharded_solve_equals_single_gpu_solve(tmp_path, mode):
+    res = run_two_ranks(mode, tmp_path)
     a, b = res
     assert a["final_cost"] == b["final_cost"] and a["iters"] == b["iters"]          # ranks decide identically
     assert a["iters"] == a["ref_iters"] and a["reduced"] == a["ref_reduced"] and a["params"] == a["ref_params"]

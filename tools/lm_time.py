@@ -1,5 +1,6 @@
 """LM iteration wall time of one configuration with the DAG Cholesky and with the per-level schedule (same task
-bodies), and the difference of the two solves.  usage: python tools/lm_time.py [C4] [iters]"""
+bodies), and the difference of the two solves.  usage: python tools/lm_time.py [C4] [iters] [priors]
+("priors": constant-velocity motion priors between all consecutive frames, scale 10, interFrameRatio 0.8)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -12,6 +13,9 @@ res = {}
 for mode in ("dag", "levels"):
     os.environ["RSBA_CHOL_LEVELS"] = "1" if mode == "levels" else "0"
     prob = make_config(name).problem
+    if len(sys.argv) > 3 and sys.argv[3] == "priors":
+        prob.prior_kind, prob.prior_scale, prob.inter_frame_ratio = 1, 10.0, 0.8
+        prob.prior_frames = np.arange(1, prob.num_frames, dtype=np.int32)
     p0, x0 = prob.poses.copy(), prob.points.copy()
     with capi.DeviceProblem(prob) as dp:
         opt = capi.default_options(max_num_iterations=iters, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
