@@ -202,6 +202,26 @@ int32_t rsba_pose_covariance(rsba_handle* h, int32_t frame, double* cov);
  * kind 0 or count 0 removes them.  With rsba_set_exchange every rank passes the same list (rank 0 contributes them). */
 int32_t rsba_set_motion_priors(rsba_handle* h, int32_t kind, double scale, double inter_frame_ratio, const int32_t* frames, int32_t count);
 
+/* == the RANSAC hypotheses of vision::solveRsPnPRansac (solveRSpnp.cpp:413-524), batched: task t is
+ * what pnpTask (:265-335) does for the subset subsets[t][0..m) of the n float points —
+ *   skipped (status 0, nothing else written) when two of its 3-D points coincide (:283-293);
+ *   vision::solveRsPnP (:100-192) from init_poses: ceres::Solve over the two pose blocks of one rolling-shutter frame,
+ *   one RsBA<float> residual block per point (:25-97; w2i without validation, tau from observed_x), max_num_iterations
+ *   (the reference: 10), all other options Ceres defaults; poses_out[t] = the result if usable (status 1), else the
+ *   initial poses (status 2);
+ *   num_inliers[t] = points whose float-rounded projection at the scan line of the TRUE observation lies closer than
+ *   reprojection_error (float distance) to the observation (:225-258, :304-310).
+ * Poses are rsba's 6-vectors (angle-axis world->camera, camera centre): [pose, pose2]; the rvec/tvec conversions of
+ * :119-128, :166-176 and the OpenCV GS initialisation (:111-117) stay with the caller.  init_stride 12 = one initial
+ * pair per task, 0 = one shared pair.  All pointers are host arrays; final_cost / num_inliers may be NULL.
+ * rsba_pnp_inliers returns the inlier flags [n] of one pose pair (the winning hypothesis' list, :312-326). */
+int32_t rsba_pnp_tasks(int32_t device, const double* cam, int32_t shutter, const int32_t* scanlines, const float* object_points,
+                       const float* image_points, int32_t n, const int32_t* subsets, int32_t m, int32_t num_tasks,
+                       const double* init_poses, int32_t init_stride, int32_t max_num_iterations, float reprojection_error,
+                       double* poses_out, uint8_t* status, double* final_cost, int32_t* num_inliers);
+int32_t rsba_pnp_inliers(int32_t device, const double* cam, int32_t shutter, const int32_t* scanlines, const float* object_points,
+                         const float* image_points, int32_t n, const double* poses, float reprojection_error, uint8_t* inlier_mask);
+
 /* ---- multi-GPU: one process per GPU, observations partitioned BY POINT, cameras replicated ----
  * (the reference is single-process; this is the exchange step SURVEY §8e derives for the path).
  * Every rank creates a handle over its own observations (all frames / points arrays are full size, a rank

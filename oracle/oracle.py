@@ -36,6 +36,7 @@ class OrcProblem(C.Structure):
         ("intrinsics_constant", C.c_void_p), ("huber_a", C.c_double),
         ("prior_kind", C.c_int32), ("num_priors", C.c_int32), ("prior_frames", C.c_void_p),
         ("prior_scale", C.c_double), ("inter_frame_ratio", C.c_double),
+        ("no_validate", C.c_int32), ("pad_", C.c_int32),
     ]
 
 
@@ -160,6 +161,21 @@ def pose_covariance(prob, frame: int):
     cov = np.zeros((cd, cd))
     ok = lib().orc_pose_covariance(C.byref(d), C.c_int32(frame), _ptr(cov))
     return cov, bool(ok)
+
+
+def pnp_task(cam, shutter, scanlines, object_points, image_points, subset, init_poses, max_iter=10, reprojection_error=8.0):
+    """One RANSAC hypothesis of solveRsPnPRansac (rsba_oracle.h: orc_pnp_task) -> dict or None if skipped"""
+    cam = np.ascontiguousarray(cam, dtype=np.float64); sl = np.ascontiguousarray(scanlines, dtype=np.int32)
+    op = np.ascontiguousarray(object_points, dtype=np.float32).reshape(-1, 3); ip = np.ascontiguousarray(image_points, dtype=np.float32).reshape(-1, 2)
+    sub = np.ascontiguousarray(subset, dtype=np.int32); init = np.ascontiguousarray(init_poses, dtype=np.float64).reshape(12)
+    poses = np.zeros((2, 6)); mask = np.zeros(len(op), dtype=np.uint8)
+    usable, cnt, cost = C.c_int32(0), C.c_int32(0), C.c_double(0.0)
+    done = lib().orc_pnp_task(_ptr(cam), C.c_int32(int(shutter)), _ptr(sl), _ptr(op), _ptr(ip), C.c_int32(len(op)), _ptr(sub), C.c_int32(len(sub)),
+                              _ptr(init), C.c_int32(int(max_iter)), C.c_double(float(reprojection_error)), _ptr(poses), C.byref(usable), C.byref(cost),
+                              C.byref(cnt), _ptr(mask))
+    if not done:
+        return None
+    return dict(poses=poses, usable=bool(usable.value), final_cost=cost.value, num_inliers=cnt.value, mask=mask.astype(bool))
 
 
 def default_options(**kw) -> OrcOptions:

@@ -44,8 +44,8 @@ bool block_eval(const orc_problem* p, int64_t i, double* r, double* J /* [2][K] 
   if (!J) {
     double rr[2];
     bool ok;
-    if (P == 2) ok = rs_residual<double>(cam, pose, pose + 6, X, ox, oy, p->shutter, p->scanlines, p->interpolate_rotation != 0, rr);
-    else ok = gs_residual<double>(cam, pose, X, ox, oy, rr);
+    if (P == 2) ok = rs_residual<double>(cam, pose, pose + 6, X, ox, oy, p->shutter, p->scanlines, p->interpolate_rotation != 0, rr, !p->no_validate);
+    else ok = gs_residual<double>(cam, pose, X, ox, oy, rr, !p->no_validate);
     if (ok) { r[0] = rr[0]; r[1] = rr[1]; }
     return ok;
   }
@@ -56,8 +56,8 @@ bool block_eval(const orc_problem* p, int64_t i, double* r, double* J /* [2][K] 
   for (int k = 0; k < 6 * P; ++k) dpose[k] = D(pose[k], col++);
   for (int k = 0; k < 3; ++k) dX[k] = D(X[k], col++);
   bool ok;
-  if (P == 2) ok = rs_residual<D>(dcam, dpose, dpose + 6, dX, ox, oy, p->shutter, p->scanlines, p->interpolate_rotation != 0, res);
-  else ok = gs_residual<D>(dcam, dpose, dX, ox, oy, res);
+  if (P == 2) ok = rs_residual<D>(dcam, dpose, dpose + 6, dX, ox, oy, p->shutter, p->scanlines, p->interpolate_rotation != 0, res, !p->no_validate);
+  else ok = gs_residual<D>(dcam, dpose, dX, ox, oy, res, !p->no_validate);
   if (!ok) return false;
   r[0] = res[0].a; r[1] = res[1].a;
   for (int k = 0; k < K; ++k) { J[k] = res[0].v[k]; J[K + k] = res[1].v[k]; }
@@ -718,6 +718,55 @@ int32_t orc_pose_covariance(const orc_problem* p, int32_t frame, double* cov) {
       if (ia != freec.end() && *ia == ga) cov[a * CD + k] = e[ia - freec.begin()];
     }
   }
+  return 1;
+}
+
+int32_t orc_pnp_task(const double cam[9], int32_t shutter, const int32_t scanlines[2], const float* object_points, const float* image_points,
+                     int32_t n, const int32_t* subset, int32_t m, const double init_poses[12], int32_t max_iter, double reprojection_error,
+                     double poses_out[12], int32_t* usable, double* final_cost, int32_t* num_inliers, uint8_t* inlier_mask) {
+  // solveRSpnp.cpp:283-293: hypotheses with two coincident 3-D points are dropped (float differences, norm in double)
+  for (int i = 0; i < m; ++i) for (int j = i + 1; j < m; ++j) {
+    const float* a = object_points + 3 * (size_t)subset[i]; const float* b = object_points + 3 * (size_t)subset[j];
+    const float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+    if (std::sqrt((double)dx * dx + (double)dy * dy + (double)dz * dz) < 1e-10) return 0;
+  }
+  // solveRSpnp.cpp:127-161: one RsBA<float> block per point over (pose, pose2); float data widened to double
+  std::vector<double> poses(init_poses, init_poses + 12), pts((size_t)3 * m), xy((size_t)2 * m), intr(cam, cam + 9);
+  std::vector<int32_t> of(m, 0), op(m); std::vector<uint8_t> pconst(m, 1);
+  for (int i = 0; i < m; ++i) {
+    op[i] = i;
+    for (int k = 0; k < 3; ++k) pts[3 * (size_t)i + k] = (double)object_points[3 * (size_t)subset[i] + k];
+    for (int k = 0; k < 2; ++k) xy[2 * (size_t)i + k] = (double)image_points[2 * (size_t)subset[i] + k];
+  }
+  orc_problem P; std::memset(&P, 0, sizeof P);
+  P.shutter = shutter; P.scanlines[0] = scanlines[0]; P.scanlines[1] = scanlines[1]; P.interpolate_rotation = 1; P.calibrated = 1;
+  P.poses_per_frame = 2; P.num_frames = 1; P.num_points = m; P.num_intrinsics = 1; P.num_observations = m;
+  P.poses = poses.data(); P.points = pts.data(); P.intrinsics = intr.data(); P.obs_xy = xy.data(); P.obs_frame = of.data(); P.obs_point = op.data();
+  P.point_constant = pconst.data(); P.no_validate = 1; P.inter_frame_ratio = 1.0;
+  orc_options o; orc_default_options(&o); o.max_num_iterations = max_iter; o.num_threads = 1;
+  orc_summary s;
+  const int32_t term = orc_solve(&P, &o, &s, nullptr, 0);
+  const bool ok = term != ORC_FAILURE;                       // Summary::IsSolutionUsable
+  for (int k = 0; k < 12; ++k) poses_out[k] = ok ? poses[k] : init_poses[k];   // :162-176: the Mats change only then
+  if (usable) *usable = ok;
+  if (final_cost) *final_cost = s.final_cost;
+  // solveRSpnp.cpp:225-258 project3dPoints + :304-310
+  int cnt = 0;
+  for (int i = 0; i < n; ++i) {
+    const double X[3] = {(double)object_points[3 * (size_t)i], (double)object_points[3 * (size_t)i + 1], (double)object_points[3 * (size_t)i + 2]};
+    const float ix = image_points[2 * (size_t)i], iy = image_points[2 * (size_t)i + 1];
+    const double obs[2] = {(double)ix, (double)iy};
+    double pose[6], proj[2];
+    interpolate_rs<double>(poses_out, poses_out + 6, shutter, scanlines, obs, pose, true);
+    bool in = false;
+    if (w2i<double>(cam, pose, X, proj, false)) {              // the reference aborts on failure; here: not an inlier
+      const float dx = ix - (float)proj[0], dy = iy - (float)proj[1];
+      in = std::sqrt((double)dx * dx + (double)dy * dy) < (double)(float)reprojection_error;
+    }
+    if (inlier_mask) inlier_mask[i] = in;
+    cnt += in;
+  }
+  if (num_inliers) *num_inliers = cnt;
   return 1;
 }
 

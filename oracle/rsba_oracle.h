@@ -40,6 +40,8 @@ typedef struct orc_problem {
   const int32_t* prior_frames;   /* [num_priors], strictly increasing, each >= 1 */
   double prior_scale;            /* opt.ceres.constFrameVelocity / constFrameAcceleration */
   double inter_frame_ratio;      /* opt.ceres.interFrameRatio */
+  int32_t no_validate;           /* 1 = the RS-PnP functor RsBA: w2i(..., validate = false) (solveRSpnp.cpp:67) */
+  int32_t pad_;
 } orc_problem;
 
 /* Ceres 1.9 Solver::Options subset (defaults: SURVEY Appendix C.5) */
@@ -101,6 +103,17 @@ int32_t orc_solve(orc_problem* p, const orc_options* opt, orc_summary* summary, 
 /* ceres::Covariance blocks of one frame's poses (VideoSfMHandler.cc:602-621): cov [CD][CD], CD = 6 * poses_per_frame;
  * returns 1 on success, 0 if J^T J is rank deficient or a functor fails. */
 int32_t orc_pose_covariance(const orc_problem* p, int32_t frame, double* cov);
+
+/* One RANSAC hypothesis of solveRsPnPRansac (solveRSpnp.cpp:265-335 pnpTask + :100-192 solveRsPnP), poses in rsba's
+ * convention (angle-axis world->camera, camera centre) — the rvec/tvec conversions either side are the caller's:
+ * the m points subset[] of the float object / image points (skipped when two of them coincide, :283-293), LM over the two
+ * pose blocks with RsBA<float> residual blocks (max_iter iterations, Ceres defaults), the result kept if usable, then
+ * the inliers among all n points: float distance between the observation and the float-rounded projection at the
+ * TRUE observation's scan line < reprojection_error (:225-258, :304-310).
+ * Returns 0 = skipped (nothing written), 1 = done.  inlier_mask may be NULL. */
+int32_t orc_pnp_task(const double cam[9], int32_t shutter, const int32_t scanlines[2], const float* object_points, const float* image_points,
+                     int32_t n, const int32_t* subset, int32_t m, const double init_poses[12], int32_t max_iter, double reprojection_error,
+                     double poses_out[12], int32_t* usable, double* final_cost, int32_t* num_inliers, uint8_t* inlier_mask);
 
 /* Scalar entry points for the known-answer tests (mat_test.cc) */
 void orc_angle_axis_rotate(const double w[3], const double p[3], double out[3]);

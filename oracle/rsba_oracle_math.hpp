@@ -336,9 +336,9 @@ inline bool ray_dist(const double cam[kCam], const double pose[kPose], const dou
 // video_bundler_free.h:44-65 ReprojectionError::operator()(camera,pose,point): w2i with validate,
 // residual = projection - observation; the 5-px branch returns true on both arms.
 template <class T>
-inline bool gs_residual(const T cam[kCam], const T pose[kPose], const T X[3], double ox, double oy, T res[2]) {
+inline bool gs_residual(const T cam[kCam], const T pose[kPose], const T X[3], double ox, double oy, T res[2], bool validate = true) {
   T proj[2];
-  if (!w2i(cam, pose, X, proj, true)) return false;
+  if (!w2i(cam, pose, X, proj, validate)) return false;
   res[0] = proj[0] - T(ox);
   res[1] = proj[1] - T(oy);
   return true;
@@ -348,11 +348,11 @@ inline bool gs_residual(const T cam[kCam], const T pose[kPose], const T X[3], do
 // entries are x (reference quirk, kept), pose = interpolate_rs(...), then the GS residual.
 template <class T>
 inline bool rs_residual(const T cam[kCam], const T p0[kPose], const T p1[kPose], const T X[3], double ox, double oy,
-                        int shutter, const int scan[2], bool interp_rotation, T res[2]) {
+                        int shutter, const int scan[2], bool interp_rotation, T res[2], bool validate = true) {
   T pose[kPose];
   const T obs[2] = {T(ox), T(ox)};
   interpolate_rs(p0, p1, shutter, scan, obs, pose, interp_rotation);
-  return gs_residual(cam, pose, X, ox, oy, res);
+  return gs_residual(cam, pose, X, ox, oy, res, validate);   // validate = false: solveRSpnp.cpp:67 (RsBA)
 }
 
 // struct/VideoSfM.cc:103-133 getPose (copying overload), 1- and 2-pose cases: the non-autodiff twin

@@ -22,6 +22,7 @@ EXPORTS = [
     "rsba_get_device_view", "rsba_time_evaluate", "rsba_default_solver_options", "rsba_solve", "rsba_normal_equations",
     "rsba_set_exchange", "rsba_get_block_structure", "rsba_set_block_structure",
     "rsba_validate_observations", "rsba_reproject", "rsba_pose_covariance", "rsba_set_motion_priors",
+    "rsba_pnp_tasks", "rsba_pnp_inliers",
 ]
 
 
@@ -263,6 +264,34 @@ class DeviceProblem:
         st = lib().rsba_solve(self._h, C.byref(o), C.byref(s), tr, C.c_int32(trace_cap))
         _check(st)
         return s, [tr[i] for i in range(min(s.num_iterations, trace_cap))]
+
+
+def pnp_tasks(cam, shutter, scanlines, object_points, image_points, subsets, init_poses, max_num_iterations=10,
+              reprojection_error=8.0, device=0):
+    """The RANSAC hypotheses of solveRsPnPRansac, batched (rsba_amd.h: rsba_pnp_tasks).
+    object_points [n,3] float32, image_points [n,2] float32, subsets [H,m] int32, init_poses [12] or [H,12].
+    -> dict(poses [H,2,6], status [H], final_cost [H], num_inliers [H])"""
+    cam = np.ascontiguousarray(cam, dtype=np.float64); sl = np.ascontiguousarray(scanlines, dtype=np.int32)
+    op = np.ascontiguousarray(object_points, dtype=np.float32).reshape(-1, 3); ip = np.ascontiguousarray(image_points, dtype=np.float32).reshape(-1, 2)
+    sub = np.ascontiguousarray(subsets, dtype=np.int32); H, m = sub.shape
+    init = np.ascontiguousarray(init_poses, dtype=np.float64).reshape(-1, 12)
+    assert len(init) in (1, H)
+    poses = np.zeros((H, 2, 6)); status = np.zeros(H, dtype=np.uint8); cost = np.zeros(H); inl = np.zeros(H, dtype=np.int32)
+    _check(lib().rsba_pnp_tasks(C.c_int32(device), _ptr(cam), C.c_int32(int(shutter)), _ptr(sl), _ptr(op), _ptr(ip), C.c_int32(len(op)),
+                                _ptr(sub), C.c_int32(m), C.c_int32(H), _ptr(init), C.c_int32(12 if len(init) == H else 0),
+                                C.c_int32(int(max_num_iterations)), C.c_float(float(reprojection_error)), _ptr(poses), _ptr(status), _ptr(cost), _ptr(inl)))
+    return dict(poses=poses, status=status, final_cost=cost, num_inliers=inl)
+
+
+def pnp_inliers(cam, shutter, scanlines, object_points, image_points, poses, reprojection_error=8.0, device=0):
+    """Inlier flags [n] of one pose pair (rsba_amd.h: rsba_pnp_inliers)."""
+    cam = np.ascontiguousarray(cam, dtype=np.float64); sl = np.ascontiguousarray(scanlines, dtype=np.int32)
+    op = np.ascontiguousarray(object_points, dtype=np.float32).reshape(-1, 3); ip = np.ascontiguousarray(image_points, dtype=np.float32).reshape(-1, 2)
+    ps = np.ascontiguousarray(poses, dtype=np.float64).reshape(12)
+    mask = np.zeros(len(op), dtype=np.uint8)
+    _check(lib().rsba_pnp_inliers(C.c_int32(device), _ptr(cam), C.c_int32(int(shutter)), _ptr(sl), _ptr(op), _ptr(ip), C.c_int32(len(op)),
+                                  _ptr(ps), C.c_float(float(reprojection_error)), _ptr(mask)))
+    return mask.astype(bool)
 
 
 def default_options(**kw) -> SolverOptions:
