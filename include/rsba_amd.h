@@ -204,7 +204,8 @@ int32_t rsba_set_motion_priors(rsba_handle* h, int32_t kind, double scale, doubl
 
 /* == the RANSAC hypotheses of vision::solveRsPnPRansac (solveRSpnp.cpp:413-524), batched: task t is
  * what pnpTask (:265-335) does for the subset subsets[t][0..m) of the n float points —
- *   skipped (status 0, nothing else written) when two of its 3-D points coincide (:283-293);
+ *   skipped (status 0, nothing else written) when drop_coincident != 0 and two of its 3-D points coincide (:283-293;
+ *   the final refinement over the inliers, :496-502, is the same call with drop_coincident = 0);
  *   vision::solveRsPnP (:100-192) from init_poses: ceres::Solve over the two pose blocks of one rolling-shutter frame,
  *   one RsBA<float> residual block per point (:25-97; w2i without validation, tau from observed_x), max_num_iterations
  *   (the reference: 10), all other options Ceres defaults; poses_out[t] = the result if usable (status 1), else the
@@ -217,7 +218,7 @@ int32_t rsba_set_motion_priors(rsba_handle* h, int32_t kind, double scale, doubl
  * rsba_pnp_inliers returns the inlier flags [n] of one pose pair (the winning hypothesis' list, :312-326). */
 int32_t rsba_pnp_tasks(int32_t device, const double* cam, int32_t shutter, const int32_t* scanlines, const float* object_points,
                        const float* image_points, int32_t n, const int32_t* subsets, int32_t m, int32_t num_tasks,
-                       const double* init_poses, int32_t init_stride, int32_t max_num_iterations, float reprojection_error,
+                       const double* init_poses, int32_t init_stride, int32_t max_num_iterations, int32_t drop_coincident, float reprojection_error,
                        double* poses_out, uint8_t* status, double* final_cost, int32_t* num_inliers);
 int32_t rsba_pnp_inliers(int32_t device, const double* cam, int32_t shutter, const int32_t* scanlines, const float* object_points,
                          const float* image_points, int32_t n, const double* poses, float reprojection_error, uint8_t* inlier_mask);

@@ -163,7 +163,7 @@ def pose_covariance(prob, frame: int):
     return cov, bool(ok)
 
 
-def pnp_task(cam, shutter, scanlines, object_points, image_points, subset, init_poses, max_iter=10, reprojection_error=8.0):
+def pnp_task(cam, shutter, scanlines, object_points, image_points, subset, init_poses, max_iter=10, reprojection_error=8.0, drop_coincident=True):
     """One RANSAC hypothesis of solveRsPnPRansac (rsba_oracle.h: orc_pnp_task) -> dict or None if skipped"""
     cam = np.ascontiguousarray(cam, dtype=np.float64); sl = np.ascontiguousarray(scanlines, dtype=np.int32)
     op = np.ascontiguousarray(object_points, dtype=np.float32).reshape(-1, 3); ip = np.ascontiguousarray(image_points, dtype=np.float32).reshape(-1, 2)
@@ -171,7 +171,7 @@ def pnp_task(cam, shutter, scanlines, object_points, image_points, subset, init_
     poses = np.zeros((2, 6)); mask = np.zeros(len(op), dtype=np.uint8)
     usable, cnt, cost = C.c_int32(0), C.c_int32(0), C.c_double(0.0)
     done = lib().orc_pnp_task(_ptr(cam), C.c_int32(int(shutter)), _ptr(sl), _ptr(op), _ptr(ip), C.c_int32(len(op)), _ptr(sub), C.c_int32(len(sub)),
-                              _ptr(init), C.c_int32(int(max_iter)), C.c_double(float(reprojection_error)), _ptr(poses), C.byref(usable), C.byref(cost),
+                              C.c_int32(int(drop_coincident)), _ptr(init), C.c_int32(int(max_iter)), C.c_double(float(reprojection_error)), _ptr(poses), C.byref(usable), C.byref(cost),
                               C.byref(cnt), _ptr(mask))
     if not done:
         return None

@@ -722,10 +722,10 @@ int32_t orc_pose_covariance(const orc_problem* p, int32_t frame, double* cov) {
 }
 
 int32_t orc_pnp_task(const double cam[9], int32_t shutter, const int32_t scanlines[2], const float* object_points, const float* image_points,
-                     int32_t n, const int32_t* subset, int32_t m, const double init_poses[12], int32_t max_iter, double reprojection_error,
+                     int32_t n, const int32_t* subset, int32_t m, int32_t drop_coincident, const double init_poses[12], int32_t max_iter, double reprojection_error,
                      double poses_out[12], int32_t* usable, double* final_cost, int32_t* num_inliers, uint8_t* inlier_mask) {
   // solveRSpnp.cpp:283-293: hypotheses with two coincident 3-D points are dropped (float differences, norm in double)
-  for (int i = 0; i < m; ++i) for (int j = i + 1; j < m; ++j) {
+  if (drop_coincident) for (int i = 0; i < m; ++i) for (int j = i + 1; j < m; ++j) {
     const float* a = object_points + 3 * (size_t)subset[i]; const float* b = object_points + 3 * (size_t)subset[j];
     const float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
     if (std::sqrt((double)dx * dx + (double)dy * dy + (double)dz * dz) < 1e-10) return 0;

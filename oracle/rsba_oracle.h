@@ -106,13 +106,13 @@ int32_t orc_pose_covariance(const orc_problem* p, int32_t frame, double* cov);
 
 /* One RANSAC hypothesis of solveRsPnPRansac (solveRSpnp.cpp:265-335 pnpTask + :100-192 solveRsPnP), poses in rsba's
  * convention (angle-axis world->camera, camera centre) — the rvec/tvec conversions either side are the caller's:
- * the m points subset[] of the float object / image points (skipped when two of them coincide, :283-293), LM over the two
+ * the m points subset[] of the float object / image points (skipped when drop_coincident and two of them coincide, :283-293), LM over the two
  * pose blocks with RsBA<float> residual blocks (max_iter iterations, Ceres defaults), the result kept if usable, then
  * the inliers among all n points: float distance between the observation and the float-rounded projection at the
  * TRUE observation's scan line < reprojection_error (:225-258, :304-310).
  * Returns 0 = skipped (nothing written), 1 = done.  inlier_mask may be NULL. */
 int32_t orc_pnp_task(const double cam[9], int32_t shutter, const int32_t scanlines[2], const float* object_points, const float* image_points,
-                     int32_t n, const int32_t* subset, int32_t m, const double init_poses[12], int32_t max_iter, double reprojection_error,
+                     int32_t n, const int32_t* subset, int32_t m, int32_t drop_coincident, const double init_poses[12], int32_t max_iter, double reprojection_error,
                      double poses_out[12], int32_t* usable, double* final_cost, int32_t* num_inliers, uint8_t* inlier_mask);
 
 /* Scalar entry points for the known-answer tests (mat_test.cc) */

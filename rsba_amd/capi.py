@@ -267,7 +267,7 @@ class DeviceProblem:
 
 
 def pnp_tasks(cam, shutter, scanlines, object_points, image_points, subsets, init_poses, max_num_iterations=10,
-              reprojection_error=8.0, device=0):
+              reprojection_error=8.0, device=0, drop_coincident=True):
     """The RANSAC hypotheses of solveRsPnPRansac, batched (rsba_amd.h: rsba_pnp_tasks).
     object_points [n,3] float32, image_points [n,2] float32, subsets [H,m] int32, init_poses [12] or [H,12].
     -> dict(poses [H,2,6], status [H], final_cost [H], num_inliers [H])"""
@@ -279,7 +279,8 @@ def pnp_tasks(cam, shutter, scanlines, object_points, image_points, subsets, ini
     poses = np.zeros((H, 2, 6)); status = np.zeros(H, dtype=np.uint8); cost = np.zeros(H); inl = np.zeros(H, dtype=np.int32)
     _check(lib().rsba_pnp_tasks(C.c_int32(device), _ptr(cam), C.c_int32(int(shutter)), _ptr(sl), _ptr(op), _ptr(ip), C.c_int32(len(op)),
                                 _ptr(sub), C.c_int32(m), C.c_int32(H), _ptr(init), C.c_int32(12 if len(init) == H else 0),
-                                C.c_int32(int(max_num_iterations)), C.c_float(float(reprojection_error)), _ptr(poses), _ptr(status), _ptr(cost), _ptr(inl)))
+                                C.c_int32(int(max_num_iterations)), C.c_int32(int(drop_coincident)), C.c_float(float(reprojection_error)), _ptr(poses), _ptr(status),
+                                _ptr(cost), _ptr(inl)))
     return dict(poses=poses, status=status, final_cost=cost, num_inliers=inl)
 
 

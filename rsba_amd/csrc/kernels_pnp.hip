@@ -59,7 +59,7 @@ __global__ __launch_bounds__(kPnpBlock) void pnp_tasks_kernel(const PnpArgs A) {
   const int32_t* sub = A.subsets + (size_t)h * A.m;
   const Model mdl{A.shutter, A.scan0, A.scan1, 1};
   // coincident 3-D points (float differences, norm in double)
-  for (int i = 0; i < A.m; ++i) for (int j = i + 1; j < A.m; ++j) {
+  if (A.drop_coincident) for (int i = 0; i < A.m; ++i) for (int j = i + 1; j < A.m; ++j) {
     const float* a = A.object_points + 3 * (size_t)sub[i]; const float* b = A.object_points + 3 * (size_t)sub[j];
     const float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
     if (sqrt((double)dx * dx + (double)dy * dy + (double)dz * dz) < 1e-10) { A.status[h] = 0; return; }

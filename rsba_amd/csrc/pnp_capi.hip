@@ -60,7 +60,7 @@ int32_t fill_camera(PnpArgs& A, const double* cam, int32_t shutter, const int32_
 
 extern "C" int32_t rsba_pnp_tasks(int32_t device, const double* cam, int32_t shutter, const int32_t* scanlines, const float* object_points,
                                   const float* image_points, int32_t n, const int32_t* subsets, int32_t m, int32_t num_tasks,
-                                  const double* init_poses, int32_t init_stride, int32_t max_num_iterations, float reprojection_error,
+                                  const double* init_poses, int32_t init_stride, int32_t max_num_iterations, int32_t drop_coincident, float reprojection_error,
                                   double* poses_out, uint8_t* status, double* final_cost, int32_t* num_inliers) {
   if (!object_points || !image_points || !subsets || !init_poses || !poses_out || !status)
     return rsba_set_error(RSBA_ERR_INVALID_ARGUMENT, "null argument");
@@ -72,7 +72,7 @@ extern "C" int32_t rsba_pnp_tasks(int32_t device, const double* cam, int32_t shu
   int32_t rc = fill_camera(A, cam, shutter, scanlines, reprojection_error);
   if (rc) return rc;
   if ((rc = select_device(device))) return rc;
-  A.n = n; A.m = m; A.num_tasks = num_tasks; A.init_stride = init_stride; A.max_num_iterations = max_num_iterations;
+  A.n = n; A.m = m; A.num_tasks = num_tasks; A.init_stride = init_stride; A.max_num_iterations = max_num_iterations; A.drop_coincident = drop_coincident;
   DeviceBuffers B;
   PNP_TRY(B.upload(&A.object_points, object_points, (size_t)n * 3));
   PNP_TRY(B.upload(&A.image_points, image_points, (size_t)n * 2));

@@ -8,7 +8,7 @@ namespace rsba {
 struct PnpArgs {
   double cam[9];                 // {fx,fy,k1,k2,p1,p2,k3,cx,cy}
   int shutter, scan0, scan1;
-  int n, m, num_tasks, init_stride, max_num_iterations;
+  int n, m, num_tasks, init_stride, max_num_iterations, drop_coincident;
   float reprojection_error;
   const float* object_points;    // [n][3]
   const float* image_points;     // [n][2]

@@ -107,3 +107,79 @@ def test_bad_arguments(capi):
         capi.pnp_tasks(CAM, HORIZONTAL, (0, 1280), X, xy, np.array([[0, 1, 2, 3, 4, 8]], dtype=np.int32), np.zeros(12))
     with pytest.raises(capi.RsbaError):
         capi.pnp_tasks(CAM, HORIZONTAL, (5, 5), X, xy, np.array([[0, 1, 2, 3, 4, 5]], dtype=np.int32), np.zeros(12))
+
+
+# ---- the whole RANSAC flow through the C++ mirror (include/rsba/solve_rs_pnp.hpp) vs a sequential replay through the oracle ----
+class CvRng:
+    """cv::RNG restated (multiply-with-carry), as in solve_rs_pnp.hpp"""
+    def __init__(self, state=0xffffffff):
+        self.state = state
+    def next(self):
+        self.state = ((self.state & 0xffffffff) * 4164903690 + (self.state >> 32)) & 0xffffffffffffffff
+        return self.state & 0xffffffff
+    def uniform(self, a, b):
+        return a if a == b else int(self.next() % (b - a) + a)
+
+
+def to_pose(oracle, rvec, tvec):
+    return np.concatenate([rvec, oracle.angle_axis_rotate(-np.asarray(rvec), -np.asarray(tvec))])
+
+
+def from_pose(oracle, pose):
+    return pose[:3].copy(), -oracle.angle_axis_rotate(pose[:3], pose[3:])
+
+
+def ransac_replay(oracle, sc, shutter, init, iterations, err, min_inliers, m, state):
+    """solveRsPnPRansac (solveRSpnp.cpp:413-524), single-threaded, every solve by the oracle"""
+    n = len(sc["X"])
+    mask = np.zeros(n, dtype=bool); mask[:m] = True
+    gen = CvRng(state)
+    best, best_pose = 0, None
+    for _ in range(iterations):
+        for _ in range(n):
+            i1, i2 = gen.uniform(0, n), gen.uniform(0, n)
+            mask[i1], mask[i2] = mask[i2], mask[i1]
+        r = oracle.pnp_task(CAM, shutter, sc["scan"], sc["X"], sc["xy"], np.flatnonzero(mask), init, 10, err)
+        if r is not None and r["num_inliers"] > best:
+            best, best_pose, best_mask = r["num_inliers"], r["poses"], r["mask"]
+        if best >= min_inliers:
+            break
+    if best_pose is None or best < m:
+        return None
+    idx = np.flatnonzero(best_mask)
+    r = oracle.pnp_task(CAM, shutter, sc["scan"], sc["X"], sc["xy"], idx, best_pose, 10, err, drop_coincident=False)
+    return (r["poses"] if r["usable"] else best_pose), idx
+
+
+@pytest.mark.parametrize("min_inliers", [100, 10 ** 6])
+def test_ransac_host_program_matches_sequential_oracle_replay(oracle, tmp_path, min_inliers):
+    import os, struct, subprocess
+    import __graft_entry__ as G
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "pnp_ransac")
+    if not os.path.exists(exe):
+        G.build()
+    sc = pnp_scene(oracle, HORIZONTAL, n=220, outliers=0.3, seed=8)
+    init = sc["init"]
+    (r1, t1), (r2, t2) = from_pose(oracle, init[0]), from_pose(oracle, init[1])
+    # the program converts rvec/tvec to poses itself: start the replay from the same converted values
+    init_rt = np.stack([to_pose(oracle, r1, t1), to_pose(oracle, r2, t2)])
+    iterations, err, m, state = 60, 3.0, 6, 0x1234567
+    with open(tmp_path / "p.bin", "wb") as f:
+        f.write(struct.pack("<7i", len(sc["X"]), HORIZONTAL, sc["scan"][0], sc["scan"][1], iterations, min(min_inliers, 2 ** 30), m))
+        f.write(struct.pack("<f", err)); f.write(struct.pack("<Q", state))
+        f.write(CAM.astype("<f8").tobytes())
+        for v in (r1, t1, r2, t2):
+            f.write(np.asarray(v, dtype="<f8").tobytes())
+        f.write(sc["X"].astype("<f4").tobytes()); f.write(sc["xy"].astype("<f4").tobytes())
+    r = subprocess.run([exe, str(tmp_path / "p.bin"), str(tmp_path / "o.bin")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    raw = open(tmp_path / "o.bin", "rb").read()
+    v = np.frombuffer(raw[:96], dtype="<f8"); cnt = struct.unpack("<i", raw[96:100])[0]
+    inl = np.frombuffer(raw[100:100 + 4 * cnt], dtype="<i4")
+    ref = ransac_replay(oracle, sc, HORIZONTAL, init_rt, iterations, err, min_inliers, m, state)
+    assert ref is not None
+    ref_poses, ref_idx = ref
+    assert len(np.setxor1d(inl, ref_idx)) <= 1                     # same winner, same inlier list (one borderline point at most)
+    got = np.stack([to_pose(oracle, v[0:3], v[3:6]), to_pose(oracle, v[6:9], v[9:12])])
+    assert np.max(np.abs(got - ref_poses)) <= 1e-6
+    assert cnt >= 0.8 * (~sc["outlier"]).sum() and np.max(np.abs(got - sc["poses"])) <= 0.05
