@@ -7,12 +7,17 @@
 //     double huber, double revalidate (squared px threshold of revalidateReprojections, <= 0 = off), double covFrame (>= 0:
 //     calcCovariances, the pp | pe | ee blocks of that frame are appended to the result file), double constFrameVelocity,
 //     constFrameAcceleration, interFrameRatio (motion priors, CeresHandler.h:147-185), double cam[9], poses[F*P*6], points[M*3], obs_xy[N*2], int32 obs_frame[N], obs_point[N]
+//   ba_session --cache session.cache out.bin [fixFirstN=1] [maxIter=20] [huber=0] [calibrated=1]
+//     replays a Session cache written by the reference (VideoSfMCache, Thrift binary; include/rsba/session_cache.hpp)
 //   g++ -std=c++17 -O2 -Iinclude examples/ba_session.cpp -Lrsba_amd/_lib -lrsba_amd -Wl,-rpath,... -o ba_session
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
 
+#include <cstring>
+
 #include "rsba/ceres_handler.hpp"
+#include "rsba/session_cache.hpp"
 
 namespace ceres = rsba_amd::ceres;
 using namespace rsba_amd;
@@ -20,7 +25,36 @@ using namespace rsba_amd;
 template <class T>
 static bool rd(FILE* f, T* p, size_t n) { return std::fread(p, sizeof(T), n, f) == n; }
 
+static int write_result(const char* path, const Session& sess, const ceres::Solver::Summary& summary, bool usable, const std::vector<std::vector<double>>& covs, double covf) {
+  FILE* g = std::fopen(path, "wb");
+  if (!g) { std::perror("out"); return 2; }
+  const double head[6] = {summary.initial_cost, summary.final_cost, (double)summary.iterations.size(), (double)summary.num_residual_blocks_reduced,
+                          (double)(int)summary.termination_type, usable ? 1.0 : 0.0};
+  std::fwrite(head, sizeof(double), 6, g);
+  for (const Frame& fr : sess.frames) for (const auto& pose : fr.poses) std::fwrite(pose.data(), sizeof(double), 6, g);
+  for (const Track& t : sess.tracks) std::fwrite(t.pt.data(), sizeof(double), 3, g);
+  if (covf >= 0 && (size_t)covf < covs.size() && covs[(size_t)covf].size() == 108) std::fwrite(covs[(size_t)covf].data(), sizeof(double), 108, g);
+  std::fclose(g);
+  return usable ? 0 : 1;
+}
+
+static int replay_cache(int argc, char** argv) {
+  Session sess;
+  try { loadCache(argv[2], sess); } catch (const std::exception& e) { std::fprintf(stderr, "%s\n", e.what()); return 2; }
+  if (sess.frames.empty()) { std::fprintf(stderr, "empty session\n"); return 2; }
+  SfmOptions opt;
+  opt.model.rolling_shutter = sess.frames[0].poses.size() == 2;
+  opt.ceres.fixFirstNCameras = argc > 4 ? (unsigned)std::atoi(argv[4]) : 1u;
+  const int maxIter = argc > 5 ? std::atoi(argv[5]) : 20;
+  opt.ceres.huberLoss = argc > 6 ? std::atof(argv[6]) : 0.0;
+  opt.model.calibrated = argc > 7 ? std::atoi(argv[7]) != 0 : true;
+  ceres::Solver::Summary summary;
+  const bool usable = BA(sess, 0, sess.frames.size() - 1, opt, maxIter, &summary, true, nullptr);
+  return write_result(argv[3], sess, summary, usable, {}, -1.0);
+}
+
 int main(int argc, char** argv) {
+  if (argc >= 4 && !std::strcmp(argv[1], "--cache")) return replay_cache(argc, argv);
   if (argc < 3) { std::fprintf(stderr, "usage: %s scene.bin out.bin\n", argv[0]); return 2; }
   FILE* f = std::fopen(argv[1], "rb");
   if (!f) { std::perror("scene"); return 2; }
@@ -58,14 +92,5 @@ int main(int argc, char** argv) {
   std::vector<std::vector<double>> covs;
   const bool usable = BA(sess, 0, F - 1, opt, hd[10], &summary, true, &covs);
 
-  FILE* g = std::fopen(argv[2], "wb");
-  if (!g) { std::perror("out"); return 2; }
-  const double head[6] = {summary.initial_cost, summary.final_cost, (double)summary.iterations.size(), (double)summary.num_residual_blocks_reduced,
-                          (double)(int)summary.termination_type, usable ? 1.0 : 0.0};
-  std::fwrite(head, sizeof(double), 6, g);
-  for (int i = 0; i < F; ++i) for (int q = 0; q < P; ++q) std::fwrite(sess.frames[i].poses[q].data(), sizeof(double), 6, g);
-  for (int j = 0; j < M; ++j) std::fwrite(sess.tracks[j].pt.data(), sizeof(double), 3, g);
-  if (covf >= 0 && (size_t)covf < covs.size() && covs[(size_t)covf].size() == 108) std::fwrite(covs[(size_t)covf].data(), sizeof(double), 108, g);
-  std::fclose(g);
-  return usable ? 0 : 1;
+  return write_result(argv[2], sess, summary, usable, covs, covf);
 }

@@ -88,6 +88,24 @@ def test_ba_with_motion_priors_matches_the_oracle(exe, oracle, tmp_path, kind, h
 
 
 @pytest.mark.gpu
+def test_replaying_a_thrift_session_cache_equals_the_scene_file_path(exe, tmp_path):
+    """A Session cache in the reference's on-disk format (Thrift binary in TFileTransport events, written here by the
+    independent encoder tests/thrift_encode.py) goes through session_cache.hpp into BA(): same solve as the flat scene file."""
+    import thrift_encode as T
+    p = small_problem(True, 2.0)
+    write_scene_file(tmp_path / "s.bin", p, fix_first_n=1, max_iter=12)
+    r = subprocess.run([exe, str(tmp_path / "s.bin"), str(tmp_path / "o.bin")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    (tmp_path / "s.cache").write_bytes(T.file_events(T.session_of_problem(p, descriptors=True), np.random.default_rng(2), max_event=4096))
+    r = subprocess.run([exe, "--cache", str(tmp_path / "s.cache"), str(tmp_path / "o2.bin"), "1", "12", "2.0", "1"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    a, b = read_result_file(tmp_path / "o.bin", p), read_result_file(tmp_path / "o2.bin", p)
+    assert a["usable"] and b["usable"] and a["iterations"] == b["iterations"] and a["reduced"] == b["reduced"]
+    assert a["initial_cost"] == b["initial_cost"] and a["final_cost"] == b["final_cost"]
+    assert np.array_equal(a["poses"], b["poses"]) and np.array_equal(a["points"], b["points"])
+
+
+@pytest.mark.gpu
 def test_free_inter_frame_ratio_is_reported(exe, tmp_path):
     """opt.ceres.interFrameRatio == 1 makes the ratio a free lower-bounded parameter in the reference: not built, said so."""
     p = small_problem(True, 0.0)
