@@ -34,3 +34,8 @@ PY
 cp $OUT/trace/t_kernel_stats.csv $OUT/kernel_stats.csv
 rm -rf $OUT/trace/t_kernel_trace.csv
 cat $OUT/bench.json
+# the rows next to the hot path: motion priors (f1), RS-PnP hypotheses (f3)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_priors -o t -- python tools/lm_time.py C4 12 priors > $OUT/lm_priors.log 2>&1
+cp $OUT/trace_priors/t_kernel_stats.csv $OUT/lm_c4_priors_kernel_stats.csv; rm -rf $OUT/trace_priors
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_pnp -o t -- python tools/pnp_time.py 16384 1000 6 > $OUT/pnp.log 2>&1
+cp $OUT/trace_pnp/t_kernel_stats.csv $OUT/f3_pnp_kernel_stats.csv; rm -rf $OUT/trace_pnp
