@@ -8,10 +8,12 @@
 //   SubsetParameterization / HuberLoss / Problem::Evaluate / Solver::Options / Solve / Summary
 //     — CeresHandler.h:78-90, 208-301, 335-382, 386-387, 394-426; VideoSfMHandler.cc:579-596, 627-630.
 //
-// Only rsba's two hot-path functors are accepted: the typed cost objects of reprojection_costs.hpp
-// (RsBundleAdjustment / ReprojectionError factories).  There is NO host-side evaluation: every
-// residual, Jacobian and solve goes through librsba_amd's HIP kernels; a cost function of any other type
-// (rsba's priors — SURVEY §8f row f1) is rejected with an error, not evaluated on the CPU.
+// Accepted cost functions: rsba's two hot-path functors — the typed cost objects of reprojection_costs.hpp
+// (RsBundleAdjustment / ReprojectionError factories) — and, between the frames those observe, the motion priors of
+// motion_priors.hpp (RsConstVeloPrior / RsConstAccelerationPrior with a constant interFrameRatio block; SURVEY §8f
+// row f1).  There is NO host-side evaluation: every residual, Jacobian and solve goes through librsba_amd's HIP
+// kernels; a cost function of any other type (SphericalPrior, GoodPosePrior, a free interFrameRatio) is rejected with
+// an error, not evaluated on the CPU.
 #pragma once
 #include <algorithm>
 #include <cmath>
