@@ -147,13 +147,15 @@ int32_t rsba_evaluate_device(rsba_handle* h, int32_t with_jacobians);
  * residuals [N][2]; jacobians [N][2][K] raw CostFunction blocks (no loss, no masks); gradient
  * [F*P*6 | M*3 | NI*9] = loss-corrected J^T r with zeros at fixed coordinates; cost = 1/2 sum rho(|r|^2).
  * Any output may be NULL.  num_failed receives the number of blocks whose functor returned false;
- * the status is then RSBA_ERR_EVALUATION_FAILED. */
+ * the status is then RSBA_ERR_EVALUATION_FAILED.  Motion prior blocks (rsba_set_motion_priors) count in cost, gradient
+ * and num_failed; residuals / jacobians cover the observation blocks only. */
 int32_t rsba_evaluate(rsba_handle* h, double* cost, double* residuals, double* jacobians, double* gradient, int64_t* num_failed);
 
 /* Loss-corrected, masked normal-equation blocks at the current parameters (no damping, no Jacobi
  * scaling) — what Ceres' SchurEliminator consumes: U [F][CD][CD], gc [F][CD] with
  * CD = 6*poses_per_frame, V [M][3][3], gp [M][3]; host arrays, any may be NULL.  These per-camera blocks
- * are also the payload of the multi-GPU exchange.  Calibrated problems only. */
+ * are also the payload of the multi-GPU exchange.  Calibrated problems only.  Motion prior blocks contribute their
+ * share of U and gc; the (f, f-1) blocks they add to the reduced camera system are not part of this output. */
 int32_t rsba_normal_equations(rsba_handle* h, double* U, double* gc, double* V, double* gp);
 
 int32_t rsba_get_device_view(rsba_handle* h, rsba_device_view* view);
