@@ -7,7 +7,7 @@
 //     double huber, double revalidate (squared px threshold of revalidateReprojections, <= 0 = off), double covFrame (>= 0:
 //     calcCovariances, the pp | pe | ee blocks of that frame are appended to the result file), double constFrameVelocity,
 //     constFrameAcceleration, interFrameRatio (motion priors, CeresHandler.h:147-185), double cam[9], poses[F*P*6], points[M*3], obs_xy[N*2], int32 obs_frame[N], obs_point[N]
-//   ba_session --cache session.cache out.bin [fixFirstN=1] [maxIter=20] [huber=0] [calibrated=1]
+//   ba_session --cache session.cache out.bin [fixFirstN=1] [maxIter=20] [huber=0] [calibrated=1] [useOnlyValidMatches=1] [sqrdThreshold=16]
 //     replays a Session cache written by the reference (VideoSfMCache, Thrift binary; include/rsba/session_cache.hpp)
 //   g++ -std=c++17 -O2 -Iinclude examples/ba_session.cpp -Lrsba_amd/_lib -lrsba_amd -Wl,-rpath,... -o ba_session
 #include <cstdio>
@@ -43,11 +43,13 @@ static int replay_cache(int argc, char** argv) {
   try { loadCache(argv[2], sess); } catch (const std::exception& e) { std::fprintf(stderr, "%s\n", e.what()); return 2; }
   if (sess.frames.empty()) { std::fprintf(stderr, "empty session\n"); return 2; }
   SfmOptions opt;
-  opt.model.rolling_shutter = sess.frames[0].poses.size() == 2;
+  opt.model.rolling_shutter = sess.frames[0].poses.size() != 1;
   opt.ceres.fixFirstNCameras = argc > 4 ? (unsigned)std::atoi(argv[4]) : 1u;
   const int maxIter = argc > 5 ? std::atoi(argv[5]) : 20;
   opt.ceres.huberLoss = argc > 6 ? std::atof(argv[6]) : 0.0;
   opt.model.calibrated = argc > 7 ? std::atoi(argv[7]) != 0 : true;
+  opt.ceres.useOnlyValidMatches = argc > 8 ? std::atoi(argv[8]) != 0 : true;
+  if (argc > 9) opt.tracks.sqrdThreshold = std::atof(argv[9]);
   ceres::Solver::Summary summary;
   const bool usable = BA(sess, 0, sess.frames.size() - 1, opt, maxIter, &summary, true, nullptr);
   return write_result(argv[3], sess, summary, usable, {}, -1.0);

@@ -2,9 +2,9 @@
 //   CeresHandler::CeresHandler / Add / solve   /root/reference/src/rsba/CeresHandler.h:76-427
 //   VideoSfMHandler::BA                        /root/reference/src/rsba/VideoSfMHandler.cc:574-631
 // Same names, argument meaning and error behaviour for the per-observation path (SURVEY Appendix D
-// steps 3-4).  Not built (they are "next" rows): pose initialisation of frames without poses
-// (Appendix D step 1), pose priors (GoodPosePrior, step 2), the structure-less ray costs, match-based track
-// lookup — reaching one of them throws std::runtime_error.  Motion priors (:147-186) are built for a known
+// steps 1, 3-4: pose initialisation of frames without poses, the observation loop incl. the match-based track lookup).
+// Not built (the rest of SURVEY §8f row f1 and out-of-scope costs): SphericalPrior, pose priors (GoodPosePrior), the
+// structure-less ray costs — reaching one of them throws std::runtime_error.  Motion priors (:147-186) are built for a known
 // opt.ceres.interFrameRatio (!= 1: constant block); the free, lower-bounded ratio is reported by Solve, not silently fixed.  opt.debug.calcCovariances (VideoSfMHandler.cc:599-621) is built.  revalidateReprojections (:239-243) runs as one
 // batched device validation per frame (video_sfm.hpp).
 #pragma once
@@ -50,7 +50,27 @@ class CeresHandler {
   void Add(const size_t frameKey, Session& sess, bool uninitialized = false) {
     Frame& f = sess.frames[frameKey];
     const int formerParamNum = problem.NumParameterBlocks();
-    if (!f.__isset.poses) throw std::runtime_error("pose initialisation (CeresHandler.h:99-144) is not built: set Frame::poses");
+    if (!f.__isset.poses) {                                            // :99-144 initialise the camera frame
+      if (frameKey > 0) {
+        Frame& f_1 = sess.frames[frameKey - 1];
+        f.poses = f_1.poses;                                            // last pose as reference
+        if (frameKey > 1) {                                             // extrapolate the linear velocity
+          Frame& f_2 = sess.frames[frameKey - 2];
+          for (size_t pi = 0; pi < f.poses.size(); ++pi)
+            for (int k = 0; k < NUM_POSE_PARAMS; ++k) f.poses[pi][k] = f_1.poses[pi][k] + (f_1.poses[pi][k] - f_2.poses[pi][k]);
+        } else {
+          bool originFrame = true;
+          for (auto& pose : f_1.poses) if (originFrame) for (double p : pose) if (p != 0) originFrame = false;
+          for (auto& pose : f.poses) { pose[3] += 1e-4; pose[4] += 1e-4; pose[5] += 1e-4; }
+          if (frameKey == 1 && originFrame)                             // :127-130
+            throw std::runtime_error("SphericalPrior (CeresHandler.h:36-50,127-130: second frame of a session that starts at the origin) is not built");
+        }
+      } else {                                                          // frameKey == 0: zeros
+        f.poses.assign(opt.model.rolling_shutter ? 2 : 1, std::vector<double>(NUM_POSE_PARAMS, 0.0));
+      }
+      uninitialized = true;
+      f.__isset.poses = true;
+    }
     if (frameKey >= opt.ceres.fixFirstNCameras) {
       if (frameKey > 0 && (opt.ceres.constFrameVelocity != 0 || opt.ceres.constFrameAcceleration != 0)) {   // :148-186
         Frame& f_1 = sess.frames[frameKey - 1];
@@ -77,8 +97,11 @@ class CeresHandler {
         throw std::runtime_error("pose priors (CeresHandler.h:188-204) are not built");
     }
     if (!opt.model.use3Dpoints) throw std::runtime_error("structure-less costs (CeresHandler.h:303-332) are not built");
-    (void)uninitialized;
     std::vector<Track*> track_of(f.obs.size(), nullptr);
+    // :220-236 "also add bad reprojections": an observation without a usable track takes the track of the first of its
+    // matches whose point validates against this frame.  The candidates of the whole frame go through ONE batched
+    // device validation; the first valid one per observation is what the reference's sequential loop finds.
+    std::vector<size_t> cand_obs; std::vector<Track*> cand_track;
     for (size_t oi = 0; oi < f.obs.size(); ++oi) {
       Observation& o = f.obs[oi];
       Track* t = nullptr;
@@ -86,8 +109,26 @@ class CeresHandler {
         t = &sess.getTrack((size_t)o.track);
         if (!t->__isset.pt || (opt.ceres.useOnlyValidMatches && !t->valid)) t = nullptr;
       }
-      if (!t || !(t->valid || !opt.ceres.useOnlyValidMatches)) continue;   // :238 (match-based lookup :220-236 not built)
-      track_of[oi] = t;
+      if (!t && (uninitialized || !opt.ceres.useOnlyValidMatches)) {
+        for (const ObservationRef& ref : o.matches) {
+          const Observation& o2 = sess.frames[(size_t)ref.frame].obs[(size_t)ref.obs];
+          if (!o2.__isset.track) continue;
+          Track* c = &sess.getTrack((size_t)o2.track);
+          if (!c->__isset.pt || (opt.ceres.useOnlyValidMatches && !c->valid)) continue;
+          cand_obs.push_back(oi); cand_track.push_back(c);
+        }
+        continue;
+      }
+      if (t && (t->valid || !opt.ceres.useOnlyValidMatches)) track_of[oi] = t;   // :238
+    }
+    if (!cand_obs.empty()) {
+      std::vector<const double*> pts; std::vector<std::array<double, 2>> xy;
+      for (size_t k = 0; k < cand_obs.size(); ++k) { pts.push_back(cand_track[k]->pt.data()); xy.push_back({f.obs[cand_obs[k]].x, f.obs[cand_obs[k]].y}); }
+      const std::vector<uint8_t> ok = validate(sess, f, opt, pts, xy);
+      for (size_t k = 0; k < cand_obs.size(); ++k) {
+        Track* c = cand_track[k];
+        if (ok[k] && !track_of[cand_obs[k]] && (c->valid || !opt.ceres.useOnlyValidMatches)) track_of[cand_obs[k]] = c;   // first found wins
+      }
     }
     if (opt.ceres.revalidateReprojections) {                           // :239-243, all observations of the frame in one launch
       std::vector<const double*> pts; std::vector<std::array<double, 2>> xy; std::vector<size_t> which;

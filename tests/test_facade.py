@@ -106,6 +106,70 @@ def test_replaying_a_thrift_session_cache_equals_the_scene_file_path(exe, tmp_pa
 
 
 @pytest.mark.gpu
+def test_match_based_track_lookup_and_pose_initialisation(exe, oracle, tmp_path):
+    """CeresHandler::Add's "also add bad reprojections" branch (CeresHandler.h:220-236) and the pose initialisation of a
+    frame that arrives without poses (:99-144), replayed from a Session cache: observations without a track take the
+    track of their first match whose point validates against the frame; the last frame's poses are extrapolated."""
+    import thrift_encode as T
+    from rsba_amd.problem import apply_gauge_masks
+    p = small_problem(True, 0.0)
+    F, thr = p.num_frames, 400.0
+    rng = np.random.default_rng(4)
+    order = np.argsort(p.obs_frame, kind="stable")
+    local = np.zeros(p.num_observations, dtype=np.int64)              # index of each observation inside its frame
+    for f in range(F):
+        idx = order[p.obs_frame[order] == f]
+        local[idx] = np.arange(len(idx))
+    by_point = {j: np.flatnonzero(p.obs_point == j) for j in range(p.num_points)}
+    detached = set(rng.choice(p.num_observations, p.num_observations // 8, replace=False).tolist())
+    # expected: poses of the last frame = linear extrapolation; detached observations resolved by the oracle's validate
+    q = p.copy()
+    q.poses[F - 1] = q.poses[F - 2] + (q.poses[F - 2] - q.poses[F - 3])
+    matches, new_point = {}, q.obs_point.copy()
+    keep = np.ones(p.num_observations, dtype=bool)
+    for i in sorted(detached):
+        f, j = int(p.obs_frame[i]), int(p.obs_point[i])
+        others = [k for k in by_point[j] if k != i and k not in detached]
+        decoy_pt = int(rng.integers(p.num_points))
+        decoys = [k for k in by_point[decoy_pt] if k not in detached][:1] if decoy_pt != j else []
+        cands = decoys + others[:1]
+        matches[i] = [(int(p.obs_frame[k]), int(local[k]), True) for k in cands]
+        found = None
+        for k in cands:
+            jj = int(p.obs_point[k])
+            if oracle.validate_obs(q.intrinsics[0], q.poses[f], q.shutter, q.scanlines, q.points[jj], q.obs_xy[i], thr, 0.0, True):
+                found = jj; break
+        if found is None:
+            keep[i] = False
+        else:
+            new_point[i] = found
+    assert keep.sum() < p.num_observations and (new_point != p.obs_point).sum() >= 0
+    obs_bytes = [[] for _ in range(F)]
+    for i in order:
+        f = int(p.obs_frame[i])
+        if i in detached:
+            obs_bytes[f].append(T.observation(p.obs_xy[i, 0], p.obs_xy[i, 1], matches=matches[i]))
+        else:
+            obs_bytes[f].append(T.observation(p.obs_xy[i, 0], p.obs_xy[i, 1], track=int(p.obs_point[i])))
+    frames = [T.frame(obs_bytes[f], poses=p.poses[f] if f < F - 1 else None) for f in range(F)]
+    tracks = [T.track([(int(p.obs_frame[k]), int(local[k]), True) for k in by_point[j] if k not in detached], pt=p.points[j], valid=True) for j in range(p.num_points)]
+    payload = T.session(p.intrinsics[0], frames, tracks, int(p.shutter), list(p.scanlines), 1280, 720)
+    (tmp_path / "s.cache").write_bytes(T.file_events(payload, np.random.default_rng(6), max_event=2048))
+    r = subprocess.run([exe, "--cache", str(tmp_path / "s.cache"), str(tmp_path / "o.bin"), "1", "15", "0", "1", "0", str(thr)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = read_result_file(tmp_path / "o.bin", p)
+    from rsba_amd.problem import BAProblem
+    e = BAProblem(poses=q.poses, points=q.points, intrinsics=q.intrinsics, obs_xy=q.obs_xy[keep], obs_frame=q.obs_frame[keep], obs_point=new_point[keep],
+                  shutter=q.shutter, scanlines=q.scanlines)
+    apply_gauge_masks(e, fix_first_n_cameras=1)
+    s_ref, _ = oracle.solve(e, oracle.default_options(max_num_iterations=15))
+    assert out["usable"] and out["reduced"] == s_ref.num_residual_blocks_reduced
+    assert abs(out["initial_cost"] - s_ref.initial_cost) <= 1e-12 * s_ref.initial_cost
+    assert abs(out["final_cost"] - s_ref.final_cost) <= 1e-6 * s_ref.final_cost
+    assert np.max(np.abs(out["poses"] - e.poses)) <= 1e-5
+
+
+@pytest.mark.gpu
 def test_free_inter_frame_ratio_is_reported(exe, tmp_path):
     """opt.ceres.interFrameRatio == 1 makes the ratio a free lower-bounded parameter in the reference: not built, said so."""
     p = small_problem(True, 0.0)
