@@ -4,7 +4,8 @@
 //   * solveRsPnP (:100-192): ceres::Solve over the two pose blocks of one rolling-shutter frame with one
 //     RsBA<float> residual block per point (:25-97: observations / points stored as float, w2i WITHOUT validation),
 //     max_num_iterations = 10, every other option at Ceres' defaults; the poses are kept if the solution is usable,
-//   * count the inliers among ALL points (:225-258 project3dPoints, :304-310).
+//   * count the inliers among ALL points (:225-258 project3dPoints, :304-310) — its own kernel, one lane per
+//     (hypothesis, point).
 // One lane per hypothesis runs the whole trust-region loop (the same rules as solver.hip's rsba_solve — Ceres 1.9
 // TrustRegionMinimizer + LevenbergMarquardtStrategy, SURVEY Appendix C.5 — on a dense 12 x 12 system): the problems are
 // independent and tiny (m x 2 residuals, 12 unknowns), so there is nothing to tile; the 78-entry normal matrix and
@@ -162,18 +163,30 @@ __global__ __launch_bounds__(kPnpBlock) void pnp_tasks_kernel(const PnpArgs A) {
   A.status[h] = usable ? 1 : 2;
   A.final_cost[h] = final_cost;
 
-  // ---- inliers among all points: tau from the TRUE observation, float-rounded projection, float distance ----
-  int cnt = 0;
-  for (int i = 0; i < A.n; ++i) {
+}
+
+// inliers of every hypothesis among all points (solveRSpnp.cpp:225-258, :304-310): tau from the TRUE observation,
+// float-rounded projection, float distance.  One lane per (hypothesis, point): H x n independent projections; the
+// count is an integer sum (order-independent), one atomic per wave.
+__global__ __launch_bounds__(256) void pnp_score_kernel(const PnpArgs A) {
+  const int h = blockIdx.x, i = blockIdx.y * 256 + threadIdx.x;   // hypotheses along x (no 65535 limit)
+  if (A.status[h] == 0) return;                       // skipped hypothesis: nothing is written
+  int in = 0;
+  if (i < A.n) {
+    const Model mdl{A.shutter, A.scan0, A.scan1, 1};
+    double x[12];
+#pragma unroll
+    for (int a = 0; a < 12; ++a) x[a] = A.poses_out[(size_t)h * 12 + a];
     const double X[3] = {(double)A.object_points[3 * i], (double)A.object_points[3 * i + 1], (double)A.object_points[3 * i + 2]};
     const float ix = A.image_points[2 * i], iy = A.image_points[2 * i + 1];
     const double src = A.shutter == kVertical ? (double)iy : (double)ix;
     ObsOut<true, 2> o;
     eval_observation<true, 2, false>(mdl, A.cam, x, X, src, 0.0, o);   // r = projection - (src, 0)
     const float dx = ix - (float)(o.r[0] + src), dy = iy - (float)o.r[1];
-    cnt += sqrt((double)dx * dx + (double)dy * dy) < (double)A.reprojection_error;
+    in = sqrt((double)dx * dx + (double)dy * dy) < (double)A.reprojection_error;
   }
-  A.num_inliers[h] = cnt;
+  const unsigned long long ballot = __ballot(in);
+  if ((threadIdx.x & 63) == 0 && ballot) atomicAdd(A.num_inliers + h, (int)__popcll(ballot));
 }
 
 // inlier flags of ONE pose pair over all points (the winning hypothesis' list, solveRSpnp.cpp:312-326)
@@ -200,6 +213,10 @@ hipError_t launch_pnp_tasks(const PnpArgs& A, hipStream_t st) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pnp_tasks_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(pnp_tasks_kernel, dim3((A.num_tasks + kPnpBlock - 1) / kPnpBlock), dim3(kPnpBlock), lds, st, A);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  // num_inliers must be zero on entry (the C ABI clears it)
+  hipLaunchKernelGGL(pnp_score_kernel, dim3(A.num_tasks, (A.n + 255) / 256), dim3(256), 0, st, A);
   return hipGetLastError();
 }
 hipError_t launch_pnp_inliers(const PnpArgs& A, const double* poses, uint8_t* mask, hipStream_t st) {
