@@ -17,6 +17,8 @@ namespace rsba {
 
 namespace {
 
+constexpr int kPriorBlock = 1024;   // the reductions are ONE workgroup (fixed order); 16 waves keep a 1k-frame video at one frame per lane
+
 __device__ __forceinline__ double wsum64(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -111,10 +113,10 @@ __global__ __launch_bounds__(64) void prior_blocks_kernel(const DeviceProblem dp
 
 // cost of the prior blocks at dp.poses, added to {cost, fixed cost}; a block whose four poses are all constant is not
 // part of the reduced program and its cost is "fixed" (Ceres: Program::RemoveFixedBlocks)
-__global__ __launch_bounds__(256) void prior_cost_kernel(const DeviceProblem dp, double* cost2, int invalid) {
-  __shared__ double s_red[2][4];
+__global__ __launch_bounds__(kPriorBlock) void prior_cost_kernel(const DeviceProblem dp, double* cost2, int invalid) {
+  __shared__ double s_red[2][kPriorBlock / 64];
   double c = 0.0, cf = 0.0;
-  for (int f = threadIdx.x; f < dp.F; f += 256) {
+  for (int f = threadIdx.x; f < dp.F; f += kPriorBlock) {
     if (!dp.prior_of[f]) continue;
     const PriorValue v = prior_value(dp, f);
     bool all_const = true;
@@ -125,19 +127,21 @@ __global__ __launch_bounds__(256) void prior_cost_kernel(const DeviceProblem dp,
   if ((threadIdx.x & 63) == 0) { s_red[0][threadIdx.x >> 6] = c; s_red[1][threadIdx.x >> 6] = cf; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    cost2[0] += (s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]);
-    cost2[1] += (s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]);
+    double a = 0.0, b = 0.0;
+    for (int w = 0; w < kPriorBlock / 64; ++w) { a += s_red[0][w]; b += s_red[1][w]; }   // fixed order
+    cost2[0] += a;
+    cost2[1] += b;
     if (invalid) *dp.fail_count += invalid;   // the functors return false for this interFrameRatio
   }
 }
 
 // model cost change of the prior blocks for the camera step in sv.rhs:  -sum m.(r~ + m/2),  m = -J~ y
-__global__ __launch_bounds__(256) void prior_model_kernel(const DeviceProblem dp, const SolverDev sv, double* out) {
-  __shared__ double s_red[4];
+__global__ __launch_bounds__(kPriorBlock) void prior_model_kernel(const DeviceProblem dp, const SolverDev sv, double* out) {
+  __shared__ double s_red[kPriorBlock / 64];
   double Ca[4], Cb[4];
   prior_coefficients(dp, Ca, Cb);
   double acc = 0.0;
-  for (int f = threadIdx.x; f < dp.F; f += 256) {
+  for (int f = threadIdx.x; f < dp.F; f += kPriorBlock) {
     if (!dp.prior_of[f]) continue;
     const PriorValue v = prior_value(dp, f);
     const double sw = sqrt(v.weight);
@@ -153,7 +157,11 @@ __global__ __launch_bounds__(256) void prior_model_kernel(const DeviceProblem dp
   acc = wsum64(acc);
   if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) *out += -((s_red[0] + s_red[1]) + (s_red[2] + s_red[3]));
+  if (threadIdx.x == 0) {
+    double a = 0.0;
+    for (int w = 0; w < kPriorBlock / 64; ++w) a += s_red[w];   // fixed order
+    *out += -a;
+  }
 }
 
 }  // namespace
@@ -163,11 +171,11 @@ hipError_t launch_prior_blocks(const DeviceProblem& dp, const SolverDev& sv, dou
   return hipGetLastError();
 }
 hipError_t launch_prior_cost(const DeviceProblem& dp, double* cost2, int invalid_blocks, hipStream_t st) {
-  hipLaunchKernelGGL(prior_cost_kernel, dim3(1), dim3(256), 0, st, dp, cost2, invalid_blocks);
+  hipLaunchKernelGGL(prior_cost_kernel, dim3(1), dim3(kPriorBlock), 0, st, dp, cost2, invalid_blocks);
   return hipGetLastError();
 }
 hipError_t launch_prior_model(const DeviceProblem& dp, const SolverDev& sv, double* model_cost_change, hipStream_t st) {
-  hipLaunchKernelGGL(prior_model_kernel, dim3(1), dim3(256), 0, st, dp, sv, model_cost_change);
+  hipLaunchKernelGGL(prior_model_kernel, dim3(1), dim3(kPriorBlock), 0, st, dp, sv, model_cost_change);
   return hipGetLastError();
 }
 
