@@ -6,7 +6,9 @@ A step = one pass of the hot path over this rank's observations: the fused resid
 Jacobian kernel (results materialised in HBM, as ceres' CostFunction::Evaluate materialises them),
 inputs resident in HBM before the timed region.  With N > 1 the scene is point-partitioned: every rank
 holds the same 1k cameras and its own 100k points / ~2M observations (weak scaling); the evaluation
-needs no collective.  LM-iteration wall-time (the metric's second half) is reported under "lm".
+needs no collective.  LM-iteration wall-time (the metric's second half) is reported under "lm"; at N = 1 the rows next
+to the path (validation filter, LM with motion priors, RS-PnP hypotheses) add bounded wall-clock figures under
+"next_rows" (about a second; --no-next-rows skips them).
 
     python bench.py --gpus 1 --steps 50 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -56,6 +58,65 @@ def cpu_baseline(prob, budget_s: float = 12.0):
             "ms_per_eval": dt * 1e3}
 
 
+def next_rows(prob, dp, device):
+    """Wall-clock figures of the rows next to the hot path, on rank 0 at N = 1 only: bounded (about a second
+    in total) and never fatal — they ride in the JSON line under "next_rows", they are not the metric."""
+    import numpy as np
+    from rsba_amd import capi
+    from rsba_amd.problem import BAProblem
+    out = {}
+
+    def timed(fn, reps=3):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            r = fn()
+        return (time.perf_counter() - t0) / reps, r
+
+    try:   # f2: validate every observation of the workload (kernel + the [N] flag copy back)
+        dt, flags = timed(lambda: dp.validate_observations(16.0, 0.0))
+        out["f2_validate"] = {"ms_per_call": dt * 1e3, "observations": int(prob.num_observations), "valid": int(flags.sum())}
+    except Exception as e:  # noqa: BLE001
+        out["f2_validate"] = {"error": repr(e)}
+    try:   # f1: LM iterations with a constant-velocity motion prior on every frame
+        q = prob.copy()
+        q.prior_kind, q.prior_scale, q.inter_frame_ratio = 1, 10.0, 0.8
+        q.prior_frames = np.arange(1, q.num_frames, dtype=np.int32)
+        with capi.DeviceProblem(q, device=device) as dq:
+            opt = capi.default_options(max_num_iterations=8, function_tolerance=0.0, parameter_tolerance=0.0, gradient_tolerance=0.0)
+            p0, x0 = q.poses.copy(), q.points.copy()
+            dq.solve(opt)
+            q.poses[:], q.points[:] = p0, x0
+            dq.upload_parameters()
+            s, _ = dq.solve(opt)
+        out["f1_lm_with_motion_priors"] = {"ms_per_lm_iteration": s.total_time_s / max(1, s.num_iterations - 1) * 1e3, "prior_blocks": int(q.num_frames - 1),
+                                           "initial_cost": s.initial_cost, "final_cost": s.final_cost}
+    except Exception as e:  # noqa: BLE001
+        out["f1_lm_with_motion_priors"] = {"error": repr(e)}
+    try:   # f3: RS-PnP RANSAC hypotheses; the scene's observations come from the device's own reproject (f2)
+        rng = np.random.default_rng(3)
+        n, H, m = 1000, 16384, 6
+        cam = prob.intrinsics[0]
+        pose0 = np.concatenate([rng.normal(0, 0.05, 3), rng.normal(0, 0.3, 3)])
+        poses = np.stack([pose0, pose0 + np.concatenate([rng.normal(0, 0.01, 3), [0.35, 0.05, -0.04]])])
+        X = np.stack([rng.uniform(-4, 4, n), rng.uniform(-2.5, 2.5, n), rng.uniform(7, 14, n)], axis=1).astype(np.float32)
+        one = BAProblem(poses=poses[None], points=X.astype(np.float64), intrinsics=cam[None], obs_xy=np.zeros((1, 2)), obs_frame=np.zeros(1), obs_point=np.zeros(1),
+                        shutter=1, scanlines=(0, 1280))
+        with capi.DeviceProblem(one, device=device) as d1:
+            xy, ok = d1.reproject(np.zeros(n, dtype=np.int32), np.arange(n, dtype=np.int32))
+        X, xy = X[ok], (xy[ok] + rng.normal(0, 0.4, (int(ok.sum()), 2))).astype(np.float32)
+        bad = rng.random(len(xy)) < 0.25
+        xy[bad] += rng.normal(0, 40.0, (int(bad.sum()), 2)).astype(np.float32)
+        subs = np.stack([rng.choice(len(X), m, replace=False) for _ in range(H)]).astype(np.int32)
+        init = poses + np.concatenate([rng.normal(0, 0.01, (2, 3)), rng.normal(0, 0.08, (2, 3))], axis=1)
+        dt, r = timed(lambda: capi.pnp_tasks(cam, 1, (0, 1280), X, xy, subs, init, 10, 3.0, device=device))
+        out["f3_pnp_hypotheses"] = {"ms_per_call": dt * 1e3, "hypotheses": H, "subset": m, "points_scored": int(len(X)), "hypotheses_per_s": H / dt,
+                                    "best_inliers": int(r["num_inliers"].max()), "true_inliers": int((~bad).sum())}
+    except Exception as e:  # noqa: BLE001
+        out["f3_pnp_hypotheses"] = {"error": repr(e)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -65,6 +126,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lm", action="store_true")
     ap.add_argument("--lm-iters", type=int, default=12)
+    ap.add_argument("--no-next-rows", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -177,6 +239,8 @@ def main():
                          "algorithmic_bytes_per_launch": abytes, "bytes_per_observation": abytes / prob.num_observations},
             "lm": lm,
         }
+        if not args.no_next_rows and world == 1 and not lm_hung and args.config == "C4":
+            out["next_rows"] = next_rows(prob, dp, local_rank)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(prob)
     if lm_hung:                      # do not touch the device or the process group again: report and leave
