@@ -340,7 +340,41 @@ def prior_solve_cases():
     return out
 
 
+def pnp_cases():
+    """RS-PnP refinement (solveRSpnp.cpp:100-192): one rolling-shutter frame, float points and observations
+    as constants, the two poses free — minimised by scipy from the same start the solvers get."""
+    out = []
+    cam = np.array([800.0, 800.0, -0.05, 0.01, 1e-3, -1e-3, 2e-3, 640.0, 360.0])
+    for name, seed, m in (("pnp_24", 31, 24), ("pnp_60", 32, 60)):
+        rng = np.random.default_rng(seed)
+        scan = (0, 1280)
+        pose0 = np.concatenate([rng.normal(0, 0.05, 3), rng.normal(0, 0.3, 3)])
+        poses = np.stack([pose0, pose0 + np.concatenate([rng.normal(0, 0.01, 3), [0.35, 0.05, -0.04]])])[None]
+        X = np.stack([rng.uniform(-4, 4, m), rng.uniform(-2.5, 2.5, m), rng.uniform(7, 14, m)], axis=1).astype(np.float32).astype(np.float64)
+        of, op = np.zeros(m, dtype=int), np.arange(m)
+        xy = np.tile(cam[7:9], (m, 1))
+        for _ in range(60):
+            xy = np_residuals(cam, poses, X, xy, of, op, HORIZONTAL, scan, True) + xy
+        xy = (xy + rng.normal(0, 0.5, xy.shape)).astype(np.float32).astype(np.float64)
+        init = poses + np.concatenate([rng.normal(0, 0.01, (1, 2, 3)), rng.normal(0, 0.08, (1, 2, 3))], axis=2)
+
+        def fun(x):
+            return np_residuals(cam, x.reshape(1, 2, 6), X, xy, of, op, HORIZONTAL, scan, True).reshape(-1)
+
+        sol = least_squares(fun, init.reshape(-1), method="trf", x_scale="jac", ftol=1e-15, xtol=1e-15, gtol=1e-15, max_nfev=400)
+        sol = least_squares(fun, sol.x, method="trf", x_scale="jac", ftol=1e-15, xtol=1e-15, gtol=1e-15, max_nfev=400)
+        out.append(dict(name=name, cam=cam.tolist(), scanlines=list(scan), shutter=HORIZONTAL, object_points=X.tolist(), image_points=xy.tolist(),
+                        init_poses=init[0].tolist(), expected=dict(initial_cost=float(0.5 * np.sum(fun(init.reshape(-1)) ** 2)), final_cost=float(sol.cost),
+                                                                   poses=sol.x.reshape(2, 6).tolist(), grad_inf=float(np.max(np.abs(sol.grad))))))
+        print(name, "cost", out[-1]["expected"]["initial_cost"], "->", sol.cost, "|g|inf", np.max(np.abs(sol.grad)), file=sys.stderr)
+    return out
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "pnp":       # only the RS-PnP cases
+        with open(os.path.join(HERE, "pnp_solves.json"), "w") as f:
+            json.dump(pnp_cases(), f)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "priors":   # only the motion-prior cases (added after the others were committed)
         with open(os.path.join(HERE, "prior_solves.json"), "w") as f:
             json.dump(prior_solve_cases(), f)

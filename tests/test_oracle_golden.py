@@ -128,6 +128,23 @@ def test_motion_prior_solve_reaches_independent_minimum(oracle, idx):
     assert s0.final_cost < (1 - 1e-4) * s.final_cost
 
 
+@pytest.mark.parametrize("idx", [0, 1])
+def test_pnp_refinement_reaches_independent_minimum(oracle, idx):
+    """RS-PnP: the oracle's hypothesis task (RsBA<float> blocks over the two poses through the LM
+    restatement) against scipy's minimum of an independent numpy model (tests/golden/make_golden.py pnp)."""
+    c = load_golden("pnp_solves.json")[idx]
+    X, xy = np.array(c["object_points"], dtype=np.float32), np.array(c["image_points"], dtype=np.float32)
+    sub = np.arange(len(X), dtype=np.int32)
+    r0 = oracle.pnp_task(c["cam"], c["shutter"], c["scanlines"], X, xy, sub, c["init_poses"], 0, 3.0)
+    assert np.array_equal(r0["poses"], np.array(c["init_poses"]))            # zero iterations: nothing moves
+    r = oracle.pnp_task(c["cam"], c["shutter"], c["scanlines"], X, xy, sub, c["init_poses"], 100, 3.0)
+    assert r["usable"]
+    # the task runs at Ceres' default tolerances, as the reference does (function_tolerance 1e-6): it stops within that of the minimum
+    assert 0 <= r["final_cost"] - c["expected"]["final_cost"] <= 2e-6 * c["expected"]["final_cost"]
+    assert np.max(np.abs(r["poses"] - np.array(c["expected"]["poses"]))) <= 1e-3
+    assert r["num_inliers"] >= 0.95 * len(X)                                  # 0.5 px noise, 3 px threshold
+
+
 def test_gradient_matches_finite_differences(oracle):
     c = load_golden("tiny_solves.json")[2]   # Huber case
     prob = problem_from_solve_case(c)
