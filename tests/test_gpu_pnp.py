@@ -116,6 +116,20 @@ def test_refinement_reaches_the_independent_minimum(capi, idx):
     assert out["num_inliers"][0] >= 0.95 * len(X)
 
 
+def test_large_batch_counts_agree_with_the_per_pose_inlier_kernel(capi, oracle):
+    """16k hypotheses in one call: the counts of the (hypothesis, point) scoring kernel equal the per-pose inlier lists"""
+    sc = pnp_scene(oracle, HORIZONTAL, n=400, outliers=0.2, seed=12)
+    rng = np.random.default_rng(2)
+    H = 16384
+    subs = random_subsets(rng, len(sc["X"]), H, 6)
+    out = capi.pnp_tasks(CAM, HORIZONTAL, sc["scan"], sc["X"], sc["xy"], subs, sc["init"], reprojection_error=3.0)
+    assert out["status"].min() >= 1 and out["num_inliers"].max() >= 0.8 * (~sc["outlier"]).sum()
+    again = capi.pnp_tasks(CAM, HORIZONTAL, sc["scan"], sc["X"], sc["xy"], subs, sc["init"], reprojection_error=3.0)
+    assert np.array_equal(out["poses"], again["poses"]) and np.array_equal(out["num_inliers"], again["num_inliers"])   # deterministic
+    for h in rng.choice(H, 24, replace=False):
+        assert capi.pnp_inliers(CAM, HORIZONTAL, sc["scan"], sc["X"], sc["xy"], out["poses"][h], 3.0).sum() == out["num_inliers"][h]
+
+
 def test_bad_arguments(capi):
     X = np.zeros((8, 3), dtype=np.float32); xy = np.zeros((8, 2), dtype=np.float32)
     with pytest.raises(capi.RsbaError):

@@ -101,3 +101,31 @@ def test_covariance_sees_the_priors(capi, oracle):
     q = small_scene()
     cov0, ok = oracle.pose_covariance(q, 5)
     assert np.trace(cov_ref) < np.trace(cov0)          # the priors add information
+
+
+def test_full_size_cost_is_additive_with_an_independent_numpy_model(capi):
+    """BASELINE config C4 (1k frames, 2M observations): Problem::Evaluate with a motion prior on every frame equals the
+    plain cost plus the priors' cost from an independent numpy model of their physical meaning (tests/golden/make_golden.py)."""
+    import importlib.util, os
+    from rsba_amd.scene import make_config
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec); spec.loader.exec_module(mg)
+    p = make_config("C4").problem
+    with capi.DeviceProblem(p) as dp:
+        plain = dp.evaluate(residuals=False, jacobians=False)["cost"]
+    for kind, scale, ratio, huber in ((1, 6.0, 0.8, 0.0), (2, 25.0, 1.25, 0.05)):
+        q = with_priors(p.copy(), kind, scale, ratio)
+        q.huber_a = huber
+        pr = mg.np_prior_residuals(q.poses, kind, scale, ratio, list(range(1, q.num_frames)))
+        s = np.sum(pr * pr, axis=1)
+        rho = np.where(s <= huber * huber, s, 2 * huber * np.sqrt(s) - huber * huber) if huber > 0 else s
+        with capi.DeviceProblem(q) as dq:
+            got = dq.evaluate(residuals=False, jacobians=False)["cost"]
+        if huber > 0:   # the observation blocks share the loss: their part under the same loss, from the device itself
+            q0 = q.copy(); q0.prior_kind = 0; q0.prior_frames = None
+            with capi.DeviceProblem(q0) as d0:
+                base = d0.evaluate(residuals=False, jacobians=False)["cost"]
+            assert np.count_nonzero(s > huber * huber) > 0
+        else:
+            base = plain
+        assert abs(got - (base + 0.5 * float(np.sum(rho)))) <= 1e-12 * got
