@@ -272,6 +272,14 @@ int32_t rsba_set_motion_priors(rsba_handle* h, int32_t kind, double scale, doubl
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), flags.size() * sizeof(int32_t)));
   h->allocs.push_back(d);
   HIP_TRY(hipMemcpy(d, flags.data(), flags.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  double* part = nullptr; unsigned* ticket = nullptr;
+  const size_t nwaves = ((size_t)dp.F + 63) / 64;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&part), 2 * nwaves * sizeof(double)));
+  h->allocs.push_back(part);
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ticket), sizeof(unsigned)));
+  h->allocs.push_back(ticket);
+  HIP_TRY(hipMemset(ticket, 0, sizeof(unsigned)));
+  dp.prior_partial = part; dp.prior_ticket = ticket;
   dp.prior_of = d; dp.prior_kind = kind; dp.prior_scale = scale; dp.prior_ratio = inter_frame_ratio;
   h->prior_frames.assign(frames, frames + count);
   // RsConstVeloPrior returns ratio >= 0, RsConstAccelerationPrior ratio >= _EPS (video_bundler_rs_inter.h:92,:157)

@@ -9,15 +9,13 @@
 // the block-tridiagonal fill SURVEY names.  The shared loss function acts on the 12-vector as a whole (:155,:166).
 //
 // O(F) work per LM iteration: one thread per frame gathers the prior it heads and the one that refers back to it
-// (no atomics, fixed order), single-workgroup reductions for the cost and the model cost change.
+// (no atomics, fixed order); the cost and the model cost change are sums of per-wave partials taken in wave order.
 #include "obs_math.hpp"
 #include "solver_state.hpp"
 
 namespace rsba {
 
 namespace {
-
-constexpr int kPriorBlock = 1024;   // the reductions are ONE workgroup (fixed order); 16 waves keep a 1k-frame video at one frame per lane
 
 __device__ __forceinline__ double wsum64(double v) {
 #pragma unroll
@@ -111,38 +109,48 @@ __global__ __launch_bounds__(64) void prior_blocks_kernel(const DeviceProblem dp
   }
 }
 
+// The two reductions below run one wave per 64 frames across the chip.  Every wave leaves its partial in
+// dp.prior_partial and draws a ticket; the wave that draws the last one adds the partials IN WAVE ORDER (so the sum does
+// not depend on which wave that is: deterministic, no floating-point atomics) and re-arms the ticket for the next launch.
+// Partials cross workgroups through agent-scope fences around the ticket.
+__device__ __forceinline__ bool last_wave_of_grid(const DeviceProblem& dp) {
+  __threadfence();                                                  // partials visible before the ticket
+  const unsigned t = atomicAdd(dp.prior_ticket, 1u);
+  if (t != gridDim.x - 1) return false;
+  __threadfence();                                                  // and read only after it
+  *dp.prior_ticket = 0u;
+  return true;
+}
+
 // cost of the prior blocks at dp.poses, added to {cost, fixed cost}; a block whose four poses are all constant is not
 // part of the reduced program and its cost is "fixed" (Ceres: Program::RemoveFixedBlocks)
-__global__ __launch_bounds__(kPriorBlock) void prior_cost_kernel(const DeviceProblem dp, double* cost2, int invalid) {
-  __shared__ double s_red[2][kPriorBlock / 64];
+__global__ __launch_bounds__(64) void prior_cost_kernel(const DeviceProblem dp, double* cost2, int invalid) {
+  const int f = blockIdx.x * 64 + threadIdx.x;
   double c = 0.0, cf = 0.0;
-  for (int f = threadIdx.x; f < dp.F; f += kPriorBlock) {
-    if (!dp.prior_of[f]) continue;
+  if (f < dp.F && dp.prior_of[f]) {
     const PriorValue v = prior_value(dp, f);
     bool all_const = true;
     for (int k = 0; k < 24; ++k) all_const = all_const && dp.scale_pose[(size_t)(f - 1) * 12 + k] == 0.0;
-    if (all_const) cf += v.cost; else c += v.cost;
+    if (all_const) cf = v.cost; else c = v.cost;
   }
   c = wsum64(c); cf = wsum64(cf);
-  if ((threadIdx.x & 63) == 0) { s_red[0][threadIdx.x >> 6] = c; s_red[1][threadIdx.x >> 6] = cf; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double a = 0.0, b = 0.0;
-    for (int w = 0; w < kPriorBlock / 64; ++w) { a += s_red[0][w]; b += s_red[1][w]; }   // fixed order
-    cost2[0] += a;
-    cost2[1] += b;
-    if (invalid) *dp.fail_count += invalid;   // the functors return false for this interFrameRatio
-  }
+  if (threadIdx.x != 0) return;
+  dp.prior_partial[2 * blockIdx.x] = c; dp.prior_partial[2 * blockIdx.x + 1] = cf;
+  if (!last_wave_of_grid(dp)) return;
+  double a = 0.0, b = 0.0;
+  for (unsigned w = 0; w < gridDim.x; ++w) { a += dp.prior_partial[2 * w]; b += dp.prior_partial[2 * w + 1]; }   // fixed order
+  cost2[0] += a;
+  cost2[1] += b;
+  if (invalid) *dp.fail_count += invalid;   // the functors return false for this interFrameRatio
 }
 
 // model cost change of the prior blocks for the camera step in sv.rhs:  -sum m.(r~ + m/2),  m = -J~ y
-__global__ __launch_bounds__(kPriorBlock) void prior_model_kernel(const DeviceProblem dp, const SolverDev sv, double* out) {
-  __shared__ double s_red[kPriorBlock / 64];
-  double Ca[4], Cb[4];
-  prior_coefficients(dp, Ca, Cb);
+__global__ __launch_bounds__(64) void prior_model_kernel(const DeviceProblem dp, const SolverDev sv, double* out) {
+  const int f = blockIdx.x * 64 + threadIdx.x;
   double acc = 0.0;
-  for (int f = threadIdx.x; f < dp.F; f += kPriorBlock) {
-    if (!dp.prior_of[f]) continue;
+  if (f < dp.F && dp.prior_of[f]) {
+    double Ca[4], Cb[4];
+    prior_coefficients(dp, Ca, Cb);
     const PriorValue v = prior_value(dp, f);
     const double sw = sqrt(v.weight);
     const double* y = sv.rhs + (size_t)(f - 1) * 12; const double* sc = dp.scale_pose + (size_t)(f - 1) * 12;   // [prev | cur]
@@ -155,13 +163,12 @@ __global__ __launch_bounds__(kPriorBlock) void prior_model_kernel(const DevicePr
     }
   }
   acc = wsum64(acc);
-  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double a = 0.0;
-    for (int w = 0; w < kPriorBlock / 64; ++w) a += s_red[w];   // fixed order
-    *out += -a;
-  }
+  if (threadIdx.x != 0) return;
+  dp.prior_partial[blockIdx.x] = acc;
+  if (!last_wave_of_grid(dp)) return;
+  double a = 0.0;
+  for (unsigned w = 0; w < gridDim.x; ++w) a += dp.prior_partial[w];   // fixed order
+  *out += -a;
 }
 
 }  // namespace
@@ -171,11 +178,11 @@ hipError_t launch_prior_blocks(const DeviceProblem& dp, const SolverDev& sv, dou
   return hipGetLastError();
 }
 hipError_t launch_prior_cost(const DeviceProblem& dp, double* cost2, int invalid_blocks, hipStream_t st) {
-  hipLaunchKernelGGL(prior_cost_kernel, dim3(1), dim3(kPriorBlock), 0, st, dp, cost2, invalid_blocks);
+  hipLaunchKernelGGL(prior_cost_kernel, dim3((dp.F + 63) / 64), dim3(64), 0, st, dp, cost2, invalid_blocks);
   return hipGetLastError();
 }
 hipError_t launch_prior_model(const DeviceProblem& dp, const SolverDev& sv, double* model_cost_change, hipStream_t st) {
-  hipLaunchKernelGGL(prior_model_kernel, dim3(1), dim3(kPriorBlock), 0, st, dp, sv, model_cost_change);
+  hipLaunchKernelGGL(prior_model_kernel, dim3((dp.F + 63) / 64), dim3(64), 0, st, dp, sv, model_cost_change);
   return hipGetLastError();
 }
 
