@@ -36,7 +36,7 @@ class OrcProblem(C.Structure):
         ("intrinsics_constant", C.c_void_p), ("huber_a", C.c_double),
         ("prior_kind", C.c_int32), ("num_priors", C.c_int32), ("prior_frames", C.c_void_p),
         ("prior_scale", C.c_double), ("inter_frame_ratio", C.c_double),
-        ("no_validate", C.c_int32), ("pad_", C.c_int32),
+        ("no_validate", C.c_int32), ("ratio_free", C.c_int32),
     ]
 
 
@@ -112,6 +112,7 @@ def desc(prob) -> OrcProblem:
     d.num_priors = 0 if d.prior_kind == 0 else len(prob.prior_frames)
     d.prior_frames = _ptr(prob.prior_frames) if d.prior_kind else None
     d.prior_scale, d.inter_frame_ratio = float(prob.prior_scale), float(prob.inter_frame_ratio)
+    d.ratio_free = int(bool(getattr(prob, 'ratio_free', False)))
     d._keep = prob  # keep arrays alive
     return d
 
@@ -194,6 +195,8 @@ def solve(prob, options: OrcOptions | None = None, trace_cap: int = 256):
     s = OrcSummary()
     tr = (OrcIteration * trace_cap)()
     lib().orc_solve(C.byref(d), C.byref(o), C.byref(s), tr, C.c_int32(trace_cap))
+    if d.ratio_free:
+        prob.inter_frame_ratio = float(d.inter_frame_ratio)      # a free ratio block is a parameter: solved for in place
     n = min(s.num_iterations, trace_cap)
     return s, [tr[i] for i in range(n)]
 

@@ -103,17 +103,20 @@ bool motion_prior(int kind, const T& ratio, double scale, const T* cur0, const T
   return kind == 1 ? !(ratio < 0.0) : !(ratio < kEps);
 }
 
-// AutoDiffCostFunction<Rs...Prior,12,1,6,6,6,6>::Evaluate with the ratio block constant (null Jacobian):
-// r[12], J[12][24] over the columns [f.poses[0] | f.poses[1] | f-1.poses[0] | f-1.poses[1]]
+// AutoDiffCostFunction<Rs...Prior,12,1,6,6,6,6>::Evaluate: r[12], J[12][25] over the columns
+// [f.poses[0] | f.poses[1] | f-1.poses[0] | f-1.poses[1] | interFrameRatio]; the last column is seeded only when the
+// ratio block is a free parameter (ratio_free), and stays zero (null Jacobian of a constant block) otherwise
+constexpr int kPC = 25;
 bool prior_eval(const orc_problem* p, int k, double* r, double* J) {
   const int f = p->prior_frames[k];
   const double* cur = p->poses + (size_t)f * 12; const double* prev = p->poses + (size_t)(f - 1) * 12;
   if (!J) return motion_prior<double>(p->prior_kind, p->inter_frame_ratio, p->prior_scale, cur, cur + 6, prev, prev + 6, r);
-  typedef Dual<24> D;
+  typedef Dual<kPC> D;
   D x[24], res[12];
   for (int c = 0; c < 12; ++c) { x[c] = D(cur[c], c); x[12 + c] = D(prev[c], 12 + c); }
-  if (!motion_prior<D>(p->prior_kind, D(p->inter_frame_ratio), p->prior_scale, x, x + 6, x + 12, x + 18, res)) return false;
-  for (int i = 0; i < 12; ++i) { r[i] = res[i].a; for (int c = 0; c < 24; ++c) J[i * 24 + c] = res[i].v[c]; }
+  const D ratio = p->ratio_free ? D(p->inter_frame_ratio, 24) : D(p->inter_frame_ratio);
+  if (!motion_prior<D>(p->prior_kind, ratio, p->prior_scale, x, x + 6, x + 12, x + 18, res)) return false;
+  for (int i = 0; i < 12; ++i) { r[i] = res[i].a; for (int c = 0; c < kPC; ++c) J[i * kPC + c] = res[i].v[c]; }
   return true;
 }
 
@@ -179,12 +182,14 @@ struct Eval {
   std::vector<uint8_t> colmask;       // per parameter column (global numbering) 1 = fixed
   int64_t ncam, nparam;               // camera-side unknowns (poses + intrinsics), all unknowns
   // motion-prior blocks: corrected residuals [NP][12], Jacobian [NP][12][24], dropped flags
-  int NP = 0; std::vector<double> pr, pJ; std::vector<uint8_t> pdropped;
+  int NP = 0, PC = 24; int64_t iratio = -1; std::vector<double> pr, pJ; std::vector<uint8_t> pdropped;   // PC 25 / iratio >= 0: free interFrameRatio
   // global column of local column c of prior k
-  inline int64_t pcol(int k, int c) const { const int f = p->prior_frames[k]; return c < 12 ? (int64_t)f * 12 + c : (int64_t)(f - 1) * 12 + (c - 12); }
+  inline int64_t pcol(int k, int c) const { const int f = p->prior_frames[k]; return c == 24 ? iratio : c < 12 ? (int64_t)f * 12 + c : (int64_t)(f - 1) * 12 + (c - 12); }
   Eval(const orc_problem* pp) : p(pp), L(layout_of(pp)) {
     N = p->num_observations; F = p->num_frames; M = p->num_points; NI = p->num_intrinsics;
     ncam = (int64_t)F * L.CD + (L.cal ? 0 : (int64_t)NI * 9);
+    NP = (p->prior_kind != 0 && L.P == 2) ? p->num_priors : 0;
+    if (NP > 0 && p->ratio_free) { iratio = ncam; ncam += 1; PC = 25; }   // the ratio is one more camera-side unknown
     nparam = ncam + (int64_t)M * 3;
     colmask.assign(nparam, 0);
     for (int f = 0; f < F; ++f) for (int q = 0; q < L.P; ++q) {
@@ -202,9 +207,8 @@ struct Eval {
       // a block is constant only if all 6 coordinates are fixed; a partially fixed pose keeps the residual
       dropped[i] = all_const;
     }
-    NP = (p->prior_kind != 0 && L.P == 2) ? p->num_priors : 0;
     pdropped.assign(NP, 0);
-    for (int k = 0; k < NP; ++k) { bool all_const = true; for (int c = 0; c < 24 && all_const; ++c) if (!colmask[pcol(k, c)]) all_const = false; pdropped[k] = all_const; }
+    for (int k = 0; k < NP; ++k) { bool all_const = true; for (int c = 0; c < PC && all_const; ++c) if (!colmask[pcol(k, c)]) all_const = false; pdropped[k] = all_const; }
   }
   // global column of local column k of observation i
   inline int64_t gcol(int64_t i, int k) const {
@@ -250,9 +254,9 @@ struct Eval {
       }
       if (Ji) for (int k = 0; k < K; ++k) if (colmask[gcol(i, k)]) { Ji[k] = 0.0; Ji[K + k] = 0.0; }
     }
-    pr.resize((size_t)12 * NP); if (want_jac) pJ.resize((size_t)12 * 24 * NP);
+    pr.resize((size_t)12 * NP); if (want_jac) pJ.resize((size_t)12 * kPC * NP);
     for (int k = 0; k < NP; ++k) {
-      double* rk = &pr[(size_t)12 * k]; double* Jk = want_jac ? &pJ[(size_t)288 * k] : nullptr;
+      double* rk = &pr[(size_t)12 * k]; double* Jk = want_jac ? &pJ[(size_t)12 * kPC * k] : nullptr;
       if (!prior_eval(p, k, rk, Jk)) { ++bad; continue; }
       double s = 0.0; for (int i = 0; i < 12; ++i) s += rk[i] * rk[i];
       double rho[3] = {s, 1.0, 0.0};
@@ -262,13 +266,13 @@ struct Eval {
         const double sr1 = std::sqrt(rho[1]);
         double rscale = sr1, alpha_sq = 0.0;
         if (!(s == 0.0 || rho[2] <= 0.0)) { const double alpha = 1.0 - std::sqrt(1.0 + 2.0 * s * rho[2] / rho[1]); rscale = sr1 / (1.0 - alpha); alpha_sq = alpha / s; }
-        if (Jk) for (int cc = 0; cc < 24; ++cc) {
-          double rtj = 0.0; for (int i = 0; i < 12; ++i) rtj += Jk[i * 24 + cc] * rk[i];
-          for (int i = 0; i < 12; ++i) Jk[i * 24 + cc] = sr1 * (Jk[i * 24 + cc] - alpha_sq * rk[i] * rtj);
+        if (Jk) for (int cc = 0; cc < PC; ++cc) {
+          double rtj = 0.0; for (int i = 0; i < 12; ++i) rtj += Jk[i * kPC + cc] * rk[i];
+          for (int i = 0; i < 12; ++i) Jk[i * kPC + cc] = sr1 * (Jk[i * kPC + cc] - alpha_sq * rk[i] * rtj);
         }
         for (int i = 0; i < 12; ++i) rk[i] *= rscale;
       }
-      if (Jk) for (int cc = 0; cc < 24; ++cc) if (colmask[pcol(k, cc)]) for (int i = 0; i < 12; ++i) Jk[i * 24 + cc] = 0.0;
+      if (Jk) for (int cc = 0; cc < PC; ++cc) if (colmask[pcol(k, cc)]) for (int i = 0; i < 12; ++i) Jk[i * kPC + cc] = 0.0;
     }
     if (cost) *cost = c;
     if (fixed) *fixed = cf;
@@ -277,11 +281,11 @@ struct Eval {
   // J^T r and J^T J contributions of the prior blocks, entry by entry
   template <class FG, class FH> void prior_normal(FG&& g, FH&& h) const {
     for (int k = 0; k < NP; ++k) {
-      const double* Jk = &pJ[(size_t)288 * k]; const double* rk = &pr[(size_t)12 * k];
-      for (int a = 0; a < 24; ++a) {
-        double ga = 0.0; for (int i = 0; i < 12; ++i) ga += Jk[i * 24 + a] * rk[i];
+      const double* Jk = &pJ[(size_t)12 * kPC * k]; const double* rk = &pr[(size_t)12 * k];
+      for (int a = 0; a < PC; ++a) {
+        double ga = 0.0; for (int i = 0; i < 12; ++i) ga += Jk[i * kPC + a] * rk[i];
         g(pcol(k, a), ga);
-        for (int b = 0; b < 24; ++b) { double hab = 0.0; for (int i = 0; i < 12; ++i) hab += Jk[i * 24 + a] * Jk[i * 24 + b]; if (hab != 0.0) h(pcol(k, a), pcol(k, b), hab); }
+        for (int b = 0; b < PC; ++b) { double hab = 0.0; for (int i = 0; i < 12; ++i) hab += Jk[i * kPC + a] * Jk[i * kPC + b]; if (hab != 0.0) h(pcol(k, a), pcol(k, b), hab); }
       }
     }
   }
@@ -558,7 +562,8 @@ int32_t orc_solve(orc_problem* p, const orc_options* opt, orc_summary* sum, orc_
     // pose blocks / intrinsics that no residual touches are not part of the problem
     std::vector<uint8_t> touched(np, 0);
     for (int64_t i = 0; i < N; ++i) for (int k = 0; k < K; ++k) touched[E.gcol(i, k)] = 1;
-    for (int k = 0; k < E.NP; ++k) for (int c = 0; c < 24; ++c) touched[E.pcol(k, c)] = 1;
+    if (E.iratio >= 0) for (int k = 0; k < 1; ++k) in_program[E.iratio] = 1;
+    for (int k = 0; k < E.NP; ++k) for (int c = 0; c < E.PC; ++c) touched[E.pcol(k, c)] = 1;
     for (int64_t a = 0; a < np; ++a) if (!touched[a]) in_program[a] = 0;
   }
   int64_t nfree = 0; for (int64_t a = 0; a < np; ++a) nfree += (in_program[a] && !E.colmask[a]);
@@ -567,9 +572,14 @@ int32_t orc_solve(orc_problem* p, const orc_options* opt, orc_summary* sum, orc_
   auto param_ptr = [&](int64_t a) -> double* {
     const int64_t npose = (int64_t)E.F * L.CD;
     if (a < npose) return p->poses + a;
+    if (a == E.iratio) return &p->inter_frame_ratio;
     if (a < E.ncam) return p->intrinsics + (a - npose);
     return p->points + (a - E.ncam);
   };
+  // SetParameterLowerBound(&interFrameRatio, 0, 0.0 | _EPS) (CeresHandler.h:161,172): the candidate is projected onto
+  // the bound (ParameterBlock::Plus), the gradient norm is that of the projected gradient.  Ceres' additional
+  // projected line search for bounded problems (>= 1.10) is NOT restated.
+  const double ratio_lb = p->prior_kind == 2 ? kEps : 0.0;
   auto x_norm_of = [&]() { double s = 0; for (int64_t a = 0; a < np; ++a) if (in_program[a]) { const double v = *param_ptr(a); s += v * v; } return std::sqrt(s); };
   auto gradient_of = [&](std::vector<double>& g) {
     g.assign(np, 0.0);
@@ -580,12 +590,12 @@ int32_t orc_solve(orc_problem* p, const orc_options* opt, orc_summary* sum, orc_
   auto scale_cols = [&](const std::vector<double>& sc) {
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < N; ++i) for (int k = 0; k < K; ++k) { const double s = sc[E.gcol(i, k)]; E.J[(size_t)2 * K * i + k] *= s; E.J[(size_t)2 * K * i + K + k] *= s; }
-    for (int k = 0; k < E.NP; ++k) for (int c = 0; c < 24; ++c) { const double s = sc[E.pcol(k, c)]; for (int i = 0; i < 12; ++i) E.pJ[(size_t)288 * k + i * 24 + c] *= s; }
+    for (int k = 0; k < E.NP; ++k) for (int c = 0; c < E.PC; ++c) { const double s = sc[E.pcol(k, c)]; for (int i = 0; i < 12; ++i) E.pJ[(size_t)12 * kPC * k + i * kPC + c] *= s; }
   };
   auto col_sq_norms = [&](std::vector<double>& d) {
     d.assign(np, 0.0);
     for (int64_t i = 0; i < N; ++i) for (int k = 0; k < K; ++k) { const double a = E.J[(size_t)2 * K * i + k], b = E.J[(size_t)2 * K * i + K + k]; d[E.gcol(i, k)] += a * a + b * b; }
-    for (int k = 0; k < E.NP; ++k) for (int c = 0; c < 24; ++c) for (int i = 0; i < 12; ++i) { const double a = E.pJ[(size_t)288 * k + i * 24 + c]; d[E.pcol(k, c)] += a * a; }
+    for (int k = 0; k < E.NP; ++k) for (int c = 0; c < E.PC; ++c) for (int i = 0; i < 12; ++i) { const double a = E.pJ[(size_t)12 * kPC * k + i * kPC + c]; d[E.pcol(k, c)] += a * a; }
   };
   int ntrace = 0;
   auto push = [&](const orc_iteration& it) { if (trace && ntrace < trace_cap) trace[ntrace] = it; ++ntrace; sum->num_iterations = ntrace; };
@@ -594,7 +604,16 @@ int32_t orc_solve(orc_problem* p, const orc_options* opt, orc_summary* sum, orc_
   if (!E.run(true, &cost, &fixed)) { sum->termination_type = ORC_FAILURE; return ORC_FAILURE; }
   sum->fixed_cost = fixed; sum->initial_cost = cost + fixed; sum->final_cost = cost + fixed;
   std::vector<double> g; gradient_of(g);
-  double gmax = 0; for (double v : g) gmax = std::max(gmax, std::fabs(v));
+  auto gmax_of = [&](const std::vector<double>& gv) {
+    double m = 0;
+    for (int64_t a = 0; a < np; ++a) {
+      double v = gv[a];
+      if (a == E.iratio) { const double x = p->inter_frame_ratio; v = x - std::max(ratio_lb, x - v); }   // projected gradient
+      m = std::max(m, std::fabs(v));
+    }
+    return m;
+  };
+  double gmax = gmax_of(g);
   double radius = opt->initial_trust_region_radius, decrease_factor = 2.0; bool reuse_diagonal = false;
   orc_iteration it; std::memset(&it, 0, sizeof it);
   it.cost = cost + fixed; it.gradient_max_norm = gmax; it.trust_region_radius = radius;
@@ -626,7 +645,7 @@ int32_t orc_solve(orc_problem* p, const orc_options* opt, orc_summary* sum, orc_
       }
       for (int k = 0; k < E.NP; ++k) for (int i = 0; i < 12; ++i) {
         double m = 0.0;
-        for (int c = 0; c < 24; ++c) m += E.pJ[(size_t)288 * k + i * 24 + c] * -y[E.pcol(k, c)];
+        for (int c = 0; c < E.PC; ++c) m += E.pJ[(size_t)12 * kPC * k + i * kPC + c] * -y[E.pcol(k, c)];
         acc += m * (E.pr[(size_t)12 * k + i] + 0.5 * m);
       }
       model_cost_change = -acc;
@@ -642,7 +661,7 @@ int32_t orc_solve(orc_problem* p, const orc_options* opt, orc_summary* sum, orc_
       invalid_streak = 0; it.step_is_valid = 1;
       // x_plus_delta = x + scale .* step (masked coordinates have step 0)
       double step_sq = 0.0;
-      for (int64_t a = 0; a < np; ++a) { x_save[a] = *param_ptr(a); const double d = -y[a] * scale[a]; if (in_program[a] && !E.colmask[a]) { *param_ptr(a) = x_save[a] + d; const double e = x_save[a] - *param_ptr(a); step_sq += e * e; } }
+      for (int64_t a = 0; a < np; ++a) { x_save[a] = *param_ptr(a); const double d = -y[a] * scale[a]; if (in_program[a] && !E.colmask[a]) { *param_ptr(a) = x_save[a] + d; if (a == E.iratio && *param_ptr(a) < ratio_lb) *param_ptr(a) = ratio_lb; const double e = x_save[a] - *param_ptr(a); step_sq += e * e; } }
       // keep the current linearisation; evaluate residuals only at the candidate
       r_cur.swap(E.r); J_cur.swap(E.J); pr_cur.swap(E.pr);
       double new_cost = 0, new_fixed = 0;
@@ -663,7 +682,7 @@ int32_t orc_solve(orc_problem* p, const orc_options* opt, orc_summary* sum, orc_
         radius = std::min(opt->max_trust_region_radius, radius); decrease_factor = 2.0; reuse_diagonal = false;
         x_norm = x_norm_of();
         if (!E.run(true, &cost, &fixed)) { sum->termination_type = ORC_FAILURE; push(it); break; }
-        gradient_of(g); gmax = 0; for (double v : g) gmax = std::max(gmax, std::fabs(v));
+        gradient_of(g); gmax = gmax_of(g);
         it.gradient_max_norm = gmax;
         sum->final_cost = std::min(sum->final_cost, cost + fixed);
         if (gmax <= opt->gradient_tolerance) { sum->termination_type = ORC_CONVERGENCE; it.cost = cost + fixed; it.trust_region_radius = radius; push(it); break; }

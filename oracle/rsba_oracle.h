@@ -41,7 +41,8 @@ typedef struct orc_problem {
   double prior_scale;            /* opt.ceres.constFrameVelocity / constFrameAcceleration */
   double inter_frame_ratio;      /* opt.ceres.interFrameRatio */
   int32_t no_validate;           /* 1 = the RS-PnP functor RsBA: w2i(..., validate = false) (solveRSpnp.cpp:67) */
-  int32_t pad_;
+  int32_t ratio_free;            /* 1 = interFrameRatio is a free, lower-bounded parameter block (the reference's default, option left at 1:
+                                  * CeresHandler.h:161,172,175); orc_solve updates inter_frame_ratio in place */
 } orc_problem;
 
 /* Ceres 1.9 Solver::Options subset (defaults: SURVEY Appendix C.5) */

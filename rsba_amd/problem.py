@@ -42,6 +42,7 @@ class BAProblem:
     prior_frames: Optional[np.ndarray] = None   # [NP] int32, frames f >= 1 that carry a prior against frame f - 1
     prior_scale: float = 0.0            # opt.ceres.constFrameVelocity / constFrameAcceleration
     inter_frame_ratio: float = 1.0      # opt.ceres.interFrameRatio
+    ratio_free: bool = False            # True: the ratio is a free, lower-bounded parameter block (the option left at 1)
 
     def __post_init__(self):
         self.poses = np.ascontiguousarray(self.poses, dtype=np.float64)

@@ -270,6 +270,53 @@ def np_prior_residuals(poses, kind, scale, ratio, frames):
     return np.array(out)
 
 
+def minimise_free_ratio(sc):
+    """As minimise(), with interFrameRatio as one more unknown bounded below (0 / DBL_EPSILON), scipy's bounded TRF."""
+    F, P = sc["poses"].shape[:2]
+    free = np.ones((F, P, 6), dtype=bool)
+    free[0] = False
+    free[-1, -1, 3:] = False
+    a = sc["huber_a"]
+    kind, scale, ratio0, frames = sc["prior"]
+    n = int(free.sum())
+
+    def fun(x):
+        poses = sc["poses"].copy(); poses[free] = x[:n]
+        pts = x[n:-1].reshape(-1, 3)
+        r = np_residuals(sc["cam"], poses, pts, sc["obs_xy"], sc["obs_frame"], sc["obs_point"], sc["shutter"], sc["scan"], True)
+        pr = np_prior_residuals(poses, kind, scale, x[-1], frames)
+        if a > 0:
+            for blk in (r, pr):
+                s = np.sum(blk * blk, axis=1)
+                rho = np.where(s <= a * a, s, 2 * a * np.sqrt(np.maximum(s, 1e-300)) - a * a)
+                blk *= np.sqrt(rho / np.maximum(s, 1e-300))[:, None]
+        return np.concatenate([r.reshape(-1), pr.reshape(-1)])
+
+    x0 = np.concatenate([sc["poses"][free], sc["points"].reshape(-1), [ratio0]])
+    lo = np.full(len(x0), -np.inf); lo[-1] = 0.0 if kind == 1 else np.finfo(np.float64).eps
+    sol = least_squares(fun, x0, bounds=(lo, np.inf), method="trf", x_scale="jac", ftol=1e-15, xtol=1e-15, gtol=1e-15, max_nfev=600)
+    sol = least_squares(fun, sol.x, bounds=(lo, np.inf), method="trf", x_scale="jac", ftol=1e-15, xtol=1e-15, gtol=1e-15, max_nfev=600)
+    poses = sc["poses"].copy(); poses[free] = sol.x[:n]
+    return dict(initial_cost=float(0.5 * np.sum(fun(x0) ** 2)), final_cost=float(sol.cost), grad_inf=float(np.max(np.abs(sol.grad))),
+                poses=poses.tolist(), points=sol.x[n:-1].reshape(-1, 3).tolist(), ratio=float(sol.x[-1]), nfev=int(sol.nfev))
+
+
+def free_ratio_cases():
+    out = []
+    for name, seed, F, M, a, outl, kind, scale, ratio in (("rs_velocity_free_ratio", 41, 6, 60, 0.0, False, 1, 6.0, 1.0),
+                                                         ("rs_acceleration_free_ratio", 42, 7, 70, 0.0, False, 2, 25.0, 1.0)):
+        sc = tiny_scene(seed, F, M, True, a, outl)
+        frames = list(range(1, F))
+        sc["prior"] = (kind, scale, ratio, frames)
+        res = minimise_free_ratio(sc)
+        out.append(dict(name=name, rolling=True, huber_a=a, cam=sc["cam"].tolist(), scanlines=list(sc["scan"]), shutter=sc["shutter"],
+                        poses=sc["poses"].tolist(), points=sc["points"].tolist(), obs_xy=sc["obs_xy"].tolist(),
+                        obs_frame=sc["obs_frame"].tolist(), obs_point=sc["obs_point"].tolist(),
+                        prior_kind=kind, prior_scale=scale, inter_frame_ratio=ratio, ratio_free=True, prior_frames=frames, expected=res))
+        print(name, "cost", res["initial_cost"], "->", res["final_cost"], "ratio", res["ratio"], "|g|inf", res["grad_inf"], file=sys.stderr)
+    return out
+
+
 def minimise(sc):
     """Gauge: frame 0 constant, translation of the last frame's last pose fixed.  Robust cost enters as
     r~ = r * sqrt(rho(s)/s) per 2-D block, so that 1/2 |r~|^2 = 1/2 rho(s) (Ceres' block-wise loss)."""
@@ -371,6 +418,10 @@ def pnp_cases():
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "free_ratio":   # only the free interFrameRatio cases
+        with open(os.path.join(HERE, "free_ratio_solves.json"), "w") as f:
+            json.dump(free_ratio_cases(), f)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "pnp":       # only the RS-PnP cases
         with open(os.path.join(HERE, "pnp_solves.json"), "w") as f:
             json.dump(pnp_cases(), f)

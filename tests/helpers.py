@@ -54,6 +54,7 @@ def problem_from_solve_case(c) -> BAProblem:
     if c.get("prior_kind"):
         prob.prior_kind, prob.prior_scale, prob.inter_frame_ratio = c["prior_kind"], c["prior_scale"], c["inter_frame_ratio"]
         prob.prior_frames = np.array(c["prior_frames"], dtype=np.int32)
+        prob.ratio_free = bool(c.get("ratio_free", False))
     return prob
 
 

@@ -129,6 +129,26 @@ def test_motion_prior_solve_reaches_independent_minimum(oracle, idx):
 
 
 @pytest.mark.parametrize("idx", [0, 1])
+def test_free_inter_frame_ratio_reaches_independent_minimum(oracle, idx):
+    """The reference's default for the motion priors (opt.ceres.interFrameRatio left at 1): the ratio is a free parameter
+    block bounded below (CeresHandler.h:161,172,175).  Restatement: one more unknown of the LM, candidate projected onto
+    the bound — against scipy's bounded minimiser on the independent numpy model (make_golden.py free_ratio)."""
+    c = load_golden("free_ratio_solves.json")[idx]
+    prob = problem_from_solve_case(c)
+    ok, cost0, _ = oracle.evaluate(prob, gradient=False)
+    assert ok and abs(cost0 - c["expected"]["initial_cost"]) <= 1e-9 * cost0
+    s, _ = oracle.solve(prob, oracle.default_options(max_num_iterations=300, function_tolerance=1e-14, parameter_tolerance=1e-14, gradient_tolerance=1e-12))
+    assert s.termination_type in (0, 1)
+    assert abs(s.final_cost - c["expected"]["final_cost"]) <= 1e-8 * c["expected"]["final_cost"]
+    assert abs(prob.inter_frame_ratio - c["expected"]["ratio"]) <= 1e-5 and prob.inter_frame_ratio > 2.0     # it moved from 1 to the scene's gap / exposure
+    assert np.max(np.abs(prob.poses - np.array(c["expected"]["poses"]))) <= 1e-5
+    # one more effective parameter than with the ratio held constant
+    fixed = problem_from_solve_case(c); fixed.ratio_free = False
+    s1, _ = oracle.solve(fixed, oracle.default_options(max_num_iterations=5))
+    assert s.num_parameters_reduced == s1.num_parameters_reduced + 1 and fixed.inter_frame_ratio == 1.0
+
+
+@pytest.mark.parametrize("idx", [0, 1])
 def test_pnp_refinement_reaches_independent_minimum(oracle, idx):
     """RS-PnP: the oracle's hypothesis task (RsBA<float> blocks over the two poses through the LM
     restatement) against scipy's minimum of an independent numpy model (tests/golden/make_golden.py pnp)."""
