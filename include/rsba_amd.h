@@ -203,6 +203,16 @@ int32_t rsba_pose_covariance(rsba_handle* h, int32_t frame, double* cov);
  * or shared-intrinsics problem.  frames strictly increasing; must precede the first solve / gradient call;
  * kind 0 or count 0 removes them.  With rsba_set_exchange every rank passes the same list (rank 0 contributes them). */
 int32_t rsba_set_motion_priors(rsba_handle* h, int32_t kind, double scale, double inter_frame_ratio, const int32_t* frames, int32_t count);
+/* The reference's DEFAULT for these priors (opt.ceres.interFrameRatio left at 1, CeresHandler.h:175): the ratio is a free
+ * parameter block with a lower bound (0 for kind 1, DBL_EPSILON for kind 2; :161,:172).  is_free != 0 makes rsba_solve
+ * treat it so: one more unknown of the LM (its column is a 1-wide dense border of the reduced camera system, served by a
+ * second solve through the factorisation), the candidate projected onto the bound as Ceres' ParameterBlock::Plus does,
+ * the gradient norm taken of the projected gradient.  Ceres' extra projected line search for bounded problems (>= 1.10)
+ * is not restated: steps follow the plain trust-region rules.  rsba_get_inter_frame_ratio returns the current value
+ * (the solved one after rsba_solve).  Must precede the first solve / gradient call; evaluate / gradient / covariance
+ * treat the ratio as the constant it currently is. */
+int32_t rsba_set_inter_frame_ratio_free(rsba_handle* h, int32_t is_free);
+int32_t rsba_get_inter_frame_ratio(rsba_handle* h, double* ratio);
 
 /* == the RANSAC hypotheses of vision::solveRsPnPRansac (solveRSpnp.cpp:413-524), batched: task t is
  * what pnpTask (:265-335) does for the subset subsets[t][0..m) of the n float points —

@@ -22,7 +22,7 @@ EXPORTS = [
     "rsba_get_device_view", "rsba_time_evaluate", "rsba_default_solver_options", "rsba_solve", "rsba_normal_equations",
     "rsba_set_exchange", "rsba_get_block_structure", "rsba_set_block_structure",
     "rsba_validate_observations", "rsba_reproject", "rsba_pose_covariance", "rsba_set_motion_priors",
-    "rsba_pnp_tasks", "rsba_pnp_inliers",
+    "rsba_pnp_tasks", "rsba_pnp_inliers", "rsba_set_inter_frame_ratio_free", "rsba_get_inter_frame_ratio",
 ]
 
 
@@ -159,6 +159,8 @@ class DeviceProblem:
         _check(lib().rsba_create(C.byref(self._desc), C.c_int32(device), C.byref(self._h)))
         if prob.prior_kind and prob.prior_frames is not None and len(prob.prior_frames):
             self.set_motion_priors(prob.prior_kind, prob.prior_scale, prob.inter_frame_ratio, prob.prior_frames)
+            if getattr(prob, "ratio_free", False):
+                _check(lib().rsba_set_inter_frame_ratio_free(self._h, C.c_int32(1)))
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
@@ -182,6 +184,12 @@ class DeviceProblem:
         fr = np.ascontiguousarray(frames, dtype=np.int32)
         _check(lib().rsba_set_motion_priors(self._h, C.c_int32(int(kind)), C.c_double(float(scale)), C.c_double(float(inter_frame_ratio)),
                                             fr.ctypes.data_as(C.c_void_p), C.c_int32(len(fr))))
+
+    def inter_frame_ratio(self) -> float:
+        """current interFrameRatio of the motion priors (the solved value when it is a free parameter)"""
+        v = C.c_double(0.0)
+        _check(lib().rsba_get_inter_frame_ratio(self._h, C.byref(v)))
+        return v.value
 
     def set_stream(self, raw_stream: int | None):
         _check(lib().rsba_set_stream(self._h, C.c_void_p(raw_stream or 0)))
@@ -263,6 +271,8 @@ class DeviceProblem:
         tr = (Iteration * trace_cap)()
         st = lib().rsba_solve(self._h, C.byref(o), C.byref(s), tr, C.c_int32(trace_cap))
         _check(st)
+        if getattr(self.prob, "ratio_free", False) and self.prob.prior_kind:
+            self.prob.inter_frame_ratio = self.inter_frame_ratio()       # a free ratio block is solved for, like every parameter
         return s, [tr[i] for i in range(min(s.num_iterations, trace_cap))]
 
 

@@ -282,9 +282,22 @@ int32_t rsba_set_motion_priors(rsba_handle* h, int32_t kind, double scale, doubl
   dp.prior_partial = part; dp.prior_ticket = ticket;
   dp.prior_of = d; dp.prior_kind = kind; dp.prior_scale = scale; dp.prior_ratio = inter_frame_ratio;
   h->prior_frames.assign(frames, frames + count);
+  h->prior_ratio_result = inter_frame_ratio;
   // RsConstVeloPrior returns ratio >= 0, RsConstAccelerationPrior ratio >= _EPS (video_bundler_rs_inter.h:92,:157)
   const bool valid = kind == 1 ? inter_frame_ratio >= 0.0 : inter_frame_ratio >= 2.220446049250313e-16;
   h->prior_invalid = valid ? 0 : count;
+  return RSBA_OK;
+}
+
+int32_t rsba_set_inter_frame_ratio_free(rsba_handle* h, int32_t is_free) {
+  if (!h) return fail(RSBA_ERR_INVALID_ARGUMENT, "null handle");
+  if (h->solver) return fail(RSBA_ERR_INVALID_ARGUMENT, "rsba_set_inter_frame_ratio_free must precede the first solve / gradient call");
+  h->prior_free = is_free != 0;
+  return RSBA_OK;
+}
+int32_t rsba_get_inter_frame_ratio(rsba_handle* h, double* ratio) {
+  if (!h || !ratio) return fail(RSBA_ERR_INVALID_ARGUMENT, "null argument");
+  *ratio = h->dp.prior_of ? h->dp.prior_ratio : 0.0;
   return RSBA_OK;
 }
 

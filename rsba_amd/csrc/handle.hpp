@@ -26,6 +26,8 @@ struct rsba_handle {
   double* d_rows = nullptr;            // [N][2 + 2K] results in the caller's layout and order, staged for one D2H copy each
   // motion priors (rsba_set_motion_priors): frames that carry one, device flags live in dp.prior_of
   std::vector<int32_t> prior_frames;
+  bool prior_free = false;             // interFrameRatio is a free, lower-bounded parameter (rsba_set_inter_frame_ratio_free)
+  double prior_ratio_result = 0.0;     // its value after the last solve
   int prior_invalid = 0;               // blocks whose functor returns false for the given interFrameRatio
   rsba::Solver* solver = nullptr;      // normal-equation / Schur / LM state, built on first use
   // multi-GPU exchange (rsba_set_exchange / rsba_set_block_structure)

@@ -68,6 +68,21 @@ __device__ __forceinline__ PriorValue prior_value(const DeviceProblem& dp, int f
   return v;
 }
 
+// d r / d interFrameRatio of the 12 residuals (the Jacobian column of the ratio block when it is a free parameter)
+__device__ __forceinline__ void prior_ratio_column(const DeviceProblem& dp, int f, double dr[12]) {
+  const double* cur = dp.poses + (size_t)f * 12; const double* prev = cur - 12;
+  const double q = dp.prior_ratio, iq2 = 1.0 / (q * q);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const double c0 = cur[i], p0 = prev[i], p1 = prev[6 + i];
+    double da, db;
+    if (dp.prior_kind == 1) { da = -(p1 - p0); db = (q > 2.220446049250313e-16) ? (c0 - p1) * iq2 : 0.0; }
+    else { da = -0.5 * (p1 - p0); db = 0.5 * (c0 - p1) * iq2; }
+    const double si = dp.prior_scale * (i < 3 ? 0.01 : 1.0);
+    dr[i] = da * si; dr[6 + i] = db * si;
+  }
+}
+
 // U_f, g_f and the (f, f-1) cross block: one thread per frame
 __global__ __launch_bounds__(64) void prior_blocks_kernel(const DeviceProblem dp, const SolverDev sv, double* __restrict__ ucross) {
   const int f = blockIdx.x * 64 + threadIdx.x;
@@ -145,7 +160,7 @@ __global__ __launch_bounds__(64) void prior_cost_kernel(const DeviceProblem dp, 
 }
 
 // model cost change of the prior blocks for the camera step in sv.rhs:  -sum m.(r~ + m/2),  m = -J~ y
-__global__ __launch_bounds__(64) void prior_model_kernel(const DeviceProblem dp, const SolverDev sv, double* out) {
+__global__ __launch_bounds__(64) void prior_model_kernel(const DeviceProblem dp, const SolverDev sv, double* out, double ratio_step) {
   const int f = blockIdx.x * 64 + threadIdx.x;
   double acc = 0.0;
   if (f < dp.F && dp.prior_of[f]) {
@@ -154,11 +169,15 @@ __global__ __launch_bounds__(64) void prior_model_kernel(const DeviceProblem dp,
     const PriorValue v = prior_value(dp, f);
     const double sw = sqrt(v.weight);
     const double* y = sv.rhs + (size_t)(f - 1) * 12; const double* sc = dp.scale_pose + (size_t)(f - 1) * 12;   // [prev | cur]
+    double dr[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) dr[i] = 0.0;
+    if (ratio_step != 0.0) prior_ratio_column(dp, f, dr);            // free ratio: its (scaled) step enters m = -J~ y too
     for (int i = 0; i < 6; ++i) {
       const double si = dp.prior_scale * (i < 3 ? 0.01 : 1.0);
       const double x0 = sc[12 + i] * y[12 + i], x1 = sc[18 + i] * y[18 + i], x2 = sc[i] * y[i], x3 = sc[6 + i] * y[6 + i];
-      const double ma = -sw * si * (Ca[0] * x0 + Ca[1] * x1 + Ca[2] * x2 + Ca[3] * x3);
-      const double mb = -sw * si * (Cb[0] * x0 + Cb[1] * x1 + Cb[2] * x2 + Cb[3] * x3);
+      const double ma = -sw * (si * (Ca[0] * x0 + Ca[1] * x1 + Ca[2] * x2 + Ca[3] * x3) + dr[i] * ratio_step);
+      const double mb = -sw * (si * (Cb[0] * x0 + Cb[1] * x1 + Cb[2] * x2 + Cb[3] * x3) + dr[6 + i] * ratio_step);
       acc += ma * (sw * v.r[i] + 0.5 * ma) + mb * (sw * v.r[6 + i] + 0.5 * mb);
     }
   }
@@ -171,7 +190,86 @@ __global__ __launch_bounds__(64) void prior_model_kernel(const DeviceProblem dp,
   *out += -a;
 }
 
+// Free interFrameRatio: the column of the ratio in the normal equations.  border[t] = (J~_x^T J~_ratio) of camera
+// coordinate t (camera scales applied, the ratio's own scale is the host's), hg = {J~_ratio^T J~_ratio, J~_ratio^T r~}.
+// One thread per frame gathers the prior it heads and the one referring back to it; hg by the last-wave reduction.
+__global__ __launch_bounds__(64) void prior_border_kernel(const DeviceProblem dp, const SolverDev sv, double* __restrict__ border, double* __restrict__ hg) {
+  const int f = blockIdx.x * 64 + threadIdx.x;
+  double hh = 0.0, gg = 0.0;
+  if (f < dp.F) {
+    const bool heads = dp.prior_of[f] != 0, referred = dp.prior_of[f + 1] != 0;
+    double Ca[4], Cb[4];
+    prior_coefficients(dp, Ca, Cb);
+    double out[12];
+#pragma unroll
+    for (int a = 0; a < 12; ++a) out[a] = 0.0;
+    if (heads) {
+      const PriorValue v = prior_value(dp, f);
+      double dr[12];
+      prior_ratio_column(dp, f, dr);
+      for (int i = 0; i < 6; ++i) {
+        const double si = dp.prior_scale * (i < 3 ? 0.01 : 1.0);
+        for (int p = 0; p < 2; ++p) out[6 * p + i] += v.weight * si * (Ca[p] * dr[i] + Cb[p] * dr[6 + i]);
+        hh += v.weight * (dr[i] * dr[i] + dr[6 + i] * dr[6 + i]);
+        gg += v.weight * (dr[i] * v.r[i] + dr[6 + i] * v.r[6 + i]);
+      }
+    }
+    if (referred) {
+      const PriorValue v = prior_value(dp, f + 1);
+      double dr[12];
+      prior_ratio_column(dp, f + 1, dr);
+      for (int i = 0; i < 6; ++i) {
+        const double si = dp.prior_scale * (i < 3 ? 0.01 : 1.0);
+        for (int p = 0; p < 2; ++p) out[6 * p + i] += v.weight * si * (Ca[2 + p] * dr[i] + Cb[2 + p] * dr[6 + i]);
+      }
+    }
+    const double* sc = dp.scale_pose + (size_t)f * 12;
+#pragma unroll
+    for (int a = 0; a < 12; ++a) border[(size_t)f * 12 + a] = out[a] * sc[a];
+  }
+  hh = wsum64(hh); gg = wsum64(gg);
+  if (threadIdx.x != 0) return;
+  dp.prior_partial[2 * blockIdx.x] = hh; dp.prior_partial[2 * blockIdx.x + 1] = gg;
+  if (!last_wave_of_grid(dp)) return;
+  double a = 0.0, b = 0.0;
+  for (unsigned w = 0; w < gridDim.x; ++w) { a += dp.prior_partial[2 * w]; b += dp.prior_partial[2 * w + 1]; }
+  hg[0] = a; hg[1] = b;
+}
+
+// out[0] = b.u, out[1] = b.v over n entries (one workgroup, fixed order)
+__global__ __launch_bounds__(1024) void border_dots_kernel(const double* __restrict__ b, const double* __restrict__ u, const double* __restrict__ v, int64_t n, double* out) {
+  __shared__ double s_red[2][16];
+  double du = 0.0, dv = 0.0;
+  for (int64_t t = threadIdx.x; t < n; t += 1024) { const double bt = b[t]; du += bt * u[t]; dv += bt * v[t]; }
+  du = wsum64(du); dv = wsum64(dv);
+  if ((threadIdx.x & 63) == 0) { s_red[0][threadIdx.x >> 6] = du; s_red[1][threadIdx.x >> 6] = dv; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0, c = 0.0;
+    for (int w = 0; w < 16; ++w) { a += s_red[0][w]; c += s_red[1][w]; }
+    out[0] = a; out[1] = c;
+  }
+}
+// y = u - c v
+__global__ void border_combine_kernel(double* __restrict__ y, const double* __restrict__ u, const double* __restrict__ v, double c, int64_t n) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t < n) y[t] = u[t] - c * v[t];
+}
+
 }  // namespace
+
+hipError_t launch_prior_border(const DeviceProblem& dp, const SolverDev& sv, double* border, double* hg, hipStream_t st) {
+  hipLaunchKernelGGL(prior_border_kernel, dim3((dp.F + 63) / 64), dim3(64), 0, st, dp, sv, border, hg);
+  return hipGetLastError();
+}
+hipError_t launch_border_dots(const double* b, const double* u, const double* v, int64_t n, double* out2, hipStream_t st) {
+  hipLaunchKernelGGL(border_dots_kernel, dim3(1), dim3(1024), 0, st, b, u, v, n, out2);
+  return hipGetLastError();
+}
+hipError_t launch_border_combine(double* y, const double* u, const double* v, double c, int64_t n, hipStream_t st) {
+  hipLaunchKernelGGL(border_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, y, u, v, c, n);
+  return hipGetLastError();
+}
 
 hipError_t launch_prior_blocks(const DeviceProblem& dp, const SolverDev& sv, double* ucross, hipStream_t st) {
   hipLaunchKernelGGL(prior_blocks_kernel, dim3((dp.F + 63) / 64), dim3(64), 0, st, dp, sv, ucross);
@@ -181,8 +279,8 @@ hipError_t launch_prior_cost(const DeviceProblem& dp, double* cost2, int invalid
   hipLaunchKernelGGL(prior_cost_kernel, dim3((dp.F + 63) / 64), dim3(64), 0, st, dp, cost2, invalid_blocks);
   return hipGetLastError();
 }
-hipError_t launch_prior_model(const DeviceProblem& dp, const SolverDev& sv, double* model_cost_change, hipStream_t st) {
-  hipLaunchKernelGGL(prior_model_kernel, dim3((dp.F + 63) / 64), dim3(64), 0, st, dp, sv, model_cost_change);
+hipError_t launch_prior_model(const DeviceProblem& dp, const SolverDev& sv, double* model_cost_change, double ratio_step, hipStream_t st) {
+  hipLaunchKernelGGL(prior_model_kernel, dim3((dp.F + 63) / 64), dim3(64), 0, st, dp, sv, model_cost_change, ratio_step);
   return hipGetLastError();
 }
 

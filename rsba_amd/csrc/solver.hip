@@ -49,6 +49,7 @@ struct Solver {
   double *d_gpose = nullptr, *d_gpoint = nullptr;
   int64_t num_pairs = 0;
   int num_reduced_blocks = 0, num_reduced_params = 0, num_priors_reduced = 0;
+  double* border = nullptr, *ubuf = nullptr, *ratio4 = nullptr;      // free interFrameRatio: its column of S [npad], the first solve's result, {h, g, b.u, b.v}
   double* ucross = nullptr;                                           // [F][CD][CD] motion-prior blocks (f, f-1), behind sv.U's J^T J blocks
 };
 
@@ -569,6 +570,13 @@ int32_t build_solver(rsba_handle* h) {
   const size_t ucross_len = h->prior_frames.empty() ? 0 : (size_t)FR * CD * CD;
   if ((rc = s_alloc(s, &sv.U, (size_t)ucross_base + ucross_len))) return rc;
   if (ucross_len) { s->ucross = sv.U + ucross_base; HIP_TRY(hipMemset(s->ucross, 0, ucross_len * sizeof(double))); }   // stays zero on the other ranks
+  if (ucross_len && h->prior_free) {   // the ratio is one more camera-side unknown: a 1-wide dense border of S, handled by a second solve
+    if ((rc = s_alloc(s, &s->border, (size_t)sv.npad))) return rc;
+    if ((rc = s_alloc(s, &s->ubuf, (size_t)sv.npad))) return rc;
+    if ((rc = s_alloc(s, &s->ratio4, 4))) return rc;
+    HIP_TRY(hipMemset(s->border, 0, (size_t)sv.npad * sizeof(double)));
+    if (lead) s->num_reduced_params += 1;
+  }
   if ((rc = s_alloc(s, &sv.gc, (size_t)F * CD))) return rc;
   if ((rc = s_alloc(s, &sv.intr_part, (size_t)FR * 54))) return rc;
   if ((rc = s_alloc(s, &sv.trial_intr, 9 * (size_t)std::max(dp.NI, 1)))) return rc;
@@ -650,6 +658,7 @@ int32_t linearize(rsba_handle* h) {
     HIP_TRY(launch_prior_cost(h->dp, h->d_cost2, h->prior_invalid, h->stream));
     HIP_TRY(launch_prior_blocks(h->dp, s->sv, s->ucross, h->stream));
   }
+  if (s->border) HIP_TRY(launch_prior_border(h->dp, s->sv, s->border, s->ratio4, h->stream));   // every rank: from replicated poses
   HIP_TRY(launch_point_blocks(h->dp, s->sv, h->stream));
   HIP_TRY(launch_pack_linearize(h->dp, s->sv, h->d_cost2, h->stream));
   int32_t rc = exchange(h, s->sv.xbuf, 2 * s->sv.n + 3, 0);
@@ -699,12 +708,29 @@ int32_t solve_reduced_system(rsba_handle* h) {
   return RSBA_OK;
 }
 
-int32_t factor_and_solve(rsba_handle* h, double radius) {
+// ratio (free interFrameRatio only): in {h_s + D/radius, g_s, scale of the ratio}, out the ratio's scaled step eta.
+// The ratio's column b of the damped normal equations is a 1-wide dense border of S:  S u = g, S v = b,
+// eta = (g_s - s b.u) / (h_s + D - s^2 b.v),  y = u - (s eta) v  — two solves through the factorisation.
+struct RatioStep { double diag, gs, scale, eta; };
+int32_t factor_and_solve(rsba_handle* h, double radius, RatioStep* ratio = nullptr) {
   Solver* s = h->solver; const SolverDev& sv = s->sv; hipStream_t st = h->stream;
   int32_t rc = reduce_system(h, radius);
   if (rc) return rc;
   if ((rc = solve_reduced_system(h))) return rc;
-  HIP_TRY(hipMemcpyAsync(sv.rhs, sv.yv, (size_t)sv.npad * sizeof(double), hipMemcpyDeviceToDevice, st));   // camera step
+  if (ratio) {
+    const size_t bytes = (size_t)sv.npad * sizeof(double);
+    HIP_TRY(hipMemcpyAsync(s->ubuf, sv.yv, bytes, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(sv.rhs, s->border, bytes, hipMemcpyDeviceToDevice, st));
+    if ((rc = solve_reduced_system(h))) return rc;                       // yv = v
+    HIP_TRY(launch_border_dots(s->border, s->ubuf, sv.yv, sv.npad, s->ratio4 + 2, st));
+    double dots[2];
+    HIP_TRY(hipMemcpyAsync(dots, s->ratio4 + 2, sizeof dots, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    ratio->eta = (ratio->gs - ratio->scale * dots[0]) / (ratio->diag - ratio->scale * ratio->scale * dots[1]);
+    HIP_TRY(launch_border_combine(sv.rhs, s->ubuf, sv.yv, ratio->scale * ratio->eta, sv.npad, st));
+  } else {
+    HIP_TRY(hipMemcpyAsync(sv.rhs, sv.yv, (size_t)sv.npad * sizeof(double), hipMemcpyDeviceToDevice, st));   // camera step
+  }
   HIP_TRY(launch_back_substitute(h->dp, sv, st));
   return RSBA_OK;
 }
@@ -865,8 +891,15 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
                   it.gradient_max_norm, it.step_norm, it.relative_decrease, it.trust_region_radius, it.step_is_successful ? "ok" : (it.iteration ? "rejected" : ""));
   };
   double host_sc[16]; double cost2[2]; int nfail = 0, cfail = 0;
+  // free interFrameRatio (the reference's default for the motion priors, CeresHandler.h:161,172,175): one more unknown of
+  // the LM, kept on the host — value, Jacobi scale, LM diagonal, and {h, g} = its column's J^T J and J^T r from the device.
+  // The candidate is projected onto the lower bound (ParameterBlock::Plus); Ceres' projected line search is not restated.
+  const bool free_ratio = s->border != nullptr;
+  const double ratio_lb = dp.prior_kind == 2 ? 2.220446049250313e-16 : 0.0;
+  double ratio = dp.prior_ratio, ratio_scale = 1.0, ratio_diag = 0.0, ratio_hg[2] = {0.0, 0.0}, ratio_new = dp.prior_ratio;
   auto read_back = [&]() -> int32_t {
     HIP_TRY(hipMemcpyAsync(host_sc, sv.scalars, sizeof host_sc, hipMemcpyDeviceToHost, st));
+    if (free_ratio) HIP_TRY(hipMemcpyAsync(ratio_hg, s->ratio4, sizeof ratio_hg, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     cost2[0] = host_sc[kCost]; cost2[1] = host_sc[kFixedCost];
     nfail = host_sc[kEvalFailed] != 0.0; cfail = host_sc[kSolveFailed] != 0.0;
@@ -881,6 +914,7 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
     HIP_TRY(hipMemcpyAsync(h->desc.points, dp.points, npt * sizeof(double), hipMemcpyDeviceToHost, st));
     if (!dp.calibrated) HIP_TRY(hipMemcpyAsync(h->desc.intrinsics, dp.intr, (size_t)dp.NI * 9 * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    h->prior_ratio_result = dp.prior_ratio;
     sum->total_time_s = now_s() - t_start;
     if (const char* path = h->solver->d_trace ? std::getenv("RSBA_CHOL_TRACE") : nullptr) {   // debugging aid, off by default
       Solver* sl = h->solver;
@@ -906,7 +940,8 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
   sum->residual_jacobian_time_s += now_s() - t0;
   if (nfail) { sum->termination_type = RSBA_FAILURE; (void)finish(RSBA_FAILURE); return rsba_set_error(RSBA_ERR_EVALUATION_FAILED, "initial residual and Jacobian evaluation failed"); }
   double cost = cost2[0]; const double fixed = cost2[1];
-  double gmax = host_sc[kGradMax];
+  auto with_ratio_gradient = [&](double g) { return free_ratio ? std::max(g, std::fabs(ratio - std::max(ratio_lb, ratio - ratio_hg[1]))) : g; };
+  double gmax = with_ratio_gradient(host_sc[kGradMax]);
   sum->fixed_cost = fixed; sum->initial_cost = cost + fixed; sum->final_cost = cost + fixed;
   double radius = opt->initial_trust_region_radius, decrease_factor = 2.0; bool reuse_diagonal = false;
   rsba_iteration it; std::memset(&it, 0, sizeof it);
@@ -916,6 +951,7 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
     // EstimateScale from the first Jacobian, then the Jacobian is column-scaled for good; here the
     // scales feed the evaluation kernel, so re-linearise once with them
     HIP_TRY(launch_jacobi_scale(dp, sv, st));
+    if (free_ratio) ratio_scale = 1.0 / (1.0 + std::sqrt(ratio_hg[0]));
     if ((rc = linearize(h))) return rc;
   }
   push(it);
@@ -928,19 +964,29 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
   while (true) {
     if (iteration >= opt->max_num_iterations) return finish(RSBA_NO_CONVERGENCE);
     t0 = now_s();
-    if (!reuse_diagonal) HIP_TRY(launch_clamp_diagonal(dp, sv, opt->min_lm_diagonal, opt->max_lm_diagonal, st));
+    if (!reuse_diagonal) {
+      HIP_TRY(launch_clamp_diagonal(dp, sv, opt->min_lm_diagonal, opt->max_lm_diagonal, st));
+      ratio_diag = std::min(std::max(ratio_scale * ratio_scale * ratio_hg[0], opt->min_lm_diagonal), opt->max_lm_diagonal);
+    }
     HIP_TRY(hipMemsetAsync(sv.chol_fail, 0, sizeof(int), st));
-    if ((rc = factor_and_solve(h, radius))) return rc;
+    RatioStep rs{ratio_scale * ratio_scale * ratio_hg[0] + ratio_diag / radius, ratio_scale * ratio_hg[1], ratio_scale, 0.0};
+    if ((rc = factor_and_solve(h, radius, free_ratio ? &rs : nullptr))) return rc;
     reuse_diagonal = true;
+    const double ratio_step = free_ratio ? ratio_scale * rs.eta : 0.0;      // the ratio's step in its own units is -ratio_step
+    ratio_new = free_ratio ? std::max(ratio_lb, ratio - ratio_step) : ratio;
     HIP_TRY(launch_model_cost_change(dp, sv, st));
-    if (s->ucross && sv.lead) HIP_TRY(launch_prior_model(dp, sv, sv.scalars + kModelCostChange, st));
+    if (s->ucross && sv.lead) HIP_TRY(launch_prior_model(dp, sv, sv.scalars + kModelCostChange, std::isfinite(ratio_step) ? ratio_step : 0.0, st));
     HIP_TRY(launch_candidate(dp, sv, st));
     // residuals only at the candidate (T = double path)
     swap_params();
     HIP_TRY(hipMemsetAsync(dp.fail_count, 0, sizeof(int), st));
     HIP_TRY(launch_eval(dp, kResidualOnly, st));
     HIP_TRY(launch_cost_reduce(dp, h->d_cost2, st));
-    if (s->ucross && sv.lead) HIP_TRY(launch_prior_cost(dp, h->d_cost2, h->prior_invalid, st));
+    if (s->ucross && sv.lead) {
+      dp.prior_ratio = std::isfinite(ratio_new) ? ratio_new : ratio;
+      HIP_TRY(launch_prior_cost(dp, h->d_cost2, h->prior_invalid, st));
+      dp.prior_ratio = ratio;
+    }
     swap_params();
     // exchange (3): model decrease, |step|^2, |x|^2, (skip the max slot), trial cost, -, failure flags
     HIP_TRY(launch_pack_trial(dp, sv, h->d_cost2, st));
@@ -951,6 +997,7 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
     sum->linear_solver_time_s += now_s() - t0;
     ++iteration;
     std::memset(&it, 0, sizeof it); it.iteration = iteration;
+    if (free_ratio) { host_sc[kStepSq] += (ratio - ratio_new) * (ratio - ratio_new); host_sc[kXSq] += ratio * ratio; }
     const double model_cost_change = host_sc[kModelCostChange];
     const bool solved = !cfail && std::isfinite(model_cost_change) && std::isfinite(host_sc[kStepSq]);
     const bool valid = solved && model_cost_change >= 0.0;
@@ -974,6 +1021,7 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
         radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * it.relative_decrease - 1.0, 3));
         radius = std::min(opt->max_trust_region_radius, radius); decrease_factor = 2.0; reuse_diagonal = false;
         swap_params();   // x = x_plus_delta
+        if (free_ratio) { ratio = ratio_new; dp.prior_ratio = ratio; }
         if (sv.NPF > 0) HIP_TRY(hipMemcpyAsync(sv.trial_intr, dp.intr, 9 * sizeof(double), hipMemcpyDeviceToDevice, st));   // constant coordinates stay in sync
         t0 = now_s();
         if ((rc = linearize(h))) return rc;
@@ -981,7 +1029,7 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
         if ((rc = read_back())) return rc;
         sum->residual_jacobian_time_s += now_s() - t0;
         if (nfail) { push(it); (void)finish(RSBA_FAILURE); return rsba_set_error(RSBA_ERR_EVALUATION_FAILED, "residual and Jacobian evaluation failed"); }
-        cost = cost2[0]; gmax = host_sc[kGradMax];
+        cost = cost2[0]; gmax = with_ratio_gradient(host_sc[kGradMax]);
         it.gradient_max_norm = gmax;
         sum->final_cost = std::min(sum->final_cost, cost + fixed);
         if (gmax <= opt->gradient_tolerance) { it.cost = cost + fixed; it.trust_region_radius = radius; push(it); return finish(RSBA_CONVERGENCE); }

@@ -131,7 +131,11 @@ hipError_t launch_model_cost_change(const DeviceProblem& dp, const SolverDev& sv
 hipError_t launch_candidate(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);              // trial params, |step|^2, |x|^2
 // motion priors (kernels_prior.hip): U_f, g_f += their J^T J / J^T r, ucross[f] = the (f, f-1) block; model cost change
 hipError_t launch_prior_blocks(const DeviceProblem& dp, const SolverDev& sv, double* ucross, hipStream_t st);
-hipError_t launch_prior_model(const DeviceProblem& dp, const SolverDev& sv, double* model_cost_change, hipStream_t st);
+hipError_t launch_prior_model(const DeviceProblem& dp, const SolverDev& sv, double* model_cost_change, double ratio_step, hipStream_t st);
+// free interFrameRatio: its column of the normal equations (border [F*12], hg = {h, g}), dots and the combined step
+hipError_t launch_prior_border(const DeviceProblem& dp, const SolverDev& sv, double* border, double* hg, hipStream_t st);
+hipError_t launch_border_dots(const double* b, const double* u, const double* v, int64_t n, double* out2, hipStream_t st);
+hipError_t launch_border_combine(double* y, const double* u, const double* v, double c, int64_t n, hipStream_t st);
 hipError_t launch_intr_blocks(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);
 hipError_t launch_virtual_records(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);
 hipError_t launch_pack_linearize(const DeviceProblem& dp, const SolverDev& sv, const double* cost2, hipStream_t st);

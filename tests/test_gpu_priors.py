@@ -129,3 +129,39 @@ def test_full_size_cost_is_additive_with_an_independent_numpy_model(capi):
         else:
             base = plain
         assert abs(got - (base + 0.5 * float(np.sum(rho)))) <= 1e-12 * got
+
+
+# ---- the free, lower-bounded interFrameRatio (the reference's default: option left at 1) ----
+@pytest.mark.parametrize("idx", [0, 1])
+def test_free_ratio_reaches_the_independent_bounded_minimum(capi, oracle, idx):
+    c = load_golden("free_ratio_solves.json")[idx]
+    p = problem_from_solve_case(c)
+    s, s_ref, p_dev, p_cpu = compare_solves(capi, oracle, p, iters=300, tight=True, final_tol=1e-8)
+    assert abs(s.final_cost - c["expected"]["final_cost"]) <= 1e-8 * c["expected"]["final_cost"]
+    assert abs(p_dev.inter_frame_ratio - c["expected"]["ratio"]) <= 1e-5 and abs(p_dev.inter_frame_ratio - p_cpu.inter_frame_ratio) <= 1e-7
+    assert np.max(np.abs(p_dev.poses - np.array(c["expected"]["poses"]))) <= 1e-5
+
+
+@pytest.mark.parametrize("kind,huber,shared_intrinsics", [(1, 0.0, False), (2, 2.0, False), (1, 2.0, True)])
+def test_free_ratio_trajectory_matches_oracle(capi, oracle, kind, huber, shared_intrinsics):
+    p = with_priors(small_scene(frames=30, points=1500, outlier_ratio=0.05 if huber else 0.0), kind, 10.0 if kind == 1 else 30.0, 1.0)
+    p.ratio_free = True
+    p.huber_a = huber
+    if shared_intrinsics:
+        p.calibrated = False
+    s, s_ref, p_dev, p_cpu = compare_solves(capi, oracle, p, iters=30)
+    assert s.num_parameters_reduced == s_ref.num_parameters_reduced
+    assert abs(p_dev.inter_frame_ratio - p_cpu.inter_frame_ratio) <= 1e-5 and abs(p_dev.inter_frame_ratio - 1.0) > 1e-3
+    assert np.max(np.abs(p_dev.poses - p_cpu.poses)) <= 1e-5
+
+
+def test_free_ratio_level_schedule_equals_dag(capi):
+    p = with_priors(small_scene(frames=60, points=3000), 1, 20.0, 1.0)
+    p.ratio_free = True
+    res = []
+    for levels in (0, 1):
+        q = p.copy()
+        with capi.DeviceProblem(q) as dp:
+            s, _ = dp.solve(capi.default_options(max_num_iterations=8, level_scheduled_cholesky=levels))
+        res.append((s.final_cost, q.poses.copy(), q.inter_frame_ratio))
+    assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1]) and res[0][2] == res[1][2] != 1.0
