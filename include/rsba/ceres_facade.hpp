@@ -10,10 +10,10 @@
 //
 // Accepted cost functions: rsba's two hot-path functors — the typed cost objects of reprojection_costs.hpp
 // (RsBundleAdjustment / ReprojectionError factories) — and, between the frames those observe, the motion priors of
-// motion_priors.hpp (RsConstVeloPrior / RsConstAccelerationPrior with a constant interFrameRatio block; SURVEY §8f
-// row f1).  There is NO host-side evaluation: every residual, Jacobian and solve goes through librsba_amd's HIP
-// kernels; a cost function of any other type (SphericalPrior, GoodPosePrior, a free interFrameRatio) is rejected with
-// an error, not evaluated on the CPU.
+// motion_priors.hpp (RsConstVeloPrior / RsConstAccelerationPrior; the interFrameRatio block constant or, as in the
+// reference's default, free with CeresHandler's lower bound).  There is NO host-side evaluation: every residual, Jacobian and solve goes through librsba_amd's HIP
+// kernels; a cost function of any other type (SphericalPrior, GoodPosePrior) is rejected with an error, not evaluated
+// on the CPU.
 #pragma once
 #include <algorithm>
 #include <cmath>
@@ -301,6 +301,8 @@ class Problem {
     // motion priors (constant interFrameRatio): lowered to rsba_set_motion_priors
     int prior_kind = 0; double prior_scale = 0, prior_ratio = 1;
     std::vector<int32_t> prior_frames;
+    double* ratio_ptr = nullptr;       // the interFrameRatio block; ratio_free: it is a (lower-bounded) parameter of the solve
+    bool ratio_free = false;
   };
   // device problem of a flattened graph: rsba_create + the prior blocks
   static int32_t create_handle(const Flat& f, int device, rsba_handle** h) {
@@ -308,6 +310,7 @@ class Problem {
     if (st != RSBA_OK) return st;
     if (!f.prior_frames.empty()) {
       st = rsba_set_motion_priors(*h, f.prior_kind, f.prior_scale, f.prior_ratio, f.prior_frames.data(), (int32_t)f.prior_frames.size());
+      if (st == RSBA_OK && f.ratio_free) st = rsba_set_inter_frame_ratio_free(*h, 1);
       if (st != RSBA_OK) { rsba_destroy(*h); *h = nullptr; }
     }
     return st;
@@ -390,7 +393,16 @@ class Problem {
       if (!c) continue;
       if (!rolling || b.x.size() != 5) return fail("motion priors need rolling-shutter frames with two poses");
       if (b.loss != loss0) return fail("all residual blocks must share one loss function (as CeresHandler does)");
-      if (!constant_.count(b.x[0])) return fail("a free interFrameRatio (opt.ceres.interFrameRatio == 1: lower-bounded parameter) is not built; set the option to the known ratio");
+      const bool ratio_free = !constant_.count(b.x[0]);                 // CeresHandler.h:175: free unless the option differs from 1
+      if (ratio_free) {
+        // the bound CeresHandler sets (:161 _EPS for the acceleration prior, :172 0 for the velocity prior) is the one the
+        // device path applies; anything else is refused rather than silently replaced
+        auto lb = lower_bounds_.find(std::make_pair(b.x[0], 0));
+        const double want = c->kind() == 2 ? std::numeric_limits<double>::epsilon() : 0.0;
+        if (lb == lower_bounds_.end() || lb->second != want) return fail("a free interFrameRatio needs the lower bound CeresHandler sets (0 / DBL_EPSILON)");
+      }
+      if (!f->prior_frames.empty() && (f->ratio_ptr != b.x[0] || f->ratio_free != ratio_free)) return fail("motion priors of one problem must share the interFrameRatio block");
+      f->ratio_ptr = b.x[0]; f->ratio_free = ratio_free;
       auto cur = frame_of.find(std::make_pair(b.x[1], b.x[2])), prev = frame_of.find(std::make_pair(b.x[3], b.x[4]));
       if (cur == frame_of.end() || prev == frame_of.end()) return fail("motion prior on a frame without observations");
       if (prev->second != cur->second - 1) return fail("motion priors must link consecutive frames");
@@ -464,6 +476,8 @@ inline void Solve(const Solver::Options& options, Problem* problem, Solver::Summ
   rsba_solver_summary s;
   std::vector<rsba_iteration> trace((size_t)options.max_num_iterations + 2);
   st = rsba_solve(h, &o, &s, trace.data(), (int32_t)trace.size());
+  double solved_ratio = 0.0;
+  if (f.ratio_free) (void)rsba_get_inter_frame_ratio(h, &solved_ratio);
   rsba_destroy(h);
   summary->termination_type = s.termination_type == RSBA_CONVERGENCE ? CONVERGENCE : s.termination_type == RSBA_NO_CONVERGENCE ? NO_CONVERGENCE : FAILURE;
   if (st != RSBA_OK) { summary->termination_type = FAILURE; summary->message = std::string(rsba_status_string(st)) + ": " + rsba_last_error(); }
@@ -475,7 +489,10 @@ inline void Solve(const Solver::Options& options, Problem* problem, Solver::Summ
   summary->linear_solver_time_in_seconds = s.linear_solver_time_s;
   trace.resize(std::min<size_t>(trace.size(), (size_t)std::max(0, s.num_iterations)));
   summary->iterations = trace;
-  if (summary->IsSolutionUsable()) problem->scatter(f);
+  if (summary->IsSolutionUsable()) {
+    problem->scatter(f);
+    if (f.ratio_free && f.ratio_ptr) *f.ratio_ptr = solved_ratio;      // a free ratio block is solved for like every parameter block
+  }
 }
 
 // ceres::Covariance for pose blocks (the use rsba makes of it, VideoSfMHandler.cc:602-621): Compute() takes pairs of

@@ -4,11 +4,12 @@
 // Same names, argument meaning and error behaviour for the per-observation path (SURVEY Appendix D
 // steps 1, 3-4: pose initialisation of frames without poses, the observation loop incl. the match-based track lookup).
 // Not built (the rest of SURVEY §8f row f1 and out-of-scope costs): SphericalPrior, pose priors (GoodPosePrior), the
-// structure-less ray costs — reaching one of them throws std::runtime_error.  Motion priors (:147-186) are built for a known
-// opt.ceres.interFrameRatio (!= 1: constant block); the free, lower-bounded ratio is reported by Solve, not silently fixed.  opt.debug.calcCovariances (VideoSfMHandler.cc:599-621) is built.  revalidateReprojections (:239-243) runs as one
+// structure-less ray costs — reaching one of them throws std::runtime_error.  Motion priors (:147-186) are built, with a known
+// opt.ceres.interFrameRatio (!= 1: constant block) and with the free, lower-bounded ratio of the default.  opt.debug.calcCovariances (VideoSfMHandler.cc:599-621) is built.  revalidateReprojections (:239-243) runs as one
 // batched device validation per frame (video_sfm.hpp).
 #pragma once
 #include <cmath>
+#include <iomanip>
 #include <iostream>
 #include <limits>
 #include <stdexcept>
@@ -84,8 +85,8 @@ class CeresHandler {
                                      f.poses[0].data(), f.poses[1].data(), f_1.poses[0].data(), f_1.poses[1].data());
             problem.SetParameterLowerBound(&opt.ceres.interFrameRatio, 0, 0.0);
           }
-          // :175-177.  With the option left at 1 the reference optimises the ratio as a lower-bounded parameter;
-          // that case is not built — Solve reports it (summary.message) instead of silently fixing the ratio.
+          // :175-177.  With the option left at 1 the ratio stays a free, lower-bounded parameter block that Solve
+          // optimises (and writes back into opt.ceres.interFrameRatio), as in the reference.
           if (opt.ceres.interFrameRatio != 1) problem.SetParameterBlockConstant(&opt.ceres.interFrameRatio);
           if (frameKey - 1 < opt.ceres.fixFirstNCameras) {   // :179-184 the previous frame is one of the fixed cameras
             for (auto& pose : f_1.poses) problem.SetParameterBlockConstant(pose.data());
@@ -196,6 +197,8 @@ class CeresHandler {
     if (n > 0) options->num_linear_solver_threads = options->num_threads = (int)n;
     ceres::Solver::Summary summary;
     ceres::Solve(*options, &problem, &summary);
+    if (opt.ceres.constFrameVelocity != 0 || opt.ceres.constFrameAcceleration != 0)   // :421-423
+      std::cout << "interFrameRatio: " << std::setprecision(17) << opt.ceres.interFrameRatio << std::endl;
     return summary;
   }
 };

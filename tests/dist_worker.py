@@ -29,9 +29,11 @@ def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     full = scene()
-    if mode == "gpu_priors":   # motion priors are replicated terms: every rank lists them, rank 0 contributes them
+    if mode in ("gpu_priors", "gpu_free_ratio"):   # motion priors are replicated terms: every rank lists them, rank 0 contributes them
         full.prior_kind, full.prior_scale, full.inter_frame_ratio = 2, 25.0, 1.2
         full.prior_frames = np.arange(1, full.num_frames, dtype=np.int32)
+        if mode == "gpu_free_ratio":   # the free ratio's scalar LM state is replicated on every rank
+            full.prior_kind, full.inter_frame_ratio, full.ratio_free = 1, 1.0, True
     shard = full.shard(rank, world)
     out = {"rank": rank, "world": world, "n_full": full.num_observations, "n_shard": shard.num_observations}
     if mode == "cpu":
@@ -75,13 +77,13 @@ def main():
         s, tr = dp.solve(capi.default_options(**opts))
         dp.close()
         gather_points(shard)
-        out.update(final_cost=s.final_cost, initial_cost=s.initial_cost, iters=s.num_iterations, reduced=s.num_residual_blocks_reduced,
+        out.update(ratio=shard.inter_frame_ratio, final_cost=s.final_cost, initial_cost=s.initial_cost, iters=s.num_iterations, reduced=s.num_residual_blocks_reduced,
                    params=s.num_parameters_reduced, term=s.termination_type)
         if rank == 0:
             ref = full.copy()
             with capi.DeviceProblem(ref) as d1:
                 s1, tr1 = d1.solve(capi.default_options(**opts))
-            out.update(ref_final=s1.final_cost, ref_initial=s1.initial_cost, ref_iters=s1.num_iterations, ref_reduced=s1.num_residual_blocks_reduced,
+            out.update(ref_ratio=ref.inter_frame_ratio, ref_final=s1.final_cost, ref_initial=s1.initial_cost, ref_iters=s1.num_iterations, ref_reduced=s1.num_residual_blocks_reduced,
                        ref_params=s1.num_parameters_reduced, pose_err=float(np.abs(ref.poses - shard.poses).max()),
                        point_err=float(np.abs(ref.points - shard.points).max()),
                        traj_err=float(max(abs(a.cost - b.cost) / b.cost for a, b in zip(tr, tr1))))

@@ -36,7 +36,7 @@ def test_sharding_and_exchange_payloads_gloo(tmp_path, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["gpu", "gpu_priors"])
+@pytest.mark.parametrize("mode", ["gpu", "gpu_priors", "gpu_free_ratio"])
 def test_sharded_solve_equals_single_gpu_solve(tmp_path, mode):
     res = run_two_ranks(mode, tmp_path)
     a, b = res
@@ -46,3 +46,5 @@ def test_sharded_solve_equals_single_gpu_solve(tmp_path, mode):
     assert a["traj_err"] <= 1e-9
     assert abs(a["final_cost"] - a["ref_final"]) <= 1e-9 * a["ref_final"]
     assert a["pose_err"] <= 1e-7 and a["point_err"] <= 1e-6
+    assert a["ratio"] == b["ratio"] and abs(a["ratio"] - a["ref_ratio"]) <= 1e-8
+    assert (mode == "gpu_free_ratio") == (a["ratio"] not in (1.0, 1.2))
