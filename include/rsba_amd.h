@@ -195,9 +195,9 @@ int32_t rsba_pose_covariance(rsba_handle* h, int32_t frame, double* cov);
  * SURVEY §8f row f1): one 12-residual block per listed frame f >= 1 over (f.poses[0], f.poses[1], f-1.poses[0],
  * f-1.poses[1]) — RsConstVeloPrior (kind 1, video_bundler_rs_inter.h:55-108) or RsConstAccelerationPrior (kind 2,
  * :113-173) with weight `scale` (opt.ceres.constFrameVelocity / constFrameAcceleration), rotation rows down-scaled
- * by 0.01, under the problem's loss function (huber_a).  inter_frame_ratio is opt.ceres.interFrameRatio as a CONSTANT
- * block — the case the reference takes when the option is != 1 (CeresHandler.h:175-177); a free, lower-bounded ratio
- * (the option left at 1) needs bounded LM and is not built: RSBA_ERR_UNSUPPORTED is the caller's cue.
+ * by 0.01, under the problem's loss function (huber_a).  inter_frame_ratio is opt.ceres.interFrameRatio: a CONSTANT
+ * block — the case the reference takes when the option is != 1 (CeresHandler.h:175-177) — unless
+ * rsba_set_inter_frame_ratio_free (below) makes it the free, lower-bounded parameter of the reference's default.
  * The blocks count in cost, gradient, num_residual_blocks and the solve; their validity flag (ratio >= 0 resp.
  * >= DBL_EPSILON) fails the evaluation like any functor returning false.  Needs poses_per_frame == 2 and a calibrated
  * or shared-intrinsics problem.  frames strictly increasing; must precede the first solve / gradient call;

@@ -1,6 +1,7 @@
 """LM iteration wall time of one configuration with the DAG Cholesky and with the per-level schedule (same task
 bodies), and the difference of the two solves.  usage: python tools/lm_time.py [C4] [iters] [priors]
-("priors": constant-velocity motion priors between all consecutive frames, scale 10, interFrameRatio 0.8)"""
+("priors": constant-velocity motion priors between all consecutive frames, scale 10, interFrameRatio 0.8;
+ "free_ratio": the same with the ratio a free, lower-bounded parameter starting at 1)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -13,9 +14,11 @@ res = {}
 for mode in ("dag", "levels"):
     os.environ["RSBA_CHOL_LEVELS"] = "1" if mode == "levels" else "0"
     prob = make_config(name).problem
-    if len(sys.argv) > 3 and sys.argv[3] == "priors":
+    if len(sys.argv) > 3 and sys.argv[3] in ("priors", "free_ratio"):
         prob.prior_kind, prob.prior_scale, prob.inter_frame_ratio = 1, 10.0, 0.8
         prob.prior_frames = np.arange(1, prob.num_frames, dtype=np.int32)
+        if sys.argv[3] == "free_ratio":   # the reference's default: the ratio starts at 1 and is solved for
+            prob.inter_frame_ratio, prob.ratio_free = 1.0, True
     p0, x0 = prob.poses.copy(), prob.points.copy()
     with capi.DeviceProblem(prob) as dp:
         opt = capi.default_options(max_num_iterations=iters, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
@@ -27,7 +30,7 @@ for mode in ("dag", "levels"):
             dt = time.perf_counter() - t0
         n = max(summ.num_iterations, 1)
         print(f"{name} {mode}: {summ.num_iterations} iterations, {1e3 * dt / n:.3f} ms/iteration (wall {dt * 1e3:.1f} ms), "
-              f"cost {summ.initial_cost:.6e} -> {summ.final_cost:.9e}", flush=True)
+              f"cost {summ.initial_cost:.6e} -> {summ.final_cost:.9e}" + (f", interFrameRatio {prob.inter_frame_ratio:.9f}" if prob.prior_kind else ""), flush=True)
         res[mode] = (summ.final_cost, prob.poses.copy(), prob.points.copy())
 print("final cost rel diff", abs(res["dag"][0] - res["levels"][0]) / res["levels"][0],
       "max pose diff", np.abs(res["dag"][1] - res["levels"][1]).max(), "max point diff", np.abs(res["dag"][2] - res["levels"][2]).max())
