@@ -91,6 +91,16 @@ def next_rows(prob, dp, device):
             s, _ = dq.solve(opt)
         out["f1_lm_with_motion_priors"] = {"ms_per_lm_iteration": s.total_time_s / max(1, s.num_iterations - 1) * 1e3, "prior_blocks": int(q.num_frames - 1),
                                            "initial_cost": s.initial_cost, "final_cost": s.final_cost}
+        q.poses[:], q.points[:] = p0, x0
+        q.inter_frame_ratio, q.ratio_free = 1.0, True            # the reference's default: the ratio is solved for
+        with capi.DeviceProblem(q, device=device) as dq:
+            s1, _ = dq.solve(opt)
+            first_ratio = q.inter_frame_ratio
+            q.poses[:], q.points[:] = p0, x0
+            dq.upload_parameters()
+            s, _ = dq.solve(opt)                                  # steady state (the ratio continues from its solved value)
+        out["f1_lm_with_free_inter_frame_ratio"] = {"ms_per_lm_iteration": s.total_time_s / max(1, s.num_iterations - 1) * 1e3, "solved_ratio": first_ratio,
+                                                    "final_cost": s1.final_cost}
     except Exception as e:  # noqa: BLE001
         out["f1_lm_with_motion_priors"] = {"error": repr(e)}
     try:   # f3: RS-PnP RANSAC hypotheses; the scene's observations come from the device's own reproject (f2)
