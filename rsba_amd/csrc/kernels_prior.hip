@@ -1,8 +1,9 @@
 // Frame-to-frame motion priors: RsConstVeloPrior / RsConstAccelerationPrior
 // (/root/reference/src/rsba/video_bundler_rs_inter.h:55-108, :113-173) as CeresHandler::Add creates them
-// (CeresHandler.h:147-185), for the case the reference takes when opt.ceres.interFrameRatio != 1: the ratio block is
-// constant (:175-177), so a prior is a 12-residual block over the four pose blocks of frames f and f-1 that is LINEAR
-// in them.  Per pose coordinate i the two residuals
+// (CeresHandler.h:147-185).  With the ratio block constant (opt.ceres.interFrameRatio != 1, :175-177) a prior is a
+// 12-residual block over the four pose blocks of frames f and f-1 that is LINEAR in them; with the ratio free (the
+// reference's default) the same blocks are linearised at the current ratio and the ratio's own column is formed by
+// prior_border_kernel (solver.hip serves it as a 1-wide border of S).  Per pose coordinate i the two residuals
 //     r[i]     = s_i * (Ca . x_i),     r[6 + i] = s_i * (Cb . x_i),     x_i = (f.p0[i], f.p1[i], (f-1).p0[i], (f-1).p1[i])
 // touch only that coordinate of the four poses (s_i = scale * 0.01 for the rotation rows, scale otherwise), so a
 // prior adds 2 x 2 blocks per coordinate to U_f, U_{f-1} and to the (f, f-1) block of the reduced camera system —
