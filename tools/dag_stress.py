@@ -18,6 +18,7 @@ while time.time() < t_end:
     seed = int(rng.integers(0, 1 << 30))
     tl = int(rng.integers(6, 30))
     prior = int(rng.integers(0, 3)) if rolling and rng.integers(0, 3) == 0 else 0   # motion priors on a third of the rolling scenes
+    free = bool(prior and rng.integers(0, 2))                                       # half of those with the free interFrameRatio
 
     def solve(mode):
         os.environ["RSBA_CHOL_LEVELS"] = mode
@@ -29,9 +30,11 @@ while time.time() < t_end:
         if prior:
             p.prior_kind, p.prior_scale, p.inter_frame_ratio = prior, 10.0, 0.8
             p.prior_frames = np.arange(1, frames, dtype=np.int32)
+            if free:
+                p.inter_frame_ratio, p.ratio_free = 1.0, True
         with capi.DeviceProblem(p) as dp:
             s, _ = dp.solve(capi.default_options(max_num_iterations=5))
-        return (s.final_cost, p.poses.copy(), p.points.copy(), p.intrinsics.copy())
+        return (s.final_cost, p.poses.copy(), p.points.copy(), p.intrinsics.copy(), np.array([p.inter_frame_ratio]))
 
     def same(a, b):
         return a[0] == b[0] and all(np.array_equal(x, y) for x, y in zip(a[1:], b[1:]))
@@ -42,7 +45,7 @@ while time.time() < t_end:
         bad += 1
         # which side moved?  solve each driver twice more
         again = {m: [solve(m), solve(m)] for m in ("0", "1")}
-        print(f"MISMATCH frames={frames} points={points} rolling={rolling} shared={shared} huber={huber} seed={seed} track_len={tl} prior={prior}: "
+        print(f"MISMATCH frames={frames} points={points} rolling={rolling} shared={shared} huber={huber} seed={seed} track_len={tl} prior={prior} free={free}: "
               f"dag {res[0][0]!r} levels {res[1][0]!r}; max pose diff {np.abs(res[0][1] - res[1][1]).max():.3e}; "
               f"dag repeats equal first dag run: {[same(res[0], r) for r in again['0']]}, equal levels: {[same(res[1], r) for r in again['0']]}; "
               f"levels repeats equal first levels run: {[same(res[1], r) for r in again['1']]}", flush=True)
