@@ -1,14 +1,18 @@
 #!/usr/bin/env python3
-"""Headline benchmark: residual+Jacobian evaluations per second on the 1k-camera / 100k-point
-rolling-shutter scene (BASELINE.json metric, config C4), one process per GPU.
+"""Headline benchmark: residual+Jacobian evaluations per second and LM-iteration wall time on the 1k-camera /
+100k-point rolling-shutter scene (BASELINE.json metric, config C4; --config C5 = the 4k-camera Huber + shared
+intrinsics scene), one process per GPU.
 
-A step = one pass of the hot path over this rank's observations: the fused residual + analytic
-Jacobian kernel (results materialised in HBM, as ceres' CostFunction::Evaluate materialises them),
-inputs resident in HBM before the timed region.  With N > 1 the scene is point-partitioned: every rank
-holds the same 1k cameras and its own 100k points / ~2M observations (weak scaling); the evaluation
-needs no collective.  LM-iteration wall-time (the metric's second half) is reported under "lm"; at N = 1 the rows next
-to the path (validation filter, LM with motion priors, RS-PnP hypotheses) add bounded wall-clock figures under
-"next_rows" (about a second; --no-next-rows skips them).
+A step = one pass of the hot path over the scene's observations: the fused residual + analytic Jacobian kernel
+(results materialised in HBM, as ceres' CostFunction::Evaluate materialises them), inputs resident in HBM before the
+timed region.  With N > 1 the SAME scene is sharded by point (BAProblem.shard: cameras replicated, every observation
+of a point on one rank): strong scaling, `value` = the scene's observations / the slowest rank's time.  The evaluation
+needs no collective; the LM iteration (the metric's second half, reported under "lm") all-reduces the per-camera
+blocks and the packed reduced camera system over RCCL, called by the library itself on its stream
+(rsba_set_exchange_rccl).  "roofline" prices the evaluation kernel against HBM, "roofline_lm" every phase of an LM
+iteration (HIP events recorded by the solver, rsba_get_phase_times).  At N = 1 the CPU oracle is timed beside it
+("cpu_baseline": evaluation at 1 and at the best of all / half / quarter of the host's threads, and its LM iteration) and
+the rows next to the path add bounded wall-clock figures under "next_rows".
 
     python bench.py --gpus 1 --steps 50 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -16,25 +20,44 @@ to the path (validation filter, LM with motion priors, RS-PnP hypot
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured float4 copy)
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured float4 copy)
+MFMA_F64_PEAK_TFLOPS = 78.6  # v_mfma_f64_16x16x4_f64: 64 cycles per 2048 flop (tools/mfma_f64_check.hip) x 4 SIMDs x 256 CUs x 2.4 GHz
 
 
 def algorithmic_bytes(prob) -> float:
-    """N*(16 obs + 8 idx + 16 r + 16 K) + F*P*48 + M*24 + 72."""
+    """N*(16 obs + 8 idx + 16 r + 16 K) + F*P*48 + M*24 + 72 (M = the points the observations refer to)."""
+    import numpy as np
     n, k = prob.num_observations, prob.jacobian_cols
-    return n * (16 + 8 + 16 + 16 * k) + prob.num_frames * prob.poses_per_frame * 48 + prob.num_points * 24 + 72
+    m = len(np.unique(prob.obs_point)) if n else 0
+    return n * (16 + 8 + 16 + 16 * k) + prob.num_frames * prob.poses_per_frame * 48 + m * 24 + 72
 
 
-def cpu_baseline(prob, budget_s: float = 12.0):
+def host_cpu():
+    """CPU model / sockets / physical cores / threads of the box, from lscpu (north_star: core count stated)."""
+    info = {"threads": os.cpu_count()}
+    try:
+        txt = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        kv = {l.split(":", 1)[0].strip(): l.split(":", 1)[1].strip() for l in txt.splitlines() if ":" in l}
+        info["model"] = kv.get("Model name")
+        info["sockets"] = int(kv.get("Socket(s)", "0") or 0)
+        info["physical_cores"] = info["sockets"] * int(kv.get("Core(s) per socket", "0") or 0)
+    except Exception as e:  # noqa: BLE001
+        info["error"] = repr(e)
+    return info
+
+
+def cpu_baseline(prob, budget_s: float = 8.0, lm_iters: int = 3):
     """Oracle timed the way Ceres runs rsba's functors (checker, never the product path).  Ceres would use
     hardware_concurrency() threads (CeresHandler.h:408-415); on a 2-socket host fewer threads can be
-    faster for this memory-light loop, so a short calibration picks the best of {all, half, quarter}."""
+    faster for this memory-light loop, so a short calibration picks the best of {all, half, quarter}.  Also one thread,
+    and the oracle's LM iteration (Schur complement in envelope storage + Cholesky) on the same scene."""
     from oracle import oracle as O
     ncpu = os.cpu_count() or 1
     best = None
@@ -52,10 +75,72 @@ def cpu_baseline(prob, budget_s: float = 12.0):
     for _ in range(reps):
         ev.run()
     dt = (time.perf_counter() - t0) / reps
-    return {"value": prob.num_observations / dt, "unit": "obs evals/s", "cores": threads, "kind": "port",
-            "sample": f"{reps} x full residual+Jacobian evaluation of the {prob.num_observations}-observation scene, "
-                      f"Dual<{prob.jacobian_cols}> autodiff, one cost object per observation, OpenMP {threads} threads",
-            "ms_per_eval": dt * 1e3}
+    ev1 = O.CeresStyleEvaluator(prob, 1)
+    ev1.run()
+    t0 = time.perf_counter(); ev1.run(); dt1 = time.perf_counter() - t0
+    out = {"value": prob.num_observations / dt, "unit": "obs evals/s", "cores": threads, "kind": "port",
+           "sample": f"{reps} x full residual+Jacobian evaluation of the {prob.num_observations}-observation scene, "
+                     f"Dual<{prob.jacobian_cols}> autodiff, one cost object per observation, OpenMP {threads} threads",
+           "ms_per_eval": dt * 1e3, "threads_1": {"value": prob.num_observations / dt1, "ms_per_eval": dt1 * 1e3},
+           "host": host_cpu()}
+    try:   # the LM iteration of the same CPU path, bounded: lm_iters iterations of the whole scene
+        O.lib().orc_set_num_threads(min(ncpu, 64))
+        q = prob.copy()
+        t0 = time.perf_counter()
+        s, tr = O.solve(q, O.default_options(max_num_iterations=lm_iters, function_tolerance=0.0, parameter_tolerance=0.0, gradient_tolerance=0.0))
+        wall = time.perf_counter() - t0
+        out["lm"] = {"ms_per_lm_iteration": wall / max(1, s.num_iterations - 1) * 1e3, "iterations": s.num_iterations - 1, "threads": min(ncpu, 64),
+                     "initial_cost": s.initial_cost, "cost_after": [t.cost for t in tr],
+                     "sample": f"{lm_iters} LM iterations of the same scene: Dual<{prob.jacobian_cols}> Jacobian, Schur complement (envelope storage), "
+                               "Cholesky, back-substitution — the Ceres-1.9 rules restated (oracle/rsba_oracle.cpp)"}
+    except Exception as e:  # noqa: BLE001
+        out["lm"] = {"error": repr(e)}
+    return out
+
+
+def roofline_lm(prob, dp, iters, capi):
+    """Per-phase device time of the LM iteration (HIP events on the solver's stream) against the bound of each phase.
+    Bytes / flops are ALGORITHMIC: what the phase must move or compute, not what it happened to."""
+    saved = (prob.poses.copy(), prob.points.copy(), prob.intrinsics.copy())
+    s, _ = dp.solve(capi.default_options(max_num_iterations=iters, function_tolerance=0.0, parameter_tolerance=0.0, gradient_tolerance=0.0, profile_phases=1))
+    prob.poses[:], prob.points[:], prob.intrinsics[:] = saved
+    dp.upload_parameters()
+    times, st = dp.phase_times(), dp.plan_stats()
+    n, k, m = prob.num_observations, prob.jacobian_cols, prob.num_points
+    cd = 6 * prob.poses_per_frame
+    rec = 8 * (2 + 2 * k)                       # the point-major record of one observation
+    prec = 8 * cd * 3                           # its P record
+    work = {   # phase -> (bound, algorithmic bytes or flops per call)
+        "eval_lm": ("hbm", n * (24 + rec + 32) + prob.num_frames * prob.poses_per_frame * 48 + m * 24),
+        "point_blocks": ("hbm", n * 64 + m * 72),
+        "project": ("hbm", n * (rec + prec)),
+        "schur": ("mfma", st["schur_entries"] * 6.75 * 2048),
+        "cholesky": ("mfma", st["cholesky_flops"]),
+        "back_substitute": ("hbm", n * rec + m * 48),
+        "eval_trial": ("hbm", n * 24 + prob.num_frames * prob.poses_per_frame * 48 + m * 24),
+    }
+    rows = []
+    for name, (ms, calls) in times.items():
+        if calls == 0:
+            continue
+        row = {"phase": name, "ms_per_call": ms / calls, "calls": calls, "ms_per_lm_iteration": ms / max(1, s.num_iterations - 1)}
+        if name in work:
+            bound, amount = work[name]
+            per_s = amount / (ms / calls * 1e-3)
+            if bound == "hbm":
+                row.update(bound="hbm", algorithmic_bytes=amount, achieved=per_s / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=per_s / 1e9 / HBM_PEAK_GBS)
+            else:
+                row.update(bound="mfma", algorithmic_flops=amount, achieved=per_s / 1e12, peak=MFMA_F64_PEAK_TFLOPS, unit="TFLOP/s",
+                           frac=per_s / 1e12 / MFMA_F64_PEAK_TFLOPS)
+        rows.append(row)
+    notes = {"schur": "issued fp64 MFMA flops (6.75 MFMAs per entry); structurally non-zero block products: "
+                      f"{st['schur_block_products']} x {2 * cd * cd * 3} flop = {st['schur_block_products'] * 2 * cd * cd * 3 / 1e9:.2f} Gflop useful",
+             "cholesky": f"latency-bound dependency chain: {st['levels']} elimination levels, {st['tasks']} tile tasks, {st['factor_tiles']} factor tiles",
+             "eval_trial": "residual only: bound by the fp64 projection math, not by HBM"}
+    for r in rows:
+        if r["phase"] in notes:
+            r["note"] = notes[r["phase"]]
+    return {"phases": rows, "plan": st, "sum_ms_per_lm_iteration": sum(r["ms_per_lm_iteration"] for r in rows)}
 
 
 def next_rows(prob, dp, device):
@@ -132,7 +217,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="C4")
+    ap.add_argument("--config", default="C4", choices=["C2", "C4", "C5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lm", action="store_true")
     ap.add_argument("--lm-iters", type=int, default=12)
@@ -145,8 +230,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    # test hook (one-GPU boxes): RSBA_BENCH_TEST_ONE_GPU=1 runs every rank on device 0 over gloo, which exercises the
-    # whole multi-rank flow of this script (sharded scenes, exchange callback, watchdog) without several GPUs
+    # test hook (one-GPU boxes): RSBA_BENCH_TEST_ONE_GPU=1 runs every rank on device 0 over gloo with the callback exchange
+    # (RCCL refuses two ranks on one device), which exercises the whole multi-rank flow of this script without several GPUs
     one_gpu = os.environ.get("RSBA_BENCH_TEST_ONE_GPU") == "1"
     if one_gpu:
         local_rank = 0
@@ -160,17 +245,17 @@ def main():
     from rsba_amd import capi
     from rsba_amd.scene import SEED, make_config
 
-    sc = make_config(args.config, seed=SEED + rank)      # same cameras on every rank, its own points
-    prob = sc.problem
-    if world > 1:
-        # cameras are replicated: every rank starts from rank 0's (perturbed) poses
-        t = torch.from_numpy(prob.poses).to("cpu" if one_gpu else "cuda")
-        dist.broadcast(t, src=0)
-        prob.poses[:] = t.cpu().numpy()
+    full = make_config(args.config, seed=SEED).problem       # the same scene on every rank
+    prob = full.shard(rank, world) if world > 1 else full     # this rank's observations: by point, cameras replicated
     dp = capi.DeviceProblem(prob, device=local_rank)
+    comm = None
+    transport = "none (single GPU)"
     if world > 1 and not args.no_lm:
-        from rsba_amd.distributed import attach
-        attach(dp)                                        # RCCL all-reduce exchange for the LM iterations
+        from rsba_amd.distributed import attach, attach_rccl
+        if one_gpu:
+            attach(dp); transport = "callback: torch.distributed gloo staged through the host (test hook)"
+        else:
+            comm = attach_rccl(dp, local_rank); transport = "native: ncclAllReduce (RCCL over xGMI) issued by librsba_amd on its stream"
 
     def barrier():
         if world > 1:
@@ -190,13 +275,14 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     cdev = "cpu" if one_gpu else "cuda"
-    n_obs = torch.tensor([float(prob.num_observations)], device=cdev)
+    n_obs = torch.tensor([float(prob.num_observations)], device=cdev, dtype=torch.float64)
     t_max = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(n_obs, op=dist.ReduceOp.SUM)
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
     elapsed = float(t_max.item())
     total_obs = float(n_obs.item())
+    assert int(total_obs) == full.num_observations, (total_obs, full.num_observations)
 
     # dominant kernel, HIP events on the stream it is launched on (rank 0's shard)
     kernel_ms = dp.time_evaluate(True, warmup=50, iters=max(50, args.steps))
@@ -205,14 +291,17 @@ def main():
     # HBM traffic of the same kernel on the same workload from the committed PMC passes (separate
     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this command; tools/profile_round.sh)
     traffic, traffic_src = None, None
-    if args.config == "C4":
+    if world == 1:
+        key = "hbm_bytes_per_launch" if args.config == "C4" else f"hbm_bytes_per_launch_{args.config}"
         prof = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if os.path.exists(os.path.join(ROOT, "profiles", p, "pmc_summary.json")))
-        if prof:
-            with open(os.path.join(ROOT, "profiles", prof[-1], "pmc_summary.json")) as fh:
+        for pr in reversed(prof):
+            with open(os.path.join(ROOT, "profiles", pr, "pmc_summary.json")) as fh:
                 pm = json.load(fh)
-            traffic, traffic_src = pm.get("hbm_bytes_per_launch"), f"profiles/{prof[-1]}/pmc_summary.json (2*FETCH_SIZE + WRITE_SIZE, calibrated)"
+            if pm.get(key):
+                traffic, traffic_src = pm[key], f"profiles/{pr}/pmc_summary.json (2*FETCH_SIZE + WRITE_SIZE, calibrated)"
+                break
 
-    lm = None
+    lm, lm_roof = None, None
     lm_hung = False
     if not args.no_lm:
         # The LM solve is the one part of this script with a collective on the data path (three all-reduces per
@@ -225,29 +314,38 @@ def main():
                 torch.cuda.set_device(local_rank)          # the current device is per thread
                 from rsba_amd.distributed import solve_timed
                 box["lm"] = solve_timed(dp, prob, world, args.lm_iters)
+                box["roof"] = roofline_lm(prob, dp, args.lm_iters, capi)
             except Exception as e:  # noqa: BLE001 - reported in the JSON line
-                box["lm"] = {"error": repr(e)}
+                box.setdefault("lm", {"error": repr(e)})
+                box.setdefault("roof", {"error": repr(e)})
 
         th = threading.Thread(target=run_lm, daemon=True)
         th.start()
         th.join(timeout=float(os.environ.get("RSBA_BENCH_LM_TIMEOUT_S", "180")))
         lm_hung = th.is_alive()
         lm = {"error": "LM solve did not finish inside the watchdog window"} if lm_hung else box.get("lm")
+        lm_roof = None if lm_hung else box.get("roof")
+        if isinstance(lm, dict) and "error" not in lm:
+            lm["exchange"] = transport
+            lm["observations_total"] = int(total_obs)
 
     out = None
     if rank == 0:
+        kname = "rsba::eval_kernel<%s,%d,1>" % ("true" if prob.calibrated else "false", prob.poses_per_frame)
         out = {
             "metric": "residual+Jacobian evals/sec", "value": total_obs * args.steps / elapsed, "unit": "obs evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "untimed_clock_ramp_steps": 200, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.config}: rolling-shutter scene, {prob.num_frames} frames x {prob.poses_per_frame} poses, "
-                                   f"{prob.num_points} points, {prob.num_observations} observations per GPU, HORIZONTAL shutter, calibrated",
-                       "observations_total": int(total_obs), "jacobian_cols": prob.jacobian_cols,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.config}: rolling-shutter scene, {full.num_frames} frames x {full.poses_per_frame} poses, "
+                                   f"{full.num_points} points, {full.num_observations} observations, HORIZONTAL shutter, "
+                                   + ("calibrated" if full.calibrated else f"shared intrinsics as a parameter block, Huber({full.huber_a:g})"),
+                       "observations_total": int(total_obs), "observations_this_rank": int(prob.num_observations), "jacobian_cols": prob.jacobian_cols,
                        "partition": "by point, cameras replicated" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "rsba::eval_kernel<true,2,1>", "kernel_ms": kernel_ms,
-                         "algorithmic_bytes_per_launch": abytes, "bytes_per_observation": abytes / prob.num_observations},
-            "lm": lm,
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel": kname, "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_launch": abytes, "bytes_per_observation": abytes / max(1, prob.num_observations),
+                         "rank": 0},
+            "lm": lm, "roofline_lm": lm_roof,
         }
         if not args.no_next_rows and world == 1 and not lm_hung and args.config == "C4":
             out["next_rows"] = next_rows(prob, dp, local_rank)
@@ -258,6 +356,8 @@ def main():
             print(json.dumps(out), flush=True)
         os._exit(0)
     dp.close()
+    if comm is not None:
+        capi.rccl_comm_destroy(comm)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -57,7 +57,7 @@ static int replay_cache(int argc, char** argv) {
 
 int main(int argc, char** argv) {
   if (argc >= 4 && !std::strcmp(argv[1], "--cache")) return replay_cache(argc, argv);
-  if (argc < 3) { std::fprintf(stderr, "usage: %s scene.bin out.bin\n", argv[0]); return 2; }
+  if (argc < 3) { std::fprintf(stderr, "usage: %s scene.bin out.bin [startFrame]\n", argv[0]); return 2; }
   FILE* f = std::fopen(argv[1], "rb");
   if (!f) { std::perror("scene"); return 2; }
   int32_t hd[11]; int64_t N; double huber, reval, covf, motion[3], cam[9];
@@ -92,7 +92,8 @@ int main(int argc, char** argv) {
 
   ceres::Solver::Summary summary;
   std::vector<std::vector<double>> covs;
-  const bool usable = BA(sess, 0, F - 1, opt, hd[10], &summary, true, &covs);
+  const int startFrame = argc > 3 ? std::atoi(argv[3]) : 0;            // windowed BA (VideoSfMClient.cc:243): frames [startFrame, F - 1]
+  const bool usable = BA(sess, startFrame, F - 1, opt, hd[10], &summary, true, &covs);
 
   return write_result(argv[2], sess, summary, usable, covs, covf);
 }

@@ -25,6 +25,7 @@
 #include <memory>
 #include <set>
 #include <sstream>
+#include <stdexcept>
 #include <string>
 #include <utility>
 #include <vector>
@@ -175,7 +176,10 @@ class MotionPriorCost : public CostFunction {
   }
   int kind() const { return kind_; }       // 1 RsConstVeloPrior, 2 RsConstAccelerationPrior
   double scale() const { return scale_; }
-  bool Evaluate(double const* const*, double*, double**) const override { return false; }
+  // not provided stand-alone (a `false` here would read as "the functor failed"): prior blocks are evaluated inside a Problem
+  bool Evaluate(double const* const*, double*, double**) const override {
+    throw std::logic_error("rsba_amd: MotionPriorCost::Evaluate is not provided stand-alone; add the block to a ceres::Problem (Problem::Evaluate / Solve)");
+  }
  private:
   int kind_; double scale_;
 };
@@ -388,6 +392,7 @@ class Problem {
       f->obs_frame.push_back(fi); f->obs_point.push_back(pi);
     }
     // motion priors (CeresHandler.h:147-185): blocks (ratio, f.p0, f.p1, f-1.p0, f-1.p1) between consecutive frames
+    std::vector<int> prior_prev;
     for (const Block& b : blocks_) {
       const MotionPriorCost* c = dynamic_cast<const MotionPriorCost*>(b.cost);
       if (!c) continue;
@@ -403,16 +408,60 @@ class Problem {
       }
       if (!f->prior_frames.empty() && (f->ratio_ptr != b.x[0] || f->ratio_free != ratio_free)) return fail("motion priors of one problem must share the interFrameRatio block");
       f->ratio_ptr = b.x[0]; f->ratio_free = ratio_free;
-      auto cur = frame_of.find(std::make_pair(b.x[1], b.x[2])), prev = frame_of.find(std::make_pair(b.x[3], b.x[4]));
-      if (cur == frame_of.end() || prev == frame_of.end()) return fail("motion prior on a frame without observations");
-      if (prev->second != cur->second - 1) return fail("motion priors must link consecutive frames");
+      // A pose pair that no reprojection block uses is a frame of its own, without observations: the frame before the
+      // window of a windowed BA (CeresHandler::Add(startFrame) links startFrame to startFrame - 1, VideoSfMHandler.cc:779),
+      // or a frame whose observations were all rejected.  Ceres optimises such a prior-only block; so does the device path.
+      auto frame_index = [&](double* p0, double* p1) {
+        const auto key = std::make_pair(p0, p1);
+        auto it = frame_of.find(key);
+        if (it != frame_of.end()) return it->second;
+        const int fi = (int)f->frame_intr.size(); frame_of[key] = fi; f->frame_intr.push_back(0);
+        f->pose_ptr.push_back(p0); f->poses.insert(f->poses.end(), p0, p0 + 6); f->slot_of[p0] = Slot{0, fi * P};
+        f->pose_ptr.push_back(p1); f->poses.insert(f->poses.end(), p1, p1 + 6); f->slot_of[p1] = Slot{0, fi * P + 1};
+        return fi;
+      };
+      const int prev = frame_index(b.x[3], b.x[4]), cur = frame_index(b.x[1], b.x[2]);
+      if (prev == cur) return fail("a motion prior links a frame with itself");
       if (f->prior_frames.empty()) { f->prior_kind = c->kind(); f->prior_scale = c->scale(); f->prior_ratio = *b.x[0]; }
       else if (f->prior_kind != c->kind() || f->prior_scale != c->scale() || f->prior_ratio != *b.x[0]) return fail("motion priors of one problem must share kind, scale and ratio");
-      f->prior_frames.push_back(cur->second);
+      f->prior_frames.push_back(cur); prior_prev.push_back(prev);
       f->slot_of[b.x[0]] = Slot{3, 0};
     }
+    if (!f->prior_frames.empty()) {
+      // The device path lists a prior by its frame f and links it to frame f - 1: number the frames so that every chain of
+      // priors runs through consecutive indices (the identity when frames were added in order, as CeresHandler does).
+      const int nf = (int)f->frame_intr.size();
+      std::vector<int> next_of(nf, -1), prev_of(nf, -1);
+      for (size_t k = 0; k < f->prior_frames.size(); ++k) {
+        const int cur = f->prior_frames[k], prev = prior_prev[k];
+        if (prev_of[cur] != -1) return fail("two motion priors on one frame");
+        if (next_of[prev] != -1) return fail("two motion priors refer back to the same frame");
+        prev_of[cur] = prev; next_of[prev] = cur;
+      }
+      std::vector<int> order; order.reserve(nf);
+      for (int fi = 0; fi < nf; ++fi) if (prev_of[fi] == -1) for (int x = fi; x != -1; x = next_of[x]) order.push_back(x);
+      if ((int)order.size() != nf) return fail("motion priors form a cycle");
+      std::vector<int> new_of(nf);
+      for (int k = 0; k < nf; ++k) new_of[order[k]] = k;
+      bool identity = true;
+      for (int k = 0; k < nf; ++k) identity = identity && order[k] == k;
+      if (!identity) {
+        std::vector<int32_t> fi2(nf); std::vector<double*> pp2(f->pose_ptr.size()); std::vector<double> po2(f->poses.size());
+        for (int k = 0; k < nf; ++k) {
+          const int o = order[k];
+          fi2[k] = f->frame_intr[o];
+          for (int q = 0; q < P; ++q) {
+            pp2[(size_t)k * P + q] = f->pose_ptr[(size_t)o * P + q];
+            std::memcpy(&po2[((size_t)k * P + q) * 6], &f->poses[((size_t)o * P + q) * 6], 6 * sizeof(double));
+            f->slot_of[pp2[(size_t)k * P + q]] = Slot{0, k * P + q};
+          }
+        }
+        f->frame_intr.swap(fi2); f->pose_ptr.swap(pp2); f->poses.swap(po2);
+        for (int32_t& x : f->obs_frame) x = new_of[x];
+        for (int32_t& x : f->prior_frames) x = new_of[x];
+      }
+    }
     std::sort(f->prior_frames.begin(), f->prior_frames.end());
-    if (std::adjacent_find(f->prior_frames.begin(), f->prior_frames.end()) != f->prior_frames.end()) return fail("two motion priors on one frame");
     const int nscalar = f->prior_frames.empty() ? 0 : 1;
     // a pose pointer may not serve as pose0 of one frame and pose1 of another
     if ((int)f->slot_of.size() - nscalar != (int)f->pose_ptr.size() + (int)f->point_ptr.size() + (with_cam ? (int)f->intr_ptr.size() : 0))

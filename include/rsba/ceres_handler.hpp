@@ -198,7 +198,7 @@ class CeresHandler {
     ceres::Solver::Summary summary;
     ceres::Solve(*options, &problem, &summary);
     if (opt.ceres.constFrameVelocity != 0 || opt.ceres.constFrameAcceleration != 0)   // :421-423
-      std::cout << "interFrameRatio: " << std::setprecision(17) << opt.ceres.interFrameRatio << std::endl;
+      std::cout << "interFrameRatio: " << opt.ceres.interFrameRatio << std::endl;
     return summary;
   }
 };

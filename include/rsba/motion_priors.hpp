@@ -3,8 +3,8 @@
 //   vision::RsConstVeloPrior            /root/reference/src/rsba/video_bundler_rs_inter.h:55-108
 //   vision::RsConstAccelerationPrior    /root/reference/src/rsba/video_bundler_rs_inter.h:113-173
 // Parameter blocks, in the reference's order: interFrameRatio[1], current frame first pose, current frame last pose,
-// previous frame first pose, previous frame last pose.  The ratio block must be constant in the problem
-// (CeresHandler.h:175-177, the case opt.ceres.interFrameRatio != 1).
+// previous frame first pose, previous frame last pose.  The ratio block is either constant in the problem
+// (CeresHandler.h:175-177, the case opt.ceres.interFrameRatio != 1) or free with the lower bound of :161 / :172 (the default).
 #pragma once
 #include "ceres_facade.hpp"
 

@@ -78,7 +78,7 @@ struct SfmOptions {
     bool fixPosition = false;
     double constFrameVelocity = 0;
     double constFrameAcceleration = 0;
-    double interFrameRatio = 1;       // SfmOptions.h:75; 1 = free (lower-bounded) parameter in the reference: not built here
+    double interFrameRatio = 1;       // SfmOptions.h:75; 1 = a free, lower-bounded parameter block that Solve optimises (CeresHandler.h:161,172,175)
     double trustPriorCamPosition = 0;
     double trustPriorCamRotation = 0;
     bool revalidateReprojections = false;

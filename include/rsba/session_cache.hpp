@@ -90,9 +90,15 @@ struct Reader {
     }
   }
   // list header: returns the count, checks the element type
+  // A count is only believed as far as the bytes that are left can hold that many elements (a corrupt file must not
+  // make the caller allocate gigabytes before the first element read throws).
+  static size_t min_wire_size(uint8_t t) {
+    switch (t) { case T_I16: return 2; case T_I32: case T_STRING: return 4; case T_I64: case T_DOUBLE: return 8; case T_LIST: case T_SET: return 5; case T_MAP: return 6; default: return 1; }
+  }
   int32_t list(uint8_t want) {
     const uint8_t et = u8(); const int32_t n = i32();
     if (n < 0 || (n > 0 && et != want)) throw std::runtime_error("unexpected list element type");
+    if ((size_t)n > (b.size() - p) / min_wire_size(et)) throw std::runtime_error("truncated Thrift stream (list count exceeds the remaining bytes)");
     return n;
   }
   std::vector<double> doubles() { const int32_t n = list(T_DOUBLE); std::vector<double> v((size_t)n); for (auto& x : v) x = f64(); return v; }
@@ -209,12 +215,27 @@ inline void write(Writer& w, const Session& s) {
 
 }  // namespace cache_detail
 
+namespace cache_detail {
+// indices a loaded Session carries are used unchecked by CeresHandler::Add (sess.frames[ref.frame].obs[ref.obs],
+// sess.getTrack(o.track)): refuse a file whose references point outside what it holds
+inline void check_indices(const Frame&) {}
+inline void check_indices(const Session& s) {
+  auto ref_ok = [&](const ObservationRef& r) { return r.frame >= 0 && (size_t)r.frame < s.frames.size() && r.obs >= 0 && (size_t)r.obs < s.frames[(size_t)r.frame].obs.size(); };
+  for (const Frame& f : s.frames) for (const Observation& o : f.obs) {
+    if (o.__isset.track && (o.track < 0 || (size_t)o.track >= s.tracks.size())) throw std::runtime_error("Session cache: observation refers to a track that does not exist");
+    for (const ObservationRef& r : o.matches) if (!ref_ok(r)) throw std::runtime_error("Session cache: match refers to an observation that does not exist");
+  }
+  for (const Track& t : s.tracks) for (const ObservationRef& r : t.obs) if (!ref_ok(r)) throw std::runtime_error("Session cache: track refers to an observation that does not exist");
+}
+}  // namespace cache_detail
+
 // VideoSfMCache::unserialize(T&) for T = Session / Frame.  Throws std::runtime_error on unreadable input.
 template <class T>
 inline void loadCache(const std::string& path, T& obj) {
   const std::vector<uint8_t> bytes = cache_detail::read_events(path);
   cache_detail::Reader r(bytes);
   cache_detail::read(r, obj);
+  cache_detail::check_indices(obj);
 }
 // VideoSfMCache::save(const T&): the same event / protocol layout the reference's serialize() produces
 template <class T>

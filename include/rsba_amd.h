@@ -83,7 +83,8 @@ typedef struct rsba_solver_options {
   int32_t level_scheduled_cholesky;         /* 0.  1 = factor the reduced camera system with one launch per elimination
                                              * level instead of the persistent task-DAG kernel (same arithmetic, same results,
                                              * no communication between workgroups inside a launch; slower) */
-  int32_t reserved;
+  int32_t profile_phases;                   /* 0.  1 = time the phases of every LM iteration with HIP events on the solver's
+                                             * stream; read with rsba_get_phase_times after the solve */
 } rsba_solver_options;
 
 enum { RSBA_CONVERGENCE = 0, RSBA_NO_CONVERGENCE = 1, RSBA_FAILURE = 2 };   /* ceres::TerminationType subset */
@@ -172,6 +173,37 @@ void rsba_default_solver_options(rsba_solver_options* opt);
 int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rsba_solver_summary* summary,
                    rsba_iteration* trace, int32_t trace_capacity);
 
+/* Measurement aids: where an LM iteration spends its device time, and the sizes of the symbolic plan the
+ * kernels' algorithmic bytes / flops follow from.  Phase p covers the launches listed; ms[p] is the HIP-event time summed
+ * over the last rsba_solve that ran with options.profile_phases != 0, calls[p] how many times the phase ran. */
+enum {
+  RSBA_PHASE_EVAL_LM = 0,        /* eval_kernel<.., kLmJacobian> + cost reduction: r, J (loss-corrected, scaled), point-major records */
+  RSBA_PHASE_CAMERA_BLOCKS = 1,  /* per-frame J^T J / J^T r blocks (+ intrinsics border) from the per-wave partials */
+  RSBA_PHASE_POINT_BLOCKS = 2,   /* V_j, g_p,j */
+  RSBA_PHASE_POINT_FACTOR = 3,   /* (V_j + D^2)^-1 factors, z_j */
+  RSBA_PHASE_PROJECT = 4,        /* P records (+ virtual intrinsics records) */
+  RSBA_PHASE_SCHUR = 5,          /* clear + Schur tile products + merge: S, rhs */
+  RSBA_PHASE_CHOLESKY = 6,       /* factor + forward / backward solve of the reduced camera system */
+  RSBA_PHASE_BACK_SUBSTITUTE = 7,/* point steps + model cost change */
+  RSBA_PHASE_CANDIDATE = 8,      /* x + delta, |step|, |x| */
+  RSBA_PHASE_EVAL_TRIAL = 9,     /* residual-only evaluation of the candidate + cost reduction */
+  RSBA_PHASE_PRIORS = 10,        /* motion-prior blocks, cost and model terms */
+  RSBA_PHASE_EXCHANGE = 11,      /* multi-GPU all-reduces (pack / collective / unpack) */
+  RSBA_PHASE_OTHER = 12,         /* diagonal clamp, gradient norm, scalar packing */
+  RSBA_NUM_PHASES = 13
+};
+typedef struct rsba_phase_times { double ms[RSBA_NUM_PHASES]; int32_t calls[RSBA_NUM_PHASES]; int32_t reserved; } rsba_phase_times;
+int32_t rsba_get_phase_times(rsba_handle* h, rsba_phase_times* out);
+const char* rsba_phase_name(int32_t phase);
+typedef struct rsba_plan_stats {
+  int64_t tiles, factor_tiles, levels, tasks;       /* 48 x 48 tiles of S, tiles of its factor after fill, elimination levels, Cholesky tasks */
+  int64_t schur_entries, schur_chunks;              /* (point, tile pair) entries of the Schur work list, workgroups */
+  int64_t schur_block_products;                     /* CD x 3 by 3 x CD block products that are not structurally zero */
+  int64_t cholesky_flops;                           /* of the tile factorisation incl. fill, forward and backward solve */
+  int64_t exchange_doubles;                         /* payload (2) of the multi-GPU exchange: packed tiles + rhs */
+} rsba_plan_stats;
+int32_t rsba_get_plan_stats(rsba_handle* h, rsba_plan_stats* out);   /* runs the symbolic phase if it has not run yet */
+
 /* ---- the steps either side of the solve: batched reprojection / validation filter ----
  * == vision::sfm::validate(sess, f, opt, pt, obs) for every observation of the problem
  * (struct/VideoSfM.cc:159-169 with getPose :103-133; callers: CeresHandler.h:239-243 revalidateReprojections,
@@ -209,8 +241,8 @@ int32_t rsba_set_motion_priors(rsba_handle* h, int32_t kind, double scale, doubl
  * second solve through the factorisation), the candidate projected onto the bound as Ceres' ParameterBlock::Plus does,
  * the gradient norm taken of the projected gradient.  Ceres' extra projected line search for bounded problems (>= 1.10)
  * is not restated: steps follow the plain trust-region rules.  rsba_get_inter_frame_ratio returns the current value
- * (the solved one after rsba_solve).  Must precede the first solve / gradient call; evaluate / gradient / covariance
- * treat the ratio as the constant it currently is. */
+ * (the solved one after rsba_solve).  Must precede the first solve / gradient call; evaluate / gradient treat the ratio
+ * as the constant it currently is; rsba_pose_covariance includes its column (the pose block of the bordered inverse). */
 int32_t rsba_set_inter_frame_ratio_free(rsba_handle* h, int32_t is_free);
 int32_t rsba_get_inter_frame_ratio(rsba_handle* h, double* ratio);
 
@@ -242,7 +274,8 @@ int32_t rsba_pnp_inliers(int32_t device, const double* cam, int32_t shutter, con
  *   (1) the per-camera gradient blocks g_c and diag(U)  + cost / failure scalars      [2*F*CD + 3 doubles]
  *   (2) the packed non-zero tiles of its partial reduced camera system S and its rhs  [nslots*48*48 + F*CD]
  *   (3) eight step scalars (model decrease, |step|^2, |x|^2, trial cost, failure flags)
- * through the callback below, which the host implements with RCCL (torch.distributed "nccl" over xGMI).
+ * through RCCL directly (rsba_set_exchange_rccl, below) or through the callback below, for hosts that bring their own
+ * transport (the tests stage it through gloo).
  * op: 0 = sum, 1 = max.  The buffer is device memory; the collective must be ordered after prior work
  * on `hip_stream` and complete (or be stream-ordered) before the callback returns.  Return 0 on success. */
 typedef int32_t (*rsba_allreduce_fn)(void* ctx, double* device_buffer, int64_t count, int32_t op, void* hip_stream);
@@ -254,6 +287,27 @@ int32_t rsba_set_exchange(rsba_handle* h, rsba_allreduce_fn fn, void* ctx, int32
  * carries the per-frame observation count (summed over ranks before it is set back). */
 int32_t rsba_get_block_structure(rsba_handle* h, uint8_t* mask, int64_t* frame_obs_count);
 int32_t rsba_set_block_structure(rsba_handle* h, const uint8_t* mask, const int64_t* frame_obs_count);
+/* The two calls above in one, over the installed exchange: every rank calls it after rsba_set_exchange[_rccl] and before
+ * the first solve; the co-visibility masks are OR-ed and the per-frame counts summed through the all-reduce itself, and
+ * the partition is checked (RSBA_ERR_INVALID_ARGUMENT when some point has observations on more than one rank). */
+int32_t rsba_sync_block_structure(rsba_handle* h);
+
+/* Native transport: RCCL's ncclAllReduce over xGMI, issued by the solver on its own HIP stream — nothing of the host
+ * language runs inside an LM iteration.  librccl is resolved at run time (RSBA_RCCL_LIB, else an RCCL already loaded in
+ * the process, else librccl.so.1); single-GPU users never load it.
+ *   rsba_rccl_get_unique_id   one rank (usually 0) fills id[RSBA_RCCL_UNIQUE_ID_BYTES] (== ncclGetUniqueId); the host
+ *                             hands the bytes to the other ranks by whatever means it has (MPI, a file, torch.distributed)
+ *   rsba_rccl_comm_create     == ncclCommInitRank on `device`; collective over all ranks; *comm_out is an ncclComm_t
+ *   rsba_set_exchange_rccl    installs the all-reduce over an ncclComm_t (one made above or the caller's own) on the
+ *                             handle; must precede the first solve / gradient call, like rsba_set_exchange
+ *   rsba_rccl_comm_destroy    == ncclCommDestroy (after the handles that use it)
+ * After a sharded rsba_solve every rank holds the complete solved parameter arrays: the points are merged over the ranks
+ * (each from the rank that owns its observations) before they are written back. */
+#define RSBA_RCCL_UNIQUE_ID_BYTES 128
+int32_t rsba_rccl_get_unique_id(void* id);
+int32_t rsba_rccl_comm_create(const void* id, int32_t rank, int32_t world, int32_t device, void** comm_out);
+void rsba_rccl_comm_destroy(void* comm);
+int32_t rsba_set_exchange_rccl(rsba_handle* h, void* nccl_comm, int32_t rank, int32_t world);
 
 #ifdef __cplusplus
 }

@@ -126,6 +126,8 @@ block_fn pick_block_fn(const Layout& L) {
   return L.P == 2 ? block_eval<false, 2> : block_eval<false, 1>;
 }
 
+constexpr int64_t kSumChunk = 4096;   // observations per partial sum of the parallel reductions (fixed: results do not depend on the team size)
+
 int threads_of(int n) {
 #ifdef _OPENMP
   return n > 0 ? n : omp_get_max_threads();
@@ -225,8 +227,13 @@ struct Eval {
     r.resize(2 * N); if (want_jac) J.resize((size_t)2 * K * N);
     block_fn fn = pick_block_fn(L);
     double c = 0.0, cf = 0.0; int64_t bad = 0;
-#pragma omp parallel for schedule(static) reduction(+ : c, cf, bad)
-    for (int64_t i = 0; i < N; ++i) {
+    // sums over fixed chunks of observations, the chunk sums added up in order: the same value for any team size
+    const int64_t nchunk = (N + kSumChunk - 1) / kSumChunk;
+    std::vector<double> ch_c(nchunk, 0.0), ch_cf(nchunk, 0.0); std::vector<int64_t> ch_bad(nchunk, 0);
+#pragma omp parallel for schedule(static)
+    for (int64_t chunk = 0; chunk < nchunk; ++chunk) {
+     double c = 0.0, cf = 0.0; int64_t bad = 0;
+     for (int64_t i = chunk * kSumChunk; i < std::min(N, (chunk + 1) * kSumChunk); ++i) {
       double* ri = &r[2 * i]; double* Ji = want_jac ? &J[(size_t)2 * K * i] : nullptr;
       if (!fn(p, i, ri, Ji)) { ++bad; continue; }
       const double s = ri[0] * ri[0] + ri[1] * ri[1];
@@ -253,7 +260,10 @@ struct Eval {
         ri[0] *= rscale; ri[1] *= rscale;
       }
       if (Ji) for (int k = 0; k < K; ++k) if (colmask[gcol(i, k)]) { Ji[k] = 0.0; Ji[K + k] = 0.0; }
+     }
+     ch_c[chunk] = c; ch_cf[chunk] = cf; ch_bad[chunk] = bad;
     }
+    for (int64_t chunk = 0; chunk < nchunk; ++chunk) { c += ch_c[chunk]; cf += ch_cf[chunk]; bad += ch_bad[chunk]; }
     pr.resize((size_t)12 * NP); if (want_jac) pJ.resize((size_t)12 * kPC * NP);
     for (int k = 0; k < NP; ++k) {
       double* rk = &pr[(size_t)12 * k]; double* Jk = want_jac ? &pJ[(size_t)12 * kPC * k] : nullptr;
@@ -291,7 +301,65 @@ struct Eval {
   }
 };
 
-// dense Cholesky A = L L^T in place (lower), returns false if not positive definite
+// Envelope (skyline) storage of a symmetric matrix: row a keeps its columns lo[a] .. a.  The reduced camera system of a
+// video is banded (a frame shares points with a few dozen neighbours) with, at most, a dense border at the end
+// (shared intrinsics, the free interFrameRatio): inside the envelope it is treated as DENSE — the Cholesky factor of a
+// matrix never leaves its envelope — so the arithmetic below is the dense row-by-row factorisation with the products
+// that are exactly zero left out (same operands, same order: bit-identical to the dense form), at O(n b^2) instead
+// of O(n^3).  That is what lets the checker run the 1k- and 4k-camera configurations (SparseCholesky in Ceres: CHOLMOD).
+struct EnvMatrix {
+  int64_t n = 0;
+  std::vector<int64_t> lo, ptr, hi;   // hi[j] = last row whose envelope reaches column j
+  std::vector<double> v;
+  void shape(const std::vector<int64_t>& lo_) {
+    n = (int64_t)lo_.size(); lo = lo_; ptr.assign(n + 1, 0); hi.assign(n, 0);
+    for (int64_t a = 0; a < n; ++a) ptr[a + 1] = ptr[a] + (a - lo[a] + 1);
+    for (int64_t j = 0; j < n; ++j) hi[j] = j;
+    for (int64_t a = 0; a < n; ++a) hi[lo[a]] = std::max(hi[lo[a]], a);
+    for (int64_t j = 1; j < n; ++j) hi[j] = std::max(hi[j], hi[j - 1]);
+    v.assign((size_t)ptr[n], 0.0);
+  }
+  inline bool has(int64_t a, int64_t b) const { return b <= a && b >= lo[a]; }
+  inline double& at(int64_t a, int64_t b) { return v[(size_t)(ptr[a] + (b - lo[a]))]; }           // b in [lo[a], a]
+  inline double get(int64_t a, int64_t b) const { if (b > a) std::swap(a, b); return b >= lo[a] ? v[(size_t)(ptr[a] + (b - lo[a]))] : 0.0; }
+  inline const double* row(int64_t a) const { return &v[(size_t)ptr[a]] - lo[a]; }                // row(a)[b] for b in [lo[a], a]
+  inline double* row(int64_t a) { return &v[(size_t)ptr[a]] - lo[a]; }
+};
+
+// Cholesky A = L L^T in place (lower, inside the envelope), returns false if not positive definite.
+// L_ij = (A_ij - sum_{k<j} L_ik L_jk) / L_jj, k ascending — the dense inner-product form.
+bool cholesky(EnvMatrix& A) {
+  const int64_t n = A.n;
+  for (int64_t j = 0; j < n; ++j) {
+    double* aj = A.row(j);
+    double d = aj[j];
+    for (int64_t k = A.lo[j]; k < j; ++k) d -= aj[k] * aj[k];
+    if (!(d > 0.0) || !std::isfinite(d)) return false;
+    const double ljj = std::sqrt(d);
+    aj[j] = ljj;
+    const double inv = 1.0 / ljj;
+    const int64_t last = A.hi[j];
+#pragma omp parallel for schedule(static) if (last - j > 256)
+    for (int64_t i = j + 1; i <= last; ++i) {
+      if (A.lo[i] > j) continue;
+      double* ai = A.row(i);
+      double s = ai[j];
+      for (int64_t k = std::max(A.lo[i], A.lo[j]); k < j; ++k) s -= ai[k] * aj[k];
+      ai[j] = s * inv;
+    }
+  }
+  return true;
+}
+void chol_solve(const EnvMatrix& A, std::vector<double>& b) {
+  const int64_t n = A.n;
+  for (int64_t i = 0; i < n; ++i) { const double* ai = A.row(i); double s = b[i]; for (int64_t k = A.lo[i]; k < i; ++k) s -= ai[k] * b[k]; b[i] = s / ai[i]; }
+  for (int64_t i = n - 1; i >= 0; --i) {
+    double s = b[i];
+    for (int64_t k = i + 1; k <= A.hi[i]; ++k) if (A.lo[k] <= i) s -= A.row(k)[i] * b[k];
+    b[i] = s / A.row(i)[i];
+  }
+}
+// dense forms (small systems: the covariance of the free coordinates)
 bool cholesky(std::vector<double>& A, int64_t n) {
   for (int64_t j = 0; j < n; ++j) {
     double d = A[j * n + j];
@@ -338,29 +406,39 @@ PointCsr point_csr(const orc_problem* p) {
 }
 
 // SchurComplementSolver restated (Ceres 1.9 schur_complement_solver.cc / schur_eliminator_impl.h):
-// solve (J^T J + D^2) y = J^T r exactly by eliminating the point blocks, dense Cholesky on the
+// solve (J^T J + D^2) y = J^T r exactly by eliminating the point blocks, Cholesky on the
 // reduced camera system, back-substitution.  J is the (already column-scaled) corrected Jacobian.
-// reduced camera system S = U + D_c^2 - sum_j W_j (V_j + D_p^2)^-1 W_j^T and its right-hand side (dense), with the
-// inverted point blocks and point gradients the back-substitution needs
+// reduced camera system S = U + D_c^2 - sum_j W_j (V_j + D_p^2)^-1 W_j^T (lower triangle, envelope storage) and its
+// right-hand side, with the inverted point blocks and point gradients the back-substitution needs.
+// Every entry of S and rhs is accumulated by ONE thread (the owner of its row: contiguous ranges of frames) in the order
+// a serial sweep would use — observations ascending, then priors, damping, points ascending — so the result does not
+// depend on the team size.
 bool reduced_system(const Eval& E, const PointCsr& pc, const std::vector<double>& J, const std::vector<double>& r,
-                    const std::vector<double>& D2, std::vector<double>& S, std::vector<double>& rhs,
+                    const std::vector<double>& D2, EnvMatrix& S, std::vector<double>& rhs,
                     std::vector<double>& Vinv, std::vector<double>& bp) {
   const Layout& L = E.L; const int K = L.K; const int KC = K - 3;   // camera-side columns of one block
-  const int64_t nc = E.ncam, N = E.N; const int M = E.M;
-  S.assign((size_t)nc * nc, 0.0); rhs.assign(nc, 0.0);
-  // camera-side Hessian and gradient
-  for (int64_t i = 0; i < N; ++i) {
-    const double* Ji = &J[(size_t)2 * K * i];
-    for (int a = 0; a < KC; ++a) {
-      const int64_t ga = E.gcol(i, a);
-      rhs[ga] += Ji[a] * r[2 * i] + Ji[K + a] * r[2 * i + 1];
-      for (int b = 0; b < KC; ++b) S[ga * nc + E.gcol(i, b)] += Ji[a] * Ji[b] + Ji[K + a] * Ji[K + b];
+  const int64_t nc = E.ncam, N = E.N; const int M = E.M; const int F = E.F;
+  // envelope: a row reaches back to the first column any of its points (or prior blocks) couples it with
+  {
+    std::vector<int64_t> lo(nc);
+    for (int64_t a = 0; a < nc; ++a) lo[a] = a;
+    for (int j = 0; j < M; ++j) {
+      int64_t cmin = nc;
+      for (int64_t t = pc.ptr[j]; t < pc.ptr[j + 1]; ++t) for (int a = 0; a < KC; ++a) cmin = std::min(cmin, E.gcol(pc.idx[t], a));
+      for (int64_t t = pc.ptr[j]; t < pc.ptr[j + 1]; ++t) for (int a = 0; a < KC; ++a) { int64_t& l = lo[E.gcol(pc.idx[t], a)]; l = std::min(l, cmin); }
     }
+    for (int k = 0; k < E.NP; ++k) {
+      int64_t cmin = nc;
+      for (int c = 0; c < E.PC; ++c) cmin = std::min(cmin, E.pcol(k, c));
+      for (int c = 0; c < E.PC; ++c) { int64_t& l = lo[E.pcol(k, c)]; l = std::min(l, cmin); }
+    }
+    S.shape(lo);
   }
-  E.prior_normal([&](int64_t a, double v) { rhs[a] += v; }, [&](int64_t a, int64_t b, double v) { S[a * nc + b] += v; });
-  for (int64_t a = 0; a < nc; ++a) S[a * nc + a] += D2[a];
+  rhs.assign(nc, 0.0);
   Vinv.assign((size_t)9 * M, 0.0); bp.assign((size_t)3 * M, 0.0);
-  bool ok = true;
+  // point blocks first (independent of each other)
+  int bad = 0;
+#pragma omp parallel for schedule(static) reduction(+ : bad)
   for (int j = 0; j < M; ++j) {
     double V[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
     for (int64_t t = pc.ptr[j]; t < pc.ptr[j + 1]; ++t) {
@@ -371,49 +449,87 @@ bool reduced_system(const Eval& E, const PointCsr& pc, const std::vector<double>
       }
     }
     for (int a = 0; a < 3; ++a) V[4 * a] += D2[nc + 3 * (int64_t)j + a];
-    double* Vi = &Vinv[(size_t)9 * j];
-    if (!inv3_sym(V, Vi)) { ok = false; continue; }
+    if (!inv3_sym(V, &Vinv[(size_t)9 * j])) { ++bad; continue; }
     for (int a = 0; a < 3; ++a) bp[3 * (size_t)j + a] = g[a];
-    // W_o = Jc_o^T Jp_o (KC x 3);  Y_o = W_o Vinv
-    const int64_t n = pc.ptr[j + 1] - pc.ptr[j];
-    std::vector<double> W((size_t)n * KC * 3), Y((size_t)n * KC * 3);
-    for (int64_t t = 0; t < n; ++t) {
-      const int64_t i = pc.idx[pc.ptr[j] + t]; const double* Ji = &J[(size_t)2 * K * i];
-      for (int a = 0; a < KC; ++a) for (int b = 0; b < 3; ++b)
-        W[(t * KC + a) * 3 + b] = Ji[a] * Ji[L.off_point + b] + Ji[K + a] * Ji[K + L.off_point + b];
-      for (int a = 0; a < KC; ++a) for (int b = 0; b < 3; ++b)
-        Y[(t * KC + a) * 3 + b] = W[(t * KC + a) * 3 + 0] * Vi[b] + W[(t * KC + a) * 3 + 1] * Vi[3 + b] + W[(t * KC + a) * 3 + 2] * Vi[6 + b];
-    }
-    for (int64_t t1 = 0; t1 < n; ++t1) {
-      const int64_t i1 = pc.idx[pc.ptr[j] + t1];
+  }
+  // frame range of every point (the rows its elimination touches), for the owners' quick skip
+  std::vector<int32_t> pf0(M, F), pf1(M, -1);
+  for (int j = 0; j < M; ++j) for (int64_t t = pc.ptr[j]; t < pc.ptr[j + 1]; ++t) { const int f = E.p->obs_frame[pc.idx[t]]; pf0[j] = std::min(pf0[j], f); pf1[j] = std::max(pf1[j], f); }
+  const int64_t npose = (int64_t)F * L.CD;
+#pragma omp parallel
+  {
+#ifdef _OPENMP
+    const int T = omp_get_num_threads(), me = omp_get_thread_num();
+#else
+    const int T = 1, me = 0;
+#endif
+    const int f_lo = (int)((int64_t)F * me / T), f_hi = (int)((int64_t)F * (me + 1) / T);   // my frames; the rows behind the poses belong to the last thread
+    const bool tail = me == T - 1;
+    auto mine = [&](int64_t ga) { return ga < npose ? (ga >= (int64_t)f_lo * L.CD && ga < (int64_t)f_hi * L.CD) : tail; };
+    // camera-side Hessian and gradient
+    for (int64_t i = 0; i < N; ++i) {
+      const int f = E.p->obs_frame[i];
+      if (!((f >= f_lo && f < f_hi) || (tail && KC > L.CD))) continue;
+      const double* Ji = &J[(size_t)2 * K * i];
       for (int a = 0; a < KC; ++a) {
-        const int64_t ga = E.gcol(i1, a);
-        const double* Ya = &Y[(t1 * KC + a) * 3];
-        rhs[ga] -= Ya[0] * g[0] + Ya[1] * g[1] + Ya[2] * g[2];
-        for (int64_t t2 = 0; t2 < n; ++t2) {
-          const int64_t i2 = pc.idx[pc.ptr[j] + t2];
-          for (int b = 0; b < KC; ++b) {
-            const double* Wb = &W[(t2 * KC + b) * 3];
-            S[ga * nc + E.gcol(i2, b)] -= Ya[0] * Wb[0] + Ya[1] * Wb[1] + Ya[2] * Wb[2];
+        const int64_t ga = E.gcol(i, a);
+        if (!mine(ga)) continue;
+        rhs[ga] += Ji[a] * r[2 * i] + Ji[K + a] * r[2 * i + 1];
+        for (int b = 0; b < KC; ++b) { const int64_t gb = E.gcol(i, b); if (gb <= ga) S.at(ga, gb) += Ji[a] * Ji[b] + Ji[K + a] * Ji[K + b]; }
+      }
+    }
+    E.prior_normal([&](int64_t a, double v) { if (mine(a)) rhs[a] += v; }, [&](int64_t a, int64_t b, double v) { if (b <= a && mine(a)) S.at(a, b) += v; });
+    for (int64_t a = 0; a < nc; ++a) if (mine(a)) S.at(a, a) += D2[a];
+    std::vector<double> W, Y;
+    for (int j = 0; j < M; ++j) {
+      if (!((pf0[j] < f_hi && pf1[j] >= f_lo) || (tail && KC > L.CD))) continue;
+      const double* Vi = &Vinv[(size_t)9 * j]; const double* g = &bp[3 * (size_t)j];
+      // W_o = Jc_o^T Jp_o (KC x 3);  Y_o = W_o Vinv
+      const int64_t n = pc.ptr[j + 1] - pc.ptr[j];
+      W.resize((size_t)n * KC * 3); Y.resize((size_t)n * KC * 3);
+      for (int64_t t = 0; t < n; ++t) {
+        const int64_t i = pc.idx[pc.ptr[j] + t]; const double* Ji = &J[(size_t)2 * K * i];
+        for (int a = 0; a < KC; ++a) for (int b = 0; b < 3; ++b)
+          W[(t * KC + a) * 3 + b] = Ji[a] * Ji[L.off_point + b] + Ji[K + a] * Ji[K + L.off_point + b];
+        for (int a = 0; a < KC; ++a) for (int b = 0; b < 3; ++b)
+          Y[(t * KC + a) * 3 + b] = W[(t * KC + a) * 3 + 0] * Vi[b] + W[(t * KC + a) * 3 + 1] * Vi[3 + b] + W[(t * KC + a) * 3 + 2] * Vi[6 + b];
+      }
+      for (int64_t t1 = 0; t1 < n; ++t1) {
+        const int64_t i1 = pc.idx[pc.ptr[j] + t1];
+        for (int a = 0; a < KC; ++a) {
+          const int64_t ga = E.gcol(i1, a);
+          if (!mine(ga)) continue;
+          const double* Ya = &Y[(t1 * KC + a) * 3];
+          rhs[ga] -= Ya[0] * g[0] + Ya[1] * g[1] + Ya[2] * g[2];
+          double* Sa = S.row(ga);
+          for (int64_t t2 = 0; t2 < n; ++t2) {
+            const int64_t i2 = pc.idx[pc.ptr[j] + t2];
+            for (int b = 0; b < KC; ++b) {
+              const int64_t gb = E.gcol(i2, b);
+              if (gb > ga) continue;
+              const double* Wb = &W[(t2 * KC + b) * 3];
+              Sa[gb] -= Ya[0] * Wb[0] + Ya[1] * Wb[1] + Ya[2] * Wb[2];
+            }
           }
         }
       }
     }
   }
-  return ok;
+  return bad == 0;
 }
 
 bool schur_solve(const Eval& E, const PointCsr& pc, const std::vector<double>& J, const std::vector<double>& r,
                  const std::vector<double>& D2, std::vector<double>& y) {
   const Layout& L = E.L; const int K = L.K; const int KC = K - 3;
   const int64_t nc = E.ncam; const int M = E.M;
-  std::vector<double> S, rhs, Vinv, bp;
+  EnvMatrix S; std::vector<double> rhs, Vinv, bp;
   y.assign(E.nparam, 0.0);
   if (!reduced_system(E, pc, J, r, D2, S, rhs, Vinv, bp)) return false;
-  if (!cholesky(S, nc)) return false;
-  chol_solve(S, nc, rhs);
+  if (!cholesky(S)) return false;
+  chol_solve(S, rhs);
   for (int64_t a = 0; a < nc; ++a) y[a] = rhs[a];
   // back-substitution  y_p = Vinv (b_p - sum_o W_o^T y_c)
+#pragma omp parallel for schedule(static)
   for (int j = 0; j < M; ++j) {
     double t3[3] = {bp[3 * (size_t)j], bp[3 * (size_t)j + 1], bp[3 * (size_t)j + 2]};
     for (int64_t t = pc.ptr[j]; t < pc.ptr[j + 1]; ++t) {
@@ -637,12 +753,19 @@ int32_t orc_solve(orc_problem* p, const orc_options* opt, orc_summary* sum, orc_
     if (solved) {
       // step = -y ; model_cost_change = -(J step) . (r + J step / 2)
       double acc = 0.0;
-#pragma omp parallel for schedule(static) reduction(+ : acc)
-      for (int64_t i = 0; i < N; ++i) {
-        double m0 = 0, m1 = 0;
-        for (int k = 0; k < K; ++k) { const double s = -y[E.gcol(i, k)]; m0 += E.J[(size_t)2 * K * i + k] * s; m1 += E.J[(size_t)2 * K * i + K + k] * s; }
-        acc += m0 * (E.r[2 * i] + 0.5 * m0) + m1 * (E.r[2 * i + 1] + 0.5 * m1);
+      const int64_t nchunk = (N + kSumChunk - 1) / kSumChunk;
+      std::vector<double> ch_acc(nchunk, 0.0);
+#pragma omp parallel for schedule(static)
+      for (int64_t chunk = 0; chunk < nchunk; ++chunk) {
+        double a = 0.0;
+        for (int64_t i = chunk * kSumChunk; i < std::min(N, (chunk + 1) * kSumChunk); ++i) {
+          double m0 = 0, m1 = 0;
+          for (int k = 0; k < K; ++k) { const double s = -y[E.gcol(i, k)]; m0 += E.J[(size_t)2 * K * i + k] * s; m1 += E.J[(size_t)2 * K * i + K + k] * s; }
+          a += m0 * (E.r[2 * i] + 0.5 * m0) + m1 * (E.r[2 * i + 1] + 0.5 * m1);
+        }
+        ch_acc[chunk] = a;
       }
+      for (int64_t chunk = 0; chunk < nchunk; ++chunk) acc += ch_acc[chunk];
       for (int k = 0; k < E.NP; ++k) for (int i = 0; i < 12; ++i) {
         double m = 0.0;
         for (int c = 0; c < E.PC; ++c) m += E.pJ[(size_t)12 * kPC * k + i * kPC + c] * -y[E.pcol(k, c)];
@@ -710,7 +833,7 @@ int32_t orc_pose_covariance(const orc_problem* p, int32_t frame, double* cov) {
   if (!E.run(true, nullptr, nullptr)) return 0;
   const int CD = E.L.CD; const int64_t nc = E.ncam;
   PointCsr pc = point_csr(p);
-  std::vector<double> D2(E.nparam, 0.0), S, rhs, Vinv, bp;
+  std::vector<double> D2(E.nparam, 0.0), rhs, Vinv, bp; EnvMatrix S;
   // fixed point coordinates: keep their (decoupled, otherwise singular) 3x3 blocks invertible
   for (int64_t a = nc; a < E.nparam; ++a) if (E.colmask[a]) D2[a] = 1.0;
   // a point that nobody observes has an all-zero block as well
@@ -721,7 +844,7 @@ int32_t orc_pose_covariance(const orc_problem* p, int32_t frame, double* cov) {
   for (int64_t a = 0; a < nc; ++a) if (!E.colmask[a]) freec.push_back(a);
   const int64_t nf = (int64_t)freec.size();
   std::vector<double> A((size_t)nf * nf);
-  for (int64_t a = 0; a < nf; ++a) for (int64_t b = 0; b < nf; ++b) A[a * nf + b] = S[freec[a] * nc + freec[b]];
+  for (int64_t a = 0; a < nf; ++a) for (int64_t b = 0; b < nf; ++b) A[a * nf + b] = S.get(freec[a], freec[b]);
   if (!cholesky(A, nf)) return 0;
   for (int a = 0; a < CD * CD; ++a) cov[a] = 0.0;
   for (int k = 0; k < CD; ++k) {

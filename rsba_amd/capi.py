@@ -23,7 +23,10 @@ EXPORTS = [
     "rsba_set_exchange", "rsba_get_block_structure", "rsba_set_block_structure",
     "rsba_validate_observations", "rsba_reproject", "rsba_pose_covariance", "rsba_set_motion_priors",
     "rsba_pnp_tasks", "rsba_pnp_inliers", "rsba_set_inter_frame_ratio_free", "rsba_get_inter_frame_ratio",
+    "rsba_sync_block_structure", "rsba_rccl_get_unique_id", "rsba_rccl_comm_create", "rsba_rccl_comm_destroy", "rsba_set_exchange_rccl",
+    "rsba_get_phase_times", "rsba_phase_name", "rsba_get_plan_stats",
 ]
+NUM_PHASES = 13
 
 
 class RsbaError(RuntimeError):
@@ -53,7 +56,7 @@ class SolverOptions(C.Structure):
         ("min_trust_region_radius", C.c_double), ("min_relative_decrease", C.c_double),
         ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
         ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
-        ("level_scheduled_cholesky", C.c_int32), ("reserved", C.c_int32),
+        ("level_scheduled_cholesky", C.c_int32), ("profile_phases", C.c_int32),
     ]
 
 
@@ -81,6 +84,15 @@ class DeviceView(C.Structure):
         ("reserved", C.c_int32), ("order_host", C.c_void_p), ("poses", C.c_void_p), ("points", C.c_void_p),
         ("intrinsics", C.c_void_p),
     ]
+
+
+class PhaseTimes(C.Structure):
+    _fields_ = [("ms", C.c_double * NUM_PHASES), ("calls", C.c_int32 * NUM_PHASES), ("reserved", C.c_int32)]
+
+
+class PlanStats(C.Structure):
+    _fields_ = [(k, C.c_int64) for k in ("tiles", "factor_tiles", "levels", "tasks", "schur_entries", "schur_chunks", "schur_block_products",
+                                         "cholesky_flops", "exchange_doubles")]
 
 
 def build(force: bool = False) -> str:
@@ -111,6 +123,9 @@ def lib():
         _lib.rsba_default_solver_options.restype = None
         _lib.rsba_set_stream.argtypes = [C.c_void_p, C.c_void_p]
         _lib.rsba_destroy.argtypes = [C.c_void_p]
+        _lib.rsba_phase_name.restype = C.c_char_p
+        _lib.rsba_rccl_comm_destroy.restype = None
+        _lib.rsba_rccl_comm_destroy.argtypes = [C.c_void_p]
     return _lib
 
 
@@ -259,6 +274,25 @@ class DeviceProblem:
         _check(lib().rsba_pose_covariance(self._h, C.c_int32(frame), _ptr(out)))
         return out
 
+    def set_exchange_rccl(self, comm, rank: int, world: int):
+        """Native transport of the multi-GPU exchange: ncclAllReduce on the solver's stream (rsba_amd.h)."""
+        _check(lib().rsba_set_exchange_rccl(self._h, C.c_void_p(comm), C.c_int32(rank), C.c_int32(world)))
+
+    def sync_block_structure(self):
+        """All ranks: union of the co-visibility structures over the installed exchange (before the first solve)."""
+        _check(lib().rsba_sync_block_structure(self._h))
+
+    def phase_times(self) -> dict:
+        """HIP-event time per phase of the last solve run with profile_phases=1 -> {name: (ms, calls)}"""
+        t = PhaseTimes()
+        _check(lib().rsba_get_phase_times(self._h, C.byref(t)))
+        return {lib().rsba_phase_name(C.c_int32(p)).decode(): (t.ms[p], t.calls[p]) for p in range(NUM_PHASES)}
+
+    def plan_stats(self) -> dict:
+        st = PlanStats()
+        _check(lib().rsba_get_plan_stats(self._h, C.byref(st)))
+        return {k: int(getattr(st, k)) for k, _ in PlanStats._fields_}
+
     def device_view(self) -> DeviceView:
         v = DeviceView()
         _check(lib().rsba_get_device_view(self._h, C.byref(v)))
@@ -274,6 +308,24 @@ class DeviceProblem:
         if getattr(self.prob, "ratio_free", False) and self.prob.prior_kind:
             self.prob.inter_frame_ratio = self.inter_frame_ratio()       # a free ratio block is solved for, like every parameter
         return s, [tr[i] for i in range(min(s.num_iterations, trace_cap))]
+
+
+def rccl_unique_id() -> bytes:
+    """== ncclGetUniqueId (one rank; hand the bytes to the others)"""
+    buf = C.create_string_buffer(128)
+    _check(lib().rsba_rccl_get_unique_id(buf))
+    return buf.raw
+
+
+def rccl_comm_create(uid: bytes, rank: int, world: int, device: int) -> int:
+    """== ncclCommInitRank; collective.  -> ncclComm_t as an integer"""
+    comm = C.c_void_p()
+    _check(lib().rsba_rccl_comm_create(C.c_char_p(uid), C.c_int32(rank), C.c_int32(world), C.c_int32(device), C.byref(comm)))
+    return comm.value
+
+
+def rccl_comm_destroy(comm: int):
+    lib().rsba_rccl_comm_destroy(C.c_void_p(comm))
 
 
 def pnp_tasks(cam, shutter, scanlines, object_points, image_points, subsets, init_poses, max_num_iterations=10,

@@ -293,6 +293,7 @@ int32_t rsba_set_inter_frame_ratio_free(rsba_handle* h, int32_t is_free) {
   if (!h) return fail(RSBA_ERR_INVALID_ARGUMENT, "null handle");
   if (h->solver) return fail(RSBA_ERR_INVALID_ARGUMENT, "rsba_set_inter_frame_ratio_free must precede the first solve / gradient call");
   h->prior_free = is_free != 0;
+  h->dp.prior_free = h->prior_free ? 1 : 0;
   return RSBA_OK;
 }
 int32_t rsba_get_inter_frame_ratio(rsba_handle* h, double* ratio) {
@@ -383,7 +384,7 @@ void rsba_default_solver_options(rsba_solver_options* o) {
   o->initial_trust_region_radius = 1e4; o->max_trust_region_radius = 1e16; o->min_trust_region_radius = 1e-32;
   o->min_relative_decrease = 1e-3; o->min_lm_diagonal = 1e-6; o->max_lm_diagonal = 1e32;
   o->function_tolerance = 1e-6; o->gradient_tolerance = 1e-10; o->parameter_tolerance = 1e-8;
-  o->level_scheduled_cholesky = 0; o->reserved = 0;
+  o->level_scheduled_cholesky = 0; o->profile_phases = 0;
 }
 
 }  // extern "C"

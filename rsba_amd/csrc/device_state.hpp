@@ -59,6 +59,7 @@ struct DeviceProblem {
   const int32_t* prior_of;       // [F + 1] 1 = frame f carries a prior against frame f - 1 (entry F is 0)
   int prior_kind;                // 1 RsConstVeloPrior, 2 RsConstAccelerationPrior
   double prior_scale, prior_ratio;
+  int prior_free;                // the interFrameRatio is a free parameter block: no prior block is "all constant" then
   double* prior_partial;         // [2 * ceil(F / 64)] per-wave partial sums of the prior reductions
   unsigned* prior_ticket;        // arrival counter of those reductions (zero between launches)
 };

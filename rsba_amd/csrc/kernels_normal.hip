@@ -650,6 +650,21 @@ __global__ __launch_bounds__(256) void candidate_kernel(const DeviceProblem dp, 
   }
 }
 
+// sharded solve, after the last iteration: every rank contributes the points it owns (the ones it has observations of),
+// buf = [M][3] values | [M] owner count; after the all-reduce the owners' values replace the local copies
+__global__ void own_points_kernel(const DeviceProblem dp, const SolverDev sv, double* buf) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= dp.M) return;
+  const bool own = sv.point_ptr[j + 1] > sv.point_ptr[j];
+  for (int k = 0; k < 3; ++k) buf[3 * j + k] = own ? dp.points[3 * j + k] : 0.0;
+  buf[3 * (int64_t)dp.M + j] = own ? 1.0 : 0.0;
+}
+__global__ void merge_points_kernel(const DeviceProblem dp, const double* buf) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= dp.M || buf[3 * (int64_t)dp.M + j] != 1.0) return;
+  for (int k = 0; k < 3; ++k) dp.points[3 * j + k] = buf[3 * j + k];
+}
+
 // exchange buffer (1): g_c | diag(U) | cost, fixed cost, failed blocks
 __global__ void pack_linearize_kernel(const DeviceProblem dp, const SolverDev sv, const double* cost2) {
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -812,6 +827,14 @@ hipError_t launch_back_substitute(const DeviceProblem& dp, const SolverDev& sv, 
 // -> scalars[kModelCostChange]; must follow launch_back_substitute directly (it reduces that kernel's partials)
 hipError_t launch_model_cost_change(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {
   LAUNCH(reduce_sum_kernel, 1, 256, st, sv.partial, dp.M > 0 ? point_step_blocks(dp) : 0, sv.scalars + kModelCostChange, -1.0);
+  return hipSuccess;
+}
+hipError_t launch_own_points(const DeviceProblem& dp, const SolverDev& sv, double* buf, hipStream_t st) {
+  LAUNCH(own_points_kernel, nblocks256(dp.M), 256, st, dp, sv, buf);
+  return hipSuccess;
+}
+hipError_t launch_merge_points(const DeviceProblem& dp, const double* buf, hipStream_t st) {
+  LAUNCH(merge_points_kernel, nblocks256(dp.M), 256, st, dp, buf);
   return hipSuccess;
 }
 hipError_t launch_candidate(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {

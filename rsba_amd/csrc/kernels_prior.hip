@@ -138,14 +138,14 @@ __device__ __forceinline__ bool last_wave_of_grid(const DeviceProblem& dp) {
   return true;
 }
 
-// cost of the prior blocks at dp.poses, added to {cost, fixed cost}; a block whose four poses are all constant is not
-// part of the reduced program and its cost is "fixed" (Ceres: Program::RemoveFixedBlocks)
+// cost of the prior blocks at dp.poses, added to {cost, fixed cost}; a block whose four poses are all constant (and whose
+// ratio block is constant too) is not part of the reduced program and its cost is "fixed" (Ceres: Program::RemoveFixedBlocks)
 __global__ __launch_bounds__(64) void prior_cost_kernel(const DeviceProblem dp, double* cost2, int invalid) {
   const int f = blockIdx.x * 64 + threadIdx.x;
   double c = 0.0, cf = 0.0;
   if (f < dp.F && dp.prior_of[f]) {
     const PriorValue v = prior_value(dp, f);
-    bool all_const = true;
+    bool all_const = dp.prior_free == 0;   // with a free ratio the block always keeps one variable parameter block
     for (int k = 0; k < 24; ++k) all_const = all_const && dp.scale_pose[(size_t)(f - 1) * 12 + k] == 0.0;
     if (all_const) cf = v.cost; else c = v.cost;
   }

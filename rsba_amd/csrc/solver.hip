@@ -23,7 +23,27 @@
 namespace rsba {
 
 
+// HIP-event timing of the phases of an LM iteration (rsba_solver_options::profile_phases): events are recorded on the
+// solver's stream around each group of launches and read after the iteration's own synchronisation point, so the
+// timed run has the same launch sequence and no extra waits.
+struct PhaseTimer {
+  bool on = false;
+  struct Rec { int phase; hipEvent_t a, b; };
+  std::vector<hipEvent_t> pool; size_t next = 0;
+  std::vector<Rec> pending;
+  double ms[RSBA_NUM_PHASES] = {}; int32_t calls[RSBA_NUM_PHASES] = {};
+  hipEvent_t get() { if (next == pool.size()) { hipEvent_t e = nullptr; (void)hipEventCreate(&e); pool.push_back(e); } return pool[next++]; }
+  void reset() { for (int p = 0; p < RSBA_NUM_PHASES; ++p) { ms[p] = 0.0; calls[p] = 0; } pending.clear(); next = 0; }
+  void resolve() {   // the stream is idle
+    for (const Rec& r : pending) { float t = 0.f; if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) { ms[r.phase] += t; ++calls[r.phase]; } }
+    pending.clear(); next = 0;
+  }
+  ~PhaseTimer() { for (hipEvent_t e : pool) (void)hipEventDestroy(e); }
+};
+
 struct Solver {
+  PhaseTimer timer;
+  rsba_plan_stats stats{};
   SolverDev sv{};
   std::vector<void*> allocs;
   // Cholesky plan over the packed tile slots, level-scheduled on the elimination structure (see build_solver)
@@ -50,6 +70,7 @@ struct Solver {
   int64_t num_pairs = 0;
   int num_reduced_blocks = 0, num_reduced_params = 0, num_priors_reduced = 0;
   double* border = nullptr, *ubuf = nullptr, *ratio4 = nullptr;      // free interFrameRatio: its column of S [npad], the first solve's result, {h, g, b.u, b.v}
+  double* merge_buf = nullptr;                                        // sharded solve: [4 M] owned point values | owner flags
   double* ucross = nullptr;                                           // [F][CD][CD] motion-prior blocks (f, f-1), behind sv.U's J^T J blocks
 };
 
@@ -89,6 +110,14 @@ int32_t s_upload_const(Solver* s, const T** p, const std::vector<T>& v) {
   *p = q;
   return rc;
 }
+
+struct PhaseScope {
+  PhaseTimer* t = nullptr; int phase; hipStream_t st; hipEvent_t a = nullptr;
+  PhaseScope(rsba_handle* h, int ph) : phase(ph), st(h->stream) {
+    if (h->solver && h->solver->timer.on) { t = &h->solver->timer; a = t->get(); (void)hipEventRecord(a, st); }
+  }
+  ~PhaseScope() { if (t) { hipEvent_t b = t->get(); (void)hipEventRecord(b, st); t->pending.push_back({phase, a, b}); } }
+};
 
 // Symbolic phase: frame / point adjacency, the per-block pair lists of the reduced camera system and
 // the tile-level fill pattern of its Cholesky factor.  Ceres does the equivalent in its preprocessor
@@ -492,7 +521,7 @@ int32_t build_solver(rsba_handle* h) {
     }
     s->num_priors_reduced = 0;
     if (lead) for (int32_t f : h->prior_frames) {
-      bool all_const = true;
+      bool all_const = !h->prior_free;
       for (int k = 0; k < 24 && all_const; ++k) all_const = h->mask_pose[(size_t)(f - 1) * CD + k] == 0.0;
       s->num_priors_reduced += !all_const;
     }
@@ -603,6 +632,7 @@ int32_t build_solver(rsba_handle* h) {
   if ((rc = s_alloc(s, &sv.chol_fail, 1))) return rc;
   if ((rc = s_alloc(s, &s->d_gpose, (size_t)F * CD))) return rc;
   if ((rc = s_alloc(s, &s->d_gpoint, (size_t)M * 3))) return rc;
+  if (h->allreduce && h->world > 1) { if ((rc = s_alloc(s, &s->merge_buf, 4 * (size_t)M))) return rc; }
   HIP_TRY(hipMemset(sv.scalars, 0, 16 * sizeof(double)));
   HIP_TRY(hipMemset(sv.chol_fail, 0, sizeof(int)));
   CholPlan& pl = s->plan;
@@ -626,6 +656,25 @@ int32_t build_solver(rsba_handle* h) {
                  s->nlev, pl.ntasks, parts, sv.ntp, (long long)s->num_pairs, sv.nchunk);
   const char* lv = std::getenv("RSBA_CHOL_LEVELS");
   s->use_levels = lv && lv[0] == '1';
+  {
+    rsba_plan_stats& ps = s->stats;
+    ps.tiles = nt; ps.factor_tiles = sv.nslots; ps.levels = s->nlev; ps.tasks = pl.ntasks;
+    ps.schur_entries = nent; ps.schur_chunks = sv.nchunk;
+    // block products of the Schur complement that are not structurally zero: per entry (frames present on the I side) x (on the J side)
+    int64_t prod = 0;
+    for (int64_t e = 0; e < nent; ++e) {
+      int ca = 0, cb = 0;
+      for (int x = 0; x < FT; ++x) { ca += g_rows[(size_t)ent_groups[2 * (size_t)e] * FT + x] != (int32_t)NS; cb += g_rows[(size_t)ent_groups[2 * (size_t)e + 1] * FT + x] != (int32_t)NS; }
+      prod += (int64_t)ca * cb;
+    }
+    ps.schur_block_products = prod;
+    // tile factorisation: per DIAG item its contributors (lower half of L L^T: T^3 each) + potrf and inverse (T^3 / 3 each);
+    // per SUB item 2 T^3 per contributor + the product with W (T^3); forward / backward solve 2 T^2 per factor tile, twice
+    const int64_t T3 = (int64_t)kTile * kTile * kTile;
+    ps.cholesky_flops = T3 * ((int64_t)(s->diag_list.size() / 2) + 2 * (int64_t)(s->sub_list.size() / 2) + (int64_t)(s->sub_info.size() / 4)) +
+                        2 * T3 / 3 * (int64_t)(s->diag_info.size() / 4) + 4 * (int64_t)kTile * kTile * ((int64_t)sv.nslots + nt);
+    ps.exchange_doubles = (int64_t)sv.nslots * kTile * kTile + sv.npad;
+  }
   return RSBA_OK;
 }
 
@@ -639,7 +688,7 @@ int32_t reset_scales(rsba_handle* h) {
 
 // all-reduce across the ranks of a point-partitioned solve (no-op for a single GPU)
 int32_t exchange(rsba_handle* h, double* buf, int64_t count, int op) {
-  if (h->world <= 1 || !h->allreduce) return RSBA_OK;
+  if (!h->allreduce) return RSBA_OK;   // (a one-rank exchange still goes through its transport: identity, but the path is exercised)
   if (h->allreduce(h->allreduce_ctx, buf, count, op, h->stream) != 0) return rsba_set_error(RSBA_ERR_COMM, "all-reduce callback failed");
   return RSBA_OK;
 }
@@ -649,17 +698,30 @@ int32_t exchange(rsba_handle* h, double* buf, int64_t count, int op) {
 // scalars[kCost, kFixedCost, kEvalFailed].
 int32_t linearize(rsba_handle* h) {
   Solver* s = h->solver;
-  HIP_TRY(hipMemsetAsync(h->dp.fail_count, 0, sizeof(int), h->stream));
-  HIP_TRY(launch_eval(h->dp, kLmJacobian, h->stream));
-  HIP_TRY(launch_cost_reduce(h->dp, h->d_cost2, h->stream));
-  HIP_TRY(launch_camera_blocks(h->dp, s->sv, h->stream));
-  HIP_TRY(launch_intr_blocks(h->dp, s->sv, h->stream));
-  if (s->ucross && s->sv.lead) {   // motion priors: replicated terms, contributed by the lead rank
-    HIP_TRY(launch_prior_cost(h->dp, h->d_cost2, h->prior_invalid, h->stream));
-    HIP_TRY(launch_prior_blocks(h->dp, s->sv, s->ucross, h->stream));
+  {
+    PhaseScope ps(h, RSBA_PHASE_EVAL_LM);
+    HIP_TRY(hipMemsetAsync(h->dp.fail_count, 0, sizeof(int), h->stream));
+    HIP_TRY(launch_eval(h->dp, kLmJacobian, h->stream));
+    HIP_TRY(launch_cost_reduce(h->dp, h->d_cost2, h->stream));
   }
-  if (s->border) HIP_TRY(launch_prior_border(h->dp, s->sv, s->border, s->ratio4, h->stream));   // every rank: from replicated poses
-  HIP_TRY(launch_point_blocks(h->dp, s->sv, h->stream));
+  {
+    PhaseScope ps(h, RSBA_PHASE_CAMERA_BLOCKS);
+    HIP_TRY(launch_camera_blocks(h->dp, s->sv, h->stream));
+    HIP_TRY(launch_intr_blocks(h->dp, s->sv, h->stream));
+  }
+  if ((s->ucross && s->sv.lead) || s->border) {
+    PhaseScope ps(h, RSBA_PHASE_PRIORS);
+    if (s->ucross && s->sv.lead) {   // motion priors: replicated terms, contributed by the lead rank
+      HIP_TRY(launch_prior_cost(h->dp, h->d_cost2, h->prior_invalid, h->stream));
+      HIP_TRY(launch_prior_blocks(h->dp, s->sv, s->ucross, h->stream));
+    }
+    if (s->border) HIP_TRY(launch_prior_border(h->dp, s->sv, s->border, s->ratio4, h->stream));   // every rank: from replicated poses
+  }
+  {
+    PhaseScope ps(h, RSBA_PHASE_POINT_BLOCKS);
+    HIP_TRY(launch_point_blocks(h->dp, s->sv, h->stream));
+  }
+  PhaseScope ps(h, RSBA_PHASE_EXCHANGE);
   HIP_TRY(launch_pack_linearize(h->dp, s->sv, h->d_cost2, h->stream));
   int32_t rc = exchange(h, s->sv.xbuf, 2 * s->sv.n + 3, 0);
   if (rc) return rc;
@@ -669,6 +731,7 @@ int32_t linearize(rsba_handle* h) {
 
 int32_t gradient_max(rsba_handle* h) {
   Solver* s = h->solver;
+  PhaseScope ps(h, RSBA_PHASE_OTHER);
   HIP_TRY(launch_gradient_max(h->dp, s->sv, h->stream));
   return exchange(h, s->sv.scalars + kGradMax, 1, 1);
 }
@@ -676,12 +739,19 @@ int32_t gradient_max(rsba_handle* h) {
 // reduced camera system S and rhs at the given trust-region radius (point elimination), summed over the ranks
 int32_t reduce_system(rsba_handle* h, double radius) {
   Solver* s = h->solver; const SolverDev& sv = s->sv; hipStream_t st = h->stream;
-  HIP_TRY(launch_point_factor(h->dp, sv, radius, st));
-  HIP_TRY(launch_project(h->dp, sv, st));
-  HIP_TRY(launch_virtual_records(h->dp, sv, st));
-  HIP_TRY(launch_clear_system(sv, st));
-  HIP_TRY(launch_schur_blocks(h->dp, sv, radius, st));
+  { PhaseScope ps(h, RSBA_PHASE_POINT_FACTOR); HIP_TRY(launch_point_factor(h->dp, sv, radius, st)); }
+  {
+    PhaseScope ps(h, RSBA_PHASE_PROJECT);
+    HIP_TRY(launch_project(h->dp, sv, st));
+    HIP_TRY(launch_virtual_records(h->dp, sv, st));
+  }
+  {
+    PhaseScope ps(h, RSBA_PHASE_SCHUR);
+    HIP_TRY(launch_clear_system(sv, st));
+    HIP_TRY(launch_schur_blocks(h->dp, sv, radius, st));
+  }
   // exchange (2): partial reduced camera systems -> the full one on every rank (then factored redundantly)
+  PhaseScope ps(h, RSBA_PHASE_EXCHANGE);
   return exchange(h, sv.S, (int64_t)sv.nslots * kTile * kTile + sv.npad, 0);
 }
 
@@ -690,6 +760,7 @@ int32_t reduce_system(rsba_handle* h, double radius) {
 // (the factor has its own tiles); y lands in sv.yv.
 int32_t solve_reduced_system(rsba_handle* h) {
   Solver* s = h->solver; const SolverDev& sv = s->sv; hipStream_t st = h->stream;
+  PhaseScope ps(h, RSBA_PHASE_CHOLESKY);
   if (!s->use_levels) {
     HIP_TRY(launch_chol_dag(sv, s->plan, s->dag_workgroups, st));
   } else {
@@ -731,6 +802,7 @@ int32_t factor_and_solve(rsba_handle* h, double radius, RatioStep* ratio = nullp
   } else {
     HIP_TRY(hipMemcpyAsync(sv.rhs, sv.yv, (size_t)sv.npad * sizeof(double), hipMemcpyDeviceToDevice, st));   // camera step
   }
+  PhaseScope ps(h, RSBA_PHASE_BACK_SUBSTITUTE);
   HIP_TRY(launch_back_substitute(h->dp, sv, st));
   return RSBA_OK;
 }
@@ -800,6 +872,56 @@ extern "C" int32_t rsba_set_block_structure(rsba_handle* h, const uint8_t* mask,
   return RSBA_OK;
 }
 
+extern "C" int32_t rsba_get_phase_times(rsba_handle* h, rsba_phase_times* out) {
+  if (!h || !out) return rsba_set_error(RSBA_ERR_INVALID_ARGUMENT, "null argument");
+  std::memset(out, 0, sizeof *out);
+  if (!h->solver) return RSBA_OK;
+  for (int p = 0; p < RSBA_NUM_PHASES; ++p) { out->ms[p] = h->solver->timer.ms[p]; out->calls[p] = h->solver->timer.calls[p]; }
+  return RSBA_OK;
+}
+extern "C" const char* rsba_phase_name(int32_t phase) {
+  static const char* names[RSBA_NUM_PHASES] = {"eval_lm", "camera_blocks", "point_blocks", "point_factor", "project", "schur", "cholesky",
+                                               "back_substitute", "candidate", "eval_trial", "priors", "exchange", "other"};
+  return phase >= 0 && phase < RSBA_NUM_PHASES ? names[phase] : "?";
+}
+extern "C" int32_t rsba_get_plan_stats(rsba_handle* h, rsba_plan_stats* out) {
+  if (!h || !out) return rsba_set_error(RSBA_ERR_INVALID_ARGUMENT, "null argument");
+  HIP_TRY(hipSetDevice(h->device));
+  int32_t rc = build_solver(h);
+  if (rc) return rc;
+  *out = h->solver->stats;
+  return RSBA_OK;
+}
+
+extern "C" int32_t rsba_sync_block_structure(rsba_handle* h) {
+  if (!h) return rsba_set_error(RSBA_ERR_INVALID_ARGUMENT, "null handle");
+  if (h->solver) return rsba_set_error(RSBA_ERR_INVALID_ARGUMENT, "rsba_sync_block_structure must precede the first solve / gradient call");
+  if (!h->allreduce) return RSBA_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t F = (size_t)h->dp.F, M = (size_t)h->dp.M, count = F * F + F + M;
+  std::vector<uint8_t> mask(F * F); std::vector<int64_t> cnt(F);
+  int32_t rc = rsba_get_block_structure(h, mask.data(), cnt.data());
+  if (rc) return rc;
+  // one all-reduce (sum) of [mask | per-frame counts | per-point "observed here" flags], as doubles: the exchange's type
+  std::vector<double> host(count, 0.0);
+  for (size_t i = 0; i < F * F; ++i) host[i] = mask[i];
+  for (size_t f = 0; f < F; ++f) host[F * F + f] = (double)cnt[f];
+  for (int64_t i = 0; i < h->dp.N; ++i) host[F * F + F + (size_t)h->obs_point[i]] = 1.0;
+  double* dev = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dev), count * sizeof(double)));
+  hipError_t e = hipMemcpyAsync(dev, host.data(), count * sizeof(double), hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess) { rc = exchange(h, dev, (int64_t)count, 0); if (rc) { (void)hipFree(dev); return rc; } }
+  if (e == hipSuccess) e = hipMemcpyAsync(host.data(), dev, count * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  (void)hipFree(dev);
+  if (e != hipSuccess) return rsba_set_error(RSBA_ERR_HIP, hipGetErrorString(e));
+  for (size_t j = 0; j < M; ++j)
+    if (host[F * F + F + j] > 1.0) return rsba_set_error(RSBA_ERR_INVALID_ARGUMENT, "a point has observations on more than one rank: partition the observations by point");
+  for (size_t i = 0; i < F * F; ++i) mask[i] = host[i] != 0.0;
+  for (size_t f = 0; f < F; ++f) cnt[f] = (int64_t)host[F * F + f];
+  return rsba_set_block_structure(h, mask.data(), cnt.data());
+}
+
 extern "C" int32_t rsba_normal_equations(rsba_handle* h, double* U, double* gc, double* V, double* gp) {
   if (!h) return rsba_set_error(RSBA_ERR_INVALID_ARGUMENT, "null handle");
   HIP_TRY(hipSetDevice(h->device));
@@ -847,15 +969,33 @@ extern "C" int32_t rsba_pose_covariance(rsba_handle* h, int32_t frame, double* c
     if ((rc = solve_reduced_system(h))) return rc;
     HIP_TRY(hipMemcpyAsync(&col[(size_t)k * CD], sv.yv + (size_t)frame * CD, (size_t)CD * sizeof(double), hipMemcpyDeviceToHost, st));
   }
+  // A free interFrameRatio is one more parameter block of J^T J, coupled to every pose through its column b (the 1-wide
+  // border of the reduced system, diagonal entry h): by the block inverse the pose block of the bordered system is
+  // S^-1 + v v^T / (h - b.v) with S v = b — what ceres::Covariance returns for the problem CeresHandler builds by default.
+  std::vector<double> vf; double hb[3] = {0.0, 0.0, 0.0};
+  if (s->border) {
+    HIP_TRY(hipMemcpyAsync(sv.rhs, s->border, (size_t)sv.npad * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if ((rc = solve_reduced_system(h))) return rc;
+    HIP_TRY(launch_border_dots(s->border, sv.yv, sv.yv, sv.npad, s->ratio4 + 2, st));
+    vf.resize(CD);
+    HIP_TRY(hipMemcpyAsync(vf.data(), sv.yv + (size_t)frame * CD, (size_t)CD * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(hb, s->ratio4, sizeof hb, hipMemcpyDeviceToHost, st));     // {h, g, b.v}
+  }
   int fail = 0, nfail = 0;
   HIP_TRY(hipMemcpyAsync(&fail, sv.chol_fail, sizeof(int), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(&nfail, h->dp.fail_count, sizeof(int), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   if (nfail) return rsba_set_error(RSBA_ERR_EVALUATION_FAILED, "residual and Jacobian evaluation failed");
   if (fail) return rsba_set_error(RSBA_ERR_UNSUPPORTED, "J^T J is rank deficient (fix the gauge): no covariance, as ceres::Covariance::Compute returns false");
+  double border_scale = 0.0;
+  if (s->border) {
+    const double schur = hb[0] - hb[2];    // the ratio's own pivot of the bordered system
+    if (!(schur > 0.0) || !std::isfinite(schur)) return rsba_set_error(RSBA_ERR_UNSUPPORTED, "J^T J is rank deficient in the interFrameRatio: no covariance");
+    border_scale = 1.0 / schur;
+  }
   for (int a = 0; a < CD; ++a) for (int b = 0; b < CD; ++b) {
     const double ma = h->mask_pose[(size_t)frame * CD + a], mb = h->mask_pose[(size_t)frame * CD + b];
-    cov[(size_t)a * CD + b] = (ma != 0.0 && mb != 0.0) ? col[(size_t)b * CD + a] : 0.0;
+    cov[(size_t)a * CD + b] = (ma != 0.0 && mb != 0.0) ? col[(size_t)b * CD + a] + (s->border ? vf[a] * vf[b] * border_scale : 0.0) : 0.0;
   }
   return RSBA_OK;
 }
@@ -869,12 +1009,14 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
   if (rc) return rc;
   Solver* s = h->solver; SolverDev& sv = s->sv; DeviceProblem& dp = h->dp; hipStream_t st = h->stream;
   sum->termination_type = RSBA_NO_CONVERGENCE;
+  s->timer.on = opt->profile_phases != 0;
+  if (s->timer.on) s->timer.reset();
   { const char* lv = std::getenv("RSBA_CHOL_LEVELS"); s->use_levels = opt->level_scheduled_cholesky != 0 || (lv && lv[0] == '1'); }
   {
     // problem-size figures of the whole (all-rank) problem
     const double npri = sv.lead ? (double)h->prior_frames.size() : 0.0;
     double cnt[3] = {(double)dp.N + npri, (double)(s->num_reduced_blocks + s->num_priors_reduced), (double)s->num_reduced_params};
-    if (h->world > 1) {
+    if (h->allreduce) {
       HIP_TRY(hipMemcpyAsync(sv.scalars + 8, cnt, sizeof cnt, hipMemcpyHostToDevice, st));
       if ((rc = exchange(h, sv.scalars + 8, 3, 0))) return rc;
       HIP_TRY(hipMemcpyAsync(cnt, sv.scalars + 8, sizeof cnt, hipMemcpyDeviceToHost, st));
@@ -901,6 +1043,7 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
     HIP_TRY(hipMemcpyAsync(host_sc, sv.scalars, sizeof host_sc, hipMemcpyDeviceToHost, st));
     if (free_ratio) HIP_TRY(hipMemcpyAsync(ratio_hg, s->ratio4, sizeof ratio_hg, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    if (s->timer.on) s->timer.resolve();
     cost2[0] = host_sc[kCost]; cost2[1] = host_sc[kFixedCost];
     nfail = host_sc[kEvalFailed] != 0.0; cfail = host_sc[kSolveFailed] != 0.0;
     return RSBA_OK;
@@ -910,10 +1053,17 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
     sum->is_solution_usable = term != RSBA_FAILURE;
     (void)reset_scales(h);
     const size_t npose = (size_t)dp.F * dp.P * 6, npt = (size_t)dp.M * 3;
+    if (h->allreduce && h->world > 1) {   // every rank leaves with the complete point array: each point from its owner
+      HIP_TRY(launch_own_points(dp, sv, s->merge_buf, st));
+      int32_t rc2 = exchange(h, s->merge_buf, 4 * (int64_t)dp.M, 0);
+      if (rc2) return rc2;
+      HIP_TRY(launch_merge_points(dp, s->merge_buf, st));
+    }
     HIP_TRY(hipMemcpyAsync(h->desc.poses, dp.poses, npose * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(h->desc.points, dp.points, npt * sizeof(double), hipMemcpyDeviceToHost, st));
     if (!dp.calibrated) HIP_TRY(hipMemcpyAsync(h->desc.intrinsics, dp.intr, (size_t)dp.NI * 9 * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    if (s->timer.on) { s->timer.resolve(); s->timer.on = false; }
     h->prior_ratio_result = dp.prior_ratio;
     sum->total_time_s = now_s() - t_start;
     if (const char* path = h->solver->d_trace ? std::getenv("RSBA_CHOL_TRACE") : nullptr) {   // debugging aid, off by default
@@ -965,6 +1115,7 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
     if (iteration >= opt->max_num_iterations) return finish(RSBA_NO_CONVERGENCE);
     t0 = now_s();
     if (!reuse_diagonal) {
+      PhaseScope ps(h, RSBA_PHASE_OTHER);
       HIP_TRY(launch_clamp_diagonal(dp, sv, opt->min_lm_diagonal, opt->max_lm_diagonal, st));
       ratio_diag = std::min(std::max(ratio_scale * ratio_scale * ratio_hg[0], opt->min_lm_diagonal), opt->max_lm_diagonal);
     }
@@ -974,24 +1125,31 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
     reuse_diagonal = true;
     const double ratio_step = free_ratio ? ratio_scale * rs.eta : 0.0;      // the ratio's step in its own units is -ratio_step
     ratio_new = free_ratio ? std::max(ratio_lb, ratio - ratio_step) : ratio;
-    HIP_TRY(launch_model_cost_change(dp, sv, st));
-    if (s->ucross && sv.lead) HIP_TRY(launch_prior_model(dp, sv, sv.scalars + kModelCostChange, std::isfinite(ratio_step) ? ratio_step : 0.0, st));
-    HIP_TRY(launch_candidate(dp, sv, st));
+    { PhaseScope ps(h, RSBA_PHASE_BACK_SUBSTITUTE); HIP_TRY(launch_model_cost_change(dp, sv, st)); }
+    if (s->ucross && sv.lead) { PhaseScope ps(h, RSBA_PHASE_PRIORS); HIP_TRY(launch_prior_model(dp, sv, sv.scalars + kModelCostChange, std::isfinite(ratio_step) ? ratio_step : 0.0, st)); }
+    { PhaseScope ps(h, RSBA_PHASE_CANDIDATE); HIP_TRY(launch_candidate(dp, sv, st)); }
     // residuals only at the candidate (T = double path)
     swap_params();
-    HIP_TRY(hipMemsetAsync(dp.fail_count, 0, sizeof(int), st));
-    HIP_TRY(launch_eval(dp, kResidualOnly, st));
-    HIP_TRY(launch_cost_reduce(dp, h->d_cost2, st));
+    {
+      PhaseScope ps(h, RSBA_PHASE_EVAL_TRIAL);
+      HIP_TRY(hipMemsetAsync(dp.fail_count, 0, sizeof(int), st));
+      HIP_TRY(launch_eval(dp, kResidualOnly, st));
+      HIP_TRY(launch_cost_reduce(dp, h->d_cost2, st));
+    }
     if (s->ucross && sv.lead) {
+      PhaseScope ps(h, RSBA_PHASE_PRIORS);
       dp.prior_ratio = std::isfinite(ratio_new) ? ratio_new : ratio;
       HIP_TRY(launch_prior_cost(dp, h->d_cost2, h->prior_invalid, st));
       dp.prior_ratio = ratio;
     }
     swap_params();
     // exchange (3): model decrease, |step|^2, |x|^2, (skip the max slot), trial cost, -, failure flags
-    HIP_TRY(launch_pack_trial(dp, sv, h->d_cost2, st));
-    if ((rc = exchange(h, sv.scalars, 3, 0))) return rc;
-    if ((rc = exchange(h, sv.scalars + kCost, 4, 0))) return rc;
+    {
+      PhaseScope ps(h, RSBA_PHASE_EXCHANGE);
+      HIP_TRY(launch_pack_trial(dp, sv, h->d_cost2, st));
+      if ((rc = exchange(h, sv.scalars, 3, 0))) return rc;
+      if ((rc = exchange(h, sv.scalars + kCost, 4, 0))) return rc;
+    }
     if ((rc = read_back())) return rc;
     cost2[1] = 0.0;   // the trial evaluation reports the total in kCost
     sum->linear_solver_time_s += now_s() - t0;

@@ -141,6 +141,8 @@ hipError_t launch_virtual_records(const DeviceProblem& dp, const SolverDev& sv, 
 hipError_t launch_pack_linearize(const DeviceProblem& dp, const SolverDev& sv, const double* cost2, hipStream_t st);
 hipError_t launch_unpack_linearize(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);
 hipError_t launch_pack_trial(const DeviceProblem& dp, const SolverDev& sv, const double* cost2, hipStream_t st);
+hipError_t launch_own_points(const DeviceProblem& dp, const SolverDev& sv, double* buf4m, hipStream_t st);   // sharded solve: [M][3] owned values | [M] owner flag
+hipError_t launch_merge_points(const DeviceProblem& dp, const double* buf4m, hipStream_t st);
 hipError_t launch_unscaled_gradient(const DeviceProblem& dp, const SolverDev& sv, double* g_pose, double* g_point, hipStream_t st);
 
 }  // namespace rsba

@@ -6,9 +6,9 @@ iteration the ranks all-reduce (include/rsba_amd.h, "multi-GPU"):
   (1) per-camera gradient blocks g_c + diag(U) + cost scalars         2*F*CD + 3 doubles
   (2) the packed non-zero tiles of the partial reduced camera system  nslots*48*48 + F*CD doubles
   (3) eight step scalars
-and then factor the (identical) reduced system redundantly.  The collective itself is torch.distributed
-("nccl" = RCCL over xGMI on the GPU box); a "gloo" process group is served by staging through the host,
-which is how the exchange logic is tested without several GPUs.
+and then factor the (identical) reduced system redundantly.  The collective itself is RCCL called by the library on the solver's stream
+(attach_rccl -> rsba_set_exchange_rccl: no Python inside an LM iteration); the callback form (attach) lets a host bring
+its own transport — a "gloo" process group staged through the host is how the exchange logic is tested without several GPUs.
 """
 from __future__ import annotations
 
@@ -74,22 +74,33 @@ def union_structure(mask: np.ndarray, counts: np.ndarray, group=None):
 
 
 def attach(dp, group=None):
-    """Install the exchange on a DeviceProblem holding this rank's shard.  Call before the first solve."""
-    import torch
+    """Install the CALLBACK exchange (torch.distributed serves the all-reduce; gloo in the tests) on a DeviceProblem
+    holding this rank's shard.  Call before the first solve.  Production runs use attach_rccl."""
     import torch.distributed as dist
     from . import capi
 
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    F = dp.prob.num_frames
-    mask = np.zeros((F, F), dtype=np.uint8)
-    counts = np.zeros(F, dtype=np.int64)
-    capi._check(capi.lib().rsba_get_block_structure(dp._h, mask.ctypes.data_as(C.c_void_p), counts.ctypes.data_as(C.c_void_p)))
-    mask, counts = union_structure(mask, counts, group)
-    mask, counts = np.ascontiguousarray(mask), np.ascontiguousarray(counts)
-    capi._check(capi.lib().rsba_set_block_structure(dp._h, mask.ctypes.data_as(C.c_void_p), counts.ctypes.data_as(C.c_void_p)))
     dp._exchange_cb = make_allreduce(group)       # keep the callback object alive as long as the handle
     capi._check(capi.lib().rsba_set_exchange(dp._h, dp._exchange_cb, None, C.c_int32(rank), C.c_int32(world)))
+    dp.sync_block_structure()                     # union of the ranks' co-visibility structures, through the exchange itself
     return dp
+
+
+def attach_rccl(dp, device: int, group=None):
+    """Install the NATIVE exchange: the library calls ncclAllReduce (RCCL over xGMI) on its own stream; Python is only used
+    here, once, to hand rank 0's unique id to the other ranks.  Returns the communicator (rccl_comm_destroy it after
+    the DeviceProblem is closed)."""
+    import torch.distributed as dist
+    from . import capi
+
+    rank, world = (dist.get_rank(group), dist.get_world_size(group)) if dist.is_initialized() else (0, 1)
+    box = [capi.rccl_unique_id() if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(box, src=0, group=group)
+    comm = capi.rccl_comm_create(box[0], rank, world, device)
+    dp.set_exchange_rccl(comm, rank, world)
+    dp.sync_block_structure()
+    return comm
 
 
 def solve_timed(dp, prob, world: int, iters: int):
@@ -115,8 +126,9 @@ def solve_timed(dp, prob, world: int, iters: int):
 
 
 def gather_points(prob, group=None):
-    """After a sharded solve every rank holds the adjusted values of the points it owns (j % world == rank);
-    merge them so each rank ends with the full point array (poses are already identical everywhere)."""
+    """Host-side merge of the points over the ranks (ownership j % world == rank).  rsba_solve does this merge itself on
+    the device since round 2 (every rank leaves a sharded solve with the complete arrays); kept for hosts that shard
+    some other way and as the reference the tests compare that merge with."""
     import torch
     import torch.distributed as dist
 

@@ -76,7 +76,10 @@ def main():
         attach(dp)
         s, tr = dp.solve(capi.default_options(**opts))
         dp.close()
+        # rsba_solve merged the points over the ranks on the device: the host-side merge must be a no-op
+        merged = shard.points.copy()
         gather_points(shard)
+        out["native_merge_equals_host_merge"] = bool(np.array_equal(merged, shard.points))
         out.update(ratio=shard.inter_frame_ratio, final_cost=s.final_cost, initial_cost=s.initial_cost, iters=s.num_iterations, reduced=s.num_residual_blocks_reduced,
                    params=s.num_parameters_reduced, term=s.termination_type)
         if rank == 0:

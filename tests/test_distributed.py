@@ -41,6 +41,7 @@ def test_sharded_solve_equals_single_gpu_solve(tmp_path, mode):
     res = run_two_ranks(mode, tmp_path)
     a, b = res
     assert a["final_cost"] == b["final_cost"] and a["iters"] == b["iters"]          # ranks decide identically
+    assert a["native_merge_equals_host_merge"] and b["native_merge_equals_host_merge"]
     assert a["iters"] == a["ref_iters"] and a["reduced"] == a["ref_reduced"] and a["params"] == a["ref_params"]
     assert abs(a["initial_cost"] - a["ref_initial"]) <= 1e-12 * a["ref_initial"]
     assert a["traj_err"] <= 1e-9
@@ -48,3 +49,54 @@ def test_sharded_solve_equals_single_gpu_solve(tmp_path, mode):
     assert a["pose_err"] <= 1e-7 and a["point_err"] <= 1e-6
     assert a["ratio"] == b["ratio"] and abs(a["ratio"] - a["ref_ratio"]) <= 1e-8
     assert (mode == "gpu_free_ratio") == (a["ratio"] not in (1.0, 1.2))
+
+
+@pytest.mark.gpu
+def test_native_rccl_transport_one_rank():
+    """rsba_set_exchange_rccl: ncclCommInitRank + ncclAllReduce issued by the library on the solver's stream.  One rank is
+    all a one-GPU box can hold (RCCL refuses two ranks on one device); the all-reduces still run — as identities — so the
+    solve must equal the plain single-GPU solve to the bit."""
+    import numpy as np
+    from rsba_amd import capi
+    from rsba_amd.distributed import attach_rccl
+    from rsba_amd.problem import apply_gauge_masks
+    from rsba_amd.scene import make_scene
+    p = make_scene(24, 1500, seed=5).problem
+    apply_gauge_masks(p, fix_first_n_cameras=1)
+    p.pose_fixed_mask[-1, -1] |= 0b111000
+    q = p.copy()
+    with capi.DeviceProblem(p) as dp:
+        s, _ = dp.solve(capi.default_options(max_num_iterations=8))
+    dq = capi.DeviceProblem(q)
+    comm = attach_rccl(dq, 0)
+    s2, _ = dq.solve(capi.default_options(max_num_iterations=8, profile_phases=1))
+    t = dq.phase_times()
+    dq.close()
+    capi.rccl_comm_destroy(comm)
+    assert s2.final_cost == s.final_cost and s2.num_iterations == s.num_iterations
+    assert np.array_equal(p.poses, q.poses) and np.array_equal(p.points, q.points)
+    assert t["exchange"][1] > 0 and t["cholesky"][1] == s.num_iterations - 1
+
+
+@pytest.mark.gpu
+def test_bench_strong_scaling_two_ranks_on_one_gpu(tmp_path):
+    """bench.py --gpus 2 through its one-GPU hook: the SAME C2 scene sharded by point over two ranks (gloo callback
+    exchange), observations_total unchanged, the sharded LM reaching the single-GPU cost."""
+    def run(nproc):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RSBA_BENCH_TEST_ONE_GPU="1")
+        args = ["--gpus", str(nproc), "--steps", "5", "--warmup", "1", "--config", "C2", "--no-cpu-baseline", "--no-next-rows", "--lm-iters", "6"]
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args if nproc == 1 else \
+              [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.join(ROOT, "bench.py")] + args
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    one, two = run(1), run(2)
+    assert one["scaling"] == two["scaling"] == "strong"
+    assert one["config"]["observations_total"] == two["config"]["observations_total"]
+    assert two["n_gpus"] == 2 and two["config"]["observations_this_rank"] < one["config"]["observations_this_rank"]
+    assert abs(two["lm"]["final_cost"] - one["lm"]["final_cost"]) <= 1e-9 * one["lm"]["final_cost"]
+    assert abs(two["lm"]["initial_cost"] - one["lm"]["initial_cost"]) <= 1e-12 * one["lm"]["initial_cost"]
+    assert {r["phase"] for r in one["roofline_lm"]["phases"]} >= {"eval_lm", "schur", "cholesky", "project"}

@@ -88,6 +88,39 @@ def test_ba_with_motion_priors_matches_the_oracle(exe, oracle, tmp_path, kind, h
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("free_ratio", [False, True])
+def test_windowed_ba_with_motion_priors_links_the_frame_before_the_window(exe, oracle, tmp_path, free_ratio):
+    """BA(startFrame > 0) with a motion prior: CeresHandler::Add(startFrame) links frame startFrame to startFrame - 1
+    (CeresHandler.h:148-186), whose poses no reprojection block of the window touches — Ceres optimises that prior-only
+    block; old tracks are frozen (:288-300)."""
+    p = small_problem(True, 0.0)
+    s0 = 5
+    ratio = 1.0 if free_ratio else 0.8
+    write_scene_file(tmp_path / "s.bin", p, fix_first_n=1, max_iter=15, const_frame_velocity=8.0, inter_frame_ratio=ratio)
+    r = subprocess.run([exe, str(tmp_path / "s.bin"), str(tmp_path / "o.bin"), str(s0)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr
+    out = read_result_file(tmp_path / "o.bin", p)
+    # the same program for the oracle: frames s0 - 1 .. F - 1 (the first one without observations), tracks seen before s0 constant
+    keep = p.obs_frame >= s0
+    q = p.copy()
+    q.poses = p.poses[s0 - 1:].copy()
+    q.obs_xy, q.obs_frame, q.obs_point = p.obs_xy[keep], p.obs_frame[keep] - (s0 - 1), p.obs_point[keep]
+    q.pose_fixed_mask = np.zeros((q.num_frames, 2), dtype=np.uint8)
+    pc = np.zeros(p.num_points, dtype=np.uint8); pc[np.unique(p.obs_point[p.obs_frame < s0])] = 1
+    q.point_constant = pc
+    q.prior_kind, q.prior_scale, q.inter_frame_ratio, q.ratio_free = 1, 8.0, ratio, free_ratio
+    q.prior_frames = np.arange(1, q.num_frames, dtype=np.int32)
+    first_pose_before = q.poses[0].copy()
+    s_ref, _ = oracle.solve(q, oracle.default_options(max_num_iterations=15))
+    assert out["usable"] and out["reduced"] == s_ref.num_residual_blocks_reduced
+    assert abs(out["initial_cost"] - s_ref.initial_cost) <= 1e-12 * s_ref.initial_cost
+    assert abs(out["final_cost"] - s_ref.final_cost) <= 1e-6 * s_ref.final_cost
+    assert np.max(np.abs(out["poses"][s0 - 1:] - q.poses)) <= 1e-5
+    assert np.array_equal(out["poses"][:s0 - 1], p.poses[:s0 - 1])              # frames before the link are not part of the problem
+    assert np.max(np.abs(q.poses[0] - first_pose_before)) > 1e-6                 # the prior-only frame did move
+
+
+@pytest.mark.gpu
 def test_replaying_a_thrift_session_cache_equals_the_scene_file_path(exe, tmp_path):
     """A Session cache in the reference's on-disk format (Thrift binary in TFileTransport events, written here by the
     independent encoder tests/thrift_encode.py) goes through session_cache.hpp into BA(): same solve as the flat scene file."""

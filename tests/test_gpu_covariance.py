@@ -74,3 +74,18 @@ def test_rank_deficient_problem_is_refused(capi, oracle):
     with capi.DeviceProblem(p) as dp:
         with pytest.raises(capi.RsbaError):
             dp.pose_covariance(3)
+
+
+@pytest.mark.parametrize("kind", [1, 2])
+def test_covariance_with_the_free_inter_frame_ratio(capi, oracle, kind):
+    """The reference's default with motion priors: the interFrameRatio is a free parameter block coupled to every pose, so
+    ceres::Covariance inverts J^T J including its column.  The device path adds the bordered correction
+    S^-1 + v v^T / (h - b.v); the constant-ratio covariance of the same scene is measurably different."""
+    p = gauge_fixed_scene(frames=12, points=500, seed=64)
+    p.prior_kind, p.prior_scale, p.inter_frame_ratio, p.ratio_free = kind, 9.0, 1.0, True
+    p.prior_frames = np.arange(1, p.num_frames, dtype=np.int32)
+    check(capi, oracle, p, [1, 6, p.num_frames - 1])
+    q = p.copy(); q.ratio_free = False
+    with capi.DeviceProblem(p) as dp, capi.DeviceProblem(q) as dq:
+        a, b = dp.pose_covariance(6), dq.pose_covariance(6)
+    assert np.abs(a - b).max() > 1e-6 * np.abs(a).max()

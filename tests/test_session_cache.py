@@ -65,13 +65,13 @@ def test_session_round_trip_with_skipped_fields_and_random_event_splits(tool, tm
 
 
 def test_chunk_boundary_padding_and_global_shutter_default(tool, tmp_path):
-    fr = T.frame([T.observation(3.0, 4.0, matches=[(1, 2, False)])], cam=[float(k) for k in range(9)], prior_poses=[[0.5] * 6])
+    fr = T.frame([T.observation(3.0, 4.0, matches=[(0, 0, False)])], cam=[float(k) for k in range(9)], prior_poses=[[0.5] * 6])
     payload = T.session([0.0] * 9, [fr], [T.track([(0, 0, True)])], 0, [0, 0], 640, 480)
     # tiny chunks force zero padding between events
     (tmp_path / "s.cache").write_bytes(T.file_events(payload, np.random.default_rng(1), chunk=16 * 1024 * 1024, max_event=9))
     s = dump(tool, "session", tmp_path / "s.cache")
     assert s["rs"] == 0 and s["frames"][0]["cam"] == [float(k) for k in range(9)] and s["frames"][0]["priorPoses"] == [[0.5] * 6]
-    assert s["frames"][0]["obs"][0]["matches"] == [{"frame": 1, "obs": 2, "valid": False}] and "track" not in s["frames"][0]["obs"][0]
+    assert s["frames"][0]["obs"][0]["matches"] == [{"frame": 0, "obs": 0, "valid": False}] and "track" not in s["frames"][0]["obs"][0]
     assert "pt" not in s["tracks"][0] and s["tracks"][0]["valid"] is False
     # an event that would straddle the 16 MiB boundary: zero fill, next event at the boundary
     head = payload[:20]
@@ -89,3 +89,26 @@ def test_corrupt_files_are_refused(tool, tmp_path):
     (tmp_path / "b.cache").write_bytes(struct.pack("<I", 3) + b"\x0f\x00\x01")            # truncated list header
     assert subprocess.run([tool, "dump", "frame", str(tmp_path / "b.cache")], capture_output=True).returncode == 1
     assert subprocess.run([tool, "dump", "frame", str(tmp_path / "missing.cache")], capture_output=True).returncode == 1
+
+
+def test_huge_list_counts_and_dangling_indices_are_refused(tool, tmp_path):
+    """A list count is believed only as far as the remaining bytes can hold it (no multi-GB allocation from 9 bytes), and
+    a Session whose track / observation references point outside the file is refused at load time (CeresHandler::Add
+    would index with them unchecked)."""
+    # Frame: field 3 (cam) = list<double> with a count of 2^30 and no elements behind it
+    payload = T.fld(T.LIST, 3) + struct.pack(">bi", T.DOUBLE, 1 << 30)
+    (tmp_path / "huge.cache").write_bytes(T.file_events(payload))
+    r = subprocess.run([tool, "dump", "frame", str(tmp_path / "huge.cache")], capture_output=True, text=True)
+    assert r.returncode == 1 and "list count" in r.stderr
+    cam = [800, 800, 0, 0, 0, 0, 0, 640, 360]
+    pose = [[0.0] * 6]
+    ok = T.session(cam, [T.frame([T.observation(1, 2, track=0)], poses=pose)], [T.track([(0, 0, True)], pt=[0, 0, 5], valid=True)], 0, [0, 0], 1280, 720)
+    (tmp_path / "ok.cache").write_bytes(T.file_events(ok))
+    assert subprocess.run([tool, "dump", "session", str(tmp_path / "ok.cache")], capture_output=True).returncode == 0
+    bad_track = T.session(cam, [T.frame([T.observation(1, 2, track=3)], poses=pose)], [T.track([(0, 0, True)], pt=[0, 0, 5], valid=True)], 0, [0, 0], 1280, 720)
+    bad_ref = T.session(cam, [T.frame([T.observation(1, 2, track=0)], poses=pose)], [T.track([(0, 7, True)], pt=[0, 0, 5], valid=True)], 0, [0, 0], 1280, 720)
+    bad_match = T.session(cam, [T.frame([T.observation(1, 2, track=0, matches=[(4, 0, True)])], poses=pose)], [T.track([(0, 0, True)], pt=[0, 0, 5], valid=True)], 0, [0, 0], 1280, 720)
+    for name, blob in (("t", bad_track), ("r", bad_ref), ("m", bad_match)):
+        (tmp_path / f"{name}.cache").write_bytes(T.file_events(blob))
+        r = subprocess.run([tool, "dump", "session", str(tmp_path / f"{name}.cache")], capture_output=True, text=True)
+        assert r.returncode == 1 and "does not exist" in r.stderr, (name, r.stderr)
