@@ -57,7 +57,7 @@ static int replay_cache(int argc, char** argv) {
 
 int main(int argc, char** argv) {
   if (argc >= 4 && !std::strcmp(argv[1], "--cache")) return replay_cache(argc, argv);
-  if (argc < 3) { std::fprintf(stderr, "usage: %s scene.bin out.bin [startFrame]\n", argv[0]); return 2; }
+  if (argc < 3) { std::fprintf(stderr, "usage: %s scene.bin out.bin [startFrame] [camEvery]\n", argv[0]); return 2; }
   FILE* f = std::fopen(argv[1], "rb");
   if (!f) { std::perror("scene"); return 2; }
   int32_t hd[11]; int64_t N; double huber, reval, covf, motion[3], cam[9];
@@ -93,6 +93,9 @@ int main(int argc, char** argv) {
   ceres::Solver::Summary summary;
   std::vector<std::vector<double>> covs;
   const int startFrame = argc > 3 ? std::atoi(argv[3]) : 0;            // windowed BA (VideoSfMClient.cc:243): frames [startFrame, F - 1]
+  const int camEvery = argc > 4 ? std::atoi(argv[4]) : 0;              // > 0: every camEvery-th frame carries its own Frame.cam (sfm.thrift:48),
+  for (int i = 0; camEvery > 0 && i < F; ++i)                          // which CeresHandler::Add uses as that frame's intrinsics block (:260,277)
+    if (i % camEvery == camEvery - 1) { sess.frames[i].cam = sess.cam; sess.frames[i].__isset.cam = true; }
   const bool usable = BA(sess, startFrame, F - 1, opt, hd[10], &summary, true, &covs);
 
   return write_result(argv[2], sess, summary, usable, covs, covf);

@@ -23,6 +23,7 @@
 #include <limits>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <set>
 #include <sstream>
 #include <stdexcept>
@@ -118,27 +119,37 @@ class ReprojectionCost : public CostFunction {
   void scanlines(int32_t out[2]) const { out[0] = (rolling_ && sess_ && sess_->scanlines.size() >= 2) ? sess_->scanlines[0] : 0; out[1] = (rolling_ && sess_ && sess_->scanlines.size() >= 2) ? sess_->scanlines[1] : 1; }
   bool interpolate_rotation() const { return opt_ ? opt_->model.interpolateRotation : true; }
 
-  // CostFunction::Evaluate for one block: a one-observation problem through the same HIP kernel
+  ~ReprojectionCost() override { if (h_) rsba_destroy(h_); }
+  ReprojectionCost(const ReprojectionCost&) = delete;
+  ReprojectionCost& operator=(const ReprojectionCost&) = delete;
+
+  // CostFunction::Evaluate for one block: a one-observation problem through the same HIP kernel.  The device problem is
+  // built on the first call and kept: later calls only upload the parameter blocks they are given (it is rebuilt if the
+  // session / option fields the functor reads at evaluation time have changed).
   bool Evaluate(double const* const* parameters, double* residuals, double** jacobians) const override {
-    rsba_problem_desc d; std::memset(&d, 0, sizeof d);
     int b = 0;
     double cam[NUM_CAM_PARAMS], poses[2 * NUM_POSE_PARAMS], point[NUM_POINT_PARAMS];
     std::memcpy(cam, with_cam_ ? parameters[b++] : cam_, sizeof cam);
     std::memcpy(poses, parameters[b++], NUM_POSE_PARAMS * sizeof(double));
     if (rolling_) std::memcpy(poses + NUM_POSE_PARAMS, parameters[b++], NUM_POSE_PARAMS * sizeof(double));
     std::memcpy(point, parameters[b++], sizeof point);
-    const int32_t zero = 0;
-    d.shutter = shutter(); scanlines(d.scanlines); d.interpolate_rotation = interpolate_rotation();
-    d.calibrated = !with_cam_; d.poses_per_frame = rolling_ ? 2 : 1;
-    d.num_frames = d.num_points = d.num_intrinsics = 1; d.num_observations = 1;
-    d.poses = poses; d.points = point; d.intrinsics = cam; d.obs_xy = obs_; d.obs_frame = &zero; d.obs_point = &zero;
-    rsba_handle* h = nullptr;
-    if (rsba_create(&d, 0, &h) != RSBA_OK) return false;
+    int32_t key[4]; key[0] = shutter(); scanlines(key + 1); key[3] = interpolate_rotation();
+    std::lock_guard<std::mutex> lock(mu_);
+    if (h_ && std::memcmp(key, key_, sizeof key) != 0) { rsba_destroy(h_); h_ = nullptr; }
+    if (!h_) {
+      rsba_problem_desc d; std::memset(&d, 0, sizeof d);
+      const int32_t zero = 0;
+      d.shutter = key[0]; d.scanlines[0] = key[1]; d.scanlines[1] = key[2]; d.interpolate_rotation = key[3];
+      d.calibrated = !with_cam_; d.poses_per_frame = rolling_ ? 2 : 1;
+      d.num_frames = d.num_points = d.num_intrinsics = 1; d.num_observations = 1;
+      d.poses = poses; d.points = point; d.intrinsics = cam; d.obs_xy = obs_; d.obs_frame = &zero; d.obs_point = &zero;
+      if (rsba_create(&d, 0, &h_) != RSBA_OK) { h_ = nullptr; return false; }
+      std::memcpy(key_, key, sizeof key);
+    } else if (rsba_upload_parameters(h_, poses, point, cam) != RSBA_OK) return false;
     const int K = (with_cam_ ? 9 : 0) + (rolling_ ? 12 : 6) + 3;
     std::vector<double> J(2 * (size_t)K);
     int64_t nfail = 0; double cost = 0;
-    const int32_t st = rsba_evaluate(h, &cost, residuals, jacobians ? J.data() : nullptr, nullptr, &nfail);
-    rsba_destroy(h);
+    const int32_t st = rsba_evaluate(h_, &cost, residuals, jacobians ? J.data() : nullptr, nullptr, &nfail);
     if (st != RSBA_OK) return false;
     if (jacobians) {
       int col = 0;
@@ -156,6 +167,9 @@ class ReprojectionCost : public CostFunction {
   double obs_[2], cam_[NUM_CAM_PARAMS];
   const Session* sess_;
   const SfmOptions* opt_;
+  mutable rsba_handle* h_ = nullptr;   // the one-observation device problem behind Evaluate()
+  mutable int32_t key_[4] = {0, 0, 0, 0};
+  mutable std::mutex mu_;
 };
 
 struct CRSMatrix {

@@ -217,6 +217,17 @@ int32_t rsba_validate_observations(rsba_handle* h, double sq_threshold, double m
  * projection moves <= 1e-3 px.  xy_out [n][2], ok_out [n] (host arrays). */
 int32_t rsba_reproject(rsba_handle* h, const int32_t* frames, const int32_t* points, int64_t n, double* xy_out, uint8_t* ok_out);
 
+/* The same two filters for ONE frame without a handle — the shape vision::sfm::validate / reproject are called in
+ * (CeresHandler.h:220-243: the observations of the frame being added against the tracks' points): cam[9], poses
+ * [num_poses][6] (1 or 2), points [n][3], obs_xy [n][2]; valid / ok_out [n], xy_out [n][2]; all host arrays.  Each host
+ * thread keeps one device arena, pinned staging buffer and stream between calls, so a call is one upload, one launch and
+ * one download. */
+int32_t rsba_validate_frame(int32_t device, const double* cam, const double* poses, int32_t num_poses, int32_t shutter, const int32_t* scanlines,
+                            int32_t interpolate_rotation, const double* points, const double* obs_xy, int64_t n, double sq_threshold,
+                            double min_distance, uint8_t* valid);
+int32_t rsba_reproject_frame(int32_t device, const double* cam, const double* poses, int32_t num_poses, int32_t shutter, const int32_t* scanlines,
+                             int32_t interpolate_rotation, const double* points, int64_t n, double* xy_out, uint8_t* ok_out);
+
 /* == the covariance blocks VideoSfMHandler::BA prints with opt.debug.calcCovariances (VideoSfMHandler.cc:602-621:
  * ceres::Covariance::Compute on (p0,p0), (p0,p1), (p1,p1) of a frame): cov [CD][CD] row-major,
  * CD = 6 * poses_per_frame, = the (frame, frame) block of (J^T J)^-1 at the current parameters, loss function applied,

@@ -24,7 +24,7 @@ EXPORTS = [
     "rsba_validate_observations", "rsba_reproject", "rsba_pose_covariance", "rsba_set_motion_priors",
     "rsba_pnp_tasks", "rsba_pnp_inliers", "rsba_set_inter_frame_ratio_free", "rsba_get_inter_frame_ratio",
     "rsba_sync_block_structure", "rsba_rccl_get_unique_id", "rsba_rccl_comm_create", "rsba_rccl_comm_destroy", "rsba_set_exchange_rccl",
-    "rsba_get_phase_times", "rsba_phase_name", "rsba_get_plan_stats",
+    "rsba_get_phase_times", "rsba_phase_name", "rsba_get_plan_stats", "rsba_validate_frame", "rsba_reproject_frame",
 ]
 NUM_PHASES = 13
 
@@ -256,9 +256,11 @@ class DeviceProblem:
 
     def validate_observations(self, sq_threshold: float, min_distance: float = 0.0) -> np.ndarray:
         """vision::sfm::validate for every observation (struct/VideoSfM.cc:159-169) -> bool [N]"""
-        out = np.zeros(self.prob.num_observations, dtype=np.uint8)
+        out = getattr(self, "_valid_buf", None)
+        if out is None or len(out) != self.prob.num_observations:
+            out = self._valid_buf = np.ones(self.prob.num_observations, dtype=np.uint8)   # touched once: no page faults inside the timed copy
         _check(lib().rsba_validate_observations(self._h, C.c_double(sq_threshold), C.c_double(min_distance), _ptr(out)))
-        return out.astype(bool)
+        return out.view(np.bool_).copy()
 
     def reproject(self, frames, points):
         """vision::sfm::reproject (struct/VideoSfM.cc:139-155) for (frame, point) pairs -> xy [n,2], ok [n]"""
@@ -308,6 +310,27 @@ class DeviceProblem:
         if getattr(self.prob, "ratio_free", False) and self.prob.prior_kind:
             self.prob.inter_frame_ratio = self.inter_frame_ratio()       # a free ratio block is solved for, like every parameter
         return s, [tr[i] for i in range(min(s.num_iterations, trace_cap))]
+
+
+def validate_frame(cam, poses, shutter, scanlines, points, obs_xy, sq_threshold, min_distance=0.0, interpolate_rotation=True, device=0):
+    """vision::sfm::validate for the (point, observation) pairs of one frame, no handle (rsba_amd.h: rsba_validate_frame)"""
+    cam = np.ascontiguousarray(cam, dtype=np.float64); ps = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 6)
+    sl = np.ascontiguousarray(scanlines, dtype=np.int32); X = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+    xy = np.ascontiguousarray(obs_xy, dtype=np.float64).reshape(-1, 2)
+    out = np.zeros(len(X), dtype=np.uint8)
+    _check(lib().rsba_validate_frame(C.c_int32(device), _ptr(cam), _ptr(ps), C.c_int32(len(ps)), C.c_int32(int(shutter)), _ptr(sl), C.c_int32(int(interpolate_rotation)),
+                                     _ptr(X), _ptr(xy), C.c_int64(len(X)), C.c_double(sq_threshold), C.c_double(min_distance), _ptr(out)))
+    return out.astype(bool)
+
+
+def reproject_frame(cam, poses, shutter, scanlines, points, interpolate_rotation=True, device=0):
+    """vision::sfm::reproject of points into one frame, no handle (rsba_amd.h: rsba_reproject_frame) -> xy [n,2], ok [n]"""
+    cam = np.ascontiguousarray(cam, dtype=np.float64); ps = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 6)
+    sl = np.ascontiguousarray(scanlines, dtype=np.int32); X = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+    xy = np.zeros((len(X), 2)); ok = np.zeros(len(X), dtype=np.uint8)
+    _check(lib().rsba_reproject_frame(C.c_int32(device), _ptr(cam), _ptr(ps), C.c_int32(len(ps)), C.c_int32(int(shutter)), _ptr(sl), C.c_int32(int(interpolate_rotation)),
+                                      _ptr(X), C.c_int64(len(X)), _ptr(xy), _ptr(ok)))
+    return xy, ok.astype(bool)
 
 
 def rccl_unique_id() -> bytes:

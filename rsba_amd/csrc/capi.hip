@@ -44,6 +44,16 @@ static int32_t dev_upload(rsba_handle* h, T** p, const T* src, size_t count) {
   return RSBA_OK;
 }
 
+// device scratch that outlives the call: (re)allocated only when it has to grow
+template <class T>
+static int32_t grow(rsba_handle* h, T** p, int64_t* cap, int64_t need) {
+  if (need <= *cap && *p) return RSBA_OK;
+  if (*p) { (void)hipFree(*p); h->allocs.erase(std::remove(h->allocs.begin(), h->allocs.end(), static_cast<void*>(*p)), h->allocs.end()); *p = nullptr; }
+  int32_t rc = dev_alloc(h, p, (size_t)need);
+  if (rc == RSBA_OK) *cap = need;
+  return rc;
+}
+
 namespace rsba {
 hipError_t allow_dynamic_lds_impl(const void* kernel, size_t bytes) {
   struct Entry { const void* fn; unsigned long long devices; size_t bytes; };
@@ -158,6 +168,7 @@ int32_t rsba_create(const rsba_problem_desc* d, int32_t device, rsba_handle** ou
   std::vector<int32_t> fi(dp.F, 0);
   if (d->frame_intrinsics) std::copy(d->frame_intrinsics, d->frame_intrinsics + dp.F, fi.begin());
   if ((rc = dev_upload(h, &dfi, fi.data(), (size_t)dp.F))) return bail(rc);
+  h->frame_intr = fi;
   dp.xy = dxy; dp.obs_frame = dof; dp.obs_point = dop; dp.frame_intr = dfi;
   h->obs_frame = std::move(of); h->obs_point = std::move(op);
   if ((rc = dev_upload(h, &dp.poses, d->poses, npose))) return bail(rc);
@@ -343,15 +354,21 @@ int32_t rsba_validate_observations(rsba_handle* h, double sq_threshold, double m
   HIP_TRY(hipSetDevice(h->device));
   const int64_t N = h->dp.N;
   if (N == 0) return RSBA_OK;
-  uint8_t* d = nullptr;
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), (size_t)N));
-  std::vector<uint8_t> tmp((size_t)N);
-  hipError_t e = launch_validate(h->dp, sq_threshold, min_distance, d, h->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(tmp.data(), d, (size_t)N, hipMemcpyDeviceToHost, h->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-  (void)hipFree(d);
-  if (e != hipSuccess) return fail(RSBA_ERR_HIP, hipGetErrorString(e));
-  for (int64_t i = 0; i < N; ++i) valid[h->order[i]] = tmp[i];
+  int32_t rc = grow(h, &h->d_flags, &h->flags_cap, N);
+  if (rc) return rc;
+  HIP_TRY(launch_validate(h->dp, sq_threshold, min_distance, h->d_flags, h->stream));
+  const uint8_t* src = h->d_flags;
+  if (!h->identity_order) {   // back to the caller's observation order on the device
+    if (!h->d_order) {
+      if ((rc = dev_alloc(h, &h->d_order, (size_t)N))) return rc;
+      HIP_TRY(hipMemcpyAsync(h->d_order, h->order.data(), (size_t)N * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    }
+    if ((rc = grow(h, &h->d_flags_out, &h->flags_out_cap, N))) return rc;
+    HIP_TRY(launch_scatter_flags(h->d_flags, h->d_order, N, h->d_flags_out, h->stream));
+    src = h->d_flags_out;
+  }
+  HIP_TRY(hipMemcpyAsync(valid, src, (size_t)N, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
   return RSBA_OK;
 }
 
@@ -361,19 +378,17 @@ int32_t rsba_reproject(rsba_handle* h, const int32_t* frames, const int32_t* poi
     if (frames[i] < 0 || frames[i] >= h->dp.F || points[i] < 0 || points[i] >= h->dp.M) return fail(RSBA_ERR_INVALID_ARGUMENT, "index out of range");
   if (n <= 0) return RSBA_OK;
   HIP_TRY(hipSetDevice(h->device));
-  int32_t *df = nullptr, *dq = nullptr; double* dxy = nullptr; uint8_t* dok = nullptr;
-  hipError_t e = hipMalloc(reinterpret_cast<void**>(&df), (size_t)n * 4);
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&dq), (size_t)n * 4);
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&dxy), (size_t)n * 16);
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&dok), (size_t)n);
-  if (e == hipSuccess) e = hipMemcpyAsync(df, frames, (size_t)n * 4, hipMemcpyHostToDevice, h->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(dq, points, (size_t)n * 4, hipMemcpyHostToDevice, h->stream);
-  if (e == hipSuccess) e = launch_reproject(h->dp, df, dq, n, dxy, dok, h->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(xy_out, dxy, (size_t)n * 16, hipMemcpyDeviceToHost, h->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(ok_out, dok, (size_t)n, hipMemcpyDeviceToHost, h->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-  (void)hipFree(df); (void)hipFree(dq); (void)hipFree(dxy); (void)hipFree(dok);
-  if (e != hipSuccess) return fail(RSBA_ERR_HIP, hipGetErrorString(e));
+  int32_t rc = grow(h, &h->d_pairs, &h->pairs_cap, 2 * n);
+  if (rc) return rc;
+  if ((rc = grow(h, &h->d_pair_xy, &h->pair_xy_cap, 2 * n))) return rc;
+  if ((rc = grow(h, &h->d_flags_out, &h->flags_out_cap, n))) return rc;
+  uint8_t* dok = h->d_flags_out;
+  HIP_TRY(hipMemcpyAsync(h->d_pairs, frames, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->d_pairs + n, points, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(launch_reproject(h->dp, h->d_pairs, h->d_pairs + n, n, h->d_pair_xy, dok, h->stream));
+  HIP_TRY(hipMemcpyAsync(xy_out, h->d_pair_xy, (size_t)n * 16, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(ok_out, dok, (size_t)n, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
   return RSBA_OK;
 }
 

@@ -81,6 +81,7 @@ hipError_t launch_untile(const DeviceProblem& dp, const int64_t* order, bool wit
 // motion priors: cost2 += {cost, fixed cost} of the prior blocks at dp.poses (fail_count += invalid_blocks)
 hipError_t launch_prior_cost(const DeviceProblem& dp, double* cost2, int invalid_blocks, hipStream_t st);
 hipError_t launch_validate(const DeviceProblem& dp, double sq_threshold, double min_distance, uint8_t* valid, hipStream_t st);
+hipError_t launch_scatter_flags(const uint8_t* in, const int64_t* order, int64_t n, uint8_t* out, hipStream_t st);   // out[order[i]] = in[i]
 hipError_t launch_reproject(const DeviceProblem& dp, const int32_t* frames, const int32_t* points, int64_t n, double* xy_out, uint8_t* ok_out, hipStream_t st);
 
 }  // namespace rsba

@@ -20,9 +20,13 @@ struct rsba_handle {
   bool identity_order = true;
   std::vector<double> mask_pose, mask_point, mask_intr;   // 0 = fixed coordinate, 1 = free
   std::vector<int32_t> obs_frame, obs_point;            // host copies, internal (frame-major) order
+  std::vector<int32_t> frame_intr;                       // [F] host copy of the frame -> intrinsics block map
   std::vector<void*> allocs;
   double* d_cost2 = nullptr;           // {cost, fixed cost}
   int64_t* d_order = nullptr;          // device copy of `order`, made on the first host-returning evaluation
+  // scratch of the handle-level filter calls (rsba_validate_observations / rsba_reproject), kept between calls
+  uint8_t* d_flags = nullptr; uint8_t* d_flags_out = nullptr; int64_t flags_cap = 0, flags_out_cap = 0;
+  int32_t* d_pairs = nullptr; double* d_pair_xy = nullptr; int64_t pairs_cap = 0, pair_xy_cap = 0;
   double* d_rows = nullptr;            // [N][2 + 2K] results in the caller's layout and order, staged for one D2H copy each
   // motion priors (rsba_set_motion_priors): frames that carry one, device flags live in dp.prior_of
   std::vector<int32_t> prior_frames;

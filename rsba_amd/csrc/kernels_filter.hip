@@ -87,7 +87,28 @@ __global__ __launch_bounds__(256) void reproject_kernel(const DeviceProblem dp, 
   ok_out[i] = ok ? 1 : 0;   // the closing validate (:154) compares the projection with itself: true whenever w2i succeeded
 }
 
+__global__ void iota_kernel(int32_t* zeros, int32_t* iota, int64_t first, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) { zeros[i] = 0; iota[i] = (int32_t)(first + i); }
+}
+// caller order: out[order[i]] = in[i]
+__global__ void scatter_flags_kernel(const uint8_t* in, const int64_t* order, int64_t n, uint8_t* out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[order[i]] = in[i];
+}
+
 }  // namespace
+
+hipError_t launch_iota(int32_t* zeros, int32_t* iota, int64_t first, int64_t n, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, zeros, iota, first, n);
+  return hipGetLastError();
+}
+hipError_t launch_scatter_flags(const uint8_t* in, const int64_t* order, int64_t n, uint8_t* out, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(scatter_flags_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, order, n, out);
+  return hipGetLastError();
+}
 
 hipError_t launch_validate(const DeviceProblem& dp, double sq_threshold, double min_distance, uint8_t* valid, hipStream_t st) {
   if (dp.N <= 0) return hipSuccess;

@@ -27,20 +27,27 @@ __device__ __forceinline__ double wmax(double v) {
 
 // Camera-side coordinate t in [0, Fx*CD): the real pose coordinates, then the intrinsics pseudo frames
 // (9 coordinates + zero-scaled padding) when the intrinsics are a parameter block.
+// Intrinsics block c (shared sess.cam: the only one; per-frame f.cam blocks: one each, CeresHandler.h:260,277) rides as
+// pseudo frames F + c * NPF + v; coordinate t behind the poses is coordinate k = v * CD + t % CD of block c (k >= 9: padding).
+__device__ __forceinline__ int intr_index(const SolverDev& sv, int64_t u /* t - F*CD */) {
+  const int blk = (int)(u / sv.CD), c = blk / sv.NPF, k = (blk % sv.NPF) * sv.CD + (int)(u % sv.CD);
+  return k < 9 ? c * 9 + k : -1;
+}
 __device__ __forceinline__ double* cam_scale_ptr(const DeviceProblem& dp, const SolverDev& sv, int64_t t) {
   const int64_t npose = (int64_t)sv.F * sv.CD;
   if (t < npose) return dp.scale_pose + t;
-  return (t - npose < 9) ? dp.scale_intr + (t - npose) : nullptr;
+  const int idx = intr_index(sv, t - npose);
+  return idx >= 0 ? dp.scale_intr + idx : nullptr;
 }
 __device__ __forceinline__ double cam_scale(const DeviceProblem& dp, const SolverDev& sv, int64_t t) {
   const double* p = cam_scale_ptr(dp, sv, t);
   return p ? *p : 0.0;
 }
 __device__ __forceinline__ size_t u_cross_off(const SolverDev& sv, int v, int f) { return ((size_t)sv.F + (size_t)v * sv.F + f) * sv.CD * sv.CD; }
-__device__ __forceinline__ size_t u_self_off(const SolverDev& sv, int v, int w) { return ((size_t)sv.F + (size_t)sv.NPF * sv.F + (size_t)v * sv.NPF + w) * sv.CD * sv.CD; }
+__device__ __forceinline__ size_t u_self_off(const SolverDev& sv, int c, int v, int w) { return ((size_t)sv.F + (size_t)sv.NPF * sv.F + ((size_t)c * sv.NPF + v) * sv.NPF + w) * sv.CD * sv.CD; }
 __device__ __forceinline__ double u_diag(const SolverDev& sv, int64_t t) {
   const int f = (int)(t / sv.CD), a = (int)(t % sv.CD);
-  const size_t base = f < sv.F ? (size_t)f * sv.CD * sv.CD : u_self_off(sv, f - sv.F, f - sv.F);
+  const size_t base = f < sv.F ? (size_t)f * sv.CD * sv.CD : u_self_off(sv, (f - sv.F) / sv.NPF, (f - sv.F) % sv.NPF, (f - sv.F) % sv.NPF);
   return sv.U[base + (size_t)a * sv.CD + a];
 }
 
@@ -94,31 +101,34 @@ __global__ __launch_bounds__(256) void camera_reduce_kernel(const DeviceProblem 
   }
 }
 
-// one workgroup per entry t of the 45 + 9 sums: lanes stride the frames, fixed-order wave / workgroup reduction
+// one workgroup per (intrinsics block c, entry t of the 45 + 9 sums): lanes stride the frames that use the block (in
+// frame order), fixed-order wave / workgroup reduction
 __global__ __launch_bounds__(256) void intr_reduce_kernel(const DeviceProblem dp, const SolverDev sv) {
   __shared__ double s_red[4];
-  const int t = blockIdx.x, tid = threadIdx.x;
+  const int c = blockIdx.x / 54, t = blockIdx.x % 54, tid = threadIdx.x;
   double v = 0.0;
-  for (int f = tid; f < sv.F; f += 256) v += sv.intr_part[(size_t)f * 54 + t];
+  for (int q = sv.intr_frame_ptr[c] + tid; q < sv.intr_frame_ptr[c + 1]; q += 256) v += sv.intr_part[(size_t)sv.intr_frame_list[q] * 54 + t];
   v = wsum(v);
   if ((tid & 63) == 0) s_red[tid >> 6] = v;
   __syncthreads();
   if (tid != 0) return;
   v = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
   const int CD = sv.CD;
-  if (t >= 45) { sv.gc[(size_t)sv.F * CD + (t - 45)] = v; return; }
+  if (t >= 45) { sv.gc[((size_t)sv.F + (size_t)c * sv.NPF) * CD + (t - 45)] = v; return; }
   int a = 0, rem = t;
   while (rem >= 9 - a) { rem -= 9 - a; ++a; }
   const int b = a + rem;
-  sv.U[u_self_off(sv, a / CD, b / CD) + (size_t)(a % CD) * CD + (b % CD)] = v;
-  sv.U[u_self_off(sv, b / CD, a / CD) + (size_t)(b % CD) * CD + (a % CD)] = v;
+  sv.U[u_self_off(sv, c, a / CD, b / CD) + (size_t)(a % CD) * CD + (b % CD)] = v;
+  sv.U[u_self_off(sv, c, b / CD, a / CD) + (size_t)(b % CD) * CD + (a % CD)] = v;
 }
 
-// virtual observation records of the pseudo frames: Q_j = sum_o Ji_o^T (Jp_o L_j^-T)   (9 x 3 per point)
+// virtual observation records of the pseudo frames: one group per (point j, intrinsics block c the point is seen through),
+// Q_j,c = sum_{o of j in frames that use c} Ji_o^T (Jp_o L_j^-T)   (9 x 3), cut into the NPF pseudo-frame records of the group
 template <int CD>
 __global__ __launch_bounds__(256) void virtual_records_kernel(const DeviceProblem dp, const SolverDev sv) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= dp.M) return;
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= sv.nvgroups) return;
+  const int j = sv.vgroup_point[g], c = sv.vgroup_intr[g];
   const int REC = 2 + 2 * dp.K, KC = dp.K - 3;
   const double* li = sv.Linv + (size_t)j * 6;
   const double i00 = li[0], i10 = li[1], i11 = li[2], i20 = li[3], i21 = li[4], i22 = li[5];
@@ -126,6 +136,7 @@ __global__ __launch_bounds__(256) void virtual_records_kernel(const DeviceProble
 #pragma unroll
   for (int k = 0; k < 9; ++k) { Q[k][0] = 0.0; Q[k][1] = 0.0; Q[k][2] = 0.0; }
   for (int64_t s = sv.point_ptr[j]; s < sv.point_ptr[j + 1]; ++s) {
+    if (sv.NIB > 1 && dp.frame_intr[sv.slot_frame[s]] != c) continue;
     const double* rec = dp.rec + (size_t)s * REC;
     double B[2][3];
 #pragma unroll
@@ -140,7 +151,7 @@ __global__ __launch_bounds__(256) void virtual_records_kernel(const DeviceProble
       for (int m = 0; m < 3; ++m) Q[k][m] += a0 * B[0][m] + a1 * B[1][m];
     }
   }
-  double* out = sv.Pm + ((size_t)dp.N + (size_t)j * sv.NPF) * (CD * 3);
+  double* out = sv.Pm + ((size_t)dp.N + (size_t)g * sv.NPF) * (CD * 3);
   for (int v = 0; v < sv.NPF; ++v)
 #pragma unroll
     for (int rl = 0; rl < CD; ++rl) {
@@ -571,7 +582,7 @@ __global__ __launch_bounds__(256) void point_step_kernel(const DeviceProblem dp,
 #pragma unroll
         for (int a = 0; a < CD; ++a) { const double y = yc[a]; t0 += rec[8 + off + a] * y; t1 += rec[8 + KC + off + a] * y; }
         if (off > 0) {
-          const double* yi = sv.rhs + (size_t)sv.F * CD;   // intrinsics step: 9 coordinates across the pseudo frames
+          const double* yi = sv.rhs + ((size_t)sv.F + (size_t)(sv.NIB > 1 ? dp.frame_intr[frame] : 0) * sv.NPF) * CD;   // step of the frame's intrinsics block: 9 coordinates across its pseudo frames
 #pragma unroll
           for (int k = 0; k < off; ++k) { const double y = yi[k]; t0 += rec[8 + k] * y; t1 += rec[8 + KC + k] * y; }
         }
@@ -630,14 +641,15 @@ __global__ __launch_bounds__(256) void candidate_kernel(const DeviceProblem dp, 
     const int64_t npose = (int64_t)sv.F * sv.CD;
     const bool intr = cam && t >= npose;
     const int64_t u = cam ? (intr ? t - npose : t) : t - nc;
-    if (intr && u >= 9) { st = 0.0; xx = 0.0; }   // padding coordinate of the last pseudo frame
+    const int ii = intr ? intr_index(sv, u) : 0;     // coordinate of its intrinsics block, -1 = padding of a pseudo frame
+    if (intr && ii < 0) { st = 0.0; xx = 0.0; }
     else {
-    const double x = cam ? (intr ? dp.intr[u] : dp.poses[u]) : dp.points[u];
+    const double x = cam ? (intr ? dp.intr[ii] : dp.poses[u]) : dp.points[u];
     const double sc = cam ? cam_scale(dp, sv, t) : dp.scale_point[u];
     const double y = cam ? sv.rhs[t] : sv.yp[u];
     const double in = cam ? (intr ? sv.inprog_intr[u] : sv.inprog_pose[u]) : sv.inprog_point[u];
     const double xn = (sc > 0.0) ? x + (-y * sc) : x;
-    if (intr) sv.trial_intr[u] = xn; else if (cam) sv.trial_poses[u] = xn; else sv.trial_points[u] = xn;
+    if (intr) sv.trial_intr[ii] = xn; else if (cam) sv.trial_poses[u] = xn; else sv.trial_points[u] = xn;
     if (in > 0.0) { const double e = x - xn; st = e * e; xx = x * x; }
     }
   }
@@ -700,9 +712,9 @@ inline int nblocks256(int64_t n) { return (int)((n + 255) / 256); }
 hipError_t launch_camera_blocks(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {
   const size_t CD2 = (size_t)sv.CD * sv.CD;
   if (sv.NPF > 0) {   // the padding coordinates of the pseudo frames stay zero
-    hipError_t e = hipMemsetAsync(sv.U + (size_t)sv.F * CD2, 0, ((size_t)sv.NPF * sv.F + (size_t)sv.NPF * sv.NPF) * CD2 * sizeof(double), st);
+    hipError_t e = hipMemsetAsync(sv.U + (size_t)sv.F * CD2, 0, ((size_t)sv.NPF * sv.F + (size_t)sv.NIB * sv.NPF * sv.NPF) * CD2 * sizeof(double), st);
     if (e != hipSuccess) return e;
-    e = hipMemsetAsync(sv.gc + (size_t)sv.F * sv.CD, 0, (size_t)sv.NPF * sv.CD * sizeof(double), st);
+    e = hipMemsetAsync(sv.gc + (size_t)sv.F * sv.CD, 0, (size_t)sv.NIB * sv.NPF * sv.CD * sizeof(double), st);
     if (e != hipSuccess) return e;
   }
   if (!dp.cam_part) {   // no observations on this rank: nothing was accumulated
@@ -775,13 +787,14 @@ hipError_t launch_project(const DeviceProblem& dp, const SolverDev& sv, hipStrea
 // intrinsics as a parameter block: the self block and the intrinsics gradient, summed over the frames
 hipError_t launch_intr_blocks(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {
   if (sv.NPF == 0) return hipSuccess;
-  LAUNCH(intr_reduce_kernel, 54, 256, st, dp, sv);
+  LAUNCH(intr_reduce_kernel, 54 * sv.NIB, 256, st, dp, sv);
   return hipSuccess;
 }
 hipError_t launch_virtual_records(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {
   if (sv.NPF == 0) return hipSuccess;
-  if (sv.CD == 12) LAUNCH(virtual_records_kernel<12>, nblocks256(dp.M), 256, st, dp, sv);
-  else LAUNCH(virtual_records_kernel<6>, nblocks256(dp.M), 256, st, dp, sv);
+  if (sv.nvgroups == 0) return hipSuccess;
+  if (sv.CD == 12) LAUNCH(virtual_records_kernel<12>, nblocks256(sv.nvgroups), 256, st, dp, sv);
+  else LAUNCH(virtual_records_kernel<6>, nblocks256(sv.nvgroups), 256, st, dp, sv);
   return hipSuccess;
 }
 hipError_t launch_clear_system(const SolverDev& sv, hipStream_t st) {

@@ -125,8 +125,6 @@ struct PhaseScope {
 int32_t build_solver(rsba_handle* h) {
   if (h->solver) return RSBA_OK;
   const DeviceProblem& dp = h->dp;
-  if (!dp.calibrated && dp.NI != 1)
-    return rsba_set_error(RSBA_ERR_UNSUPPORTED, "solve with per-frame intrinsics parameter blocks is not built yet (shared sess.cam is)");
   Solver* s = new Solver();
   h->solver = s;   // owned by the handle from here on (freed by rsba_destroy_solver)
   const bool dbg_plan = std::getenv("RSBA_DEBUG_PLAN") != nullptr;
@@ -138,10 +136,13 @@ int32_t build_solver(rsba_handle* h) {
   };
   SolverDev& sv = s->sv;
   const int FR = dp.F, M = dp.M, CD = 6 * dp.P;          // FR real frames
-  const int NPF = dp.calibrated ? 0 : (9 + CD - 1) / CD;   // intrinsics pseudo frames (solver_state.hpp)
-  const int F = FR + NPF;                                 // camera-side blocks of the reduced system
+  const int NIB = dp.calibrated ? 0 : dp.NI;               // intrinsics parameter blocks: sess.cam and / or per-frame f.cam (CeresHandler.h:260,277)
+  const int NPF = dp.calibrated ? 0 : (9 + CD - 1) / CD;   // pseudo frames per intrinsics block (solver_state.hpp)
+  const int F = FR + NIB * NPF;                            // camera-side blocks of the reduced system
   const int64_t N = dp.N;
-  sv.F = FR; sv.Fx = F; sv.NPF = NPF;
+  sv.F = FR; sv.Fx = F; sv.NPF = NPF; sv.NIB = NIB;
+  const std::vector<int32_t>& fi = h->frame_intr;          // frame -> intrinsics block
+  auto intr_of = [&](int f) { return NIB > 1 ? fi[f] : 0; };
   sv.CD = CD; sv.n = (int64_t)F * CD;
   const int FT = kTile / CD;
   sv.nt = (F + FT - 1) / FT; sv.npad = (int64_t)sv.nt * kTile;
@@ -151,21 +152,40 @@ int32_t build_solver(rsba_handle* h) {
   for (int64_t i = 0; i < N; ++i) { frame_ptr[of[i] + 1]++; point_ptr[op[i] + 1]++; }
   for (int f = 0; f < FR; ++f) frame_ptr[f + 1] += frame_ptr[f];
   for (int j = 0; j < M; ++j) point_ptr[j + 1] += point_ptr[j];
-  // slots: stable counting sort of the frame-major list by point -> ascending frame inside a point;
-  // behind them one virtual slot per (point, pseudo frame)
-  const int64_t NS = N + (int64_t)M * NPF;
-  if ((NS + 1) * (int64_t)CD * 3 >= ((int64_t)1 << 32)) return rsba_set_error(RSBA_ERR_UNSUPPORTED, "more than 2^32 doubles of P records: the Schur kernel indexes them with 32 bits");
-  std::vector<int32_t> obs_slot(N), slot_frame(NS), slot_point(NS);
+  // slots: stable counting sort of the frame-major list by point -> ascending frame inside a point
+  std::vector<int32_t> obs_slot(N), real_frame(N);
   {
     std::vector<int64_t> fill(point_ptr.begin(), point_ptr.end() - 1);
-    for (int64_t i = 0; i < N; ++i) { const int64_t sl = fill[op[i]]++; obs_slot[i] = (int32_t)sl; slot_frame[sl] = of[i]; slot_point[sl] = op[i]; }
-    for (int j = 0; j < M; ++j) for (int v = 0; v < NPF; ++v) { slot_frame[N + (int64_t)j * NPF + v] = FR + v; slot_point[N + (int64_t)j * NPF + v] = j; }
+    for (int64_t i = 0; i < N; ++i) { const int64_t sl = fill[op[i]]++; obs_slot[i] = (int32_t)sl; real_frame[sl] = of[i]; }
   }
-  // the slots of point j in ascending frame order (virtual ones last; only for points that are observed)
+  // virtual groups: one per (observed point, intrinsics block it is seen through), blocks ascending; each owns NPF virtual
+  // slots behind the real ones
+  std::vector<int64_t> vgroup_ptr(M + 1, 0);
+  std::vector<int32_t> vgroup_point, vgroup_intr;
+  if (NIB > 0) {
+    std::vector<int32_t> seen;
+    for (int j = 0; j < M; ++j) {
+      seen.clear();
+      for (int64_t x = point_ptr[j]; x < point_ptr[j + 1]; ++x) seen.push_back(intr_of(real_frame[x]));
+      std::sort(seen.begin(), seen.end()); seen.erase(std::unique(seen.begin(), seen.end()), seen.end());
+      for (int32_t c : seen) { vgroup_point.push_back(j); vgroup_intr.push_back(c); }
+      vgroup_ptr[j + 1] = (int64_t)vgroup_point.size();
+    }
+  }
+  const int64_t NVG = (int64_t)vgroup_point.size();
+  sv.nvgroups = NVG;
+  const int64_t NS = N + NVG * NPF;
+  if ((NS + 1) * (int64_t)CD * 3 >= ((int64_t)1 << 32)) return rsba_set_error(RSBA_ERR_UNSUPPORTED, "more than 2^32 doubles of P records: the Schur kernel indexes them with 32 bits");
+  std::vector<int32_t> slot_frame(NS), slot_point(NS);
+  for (int64_t x = 0; x < N; ++x) slot_frame[x] = real_frame[x];
+  for (int j = 0; j < M; ++j) for (int64_t x = point_ptr[j]; x < point_ptr[j + 1]; ++x) slot_point[x] = j;
+  for (int64_t g = 0; g < NVG; ++g) for (int v = 0; v < NPF; ++v) { slot_frame[N + g * NPF + v] = FR + vgroup_intr[g] * NPF + v; slot_point[N + g * NPF + v] = vgroup_point[g]; }
+  std::vector<int32_t>().swap(real_frame);
+  // the slots of point j in ascending frame order (virtual ones last, by intrinsics block; only for points that are observed)
   auto slots_of = [&](int j, std::vector<int64_t>& out) {
     out.clear();
     for (int64_t x = point_ptr[j]; x < point_ptr[j + 1]; ++x) out.push_back(x);
-    if (!out.empty()) for (int v = 0; v < NPF; ++v) out.push_back(N + (int64_t)j * NPF + v);
+    for (int64_t g = vgroup_ptr[j]; g < vgroup_ptr[j + 1]; ++g) for (int v = 0; v < NPF; ++v) out.push_back(N + g * NPF + v);
   };
   std::vector<int64_t> pslots;
   tick("slots");
@@ -205,9 +225,18 @@ int32_t build_solver(rsba_handle* h) {
     else sparse_cnt[key] += by;
   };
   for (int I = 0; I < nt; ++I) bump(I, I, 0);                // every diagonal tile exists (U + D^2, rhs)
+  auto bump_blocks = [&](int a, int b) { const int I = std::max(a, b) / FT, J = std::min(a, b) / FT; bump(I, J, 0); };
   if (!h->union_mask.empty())                                  // multi-GPU: tiles other ranks fill, so all ranks share one layout
-    for (int a = 0; a < FR; ++a) for (int b = 0; b <= a; ++b) if (h->union_mask[(size_t)a * FR + b]) bump(a / FT, b / FT, 0);
-  for (int v = 0; v < NPF; ++v) for (int b = 0; b < FR + v; ++b) bump((FR + v) / FT, b / FT, 0);   // the intrinsics border is dense
+    for (int a = 0; a < FR; ++a) for (int b = 0; b <= a; ++b) if (h->union_mask[(size_t)a * FR + b]) {
+      bump(a / FT, b / FT, 0);
+      for (int v = 0; v < NPF; ++v) {                          // ... and the rows of the two frames' intrinsics blocks
+        bump_blocks(FR + intr_of(a) * NPF + v, b); bump_blocks(FR + intr_of(b) * NPF + v, a);
+        for (int w = 0; w < NPF; ++w) bump_blocks(FR + intr_of(a) * NPF + v, FR + intr_of(b) * NPF + w);
+      }
+    }
+  // J^T J blocks that do not come from a point: (intrinsics block of a frame) x (that frame), and an intrinsics block with itself
+  for (int f = 0; f < FR && NIB > 0; ++f) for (int v = 0; v < NPF; ++v) bump_blocks(FR + intr_of(f) * NPF + v, f);
+  for (int c = 0; c < NIB; ++c) for (int v = 0; v < NPF; ++v) for (int w = 0; w <= v; ++w) bump_blocks(FR + c * NPF + v, FR + c * NPF + w);
   for (int32_t f : h->prior_frames) bump(f / FT, (f - 1) / FT, 0);   // motion priors couple frame f with f - 1 (every rank: one layout)
   // entries of point j: every pair of its tiles (X >= Y) times every combination of their layers — for X == Y both
   // orders of two different layers (the diagonal tile pair is stored in full)
@@ -471,7 +500,7 @@ int32_t build_solver(rsba_handle* h) {
   { const char* e = std::getenv("RSBA_SCHUR_LINEAR"); sv.schur_linear = e && e[0] == '1'; }
   std::vector<uint8_t> has_prior((size_t)FR + 1, 0);
   for (int32_t f : h->prior_frames) has_prior[f] = 1;
-  const int64_t ucross_base = ((int64_t)FR + (int64_t)NPF * FR + (int64_t)NPF * NPF) * CD * CD;   // behind the J^T J blocks in sv.U
+  const int64_t ucross_base = ((int64_t)FR + (int64_t)NPF * FR + (int64_t)NIB * NPF * NPF) * CD * CD;   // behind the J^T J blocks in sv.U
   std::vector<int32_t> tp_dst(ntp); std::vector<uint8_t> tp_trans(ntp, 0);
   std::vector<int64_t> tp_add((size_t)ntp * FT * FT, -1);
   for (int t = 0; t < ntp; ++t) {
@@ -487,8 +516,11 @@ int32_t build_solver(rsba_handle* h) {
         if (a == b) add = (int64_t)a * CD * CD;
         else if (b == a - 1 && has_prior[a]) add = ucross_base + (int64_t)a * CD * CD;   // motion prior block (a, a-1)
       }
-      else if (b < FR) add = ((int64_t)FR + (int64_t)(a - FR) * FR + b) * CD * CD;
-      else add = ((int64_t)FR + (int64_t)NPF * FR + (int64_t)(a - FR) * NPF + (b - FR)) * CD * CD;
+      else {
+        const int ca = (a - FR) / NPF, va = (a - FR) % NPF;     // pseudo frame va of intrinsics block ca
+        if (b < FR) { if (intr_of(b) == ca) add = ((int64_t)FR + (int64_t)va * FR + b) * CD * CD; }   // only with the frames that use the block
+        else if ((b - FR) / NPF == ca) add = ((int64_t)FR + (int64_t)NPF * FR + ((int64_t)ca * NPF + va) * NPF + (b - FR) % NPF) * CD * CD;
+      }
       tp_add[((size_t)t * FT + x) * FT + y] = add;
     }
   }
@@ -496,7 +528,7 @@ int32_t build_solver(rsba_handle* h) {
   tick("chunks");
   // which coordinates belong to the reduced program (for |x| and |step|): blocks that are not constant
   // and are touched by at least one residual block
-  std::vector<double> inprog_pose((size_t)FR * CD, 0.0), inprog_point((size_t)M * 3, 0.0), inprog_intr((size_t)std::max(NPF, 1) * CD, 0.0);
+  std::vector<double> inprog_pose((size_t)FR * CD, 0.0), inprog_point((size_t)M * 3, 0.0), inprog_intr((size_t)std::max(NIB * NPF, 1) * CD, 0.0);
   int nfree = 0;
   const bool lead = h->rank == 0;
   sv.lead = lead;
@@ -504,7 +536,13 @@ int32_t build_solver(rsba_handle* h) {
     if (has_prior[f] || has_prior[f + 1]) return true;   // touched by a motion prior block
     return h->frame_obs_total.empty() ? frame_ptr[f + 1] > frame_ptr[f] : h->frame_obs_total[f] > 0;
   };
-  if (NPF > 0 && lead && h->mask_intr[0] != 0.0 && N > 0) for (int k = 0; k < 9; ++k) { inprog_intr[k] = 1.0; ++nfree; }
+  {
+    // an intrinsics block is part of the program when it is not constant and a residual block touches it
+    std::vector<uint8_t> touched((size_t)std::max(NIB, 1), 0);
+    for (int f = 0; f < FR && NIB > 0; ++f) if (h->frame_obs_total.empty() ? frame_ptr[f + 1] > frame_ptr[f] : h->frame_obs_total[f] > 0) touched[intr_of(f)] = 1;
+    for (int c = 0; c < NIB; ++c) if (lead && touched[c] && h->mask_intr[(size_t)c * 9] != 0.0)
+      for (int k = 0; k < 9; ++k) { inprog_intr[((size_t)c * NPF + k / CD) * CD + k % CD] = 1.0; ++nfree; }
+  }
   for (int f = 0; f < FR; ++f) for (int q = 0; q < dp.P; ++q) {
     bool any_free = false;
     for (int k = 0; k < 6; ++k) any_free = any_free || h->mask_pose[((size_t)f * dp.P + q) * 6 + k] != 0.0;
@@ -515,7 +553,7 @@ int32_t build_solver(rsba_handle* h) {
   {
     int64_t nred = 0;
     for (int64_t i = 0; i < N; ++i) {
-      bool all_const = h->mask_point[(size_t)op[i] * 3] == 0.0 && (NPF == 0 || h->mask_intr[0] == 0.0);
+      bool all_const = h->mask_point[(size_t)op[i] * 3] == 0.0 && (NIB == 0 || h->mask_intr[(size_t)intr_of(of[i]) * 9] == 0.0);
       for (int k = 0; k < CD && all_const; ++k) all_const = h->mask_pose[(size_t)of[i] * CD + k] == 0.0;
       nred += !all_const;
     }
@@ -542,6 +580,17 @@ int32_t build_solver(rsba_handle* h) {
   if ((rc = s_upload_const(s, &sv.inprog_pose, inprog_pose))) return rc;
   if ((rc = s_upload_const(s, &sv.inprog_point, inprog_point))) return rc;
   if ((rc = s_upload_const(s, &sv.inprog_intr, inprog_intr))) return rc;
+  {
+    std::vector<int32_t> ifp((size_t)NIB + 1, 0), ifl;
+    for (int f = 0; f < FR && NIB > 0; ++f) ifp[intr_of(f) + 1]++;
+    for (int c = 0; c < NIB; ++c) ifp[c + 1] += ifp[c];
+    ifl.resize(NIB > 0 ? FR : 0);
+    { std::vector<int32_t> fill(ifp.begin(), ifp.end() - 1); for (int f = 0; f < FR && NIB > 0; ++f) ifl[fill[intr_of(f)]++] = f; }
+    if ((rc = s_upload_const(s, &sv.intr_frame_ptr, ifp))) return rc;
+    if ((rc = s_upload_const(s, &sv.intr_frame_list, ifl))) return rc;
+    if ((rc = s_upload_const(s, &sv.vgroup_point, vgroup_point))) return rc;
+    if ((rc = s_upload_const(s, &sv.vgroup_intr, vgroup_intr))) return rc;
+  }
   if ((rc = s_upload(s, &s->d_obs_slot, obs_slot))) return rc;
   if ((rc = s_upload_const(s, &sv.chunk_tp, chunk_tp))) return rc;
   if ((rc = s_upload_const(s, &sv.chunk_e0, chunk_e0))) return rc;
@@ -583,8 +632,8 @@ int32_t build_solver(rsba_handle* h) {
     // camera (and intrinsics border) blocks inside the evaluation kernel: per (64-observation wave, frame it touches)
     // the 16 x 16 blocks on and below the diagonal of [Ji | Jc | r]^T [Ji | Jc | r]
     const int64_t nwaves = (int64_t)eval_num_blocks(N) * (kEvalBlock / 64);
-    std::vector<int32_t> wave_seg_base((size_t)nwaves + 1, 0), frame_rank(F, 0);
-    { int rk = 0; for (int f = 0; f < F; ++f) { frame_rank[f] = rk; if (frame_ptr[f + 1] > frame_ptr[f]) ++rk; } }
+    std::vector<int32_t> wave_seg_base((size_t)nwaves + 1, 0), frame_rank(FR, 0);
+    { int rk = 0; for (int f = 0; f < FR; ++f) { frame_rank[f] = rk; if (frame_ptr[f + 1] > frame_ptr[f]) ++rk; } }
     for (int64_t w = 0; w < nwaves; ++w) {
       const int64_t a = w * 64, b = std::min<int64_t>(a + 64, N);
       wave_seg_base[w + 1] = wave_seg_base[w] + (a < N ? frame_rank[of[b - 1]] - frame_rank[of[a]] + 1 : 0);
@@ -831,7 +880,8 @@ int32_t rsba_gradient(rsba_handle* h, double* g) {
   HIP_TRY(hipMemcpyAsync(g, s->d_gpose, npose * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipMemcpyAsync(g + npose, s->d_gpoint, npt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   std::fill(g + npose + npt, g + npose + npt + (size_t)dp.NI * 9, 0.0);
-  if (s->sv.NPF > 0) HIP_TRY(hipMemcpyAsync(g + npose + npt, s->d_gpose + npose, 9 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  for (int c = 0; c < s->sv.NIB; ++c)   // the 9 coordinates of block c sit at the front of its pseudo frames
+    HIP_TRY(hipMemcpyAsync(g + npose + npt + (size_t)c * 9, s->d_gpose + npose + (size_t)c * s->sv.NPF * s->sv.CD, 9 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   return RSBA_OK;
 }
@@ -1180,7 +1230,7 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
         radius = std::min(opt->max_trust_region_radius, radius); decrease_factor = 2.0; reuse_diagonal = false;
         swap_params();   // x = x_plus_delta
         if (free_ratio) { ratio = ratio_new; dp.prior_ratio = ratio; }
-        if (sv.NPF > 0) HIP_TRY(hipMemcpyAsync(sv.trial_intr, dp.intr, 9 * sizeof(double), hipMemcpyDeviceToDevice, st));   // constant coordinates stay in sync
+        if (sv.NPF > 0) HIP_TRY(hipMemcpyAsync(sv.trial_intr, dp.intr, 9 * (size_t)dp.NI * sizeof(double), hipMemcpyDeviceToDevice, st));   // constant coordinates stay in sync
         t0 = now_s();
         if ((rc = linearize(h))) return rc;
         if ((rc = gradient_max(h))) return rc;

@@ -18,14 +18,21 @@ namespace rsba {
 constexpr int kSchurChunk = 512;   // entries per workgroup of the Schur kernel (its four waves take every fourth)
 constexpr int kTile = 48;   // Cholesky tile: 4 rolling-shutter frames (12 unknowns) or 8 global-shutter frames
 
-// Intrinsics as a parameter block (opt.model.calibrated == false with the shared sess.cam,
-// CeresHandler.h:256-264,273-280): its 9 coordinates ride as NPF = ceil(9/CD) extra "pseudo frames" at the
-// end of the camera-side ordering (zero-scaled padding fills the last one), and every point gets one
-// VIRTUAL observation slot per pseudo frame whose P record is Q_j = sum_o Ji_o^T Jp_o L^-T.  The pair lists
-// of the symbolic phase then produce the 9-wide dense border of the reduced system with the same Schur and
-// Cholesky kernels; only the (non block-diagonal) U cross terms need their own reductions.
+// Intrinsics as parameter blocks (opt.model.calibrated == false: the shared sess.cam and / or per-frame f.cam blocks,
+// CeresHandler.h:256-264,273-280): the 9 coordinates of block c ride as NPF = ceil(9/CD) extra "pseudo frames"
+// F + c*NPF + v behind the real frames in the camera-side ordering (zero-scaled padding fills the last one), and every
+// point gets one VIRTUAL observation slot per (intrinsics block it is seen through, pseudo frame) whose P record is
+// Q_j,c = sum_{o through c} Ji_o^T Jp_o L^-T.  The pair lists of the symbolic phase then produce the rows of the reduced
+// system that belong to the intrinsics (a dense 9-wide border for the shared block, band rows for per-frame blocks) with
+// the same Schur and Cholesky kernels; only the (non block-diagonal) U cross terms need their own reductions.
 struct SolverDev {
-  int F, Fx, NPF;               // real frames, frames + pseudo frames, pseudo frames (0 when calibrated)
+  int F, Fx, NPF;               // real frames, frames + pseudo frames, pseudo frames PER intrinsics block (0 when calibrated)
+  int NIB;                      // intrinsics parameter blocks (0 when calibrated; 1 = the shared sess.cam; per-frame f.cam blocks: one each)
+  const int32_t* intr_frame_ptr;// [NIB+1] frames that use each intrinsics block,
+  const int32_t* intr_frame_list;//        ascending
+  int64_t nvgroups;             // (point, intrinsics block it is seen through) pairs: each owns NPF virtual slots N + g*NPF + v
+  const int32_t* vgroup_point;  // [nvgroups]
+  const int32_t* vgroup_intr;   // [nvgroups]
   int CD;                       // 6 * P
   int64_t n, npad;              // camera unknowns F*CD, padded to a multiple of kTile
   int nt;                       // npad / kTile
@@ -59,11 +66,11 @@ struct SolverDev {
   const int64_t* tp_add;        // [ntp][FT][FT] offset into U of the J^T J block to add, -1 none
   double* schur_part;           // [nchunk][kTile*kTile + kTile] partial tiles (+ rhs partials) of the chunks
   // numeric
-  double* U;                    // [F][CD][CD] frame blocks | [NPF][F][CD][CD] intrinsics x frame | [NPF][NPF][CD][CD]
+  double* U;                    // [F][CD][CD] frame blocks | [NPF][F][CD][CD] (pseudo v of the frame's intrinsics block) x frame | [NIB][NPF][NPF][CD][CD]
   double* gc;                   // [Fx][CD]     (scaled) J_c^T r, intrinsics gradient in the pseudo frames
   double* intr_part;            // [F][9*10/2 + 9] per-frame partials of Ji^T Ji and Ji^T r
-  double* trial_intr;           // [9] candidate intrinsics
-  const double* inprog_intr;    // [NPF*CD]
+  double* trial_intr;           // [NI][9] candidate intrinsics
+  const double* inprog_intr;    // [NIB*NPF*CD]
   double* V;                    // [M][6]  xx xy xz yy yz zz
   double* gp;                   // [M][3]
   double* diag_c;               // [F*CD]  clamped squared column norms (LM "diagonal_")

@@ -121,6 +121,31 @@ def test_windowed_ba_with_motion_priors_links_the_frame_before_the_window(exe, o
 
 
 @pytest.mark.gpu
+def test_frames_with_their_own_cam_block(exe, oracle, tmp_path):
+    """opt.model.calibrated = false with Frame.cam set on every third frame: CeresHandler::Add hands f.cam to the residual
+    blocks of those frames and sess.cam to the others (CeresHandler.h:256-264) — four intrinsics parameter blocks here."""
+    from rsba_amd.problem import apply_gauge_masks
+    p = small_problem(True, 2.0)
+    p.calibrated = False
+    write_scene_file(tmp_path / "s.bin", p, fix_first_n=1, max_iter=15)
+    r = subprocess.run([exe, str(tmp_path / "s.bin"), str(tmp_path / "o.bin"), "0", "3"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr
+    out = read_result_file(tmp_path / "o.bin", p)
+    q = p.copy()
+    apply_gauge_masks(q, fix_first_n_cameras=1)
+    own = np.arange(q.num_frames) % 3 == 2
+    fi = np.zeros(q.num_frames, dtype=np.int32); fi[own] = 1 + np.arange(own.sum())
+    q.frame_intrinsics = fi
+    q.intrinsics = np.tile(p.intrinsics[:1], (1 + int(own.sum()), 1))
+    s_ref, _ = oracle.solve(q, oracle.default_options(max_num_iterations=15))
+    assert out["usable"] and out["reduced"] == s_ref.num_residual_blocks_reduced
+    assert abs(out["initial_cost"] - s_ref.initial_cost) <= 1e-12 * s_ref.initial_cost
+    assert abs(out["final_cost"] - s_ref.final_cost) <= 1e-6 * s_ref.final_cost
+    assert np.max(np.abs(out["poses"] - q.poses)) <= 1e-5 and np.max(np.abs(out["points"] - q.points)) <= 1e-4
+    assert len(np.unique(q.intrinsics, axis=0)) == len(q.intrinsics)          # the blocks went their own ways
+
+
+@pytest.mark.gpu
 def test_replaying_a_thrift_session_cache_equals_the_scene_file_path(exe, tmp_path):
     """A Session cache in the reference's on-disk format (Thrift binary in TFileTransport events, written here by the
     independent encoder tests/thrift_encode.py) goes through session_cache.hpp into BA(): same solve as the flat scene file."""

@@ -155,6 +155,42 @@ def test_constant_shared_intrinsics_block(capi, oracle):
     assert np.array_equal(p_dev.intrinsics, p.intrinsics)
 
 
+@pytest.mark.parametrize("layout", ["per_frame", "mixed", "mixed_global_shutter", "unsorted"])
+def test_per_frame_intrinsics_blocks_in_the_solve(capi, oracle, layout):
+    """CeresHandler::Add uses f.cam as the intrinsics parameter block of a frame that carries one and sess.cam otherwise
+    (CeresHandler.h:256-264, 273-280): several 9-blocks, each coupled to the frames that use it.  per_frame: one block per
+    frame; mixed: the first half of the video shares block 0, the rest have their own, one of them constant; the global-
+    shutter variant has 6-wide camera blocks (two pseudo frames per intrinsics block)."""
+    rolling = layout != "mixed_global_shutter"
+    p = small_scene(rolling=rolling, frames=16, points=800, seed=57, outlier_ratio=0.03)
+    p.calibrated = False
+    p.huber_a = 2.0
+    rng = np.random.default_rng(3)
+    F = p.num_frames
+    if layout in ("per_frame", "unsorted"):
+        fi = np.arange(F, dtype=np.int32)
+    else:
+        fi = np.concatenate([np.zeros(F // 2, dtype=np.int32), np.arange(1, F - F // 2 + 1, dtype=np.int32)])
+    ni = int(fi.max()) + 1
+    p.intrinsics = np.tile(p.intrinsics[:1], (ni, 1)) * (1.0 + 1e-3 * rng.normal(size=(ni, 9)) * np.array([[1, 1, 20, 20, 10, 10, 10, 0.5, 0.5]]))
+    p.frame_intrinsics = fi
+    if layout == "unsorted":
+        p.frame_intrinsics = rng.permutation(F).astype(np.int32)
+        perm = rng.permutation(p.num_observations)
+        p.obs_xy, p.obs_frame, p.obs_point = p.obs_xy[perm].copy(), p.obs_frame[perm].copy(), p.obs_point[perm].copy()
+    if layout.startswith("mixed"):
+        p.intrinsics_constant = np.zeros(ni, dtype=np.uint8); p.intrinsics_constant[2] = 1
+    start = p.intrinsics.copy()
+    check_normal_equations_uncalibrated(capi, oracle, p)
+    s, s_ref, p_dev, p_cpu = compare_solves(capi, oracle, p, iters=25)
+    assert np.max(np.abs(p_dev.intrinsics - p_cpu.intrinsics) / np.maximum(1.0, np.abs(p_cpu.intrinsics))) <= 1e-6
+    moved = np.any(p_dev.intrinsics != start, axis=1)
+    if layout.startswith("mixed"):
+        assert not moved[2] and moved[[0, 1, 3]].all()
+    else:
+        assert moved.all()
+
+
 def check_normal_equations_uncalibrated(capi, oracle, p, tol=1e-11):
     ok, cost_ref, g_ref = oracle.evaluate(p)
     with capi.DeviceProblem(p) as dp:
