@@ -350,7 +350,7 @@ def main():
         if not args.no_next_rows and world == 1 and not lm_hung and args.config == "C4":
             out["next_rows"] = next_rows(prob, dp, local_rank)
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(prob)
+            out["cpu_baseline"] = cpu_baseline(prob, lm_iters=3 if prob.num_observations < 5_000_000 else 1)
     if lm_hung:                      # do not touch the device or the process group again: report and leave
         if rank == 0:
             print(json.dumps(out), flush=True)

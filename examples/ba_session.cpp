@@ -7,7 +7,7 @@
 //     double huber, double revalidate (squared px threshold of revalidateReprojections, <= 0 = off), double covFrame (>= 0:
 //     calcCovariances, the pp | pe | ee blocks of that frame are appended to the result file), double constFrameVelocity,
 //     constFrameAcceleration, interFrameRatio (motion priors, CeresHandler.h:147-185), double cam[9], poses[F*P*6], points[M*3], obs_xy[N*2], int32 obs_frame[N], obs_point[N]
-//   ba_session --cache session.cache out.bin [fixFirstN=1] [maxIter=20] [huber=0] [calibrated=1] [useOnlyValidMatches=1] [sqrdThreshold=16]
+//   ba_session --cache session.cache out.bin [fixFirstN=1] [maxIter=20] [huber=0] [calibrated=1] [useOnlyValidMatches=1] [sqrdThreshold=16] [trustRotation=0] [trustPosition=0]
 //     replays a Session cache written by the reference (VideoSfMCache, Thrift binary; include/rsba/session_cache.hpp)
 //   g++ -std=c++17 -O2 -Iinclude examples/ba_session.cpp -Lrsba_amd/_lib -lrsba_amd -Wl,-rpath,... -o ba_session
 #include <cstdio>
@@ -33,6 +33,7 @@ static int write_result(const char* path, const Session& sess, const ceres::Solv
   std::fwrite(head, sizeof(double), 6, g);
   for (const Frame& fr : sess.frames) for (const auto& pose : fr.poses) std::fwrite(pose.data(), sizeof(double), 6, g);
   for (const Track& t : sess.tracks) std::fwrite(t.pt.data(), sizeof(double), 3, g);
+  for (const Frame& fr : sess.frames) if (fr.__isset.priorPoses) for (const auto& pose : fr.priorPoses) std::fwrite(pose.data(), sizeof(double), 6, g);   // solved priorPoses blocks
   if (covf >= 0 && (size_t)covf < covs.size() && covs[(size_t)covf].size() == 108) std::fwrite(covs[(size_t)covf].data(), sizeof(double), 108, g);
   std::fclose(g);
   return usable ? 0 : 1;
@@ -50,6 +51,8 @@ static int replay_cache(int argc, char** argv) {
   opt.model.calibrated = argc > 7 ? std::atoi(argv[7]) != 0 : true;
   opt.ceres.useOnlyValidMatches = argc > 8 ? std::atoi(argv[8]) != 0 : true;
   if (argc > 9) opt.tracks.sqrdThreshold = std::atof(argv[9]);
+  if (argc > 10) opt.ceres.trustPriorCamRotation = std::atof(argv[10]);   // GoodPosePrior on the frames that carry priorPoses (CeresHandler.h:188-204)
+  if (argc > 11) opt.ceres.trustPriorCamPosition = std::atof(argv[11]);
   ceres::Solver::Summary summary;
   const bool usable = BA(sess, 0, sess.frames.size() - 1, opt, maxIter, &summary, true, nullptr);
   return write_result(argv[3], sess, summary, usable, {}, -1.0);

@@ -12,8 +12,8 @@
 // (RsBundleAdjustment / ReprojectionError factories) — and, between the frames those observe, the motion priors of
 // motion_priors.hpp (RsConstVeloPrior / RsConstAccelerationPrior; the interFrameRatio block constant or, as in the
 // reference's default, free with CeresHandler's lower bound).  There is NO host-side evaluation: every residual, Jacobian and solve goes through librsba_amd's HIP
-// kernels; a cost function of any other type (SphericalPrior, GoodPosePrior) is rejected with an error, not evaluated
-// on the CPU.
+// kernels; so do the per-pose priors of pose_priors.hpp (GoodPosePrior, SphericalPrior).  A cost function of any other type
+// is rejected with an error, not evaluated on the CPU.
 #pragma once
 #include <algorithm>
 #include <cmath>
@@ -198,6 +198,26 @@ class MotionPriorCost : public CostFunction {
   int kind_; double scale_;
 };
 
+// Per-pose prior blocks of CeresHandler (CeresHandler.h:24-73): typed handles created by the factories in pose_priors.hpp.
+//   kind 0  GoodPosePrior(rotation, position): blocks priorPose[6], pose[6]; 6 residuals
+//   kind 1  SphericalPrior: block pose[6]; 2 residuals
+// Evaluated inside a Problem (device path, rsba_set_pose_priors); the reference attaches them without a loss function.
+class PosePriorCost : public CostFunction {
+ public:
+  PosePriorCost(int kind, double rotation, double position) : kind_(kind), rotation_(rotation), position_(position) {
+    num_residuals_ = kind == 0 ? 6 : 2;
+    if (kind == 0) sizes_ = {NUM_POSE_PARAMS, NUM_POSE_PARAMS}; else sizes_ = {NUM_POSE_PARAMS};
+  }
+  int kind() const { return kind_; }
+  double rotation() const { return rotation_; }
+  double position() const { return position_; }
+  bool Evaluate(double const* const*, double*, double**) const override {
+    throw std::logic_error("rsba_amd: PosePriorCost::Evaluate is not provided stand-alone; add the block to a ceres::Problem (Problem::Evaluate / Solve)");
+  }
+ private:
+  int kind_; double rotation_, position_;
+};
+
 class Problem;
 struct Solver {
   struct Options {
@@ -284,6 +304,7 @@ class Problem {
     if (!flatten(&f, nullptr)) return false;
     rsba_handle* h = nullptr;
     if (residuals && !f.prior_frames.empty()) return false;   // per-block residual output covers the reprojection blocks only
+    if (gradient && !f.pp_blocks.empty()) return false;   // the gradient over the priorPoses blocks is not part of the device output
     if (create_handle(f, 0, &h) != RSBA_OK) return false;
     std::vector<double> g;
     if (gradient) g.resize(f.poses.size() + f.points.size() + f.intr.size());
@@ -296,7 +317,7 @@ class Problem {
       gradient->clear();
       for (double* p : block_order_) {
         const Slot s = f.slot_of[p];
-        if (s.kind == 3) { gradient->insert(gradient->end(), (size_t)block_sizes_[p], 0.0); continue; }   // constant data block
+        if (s.kind == 3 || s.kind == 4) { gradient->insert(gradient->end(), (size_t)block_sizes_[p], 0.0); continue; }   // constant data block
         const double* src = s.kind == 0 ? &g[(size_t)s.index * 6] : s.kind == 1 ? &g[f.poses.size() + (size_t)s.index * 3] : &g[f.poses.size() + f.points.size() + (size_t)s.index * 9];
         gradient->insert(gradient->end(), src, src + block_sizes_[p]);
       }
@@ -308,7 +329,7 @@ class Problem {
   friend void Solve(const Solver::Options&, Problem*, Solver::Summary*);
   friend class Covariance;
   struct Block { CostFunction* cost; LossFunction* loss; std::vector<double*> x; };
-  struct Slot { int kind; int index; };   // kind 0 pose block, 1 point, 2 intrinsics, 3 constant scalar data (interFrameRatio)
+  struct Slot { int kind; int index; };   // kind 0 pose block, 1 point, 2 intrinsics, 3 scalar (interFrameRatio), 4 priorPoses block of a GoodPosePrior
   struct Flat {
     rsba_problem_desc desc;
     std::vector<double> poses, points, intr, xy;
@@ -321,6 +342,9 @@ class Problem {
     std::vector<int32_t> prior_frames;
     double* ratio_ptr = nullptr;       // the interFrameRatio block; ratio_free: it is a (lower-bounded) parameter of the solve
     bool ratio_free = false;
+    // per-pose priors: lowered to rsba_set_pose_priors
+    std::vector<int32_t> pp_blocks; std::vector<double> pp_values; std::vector<double*> pp_ptr;   // GoodPosePrior: pose block, priorPoses values / where they came from
+    double pp_rotation = 0, pp_position = 0; int32_t spherical_block = -1;
   };
   // device problem of a flattened graph: rsba_create + the prior blocks
   static int32_t create_handle(const Flat& f, int device, rsba_handle** h) {
@@ -329,6 +353,10 @@ class Problem {
     if (!f.prior_frames.empty()) {
       st = rsba_set_motion_priors(*h, f.prior_kind, f.prior_scale, f.prior_ratio, f.prior_frames.data(), (int32_t)f.prior_frames.size());
       if (st == RSBA_OK && f.ratio_free) st = rsba_set_inter_frame_ratio_free(*h, 1);
+      if (st != RSBA_OK) { rsba_destroy(*h); *h = nullptr; return st; }
+    }
+    if (!f.pp_blocks.empty() || f.spherical_block >= 0) {
+      st = rsba_set_pose_priors(*h, f.pp_rotation, f.pp_position, f.pp_blocks.data(), const_cast<double*>(f.pp_values.data()), (int32_t)f.pp_blocks.size(), f.spherical_block);
       if (st != RSBA_OK) { rsba_destroy(*h); *h = nullptr; }
     }
     return st;
@@ -365,7 +393,7 @@ class Problem {
     std::map<std::vector<double>, int> intr_by_value;
     int32_t sl[2]; first->scanlines(sl);
     for (const Block& b : blocks_) {
-      if (dynamic_cast<const MotionPriorCost*>(b.cost)) continue;   // second pass below, once every frame has its number
+      if (dynamic_cast<const MotionPriorCost*>(b.cost) || dynamic_cast<const PosePriorCost*>(b.cost)) continue;   // later passes, once every frame has its number
       const ReprojectionCost* c = dynamic_cast<const ReprojectionCost*>(b.cost);
       if (!c) return fail("only rsba's reprojection cost functions (plus motion priors between their frames) are accelerated");
       if (c->rolling() != rolling || c->with_cam() != with_cam) return fail("mixed functor shapes in one problem are not supported");
@@ -476,7 +504,29 @@ class Problem {
       }
     }
     std::sort(f->prior_frames.begin(), f->prior_frames.end());
-    const int nscalar = f->prior_frames.empty() ? 0 : 1;
+    // per-pose priors (CeresHandler.h:127-130, 188-204): GoodPosePrior over (priorPoses[i], poses[i]), SphericalPrior over poses[0]
+    for (const Block& b : blocks_) {
+      const PosePriorCost* c = dynamic_cast<const PosePriorCost*>(b.cost);
+      if (!c) continue;
+      if (b.loss != nullptr) return fail("pose priors take no loss function (CeresHandler passes nullptr)");
+      if (b.x.size() != c->parameter_block_sizes().size()) return fail("wrong number of parameter blocks");
+      double* pose = b.x.back();
+      auto it = f->slot_of.find(pose);
+      if (it == f->slot_of.end() || it->second.kind != 0) return fail("pose prior on a pose block that no reprojection block or motion prior uses");
+      if (c->kind() == 1) {
+        if (f->spherical_block >= 0) return fail("two SphericalPrior blocks in one problem");
+        f->spherical_block = it->second.index;
+      } else {
+        if (constant_.count(b.x[0])) return fail("a constant priorPoses block is not supported (CeresHandler leaves them free)");
+        if (f->slot_of.count(b.x[0])) return fail("a priorPoses block is used in another role");
+        if (!f->pp_blocks.empty() && (f->pp_rotation != c->rotation() || f->pp_position != c->position())) return fail("GoodPosePrior blocks of one problem must share their weights");
+        f->pp_rotation = c->rotation(); f->pp_position = c->position();
+        f->pp_blocks.push_back(it->second.index); f->pp_ptr.push_back(b.x[0]);
+        f->pp_values.insert(f->pp_values.end(), b.x[0], b.x[0] + 6);
+      }
+    }
+    for (size_t k = 0; k < f->pp_ptr.size(); ++k) f->slot_of[f->pp_ptr[k]] = Slot{4, (int)k};
+    const int nscalar = (f->prior_frames.empty() ? 0 : 1) + (int)f->pp_ptr.size();
     // a pose pointer may not serve as pose0 of one frame and pose1 of another
     if ((int)f->slot_of.size() - nscalar != (int)f->pose_ptr.size() + (int)f->point_ptr.size() + (with_cam ? (int)f->intr_ptr.size() : 0))
       return fail("a parameter block is used in two different roles");
@@ -484,6 +534,7 @@ class Problem {
     for (double* p : f->point_ptr) f->point_const.push_back(constant_.count(p) ? 1 : 0);
     for (double* p : f->intr_ptr) f->intr_const.push_back(p && constant_.count(p) ? 1 : 0);
     for (const auto& lb : lower_bounds_) { auto it = f->slot_of.find(lb.first.first); if (it != f->slot_of.end() && it->second.kind != 3) return fail("bounds on pose / point / intrinsics blocks are not supported"); }
+    for (double* q : f->pp_ptr) if (parameterization_.count(q)) return fail("a parameterization on a priorPoses block is not supported");
     rsba_problem_desc& d = f->desc; std::memset(&d, 0, sizeof d);
     d.shutter = first->shutter(); d.scanlines[0] = sl[0]; d.scanlines[1] = sl[1];
     d.interpolate_rotation = first->interpolate_rotation(); d.calibrated = !with_cam; d.poses_per_frame = P;
@@ -504,6 +555,7 @@ class Problem {
     for (int b = 0; b < nposeblk; ++b) std::memcpy(f.pose_ptr[b], &f.poses[(size_t)b * 6], 6 * sizeof(double));
     for (size_t j = 0; j < f.point_ptr.size(); ++j) std::memcpy(f.point_ptr[j], &f.points[j * 3], 3 * sizeof(double));
     for (size_t c = 0; c < f.intr_ptr.size(); ++c) if (f.intr_ptr[c]) std::memcpy(f.intr_ptr[c], &f.intr[c * 9], 9 * sizeof(double));
+    for (size_t k = 0; k < f.pp_ptr.size(); ++k) std::memcpy(f.pp_ptr[k], &f.pp_values[k * 6], 6 * sizeof(double));   // the priorPoses blocks are solved for too
   }
 
   std::vector<Block> blocks_;

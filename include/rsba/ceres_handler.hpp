@@ -3,8 +3,8 @@
 //   VideoSfMHandler::BA                        /root/reference/src/rsba/VideoSfMHandler.cc:574-631
 // Same names, argument meaning and error behaviour for the per-observation path (SURVEY Appendix D
 // steps 1, 3-4: pose initialisation of frames without poses, the observation loop incl. the match-based track lookup).
-// Not built (the rest of SURVEY §8f row f1 and out-of-scope costs): SphericalPrior, pose priors (GoodPosePrior), the
-// structure-less ray costs — reaching one of them throws std::runtime_error.  Motion priors (:147-186) are built, with a known
+// Not built (out-of-scope costs): the structure-less ray costs — reaching them throws std::runtime_error.  The per-pose priors
+// (SphericalPrior :127-130, GoodPosePrior :188-204) and the motion priors (:147-186) are built, the latter with a known
 // opt.ceres.interFrameRatio (!= 1: constant block) and with the free, lower-bounded ratio of the default.  opt.debug.calcCovariances (VideoSfMHandler.cc:599-621) is built.  revalidateReprojections (:239-243) runs as one
 // batched device validation per frame (video_sfm.hpp).
 #pragma once
@@ -16,6 +16,7 @@
 #include <thread>
 
 #include "motion_priors.hpp"
+#include "pose_priors.hpp"
 #include "reprojection_costs.hpp"
 #include "video_sfm.hpp"
 
@@ -64,7 +65,7 @@ class CeresHandler {
           for (auto& pose : f_1.poses) if (originFrame) for (double p : pose) if (p != 0) originFrame = false;
           for (auto& pose : f.poses) { pose[3] += 1e-4; pose[4] += 1e-4; pose[5] += 1e-4; }
           if (frameKey == 1 && originFrame)                             // :127-130
-            throw std::runtime_error("SphericalPrior (CeresHandler.h:36-50,127-130: second frame of a session that starts at the origin) is not built");
+            problem.AddResidualBlock(SphericalPrior::Create(), nullptr, f.poses[0].data());
         }
       } else {                                                          // frameKey == 0: zeros
         f.poses.assign(opt.model.rolling_shutter ? 2 : 1, std::vector<double>(NUM_POSE_PARAMS, 0.0));
@@ -94,8 +95,12 @@ class CeresHandler {
           }
         }
       }
-      if ((opt.ceres.trustPriorCamRotation != 0 || opt.ceres.trustPriorCamPosition != 0) && f.__isset.priorPoses && !f.priorPoses.empty())
-        throw std::runtime_error("pose priors (CeresHandler.h:188-204) are not built");
+      if ((opt.ceres.trustPriorCamRotation != 0 || opt.ceres.trustPriorCamPosition != 0) && f.__isset.priorPoses && !f.priorPoses.empty()) {   // :188-204
+        if (!f.__isset.poses || f.poses.size() != f.priorPoses.size()) f.poses = f.priorPoses;
+        for (size_t i = 0; i < f.poses.size(); i++)
+          problem.AddResidualBlock(GoodPosePrior::Create(opt.ceres.trustPriorCamRotation, opt.ceres.trustPriorCamPosition), nullptr,
+                                   f.priorPoses[i].data(), f.poses[i].data());
+      }
     }
     if (!opt.model.use3Dpoints) throw std::runtime_error("structure-less costs (CeresHandler.h:303-332) are not built");
     std::vector<Track*> track_of(f.obs.size(), nullptr);

@@ -257,6 +257,22 @@ int32_t rsba_set_motion_priors(rsba_handle* h, int32_t kind, double scale, doubl
 int32_t rsba_set_inter_frame_ratio_free(rsba_handle* h, int32_t is_free);
 int32_t rsba_get_inter_frame_ratio(rsba_handle* h, double* ratio);
 
+/* == the per-pose prior blocks of CeresHandler::Add, neither with a loss function (nullptr in the reference):
+ *   GoodPosePrior (CeresHandler.h:52-73, attached at :188-204 when opt.ceres.trustPriorCamRotation / trustPriorCamPosition are set
+ *     and the frame has priorPoses): 6 residuals W (prior - pose) over TWO parameter blocks — the frame's priorPoses[i], a FREE
+ *     block like every block Ceres is handed, and poses[i]; rotation rows times `rotation`, position rows times `position`; the
+ *     functor fails when residual[0] >= 1.  pose_blocks[k] = f * poses_per_frame + i, distinct; prior_values [count][6] are the
+ *     caller's priorPoses blocks: rsba_solve writes the solved values back, rsba_upload_parameters re-reads them.
+ *   SphericalPrior (:36-50, attached at :127-130 to poses[0] of frame 1 of a session that starts at the origin): residuals
+ *     |rot|^2 and 1e20 (1 - |cx| - |cy| - |cz|); fails when |rot|^2 >= 1.  spherical_pose_block = its pose block, -1 = none.
+ *     (A 1e20-weighted residual: once it is met, its value is rounding noise times 1e20 — the cost Ceres and this library
+ *     report then carries that noise; see DESIGN.md.)
+ * The blocks count in cost, gradient (pose coordinates), num_residual_blocks and the solve; the priorPoses blocks are eliminated
+ * in closed form like points.  Must precede the first solve / gradient call.  With rsba_set_exchange every rank passes the same
+ * blocks (rank 0 contributes them). */
+int32_t rsba_set_pose_priors(rsba_handle* h, double rotation, double position, const int32_t* pose_blocks, double* prior_values, int32_t count,
+                             int32_t spherical_pose_block);
+
 /* == the RANSAC hypotheses of vision::solveRsPnPRansac (solveRSpnp.cpp:413-524), batched: task t is
  * what pnpTask (:265-335) does for the subset subsets[t][0..m) of the n float points —
  *   skipped (status 0, nothing else written) when drop_coincident != 0 and two of its 3-D points coincide (:283-293;

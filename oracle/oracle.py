@@ -36,6 +36,9 @@ class OrcProblem(C.Structure):
         ("intrinsics_constant", C.c_void_p), ("huber_a", C.c_double),
         ("prior_kind", C.c_int32), ("num_priors", C.c_int32), ("prior_frames", C.c_void_p),
         ("prior_scale", C.c_double), ("inter_frame_ratio", C.c_double),
+        ("num_pose_priors", C.c_int32), ("pose_prior_block", C.c_void_p), ("pose_prior_values", C.c_void_p),
+        ("pose_prior_rotation", C.c_double), ("pose_prior_position", C.c_double),
+        ("spherical_pose_block", C.c_int32), ("has_spherical", C.c_int32),
         ("no_validate", C.c_int32), ("ratio_free", C.c_int32),
     ]
 
@@ -113,6 +116,14 @@ def desc(prob) -> OrcProblem:
     d.prior_frames = _ptr(prob.prior_frames) if d.prior_kind else None
     d.prior_scale, d.inter_frame_ratio = float(prob.prior_scale), float(prob.inter_frame_ratio)
     d.ratio_free = int(bool(getattr(prob, 'ratio_free', False)))
+    pb = getattr(prob, "pose_prior_block", None)
+    if pb is not None and len(pb):
+        d.num_pose_priors = len(pb)
+        d.pose_prior_block, d.pose_prior_values = _ptr(prob.pose_prior_block), _ptr(prob.pose_prior_values)
+        d.pose_prior_rotation, d.pose_prior_position = float(prob.pose_prior_rotation), float(prob.pose_prior_position)
+    sp = getattr(prob, "spherical_pose_block", None)
+    if sp is not None and sp >= 0:
+        d.spherical_pose_block, d.has_spherical = int(sp), 1
     d._keep = prob  # keep arrays alive
     return d
 

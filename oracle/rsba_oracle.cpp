@@ -120,6 +120,22 @@ bool prior_eval(const orc_problem* p, int k, double* r, double* J) {
   return true;
 }
 
+// GoodPosePrior::operator() (CeresHandler.h:58-64): minus6(pose0, pose), rotation rows times `rotation`, position rows times
+// `position`; valid while residuals[0] < 1.  SphericalPrior::operator() (:40-44).
+template <class T>
+bool good_pose_prior(double rotation, double position, const T* pose0, const T* pose, T* res) {
+  for (int i = 0; i < 6; ++i) res[i] = pose0[i] - pose[i];
+  for (int i = 0; i < 3; ++i) res[i] = res[i] * T(rotation);
+  for (int i = 3; i < 6; ++i) res[i] = res[i] * T(position);
+  return res[0] < T(1.0);
+}
+template <class T>
+bool spherical_prior(const T* pose, T* res) {
+  res[0] = (pose[0] * pose[0] + pose[1] * pose[1] + pose[2] * pose[2]);
+  res[1] = T(1e20) * (T(1.0) - abs(pose[3]) - abs(pose[4]) - abs(pose[5]));
+  return res[0] < T(1.0);
+}
+
 typedef bool (*block_fn)(const orc_problem*, int64_t, double*, double*);
 block_fn pick_block_fn(const Layout& L) {
   if (L.cal) return L.P == 2 ? block_eval<true, 2> : block_eval<true, 1>;
@@ -185,6 +201,10 @@ struct Eval {
   int64_t ncam, nparam;               // camera-side unknowns (poses + intrinsics), all unknowns
   // motion-prior blocks: corrected residuals [NP][12], Jacobian [NP][12][24], dropped flags
   int NP = 0, PC = 24; int64_t iratio = -1; std::vector<double> pr, pJ; std::vector<uint8_t> pdropped;   // PC 25 / iratio >= 0: free interFrameRatio
+  // per-pose prior blocks (GoodPosePrior: columns [priorPoses block 6 | pose block 6], 6 residuals; SphericalPrior: [pose
+  // block 6], 2 residuals), no loss function.  The priorPoses blocks are camera-side unknowns behind everything else.
+  struct Extra { int nres, ncol; int64_t col[12]; double r[6], J[6 * 12]; bool dropped; int kind, which; };
+  std::vector<Extra> ex; int64_t ipp = -1;
   // global column of local column c of prior k
   inline int64_t pcol(int k, int c) const { const int f = p->prior_frames[k]; return c == 24 ? iratio : c < 12 ? (int64_t)f * 12 + c : (int64_t)(f - 1) * 12 + (c - 12); }
   Eval(const orc_problem* pp) : p(pp), L(layout_of(pp)) {
@@ -192,6 +212,17 @@ struct Eval {
     ncam = (int64_t)F * L.CD + (L.cal ? 0 : (int64_t)NI * 9);
     NP = (p->prior_kind != 0 && L.P == 2) ? p->num_priors : 0;
     if (NP > 0 && p->ratio_free) { iratio = ncam; ncam += 1; PC = 25; }   // the ratio is one more camera-side unknown
+    if (p->num_pose_priors > 0) { ipp = ncam; ncam += 6 * (int64_t)p->num_pose_priors; }
+    for (int k = 0; k < p->num_pose_priors; ++k) {
+      Extra e{}; e.nres = 6; e.ncol = 12; e.kind = 0; e.which = k;
+      for (int c = 0; c < 6; ++c) { e.col[c] = ipp + 6 * (int64_t)k + c; e.col[6 + c] = 6 * (int64_t)p->pose_prior_block[k] + c; }
+      ex.push_back(e);
+    }
+    if (p->has_spherical) {
+      Extra e{}; e.nres = 2; e.ncol = 6; e.kind = 1; e.which = p->spherical_pose_block;
+      for (int c = 0; c < 6; ++c) e.col[c] = 6 * (int64_t)p->spherical_pose_block + c;
+      ex.push_back(e);
+    }
     nparam = ncam + (int64_t)M * 3;
     colmask.assign(nparam, 0);
     for (int f = 0; f < F; ++f) for (int q = 0; q < L.P; ++q) {
@@ -211,7 +242,10 @@ struct Eval {
     }
     pdropped.assign(NP, 0);
     for (int k = 0; k < NP; ++k) { bool all_const = true; for (int c = 0; c < PC && all_const; ++c) if (!colmask[pcol(k, c)]) all_const = false; pdropped[k] = all_const; }
+    for (Extra& e : ex) { bool all_const = true; for (int c = 0; c < e.ncol && all_const; ++c) if (!colmask[e.col[c]]) all_const = false; e.dropped = all_const; }
   }
+  // value of global camera-side column a that belongs to a pose or a priorPoses block
+  inline double pose_like_value(int64_t a) const { return (ipp >= 0 && a >= ipp) ? p->pose_prior_values[a - ipp] : p->poses[a]; }
   // global column of local column k of observation i
   inline int64_t gcol(int64_t i, int k) const {
     const int f = p->obs_frame[i];
@@ -284,6 +318,16 @@ struct Eval {
       }
       if (Jk) for (int cc = 0; cc < PC; ++cc) if (colmask[pcol(k, cc)]) for (int i = 0; i < 12; ++i) Jk[i * kPC + cc] = 0.0;
     }
+    for (Extra& e : ex) {
+      typedef Dual<12> D;
+      D x[12], res[6];
+      for (int cc = 0; cc < e.ncol; ++cc) x[cc] = D(pose_like_value(e.col[cc]), cc);
+      const bool ok = e.kind == 0 ? good_pose_prior<D>(p->pose_prior_rotation, p->pose_prior_position, x, x + 6, res) : spherical_prior<D>(x, res);
+      if (!ok) { ++bad; continue; }
+      double sq = 0.0;
+      for (int i = 0; i < e.nres; ++i) { e.r[i] = res[i].a; sq += e.r[i] * e.r[i]; for (int cc = 0; cc < e.ncol; ++cc) e.J[i * 12 + cc] = colmask[e.col[cc]] ? 0.0 : res[i].v[cc]; }
+      if (e.dropped) cf += 0.5 * sq; else c += 0.5 * sq;     // no loss function on these blocks
+    }
     if (cost) *cost = c;
     if (fixed) *fixed = cf;
     return bad == 0;
@@ -296,6 +340,13 @@ struct Eval {
         double ga = 0.0; for (int i = 0; i < 12; ++i) ga += Jk[i * kPC + a] * rk[i];
         g(pcol(k, a), ga);
         for (int b = 0; b < PC; ++b) { double hab = 0.0; for (int i = 0; i < 12; ++i) hab += Jk[i * kPC + a] * Jk[i * kPC + b]; if (hab != 0.0) h(pcol(k, a), pcol(k, b), hab); }
+      }
+    }
+    for (const Extra& e : ex) {
+      for (int a = 0; a < e.ncol; ++a) {
+        double ga = 0.0; for (int i = 0; i < e.nres; ++i) ga += e.J[i * 12 + a] * e.r[i];
+        g(e.col[a], ga);
+        for (int b = 0; b < e.ncol; ++b) { double hab = 0.0; for (int i = 0; i < e.nres; ++i) hab += e.J[i * 12 + a] * e.J[i * 12 + b]; if (hab != 0.0) h(e.col[a], e.col[b], hab); }
       }
     }
   }
@@ -431,6 +482,11 @@ bool reduced_system(const Eval& E, const PointCsr& pc, const std::vector<double>
       int64_t cmin = nc;
       for (int c = 0; c < E.PC; ++c) cmin = std::min(cmin, E.pcol(k, c));
       for (int c = 0; c < E.PC; ++c) { int64_t& l = lo[E.pcol(k, c)]; l = std::min(l, cmin); }
+    }
+    for (const Eval::Extra& e : E.ex) {
+      int64_t cmin = nc;
+      for (int c = 0; c < e.ncol; ++c) cmin = std::min(cmin, e.col[c]);
+      for (int c = 0; c < e.ncol; ++c) { int64_t& l = lo[e.col[c]]; l = std::min(l, cmin); }
     }
     S.shape(lo);
   }
@@ -647,8 +703,9 @@ int32_t orc_normal_equations(const orc_problem* p, double* U, double* gc, double
     }
   }
   // motion priors: their share of the block diagonal (the frame-to-frame cross blocks are not part of this output)
-  E.prior_normal([&](int64_t a, double v) { gc[a] += v; },
-                 [&](int64_t a, int64_t b, double v) { if (a / CD == b / CD) U[(size_t)(a / CD) * CD * CD + (a % CD) * CD + (b % CD)] += v; });
+  const int64_t npose_cols = (int64_t)E.F * CD;   // (the priorPoses blocks of GoodPosePrior are not part of this output)
+  E.prior_normal([&](int64_t a, double v) { if (a < npose_cols) gc[a] += v; },
+                 [&](int64_t a, int64_t b, double v) { if (a < npose_cols && b < npose_cols && a / CD == b / CD) U[(size_t)(a / CD) * CD * CD + (a % CD) * CD + (b % CD)] += v; });
   return 0;
 }
 
@@ -661,9 +718,10 @@ int32_t orc_solve(orc_problem* p, const orc_options* opt, orc_summary* sum, orc_
   const PointCsr pc = point_csr(p);
   std::memset(sum, 0, sizeof *sum);
   sum->termination_type = ORC_NO_CONVERGENCE;
-  sum->num_residual_blocks = (int32_t)(N + E.NP);
+  sum->num_residual_blocks = (int32_t)(N + E.NP + (int64_t)E.ex.size());
   int64_t nred = 0; for (int64_t i = 0; i < N; ++i) nred += !E.dropped[i];
   for (int k = 0; k < E.NP; ++k) nred += !E.pdropped[k];
+  for (const Eval::Extra& e : E.ex) nred += !e.dropped;
   sum->num_residual_blocks_reduced = (int32_t)nred;
   // which parameter BLOCKS are in the reduced program (non-constant): used for |x| and |step|
   std::vector<uint8_t> in_program(np, 0);
@@ -680,6 +738,8 @@ int32_t orc_solve(orc_problem* p, const orc_options* opt, orc_summary* sum, orc_
     for (int64_t i = 0; i < N; ++i) for (int k = 0; k < K; ++k) touched[E.gcol(i, k)] = 1;
     if (E.iratio >= 0) for (int k = 0; k < 1; ++k) in_program[E.iratio] = 1;
     for (int k = 0; k < E.NP; ++k) for (int c = 0; c < E.PC; ++c) touched[E.pcol(k, c)] = 1;
+    if (E.ipp >= 0) for (int64_t a = E.ipp; a < E.ncam; ++a) in_program[a] = 1;     // the priorPoses blocks are free parameter blocks
+    for (const Eval::Extra& e : E.ex) for (int c = 0; c < e.ncol; ++c) touched[e.col[c]] = 1;
     for (int64_t a = 0; a < np; ++a) if (!touched[a]) in_program[a] = 0;
   }
   int64_t nfree = 0; for (int64_t a = 0; a < np; ++a) nfree += (in_program[a] && !E.colmask[a]);
@@ -689,6 +749,7 @@ int32_t orc_solve(orc_problem* p, const orc_options* opt, orc_summary* sum, orc_
     const int64_t npose = (int64_t)E.F * L.CD;
     if (a < npose) return p->poses + a;
     if (a == E.iratio) return &p->inter_frame_ratio;
+    if (E.ipp >= 0 && a >= E.ipp && a < E.ncam) return p->pose_prior_values + (a - E.ipp);
     if (a < E.ncam) return p->intrinsics + (a - npose);
     return p->points + (a - E.ncam);
   };
@@ -707,11 +768,13 @@ int32_t orc_solve(orc_problem* p, const orc_options* opt, orc_summary* sum, orc_
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < N; ++i) for (int k = 0; k < K; ++k) { const double s = sc[E.gcol(i, k)]; E.J[(size_t)2 * K * i + k] *= s; E.J[(size_t)2 * K * i + K + k] *= s; }
     for (int k = 0; k < E.NP; ++k) for (int c = 0; c < E.PC; ++c) { const double s = sc[E.pcol(k, c)]; for (int i = 0; i < 12; ++i) E.pJ[(size_t)12 * kPC * k + i * kPC + c] *= s; }
+    for (Eval::Extra& e : E.ex) for (int c = 0; c < e.ncol; ++c) { const double s = sc[e.col[c]]; for (int i = 0; i < e.nres; ++i) e.J[i * 12 + c] *= s; }
   };
   auto col_sq_norms = [&](std::vector<double>& d) {
     d.assign(np, 0.0);
     for (int64_t i = 0; i < N; ++i) for (int k = 0; k < K; ++k) { const double a = E.J[(size_t)2 * K * i + k], b = E.J[(size_t)2 * K * i + K + k]; d[E.gcol(i, k)] += a * a + b * b; }
     for (int k = 0; k < E.NP; ++k) for (int c = 0; c < E.PC; ++c) for (int i = 0; i < 12; ++i) { const double a = E.pJ[(size_t)12 * kPC * k + i * kPC + c]; d[E.pcol(k, c)] += a * a; }
+    for (const Eval::Extra& e : E.ex) for (int c = 0; c < e.ncol; ++c) for (int i = 0; i < e.nres; ++i) { const double a = e.J[i * 12 + c]; d[e.col[c]] += a * a; }
   };
   int ntrace = 0;
   auto push = [&](const orc_iteration& it) { if (trace && ntrace < trace_cap) trace[ntrace] = it; ++ntrace; sum->num_iterations = ntrace; };
@@ -771,6 +834,11 @@ int32_t orc_solve(orc_problem* p, const orc_options* opt, orc_summary* sum, orc_
         for (int c = 0; c < E.PC; ++c) m += E.pJ[(size_t)12 * kPC * k + i * kPC + c] * -y[E.pcol(k, c)];
         acc += m * (E.pr[(size_t)12 * k + i] + 0.5 * m);
       }
+      for (const Eval::Extra& e : E.ex) for (int i = 0; i < e.nres; ++i) {
+        double m = 0.0;
+        for (int c = 0; c < e.ncol; ++c) m += e.J[i * 12 + c] * -y[e.col[c]];
+        acc += m * (e.r[i] + 0.5 * m);
+      }
       model_cost_change = -acc;
       valid = model_cost_change >= 0.0;   // Ceres: invalid iff model_cost_change < 0
     }
@@ -787,9 +855,11 @@ int32_t orc_solve(orc_problem* p, const orc_options* opt, orc_summary* sum, orc_
       for (int64_t a = 0; a < np; ++a) { x_save[a] = *param_ptr(a); const double d = -y[a] * scale[a]; if (in_program[a] && !E.colmask[a]) { *param_ptr(a) = x_save[a] + d; if (a == E.iratio && *param_ptr(a) < ratio_lb) *param_ptr(a) = ratio_lb; const double e = x_save[a] - *param_ptr(a); step_sq += e * e; } }
       // keep the current linearisation; evaluate residuals only at the candidate
       r_cur.swap(E.r); J_cur.swap(E.J); pr_cur.swap(E.pr);
+      const std::vector<Eval::Extra> ex_cur = E.ex;
       double new_cost = 0, new_fixed = 0;
       const bool ev_ok = E.run(false, &new_cost, &new_fixed);
       E.r.swap(r_cur); E.J.swap(J_cur); E.pr.swap(pr_cur);
+      E.ex = ex_cur;
       if (!ev_ok) new_cost = std::numeric_limits<double>::max();
       it.step_norm = std::sqrt(step_sq);
       const double step_tol = opt->parameter_tolerance * (x_norm + opt->parameter_tolerance);

@@ -40,6 +40,18 @@ typedef struct orc_problem {
   const int32_t* prior_frames;   /* [num_priors], strictly increasing, each >= 1 */
   double prior_scale;            /* opt.ceres.constFrameVelocity / constFrameAcceleration */
   double inter_frame_ratio;      /* opt.ceres.interFrameRatio */
+  /* Per-pose prior blocks of CeresHandler::Add, neither with a loss function (nullptr in the reference):
+   *   GoodPosePrior (CeresHandler.h:52-73, attached at :188-204): 6 residuals over TWO parameter blocks, the frame's
+   *   priorPoses[i] — free, like every block Ceres is handed — and poses[i]: (prior - pose), rotation rows times
+   *   pose_prior_rotation, position rows times pose_prior_position; the functor fails when residual[0] >= 1.
+   *   SphericalPrior (:36-50, attached at :127-130 to poses[0] of frame 1 of a session that starts at the origin):
+   *   residuals |rot|^2 and 1e20 (1 - |cx| - |cy| - |cz|); fails when |rot|^2 >= 1. */
+  int32_t num_pose_priors;
+  const int32_t* pose_prior_block;  /* [num_pose_priors] pose block index f * P + q */
+  double* pose_prior_values;        /* [num_pose_priors][6] the priorPoses blocks, in/out */
+  double pose_prior_rotation, pose_prior_position;   /* opt.ceres.trustPriorCamRotation / trustPriorCamPosition */
+  int32_t spherical_pose_block;     /* pose block carrying the SphericalPrior; only read when has_spherical != 0 */
+  int32_t has_spherical;
   int32_t no_validate;           /* 1 = the RS-PnP functor RsBA: w2i(..., validate = false) (solveRSpnp.cpp:67) */
   int32_t ratio_free;            /* 1 = interFrameRatio is a free, lower-bounded parameter block (the reference's default, option left at 1:
                                   * CeresHandler.h:161,172,175); orc_solve updates inter_frame_ratio in place */

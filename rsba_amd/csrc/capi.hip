@@ -153,6 +153,7 @@ int32_t rsba_create(const rsba_problem_desc* d, int32_t device, rsba_handle** ou
 
   DeviceProblem& dp = h->dp;
   std::memset(&dp, 0, sizeof dp);
+  dp.pp_spherical = -1;
   dp.shutter = d->shutter; dp.scan0 = d->scanlines[0]; dp.scan1 = d->scanlines[1];
   dp.interp_rotation = d->interpolate_rotation != 0; dp.calibrated = d->calibrated != 0; dp.P = d->poses_per_frame;
   dp.F = d->num_frames; dp.M = d->num_points; dp.NI = d->num_intrinsics; dp.N = N;
@@ -223,6 +224,7 @@ int32_t rsba_upload_parameters(rsba_handle* h, const double* poses, const double
   if (poses) HIP_TRY(hipMemcpyAsync(dp.poses, poses, (size_t)dp.F * dp.P * 6 * sizeof(double), hipMemcpyHostToDevice, h->stream));
   if (points) HIP_TRY(hipMemcpyAsync(dp.points, points, (size_t)dp.M * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
   if (intr) HIP_TRY(hipMemcpyAsync(dp.intr, intr, (size_t)dp.NI * 9 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (dp.pp_count > 0 && h->pp_host) HIP_TRY(hipMemcpyAsync(dp.pp_value, h->pp_host, 6 * (size_t)dp.pp_count * sizeof(double), hipMemcpyHostToDevice, h->stream));   // the priorPoses blocks are parameters too
   HIP_TRY(hipStreamSynchronize(h->stream));
   return RSBA_OK;
 }
@@ -300,6 +302,34 @@ int32_t rsba_set_motion_priors(rsba_handle* h, int32_t kind, double scale, doubl
   return RSBA_OK;
 }
 
+int32_t rsba_set_pose_priors(rsba_handle* h, double rotation, double position, const int32_t* pose_blocks, double* prior_values, int32_t count,
+                             int32_t spherical_pose_block) {
+  if (!h || count < 0 || (count > 0 && (!pose_blocks || !prior_values))) return fail(RSBA_ERR_INVALID_ARGUMENT, "bad pose prior arguments");
+  if (h->solver) return fail(RSBA_ERR_INVALID_ARGUMENT, "rsba_set_pose_priors must precede the first solve / gradient call");
+  DeviceProblem& dp = h->dp;
+  const int nblocks = dp.F * dp.P;
+  if (spherical_pose_block >= nblocks) return fail(RSBA_ERR_INVALID_ARGUMENT, "spherical pose block out of range");
+  std::vector<uint8_t> used((size_t)nblocks, 0);
+  for (int32_t k = 0; k < count; ++k) {
+    if (pose_blocks[k] < 0 || pose_blocks[k] >= nblocks || used[pose_blocks[k]]) return fail(RSBA_ERR_INVALID_ARGUMENT, "pose prior blocks must be distinct pose blocks f * P + q");
+    used[pose_blocks[k]] = 1;
+  }
+  HIP_TRY(hipSetDevice(h->device));
+  dp.pp_count = count; dp.pp_rotation = rotation; dp.pp_position = position; dp.pp_spherical = spherical_pose_block < 0 ? -1 : spherical_pose_block;
+  h->pp_blocks.assign(pose_blocks, pose_blocks + count); h->pp_host = prior_values;
+  if (count > 0) {
+    int32_t* d_blocks = nullptr;
+    int32_t rc = dev_upload(h, &d_blocks, pose_blocks, (size_t)count);
+    if (rc) return rc;
+    dp.pp_block = d_blocks;
+    if ((rc = dev_upload(h, &dp.pp_value, prior_values, 6 * (size_t)count))) return rc;
+    if ((rc = dev_upload(h, &dp.pp_trial, prior_values, 6 * (size_t)count))) return rc;
+    std::vector<double> ones(6 * (size_t)count, 1.0);
+    if ((rc = dev_upload(h, &dp.pp_scale, ones.data(), ones.size()))) return rc;
+  }
+  return RSBA_OK;
+}
+
 int32_t rsba_set_inter_frame_ratio_free(rsba_handle* h, int32_t is_free) {
   if (!h) return fail(RSBA_ERR_INVALID_ARGUMENT, "null handle");
   if (h->solver) return fail(RSBA_ERR_INVALID_ARGUMENT, "rsba_set_inter_frame_ratio_free must precede the first solve / gradient call");
@@ -322,6 +352,7 @@ int32_t rsba_evaluate(rsba_handle* h, double* cost, double* residuals, double* j
   HIP_TRY(launch_eval(dp, jacobians ? kRawJacobian : kResidualOnly, h->stream));
   HIP_TRY(launch_cost_reduce(dp, h->d_cost2, h->stream));
   if (dp.prior_of && h->rank == 0) HIP_TRY(launch_prior_cost(dp, h->d_cost2, h->prior_invalid, h->stream));
+  if (h->rank == 0) HIP_TRY(launch_pose_prior_cost(dp, h->d_cost2, h->stream));
   double c2[2] = {0, 0}; int nfail = 0;
   HIP_TRY(hipMemcpyAsync(c2, h->d_cost2, sizeof c2, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipMemcpyAsync(&nfail, dp.fail_count, sizeof nfail, hipMemcpyDeviceToHost, h->stream));

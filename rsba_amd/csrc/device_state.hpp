@@ -60,6 +60,15 @@ struct DeviceProblem {
   int prior_kind;                // 1 RsConstVeloPrior, 2 RsConstAccelerationPrior
   double prior_scale, prior_ratio;
   int prior_free;                // the interFrameRatio is a free parameter block: no prior block is "all constant" then
+  // per-pose prior blocks (kernels_pose_prior.hip): GoodPosePrior on the listed pose blocks, each with its own
+  // free priorPoses parameter block, and at most one SphericalPrior
+  int pp_count;                  // GoodPosePrior blocks (0 = none)
+  const int32_t* pp_block;       // [pp_count] pose block f * P + q
+  double* pp_value;              // [pp_count][6] current priorPoses values
+  double* pp_trial;              // [pp_count][6] candidate values
+  double* pp_scale;              // [pp_count][6] column scales (1 before the Jacobi scale is estimated)
+  double pp_rotation, pp_position;   // opt.ceres.trustPriorCamRotation / trustPriorCamPosition
+  int pp_spherical;              // pose block carrying the SphericalPrior, -1 = none
   double* prior_partial;         // [2 * ceil(F / 64)] per-wave partial sums of the prior reductions
   unsigned* prior_ticket;        // arrival counter of those reductions (zero between launches)
 };
@@ -80,6 +89,8 @@ hipError_t launch_cost_reduce(const DeviceProblem& dp, double* out2, hipStream_t
 hipError_t launch_untile(const DeviceProblem& dp, const int64_t* order, bool with_jacobians, double* res_rows, double* jac_rows, hipStream_t st);
 // motion priors: cost2 += {cost, fixed cost} of the prior blocks at dp.poses (fail_count += invalid_blocks)
 hipError_t launch_prior_cost(const DeviceProblem& dp, double* cost2, int invalid_blocks, hipStream_t st);
+// per-pose priors: cost2 += {cost, fixed cost} of the blocks at dp.poses / dp.pp_value (fail_count += failed functors)
+hipError_t launch_pose_prior_cost(const DeviceProblem& dp, double* cost2, hipStream_t st);
 hipError_t launch_validate(const DeviceProblem& dp, double sq_threshold, double min_distance, uint8_t* valid, hipStream_t st);
 hipError_t launch_scatter_flags(const uint8_t* in, const int64_t* order, int64_t n, uint8_t* out, hipStream_t st);   // out[order[i]] = in[i]
 hipError_t launch_reproject(const DeviceProblem& dp, const int32_t* frames, const int32_t* points, int64_t n, double* xy_out, uint8_t* ok_out, hipStream_t st);

@@ -33,6 +33,9 @@ struct rsba_handle {
   bool prior_free = false;             // interFrameRatio is a free, lower-bounded parameter (rsba_set_inter_frame_ratio_free)
   double prior_ratio_result = 0.0;     // its value after the last solve
   int prior_invalid = 0;               // blocks whose functor returns false for the given interFrameRatio
+  // per-pose priors (rsba_set_pose_priors)
+  std::vector<int32_t> pp_blocks;      // pose blocks carrying a GoodPosePrior
+  double* pp_host = nullptr;           // caller's priorPoses values [count][6], written back by rsba_solve
   rsba::Solver* solver = nullptr;      // normal-equation / Schur / LM state, built on first use
   // multi-GPU exchange (rsba_set_exchange / rsba_set_block_structure)
   rsba_allreduce_fn allreduce = nullptr;

@@ -70,6 +70,7 @@ struct Solver {
   int64_t num_pairs = 0;
   int num_reduced_blocks = 0, num_reduced_params = 0, num_priors_reduced = 0;
   double* border = nullptr, *ubuf = nullptr, *ratio4 = nullptr;      // free interFrameRatio: its column of S [npad], the first solve's result, {h, g, b.u, b.v}
+  PosePriorDev pp{};                                                  // per-pose priors: linearisation of the priorPoses coordinates
   double* merge_buf = nullptr;                                        // sharded solve: [4 M] owned point values | owner flags
   double* ucross = nullptr;                                           // [F][CD][CD] motion-prior blocks (f, f-1), behind sv.U's J^T J blocks
 };
@@ -532,8 +533,11 @@ int32_t build_solver(rsba_handle* h) {
   int nfree = 0;
   const bool lead = h->rank == 0;
   sv.lead = lead;
+  std::vector<uint8_t> has_pose_prior((size_t)FR, 0);
+  for (int32_t b : h->pp_blocks) has_pose_prior[b / dp.P] = 1;
+  if (dp.pp_spherical >= 0) has_pose_prior[dp.pp_spherical / dp.P] = 1;
   auto frame_has_obs = [&](int f) {
-    if (has_prior[f] || has_prior[f + 1]) return true;   // touched by a motion prior block
+    if (has_prior[f] || has_prior[f + 1] || has_pose_prior[f]) return true;   // touched by a motion prior / pose prior block
     return h->frame_obs_total.empty() ? frame_ptr[f + 1] > frame_ptr[f] : h->frame_obs_total[f] > 0;
   };
   {
@@ -562,6 +566,12 @@ int32_t build_solver(rsba_handle* h) {
       bool all_const = !h->prior_free;
       for (int k = 0; k < 24 && all_const; ++k) all_const = h->mask_pose[(size_t)(f - 1) * CD + k] == 0.0;
       s->num_priors_reduced += !all_const;
+    }
+    if (lead) {   // per-pose priors: a GoodPosePrior always keeps its free priorPoses block; a SphericalPrior on a constant pose is dropped
+      s->num_priors_reduced += (int)h->pp_blocks.size();
+      nfree += 6 * (int)h->pp_blocks.size();
+      s->num_reduced_params = nfree;
+      if (dp.pp_spherical >= 0) { bool all_const = true; for (int k = 0; k < 6; ++k) all_const = all_const && h->mask_pose[(size_t)dp.pp_spherical * 6 + k] == 0.0; s->num_priors_reduced += !all_const; }
     }
     s->num_reduced_blocks = (int)nred;
   }
@@ -682,6 +692,16 @@ int32_t build_solver(rsba_handle* h) {
   if ((rc = s_alloc(s, &s->d_gpose, (size_t)F * CD))) return rc;
   if ((rc = s_alloc(s, &s->d_gpoint, (size_t)M * 3))) return rc;
   if (h->allreduce && h->world > 1) { if ((rc = s_alloc(s, &s->merge_buf, 4 * (size_t)M))) return rc; }
+  if (dp.pp_count > 0) {
+    const size_t n6 = 6 * (size_t)dp.pp_count;
+    if ((rc = s_alloc(s, &s->pp.v0, n6))) return rc;
+    if ((rc = s_alloc(s, &s->pp.g0, n6))) return rc;
+    if ((rc = s_alloc(s, &s->pp.cross, n6))) return rc;
+    if ((rc = s_alloc(s, &s->pp.diag, n6))) return rc;
+    std::vector<int32_t> tds(nt);
+    for (int t = 0; t < nt; ++t) tds[t] = slot_base[iperm[t]];
+    if ((rc = s_upload_const(s, &s->pp.tile_diag_slot, tds))) return rc;
+  }
   HIP_TRY(hipMemset(sv.scalars, 0, 16 * sizeof(double)));
   HIP_TRY(hipMemset(sv.chol_fail, 0, sizeof(int)));
   CholPlan& pl = s->plan;
@@ -732,6 +752,11 @@ int32_t reset_scales(rsba_handle* h) {
   HIP_TRY(hipMemcpyAsync(dp.scale_pose, h->mask_pose.data(), h->mask_pose.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipMemcpyAsync(dp.scale_point, h->mask_point.data(), h->mask_point.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipMemcpyAsync(dp.scale_intr, h->mask_intr.data(), h->mask_intr.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (dp.pp_count > 0) {   // the priorPoses blocks are always free: scale 1
+    static const std::vector<double> ones(1 << 16, 1.0);
+    for (size_t o = 0; o < 6 * (size_t)dp.pp_count; o += ones.size())
+      HIP_TRY(hipMemcpyAsync(dp.pp_scale + o, ones.data(), std::min(ones.size(), 6 * (size_t)dp.pp_count - o) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  }
   return RSBA_OK;
 }
 
@@ -766,6 +791,11 @@ int32_t linearize(rsba_handle* h) {
     }
     if (s->border) HIP_TRY(launch_prior_border(h->dp, s->sv, s->border, s->ratio4, h->stream));   // every rank: from replicated poses
   }
+  if (s->sv.lead && (h->dp.pp_count > 0 || h->dp.pp_spherical >= 0)) {   // per-pose priors: replicated terms, contributed by the lead rank
+    PhaseScope ps(h, RSBA_PHASE_PRIORS);
+    HIP_TRY(launch_pose_prior_cost(h->dp, h->d_cost2, h->stream));
+    HIP_TRY(launch_pose_prior_blocks(h->dp, s->sv, s->pp, h->stream));
+  }
   {
     PhaseScope ps(h, RSBA_PHASE_POINT_BLOCKS);
     HIP_TRY(launch_point_blocks(h->dp, s->sv, h->stream));
@@ -782,6 +812,7 @@ int32_t gradient_max(rsba_handle* h) {
   Solver* s = h->solver;
   PhaseScope ps(h, RSBA_PHASE_OTHER);
   HIP_TRY(launch_gradient_max(h->dp, s->sv, h->stream));
+  if (s->sv.lead) HIP_TRY(launch_pose_prior_gradmax(h->dp, s->sv, s->pp, h->stream));
   return exchange(h, s->sv.scalars + kGradMax, 1, 1);
 }
 
@@ -798,6 +829,7 @@ int32_t reduce_system(rsba_handle* h, double radius) {
     PhaseScope ps(h, RSBA_PHASE_SCHUR);
     HIP_TRY(launch_clear_system(sv, st));
     HIP_TRY(launch_schur_blocks(h->dp, sv, radius, st));
+    if (sv.lead) HIP_TRY(launch_pose_prior_reduce(h->dp, sv, s->pp, radius, st));   // the priorPoses blocks leave the system like points
   }
   // exchange (2): partial reduced camera systems -> the full one on every rank (then factored redundantly)
   PhaseScope ps(h, RSBA_PHASE_EXCHANGE);
@@ -1009,6 +1041,7 @@ extern "C" int32_t rsba_pose_covariance(rsba_handle* h, int32_t frame, double* c
   if ((rc = reset_scales(h))) return rc;
   if ((rc = linearize(h))) return rc;
   HIP_TRY(launch_clamp_diagonal(h->dp, sv, 1e-6, 1e32, st));   // only its floor matters: the decoupled diagonal of fixed coordinates
+  HIP_TRY(launch_pose_prior_clamp(h->dp, s->pp, 1e-6, 1e32, st));
   HIP_TRY(hipMemsetAsync(sv.chol_fail, 0, sizeof(int), st));
   if ((rc = reduce_system(h, 1e300))) return rc;
   std::vector<double> col((size_t)CD * CD, 0.0);
@@ -1064,7 +1097,7 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
   { const char* lv = std::getenv("RSBA_CHOL_LEVELS"); s->use_levels = opt->level_scheduled_cholesky != 0 || (lv && lv[0] == '1'); }
   {
     // problem-size figures of the whole (all-rank) problem
-    const double npri = sv.lead ? (double)h->prior_frames.size() : 0.0;
+    const double npri = sv.lead ? (double)h->prior_frames.size() + (double)h->pp_blocks.size() + (dp.pp_spherical >= 0 ? 1.0 : 0.0) : 0.0;
     double cnt[3] = {(double)dp.N + npri, (double)(s->num_reduced_blocks + s->num_priors_reduced), (double)s->num_reduced_params};
     if (h->allreduce) {
       HIP_TRY(hipMemcpyAsync(sv.scalars + 8, cnt, sizeof cnt, hipMemcpyHostToDevice, st));
@@ -1112,6 +1145,7 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
     HIP_TRY(hipMemcpyAsync(h->desc.poses, dp.poses, npose * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(h->desc.points, dp.points, npt * sizeof(double), hipMemcpyDeviceToHost, st));
     if (!dp.calibrated) HIP_TRY(hipMemcpyAsync(h->desc.intrinsics, dp.intr, (size_t)dp.NI * 9 * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (dp.pp_count > 0 && h->pp_host) HIP_TRY(hipMemcpyAsync(h->pp_host, dp.pp_value, 6 * (size_t)dp.pp_count * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (s->timer.on) { s->timer.resolve(); s->timer.on = false; }
     h->prior_ratio_result = dp.prior_ratio;
@@ -1151,13 +1185,18 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
     // EstimateScale from the first Jacobian, then the Jacobian is column-scaled for good; here the
     // scales feed the evaluation kernel, so re-linearise once with them
     HIP_TRY(launch_jacobi_scale(dp, sv, st));
+    HIP_TRY(launch_pose_prior_scale(dp, s->pp, st));
     if (free_ratio) ratio_scale = 1.0 / (1.0 + std::sqrt(ratio_hg[0]));
     if ((rc = linearize(h))) return rc;
   }
   push(it);
 
   // current <-> candidate parameter buffers (intrinsics only when they are a parameter block)
-  auto swap_params = [&]() { std::swap(dp.poses, sv.trial_poses); std::swap(dp.points, sv.trial_points); if (sv.NPF > 0) std::swap(dp.intr, sv.trial_intr); };
+  auto swap_params = [&]() {
+    std::swap(dp.poses, sv.trial_poses); std::swap(dp.points, sv.trial_points);
+    if (sv.NPF > 0) std::swap(dp.intr, sv.trial_intr);
+    if (dp.pp_count > 0) std::swap(dp.pp_value, dp.pp_trial);
+  };
   int invalid_streak = 0, iteration = 0;
   const size_t pose_bytes = (size_t)dp.F * dp.P * 6 * sizeof(double), point_bytes = (size_t)dp.M * 3 * sizeof(double);
   (void)pose_bytes; (void)point_bytes;
@@ -1167,6 +1206,7 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
     if (!reuse_diagonal) {
       PhaseScope ps(h, RSBA_PHASE_OTHER);
       HIP_TRY(launch_clamp_diagonal(dp, sv, opt->min_lm_diagonal, opt->max_lm_diagonal, st));
+      HIP_TRY(launch_pose_prior_clamp(dp, s->pp, opt->min_lm_diagonal, opt->max_lm_diagonal, st));
       ratio_diag = std::min(std::max(ratio_scale * ratio_scale * ratio_hg[0], opt->min_lm_diagonal), opt->max_lm_diagonal);
     }
     HIP_TRY(hipMemsetAsync(sv.chol_fail, 0, sizeof(int), st));
@@ -1178,6 +1218,7 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
     { PhaseScope ps(h, RSBA_PHASE_BACK_SUBSTITUTE); HIP_TRY(launch_model_cost_change(dp, sv, st)); }
     if (s->ucross && sv.lead) { PhaseScope ps(h, RSBA_PHASE_PRIORS); HIP_TRY(launch_prior_model(dp, sv, sv.scalars + kModelCostChange, std::isfinite(ratio_step) ? ratio_step : 0.0, st)); }
     { PhaseScope ps(h, RSBA_PHASE_CANDIDATE); HIP_TRY(launch_candidate(dp, sv, st)); }
+    if (sv.lead && (dp.pp_count > 0 || dp.pp_spherical >= 0)) { PhaseScope ps(h, RSBA_PHASE_PRIORS); HIP_TRY(launch_pose_prior_step(dp, sv, s->pp, radius, st)); }
     // residuals only at the candidate (T = double path)
     swap_params();
     {
@@ -1192,6 +1233,7 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
       HIP_TRY(launch_prior_cost(dp, h->d_cost2, h->prior_invalid, st));
       dp.prior_ratio = ratio;
     }
+    if (sv.lead) HIP_TRY(launch_pose_prior_cost(dp, h->d_cost2, st));
     swap_params();
     // exchange (3): model decrease, |step|^2, |x|^2, (skip the max slot), trial cost, -, failure flags
     {

@@ -119,6 +119,20 @@ struct CholPlan {
 
 enum : int { kTaskUpdate = 0, kTaskDiag = 1, kTaskSub = 2, kTaskBack = 3 };
 
+// per-pose priors (kernels_pose_prior.hip): linearisation of the priorPoses coordinates [pp_count][6] and where the pose
+// entries sit in the packed tiles
+struct PosePriorDev {
+  double *v0, *g0, *cross;       // scaled J^T J diagonal, J^T r, and the (prior, pose) cross term of each coordinate
+  double* diag;                  // LM "diagonal_" of the coordinates
+  const int32_t* tile_diag_slot; // [nt] packed slot of the diagonal tile of each (unpermuted) tile index
+};
+hipError_t launch_pose_prior_blocks(const DeviceProblem& dp, const SolverDev& sv, const PosePriorDev& pp, hipStream_t st);
+hipError_t launch_pose_prior_scale(const DeviceProblem& dp, const PosePriorDev& pp, hipStream_t st);
+hipError_t launch_pose_prior_clamp(const DeviceProblem& dp, const PosePriorDev& pp, double lo, double hi, hipStream_t st);
+hipError_t launch_pose_prior_gradmax(const DeviceProblem& dp, const SolverDev& sv, const PosePriorDev& pp, hipStream_t st);
+hipError_t launch_pose_prior_reduce(const DeviceProblem& dp, const SolverDev& sv, const PosePriorDev& pp, double radius, hipStream_t st);
+hipError_t launch_pose_prior_step(const DeviceProblem& dp, const SolverDev& sv, const PosePriorDev& pp, double radius, hipStream_t st);
+
 // cholesky.hip
 hipError_t launch_chol_level(const SolverDev& sv, const CholPlan& pl, int kind, int first, int count, hipStream_t st);
 hipError_t launch_chol_dag(const SolverDev& sv, const CholPlan& pl, int workgroups, hipStream_t st);

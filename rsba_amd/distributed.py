@@ -107,16 +107,16 @@ def solve_timed(dp, prob, world: int, iters: int):
     """Run `iters` LM iterations of the device solver on this rank's problem and report wall time per
     iteration (the metric's second half).  Parameters are restored afterwards."""
     from . import capi
-    saved = (prob.poses.copy(), prob.points.copy())
+    saved = (prob.poses.copy(), prob.points.copy(), prob.intrinsics.copy())
     t0 = time.perf_counter()
     s, trace = dp.solve(capi.default_options(max_num_iterations=iters, function_tolerance=0.0, parameter_tolerance=0.0, gradient_tolerance=0.0))
     wall_first = time.perf_counter() - t0
-    prob.poses[:], prob.points[:] = saved
+    prob.poses[:], prob.points[:], prob.intrinsics[:] = saved
     dp.upload_parameters()
     t0 = time.perf_counter()
     s, trace = dp.solve(capi.default_options(max_num_iterations=iters, function_tolerance=0.0, parameter_tolerance=0.0, gradient_tolerance=0.0))
     wall = time.perf_counter() - t0
-    prob.poses[:], prob.points[:] = saved
+    prob.poses[:], prob.points[:], prob.intrinsics[:] = saved
     dp.upload_parameters()
     n_it = max(1, s.num_iterations - 1)
     return {"iterations": n_it, "ms_per_lm_iteration": s.total_time_s / n_it * 1e3, "wall_s": wall, "first_solve_wall_s": wall_first,

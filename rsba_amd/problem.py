@@ -43,6 +43,12 @@ class BAProblem:
     prior_scale: float = 0.0            # opt.ceres.constFrameVelocity / constFrameAcceleration
     inter_frame_ratio: float = 1.0      # opt.ceres.interFrameRatio
     ratio_free: bool = False            # True: the ratio is a free, lower-bounded parameter block (the option left at 1)
+    # per-pose prior blocks (CeresHandler.h:24-73, 127-130, 188-204)
+    pose_prior_block: Optional[np.ndarray] = None    # [NG] int32 pose block f * P + q carrying a GoodPosePrior
+    pose_prior_values: Optional[np.ndarray] = None   # [NG, 6] the priorPoses blocks (free parameter blocks: solved for, in place)
+    pose_prior_rotation: float = 0.0    # opt.ceres.trustPriorCamRotation
+    pose_prior_position: float = 0.0    # opt.ceres.trustPriorCamPosition
+    spherical_pose_block: int = -1      # pose block carrying the SphericalPrior (frame 1 of a session started at the origin), -1 none
 
     def __post_init__(self):
         self.poses = np.ascontiguousarray(self.poses, dtype=np.float64)
@@ -53,7 +59,9 @@ class BAProblem:
         self.obs_frame = np.ascontiguousarray(self.obs_frame, dtype=np.int32).reshape(-1)
         self.obs_point = np.ascontiguousarray(self.obs_point, dtype=np.int32).reshape(-1)
         assert len(self.obs_frame) == len(self.obs_point) == len(self.obs_xy)
-        for name, dt in (("frame_intrinsics", np.int32), ("prior_frames", np.int32), ("pose_fixed_mask", np.uint8),
+        if self.pose_prior_values is not None:
+            self.pose_prior_values = np.ascontiguousarray(self.pose_prior_values, dtype=np.float64).reshape(-1, 6)
+        for name, dt in (("frame_intrinsics", np.int32), ("prior_frames", np.int32), ("pose_prior_block", np.int32), ("pose_fixed_mask", np.uint8),
                          ("point_constant", np.uint8), ("intrinsics_constant", np.uint8)):
             v = getattr(self, name)
             if v is not None:

@@ -296,3 +296,43 @@ def test_calc_covariances_prints_what_the_oracle_computes(exe, oracle, tmp_path)
     assert np.abs(out["covariance"][0] - ref[:6, :6]).max() <= 1e-7 * scale
     assert np.abs(out["covariance"][1] - ref[:6, 6:]).max() <= 1e-7 * scale
     assert np.abs(out["covariance"][2] - ref[6:, 6:]).max() <= 1e-7 * scale
+
+
+@pytest.mark.gpu
+def test_session_start_and_pose_priors_through_ceres_handler(exe, oracle, tmp_path):
+    """CeresHandler::Add on a session that starts without poses (frame 0: zeros, frame 1: zeros + 1e-4 and a SphericalPrior,
+    CeresHandler.h:99-144) and whose later frames carry priorPoses (GoodPosePrior, :188-204), replayed from a Session cache."""
+    import thrift_encode as T
+    p = small_problem(True, 0.0)
+    F = p.num_frames
+    rng = np.random.default_rng(9)
+    order = np.argsort(p.obs_frame, kind="stable")
+    local = np.zeros(p.num_observations, dtype=np.int64)
+    for f in range(F):
+        idx = order[p.obs_frame[order] == f]
+        local[idx] = np.arange(len(idx))
+    prior = {f: p.poses[f] + rng.normal(0, 0.01, p.poses[f].shape) for f in range(3, F, 2)}
+    obs_bytes = [[] for _ in range(F)]
+    for i in order:
+        obs_bytes[int(p.obs_frame[i])].append(T.observation(p.obs_xy[i, 0], p.obs_xy[i, 1], track=int(p.obs_point[i])))
+    frames = [T.frame(obs_bytes[f], poses=p.poses[f] if f >= 2 else None, prior_poses=prior.get(f)) for f in range(F)]
+    tracks = [T.track([(int(p.obs_frame[k]), int(local[k]), True) for k in np.flatnonzero(p.obs_point == j)], pt=p.points[j], valid=True) for j in range(p.num_points)]
+    (tmp_path / "s.cache").write_bytes(T.file_events(T.session(p.intrinsics[0], frames, tracks, int(p.shutter), list(p.scanlines), 1280, 720), np.random.default_rng(6), max_event=2048))
+    r = subprocess.run([exe, "--cache", str(tmp_path / "s.cache"), str(tmp_path / "o.bin"), "1", "12", "0", "1", "1", "16", "3.0", "5.0"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr
+    out = read_result_file(tmp_path / "o.bin", p)
+    q = p.copy()
+    q.poses[0] = 0.0
+    q.poses[1] = 0.0; q.poses[1, :, 3:] += 1e-4
+    from rsba_amd.problem import apply_gauge_masks
+    apply_gauge_masks(q, fix_first_n_cameras=1)
+    q.spherical_pose_block = 2
+    blocks = [2 * f + i for f in sorted(prior) for i in range(2)]
+    q.pose_prior_block = np.array(blocks, dtype=np.int32)
+    q.pose_prior_values = np.concatenate([prior[f] for f in sorted(prior)])
+    q.pose_prior_rotation, q.pose_prior_position = 3.0, 5.0
+    s_ref, tr_ref = oracle.solve(q, oracle.default_options(max_num_iterations=12))
+    assert out["usable"] and out["reduced"] == s_ref.num_residual_blocks_reduced
+    assert abs(out["initial_cost"] - s_ref.initial_cost) <= 1e-12 * s_ref.initial_cost
+    assert abs(1.0 - np.abs(out["poses"][1, 0, 3:]).sum()) <= 4e-16                 # the gauge the SphericalPrior sets
+    assert np.max(np.abs(out["poses"][1, 0, 3:] - q.poses[1, 0, 3:])) <= 1e-9

@@ -1,40 +1,42 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun): collects this round's evidence into gpurun_out/$1/ (default r01).
-#   kernel-trace stats of the bench command, FETCH_SIZE and WRITE_SIZE in separate --pmc passes
-#   (never combined with tracing), the HBM stream calibration, and the bench line itself.
-R=${1:-r01}
+# Runs on the GPU box (via gpurun): collects this round's evidence into gpurun_out/$1/ (default r02).
+#   the bench lines (C4 = the metric's workload, C5 = the 4k-camera Huber + shared-intrinsics scene), kernel-trace stats of the
+#   same commands, FETCH_SIZE and WRITE_SIZE in separate --pmc passes (never combined with tracing), the HBM stream calibration.
+R=${1:-r02}
 OUT=gpurun_out/$R
 mkdir -p $OUT
 export TMPDIR=/tmp
-B="python bench.py --steps 30 --warmup 5 --no-cpu-baseline --lm-iters 12"
 python bench.py --steps 50 --warmup 5 --lm-iters 12 > $OUT/bench.json 2> $OUT/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $B > $OUT/trace.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o f -- $B --no-lm > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o w -- $B --no-lm > $OUT/pmc_write.log 2>&1
+python bench.py --config C5 --steps 20 --warmup 3 --lm-iters 8 > $OUT/bench_c5.json 2> $OUT/bench_c5.err
+for C in C4 C5; do
+  B="python bench.py --config $C --steps 30 --warmup 5 --no-cpu-baseline --no-next-rows --lm-iters 12"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$C -o t -- $B > $OUT/trace_$C.log 2>&1
+  cp $OUT/trace_$C/t_kernel_stats.csv $OUT/kernel_stats_$C.csv; rm -rf $OUT/trace_$C
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$C -o f -- $B --no-lm > $OUT/pmc_fetch_$C.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$C -o w -- $B --no-lm > $OUT/pmc_write_$C.log 2>&1
+done
 ./tools/hbm_calib > $OUT/hbm_calib.txt 2>&1
 python - "$OUT" <<'PY'
-import collections, csv, json, sys
+import csv, json, sys
 out = sys.argv[1]
 def mean_counter(path, counter, kernel_sub):
     vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter and kernel_sub in r["Kernel_Name"]]
     return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
-k = "eval_kernel<true, 2, 1>"
-f, nf = mean_counter(f"{out}/pmc_fetch/f_counter_collection.csv", "FETCH_SIZE", k)
-w, nw = mean_counter(f"{out}/pmc_write/w_counter_collection.csv", "WRITE_SIZE", k)
-stats = {r["Name"]: r for r in csv.DictReader(open(f"{out}/trace/t_kernel_stats.csv"))}
-avg_ns = next((float(v["AverageNs"]) for n, v in stats.items() if k in n), None)
-summary = {"kernel": "rsba::" + k, "launches_fetch": nf, "launches_write": nw,
-           "FETCH_SIZE_KB_per_launch": f, "WRITE_SIZE_KB_per_launch": w,
-           "note": "gfx950 calibration (tools/hbm_calib.hip under the same counters): FETCH_SIZE reads 0.500x of coalesced read streams, WRITE_SIZE 1.000x",
-           "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0 if f and w else None,
-           "rocprof_avg_kernel_ns": avg_ns}
+summary = {"note": "gfx950 calibration (tools/hbm_calib.hip under the same counters): FETCH_SIZE reads 0.500x of coalesced read streams, WRITE_SIZE 1.000x; "
+                   "hbm bytes = (2 * FETCH_SIZE + WRITE_SIZE) KB, separate --pmc passes"}
+for cfg, k, key in (("C4", "eval_kernel<true, 2, 1>", "hbm_bytes_per_launch"), ("C5", "eval_kernel<false, 2, 1>", "hbm_bytes_per_launch_C5")):
+    f, nf = mean_counter(f"{out}/pmc_fetch_{cfg}/f_counter_collection.csv", "FETCH_SIZE", k)
+    w, nw = mean_counter(f"{out}/pmc_write_{cfg}/w_counter_collection.csv", "WRITE_SIZE", k)
+    stats = {r["Name"]: r for r in csv.DictReader(open(f"{out}/kernel_stats_{cfg}.csv"))}
+    avg_ns = next((float(v["AverageNs"]) for n, v in stats.items() if k in n), None)
+    summary[key] = (2.0 * f + w) * 1024.0 if f and w else None
+    summary[cfg] = {"kernel": "rsba::" + k, "launches_fetch": nf, "launches_write": nw, "FETCH_SIZE_KB_per_launch": f, "WRITE_SIZE_KB_per_launch": w, "rocprof_avg_kernel_ns": avg_ns}
 json.dump(summary, open(f"{out}/pmc_summary.json", "w"), indent=1)
 print(json.dumps(summary))
 PY
-cp $OUT/trace/t_kernel_stats.csv $OUT/kernel_stats.csv
-rm -rf $OUT/trace/t_kernel_trace.csv
+cp $OUT/kernel_stats_C4.csv $OUT/kernel_stats.csv
 cat $OUT/bench.json
-# the rows next to the hot path: motion priors (f1), RS-PnP hypotheses (f3)
+# the rows next to the hot path: motion priors (f1), RS-PnP hypotheses (f3), filters (f2)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_priors -o t -- python tools/lm_time.py C4 12 priors > $OUT/lm_priors.log 2>&1
 cp $OUT/trace_priors/t_kernel_stats.csv $OUT/lm_c4_priors_kernel_stats.csv; rm -rf $OUT/trace_priors
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_pnp -o t -- python tools/pnp_time.py 16384 1000 6 > $OUT/pnp.log 2>&1
