@@ -241,6 +241,7 @@ struct Solver {
     double initial_cost = 0, final_cost = 0, fixed_cost = 0;
     int num_successful_steps = 0, num_unsuccessful_steps = 0;
     int num_residual_blocks = 0, num_residual_blocks_reduced = 0, num_parameters_reduced = 0;
+    int num_dag_fallbacks = 0;   // extension: see rsba_solver_summary
     double total_time_in_seconds = 0, jacobian_evaluation_time_in_seconds = 0, linear_solver_time_in_seconds = 0;
     std::vector<rsba_iteration> iterations;
     bool IsSolutionUsable() const { return termination_type == CONVERGENCE || termination_type == NO_CONVERGENCE || termination_type == USER_SUCCESS; }
@@ -599,7 +600,7 @@ inline void Solve(const Solver::Options& options, Problem* problem, Solver::Summ
   summary->initial_cost = s.initial_cost; summary->final_cost = s.final_cost; summary->fixed_cost = s.fixed_cost;
   summary->num_successful_steps = s.num_successful_steps; summary->num_unsuccessful_steps = s.num_unsuccessful_steps;
   summary->num_residual_blocks = s.num_residual_blocks; summary->num_residual_blocks_reduced = s.num_residual_blocks_reduced;
-  summary->num_parameters_reduced = s.num_parameters_reduced;
+  summary->num_parameters_reduced = s.num_parameters_reduced; summary->num_dag_fallbacks = s.num_dag_fallbacks;
   summary->total_time_in_seconds = s.total_time_s; summary->jacobian_evaluation_time_in_seconds = s.residual_jacobian_time_s;
   summary->linear_solver_time_in_seconds = s.linear_solver_time_s;
   trace.resize(std::min<size_t>(trace.size(), (size_t)std::max(0, s.num_iterations)));

@@ -16,7 +16,7 @@
 extern "C" {
 #endif
 
-#define RSBA_AMD_ABI_VERSION 1
+#define RSBA_AMD_ABI_VERSION 2
 
 typedef enum rsba_status {
   RSBA_OK = 0,
@@ -102,6 +102,9 @@ typedef struct rsba_solver_summary {
   int32_t num_residual_blocks, num_residual_blocks_reduced, num_parameters_reduced, is_solution_usable;
   double initial_cost, final_cost, fixed_cost;
   double total_time_s, residual_jacobian_time_s, linear_solver_time_s;
+  int32_t num_dag_fallbacks;     /* linear solves of the persistent Cholesky driver whose residual check failed and that were
+                                  * repeated on the level schedule (0 in every run so far) */
+  int32_t reserved;
 } rsba_solver_summary;
 
 /* Pointers into HBM for callers that keep results on the device.  All fp64, tiled component-major:

@@ -75,6 +75,7 @@ class SolverSummary(C.Structure):
         ("num_parameters_reduced", C.c_int32), ("is_solution_usable", C.c_int32),
         ("initial_cost", C.c_double), ("final_cost", C.c_double), ("fixed_cost", C.c_double),
         ("total_time_s", C.c_double), ("residual_jacobian_time_s", C.c_double), ("linear_solver_time_s", C.c_double),
+        ("num_dag_fallbacks", C.c_int32), ("reserved", C.c_int32),
     ]
 
 

@@ -41,6 +41,15 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
+// Workgroup barrier that orders LDS traffic only.  Everything the waves of a workgroup hand each other here goes through
+// LDS; what they write to HBM (write-once cells, partial tiles) is for OTHER workgroups, which find it by polling.  A full
+// __syncthreads() would also wait for those global stores — and for every prefetch still in flight — to drain (vmcnt(0)).
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 constexpr int NB = 16;   // panel width of the tile factorisation: one MFMA block column
 typedef double dbl4_t __attribute__((ext_vector_type(4)));
 
@@ -68,17 +77,22 @@ __device__ __forceinline__ bool potrf_blocked(double* A, int tid) {
       for (int jj = 0; jj < NB; ++jj) {
         const double djj = readlane_f64(a[jj], jj);
         ok = ok && (djj > 0.0) && isfinite(djj);
-        const double rinv = rsqrt_nr(djj);
-        a[jj] = (tid == jj) ? djj * rinv : a[jj] * rinv;
+        // the column is broadcast BEFORE it is scaled: the lane reads do not wait for the 1/sqrt chain, only the FMAs do
+        double u[NB];
 #pragma unroll
-        for (int m = jj + 1; m < NB; ++m) a[m] -= a[jj] * readlane_f64(a[jj], m);
+        for (int m = jj + 1; m < NB; ++m) u[m] = readlane_f64(a[jj], m);
+        const double rinv = rsqrt_nr(djj);
+        const double t = a[jj] * (rinv * rinv);                 // a_r / d
+#pragma unroll
+        for (int m = jj + 1; m < NB; ++m) a[m] -= t * u[m];      // a_rm -= a_r a_m / d
+        a[jj] = (tid == jj) ? djj * rinv : a[jj] * rinv;
       }
       if (live) {
 #pragma unroll
         for (int m = 0; m < NB; ++m) if (c0 + m <= row) A[row * TP + c0 + m] = a[m];
       }
     }
-    __syncthreads();
+    lds_barrier();
     // rank-16 trailing update A[r][c] -= sum_m L[r][c0 + m] L[c][c0 + m] for c0 + 12 <= c <= r on the matrix pipe
     // (K = 16 = four MFMA steps): the 16 x 16 blocks of the tile grid that reach into the trailing part are
     // dealt to the waves, products formed in full and subtracted under a mask.
@@ -102,7 +116,7 @@ __device__ __forceinline__ bool potrf_blocked(double* A, int tid) {
             if (c >= c0 + NB && c <= r) A[r * TP + c] -= acc[v];
           }
         }
-      __syncthreads();
+      lds_barrier();
     }
   }
   return ok;
@@ -214,6 +228,7 @@ constexpr int kBuf = T * TP;
 constexpr int kVecOff = 4 * kBuf;            // [4][T] per-wave rhs partials, [T] b, [T] 1/diag, pivot-failure word
 constexpr int kCholLds = kVecOff + 8 * T;
 
+
 template <bool DAG>
 __device__ __forceinline__ void Frag::load(const double* tile, int wave, int lane) {
   const double* p = tile + (lane & 15) * T + 12 * wave + 3 * (lane >> 4);
@@ -322,7 +337,7 @@ __device__ __forceinline__ void task_update(const SolverDev& sv, const CholPlan&
   CHOL_STAMP(3);
   acc.spill(smem + wave * kBuf, lane);
   if (diag) spill_bz(bz, smem + kVecOff + wave * T, lane);
-  __syncthreads();
+  lds_barrier();
   double* out = sv.chol_part + (size_t)u[3] * (T * T + T);
   for (int e = tid; e < T * T; e += 256) {
     const int o = (e / T) * TP + e % T;
@@ -394,7 +409,7 @@ __device__ __forceinline__ void invert_lower_blocked(const double* L, const doub
       for (int i = 0; i < B; ++i) Wl[(o + i) * TP + o + cc] = w[i];
     }
   }
-  __syncthreads();
+  lds_barrier();
   // 16 x 16 block products on the matrix pipe, one wave each: (rows xr.., columns xo.. of X) times (rows yo.., columns
   // yc.. of Y), result in the MFMA layout (this lane: column lane & 15, rows (lane >> 4) + 4v)
   const int mi = lane & 15, mg = lane >> 4;
@@ -413,10 +428,10 @@ __device__ __forceinline__ void invert_lower_blocked(const double* L, const doub
   if (wave == 0) put(Tm, 16, 0, mm16(L, 16, 0, Wl, 0, 0, zero), 1.0);          // T10 = L10 W00
   else if (wave == 1) put(Tm, 32, 16, mm16(L, 32, 16, Wl, 16, 16, zero), 1.0);  // T21 = L21 W11
   else if (wave == 2) put(Tm, 32, 0, mm16(L, 32, 0, Wl, 0, 0, zero), 1.0);      // T20 = L20 W00
-  __syncthreads();
+  lds_barrier();
   if (wave == 0) put(Wl, 16, 0, mm16(Wl, 16, 16, Tm, 16, 0, zero), -1.0);       // W10 = -W11 T10
   else if (wave == 1) put(Wl, 32, 16, mm16(Wl, 32, 32, Tm, 32, 16, zero), -1.0);   // W21 = -W22 T21
-  __syncthreads();
+  lds_barrier();
   if (wave == 0) {                                                              // T20 += L21 W10 ; W20 = -W22 T20
     dbl4 t;
 #pragma unroll
@@ -425,14 +440,54 @@ __device__ __forceinline__ void invert_lower_blocked(const double* L, const doub
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     put(Wl, 32, 0, mm16(Wl, 32, 32, Tm, 32, 0, zero), -1.0);
   }
-  __syncthreads();
+  lds_barrier();
+}
+
+// second half of a DIAG task: the updates are in acc / bz, the tile and rhs (less the partial tiles) in sreg / breg
+template <bool DAG>
+__device__ __forceinline__ void diag_finish(const SolverDev& sv, int tile_j, double sreg[9], double breg, Acc& acc, double bz[3], double* smem, int tid) {
+  const int wave = tid >> 6, lane = tid & 63;
+  double* D = smem; double* Wl = smem + kBuf;
+  double* vec = smem + kVecOff; double* bvec = vec + 4 * T; double* dinv = vec + 5 * T; int* s_okp = reinterpret_cast<int*>(vec + 6 * T);
+  CHOL_STAMP(3);
+  acc.spill(smem + wave * kBuf, lane);
+  spill_bz(bz, vec + wave * T, lane);
+  lds_barrier();
+#pragma unroll
+  for (int q = 0; q < 9; ++q) {
+    const int e = tid + 256 * q, r = e / T, c = e % T, o = r * TP + c;
+    const double upd = (smem[o] + smem[kBuf + o]) + (smem[2 * kBuf + o] + smem[3 * kBuf + o]);
+    sreg[q] = (c <= r) ? sreg[q] - upd : 0.0;
+  }
+  if (tid < T) bvec[tid] = breg - ((vec[tid] + vec[T + tid]) + (vec[2 * T + tid] + vec[3 * T + tid]));
+  if (tid == 0) *s_okp = 1;
+  lds_barrier();
+#pragma unroll
+  for (int q = 0; q < 9; ++q) { const int e = tid + 256 * q; D[(e / T) * TP + e % T] = sreg[q]; }
+  lds_barrier();
+  CHOL_STAMP(4);
+  const bool ok = potrf_blocked(D, tid);
+  if (tid < 64 && !ok) *s_okp = 0;
+  if (tid < T) dinv[tid] = 1.0 / D[tid * TP + tid];
+  lds_barrier();
+  CHOL_STAMP(5);
+  if (!*s_okp && tid == 0) atomicExch(sv.chol_fail, 1);
+  // L_jj itself is not stored: everything downstream uses W_j
+  invert_lower_blocked(D, dinv, Wl, smem + 2 * kBuf, tid);
+  CHOL_STAMP(6);
+  double* wout = sv.Winv + (size_t)tile_j * (T * T);
+  for (int e = tid; e < T * T; e += 256) { const int r = e / T, c = e % T; st<DAG>(wout + e, (c <= r) ? Wl[r * TP + c] : 0.0); }
+  if (tid < T) {   // z_j = W b
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll 8
+    for (int m = 0; m < T; m += 2) { if (m <= tid) s0 += Wl[tid * TP + m] * bvec[m]; if (m + 1 <= tid) s1 += Wl[tid * TP + m + 1] * bvec[m + 1]; }
+    st<DAG>(sv.zv + (size_t)tile_j * T + tid, s0 + s1);
+  }
 }
 
 template <bool DAG>
 __device__ __forceinline__ void task_diag(const SolverDev& sv, const CholPlan& pl, int b, double* smem, int tid) {
   const int wave = tid >> 6, lane = tid & 63;
-  double* D = smem; double* Wl = smem + kBuf;
-  double* vec = smem + kVecOff; double* bvec = vec + 4 * T; double* dinv = vec + 5 * T; int* s_okp = reinterpret_cast<int*>(vec + 6 * T);
   const int32_t* info = pl.diag_info + 4 * b;
   const int slot_jj = info[0], tile_j = info[1], part0 = info[2], nparts = info[3];
   const int p0 = pl.diag_own[b], p1 = pl.diag_ptr[b + 1];   // the owner's share of the contributor list
@@ -447,40 +502,7 @@ __device__ __forceinline__ void task_diag(const SolverDev& sv, const CholPlan& p
   Acc acc; acc.clear();
   double bz[3] = {0, 0, 0};
   accumulate<DAG, true>(sv, pl, pl.diag_list, p0, p1, acc, bz, wave, lane);
-  CHOL_STAMP(3);
-  acc.spill(smem + wave * kBuf, lane);
-  spill_bz(bz, vec + wave * T, lane);
-  __syncthreads();
-#pragma unroll
-  for (int q = 0; q < 9; ++q) {
-    const int e = tid + 256 * q, r = e / T, c = e % T, o = r * TP + c;
-    const double upd = (smem[o] + smem[kBuf + o]) + (smem[2 * kBuf + o] + smem[3 * kBuf + o]);
-    sreg[q] = (c <= r) ? sreg[q] - upd : 0.0;
-  }
-  if (tid < T) bvec[tid] = breg - ((vec[tid] + vec[T + tid]) + (vec[2 * T + tid] + vec[3 * T + tid]));
-  if (tid == 0) *s_okp = 1;
-  __syncthreads();
-#pragma unroll
-  for (int q = 0; q < 9; ++q) { const int e = tid + 256 * q; D[(e / T) * TP + e % T] = sreg[q]; }
-  __syncthreads();
-  CHOL_STAMP(4);
-  const bool ok = potrf_blocked(D, tid);
-  if (tid < 64 && !ok) *s_okp = 0;
-  if (tid < T) dinv[tid] = 1.0 / D[tid * TP + tid];
-  __syncthreads();
-  CHOL_STAMP(5);
-  if (!*s_okp && tid == 0) atomicExch(sv.chol_fail, 1);
-  (void)slot_jj;   // L_jj itself is not stored: everything downstream uses W_j
-  invert_lower_blocked(D, dinv, Wl, smem + 2 * kBuf, tid);
-  CHOL_STAMP(6);
-  double* wout = sv.Winv + (size_t)tile_j * (T * T);
-  for (int e = tid; e < T * T; e += 256) { const int r = e / T, c = e % T; st<DAG>(wout + e, (c <= r) ? Wl[r * TP + c] : 0.0); }
-  if (tid < T) {   // z_j = W b
-    double s0 = 0.0, s1 = 0.0;
-#pragma unroll 8
-    for (int m = 0; m < T; m += 2) { if (m <= tid) s0 += Wl[tid * TP + m] * bvec[m]; if (m + 1 <= tid) s1 += Wl[tid * TP + m + 1] * bvec[m + 1]; }
-    st<DAG>(sv.zv + (size_t)tile_j * T + tid, s0 + s1);
-  }
+  diag_finish<DAG>(sv, tile_j, sreg, breg, acc, bz, smem, tid);
 }
 
 template <bool DAG>
@@ -500,17 +522,17 @@ __device__ __forceinline__ void task_sub(const SolverDev& sv, const CholPlan& pl
   accumulate<DAG, false>(sv, pl, pl.sub_list, p0, p1, acc, bz, wave, lane);
   CHOL_STAMP(3);
   acc.spill(smem + wave * kBuf, lane);
-  __syncthreads();
+  lds_barrier();
 #pragma unroll
   for (int q = 0; q < 9; ++q) {
     const int e = tid + 256 * q, o = (e / T) * TP + e % T;
     sreg[q] -= (smem[o] + smem[kBuf + o]) + (smem[2 * kBuf + o] + smem[3 * kBuf + o]);
   }
-  __syncthreads();
+  lds_barrier();
 #pragma unroll
   for (int q = 0; q < 9; ++q) { const int e = tid + 256 * q; X[(e / T) * TP + e % T] = sreg[q]; }
   CHOL_STAMP(4);
-  __syncthreads();
+  lds_barrier();
   CHOL_STAMP(5);
   // L_ij = X W_j^T: wave I forms row block I; W is lower triangular, so column block J only needs k < 16 (J + 1).
   // W_j comes from the DIAG task of this column: its cells are read until they are all there.
@@ -519,18 +541,20 @@ __device__ __forceinline__ void task_sub(const SolverDev& sv, const CholPlan& pl
     const double* Wg = sv.Winv + (size_t)tile_j * (T * T);
     double* out = factor_ptr(sv, slot_ij);
     double wv[3][12];   // B operand: W[16J + r][4kk + g]
-    bool late = false;
-    for (;;) {
-      bool ok = true;
+    {
+      bool late = false;
+      for (;;) {
+        bool ok = true;
 #pragma unroll
-      for (int J = 0; J < 3; ++J)
+        for (int J = 0; J < 3; ++J)
 #pragma unroll
-        for (int kk = 0; kk < 4 * (J + 1); ++kk) { wv[J][kk] = ld<DAG>(Wg + (16 * J + r) * T + 4 * kk + g); ok = ok && filled(wv[J][kk]); }
-      if (!DAG || __ballot(!ok) == 0ull) break;
-      late = true;
-      watch_cell<DAG>(Wg + (T * T - 1));   // the corner of the inverse
+          for (int kk = 0; kk < 4 * (J + 1); ++kk) { wv[J][kk] = ld<DAG>(Wg + (16 * J + r) * T + 4 * kk + g); ok = ok && filled(wv[J][kk]); }
+        if (!DAG || __ballot(!ok) == 0ull) break;
+        late = true;
+        watch_cell<DAG>(Wg + (T * T - 1));   // the corner of the inverse
+      }
+      if (late) note_late_input();
     }
-    if (late) note_late_input();
     dbl4 c[3] = {dbl4{0, 0, 0, 0}, dbl4{0, 0, 0, 0}, dbl4{0, 0, 0, 0}};
 #pragma unroll
     for (int kk = 0; kk < 12; ++kk) {
@@ -542,7 +566,9 @@ __device__ __forceinline__ void task_sub(const SolverDev& sv, const CholPlan& pl
 #pragma unroll
     for (int J = 0; J < 3; ++J)
 #pragma unroll
-      for (int v = 0; v < 4; ++v) st<DAG>(out + (16 * I + g + 4 * v) * T + 16 * J + r, c[J][v]);
+      for (int v = 0; v < 4; ++v) {
+        st<DAG>(out + (16 * I + g + 4 * v) * T + 16 * J + r, c[J][v]);
+      }
   }
   CHOL_STAMP(6);
   (void)slot_jj;
@@ -621,7 +647,7 @@ __device__ __forceinline__ void task_back(const SolverDev& sv, const CholPlan& p
     }
   }
   if (worker) { part[rg * T + 2 * c2] = s0; part[rg * T + 2 * c2 + 1] = s1; }
-  __syncthreads();
+  lds_barrier();
   CHOL_STAMP(3);
   if (tid < T) {
     double t = ld<DAG>(sv.zv + (size_t)tile_j * T + tid);   // z_j, from the DIAG task of this column
@@ -630,7 +656,7 @@ __device__ __forceinline__ void task_back(const SolverDev& sv, const CholPlan& p
     for (int g = 0; g < 10; ++g) t -= part[g * T + tid];
     tvec[tid] = t;
   }
-  __syncthreads();
+  lds_barrier();
   // y = W^T t
   {
     const double* Wg = sv.Winv + (size_t)tile_j * (T * T);
@@ -641,9 +667,9 @@ __device__ __forceinline__ void task_back(const SolverDev& sv, const CholPlan& p
 #pragma unroll
     for (int u = 0; u < 5; ++u) { s0 += v[u].x * yy[u]; s1 += v[u].y * yy[u]; }
   }
-  __syncthreads();
+  lds_barrier();
   if (worker) { part[rg * T + 2 * c2] = s0; part[rg * T + 2 * c2 + 1] = s1; }
-  __syncthreads();
+  lds_barrier();
   if (tid < T) {
     double y = 0.0;
 #pragma unroll
@@ -670,27 +696,92 @@ __global__ __launch_bounds__(256) void chol_level_kernel(const SolverDev sv, con
 }
 
 // the whole factorisation + both triangular solves in one persistent launch
-__global__ __launch_bounds__(256) void chol_dag_kernel(const SolverDev sv, const CholPlan pl) {
+__global__ __launch_bounds__(256) void chol_dag_kernel(const DagArgs* __restrict__ args) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   __shared__ int s_ticket;
   const int tid = threadIdx.x;
+  const CholPlan& pl = args->pl;
   for (;;) {
-    __syncthreads();   // the previous task's LDS is free, s_ticket has been read by everyone
+    lds_barrier();   // the previous task's LDS is free, s_ticket has been read by everyone
     if (tid == 0) {
       const int tk = (int)__hip_atomic_fetch_add(pl.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       s_ticket = tk;
       s_trace_slot = (pl.trace && tk < pl.ntasks) ? pl.trace + 8 * (size_t)tk : nullptr;
       if (s_trace_slot) { s_trace_slot[0] = blockIdx.x; s_trace_slot[1] = s_trace_slot[2] = wall_clock64(); }
     }
-    __syncthreads();
+    lds_barrier();
     const int t = s_ticket;
     if (t >= pl.ntasks) return;
-    run_task<true>(sv, pl, pl.tasks[2 * t], pl.tasks[2 * t + 1], smem, tid);
+    // every task recomputes what it derives from the thread index: left alone, the compiler hoists dozens of per-thread LDS
+    // offsets out of this loop, keeps them live across all task bodies and spills them to scratch — whose reloads (vmcnt)
+    // then stall on every prefetch in flight
+    int task_tid = tid;
+    asm volatile("" : "+v"(task_tid));
+    run_task<true>(args->sv, pl, pl.tasks[2 * t], pl.tasks[2 * t + 1], smem, task_tid);
     if (tid == 0 && s_trace_slot) s_trace_slot[7] = wall_clock64();
   }
 }
 
+// ---- verification of the persistent driver's result -------------------------------------------------------------
+// The task-DAG kernel has no safety net inside: its hand-offs are write-once cells found by polling.  What it returns is
+// therefore checked against the system it was asked to solve: res = rhs - S y over the packed tiles (S symmetric, lower
+// tiles stored), with den = |rhs| + |S| |y| as the yardstick of a backward-stable solve.  A stale or torn cell anywhere
+// in the factorisation shows up here as a residual many orders above rounding; the solver then repeats the solve on the
+// level schedule (solver.hip).  Sums are fp64 atomics in arbitrary order: this is a check, not a result.
+// res / den start out zero (the check kernel re-arms them after it has looked): one workgroup per packed tile adds what the
+// tile contributes — thread (r, q) = (tid / 4, tid % 4) takes a quarter of row r resp. column r.
+__global__ __launch_bounds__(256) void chol_residual_kernel(const SolverDev sv, const int32_t* __restrict__ slot_tiles, double* res, double* den) {
+  __shared__ double tile[T * TP];
+  __shared__ double yj[T], yi[T];
+  const int slot = blockIdx.x, tid = threadIdx.x, r = tid >> 2, q = tid & 3;
+  const int tile_i = slot_tiles[2 * slot], tile_j = slot_tiles[2 * slot + 1];
+  auto quad_sum = [](double v) { v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); return v; };
+  if (tid < T) { yj[tid] = sv.yv[(size_t)tile_j * T + tid]; yi[tid] = sv.yv[(size_t)tile_i * T + tid]; }
+  const double* St = tile_ptr(sv, slot);
+  for (int e = tid; e < T * T; e += 256) tile[(e / T) * TP + e % T] = St[e];
+  __syncthreads();
+  if (r >= T) return;
+  if (tile_i == tile_j) {   // a diagonal tile through its lower triangle (what the factorisation reads); the rhs enters here
+    double s = 0.0, a = 0.0;
+    for (int c = 12 * q; c < 12 * q + 12; ++c) { const double v = tile[max(r, c) * TP + min(r, c)]; s += v * yj[c]; a += fabs(v) * fabs(yj[c]); }
+    s = quad_sum(s); a = quad_sum(a);
+    if (q == 0) { const double b = sv.rhs[(size_t)tile_j * T + r]; atomicAdd(res + (size_t)tile_j * T + r, b - s); atomicAdd(den + (size_t)tile_j * T + r, fabs(b) + a); }
+    return;
+  }
+  double s = 0.0, a = 0.0, st = 0.0, at = 0.0;
+  for (int c = 12 * q; c < 12 * q + 12; ++c) {
+    const double v = tile[r * TP + c]; s += v * yj[c]; a += fabs(v) * fabs(yj[c]);          // row r of tile (i, j) against y_j
+    const double w = tile[c * TP + r]; st += w * yi[c]; at += fabs(w) * fabs(yi[c]);        // column r of it against y_i
+  }
+  s = quad_sum(s); a = quad_sum(a); st = quad_sum(st); at = quad_sum(at);
+  if (q == 0) {
+    atomicAdd(res + (size_t)tile_i * T + r, -s); atomicAdd(den + (size_t)tile_i * T + r, a);
+    atomicAdd(res + (size_t)tile_j * T + r, -st); atomicAdd(den + (size_t)tile_j * T + r, at);
+  }
+}
+// flag = 1 when some |res_t| exceeds tol * den_t (NaN included) although no pivot failed; res / den are zeroed for the next solve
+__global__ __launch_bounds__(1024) void chol_residual_check_kernel(const SolverDev sv, double* res, double* den, double tol, double* flag) {
+  __shared__ int s_bad;
+  if (threadIdx.x == 0) s_bad = 0;
+  __syncthreads();
+  bool bad = false;
+  for (int64_t t = threadIdx.x; t < sv.npad; t += 1024) {
+    const double rr = fabs(res[t]), d = den[t];
+    if (!(rr <= tol * d) && !(rr == 0.0)) bad = true;
+    res[t] = 0.0; den[t] = 0.0;
+  }
+  if (bad) s_bad = 1;
+  __syncthreads();
+  if (threadIdx.x == 0) *flag = (s_bad && *sv.chol_fail == 0) ? 1.0 : 0.0;   // a failed pivot is reported through chol_fail, not here
+}
+
 }  // namespace
+
+hipError_t launch_chol_verify(const SolverDev& sv, const int32_t* slot_tiles, double* res, double* den, double tol, double* flag, hipStream_t st) {
+  hipLaunchKernelGGL(chol_residual_kernel, dim3(sv.nslots), dim3(256), 0, st, sv, slot_tiles, res, den);
+  hipLaunchKernelGGL(chol_residual_check_kernel, dim3(1), dim3(1024), 0, st, sv, res, den, tol, flag);
+  return hipGetLastError();
+}
 
 hipError_t launch_chol_level(const SolverDev& sv, const CholPlan& pl, int kind, int first, int count, hipStream_t st) {
   if (count <= 0) return hipSuccess;
@@ -700,7 +791,7 @@ hipError_t launch_chol_level(const SolverDev& sv, const CholPlan& pl, int kind, 
   return hipGetLastError();
 }
 
-hipError_t launch_chol_dag(const SolverDev& sv, const CholPlan& pl, int workgroups, hipStream_t st) {
+hipError_t launch_chol_dag(const SolverDev& sv, const CholPlan& pl, const DagArgs* device_args, int workgroups, hipStream_t st) {
   if (pl.ntasks <= 0) return hipSuccess;
   hipError_t e = allow_dynamic_lds(chol_dag_kernel, kCholLds * sizeof(double));
   if (e != hipSuccess) return e;
@@ -711,7 +802,7 @@ hipError_t launch_chol_dag(const SolverDev& sv, const CholPlan& pl, int workgrou
   if (e == hipSuccess) e = hipMemsetAsync(sv.Winv, 0xFF, (size_t)sv.nt * T * T * sizeof(double), st);
   if (e == hipSuccess) e = hipMemsetAsync(sv.zv, 0xFF, 2 * (size_t)sv.npad * sizeof(double), st);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(chol_dag_kernel, dim3(workgroups), dim3(256), kCholLds * sizeof(double), st, sv, pl);
+  hipLaunchKernelGGL(chol_dag_kernel, dim3(workgroups), dim3(256), kCholLds * sizeof(double), st, device_args);
   return hipGetLastError();
 }
 

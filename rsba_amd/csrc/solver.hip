@@ -58,6 +58,12 @@ struct Solver {
   int32_t *d_diag_info = nullptr, *d_diag_ptr = nullptr, *d_diag_list = nullptr, *d_sub_info = nullptr, *d_sub_ptr = nullptr,
           *d_sub_list = nullptr, *d_sub_col = nullptr, *d_diag_own = nullptr, *d_sub_own = nullptr, *d_back_info = nullptr, *d_back_ptr = nullptr, *d_back_list = nullptr;
   std::vector<int32_t> tasks;                                         // {kind, item} in level order, backward solve last
+  DagArgs* d_dag_args = nullptr;
+  int32_t* d_slot_tiles = nullptr;                                    // [nslots][2] {row tile, column tile} of every packed tile
+  double* d_verify = nullptr;                                         // [2 * npad] residual and yardstick of the DAG verification
+  bool verify_dag = true;                                             // RSBA_CHOL_VERIFY=0 switches the check off
+  bool test_corrupt_once = false;                                     // RSBA_CHOL_TEST_CORRUPT=1 (tests): the first DAG solve loses one entry of y
+  int dag_fallbacks = 0;                                              // solves repeated on the level schedule after a failed check                                      // device copy of {sv, plan} for the persistent kernel
   int32_t* d_tasks = nullptr;
   unsigned int* d_dag_sync = nullptr;                                 // [ticket, pad x3]
   long long* d_trace = nullptr;                                       // RSBA_CHOL_TRACE=<file>: task time stamps of the last factorisation
@@ -384,7 +390,9 @@ int32_t build_solver(rsba_handle* h) {
   // level — for itself: on the critical path a freshly finished tile is then multiplied by its consumer directly
   // instead of passing through a partial tile in HBM (two memory round trips less per level).
   // An UPDATE task becomes runnable one level after its last contributor, which is where it enters the ticket order.
-  const int kChunk = 6, kTail = 4;
+  int kChunk = 6, kTail = 4;
+  if (const char* e = std::getenv("RSBA_CHOL_TAIL")) kTail = std::max(1, std::atoi(e));       // tuning aids
+  if (const char* e = std::getenv("RSBA_CHOL_CHUNK")) kChunk = std::max(kTail, std::atoi(e));
   s->lev_diag_ptr.assign(1, 0); s->lev_sub_ptr.assign(1, 0); s->lev_upd_ptr.assign(1, 0);
   s->diag_ptr.assign(1, 0); s->sub_ptr.assign(1, 0); s->back_ptr.assign(1, 0);
   int parts = 0;
@@ -714,7 +722,10 @@ int32_t build_solver(rsba_handle* h) {
   int cus = 0;
   HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
   s->dag_workgroups = std::max(1, std::min(pl.ntasks, std::max(cus, 1)));   // one 4-wave workgroup per CU (register budget)
-  if (std::getenv("RSBA_CHOL_TRACE")) { if ((rc = s_alloc(s, &s->d_trace, 8 * (size_t)pl.ntasks))) return rc; }
+  if (std::getenv("RSBA_CHOL_TRACE")) {
+    if ((rc = s_alloc(s, &s->d_trace, 8 * (size_t)pl.ntasks))) return rc;
+    HIP_TRY(hipMemset(s->d_trace, 0, 8 * (size_t)pl.ntasks * sizeof(long long)));
+  }
   pl.trace = s->d_trace;
   if (std::getenv("RSBA_DEBUG_PLAN"))
     tick("allocations");
@@ -725,6 +736,23 @@ int32_t build_solver(rsba_handle* h) {
                  s->nlev, pl.ntasks, parts, sv.ntp, (long long)s->num_pairs, sv.nchunk);
   const char* lv = std::getenv("RSBA_CHOL_LEVELS");
   s->use_levels = lv && lv[0] == '1';
+  {
+    DagArgs host_args{sv, pl};
+    {
+      std::vector<int32_t> st2(2 * (size_t)sv.nslots);
+      for (int k = 0; k < nt; ++k) {
+        st2[2 * (size_t)slot_base[k]] = perm[k]; st2[2 * (size_t)slot_base[k] + 1] = perm[k];
+        for (size_t u = 0; u < col[k].size(); ++u) { st2[2 * (size_t)(slot_base[k] + 1 + u)] = perm[col[k][u]]; st2[2 * (size_t)(slot_base[k] + 1 + u) + 1] = perm[k]; }
+      }
+      if ((rc = s_upload(s, &s->d_slot_tiles, st2))) return rc;
+    }
+    if ((rc = s_alloc(s, &s->d_verify, 2 * (size_t)sv.npad))) return rc;
+    HIP_TRY(hipMemset(s->d_verify, 0, 2 * (size_t)sv.npad * sizeof(double)));   // the check kernel leaves it zero again
+    { const char* v = std::getenv("RSBA_CHOL_VERIFY"); s->verify_dag = !(v && v[0] == '0'); }
+    { const char* v = std::getenv("RSBA_CHOL_TEST_CORRUPT"); s->test_corrupt_once = v && v[0] == '1'; }
+    if ((rc = s_alloc(s, &s->d_dag_args, 1))) return rc;
+    HIP_TRY(hipMemcpy(s->d_dag_args, &host_args, sizeof host_args, hipMemcpyHostToDevice));
+  }
   {
     rsba_plan_stats& ps = s->stats;
     ps.tiles = nt; ps.factor_tiles = sv.nslots; ps.levels = s->nlev; ps.tasks = pl.ntasks;
@@ -843,7 +871,9 @@ int32_t solve_reduced_system(rsba_handle* h) {
   Solver* s = h->solver; const SolverDev& sv = s->sv; hipStream_t st = h->stream;
   PhaseScope ps(h, RSBA_PHASE_CHOLESKY);
   if (!s->use_levels) {
-    HIP_TRY(launch_chol_dag(sv, s->plan, s->dag_workgroups, st));
+    HIP_TRY(launch_chol_dag(sv, s->plan, s->d_dag_args, s->dag_workgroups, st));
+    if (s->test_corrupt_once) { s->test_corrupt_once = false; HIP_TRY(hipMemsetAsync(sv.yv + (sv.n / 2 / 6) * 6 + 1, 0, sizeof(double), st)); }   // test hook: one entry of the solution (a pose coordinate in mid-video) lost
+    if (s->verify_dag) HIP_TRY(launch_chol_verify(sv, s->d_slot_tiles, s->d_verify, s->d_verify + sv.npad, 1e-7, sv.scalars + kDagSuspect, st));
   } else {
     for (int l = 0; l < s->nlev; ++l) {
       const int d0 = s->lev_diag_ptr[l], d1 = s->lev_diag_ptr[l + 1], t0 = s->lev_sub_ptr[l], t1 = s->lev_sub_ptr[l + 1];
@@ -1103,6 +1133,7 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
       HIP_TRY(hipMemcpyAsync(sv.scalars + 8, cnt, sizeof cnt, hipMemcpyHostToDevice, st));
       if ((rc = exchange(h, sv.scalars + 8, 3, 0))) return rc;
       HIP_TRY(hipMemcpyAsync(cnt, sv.scalars + 8, sizeof cnt, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemsetAsync(sv.scalars + 8, 0, 4 * sizeof(double), st));   // slots 8-11 ride in the per-iteration sum from here on
       HIP_TRY(hipStreamSynchronize(st));
     }
     sum->num_residual_blocks = (int32_t)cnt[0]; sum->num_residual_blocks_reduced = (int32_t)cnt[1]; sum->num_parameters_reduced = (int32_t)cnt[2];
@@ -1240,9 +1271,16 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
       PhaseScope ps(h, RSBA_PHASE_EXCHANGE);
       HIP_TRY(launch_pack_trial(dp, sv, h->d_cost2, st));
       if ((rc = exchange(h, sv.scalars, 3, 0))) return rc;
-      if ((rc = exchange(h, sv.scalars + kCost, 4, 0))) return rc;
+      if ((rc = exchange(h, sv.scalars + kCost, 8, 0))) return rc;   // ... and the verification flag of the Cholesky driver: every rank decides alike
     }
     if ((rc = read_back())) return rc;
+    if (host_sc[kDagSuspect] != 0.0 && !s->use_levels) {
+      // the persistent driver's solution does not satisfy the system it was given: nothing of this iteration has touched
+      // x yet — repeat it, and finish this problem, on the level schedule
+      s->use_levels = true; ++s->dag_fallbacks; ++sum->num_dag_fallbacks;
+      HIP_TRY(hipMemsetAsync(sv.scalars + kDagSuspect, 0, sizeof(double), st));
+      continue;
+    }
     cost2[1] = 0.0;   // the trial evaluation reports the total in kCost
     sum->linear_solver_time_s += now_s() - t0;
     ++iteration;

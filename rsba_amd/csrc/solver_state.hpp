@@ -100,6 +100,7 @@ struct SolverDev {
 
 enum ScalarSlot : int {
   kModelCostChange = 0, kStepSq = 1, kXSq = 2, kGradMax = 3, kCost = 4, kFixedCost = 5, kEvalFailed = 6, kSolveFailed = 7,
+  kDagSuspect = 11,   // set by the verification of the persistent Cholesky driver (slots 8-10: exchange scratch of the problem-size counts)
 };
 
 // Dynamic LDS above the 64 KB default needs the kernel's cap raised, once per (kernel, device).
@@ -135,7 +136,11 @@ hipError_t launch_pose_prior_step(const DeviceProblem& dp, const SolverDev& sv, 
 
 // cholesky.hip
 hipError_t launch_chol_level(const SolverDev& sv, const CholPlan& pl, int kind, int first, int count, hipStream_t st);
-hipError_t launch_chol_dag(const SolverDev& sv, const CholPlan& pl, int workgroups, hipStream_t st);
+// res = rhs - S y with den = |rhs| + |S||y| over the packed tiles; *flag = 1 when |res| > tol * den somewhere (cholesky.hip)
+// slot_tiles [nslots][2] = {row tile, column tile} (unpermuted tile indices) of every packed tile
+hipError_t launch_chol_verify(const SolverDev& sv, const int32_t* slot_tiles, double* res, double* den, double tol, double* flag, hipStream_t st);
+struct DagArgs { SolverDev sv; CholPlan pl; };   // device copy the persistent kernel reads its state through (uploaded once per plan)
+hipError_t launch_chol_dag(const SolverDev& sv, const CholPlan& pl, const DagArgs* device_args, int workgroups, hipStream_t st);
 
 // kernels_normal.hip
 hipError_t launch_camera_blocks(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);

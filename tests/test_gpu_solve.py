@@ -265,3 +265,23 @@ def test_shared_intrinsics_with_many_points(capi, oracle):
     p.intrinsics = p.intrinsics * (1.0 + 1e-3 * np.array([[1, -1, 20, -20, 10, 10, -10, 0.5, -0.5]]))
     s, s_ref, p_dev, p_cpu = compare_solves(capi, oracle, p, iters=8)
     assert np.max(np.abs(p_dev.intrinsics - p_cpu.intrinsics) / np.maximum(1.0, np.abs(p_cpu.intrinsics))) <= 1e-6
+
+
+def test_a_wrong_dag_result_is_caught_and_redone_on_the_level_schedule(capi, monkeypatch):
+    """The persistent Cholesky driver's solution is verified against the system it was given (res = rhs - S y against
+    |rhs| + |S||y|).  RSBA_CHOL_TEST_CORRUPT=1 makes the first DAG solve lose one entry of y: the check must notice, the
+    iteration is repeated — and the problem finished — on the level schedule, and the result is the level schedule's, bit
+    for bit.  Without the hook no solve of this suite trips the check."""
+    from rsba_amd.scene import make_config
+    out = {}
+    for mode in ("corrupt", "levels", "plain"):
+        monkeypatch.delenv("RSBA_CHOL_TEST_CORRUPT", raising=False)
+        if mode == "corrupt":
+            monkeypatch.setenv("RSBA_CHOL_TEST_CORRUPT", "1")
+        p = make_config("C2").problem
+        with capi.DeviceProblem(p) as dp:
+            s, _ = dp.solve(capi.default_options(max_num_iterations=6, level_scheduled_cholesky=int(mode == "levels")))
+        out[mode] = (s.final_cost, s.num_iterations, s.num_dag_fallbacks, p.poses.copy(), p.points.copy())
+    assert out["corrupt"][2] == 1 and out["levels"][2] == 0 and out["plain"][2] == 0
+    for a, b in ((out["corrupt"], out["levels"]), (out["plain"], out["levels"])):
+        assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
