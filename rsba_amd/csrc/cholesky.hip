@@ -122,6 +122,178 @@ __device__ __forceinline__ bool potrf_blocked(double* A, int tid) {
   return ok;
 }
 
+// LDS map (doubles): four partial-tile buffers, then small vectors
+constexpr int kBuf = T * TP;
+constexpr int kVecOff = 4 * kBuf;            // [4][T] per-wave rhs partials, [T] b, [T] unused, [T] unused, [T] z of the last contributor
+constexpr int kXOff = kVecOff + 8 * T;       // two more tiles for a DIAG task that forms its last contributor itself: X, then L = X W^T
+constexpr int kMsg = 64;                     // one pivot's message between the two waves of the tile factorisation: a double per lane
+constexpr int kMsgOff = kXOff + 2 * kBuf;    // [3 diagonal blocks][16 pivots][kMsg]
+constexpr int kCholLds = kMsgOff + 3 * 16 * kMsg;
+
+// "empty" bit pattern of the write-once cells (below) — also of the pivot messages in LDS
+__device__ __forceinline__ bool filled(double v) { return __double_as_longlong(v) != -1ll; }
+
+// ---- factorisation + inverse of one 48 x 48 tile on the matrix pipe -------------------------------------------------
+// The serial part of the whole solve is the chain of diagonal tiles: W_j = chol(D_j)^-1 for one tile after the other.  A
+// lane-per-row Cholesky pays ~30 cross-lane broadcasts (v_readlane) per pivot.  Here a pivot is ONE rank-1 MFMA instead:
+// the 16 x 16 diagonal block lives in the accumulator layout of v_mfma_f64_16x16x4_f64 (lane (c, g): rows g + 4v, column
+// c), kept in full (symmetric), so row jj — the multipliers of pivot jj, by symmetry — already sits in lane group
+// g = jj % 4, register jj / 4, one column per lane: exactly where the instruction wants the k = g slice of its A and B
+// operands.  D -= (row / d) row^T is then a select and a multiply per lane, no data movement at all.  The same multipliers
+// applied to an identity give L'^-1 of the unit-lower LDL^T factor (second MFMA of the pivot), and
+// W = chol(D)^-1 = diag(d)^-1/2 L'^-1: no square root on the chain, and the factor itself is never formed (nothing
+// downstream reads it).  The reciprocal of a pivot (v_rcp + two Newton steps) is taken one pivot ahead.
+__device__ __forceinline__ double rcp_nr(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = fma(fma(-x, y, 1.0), y, y);
+  y = fma(fma(-x, y, 1.0), y, y);
+  return y;
+}
+
+// fp64 MFMAs and fp64 vector instructions do not overlap on this chip (tools/ldl_probe.hip: their times add up, the matrix
+// pipe runs on the vector unit's fp64 datapath), so whatever one wave does per pivot is serial.  The step is therefore
+// split over TWO waves (two SIMDs): the first eliminates (one MFMA, the pivot's reciprocal by v_rcp + y0 (1 + e + e^2),
+// ~180 cycles per pivot) and posts each pivot's multipliers and the pivot itself in LDS; the second picks a message up as
+// soon as it is complete (the data is its own flag, as with the write-once cells in HBM), applies it to the identity and
+// ends up with the inverse a few hundred cycles after the last pivot.  The messages must be armed (armed = empty pattern)
+// before the workgroup barrier that precedes the step.
+__device__ __forceinline__ void arm_pivot_messages(double* smem, int tid) {
+  for (int e = tid; e < 3 * 16 * kMsg; e += 256) smem[kMsgOff + e] = __longlong_as_double(-1ll);
+}
+// first wave: d = symmetric positive definite 16 x 16 block, accumulator layout.  false on a non-positive / non-finite pivot.
+__device__ __forceinline__ bool ldl16_eliminate(dbl4_t d, double* msg, int lane) {
+  const int c = lane & 15, g = lane >> 4;
+  typedef __attribute__((address_space(3))) double* lds_ptr;
+  lds_ptr lm = (lds_ptr)msg;
+  bool ok = true;
+#pragma unroll
+  for (int jj = 0; jj < 16; ++jj) {
+    const int gg = jj & 3, vv = jj >> 2;
+    const bool grp = g == gg;
+    const double dv = d[vv];
+    const double piv = readlane_f64(dv, 16 * gg + jj);
+    ok = ok && (piv > 0.0) && isfinite(piv);
+    // -dv / piv = -(dv y0) (1 + e + e^2), e = 1 - piv y0: v_rcp_f64 is good to ~2^-23, e^3 is far below rounding; dv y0 runs
+    // beside e, so the chain behind v_rcp is three operations long
+    const double y0 = __builtin_amdgcn_rcp(piv), e = fma(-piv, y0, 1.0), t = dv * y0;
+    const double q = fma(t, fma(e, e, e), t);
+    const double row = grp ? dv : 0.0;                  // B: row jj of D   (k = gg slice, zero elsewhere)
+    const double mul = (grp && c > jj) ? -q : 0.0;      // A: -D[jj][i] / d for the rows i below the pivot
+    lm[jj * kMsg + lane] = (grp && c == jj) ? dv : mul;  // the message: the multipliers, with the pivot itself in the (otherwise zero) lane of the diagonal
+    if (jj < 15) d = __builtin_amdgcn_mfma_f64_16x16x4f64(mul, row, d, 0, 0, 0);
+  }
+  return ok;
+}
+// second wave: W = chol(d)^-1 (lower, exact zeros above the diagonal), accumulator layout
+__device__ __forceinline__ dbl4_t ldl16_follow(const double* msg, int lane, long long* fstamp = nullptr) {
+  const int c = lane & 15, g = lane >> 4;
+  typedef const volatile __attribute__((address_space(3))) double* lds_cvptr;   // volatile: re-read on every look; explicitly LDS (a volatile generic pointer would be read with flat loads)
+  lds_cvptr vm = (lds_cvptr)msg;
+  dbl4_t w;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) w[v] = (g + 4 * v == c) ? 1.0 : 0.0;
+  double pv[4] = {1.0, 1.0, 1.0, 1.0};   // the pivots of this lane's four rows
+  double next = vm[lane];
+#pragma unroll
+  for (int jj = 0; jj < 16; ++jj) {
+    const int gg = jj & 3, vv = jj >> 2;
+    const bool grp = g == gg;
+    double m = next;
+    while (__ballot(!filled(m)) != 0ull) m = vm[jj * kMsg + lane];
+    // the next message is requested BEFORE this pivot's MFMA and looked at after it (a speculative read: what is not there yet
+    // is read again above) — the LDS round trip would otherwise sit between every two MFMAs of this wave
+    if (jj < 15) next = vm[(jj + 1) * kMsg + lane];
+    __builtin_amdgcn_sched_barrier(0);
+    const double piv = readlane_f64(m, 16 * gg + jj);
+    const double mul = (grp && c == jj) ? 0.0 : m;
+    const double wrow = grp ? w[vv] : 0.0;                     // B: row jj of W' = L'^-1 as it stands
+    if (jj < 15) w = __builtin_amdgcn_mfma_f64_16x16x4f64(mul, wrow, w, 0, 0, 0);
+    pv[vv] = grp ? piv : pv[vv];
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int v = 0; v < 4; ++v) w[v] *= rsqrt_nr(pv[v]);
+  return w;
+}
+
+// the 16 x 16 block at (o, o) of a tile whose lower triangle is valid (LDS, pitch TP), mirrored into the accumulator layout
+__device__ __forceinline__ dbl4_t load_sym16(const double* D, int o, int lane) {
+  const int c = lane & 15, g = lane >> 4;
+  dbl4_t d;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) { const int r = g + 4 * v; d[v] = D[(o + (r > c ? r : c)) * TP + o + (r > c ? c : r)]; }
+  return d;
+}
+__device__ __forceinline__ dbl4_t load16(const double* M, int rb, int cb, int lane) {
+  dbl4_t d;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) d[v] = M[(rb + (lane >> 4) + 4 * v) * TP + cb + (lane & 15)];
+  return d;
+}
+__device__ __forceinline__ void put16(double* M, int rb, int cb, dbl4_t x, int lane) {
+#pragma unroll
+  for (int v = 0; v < 4; ++v) M[(rb + (lane >> 4) + 4 * v) * TP + cb + (lane & 15)] = x[v];
+}
+// 16 x 16 x 16 block products out of LDS (pitch TP): acc + sign * X(xr.., xc..) Y(yr.., yc..)^T  resp.  acc + sign * X Y
+__device__ __forceinline__ dbl4_t mm16_nt(const double* X, int xr, int xc, const double* Y, int yr, int yc, dbl4_t acc, double sign, int lane) {
+  const int mi = lane & 15, mg = lane >> 4;
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk)
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sign * X[(xr + mi) * TP + xc + 4 * kk + mg], Y[(yr + mi) * TP + yc + 4 * kk + mg], acc, 0, 0, 0);
+  return acc;
+}
+__device__ __forceinline__ dbl4_t mm16_nn(const double* X, int xr, int xc, const double* Y, int yr, int yc, dbl4_t acc, double sign, int lane) {
+  const int mi = lane & 15, mg = lane >> 4;
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk)
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sign * X[(xr + mi) * TP + xc + 4 * kk + mg], Y[(yr + 4 * kk + mg) * TP + yc + mi], acc, 0, 0, 0);
+  return acc;
+}
+
+// W = chol(D)^-1 for the T x T tile D in LDS (lower triangle valid, pitch TP; destroyed) into Wl (lower blocks; the blocks
+// above the diagonal are left untouched), by 16 x 16 blocks: the first two waves walk the three diagonal blocks (the serial
+// chain), the others keep the off-diagonal algebra out of their way:
+//   L_I0 = D_I0 W_00^T ;  D_11 -= L_10 L_10^T, D_21 -= L_20 L_10^T, D_22 -= L_20 L_20^T ;  L_21 = D_21 W_11^T ;  D_22 -= L_21 L_21^T
+//   W_10 = -W_11 (L_10 W_00),  W_21 = -W_22 (L_21 W_11),  W_20 = -W_22 (L_20 W_00 + L_21 W_10).
+// Tm and Lp are scratch tiles; D must be the task's first LDS buffer and the pivot messages armed (arm_pivot_messages)
+// before the barrier in front of this call.  All threads must call; ends with a barrier.  Returns (in the first wave)
+// false on a non-positive pivot.
+template <bool TRACE = false>
+__device__ __forceinline__ bool factor_invert_tile(double* D, double* Wl, double* Tm, double* Lp, int tid, long long* stamps = nullptr) {
+  const int wave = tid >> 6, lane = tid & 63;
+  const dbl4_t zero = {0.0, 0.0, 0.0, 0.0};
+  bool ok = true;
+  int nstamp = 0;
+  auto stamp = [&]() { if (TRACE && tid == 0) stamps[nstamp++] = clock64(); };   // tools/tile_factor_bench.hip
+  double* msg = D + kMsgOff;   // (D is the first LDS buffer of the task)
+  stamp();
+  if (wave == 0) ok = ldl16_eliminate(load_sym16(D, 0, lane), msg, lane);
+  else if (wave == 1) put16(Wl, 0, 0, ldl16_follow(msg, lane, TRACE ? stamps + 16 : nullptr), lane);
+  stamp(); lds_barrier(); stamp();
+  if (wave < 2) put16(Lp, 16 + 16 * wave, 0, mm16_nt(D, 16 + 16 * wave, 0, Wl, 0, 0, zero, 1.0, lane), lane);   // L_10, L_20
+  stamp(); lds_barrier(); stamp();
+  if (wave == 0) ok = ldl16_eliminate(mm16_nt(Lp, 16, 0, Lp, 16, 0, load_sym16(D, 16, lane), -1.0, lane), msg + 16 * kMsg, lane) && ok;
+  else if (wave == 1) put16(Wl, 16, 16, ldl16_follow(msg + 16 * kMsg, lane), lane);
+  else if (wave == 2) {
+    put16(D, 32, 16, mm16_nt(Lp, 32, 0, Lp, 16, 0, load16(D, 32, 16, lane), -1.0, lane), lane);
+    put16(Tm, 16, 0, mm16_nn(Lp, 16, 0, Wl, 0, 0, zero, 1.0, lane), lane);                                         // T_10 = L_10 W_00
+  } else put16(D, 32, 32, mm16_nt(Lp, 32, 0, Lp, 32, 0, load16(D, 32, 32, lane), -1.0, lane), lane);              // (its upper half is never read)
+  stamp(); lds_barrier(); stamp();
+  if (wave == 0) put16(Lp, 32, 16, mm16_nt(D, 32, 16, Wl, 16, 16, zero, 1.0, lane), lane);       // L_21
+  else if (wave == 1) put16(Wl, 16, 0, mm16_nn(Wl, 16, 16, Tm, 16, 0, zero, -1.0, lane), lane);  // W_10
+  else if (wave == 2) put16(Tm, 32, 0, mm16_nn(Lp, 32, 0, Wl, 0, 0, zero, 1.0, lane), lane);     // T_20 = L_20 W_00
+  stamp(); lds_barrier(); stamp();
+  if (wave == 0) ok = ldl16_eliminate(mm16_nt(Lp, 32, 16, Lp, 32, 16, load_sym16(D, 32, lane), -1.0, lane), msg + 32 * kMsg, lane) && ok;
+  else if (wave == 1) put16(Wl, 32, 32, ldl16_follow(msg + 32 * kMsg, lane), lane);
+  else if (wave == 2) put16(Tm, 32, 16, mm16_nn(Lp, 32, 16, Wl, 16, 16, zero, 1.0, lane), lane);                    // T_21 = L_21 W_11
+  else put16(Tm, 32, 0, mm16_nn(Lp, 32, 16, Wl, 16, 0, load16(Tm, 32, 0, lane), 1.0, lane), lane);                  // T_20 += L_21 W_10
+  stamp(); lds_barrier(); stamp();
+  if (wave == 0) put16(Wl, 32, 16, mm16_nn(Wl, 32, 32, Tm, 32, 16, zero, -1.0, lane), lane);      // W_21
+  else if (wave == 1) put16(Wl, 32, 0, mm16_nn(Wl, 32, 32, Tm, 32, 0, zero, -1.0, lane), lane);   // W_20
+  stamp(); lds_barrier(); stamp();
+  return ok;
+}
+
 // ---- MFMA tile products ------------------------------------------------------------------------------------
 // C(48x48) += A B^T on v_mfma_f64_16x16x4_f64, operands straight from HBM/L2 into registers — no LDS, no
 // barrier in the accumulation loop.  The four waves of the workgroup split K: wave w owns columns
@@ -201,7 +373,6 @@ __shared__ long long* s_trace_slot;   // RSBA_CHOL_TRACE: where the running task
 // Cells move through agent-coherent accesses: relaxed agent-scope atomic loads / stores of the individual doubles,
 // which gfx950 issues with sc1 (the L2 of the other XCDs is not coherent with ours; sc1 accesses go to the memory
 // side), so neither side needs cache maintenance.  The level driver (DAG = false) uses plain loads and stores.
-__device__ __forceinline__ bool filled(double v) { return __double_as_longlong(v) != -1ll; }
 template <bool DAG> __device__ __forceinline__ double ld(const double* p) {
   if (DAG) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return *p;
@@ -223,10 +394,6 @@ __device__ __forceinline__ void note_late_input() { if (threadIdx.x == 0 && s_tr
 
 __device__ __forceinline__ double* factor_ptr(const SolverDev& sv, int slot) { return sv.Lf + (size_t)slot * (T * T); }
 
-// LDS map (doubles): four partial-tile buffers, then small vectors
-constexpr int kBuf = T * TP;
-constexpr int kVecOff = 4 * kBuf;            // [4][T] per-wave rhs partials, [T] b, [T] 1/diag, pivot-failure word
-constexpr int kCholLds = kVecOff + 8 * T;
 
 
 template <bool DAG>
@@ -443,15 +610,47 @@ __device__ __forceinline__ void invert_lower_blocked(const double* L, const doub
   lds_barrier();
 }
 
-// second half of a DIAG task: the updates are in acc / bz, the tile and rhs (less the partial tiles) in sreg / breg
+// L = X W_j^T for the tile X held in LDS (pitch TP): wave I < 3 forms row block I into c[J] (MFMA result layout: rows
+// 16I + (lane >> 4) + 4v, column 16J + (lane & 15)); W is lower triangular, so column block J only needs k < 16 (J + 1).
+// W_j comes from the DIAG task of column j: its cells are read until they are all there.
 template <bool DAG>
-__device__ __forceinline__ void diag_finish(const SolverDev& sv, int tile_j, double sreg[9], double breg, Acc& acc, double bz[3], double* smem, int tid) {
+__device__ __forceinline__ void times_inverse_transposed(const SolverDev& sv, int tile_j, const double* X, dbl4 c[3], int wave, int lane) {
+  const int I = wave, r = lane & 15, g = lane >> 4;
+  const double* Wg = sv.Winv + (size_t)tile_j * (T * T);
+  double wv[3][12];   // B operand: W[16J + r][4kk + g]
+  {
+    bool late = false;
+    for (;;) {
+      bool ok = true;
+#pragma unroll
+      for (int J = 0; J < 3; ++J)
+#pragma unroll
+        for (int kk = 0; kk < 4 * (J + 1); ++kk) { wv[J][kk] = ld<DAG>(Wg + (16 * J + r) * T + 4 * kk + g); ok = ok && filled(wv[J][kk]); }
+      if (!DAG || __ballot(!ok) == 0ull) break;
+      late = true;
+      watch_cell<DAG>(Wg + (T * T - 1));   // the corner of the inverse
+    }
+    if (late) note_late_input();
+  }
+  c[0] = c[1] = c[2] = dbl4{0, 0, 0, 0};
+#pragma unroll
+  for (int kk = 0; kk < 12; ++kk) {
+    const double a = X[(16 * I + r) * TP + 4 * kk + g];
+#pragma unroll
+    for (int J = 0; J < 3; ++J)
+      if (kk < 4 * (J + 1)) c[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, wv[J][kk], c[J], 0, 0, 0);
+  }
+}
+
+// DIAG task, early half: the updates formed so far are in acc / bz (K split over the waves), the tile and rhs (less the partial
+// tiles) in sreg / breg — D = S_jj - updates (lower triangle) and b = rhs - updates go to LDS.  No barrier at the end.
+__device__ __forceinline__ void diag_assemble(double sreg[9], double breg, Acc& acc, double bz[3], double* smem, int tid) {
   const int wave = tid >> 6, lane = tid & 63;
-  double* D = smem; double* Wl = smem + kBuf;
-  double* vec = smem + kVecOff; double* bvec = vec + 4 * T; double* dinv = vec + 5 * T; int* s_okp = reinterpret_cast<int*>(vec + 6 * T);
-  CHOL_STAMP(3);
+  double* D = smem;
+  double* vec = smem + kVecOff; double* bvec = vec + 4 * T;
   acc.spill(smem + wave * kBuf, lane);
   spill_bz(bz, vec + wave * T, lane);
+  arm_pivot_messages(smem, tid);
   lds_barrier();
 #pragma unroll
   for (int q = 0; q < 9; ++q) {
@@ -460,20 +659,20 @@ __device__ __forceinline__ void diag_finish(const SolverDev& sv, int tile_j, dou
     sreg[q] = (c <= r) ? sreg[q] - upd : 0.0;
   }
   if (tid < T) bvec[tid] = breg - ((vec[tid] + vec[T + tid]) + (vec[2 * T + tid] + vec[3 * T + tid]));
-  if (tid == 0) *s_okp = 1;
   lds_barrier();
 #pragma unroll
   for (int q = 0; q < 9; ++q) { const int e = tid + 256 * q; D[(e / T) * TP + e % T] = sreg[q]; }
-  lds_barrier();
+}
+
+// DIAG task, the serial half: D (LDS, complete) = L_jj L_jj^T, W_j = L_jj^-1, z_j = W_j b
+template <bool DAG>
+__device__ __forceinline__ void diag_factor(const SolverDev& sv, int tile_j, double* smem, int tid) {
+  double* D = smem; double* Wl = smem + kBuf;
+  double* vec = smem + kVecOff; double* bvec = vec + 4 * T;
   CHOL_STAMP(4);
-  const bool ok = potrf_blocked(D, tid);
-  if (tid < 64 && !ok) *s_okp = 0;
-  if (tid < T) dinv[tid] = 1.0 / D[tid * TP + tid];
-  lds_barrier();
-  CHOL_STAMP(5);
-  if (!*s_okp && tid == 0) atomicExch(sv.chol_fail, 1);
-  // L_jj itself is not stored: everything downstream uses W_j
-  invert_lower_blocked(D, dinv, Wl, smem + 2 * kBuf, tid);
+  // L_jj itself is never formed: everything downstream uses W_j
+  const bool ok = factor_invert_tile(D, Wl, smem + 2 * kBuf, smem + 3 * kBuf, tid);
+  if (tid == 0 && !ok) atomicExch(sv.chol_fail, 1);
   CHOL_STAMP(6);
   double* wout = sv.Winv + (size_t)tile_j * (T * T);
   for (int e = tid; e < T * T; e += 256) { const int r = e / T, c = e % T; st<DAG>(wout + e, (c <= r) ? Wl[r * TP + c] : 0.0); }
@@ -490,7 +689,19 @@ __device__ __forceinline__ void task_diag(const SolverDev& sv, const CholPlan& p
   const int wave = tid >> 6, lane = tid & 63;
   const int32_t* info = pl.diag_info + 4 * b;
   const int slot_jj = info[0], tile_j = info[1], part0 = info[2], nparts = info[3];
-  const int p0 = pl.diag_own[b], p1 = pl.diag_ptr[b + 1];   // the owner's share of the contributor list
+  // The last contributor k* (the column that finishes one level before this one) is formed HERE from W_k* instead of being
+  // read back from the SUB task of tile (j, k*) (item fs).
+  const int fs = pl.diag_fuse[b];
+  const int p0 = pl.diag_own[b], p1 = pl.diag_ptr[b + 1] - (fs >= 0 ? 1 : 0);   // the owner's share of the contributor list
+  double* XB = smem + kXOff; double* LB = XB + kBuf;
+  // X = S_jk* - (older updates) comes from the SUB task of that tile, which publishes it before it starts waiting for W_k*:
+  // requested here, looked at when it is needed
+  double xreg[9];
+  const double* xs = sv.Xpub + (size_t)b * (T * T);
+  if (fs >= 0) {
+#pragma unroll
+    for (int q = 0; q < 9; ++q) xreg[q] = ld<DAG>(xs + tid + 256 * q);
+  }
   // the tile itself (left by the Schur kernels before this launch) travels while the updates are formed
   double sreg[9];
   const double* src = tile_ptr(sv, slot_jj);
@@ -502,7 +713,74 @@ __device__ __forceinline__ void task_diag(const SolverDev& sv, const CholPlan& p
   Acc acc; acc.clear();
   double bz[3] = {0, 0, 0};
   accumulate<DAG, true>(sv, pl, pl.diag_list, p0, p1, acc, bz, wave, lane);
-  diag_finish<DAG>(sv, tile_j, sreg, breg, acc, bz, smem, tid);
+  CHOL_STAMP(3);
+  diag_assemble(sreg, breg, acc, bz, smem, tid);   // everything that does not need column k*: off the critical path
+  if (fs >= 0) {
+    const int tile_k = pl.sub_col[fs];
+    double* D = smem;
+    double* vec = smem + kVecOff; double* bvec = vec + 4 * T; double* zs = vec + 7 * T;
+    {
+      bool late = false;
+      for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) ok = ok && filled(xreg[q]);
+        if (!DAG || ok) break;
+        late = true;
+        watch_cell<DAG>(xs + tid + 256 * 8);
+#pragma unroll
+        for (int q = 0; q < 9; ++q) xreg[q] = ld<DAG>(xs + tid + 256 * q);
+      }
+      if (late) note_late_input();
+#pragma unroll
+      for (int q = 0; q < 9; ++q) { const int e = tid + 256 * q; XB[(e / T) * TP + e % T] = xreg[q]; }
+    }
+    lds_barrier();   // X and D are in LDS
+    if (wave < 3) {
+      const int r = lane & 15, g = lane >> 4;
+      dbl4 c[3];
+      times_inverse_transposed<DAG>(sv, tile_k, XB, c, wave, lane);
+#pragma unroll
+      for (int J = 0; J < 3; ++J)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) LB[(16 * wave + g + 4 * v) * TP + 16 * J + r] = c[J][v];
+    } else if (lane < T) {   // z_k*, stored right behind W_k*
+      const double* zk = sv.zv + (size_t)tile_k * T + lane;
+      double z = ld<DAG>(zk);
+      while (DAG && !filled(z)) { __builtin_amdgcn_s_sleep(2); z = ld<DAG>(zk); }
+      zs[lane] = z;
+    }
+    lds_barrier();
+    // D -= L L^T on the lower 16 x 16 blocks, dealt to the waves (each block over all of K: no partial tiles to add up
+    // on the critical path); b -= L z_k* by two lanes per row of waves 2 and 3, which only have one block each
+    {
+      const int mi = lane & 15, mg = lane >> 4;
+#pragma unroll
+      for (int blk = 0; blk < 6; ++blk) {
+        if ((blk & 3) != wave) continue;
+        const int I = blk < 1 ? 0 : (blk < 3 ? 1 : 2), J = blk - (I * (I + 1)) / 2;
+        dbl4 a4 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < T / 4; ++kk)
+          a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(LB[(16 * I + mi) * TP + 4 * kk + mg], LB[(16 * J + mi) * TP + 4 * kk + mg], a4, 0, 0, 0);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int r = 16 * I + mg + 4 * v, c = 16 * J + mi;
+          if (c <= r) D[r * TP + c] -= a4[v];
+        }
+      }
+      if (tid >= 128 && tid < 128 + 2 * T) {
+        const int row = (tid - 128) >> 1, h = tid & 1;
+        double s0 = 0.0;
+#pragma unroll
+        for (int m = 0; m < T / 2; ++m) s0 += LB[row * TP + (T / 2) * h + m] * zs[(T / 2) * h + m];
+        s0 += __shfl_xor(s0, 1, 64);
+        if (h == 0) bvec[row] -= s0;
+      }
+    }
+  }
+  lds_barrier();
+  diag_factor<DAG>(sv, tile_j, smem, tid);
 }
 
 template <bool DAG>
@@ -531,38 +809,20 @@ __device__ __forceinline__ void task_sub(const SolverDev& sv, const CholPlan& pl
   lds_barrier();
 #pragma unroll
   for (int q = 0; q < 9; ++q) { const int e = tid + 256 * q; X[(e / T) * TP + e % T] = sreg[q]; }
+  if (const int pub = pl.sub_pub[b]; pub >= 0) {   // the DIAG task of row i multiplies this by W_j itself (look-ahead on the critical path)
+    double* xp = sv.Xpub + (size_t)pub * (T * T);
+#pragma unroll
+    for (int q = 0; q < 9; ++q) st<DAG>(xp + tid + 256 * q, sreg[q]);
+  }
   CHOL_STAMP(4);
   lds_barrier();
   CHOL_STAMP(5);
-  // L_ij = X W_j^T: wave I forms row block I; W is lower triangular, so column block J only needs k < 16 (J + 1).
-  // W_j comes from the DIAG task of this column: its cells are read until they are all there.
+  // L_ij = X W_j^T
   if (wave < 3) {
     const int I = wave, r = lane & 15, g = lane >> 4;
-    const double* Wg = sv.Winv + (size_t)tile_j * (T * T);
     double* out = factor_ptr(sv, slot_ij);
-    double wv[3][12];   // B operand: W[16J + r][4kk + g]
-    {
-      bool late = false;
-      for (;;) {
-        bool ok = true;
-#pragma unroll
-        for (int J = 0; J < 3; ++J)
-#pragma unroll
-          for (int kk = 0; kk < 4 * (J + 1); ++kk) { wv[J][kk] = ld<DAG>(Wg + (16 * J + r) * T + 4 * kk + g); ok = ok && filled(wv[J][kk]); }
-        if (!DAG || __ballot(!ok) == 0ull) break;
-        late = true;
-        watch_cell<DAG>(Wg + (T * T - 1));   // the corner of the inverse
-      }
-      if (late) note_late_input();
-    }
-    dbl4 c[3] = {dbl4{0, 0, 0, 0}, dbl4{0, 0, 0, 0}, dbl4{0, 0, 0, 0}};
-#pragma unroll
-    for (int kk = 0; kk < 12; ++kk) {
-      const double a = X[(16 * I + r) * TP + 4 * kk + g];
-#pragma unroll
-      for (int J = 0; J < 3; ++J)
-        if (kk < 4 * (J + 1)) c[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, wv[J][kk], c[J], 0, 0, 0);
-    }
+    dbl4 c[3];
+    times_inverse_transposed<DAG>(sv, tile_j, X, c, wave, lane);
 #pragma unroll
     for (int J = 0; J < 3; ++J)
 #pragma unroll
@@ -801,6 +1061,7 @@ hipError_t launch_chol_dag(const SolverDev& sv, const CholPlan& pl, const DagArg
   if (e == hipSuccess) e = hipMemsetAsync(sv.chol_part, 0xFF, (size_t)(pl.nparts > 0 ? pl.nparts : 1) * (T * T + T) * sizeof(double), st);
   if (e == hipSuccess) e = hipMemsetAsync(sv.Winv, 0xFF, (size_t)sv.nt * T * T * sizeof(double), st);
   if (e == hipSuccess) e = hipMemsetAsync(sv.zv, 0xFF, 2 * (size_t)sv.npad * sizeof(double), st);
+  if (e == hipSuccess) e = hipMemsetAsync(sv.Xpub, 0xFF, (size_t)sv.nt * T * T * sizeof(double), st);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(chol_dag_kernel, dim3(workgroups), dim3(256), kCholLds * sizeof(double), st, device_args);
   return hipGetLastError();

@@ -52,6 +52,10 @@ struct Solver {
   int32_t* d_upd = nullptr;
   std::vector<int32_t> diag_info, diag_ptr, diag_list;                // per column: {slot_jj, old tile}; contributors {slot_jk, old tile k}
   std::vector<int32_t> diag_own, sub_own;                             // first contributor the owner multiplies itself (the ones before arrive as partial tiles)
+  std::vector<int32_t> diag_fuse;                                     // per column j: SUB item of tile (j, k*), k* = its last contributor, which the DIAG task forms itself (-1: none)
+  int32_t* d_diag_fuse = nullptr;
+  std::vector<int32_t> sub_pub;                                       // per SUB item: DIAG item that wants its X = S_ij - updates published (sv.Xpub slot), -1: nobody
+  int32_t* d_sub_pub = nullptr;
   std::vector<int32_t> sub_col;                                       // per sub tile: tile index of its column (W_j, z_j)
   std::vector<int32_t> sub_info, sub_ptr, sub_list;                   // per tile (i,j): {slot_ij, slot_jj}; contributors {slot_ik, slot_jk}
   std::vector<int32_t> back_info, back_ptr, back_list;                // per column: {slot_jj, old tile}; tiles {slot_ij, old tile i}
@@ -390,6 +394,14 @@ int32_t build_solver(rsba_handle* h) {
   // level — for itself: on the critical path a freshly finished tile is then multiplied by its consumer directly
   // instead of passing through a partial tile in HBM (two memory round trips less per level).
   // An UPDATE task becomes runnable one level after its last contributor, which is where it enters the ticket order.
+  // Look-ahead on the critical path: the LAST contributor k* of column j finishes one level before j and would reach the
+  // DIAG task through the SUB task of tile (j, k*) — W_k* out, L_jk* = X W_k*^T back, two hand-offs through memory.  The DIAG
+  // task takes X = S_jk* - (older updates) — which the SUB task publishes as soon as it has it, long before W_k* exists — and
+  // multiplies by W_k* itself the moment it lands (one hand-off).  The SUB task still writes L_jk* for everyone else; both
+  // follow the same arithmetic, bit for bit.
+  bool fuse_last = true;
+  if (const char* e = std::getenv("RSBA_CHOL_FUSE")) fuse_last = e[0] != '0';
+  std::vector<int32_t> sub_base(nt, 0);   // first SUB item of each column (items of a column follow col[] order)
   int kChunk = 6, kTail = 4;
   if (const char* e = std::getenv("RSBA_CHOL_TAIL")) kTail = std::max(1, std::atoi(e));       // tuning aids
   if (const char* e = std::getenv("RSBA_CHOL_CHUNK")) kChunk = std::max(kTail, std::atoi(e));
@@ -422,11 +434,18 @@ int32_t build_solver(rsba_handle* h) {
       for (int32_t k : rj) { s->diag_list.push_back(slot_of(j, k)); s->diag_list.push_back(perm[k]); klev.push_back(level[k]); }
       s->diag_ptr.push_back((int32_t)(s->diag_list.size() / 2));
       chunk_it(0, dp0, (int32_t)(s->diag_list.size() / 2), s->diag_info, s->diag_own);
+      if (fuse_last && !rj.empty()) {
+        const int32_t ks = rj.back();
+        const int32_t fs = sub_base[ks] + (int32_t)(std::lower_bound(col[ks].begin(), col[ks].end(), j) - col[ks].begin());
+        s->diag_fuse.push_back(fs);
+        s->sub_pub[fs] = (int32_t)(s->diag_info.size() / 4) - 1;
+      } else s->diag_fuse.push_back(-1);
+      sub_base[j] = (int32_t)(s->sub_info.size() / 4);
       s->back_info.push_back(slot_base[j]); s->back_info.push_back(perm[j]);
       for (auto it = col[j].rbegin(); it != col[j].rend(); ++it) { s->back_list.push_back(slot_of(*it, j)); s->back_list.push_back(perm[*it]); }   // bottom-up: the order the y_i arrive in
       s->back_ptr.push_back((int32_t)(s->back_list.size() / 2));
       for (int32_t i : col[j]) {
-        s->sub_info.push_back(slot_of(i, j)); s->sub_info.push_back(slot_base[j]); s->sub_col.push_back(perm[j]);
+        s->sub_info.push_back(slot_of(i, j)); s->sub_info.push_back(slot_base[j]); s->sub_col.push_back(perm[j]); s->sub_pub.push_back(-1);
         const int32_t sp0 = (int32_t)(s->sub_list.size() / 2);
         // k in row[j] with tile (i,k) present
         klev.clear();
@@ -636,6 +655,9 @@ int32_t build_solver(rsba_handle* h) {
   if ((rc = s_upload(s, &s->d_sub_list, s->sub_list))) return rc;
   if ((rc = s_upload(s, &s->d_sub_col, s->sub_col))) return rc;
   if ((rc = s_upload(s, &s->d_diag_own, s->diag_own))) return rc;
+  if ((rc = s_upload(s, &s->d_diag_fuse, s->diag_fuse))) return rc;
+  if ((rc = s_upload(s, &s->d_sub_pub, s->sub_pub))) return rc;
+  if ((rc = s_alloc(s, &sv.Xpub, (size_t)nt * kTile * kTile))) return rc;
   if ((rc = s_upload(s, &s->d_sub_own, s->sub_own))) return rc;
   if ((rc = s_alloc(s, &sv.Winv, (size_t)nt * kTile * kTile))) return rc;
   if ((rc = s_upload(s, &s->d_back_info, s->back_info))) return rc;
@@ -715,6 +737,7 @@ int32_t build_solver(rsba_handle* h) {
   CholPlan& pl = s->plan;
   pl.upd = s->d_upd; pl.diag_info = s->d_diag_info; pl.diag_ptr = s->d_diag_ptr; pl.diag_list = s->d_diag_list;
   pl.sub_info = s->d_sub_info; pl.sub_ptr = s->d_sub_ptr; pl.sub_list = s->d_sub_list; pl.sub_col = s->d_sub_col; pl.diag_own = s->d_diag_own; pl.sub_own = s->d_sub_own;
+  pl.diag_fuse = s->d_diag_fuse; pl.sub_pub = s->d_sub_pub;
   pl.back_info = s->d_back_info; pl.back_ptr = s->d_back_ptr; pl.back_list = s->d_back_list;
   pl.tasks = s->d_tasks; pl.ntasks = (int)(s->tasks.size() / 2);
   pl.ticket = s->d_dag_sync;

@@ -84,6 +84,7 @@ struct SolverDev {
   double* yv;                   // [npad] the camera step y (copied to rhs when the solve is done)
   double* Winv;                 // [nt][kTile][kTile] inverses of the factored diagonal tiles (by tile index)
   double* chol_part;            // [all chunks][kTile*kTile + kTile] partial update tiles (+ rhs partials)
+  double* Xpub;                 // [nt][kTile][kTile] by DIAG item: tile (j, k*) less its updates, published by its SUB task for the DIAG task of column j
   double* rhs;                  // [npad] directly behind S (one exchange buffer) -> z (forward) -> y_c (backward)
   double* udiag;                // [F*CD] diag(U), global after the exchange
   double* xbuf;                 // [2*F*CD + 3] exchange buffer: g_c | diag(U) | cost, fixed cost, failed blocks
@@ -111,6 +112,8 @@ inline hipError_t allow_dynamic_lds(K kernel, size_t bytes) { return allow_dynam
 // Cholesky task plan (cholesky.hip): flattened work lists of the symbolic phase, device pointers
 struct CholPlan {
   const int32_t *upd, *diag_info, *diag_ptr, *diag_list, *sub_info, *sub_ptr, *sub_list, *sub_col, *diag_own, *sub_own, *back_info, *back_ptr, *back_list;
+  const int32_t* diag_fuse;  // per DIAG item: the SUB item of its last contributor, whose product with W the DIAG task forms itself (-1: none)
+  const int32_t* sub_pub;    // per SUB item: DIAG item that takes its X = S_ij - updates from sv.Xpub (-1: nobody)
   const int32_t* tasks;      // [ntasks][2] {kind, item} in a topological order
   int ntasks;
   unsigned int* ticket;
