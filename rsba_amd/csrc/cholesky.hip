@@ -373,13 +373,18 @@ __shared__ long long* s_trace_slot;   // RSBA_CHOL_TRACE: where the running task
 // Cells move through agent-coherent accesses: relaxed agent-scope atomic loads / stores of the individual doubles,
 // which gfx950 issues with sc1 (the L2 of the other XCDs is not coherent with ours; sc1 accesses go to the memory
 // side), so neither side needs cache maintenance.  The level driver (DAG = false) uses plain loads and stores.
+// Every access to HBM below says so explicitly (address space 1).  The persistent kernel reads its pointers out of a device copy
+// of the plan, so the compiler cannot tell where they point: left alone it issues FLAT loads, which count on the LDS counter
+// (lgkmcnt) as well — and every LDS wait and LDS-only barrier of a task then also waits for the prefetches in flight.
+#define RSBA_GLOBAL __attribute__((address_space(1)))
+template <class V> __device__ __forceinline__ V gl(const V* p) { return *(const RSBA_GLOBAL V*)p; }
 template <bool DAG> __device__ __forceinline__ double ld(const double* p) {
-  if (DAG) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return *p;
+  if (DAG) return __hip_atomic_load((const RSBA_GLOBAL double*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return gl(p);
 }
 template <bool DAG> __device__ __forceinline__ void st(double* p, double v) {
-  if (DAG) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else *p = v;
+  if (DAG) __hip_atomic_store((RSBA_GLOBAL double*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *(RSBA_GLOBAL double*)p = v;
 }
 // Waiting costs memory traffic: a task that found a group of cells incomplete does not keep re-reading the whole group
 // (hundreds of claimed-but-waiting tasks doing that saturate the memory system) — it watches ONE cell of the
@@ -424,10 +429,10 @@ __device__ __forceinline__ void accumulate(const SolverDev& sv, const CholPlan& 
 #pragma unroll
     for (int u = 0; u < kGroup; ++u) {
       const int q = min(p + u, p1 - 1);
-      g.a[u].template load<DAG>(factor_ptr(sv, list[2 * q]), wave, lane);
-      if (!DIAG) g.b[u].template load<DAG>(factor_ptr(sv, list[2 * q + 1]), wave, lane);
+      g.a[u].template load<DAG>(factor_ptr(sv, gl(list + 2 * q)), wave, lane);
+      if (!DIAG) g.b[u].template load<DAG>(factor_ptr(sv, gl(list + 2 * q + 1)), wave, lane);
       else {
-        const double* zk = sv.zv + (size_t)list[2 * q + 1] * T + 12 * wave + 3 * (lane >> 4);
+        const double* zk = sv.zv + (size_t)gl(list + 2 * q + 1) * T + 12 * wave + 3 * (lane >> 4);
         g.z[u][0] = ld<DAG>(zk); g.z[u][1] = ld<DAG>(zk + 1); g.z[u][2] = ld<DAG>(zk + 2);
       }
     }
@@ -469,8 +474,8 @@ __device__ __forceinline__ void accumulate(const SolverDev& sv, const CholPlan& 
       while (!complete(cur)) {
         // the list is in the order the contributors finish: watch the last one of the group
         const int q = min(p + kGroup, p1) - 1;
-        watch_cell<DAG>(factor_ptr(sv, list[2 * q]) + 12 * wave);
-        if (!DIAG) watch_cell<DAG>(factor_ptr(sv, list[2 * q + 1]) + 12 * wave);
+        watch_cell<DAG>(factor_ptr(sv, gl(list + 2 * q)) + 12 * wave);
+        if (!DIAG) watch_cell<DAG>(factor_ptr(sv, gl(list + 2 * q + 1)) + 12 * wave);
         fetch_group(cur, p);
         late = true;
       }
@@ -496,16 +501,17 @@ template <bool DAG>
 __device__ __forceinline__ void task_update(const SolverDev& sv, const CholPlan& pl, int item, double* smem, int tid) {
   const int wave = tid >> 6, lane = tid & 63;
   const int32_t* u = pl.upd + 4 * item;
-  const bool diag = u[0] == 0;
+  const int u0 = gl(u), u1 = gl(u + 1), u2 = gl(u + 2), u3 = gl(u + 3);
+  const bool diag = u0 == 0;
   Acc acc; acc.clear();
   double bz[3] = {0, 0, 0};
-  if (diag) accumulate<DAG, true>(sv, pl, pl.diag_list, u[1], u[2], acc, bz, wave, lane);
-  else accumulate<DAG, false>(sv, pl, pl.sub_list, u[1], u[2], acc, bz, wave, lane);
+  if (diag) accumulate<DAG, true>(sv, pl, pl.diag_list, u1, u2, acc, bz, wave, lane);
+  else accumulate<DAG, false>(sv, pl, pl.sub_list, u1, u2, acc, bz, wave, lane);
   CHOL_STAMP(3);
   acc.spill(smem + wave * kBuf, lane);
   if (diag) spill_bz(bz, smem + kVecOff + wave * T, lane);
   lds_barrier();
-  double* out = sv.chol_part + (size_t)u[3] * (T * T + T);
+  double* out = sv.chol_part + (size_t)u3 * (T * T + T);
   for (int e = tid; e < T * T; e += 256) {
     const int o = (e / T) * TP + e % T;
     st<DAG>(out + e, (smem[o] + smem[kBuf + o]) + (smem[2 * kBuf + o] + smem[3 * kBuf + o]));
@@ -688,11 +694,11 @@ template <bool DAG>
 __device__ __forceinline__ void task_diag(const SolverDev& sv, const CholPlan& pl, int b, double* smem, int tid) {
   const int wave = tid >> 6, lane = tid & 63;
   const int32_t* info = pl.diag_info + 4 * b;
-  const int slot_jj = info[0], tile_j = info[1], part0 = info[2], nparts = info[3];
+  const int slot_jj = gl(info), tile_j = gl(info + 1), part0 = gl(info + 2), nparts = gl(info + 3);
   // The last contributor k* (the column that finishes one level before this one) is formed HERE from W_k* instead of being
   // read back from the SUB task of tile (j, k*) (item fs).
-  const int fs = pl.diag_fuse[b];
-  const int p0 = pl.diag_own[b], p1 = pl.diag_ptr[b + 1] - (fs >= 0 ? 1 : 0);   // the owner's share of the contributor list
+  const int fs = gl(pl.diag_fuse + b);
+  const int p0 = gl(pl.diag_own + b), p1 = gl(pl.diag_ptr + b + 1) - (fs >= 0 ? 1 : 0);   // the owner's share of the contributor list
   double* XB = smem + kXOff; double* LB = XB + kBuf;
   // X = S_jk* - (older updates) comes from the SUB task of that tile, which publishes it before it starts waiting for W_k*:
   // requested here, looked at when it is needed
@@ -706,8 +712,8 @@ __device__ __forceinline__ void task_diag(const SolverDev& sv, const CholPlan& p
   double sreg[9];
   const double* src = tile_ptr(sv, slot_jj);
 #pragma unroll
-  for (int q = 0; q < 9; ++q) sreg[q] = src[tid + 256 * q];
-  double breg = tid < T ? sv.rhs[(size_t)tile_j * T + tid] : 0.0;
+  for (int q = 0; q < 9; ++q) sreg[q] = gl(src + tid + 256 * q);
+  double breg = tid < T ? gl(sv.rhs + (size_t)tile_j * T + tid) : 0.0;
   // the early part of a long contributor list arrives pre-reduced (UPDATE tasks), well before the owner's own share
   subtract_partials<DAG, true>(sv, part0, nparts, sreg, breg, tid);
   Acc acc; acc.clear();
@@ -716,7 +722,7 @@ __device__ __forceinline__ void task_diag(const SolverDev& sv, const CholPlan& p
   CHOL_STAMP(3);
   diag_assemble(sreg, breg, acc, bz, smem, tid);   // everything that does not need column k*: off the critical path
   if (fs >= 0) {
-    const int tile_k = pl.sub_col[fs];
+    const int tile_k = gl(pl.sub_col + fs);
     double* D = smem;
     double* vec = smem + kVecOff; double* bvec = vec + 4 * T; double* zs = vec + 7 * T;
     {
@@ -788,12 +794,12 @@ __device__ __forceinline__ void task_sub(const SolverDev& sv, const CholPlan& pl
   const int wave = tid >> 6, lane = tid & 63;
   double* X = smem;
   const int32_t* info = pl.sub_info + 4 * b;
-  const int slot_ij = info[0], slot_jj = info[1], part0 = info[2], nparts = info[3], tile_j = pl.sub_col[b];
-  const int p0 = pl.sub_own[b], p1 = pl.sub_ptr[b + 1];
+  const int slot_ij = gl(info), slot_jj = gl(info + 1), part0 = gl(info + 2), nparts = gl(info + 3), tile_j = gl(pl.sub_col + b);
+  const int p0 = gl(pl.sub_own + b), p1 = gl(pl.sub_ptr + b + 1);
   double sreg[9];
   const double* src = tile_ptr(sv, slot_ij);
 #pragma unroll
-  for (int q = 0; q < 9; ++q) sreg[q] = src[tid + 256 * q];
+  for (int q = 0; q < 9; ++q) sreg[q] = gl(src + tid + 256 * q);
   { double none = 0.0; subtract_partials<DAG, false>(sv, part0, nparts, sreg, none, tid); }
   Acc acc; acc.clear();
   double bz[3] = {0, 0, 0};
@@ -809,7 +815,7 @@ __device__ __forceinline__ void task_sub(const SolverDev& sv, const CholPlan& pl
   lds_barrier();
 #pragma unroll
   for (int q = 0; q < 9; ++q) { const int e = tid + 256 * q; X[(e / T) * TP + e % T] = sreg[q]; }
-  if (const int pub = pl.sub_pub[b]; pub >= 0) {   // the DIAG task of row i multiplies this by W_j itself (look-ahead on the critical path)
+  if (const int pub = gl(pl.sub_pub + b); pub >= 0) {   // the DIAG task of row i multiplies this by W_j itself (look-ahead on the critical path)
     double* xp = sv.Xpub + (size_t)pub * (T * T);
 #pragma unroll
     for (int q = 0; q < 9; ++q) st<DAG>(xp + tid + 256 * q, sreg[q]);
@@ -840,8 +846,8 @@ __device__ __forceinline__ void task_back(const SolverDev& sv, const CholPlan& p
   double* tvec = smem + 10 * T;   // [T]
   const int32_t* list = pl.back_list;
   const int c2 = tid % 24, rg = tid / 24;   // column pair, row group (rg < 10 for tid < 240)
-  const int tile_j = pl.back_info[2 * b + 1];
-  const int p0 = pl.back_ptr[b], p1 = pl.back_ptr[b + 1];
+  const int tile_j = gl(pl.back_info + 2 * b + 1);
+  const int p0 = gl(pl.back_ptr + b), p1 = gl(pl.back_ptr + b + 1);
   const bool worker = rg < 10;
   // rows of a 48 x 48 tile handled by this thread: rg, rg + 10, .. ; columns 2 c2, 2 c2 + 1 (threads without work
   // read nothing).  Whether the cells were all there is asked where the values are USED (gathered_ok), never next to
@@ -873,7 +879,7 @@ __device__ __forceinline__ void task_back(const SolverDev& sv, const CholPlan& p
     Group cur, nxt;
     auto fetch_group = [&](Group& g, int p) {
 #pragma unroll
-      for (int u = 0; u < kGroup; ++u) { const int q = min(p + u, p1 - 1); gather(factor_ptr(sv, list[2 * q]), sv.yv + (size_t)list[2 * q + 1] * T, g.v[u], g.yy[u], false); }
+      for (int u = 0; u < kGroup; ++u) { const int q = min(p + u, p1 - 1); gather(factor_ptr(sv, gl(list + 2 * q)), sv.yv + (size_t)gl(list + 2 * q + 1) * T, g.v[u], g.yy[u], false); }
     };
     auto group_ok = [&](const Group& g) {
       bool ok = true;
@@ -896,7 +902,7 @@ __device__ __forceinline__ void task_back(const SolverDev& sv, const CholPlan& p
       if (DAG) {
         bool late = false;
         while (!group_ok(cur)) {
-          watch_cell<DAG>(sv.yv + (size_t)list[2 * (min(p + kGroup, p1) - 1) + 1] * T);   // y of the last tile of the group
+          watch_cell<DAG>(sv.yv + (size_t)gl(list + 2 * (min(p + kGroup, p1) - 1) + 1) * T);   // y of the last tile of the group
           fetch_group(cur, p);
           late = true;
         }
@@ -977,7 +983,7 @@ __global__ __launch_bounds__(256) void chol_dag_kernel(const DagArgs* __restrict
     // then stall on every prefetch in flight
     int task_tid = tid;
     asm volatile("" : "+v"(task_tid));
-    run_task<true>(args->sv, pl, pl.tasks[2 * t], pl.tasks[2 * t + 1], smem, task_tid);
+    run_task<true>(args->sv, pl, gl(pl.tasks + 2 * t), gl(pl.tasks + 2 * t + 1), smem, task_tid);
     if (tid == 0 && s_trace_slot) s_trace_slot[7] = wall_clock64();
   }
 }
