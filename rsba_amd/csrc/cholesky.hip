@@ -619,7 +619,7 @@ __device__ __forceinline__ void invert_lower_blocked(const double* L, const doub
 // L = X W_j^T for the tile X held in LDS (pitch TP): wave I < 3 forms row block I into c[J] (MFMA result layout: rows
 // 16I + (lane >> 4) + 4v, column 16J + (lane & 15)); W is lower triangular, so column block J only needs k < 16 (J + 1).
 // W_j comes from the DIAG task of column j: its cells are read until they are all there.
-template <bool DAG>
+template <bool DAG, bool EAGER = false>
 __device__ __forceinline__ void times_inverse_transposed(const SolverDev& sv, int tile_j, const double* X, dbl4 c[3], int wave, int lane) {
   const int I = wave, r = lane & 15, g = lane >> 4;
   const double* Wg = sv.Winv + (size_t)tile_j * (T * T);
@@ -634,10 +634,15 @@ __device__ __forceinline__ void times_inverse_transposed(const SolverDev& sv, in
         for (int kk = 0; kk < 4 * (J + 1); ++kk) { wv[J][kk] = ld<DAG>(Wg + (16 * J + r) * T + 4 * kk + g); ok = ok && filled(wv[J][kk]); }
       if (!DAG || __ballot(!ok) == 0ull) break;
       late = true;
-      watch_cell<DAG>(Wg + (T * T - 1));   // the corner of the inverse
+      // A SUB task watches one cell and reads again when it has landed (hundreds of them wait at a time).  A DIAG task is the
+      // next link of the critical chain and only a handful wait for their W at any moment: it reads everything again straight
+      // away — one memory round trip less per level of the elimination tree.
+      if (EAGER) __builtin_amdgcn_s_sleep(2);
+      else watch_cell<DAG>(Wg + (T * T - 1));   // the corner of the inverse
     }
     if (late) note_late_input();
   }
+  if (DAG && EAGER && threadIdx.x == 0 && s_trace_slot) s_trace_slot[5] = wall_clock64();   // trace: W_k* complete in registers
   c[0] = c[1] = c[2] = dbl4{0, 0, 0, 0};
 #pragma unroll
   for (int kk = 0; kk < 12; ++kk) {
@@ -745,7 +750,7 @@ __device__ __forceinline__ void task_diag(const SolverDev& sv, const CholPlan& p
     if (wave < 3) {
       const int r = lane & 15, g = lane >> 4;
       dbl4 c[3];
-      times_inverse_transposed<DAG>(sv, tile_k, XB, c, wave, lane);
+      times_inverse_transposed<DAG, true>(sv, tile_k, XB, c, wave, lane);
 #pragma unroll
       for (int J = 0; J < 3; ++J)
 #pragma unroll

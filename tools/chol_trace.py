@@ -46,3 +46,9 @@ bk = np.where(tasks[:, 0] == 3)[0]
 print("back completions (us), every 10th:", np.round(np.sort(us[bk, 2])[::10], 1))
 print("back: claimed->late input / late input->done for the last 12 finishing:", np.round(us[bk[np.argsort(us[bk, 2])][-12:], 1] - us[bk[np.argsort(us[bk, 2])][-12:], 0], 1), np.round(us[bk[np.argsort(us[bk, 2])][-12:], 2] - us[bk[np.argsort(us[bk, 2])][-12:], 1], 1))
 np.save("/tmp/chol_trace.npy", np.concatenate([tasks, us], axis=1))
+# the DIAG tasks in order of completion: gap to the previous completion and the task's own stamps relative to its completion
+print("last 40 DIAG tasks by completion: done(us)  gap  | relative to done: claimed  late-input  accumulate-end(3)  W-in-registers(5)  factor-start(4)  factor-end(6) | workgroup")
+for k in order[-40:]:
+    prev = ends[np.searchsorted(ends, us[k, 2]) - 1] if us[k, 2] > ends[0] else 0.0
+    rel = [us[k, 0] - us[k, 2], us[k, 1] - us[k, 2]] + [((tr[k, j] - tr[k, 1]) * 0.01 + us[k, 0] - us[k, 2]) if tr[k, j] > 0 else float('nan') for j in (3, 5, 4, 6)]
+    print(f"  {us[k, 2]:8.1f} {us[k, 2] - prev:6.1f} | " + " ".join(f"{x:8.1f}" for x in rel) + f" | {int(tr[k, 0])}")
