@@ -1,5 +1,6 @@
-// What one pivot of the MFMA-pivot LDL^T step (rsba_amd/csrc/cholesky.hip, ldl16_inverse) costs, piece by piece: one wave,
-// 16 pivots, variants with parts of the per-pivot work switched off.  Prints clock64 ticks and wall_clock64 (100 MHz) time
+// What one pivot of the MFMA-pivot LDL^T step (rsba_amd/csrc/cholesky.hip, ldl16_eliminate / ldl16_follow) costs, piece by piece:
+// one wave, 16 pivots, variants with parts of the per-pivot work switched off (fp64 MFMA and fp64 vector time add up), then the
+// step split over two waves that talk through LDS.  Prints clock64 ticks and wall_clock64 (100 MHz) time
 // per 16-pivot block.   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ldl_probe.hip -o tools/ldl_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
