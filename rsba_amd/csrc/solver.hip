@@ -402,7 +402,7 @@ int32_t build_solver(rsba_handle* h) {
   bool fuse_last = true;
   if (const char* e = std::getenv("RSBA_CHOL_FUSE")) fuse_last = e[0] != '0';
   std::vector<int32_t> sub_base(nt, 0);   // first SUB item of each column (items of a column follow col[] order)
-  int kChunk = 6, kTail = 4;
+  int kChunk = 12, kTail = 2;   // (swept on C4 / C5 after the look-ahead: fewer, longer UPDATE tasks and a short own share — 2.45 -> 2.36 ms per C4 iteration)
   if (const char* e = std::getenv("RSBA_CHOL_TAIL")) kTail = std::max(1, std::atoi(e));       // tuning aids
   if (const char* e = std::getenv("RSBA_CHOL_CHUNK")) kChunk = std::max(kTail, std::atoi(e));
   s->lev_diag_ptr.assign(1, 0); s->lev_sub_ptr.assign(1, 0); s->lev_upd_ptr.assign(1, 0);
