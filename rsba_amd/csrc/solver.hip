@@ -313,7 +313,8 @@ int32_t build_solver(rsba_handle* h) {
       lv.clear(); std::vector<int32_t> cur{root}; std::vector<uint8_t> seen(nt, 0); seen[root] = 1;
       while (!cur.empty()) { lv.push_back(cur); std::vector<int32_t> nxt; for (int u : cur) for (int v : adj[u]) if (tag[v] == mytag && !seen[v]) { seen[v] = 1; nxt.push_back(v); } std::sort(nxt.begin(), nxt.end()); cur.swap(nxt); }
     };
-    const int kLeaf = 24;
+    int kLeaf = 24;
+    if (const char* e = std::getenv("RSBA_CHOL_LEAF")) kLeaf = std::max(2, std::atoi(e));   // tuning aid
     std::function<void(std::vector<int32_t>)> nd = [&](std::vector<int32_t> nodes) {
       if (nodes.empty()) return;
       const int mytag = ++tagc;
