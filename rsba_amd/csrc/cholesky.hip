@@ -125,10 +125,16 @@ __device__ __forceinline__ bool potrf_blocked(double* A, int tid) {
 // LDS map (doubles): four partial-tile buffers, then small vectors
 constexpr int kBuf = T * TP;
 constexpr int kVecOff = 4 * kBuf;            // [4][T] per-wave rhs partials, [T] b, [T] unused, [T] unused, [T] z of the last contributor
-constexpr int kXOff = kVecOff + 8 * T;       // two more tiles for a DIAG task that forms its last contributor itself: X, then L = X W^T
-constexpr int kMsg = 64;                     // one pivot's message between the two waves of the tile factorisation: a double per lane
-constexpr int kMsgOff = kXOff + 2 * kBuf;    // [3 diagonal blocks][16 pivots][kMsg]
-constexpr int kCholLds = kMsgOff + 3 * 16 * kMsg;
+constexpr int kCholLds = kVecOff + 8 * T;    // 78 KB: two workgroups fit a CU
+// Nothing else is allocated: what a DIAG task needs beyond the four tile buffers lives in parts of them that are idle at the time —
+//   X (tile (j, k*) less its updates) in buffer 1 and L = X W^T in buffer 3 while the last contributor is applied (the
+//   factorisation, which uses buffers 1 .. 3 as W, T and L-panel scratch, has not started), and
+//   the pivot messages between the two waves of the tile factorisation in rows 0 .. 15 of buffers 2 and 3, which the
+//   factorisation never touches (its scratch blocks sit in rows 16 .. 47): pivots 0 .. 7 in buffer 2, 8 .. 15 in buffer 3.
+constexpr int kXBuf = 1 * kBuf, kLBuf = 3 * kBuf;
+constexpr int kMsg = 64;                     // one pivot's message: a double per lane
+__device__ __forceinline__ constexpr int msg_off(int jj) { return (jj < 8 ? 2 * kBuf : 3 * kBuf) + (jj & 7) * kMsg; }
+static_assert(8 * kMsg <= 16 * TP, "the messages of eight pivots must fit the sixteen idle rows of a scratch tile");
 
 // "empty" bit pattern of the write-once cells (below) — also of the pivot messages in LDS
 __device__ __forceinline__ bool filled(double v) { return __double_as_longlong(v) != -1ll; }
@@ -158,7 +164,11 @@ __device__ __forceinline__ double rcp_nr(double x) {
 // ends up with the inverse a few hundred cycles after the last pivot.  The messages must be armed (armed = empty pattern)
 // before the workgroup barrier that precedes the step.
 __device__ __forceinline__ void arm_pivot_messages(double* smem, int tid) {
-  for (int e = tid; e < 3 * 16 * kMsg; e += 256) smem[kMsgOff + e] = __longlong_as_double(-1ll);
+  for (int e = tid; e < 16 * kMsg; e += 256) smem[msg_off(e / kMsg) + e % kMsg] = __longlong_as_double(-1ll);
+}
+// one wave re-arms the messages of pivots [j0, j1) (between two diagonal blocks, while it has nothing else to do)
+__device__ __forceinline__ void rearm_pivot_messages(double* smem, int lane, int j0, int j1) {
+  for (int jj = j0; jj < j1; ++jj) smem[msg_off(jj) + lane] = __longlong_as_double(-1ll);
 }
 // first wave: d = symmetric positive definite 16 x 16 block, accumulator layout.  false on a non-positive / non-finite pivot.
 __device__ __forceinline__ bool ldl16_eliminate(dbl4_t d, double* msg, int lane) {
@@ -179,7 +189,7 @@ __device__ __forceinline__ bool ldl16_eliminate(dbl4_t d, double* msg, int lane)
     const double q = fma(t, fma(e, e, e), t);
     const double row = grp ? dv : 0.0;                  // B: row jj of D   (k = gg slice, zero elsewhere)
     const double mul = (grp && c > jj) ? -q : 0.0;      // A: -D[jj][i] / d for the rows i below the pivot
-    lm[jj * kMsg + lane] = (grp && c == jj) ? dv : mul;  // the message: the multipliers, with the pivot itself in the (otherwise zero) lane of the diagonal
+    lm[msg_off(jj) + lane] = (grp && c == jj) ? dv : mul;  // the message: the multipliers, with the pivot itself in the (otherwise zero) lane of the diagonal
     if (jj < 15) d = __builtin_amdgcn_mfma_f64_16x16x4f64(mul, row, d, 0, 0, 0);
   }
   return ok;
@@ -193,16 +203,16 @@ __device__ __forceinline__ dbl4_t ldl16_follow(const double* msg, int lane, long
 #pragma unroll
   for (int v = 0; v < 4; ++v) w[v] = (g + 4 * v == c) ? 1.0 : 0.0;
   double pv[4] = {1.0, 1.0, 1.0, 1.0};   // the pivots of this lane's four rows
-  double next = vm[lane];
+  double next = vm[msg_off(0) + lane];
 #pragma unroll
   for (int jj = 0; jj < 16; ++jj) {
     const int gg = jj & 3, vv = jj >> 2;
     const bool grp = g == gg;
     double m = next;
-    while (__ballot(!filled(m)) != 0ull) m = vm[jj * kMsg + lane];
+    while (__ballot(!filled(m)) != 0ull) m = vm[msg_off(jj) + lane];
     // the next message is requested BEFORE this pivot's MFMA and looked at after it (a speculative read: what is not there yet
     // is read again above) — the LDS round trip would otherwise sit between every two MFMAs of this wave
-    if (jj < 15) next = vm[(jj + 1) * kMsg + lane];
+    if (jj < 15) next = vm[msg_off(jj < 15 ? jj + 1 : 15) + lane];
     __builtin_amdgcn_sched_barrier(0);
     const double piv = readlane_f64(m, 16 * gg + jj);
     const double mul = (grp && c == jj) ? 0.0 : m;
@@ -255,8 +265,8 @@ __device__ __forceinline__ dbl4_t mm16_nn(const double* X, int xr, int xc, const
 // chain), the others keep the off-diagonal algebra out of their way:
 //   L_I0 = D_I0 W_00^T ;  D_11 -= L_10 L_10^T, D_21 -= L_20 L_10^T, D_22 -= L_20 L_20^T ;  L_21 = D_21 W_11^T ;  D_22 -= L_21 L_21^T
 //   W_10 = -W_11 (L_10 W_00),  W_21 = -W_22 (L_21 W_11),  W_20 = -W_22 (L_20 W_00 + L_21 W_10).
-// Tm and Lp are scratch tiles; D must be the task's first LDS buffer and the pivot messages armed (arm_pivot_messages)
-// before the barrier in front of this call.  All threads must call; ends with a barrier.  Returns (in the first wave)
+// D, Wl, Tm, Lp must be the task's LDS buffers 0 .. 3 (the pivot messages live in idle rows of Tm and Lp, see the LDS map) and the
+// messages armed (arm_pivot_messages) before the barrier in front of this call.  All threads must call; ends with a barrier.  Returns (in the first wave)
 // false on a non-positive pivot.
 template <bool TRACE = false>
 __device__ __forceinline__ bool factor_invert_tile(double* D, double* Wl, double* Tm, double* Lp, int tid, long long* stamps = nullptr) {
@@ -265,15 +275,16 @@ __device__ __forceinline__ bool factor_invert_tile(double* D, double* Wl, double
   bool ok = true;
   int nstamp = 0;
   auto stamp = [&]() { if (TRACE && tid == 0) stamps[nstamp++] = clock64(); };   // tools/tile_factor_bench.hip
-  double* msg = D + kMsgOff;   // (D is the first LDS buffer of the task)
+  double* msg = D;   // (D is the first LDS buffer of the task; the messages sit at msg_off() behind it)
   stamp();
   if (wave == 0) ok = ldl16_eliminate(load_sym16(D, 0, lane), msg, lane);
   else if (wave == 1) put16(Wl, 0, 0, ldl16_follow(msg, lane, TRACE ? stamps + 16 : nullptr), lane);
   stamp(); lds_barrier(); stamp();
   if (wave < 2) put16(Lp, 16 + 16 * wave, 0, mm16_nt(D, 16 + 16 * wave, 0, Wl, 0, 0, zero, 1.0, lane), lane);   // L_10, L_20
+  else rearm_pivot_messages(D, lane, 8 * (wave - 2), 8 * (wave - 1));   // (both waves of block 0 are done with them; block 1 starts behind the next barrier)
   stamp(); lds_barrier(); stamp();
-  if (wave == 0) ok = ldl16_eliminate(mm16_nt(Lp, 16, 0, Lp, 16, 0, load_sym16(D, 16, lane), -1.0, lane), msg + 16 * kMsg, lane) && ok;
-  else if (wave == 1) put16(Wl, 16, 16, ldl16_follow(msg + 16 * kMsg, lane), lane);
+  if (wave == 0) ok = ldl16_eliminate(mm16_nt(Lp, 16, 0, Lp, 16, 0, load_sym16(D, 16, lane), -1.0, lane), msg, lane) && ok;
+  else if (wave == 1) put16(Wl, 16, 16, ldl16_follow(msg, lane), lane);
   else if (wave == 2) {
     put16(D, 32, 16, mm16_nt(Lp, 32, 0, Lp, 16, 0, load16(D, 32, 16, lane), -1.0, lane), lane);
     put16(Tm, 16, 0, mm16_nn(Lp, 16, 0, Wl, 0, 0, zero, 1.0, lane), lane);                                         // T_10 = L_10 W_00
@@ -282,9 +293,10 @@ __device__ __forceinline__ bool factor_invert_tile(double* D, double* Wl, double
   if (wave == 0) put16(Lp, 32, 16, mm16_nt(D, 32, 16, Wl, 16, 16, zero, 1.0, lane), lane);       // L_21
   else if (wave == 1) put16(Wl, 16, 0, mm16_nn(Wl, 16, 16, Tm, 16, 0, zero, -1.0, lane), lane);  // W_10
   else if (wave == 2) put16(Tm, 32, 0, mm16_nn(Lp, 32, 0, Wl, 0, 0, zero, 1.0, lane), lane);     // T_20 = L_20 W_00
+  else rearm_pivot_messages(D, lane, 0, 16);
   stamp(); lds_barrier(); stamp();
-  if (wave == 0) ok = ldl16_eliminate(mm16_nt(Lp, 32, 16, Lp, 32, 16, load_sym16(D, 32, lane), -1.0, lane), msg + 32 * kMsg, lane) && ok;
-  else if (wave == 1) put16(Wl, 32, 32, ldl16_follow(msg + 32 * kMsg, lane), lane);
+  if (wave == 0) ok = ldl16_eliminate(mm16_nt(Lp, 32, 16, Lp, 32, 16, load_sym16(D, 32, lane), -1.0, lane), msg, lane) && ok;
+  else if (wave == 1) put16(Wl, 32, 32, ldl16_follow(msg, lane), lane);
   else if (wave == 2) put16(Tm, 32, 16, mm16_nn(Lp, 32, 16, Wl, 16, 16, zero, 1.0, lane), lane);                    // T_21 = L_21 W_11
   else put16(Tm, 32, 0, mm16_nn(Lp, 32, 16, Wl, 16, 0, load16(Tm, 32, 0, lane), 1.0, lane), lane);                  // T_20 += L_21 W_10
   stamp(); lds_barrier(); stamp();
@@ -422,7 +434,7 @@ __device__ __forceinline__ void accumulate(const SolverDev& sv, const CholPlan& 
   // re-reads its last contributor rather than branch).  The prefetch is speculative — a tile that has not been
   // produced yet reads as empty cells — and a group is checked when it is about to be multiplied: a wave whose
   // share of it is incomplete reads it again until it is.
-  constexpr int kGroup = 2;
+  constexpr int kGroup = 1;   // (one contributor ahead: with two, the operand registers push the persistent kernel past 256 per lane and a CU holds one workgroup instead of two)
   struct Group { Frag a[kGroup], b[kGroup]; double z[kGroup][3]; };
   Group cur, nxt;
   auto fetch_group = [&](Group& g, int p) {
@@ -661,7 +673,6 @@ __device__ __forceinline__ void diag_assemble(double sreg[9], double breg, Acc& 
   double* vec = smem + kVecOff; double* bvec = vec + 4 * T;
   acc.spill(smem + wave * kBuf, lane);
   spill_bz(bz, vec + wave * T, lane);
-  arm_pivot_messages(smem, tid);
   lds_barrier();
 #pragma unroll
   for (int q = 0; q < 9; ++q) {
@@ -680,6 +691,8 @@ template <bool DAG>
 __device__ __forceinline__ void diag_factor(const SolverDev& sv, int tile_j, double* smem, int tid) {
   double* D = smem; double* Wl = smem + kBuf;
   double* vec = smem + kVecOff; double* bvec = vec + 4 * T;
+  arm_pivot_messages(smem, tid);   // (rows of buffers 2 and 3 that held X / L of the last contributor until the barrier in front of this call)
+  lds_barrier();
   CHOL_STAMP(4);
   // L_jj itself is never formed: everything downstream uses W_j
   const bool ok = factor_invert_tile(D, Wl, smem + 2 * kBuf, smem + 3 * kBuf, tid);
@@ -704,7 +717,7 @@ __device__ __forceinline__ void task_diag(const SolverDev& sv, const CholPlan& p
   // read back from the SUB task of tile (j, k*) (item fs).
   const int fs = gl(pl.diag_fuse + b);
   const int p0 = gl(pl.diag_own + b), p1 = gl(pl.diag_ptr + b + 1) - (fs >= 0 ? 1 : 0);   // the owner's share of the contributor list
-  double* XB = smem + kXOff; double* LB = XB + kBuf;
+  double* XB = smem + kXBuf; double* LB = smem + kLBuf;
   // X = S_jk* - (older updates) comes from the SUB task of that tile, which publishes it before it starts waiting for W_k*:
   // requested here, looked at when it is needed
   double xreg[9];
@@ -879,7 +892,7 @@ __device__ __forceinline__ void task_back(const SolverDev& sv, const CholPlan& p
     // L_ij (forward phase) is long finished; y_i is what the task waits for.  The host lists the tiles of the
     // column bottom-up, the order in which the y_i become available; loads run one group of two tiles ahead and a
     // thread whose cells of a group are not all there yet reads the group again.
-    constexpr int kGroup = 2;
+    constexpr int kGroup = 1;
     struct Group { double2 v[kGroup][5]; double yy[kGroup][5]; };
     Group cur, nxt;
     auto fetch_group = [&](Group& g, int p) {
@@ -967,7 +980,7 @@ __global__ __launch_bounds__(256) void chol_level_kernel(const SolverDev sv, con
 }
 
 // the whole factorisation + both triangular solves in one persistent launch
-__global__ __launch_bounds__(256) void chol_dag_kernel(const DagArgs* __restrict__ args) {
+__global__ __launch_bounds__(256, 2) void chol_dag_kernel(const DagArgs* __restrict__ args) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   __shared__ int s_ticket;
   const int tid = threadIdx.x;

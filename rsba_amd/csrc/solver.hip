@@ -745,7 +745,12 @@ int32_t build_solver(rsba_handle* h) {
   pl.nslots = sv.nslots; pl.nparts = parts;
   int cus = 0;
   HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
-  s->dag_workgroups = std::max(1, std::min(pl.ntasks, std::max(cus, 1)));   // one 4-wave workgroup per CU (register budget)
+  // One persistent workgroup per CU.  Claimed tasks that wait for their inputs hold a workgroup and the schedule is short of them
+  // (192 instead of 256 workgroups cost 5 % at C4), and the kernel is built so that two fit a CU (78 KB of LDS, <= 256
+  // registers per lane) — but with 384 or 512 resident workgroups the solve slows down by three orders of magnitude (waves
+  // that poll share a SIMD with the waves they wait for); RSBA_CHOL_WGS is there to experiment with, capped at two per CU.
+  s->dag_workgroups = std::max(1, std::min(pl.ntasks, std::max(cus, 1)));
+  if (const char* e = std::getenv("RSBA_CHOL_WGS")) s->dag_workgroups = std::max(1, std::min(std::min(pl.ntasks, 2 * std::max(cus, 1)), std::atoi(e)));
   if (std::getenv("RSBA_CHOL_TRACE")) {
     if ((rc = s_alloc(s, &s->d_trace, 8 * (size_t)pl.ntasks))) return rc;
     HIP_TRY(hipMemset(s->d_trace, 0, 8 * (size_t)pl.ntasks * sizeof(long long)));

@@ -48,7 +48,7 @@ template <int MODE, int FW>
 __global__ __launch_bounds__(256) void pair_kernel(const double* __restrict__ Din, double* __restrict__ out, long long* t, int reps) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  double* D = smem; double* msg = smem + kMsgOff;
+  double* D = smem; double* msg = smem;
   for (int e = tid; e < T * T; e += 256) { const int r = e / T, c = e % T; D[r * TP + c] = (c <= r) ? Din[e] : 0.0; }
   __syncthreads();
   const dbl4_t d0 = load_sym16(D, 0, lane);
