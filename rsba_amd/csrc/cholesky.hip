@@ -53,6 +53,8 @@ __device__ __forceinline__ void lds_barrier() {
 constexpr int NB = 16;   // panel width of the tile factorisation: one MFMA block column
 typedef double dbl4_t __attribute__((ext_vector_type(4)));
 
+// (Round-1 form of the tile factorisation; the tasks now use factor_invert_tile below.  Kept as the baseline that
+// tools/tile_factor_bench.hip times and checks it against.)
 // Factor the T x T tile held in LDS (lower triangle, pitch TP) in place: blocked right-looking Cholesky.
 // Each 16-column panel is factored by the first wave entirely in registers (lane = row, pivot rows
 // broadcast with v_readlane, 1/sqrt instead of sqrt + divide: no LDS round trips or barriers on the
@@ -570,6 +572,7 @@ __device__ __forceinline__ void subtract_partials(const SolverDev& sv, int part0
   }
 }
 
+// (Round-1 form, see potrf_blocked: only tools/tile_factor_bench.hip calls it.)
 // W = L^-1 for the factored lower-triangular tile L in LDS (pitch TP), into Wl (pitch TP; blocks above the
 // diagonal left untouched), by 16 x 16 blocks over all 256 threads — thread (r, c) = (tid >> 4, tid & 15) owns
 // element (r, c) of every block:
