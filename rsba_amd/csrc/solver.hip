@@ -14,6 +14,7 @@
 #include <functional>
 #include <limits>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -198,7 +199,6 @@ int32_t build_solver(rsba_handle* h) {
     for (int64_t x = point_ptr[j]; x < point_ptr[j + 1]; ++x) out.push_back(x);
     for (int64_t g = vgroup_ptr[j]; g < vgroup_ptr[j + 1]; ++g) for (int v = 0; v < NPF; ++v) out.push_back(N + g * NPF + v);
   };
-  std::vector<int64_t> pslots;
   tick("slots");
   // ---- work list of the point elimination: one ENTRY per (point, pair of frame tiles I >= J) ----
   // An entry lists the point's observation slot in each of the FT frames of tile I (sa) and of tile J (sb),
@@ -211,6 +211,7 @@ int32_t build_solver(rsba_handle* h) {
   std::vector<int64_t> pt_group(M + 1, 0);     // groups of point j: [pt_group[j], pt_group[j+1])
   std::vector<int32_t> g_tile, g_rows;          // tile of each group; FT slots per group (NS = not observed)
   g_tile.reserve((size_t)N / 2); g_rows.reserve((size_t)N * 2);
+  std::vector<int64_t> pslots;
   for (int j = 0; j < M; ++j) {
     slots_of(j, pslots);
     int prev_frame = -1, layer = 0, cur_tile = -1;
@@ -262,6 +263,28 @@ int32_t build_solver(rsba_handle* h) {
       xa = xb;
     }
   };
+  // The two passes over all (point, tile pair) entries — count, then fill — are most of the symbolic phase (2 M entries at 1k cameras):
+  // with dense keys they run on a few host threads over contiguous point ranges, each with its own counters per tile pair, and
+  // the fill starts every thread where the threads before it end: the entry lists come out exactly as from one thread.
+  const int nthreads = dense_keys && M >= 4096 ? (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())) : 1;
+  std::vector<std::vector<int32_t>> thread_cnt(nthreads > 1 ? nthreads : 0);
+  auto point_range = [&](int t) { return std::pair<int, int>((int)((int64_t)M * t / nthreads), (int)((int64_t)M * (t + 1) / nthreads)); };
+  if (nthreads > 1) {
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nthreads; ++t)
+      pool.emplace_back([&, t]() {
+        std::vector<int32_t>& c = thread_cnt[t];
+        c.assign((size_t)nt * nt, 0);
+        const auto r = point_range(t);
+        for (int j = r.first; j < r.second; ++j) for_each_entry(j, [&](int64_t gx, int64_t gy) { ++c[(size_t)g_tile[gx] * nt + g_tile[gy]]; });
+      });
+    for (auto& th : pool) th.join();
+    for (size_t key = 0; key < (size_t)nt * nt; ++key) {
+      int64_t sum = 0;
+      for (int t = 0; t < nthreads; ++t) sum += thread_cnt[t][key];
+      if (sum > 0) { int64_t& c = dense_cnt[key]; c = (c < 0 ? 0 : c) + sum; }
+    }
+  } else
   for (int j = 0; j < M; ++j) for_each_entry(j, [&](int64_t gx, int64_t gy) { bump(g_tile[gx], g_tile[gy], 1); });
   std::vector<int32_t> tp_I, tp_J; std::vector<int64_t> tp_ptr(1, 0);
   std::unordered_map<int64_t, int32_t> tp_index; std::vector<int32_t> dense_index;
@@ -284,6 +307,28 @@ int32_t build_solver(rsba_handle* h) {
   std::vector<int32_t> ent_groups((size_t)nent * 2), ent_pt(nent);
   {
     std::vector<int64_t> fill(tp_ptr.begin(), tp_ptr.end() - 1);
+    if (nthreads > 1) {
+      // per thread and tile pair: where its entries start (the counters become cursors)
+      std::vector<std::vector<int64_t>> cursor(nthreads, std::vector<int64_t>(tp_I.size(), 0));
+      for (size_t t_ = 0; t_ < tp_I.size(); ++t_) {
+        const size_t key = (size_t)tp_I[t_] * nt + tp_J[t_];
+        int64_t at = fill[t_];
+        for (int t = 0; t < nthreads; ++t) { cursor[t][t_] = at; at += thread_cnt[t][key]; }
+      }
+      std::vector<std::thread> pool;
+      for (int t = 0; t < nthreads; ++t)
+        pool.emplace_back([&, t]() {
+          std::vector<int64_t>& cur = cursor[t];
+          const auto r = point_range(t);
+          for (int j = r.first; j < r.second; ++j)
+            for_each_entry(j, [&](int64_t gx, int64_t gy) {
+              const int64_t w = cur[dense_index[(size_t)g_tile[gx] * nt + g_tile[gy]]]++;
+              ent_groups[2 * (size_t)w] = (int32_t)gx; ent_groups[2 * (size_t)w + 1] = (int32_t)gy;
+              ent_pt[w] = j | (gx == gy ? (int32_t)0x80000000 : 0);
+            });
+        });
+      for (auto& th : pool) th.join();
+    } else
     for (int j = 0; j < M; ++j)
       for_each_entry(j, [&](int64_t gx, int64_t gy) {
         const int64_t w = fill[index_of(g_tile[gx], g_tile[gy])]++;
