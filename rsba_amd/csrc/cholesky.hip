@@ -653,7 +653,7 @@ __device__ __forceinline__ void times_inverse_transposed(const SolverDev& sv, in
       // next link of the critical chain and only a handful wait for their W at any moment: it reads everything again straight
       // away — one memory round trip less per level of the elimination tree.
       if (EAGER) __builtin_amdgcn_s_sleep(2);
-      else watch_cell<DAG>(Wg + (T * T - 1));   // the corner of the inverse
+      else watch_cell<DAG>(Wg + (T * T - 1) - T * (blockIdx.x & 15));   // the last cell of one of the last sixteen rows (all of them land with the last stores): the SUB tasks of a column spread over sixteen cache lines instead of all polling the one the producer is about to write
     }
     if (late) note_late_input();
   }
