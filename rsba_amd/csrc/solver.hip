@@ -266,7 +266,7 @@ int32_t build_solver(rsba_handle* h) {
   // The two passes over all (point, tile pair) entries — count, then fill — are most of the symbolic phase (2 M entries at 1k cameras):
   // with dense keys they run on a few host threads over contiguous point ranges, each with its own counters per tile pair, and
   // the fill starts every thread where the threads before it end: the entry lists come out exactly as from one thread.
-  const int nthreads = dense_keys && M >= 4096 ? (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())) : 1;
+  const int nthreads = dense_keys && (int64_t)nt * nt <= ((int64_t)1 << 22) && M >= 4096 ? (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())) : 1;   // (per-thread counters: 4 nt^2 bytes each)
   std::vector<std::vector<int32_t>> thread_cnt(nthreads > 1 ? nthreads : 0);
   auto point_range = [&](int t) { return std::pair<int, int>((int)((int64_t)M * t / nthreads), (int)((int64_t)M * (t + 1) / nthreads)); };
   if (nthreads > 1) {
