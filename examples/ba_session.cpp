@@ -60,7 +60,7 @@ static int replay_cache(int argc, char** argv) {
 
 int main(int argc, char** argv) {
   if (argc >= 4 && !std::strcmp(argv[1], "--cache")) return replay_cache(argc, argv);
-  if (argc < 3) { std::fprintf(stderr, "usage: %s scene.bin out.bin [startFrame] [camEvery]\n", argv[0]); return 2; }
+  if (argc < 3) { std::fprintf(stderr, "usage: %s scene.bin out.bin [startFrame] [camEvery] [BA|fullBA|windowedBA] [validTracks] [useOnlyValidMatches]\n", argv[0]); return 2; }
   FILE* f = std::fopen(argv[1], "rb");
   if (!f) { std::perror("scene"); return 2; }
   int32_t hd[11]; int64_t N; double huber, reval, covf, motion[3], cam[9];
@@ -99,7 +99,15 @@ int main(int argc, char** argv) {
   const int camEvery = argc > 4 ? std::atoi(argv[4]) : 0;              // > 0: every camEvery-th frame carries its own Frame.cam (sfm.thrift:48),
   for (int i = 0; camEvery > 0 && i < F; ++i)                          // which CeresHandler::Add uses as that frame's intrinsics block (:260,277)
     if (i % camEvery == camEvery - 1) { sess.frames[i].cam = sess.cam; sess.frames[i].__isset.cam = true; }
-  const bool usable = BA(sess, startFrame, F - 1, opt, hd[10], &summary, true, &covs);
+  // entry point (default BA): "fullBA" / "windowedBA" run the callers of VideoSfMHandler.cc:153-214 with their option rules;
+  // validTracks >= 0 marks only the first validTracks tracks valid (the < 100 valid tracks rule)
+  const char* entry = argc > 5 ? argv[5] : "BA";
+  const int validTracks = argc > 6 ? std::atoi(argv[6]) : -1;
+  for (int j = 0; validTracks >= 0 && j < M; ++j) sess.tracks[j].valid = j < validTracks;
+  if (argc > 7) opt.ceres.useOnlyValidMatches = std::atoi(argv[7]) != 0;
+  const bool usable = !std::strcmp(entry, "fullBA")       ? fullBA(sess, opt, hd[10], &summary, true, &covs)
+                      : !std::strcmp(entry, "windowedBA") ? windowedBA(sess, opt, startFrame, F - 1, hd[10], &summary, true, &covs)
+                                                          : BA(sess, startFrame, F - 1, opt, hd[10], &summary, true, &covs);
 
   return write_result(argv[2], sess, summary, usable, covs, covf);
 }

@@ -198,8 +198,10 @@ class CeresHandler {
       options->minimizer_progress_to_stdout = true;
       options->max_num_iterations = 50;
     }
-    const unsigned n = std::thread::hardware_concurrency();   // :408-415 (the device path ignores host threads)
+#ifdef NDEBUG   // :408-415: all hardware threads in Release builds only (the device path ignores host threads either way)
+    const unsigned n = std::thread::hardware_concurrency();
     if (n > 0) options->num_linear_solver_threads = options->num_threads = (int)n;
+#endif
     ceres::Solver::Summary summary;
     ceres::Solve(*options, &problem, &summary);
     if (opt.ceres.constFrameVelocity != 0 || opt.ceres.constFrameAcceleration != 0)   // :421-423
@@ -253,6 +255,39 @@ inline bool BA(Session& sess, const int32_t startFrame, const int32_t endFrame, 
     std::cout << "average reprojection error: " << std::sqrt(summary.final_cost / summary.num_residual_blocks_reduced) << std::endl;
   if (out) *out = summary;
   return summary.IsSolutionUsable();
+}
+
+namespace detail {
+// VideoSfMHandler.cc:163-172 = :197-206: with fewer than 100 valid tracks in the whole session the valid-only filter is dropped
+inline void relax_valid_matches_rule(const Session& sess, SfmOptions& opt) {
+  if (!opt.ceres.useOnlyValidMatches) return;
+  size_t ntracks = 0;
+  for (const Track& t : sess.tracks) ntracks += t.valid ? 1 : 0;
+  if (ntracks >= 100) return;
+  opt.ceres.useOnlyValidMatches = false;
+  std::cout << "!!! Not enough valid matches: " << ntracks << " !!!" << std::endl;
+}
+}  // namespace detail
+
+// VideoSfMHandler::fullBA (VideoSfMHandler.cc:153-180) without the RPC arguments and the PLY dump: every frame of the session, the
+// options as configured except for the valid-matches rule above.  (`reproject` — createTracks after the solve — is the caller's.)
+inline bool fullBA(Session& sess, const SfmOptions& options, const int32_t maxIter, ceres::Solver::Summary* out = nullptr, bool progress = true,
+                   std::vector<std::vector<double>>* covariances = nullptr) {
+  SfmOptions opt = options;
+  detail::relax_valid_matches_rule(sess, opt);
+  return BA(sess, 0, (int32_t)sess.frames.size() - 1, opt, maxIter, out, progress, covariances);
+}
+
+// VideoSfMHandler::windowedBA (VideoSfMHandler.cc:185-214): frames [startFrame, endFrame], the poses before the window stay as they
+// are; fixScale is switched off (:195 — the window is anchored by the frozen tracks) and the valid-matches rule counts the tracks of
+// the whole session, as the reference does (:199 "TODO check tracks within window?").
+inline bool windowedBA(Session& sess, const SfmOptions& options, const int32_t startFrame, const int32_t endFrame, const int32_t maxIter,
+                       ceres::Solver::Summary* out = nullptr, bool progress = true, std::vector<std::vector<double>>* covariances = nullptr) {
+  if (endFrame >= (int32_t)sess.frames.size()) throw std::out_of_range("windowedBA: endFrame");   // CHECK_LT (:192)
+  SfmOptions opt = options;
+  opt.ceres.fixScale = false;
+  detail::relax_valid_matches_rule(sess, opt);
+  return BA(sess, startFrame, endFrame, opt, maxIter, out, progress, covariances);
 }
 
 }  // namespace rsba_amd

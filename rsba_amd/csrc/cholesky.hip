@@ -1046,7 +1046,9 @@ __global__ __launch_bounds__(256) void chol_residual_kernel(const SolverDev sv, 
     atomicAdd(res + (size_t)tile_j * T + r, -st); atomicAdd(den + (size_t)tile_j * T + r, at);
   }
 }
-// flag = 1 when some |res_t| exceeds tol * den_t (NaN included) although no pivot failed; res / den are zeroed for the next solve
+// flag = 1 when some |res_t| exceeds tol * den_t (NaN included) although no pivot failed; res / den are zeroed for the next solve.
+// The flag is STICKY: a clean solve leaves it alone, so that several solves between two host reads (the free interFrameRatio's
+// second right-hand side, the columns of a covariance block) cannot mask each other; the host clears it before the first one.
 __global__ __launch_bounds__(1024) void chol_residual_check_kernel(const SolverDev sv, double* res, double* den, double tol, double* flag) {
   __shared__ int s_bad;
   if (threadIdx.x == 0) s_bad = 0;
@@ -1059,7 +1061,7 @@ __global__ __launch_bounds__(1024) void chol_residual_check_kernel(const SolverD
   }
   if (bad) s_bad = 1;
   __syncthreads();
-  if (threadIdx.x == 0) *flag = (s_bad && *sv.chol_fail == 0) ? 1.0 : 0.0;   // a failed pivot is reported through chol_fail, not here
+  if (threadIdx.x == 0 && s_bad && *sv.chol_fail == 0) *flag = 1.0;   // a failed pivot is reported through chol_fail, not here
 }
 
 }  // namespace
@@ -1078,9 +1080,14 @@ hipError_t launch_chol_level(const SolverDev& sv, const CholPlan& pl, int kind, 
   return hipGetLastError();
 }
 
-hipError_t launch_chol_dag(const SolverDev& sv, const CholPlan& pl, const DagArgs* device_args, int workgroups, hipStream_t st) {
+hipError_t launch_chol_dag(const SolverDev& sv, const CholPlan& pl, const DagArgs* device_args, int workgroups, bool one_per_cu, hipStream_t st) {
   if (pl.ntasks <= 0) return hipSuccess;
-  hipError_t e = allow_dynamic_lds(chol_dag_kernel, kCholLds * sizeof(double));
+  // The kernel needs 78 KB of LDS and would fit a CU twice — and two workgroups sharing a CU (polling waves on the SIMDs of the
+  // waves they wait for) slow the solve down by orders of magnitude.  The production launch therefore asks for more than half
+  // of a CU's 160 KB: the dispatcher cannot co-locate two of them, whatever else runs on the device.
+  const size_t lds_bytes = one_per_cu ? (size_t)84 * 1024 : kCholLds * sizeof(double);
+  static_assert(kCholLds * sizeof(double) <= (size_t)84 * 1024, "LDS map of the Cholesky tasks");
+  hipError_t e = allow_dynamic_lds(chol_dag_kernel, lds_bytes);
   if (e != hipSuccess) return e;
   e = hipMemsetAsync(pl.ticket, 0, 16, st);
   // every write-once cell starts out empty (all ones): factor tiles, partial tiles, W, z | y
@@ -1090,7 +1097,7 @@ hipError_t launch_chol_dag(const SolverDev& sv, const CholPlan& pl, const DagArg
   if (e == hipSuccess) e = hipMemsetAsync(sv.zv, 0xFF, 2 * (size_t)sv.npad * sizeof(double), st);
   if (e == hipSuccess) e = hipMemsetAsync(sv.Xpub, 0xFF, (size_t)sv.nt * T * T * sizeof(double), st);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(chol_dag_kernel, dim3(workgroups), dim3(256), kCholLds * sizeof(double), st, device_args);
+  hipLaunchKernelGGL(chol_dag_kernel, dim3(workgroups), dim3(256), lds_bytes, st, device_args);
   return hipGetLastError();
 }
 

@@ -6,7 +6,25 @@
 // librccl is looked up at run time (RSBA_RCCL_LIB, an RCCL already present in the process, librccl.so.1), so that a
 // single-GPU user of librsba_amd.so does not load it at all.
 #include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+// The library is resolved with dlopen at run time; a build host without the RCCL headers only needs the handful of
+// declarations used below (NCCL's stable C API: nccl.h of NCCL 2.x / RCCL).
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclSum = 0, ncclProd = 1, ncclMax = 2, ncclMin = 3 } ncclRedOp_t;
+typedef enum { ncclInt8 = 0, ncclUint8 = 1, ncclInt32 = 2, ncclUint32 = 3, ncclInt64 = 4, ncclUint64 = 5, ncclFloat16 = 6, ncclFloat32 = 7, ncclFloat64 = 8, ncclDouble = 8 } ncclDataType_t;
+ncclResult_t ncclGetUniqueId(ncclUniqueId* uniqueId);
+ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId commId, int rank);
+ncclResult_t ncclCommDestroy(ncclComm_t comm);
+ncclResult_t ncclAllReduce(const void* sendbuff, void* recvbuff, size_t count, ncclDataType_t datatype, ncclRedOp_t op, ncclComm_t comm, hipStream_t stream);
+const char* ncclGetErrorString(ncclResult_t result);
+}
+#endif
 
 #include <cstdlib>
 #include <cstring>

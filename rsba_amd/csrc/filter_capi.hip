@@ -39,6 +39,9 @@ struct Arena {
     (void)hipHostFree(h_in); (void)hipHostFree(h_xy); (void)hipHostFree(h_flags);
     d_in = d_xy = nullptr; d_flags = nullptr; d_zero = d_iota = nullptr; h_in = h_xy = nullptr; h_flags = nullptr; cap = 0;
   }
+  // (thread_local: destroyed when its thread ends — for the main thread before the static destructors of libamdhip64, which this
+  // library depends on and which was therefore loaded, and registered its teardown, first; threads still alive at exit never run
+  // it.  Errors of the frees are ignored either way.)
   ~Arena() { release(); if (stream) (void)hipStreamDestroy(stream); }
   int32_t reserve(int dev, int64_t n) {
     if (dev != device) { release(); if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; } device = dev; }
@@ -79,6 +82,7 @@ int32_t stage(Arena& A, DeviceProblem& dp, int32_t device, const double* cam, co
   if (obs_xy) std::memcpy(A.h_in + 21 + 3 * (size_t)n, obs_xy, 2 * (size_t)n * sizeof(double));
   FILTER_TRY(hipMemcpyAsync(A.d_in, A.h_in, (21 + (obs_xy ? 5 : 3) * (size_t)n) * sizeof(double), hipMemcpyHostToDevice, A.stream));
   std::memset(&dp, 0, sizeof dp);
+  dp.pp_spherical = -1;   // "no SphericalPrior" is -1, not 0 (only the filter kernels see this dp, but a zero would name pose block 0)
   dp.shutter = shutter; dp.scan0 = scanlines[0]; dp.scan1 = scanlines[1]; dp.interp_rotation = interpolate_rotation != 0; dp.calibrated = 1; dp.P = num_poses;
   dp.F = 1; dp.M = (int)n; dp.NI = 1; dp.N = n;
   dp.intr = A.d_in; dp.poses = A.d_in + 9; dp.points = A.d_in + 21;

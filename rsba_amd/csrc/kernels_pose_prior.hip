@@ -77,7 +77,7 @@ __global__ __launch_bounds__(kPPThreads) void pose_prior_cost_kernel(const Devic
   if (bad > 0.0) *dp.fail_count += (int)bad;
 }
 
-// linearisation: U_f, g_f += the blocks' J^T J / J^T r over the pose coordinates; per priorPoses coordinate v0, g0, c
+// linearisation: U_f, g_f += the blocks' J^T J / J^T r over the pose coordinates (lead rank only); per priorPoses coordinate v0, g0, c (every rank)
 __global__ __launch_bounds__(kPPThreads) void pose_prior_blocks_kernel(const DeviceProblem dp, const SolverDev sv, double* __restrict__ v0, double* __restrict__ g0,
                                                                         double* __restrict__ cross) {
   const int CD = sv.CD;
@@ -88,15 +88,17 @@ __global__ __launch_bounds__(kPPThreads) void pose_prior_blocks_kernel(const Dev
       const double w = pp_weight(dp, i), r = (p0[i] - pose[i]) * w;
       const double s0 = dp.pp_scale[(size_t)k * 6 + i], sp = dp.scale_pose[(size_t)b * 6 + i];
       const int a = 6 * q + i;
-      sv.U[((size_t)f * CD + a) * CD + a] += (w * sp) * (w * sp);
-      sv.gc[(size_t)f * CD + a] += -(w * sp) * r;
+      if (sv.lead) {   // replicated terms of the normal equations: contributed once, by the lead rank of a sharded solve
+        sv.U[((size_t)f * CD + a) * CD + a] += (w * sp) * (w * sp);
+        sv.gc[(size_t)f * CD + a] += -(w * sp) * r;
+      }
       v0[(size_t)k * 6 + i] = (w * s0) * (w * s0);
       g0[(size_t)k * 6 + i] = (w * s0) * r;
       cross[(size_t)k * 6 + i] = -(w * s0) * (w * sp);
     }
   }
   __syncthreads();   // a SphericalPrior may sit on a pose that also carries a GoodPosePrior: after the loop above
-  if (threadIdx.x == 0 && dp.pp_spherical >= 0) {
+  if (threadIdx.x == 0 && dp.pp_spherical >= 0 && sv.lead) {
     const int b = dp.pp_spherical, f = b / dp.P, q = b % dp.P;
     const Spherical s = spherical_at(dp.poses + (size_t)b * 6);
     double J[2][6];
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(kPPThreads) void pose_prior_step_kernel(const Devic
     }
   }
   acc = block_sum(acc, s_red); st = block_sum(st, s_red); xx = block_sum(xx, s_red);
-  if (threadIdx.x != 0) return;
+  if (threadIdx.x != 0 || !sv.lead) return;   // every rank of a sharded solve forms the candidate values; the scalars are summed over the ranks
   if (dp.pp_spherical >= 0) {
     const int b = dp.pp_spherical;
     const Spherical s = spherical_at(dp.poses + (size_t)b * 6);

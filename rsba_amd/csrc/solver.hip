@@ -74,6 +74,7 @@ struct Solver {
   long long* d_trace = nullptr;                                       // RSBA_CHOL_TRACE=<file>: task time stamps of the last factorisation
   CholPlan plan{};
   int dag_workgroups = 0;
+  bool dag_one_per_cu = true;                                         // LDS request above half a CU's: two persistent workgroups never share a CU (RSBA_CHOL_WGS above the CU count lifts it)
   bool use_levels = false;                                            // RSBA_CHOL_LEVELS=1: one launch per (level, kind)
   int last_diag_slot = 0;
   int32_t* d_obs_slot = nullptr;
@@ -795,7 +796,7 @@ int32_t build_solver(rsba_handle* h) {
   // registers per lane) — but with 384 or 512 resident workgroups the solve slows down by three orders of magnitude (waves
   // that poll share a SIMD with the waves they wait for); RSBA_CHOL_WGS is there to experiment with, capped at two per CU.
   s->dag_workgroups = std::max(1, std::min(pl.ntasks, std::max(cus, 1)));
-  if (const char* e = std::getenv("RSBA_CHOL_WGS")) s->dag_workgroups = std::max(1, std::min(std::min(pl.ntasks, 2 * std::max(cus, 1)), std::atoi(e)));
+  if (const char* e = std::getenv("RSBA_CHOL_WGS")) { s->dag_workgroups = std::max(1, std::min(std::min(pl.ntasks, 2 * std::max(cus, 1)), std::atoi(e))); s->dag_one_per_cu = s->dag_workgroups <= cus; }
   if (std::getenv("RSBA_CHOL_TRACE")) {
     if ((rc = s_alloc(s, &s->d_trace, 8 * (size_t)pl.ntasks))) return rc;
     HIP_TRY(hipMemset(s->d_trace, 0, 8 * (size_t)pl.ntasks * sizeof(long long)));
@@ -893,9 +894,9 @@ int32_t linearize(rsba_handle* h) {
     }
     if (s->border) HIP_TRY(launch_prior_border(h->dp, s->sv, s->border, s->ratio4, h->stream));   // every rank: from replicated poses
   }
-  if (s->sv.lead && (h->dp.pp_count > 0 || h->dp.pp_spherical >= 0)) {   // per-pose priors: replicated terms, contributed by the lead rank
-    PhaseScope ps(h, RSBA_PHASE_PRIORS);
-    HIP_TRY(launch_pose_prior_cost(h->dp, h->d_cost2, h->stream));
+  if (h->dp.pp_count > 0 || h->dp.pp_spherical >= 0) {   // per-pose priors: replicated terms, contributed by the lead rank;
+    PhaseScope ps(h, RSBA_PHASE_PRIORS);                   // the linearisation of the priorPoses coordinates (v0, g0, cross) on every rank: each one steps them itself
+    if (s->sv.lead) HIP_TRY(launch_pose_prior_cost(h->dp, h->d_cost2, h->stream));
     HIP_TRY(launch_pose_prior_blocks(h->dp, s->sv, s->pp, h->stream));
   }
   {
@@ -945,7 +946,7 @@ int32_t solve_reduced_system(rsba_handle* h) {
   Solver* s = h->solver; const SolverDev& sv = s->sv; hipStream_t st = h->stream;
   PhaseScope ps(h, RSBA_PHASE_CHOLESKY);
   if (!s->use_levels) {
-    HIP_TRY(launch_chol_dag(sv, s->plan, s->d_dag_args, s->dag_workgroups, st));
+    HIP_TRY(launch_chol_dag(sv, s->plan, s->d_dag_args, s->dag_workgroups, s->dag_one_per_cu, st));
     if (s->test_corrupt_once) { s->test_corrupt_once = false; HIP_TRY(hipMemsetAsync(sv.yv + (sv.n / 2 / 6) * 6 + 1, 0, sizeof(double), st)); }   // test hook: one entry of the solution (a pose coordinate in mid-video) lost
     if (s->verify_dag) HIP_TRY(launch_chol_verify(sv, s->d_slot_tiles, s->d_verify, s->d_verify + sv.npad, 1e-7, sv.scalars + kDagSuspect, st));
   } else {
@@ -1150,6 +1151,12 @@ extern "C" int32_t rsba_pose_covariance(rsba_handle* h, int32_t frame, double* c
   if ((rc = reduce_system(h, 1e300))) return rc;
   std::vector<double> col((size_t)CD * CD, 0.0);
   const double one = 1.0;
+  // CD (+1 with the border) solves through the factorisation; the DAG driver's verification flag is sticky, so one read after
+  // the last solve covers them all — a suspect result is thrown away and the solves are repeated on the level schedule
+  const bool levels_before = s->use_levels;
+  std::vector<double> vf; double hb[3] = {0.0, 0.0, 0.0};
+  for (int attempt = 0; attempt < 2; ++attempt) {
+  HIP_TRY(hipMemsetAsync(sv.scalars + kDagSuspect, 0, sizeof(double), st));
   for (int k = 0; k < CD; ++k) {
     HIP_TRY(hipMemsetAsync(sv.rhs, 0, (size_t)sv.npad * sizeof(double), st));
     HIP_TRY(hipMemcpyAsync(sv.rhs + (size_t)frame * CD + k, &one, sizeof(double), hipMemcpyHostToDevice, st));
@@ -1159,7 +1166,6 @@ extern "C" int32_t rsba_pose_covariance(rsba_handle* h, int32_t frame, double* c
   // A free interFrameRatio is one more parameter block of J^T J, coupled to every pose through its column b (the 1-wide
   // border of the reduced system, diagonal entry h): by the block inverse the pose block of the bordered system is
   // S^-1 + v v^T / (h - b.v) with S v = b — what ceres::Covariance returns for the problem CeresHandler builds by default.
-  std::vector<double> vf; double hb[3] = {0.0, 0.0, 0.0};
   if (s->border) {
     HIP_TRY(hipMemcpyAsync(sv.rhs, s->border, (size_t)sv.npad * sizeof(double), hipMemcpyDeviceToDevice, st));
     if ((rc = solve_reduced_system(h))) return rc;
@@ -1168,6 +1174,13 @@ extern "C" int32_t rsba_pose_covariance(rsba_handle* h, int32_t frame, double* c
     HIP_TRY(hipMemcpyAsync(vf.data(), sv.yv + (size_t)frame * CD, (size_t)CD * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(hb, s->ratio4, sizeof hb, hipMemcpyDeviceToHost, st));     // {h, g, b.v}
   }
+  double suspect = 0.0;
+  HIP_TRY(hipMemcpyAsync(&suspect, sv.scalars + kDagSuspect, sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (suspect == 0.0 || s->use_levels) break;
+  s->use_levels = true; ++s->dag_fallbacks;
+  }
+  s->use_levels = levels_before;
   int fail = 0, nfail = 0;
   HIP_TRY(hipMemcpyAsync(&fail, sv.chol_fail, sizeof(int), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(&nfail, h->dp.fail_count, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -1198,6 +1211,10 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
   sum->termination_type = RSBA_NO_CONVERGENCE;
   s->timer.on = opt->profile_phases != 0;
   if (s->timer.on) s->timer.reset();
+  struct TimerGuard {   // whichever way this call returns, later rsba_gradient / covariance calls must not keep queueing phase records
+    PhaseTimer& t;
+    ~TimerGuard() { if (t.on) { t.on = false; t.pending.clear(); t.next = 0; } }
+  } timer_guard{s->timer};
   { const char* lv = std::getenv("RSBA_CHOL_LEVELS"); s->use_levels = opt->level_scheduled_cholesky != 0 || (lv && lv[0] == '1'); }
   {
     // problem-size figures of the whole (all-rank) problem
@@ -1315,6 +1332,7 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
       ratio_diag = std::min(std::max(ratio_scale * ratio_scale * ratio_hg[0], opt->min_lm_diagonal), opt->max_lm_diagonal);
     }
     HIP_TRY(hipMemsetAsync(sv.chol_fail, 0, sizeof(int), st));
+    HIP_TRY(hipMemsetAsync(sv.scalars + kDagSuspect, 0, sizeof(double), st));   // sticky verification flag of the DAG Cholesky: any solve of this iteration may raise it
     RatioStep rs{ratio_scale * ratio_scale * ratio_hg[0] + ratio_diag / radius, ratio_scale * ratio_hg[1], ratio_scale, 0.0};
     if ((rc = factor_and_solve(h, radius, free_ratio ? &rs : nullptr))) return rc;
     reuse_diagonal = true;
@@ -1323,7 +1341,7 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
     { PhaseScope ps(h, RSBA_PHASE_BACK_SUBSTITUTE); HIP_TRY(launch_model_cost_change(dp, sv, st)); }
     if (s->ucross && sv.lead) { PhaseScope ps(h, RSBA_PHASE_PRIORS); HIP_TRY(launch_prior_model(dp, sv, sv.scalars + kModelCostChange, std::isfinite(ratio_step) ? ratio_step : 0.0, st)); }
     { PhaseScope ps(h, RSBA_PHASE_CANDIDATE); HIP_TRY(launch_candidate(dp, sv, st)); }
-    if (sv.lead && (dp.pp_count > 0 || dp.pp_spherical >= 0)) { PhaseScope ps(h, RSBA_PHASE_PRIORS); HIP_TRY(launch_pose_prior_step(dp, sv, s->pp, radius, st)); }
+    if (dp.pp_count > 0 || dp.pp_spherical >= 0) { PhaseScope ps(h, RSBA_PHASE_PRIORS); HIP_TRY(launch_pose_prior_step(dp, sv, s->pp, radius, st)); }   // every rank: candidate priorPoses values (scalars from the lead rank only)
     // residuals only at the candidate (T = double path)
     swap_params();
     {
@@ -1352,8 +1370,7 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
       // the persistent driver's solution does not satisfy the system it was given: nothing of this iteration has touched
       // x yet — repeat it, and finish this problem, on the level schedule
       s->use_levels = true; ++s->dag_fallbacks; ++sum->num_dag_fallbacks;
-      HIP_TRY(hipMemsetAsync(sv.scalars + kDagSuspect, 0, sizeof(double), st));
-      continue;
+      continue;   // (the flag is cleared at the top of the iteration)
     }
     cost2[1] = 0.0;   // the trial evaluation reports the total in kCost
     sum->linear_solver_time_s += now_s() - t0;

@@ -139,11 +139,11 @@ hipError_t launch_pose_prior_step(const DeviceProblem& dp, const SolverDev& sv, 
 
 // cholesky.hip
 hipError_t launch_chol_level(const SolverDev& sv, const CholPlan& pl, int kind, int first, int count, hipStream_t st);
-// res = rhs - S y with den = |rhs| + |S||y| over the packed tiles; *flag = 1 when |res| > tol * den somewhere (cholesky.hip)
+// res = rhs - S y with den = |rhs| + |S||y| over the packed tiles; *flag = 1 when |res| > tol * den somewhere, left alone otherwise (sticky; cholesky.hip)
 // slot_tiles [nslots][2] = {row tile, column tile} (unpermuted tile indices) of every packed tile
 hipError_t launch_chol_verify(const SolverDev& sv, const int32_t* slot_tiles, double* res, double* den, double tol, double* flag, hipStream_t st);
 struct DagArgs { SolverDev sv; CholPlan pl; };   // device copy the persistent kernel reads its state through (uploaded once per plan)
-hipError_t launch_chol_dag(const SolverDev& sv, const CholPlan& pl, const DagArgs* device_args, int workgroups, hipStream_t st);
+hipError_t launch_chol_dag(const SolverDev& sv, const CholPlan& pl, const DagArgs* device_args, int workgroups, bool one_per_cu, hipStream_t st);   // one_per_cu: LDS request above half a CU's, so that two never share one
 
 // kernels_normal.hip
 hipError_t launch_camera_blocks(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);

@@ -1,7 +1,8 @@
 """Worker for tests/test_distributed.py, launched by torch.distributed.run with 2 ranks.
    python -m torch.distributed.run --nproc-per-node 2 ... tests/dist_worker.py <mode> <outdir>
 mode "cpu": host-side exchange logic over gloo, partial blocks from the oracle (no GPU needed)
-mode "gpu": the sharded on-device LM solve, both ranks on GPU 0, exchange staged through gloo ("gpu_priors": with motion priors)"""
+mode "gpu": the sharded on-device LM solve, both ranks on GPU 0, exchange staged through gloo ("gpu_priors": with motion priors,
+"gpu_free_ratio": with a free interFrameRatio, "gpu_pose_priors": with GoodPosePrior blocks)"""
 import json
 import os
 import sys
@@ -34,6 +35,11 @@ def main():
         full.prior_frames = np.arange(1, full.num_frames, dtype=np.int32)
         if mode == "gpu_free_ratio":   # the free ratio's scalar LM state is replicated on every rank
             full.prior_kind, full.inter_frame_ratio, full.ratio_free = 1, 1.0, True
+    if mode == "gpu_pose_priors":   # GoodPosePrior blocks (CeresHandler.h:188-204): every rank passes the same blocks and must leave with the same solved priorPoses
+        rng = np.random.default_rng(5)
+        full.pose_prior_block = np.arange(2, 2 * full.num_frames, dtype=np.int32)
+        full.pose_prior_values = full.poses.reshape(-1, 6)[full.pose_prior_block] + rng.normal(0, 0.01, (len(full.pose_prior_block), 6))
+        full.pose_prior_rotation, full.pose_prior_position = 3.0, 5.0
     shard = full.shard(rank, world)
     out = {"rank": rank, "world": world, "n_full": full.num_observations, "n_shard": shard.num_observations}
     if mode == "cpu":
@@ -82,6 +88,7 @@ def main():
         out["native_merge_equals_host_merge"] = bool(np.array_equal(merged, shard.points))
         out.update(ratio=shard.inter_frame_ratio, final_cost=s.final_cost, initial_cost=s.initial_cost, iters=s.num_iterations, reduced=s.num_residual_blocks_reduced,
                    params=s.num_parameters_reduced, term=s.termination_type)
+        if mode == "gpu_pose_priors": out["prior_values"] = shard.pose_prior_values.ravel().tolist()
         if rank == 0:
             ref = full.copy()
             with capi.DeviceProblem(ref) as d1:
@@ -90,6 +97,9 @@ def main():
                        ref_params=s1.num_parameters_reduced, pose_err=float(np.abs(ref.poses - shard.poses).max()),
                        point_err=float(np.abs(ref.points - shard.points).max()),
                        traj_err=float(max(abs(a.cost - b.cost) / b.cost for a, b in zip(tr, tr1))))
+            if mode == "gpu_pose_priors":
+                out.update(prior_err=float(np.abs(ref.pose_prior_values - shard.pose_prior_values).max()),
+                           prior_moved=float(np.abs(ref.pose_prior_values - full.pose_prior_values).max()))
     with open(os.path.join(outdir, f"rank{rank}.json"), "w") as f:
         json.dump(out, f)
     dist.barrier()

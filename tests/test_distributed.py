@@ -52,6 +52,18 @@ def test_sharded_solve_equals_single_gpu_solve(tmp_path, mode):
 
 
 @pytest.mark.gpu
+def test_sharded_solve_with_pose_priors_leaves_every_rank_with_the_solved_prior_poses(tmp_path):
+    """GoodPosePrior blocks in a sharded solve: the priorPoses blocks are free parameter blocks (CeresHandler.h:188-204), their
+    replicated normal-equation terms come from rank 0 — but EVERY rank steps them and writes the solved values back."""
+    a, b = run_two_ranks("gpu_pose_priors", tmp_path)
+    assert a["final_cost"] == b["final_cost"] and a["iters"] == b["iters"]
+    assert a["prior_values"] == b["prior_values"]                       # rank 1 used to return the values it was given
+    assert a["iters"] == a["ref_iters"] and a["params"] == a["ref_params"] and a["reduced"] == a["ref_reduced"]
+    assert a["traj_err"] <= 1e-9 and abs(a["final_cost"] - a["ref_final"]) <= 1e-9 * a["ref_final"]
+    assert a["prior_err"] <= 1e-7 and a["pose_err"] <= 1e-7 and a["prior_moved"] > 1e-4
+
+
+@pytest.mark.gpu
 def test_native_rccl_transport_one_rank():
     """rsba_set_exchange_rccl: ncclCommInitRank + ncclAllReduce issued by the library on the solver's stream.  One rank is
     all a one-GPU box can hold (RCCL refuses two ranks on one device); the all-reduces still run — as identities — so the

@@ -336,3 +336,48 @@ def test_session_start_and_pose_priors_through_ceres_handler(exe, oracle, tmp_pa
     assert abs(out["initial_cost"] - s_ref.initial_cost) <= 1e-12 * s_ref.initial_cost
     assert abs(1.0 - np.abs(out["poses"][1, 0, 3:]).sum()) <= 4e-16                 # the gauge the SphericalPrior sets
     assert np.max(np.abs(out["poses"][1, 0, 3:] - q.poses[1, 0, 3:])) <= 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("valid_tracks", [60, 150])
+def test_full_ba_drops_the_valid_only_filter_below_100_valid_tracks(exe, oracle, tmp_path, valid_tracks):
+    """VideoSfMHandler::fullBA (VideoSfMHandler.cc:163-172): with fewer than 100 valid tracks in the session
+    useOnlyValidMatches is switched off and every track with a point takes part; with 100 or more only the valid ones do."""
+    from rsba_amd.problem import apply_gauge_masks
+    p = small_problem(True, 0.0)
+    write_scene_file(tmp_path / "s.bin", p, fix_first_n=1, max_iter=12)
+    r = subprocess.run([exe, str(tmp_path / "s.bin"), str(tmp_path / "o.bin"), "0", "0", "fullBA", str(valid_tracks)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert ("Not enough valid matches: 60" in r.stdout) == (valid_tracks < 100)
+    out = read_result_file(tmp_path / "o.bin", p)
+    q = p.copy()
+    if valid_tracks >= 100:
+        keep = p.obs_point < valid_tracks
+        q.obs_xy, q.obs_frame, q.obs_point = p.obs_xy[keep], p.obs_frame[keep], p.obs_point[keep]
+    apply_gauge_masks(q, fix_first_n_cameras=1)
+    s_ref, _ = oracle.solve(q, oracle.default_options(max_num_iterations=12))
+    assert out["usable"] and out["reduced"] == s_ref.num_residual_blocks_reduced
+    assert abs(out["initial_cost"] - s_ref.initial_cost) <= 1e-12 * s_ref.initial_cost
+    assert abs(out["final_cost"] - s_ref.final_cost) <= 1e-6 * s_ref.final_cost
+
+
+@pytest.mark.gpu
+def test_windowed_ba_switches_fix_scale_off(exe, oracle, tmp_path):
+    """VideoSfMHandler::windowedBA (VideoSfMHandler.cc:195): opt.ceres.fixScale = false whatever the session options say —
+    BA() on the same window with fixScale keeps the translation of the last frame's last pose, windowedBA() moves it."""
+    from rsba_amd.problem import apply_gauge_masks
+    p = small_problem(True, 0.0)
+    write_scene_file(tmp_path / "s.bin", p, fix_first_n=1, fix_scale=True, max_iter=12)
+    res = {}
+    for entry in ("BA", "windowedBA"):
+        r = subprocess.run([exe, str(tmp_path / "s.bin"), str(tmp_path / f"{entry}.bin"), "0", "0", entry], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        res[entry] = read_result_file(tmp_path / f"{entry}.bin", p)
+    assert np.array_equal(res["BA"]["poses"][-1, -1, 3:], p.poses[-1, -1, 3:])
+    assert not np.array_equal(res["windowedBA"]["poses"][-1, -1, 3:], p.poses[-1, -1, 3:])
+    q = p.copy()
+    apply_gauge_masks(q, fix_first_n_cameras=1, fix_scale=False)
+    s_ref, _ = oracle.solve(q, oracle.default_options(max_num_iterations=12))
+    out = res["windowedBA"]
+    assert out["usable"] and abs(out["final_cost"] - s_ref.final_cost) <= 1e-6 * s_ref.final_cost
+    assert np.max(np.abs(out["poses"] - q.poses)) <= 1e-5

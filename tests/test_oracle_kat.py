@@ -103,15 +103,7 @@ def test_distortion_roundtrip(oracle):  # mat_test.cc:145-167 (only 7 initialise
             assert math.hypot(img[0] - u[0], img[1] - u[1]) <= 1e-6
 
 
-POSE_REF = [0, 0, 0, 20, 20, 0]
-POSES = [[0, 0, 0, 0, 0, 0], [0, 0, 0, 1, 1, 1], [0, 0, PI2, 20, 20, 20], [0, PI2, PI2, -2, 20, 20],
-         [PI2, PI2, PI2, -2, -2, 20], [-1, -1, -1, -2, -2, -2], [-PI2, -1, -1, -20, -2, -2],
-         [0.5, -PI2, -1, -2, -20, -2], [0.5, 0.5, -PI2, 0.2, -2, -20], [EPS] * 6, [-EPS] * 6]
-PTS = [[10, 10, 10], [100, 0, 1], [0, 100, 1], [0, 0, 100], [-100, 0, 1], [0, -100, 1], [0, 0, -100], [0, 0, -1],
-       [0, 0, 0], [1, 1, 1], [-1, -1, -1], [0.1, 0.1, 0.1], [100, 100, 100], [-100, -100, -100],
-       [-0.39, 1.25, 2014], [EPS, EPS, EPS], [EPS, EPS, -EPS], [-EPS, -EPS, -EPS]]
-CAMS = [[0.1, 0.1, 0, 0, 0, 0, 0, 0, 0], [100, 100, 0, 0, 0, 0, 0, 0, 0], [500, 500, 0, 0, 0, 0, 0, 640, 480],
-        [100, 100, EPS, 0, 0, 0, 0, 0, 0], [500, 500, -EPS, -EPS, 0, 0, 0, 0, 0], [860, 860, 0.001, 0, 0, 0, 0, 100, 200]]
+from kat_tables import CAMS, POSE_REF, POSES, PTS   # mat_test.cc:171-214 (shared with the GPU replay, tests/test_gpu_kat.py)
 
 
 def test_reprojection(oracle):  # mat_test.cc:170-313
