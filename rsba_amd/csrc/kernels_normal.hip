@@ -151,8 +151,10 @@ __global__ __launch_bounds__(256) void virtual_records_kernel(const DeviceProble
       for (int m = 0; m < 3; ++m) Q[k][m] += a0 * B[0][m] + a1 * B[1][m];
     }
   }
-  double* out = sv.Pm + ((size_t)dp.N + (size_t)g * sv.NPF) * (CD * 3);
-  for (int v = 0; v < sv.NPF; ++v)
+  constexpr int FT = kTile / CD;
+  for (int v = 0; v < sv.NPF; ++v) {
+    const int gpos = sv.slot_gpos[dp.N + g * sv.NPF + v];   // the virtual slot's place: group gpos / FT, frame position gpos % FT of its tile
+    double* out = sv.Pm + (size_t)(gpos / FT) * (kTile * 3) + (gpos % FT) * CD;
 #pragma unroll
     for (int rl = 0; rl < CD; ++rl) {
       const int k = v * CD + rl;
@@ -161,9 +163,10 @@ __global__ __launch_bounds__(256) void virtual_records_kernel(const DeviceProble
         double q = 0.0;
 #pragma unroll
         for (int kk = 0; kk < 9; ++kk) if (kk == k) q = Q[kk][m];
-        out[(size_t)v * (CD * 3) + rl * 3 + m] = q;
+        out[m * kTile + rl] = q;
       }
     }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -271,33 +274,39 @@ __global__ __launch_bounds__(256) void point_factor_kernel(const DeviceProblem d
 }
 
 // K5b  per observation (point-major): P = Jc^T (Jp L^-T)   (CD x 3)
-// One wave = 64 consecutive slots.  Records and results are moved between HBM and LDS with fully
-// coalesced 512-B wave accesses (a lane-per-record global access pattern touches 64 cache lines per
-// instruction and ran 4x slower); each lane then works on its own record out of LDS (odd pitch: no
-// bank conflicts).
+// One wave = 64 consecutive slots.  Records are moved from HBM to LDS with fully coalesced 512-B wave
+// accesses (a lane-per-record global access pattern touches 64 cache lines per instruction and ran 4x
+// slower); each lane then works on its own record out of LDS (odd pitch: no bank conflicts).
+// The results go to the GROUP layout the Schur kernel reads (solver_state.hpp, Pm): coordinate c of the point
+// against the CD rows of the slot's frame is a run of CD doubles at row c of the slot's (point, tile) group,
+// position (frame % FT) * CD.  Consecutive slots of a point are consecutive frames, so the runs of one
+// coordinate line up back to back: the wave stores coordinate by coordinate, each store instruction covering
+// (mostly) whole 128-B lines.
 constexpr int kProjectChunks = 8;   // consecutive 64-slot chunks per wave of the projection kernel
 
 template <int CD, int KC>
 __global__ __launch_bounds__(256) void project_kernel(const DeviceProblem dp, const SolverDev sv) {
-  constexpr int REC = 8 + 2 * KC, OUT = CD * 3;
+  constexpr int REC = 8 + 2 * KC, OUT = CD * 3, FT = kTile / CD;
   constexpr int PITCH = (REC > OUT ? REC : OUT) | 1;          // odd
   constexpr int off = KC - CD;                                  // 9 when intrinsics columns precede the pose
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double* buf = smem + (size_t)wave * 64 * PITCH;
+  double* buf = smem + (size_t)wave * (64 * PITCH + 32);
+  int32_t* s_gpos = reinterpret_cast<int32_t*>(buf + 64 * PITCH);   // [64] where each slot of the chunk goes
   const int64_t sb = ((int64_t)blockIdx.x * 4 + wave) * 64 * kProjectChunks;
   if (sb >= dp.N) return;
   const int64_t se = sb + 64 * kProjectChunks < dp.N ? sb + 64 * kProjectChunks : dp.N;
   // the next chunk's records (and the point of each slot) travel in registers while this one is worked on; indices
   // are clamped rather than predicated so that nothing next to the loads waits for them
   double pre[REC];
-  int pre_point = 0;
+  int pre_point = 0, pre_gpos = 0;
   auto issue = [&](int64_t c0) {
     const int64_t last = (se - c0) * REC - 1;
     const double* src = dp.rec + (size_t)c0 * REC;
 #pragma unroll
     for (int k = 0; k < REC; ++k) { const int64_t idx = k * 64 + lane; pre[k] = src[idx < last ? idx : last]; }
-    pre_point = sv.slot_point[c0 + lane < se ? c0 + lane : se - 1];
+    const int64_t sl = c0 + lane < se ? c0 + lane : se - 1;
+    pre_point = sv.slot_point[sl]; pre_gpos = sv.slot_gpos[sl];
   };
   issue(sb);
   for (int64_t s0 = sb; s0 < se; s0 += 64) {
@@ -306,6 +315,7 @@ __global__ __launch_bounds__(256) void project_kernel(const DeviceProblem dp, co
     for (int k = 0; k < REC; ++k) { const int idx = k * 64 + lane; buf[(idx / REC) * PITCH + idx % REC] = pre[k]; }
     const double* li = sv.Linv + (size_t)pre_point * 6;
     const double i00 = li[0], i10 = li[1], i11 = li[2], i20 = li[3], i21 = li[4], i22 = li[5];
+    s_gpos[lane] = pre_gpos;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (s0 + 64 < se) issue(s0 + 64);
     double out[OUT];
@@ -321,18 +331,30 @@ __global__ __launch_bounds__(256) void project_kernel(const DeviceProblem dp, co
       for (int a = 0; a < CD; ++a) {
         const double c0 = rec[8 + off + a], c1 = rec[8 + KC + off + a];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) out[a * 3 + k] = c0 * B[0][k] + c1 * B[1][k];
+        for (int k = 0; k < 3; ++k) out[k * CD + a] = c0 * B[0][k] + c1 * B[1][k];   // component-major inside the record
       }
     }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int e = 0; e < OUT; ++e) buf[lane * PITCH + e] = out[e];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    double* dst = sv.Pm + (size_t)s0 * OUT;
-#pragma unroll 4
-    for (int k = 0; k < OUT; ++k) {
-      const int idx = k * 64 + lane;
-      if (idx < nslot * OUT) dst[idx] = buf[(idx / OUT) * PITCH + idx % OUT];
+    // Stores: a lane owns one double (w) of the CD-long runs; kPer = 64 / CD consecutive slots per instruction (their runs of one
+    // coordinate sit back to back while the slots stay inside one group), three instructions — one per coordinate, 48 doubles
+    // apart: the store's immediate offset — per address computation.  (64 % CD lanes idle.)
+    constexpr int kPer = 64 / CD;
+    const int my = lane / CD, w = lane % CD;
+    if (my < kPer) {
+#pragma unroll 2
+      for (int i = 0; i * kPer < 64; ++i) {
+        const int sl = i * kPer + my;
+        if (sl < nslot) {
+          const int gpos = s_gpos[sl];
+          double* dst = sv.Pm + ((size_t)(gpos / FT) * (kTile * 3) + (size_t)((gpos % FT) * CD + w));
+          const double* src = buf + sl * PITCH + w;
+#pragma unroll
+          for (int comp = 0; comp < 3; ++comp) dst[comp * kTile] = src[comp * CD];
+        }
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
@@ -341,11 +363,20 @@ __global__ __launch_bounds__(256) void project_kernel(const DeviceProblem dp, co
 // ---------------------------------------------------------------------------------------------
 // K5c  reduced camera system  S = U + D_c^2 - sum_j (sum_a P_aj)(sum_b P_bj)^T ,  rhs = g_c - sum P z
 // Work unit = ENTRY (point j, frame tiles I >= J): the point's P records in the FT frames of I and of J, stacked
-// into A_j(I) and A_j(J) (48 x 3 each; a frame that does not see the point contributes the all-zero record).
+// into A_j(I) and A_j(J) (48 x 3 each; a frame that does not see the point contributes zero rows) — exactly the
+// (point, tile) GROUPS the projection kernel writes: group g is a [3][48] block of Pm, coordinate-major.
 // The tile of the pair is the banded SYRK  S_IJ = sum_j A_j(I) A_j(J)^T  — GEMM-shaped, K = 3 per point — and runs
-// on v_mfma_f64_16x16x4_f64 (four points fill three MFMA steps of k = 4), operands gathered from HBM/L2 straight
+// on v_mfma_f64_16x16x4_f64 (four points fill three MFMA steps of k = 4), operands loaded from HBM/L2 straight
 // into the instruction's register layout: lane (r = lane & 15, g = lane >> 4) holds P[row 16 Ib + r][one
-// coordinate of one point] for the three 16-row blocks Ib of each side.  No LDS, no barrier in the loop.  One workgroup per chunk of kSchurChunk entries; its four waves take every fourth entry and keep all
+// coordinate of one point] for the three 16-row blocks Ib of each side — in the group layout the sixteen lanes of
+// a lane group read ONE aligned 128-B line, a wave instruction four of them (round 2 gathered the same sixteen
+// values from slot-major records at a 24-B stride: three to four lines per lane group, and the kernel was bound by
+// those gathers as much as by the matrix pipe).  No LDS, no barrier in the loop.
+// 16 x 16 operand blocks that are all zero for the four points of an MFMA step — frames of the tile that do not see them —
+// are found with one wave vote per block and their MFMAs are not issued (a fifth of them at 1k cameras; 0 * x adds nothing,
+// so the result is the same to the bit), and a tile paired with itself only forms the blocks on and below the
+// diagonal (nothing reads the upper triangle of a diagonal tile of S).
+// One workgroup per chunk of kSchurChunk entries; its four waves take every fourth entry and keep all
 // nine 16x16 blocks (loads run kDepth groups ahead of the MFMAs in a register ring), the four partial tiles meet
 // once in LDS.  The fp64 VALU form of this product was bound by LDS operand reads at 2.0 ms per 1k-camera
 // iteration.  Chunks write partial tiles; the merge kernel sums them in chunk order (fixed order, no atomics)
@@ -353,43 +384,60 @@ __global__ __launch_bounds__(256) void project_kernel(const DeviceProblem dp, co
 // ---------------------------------------------------------------------------------------------
 typedef double dbl4 __attribute__((ext_vector_type(4)));
 
-template <int CD>
-__global__ __launch_bounds__(256) void schur_tile_kernel(const SolverDev sv, const double* __restrict__ Pm, const double* __restrict__ zz) {
-  constexpr int FT = kTile / CD, PW = CD * 3;          // frames per tile, doubles per P record
-  constexpr int NREC = 2 * FT;                         // records per entry
+// LDS of the loop (bytes): [2 kSchurChunk] uint32 element offsets of the entries' two groups | [kSchurChunk] uint16 block masks | (diagonal
+// pairs) [3 kSchurChunk] doubles z.  The four partial tiles of the epilogue reuse it from the start.
+constexpr int kSchurOffBytes = 2 * kSchurChunk * 4, kSchurMskBytes = kSchurChunk * 2;
+constexpr unsigned kLowerBlocks = 0x1D9;   // bits 3 I + J with J <= I
+
+// One chunk.  DIAG: a tile paired with itself — only the blocks on and below the diagonal are formed, and its entries carry
+// the rhs term P z.  The loop is written for the instruction issue port: fp64 MFMAs run on the vector unit's fp64 datapath,
+// so every vector / scalar instruction around them is time the matrix pipe idles (round 2's loop spent 6 scalar and 5 vector
+// instructions per MFMA on 64-bit gather addresses, tail selects and per-step votes: the pipe was busy 39 % of the time,
+// SQ_VALU_MFMA_BUSY_CYCLES).  Here: entry counts are padded to a multiple of 16 with entries that point at an all-zero group
+// (no tail selects), the table holds ready element offsets (one 64-bit add per operand triple, the three 16-row blocks ride
+// on the load's immediate offset), and which of the nine 16 x 16 blocks of a group of four entries have anything to multiply
+// is ONE scalar read of host-computed masks (a full mask — the common case — runs 27 MFMAs without a branch).
+template <bool DIAG, int kDepth>
+__device__ __forceinline__ void schur_chunk(const SolverDev& sv, const double* __restrict__ Pm, const double* __restrict__ zz, int chunk, double* smem) {
+  constexpr int GW = kTile * 3;                        // doubles per group
   constexpr int TPITCH = kTile + 1;
-  constexpr int kDepth = 3;                            // groups of four entries in flight per wave (54 loads: vmcnt counts to 63)
-  extern __shared__ __attribute__((aligned(16))) double smem[];   // slot table + z during the loop, partial tiles after it
-  double* s_z = smem;                                              // [kSchurChunk][3], zero where the entry carries no rhs term
-  int32_t* s_slot = reinterpret_cast<int32_t*>(smem + 3 * kSchurChunk);
+  constexpr unsigned kFull = DIAG ? kLowerBlocks : 0x1FFu;
+  uint32_t* s_off = reinterpret_cast<uint32_t*>(smem);
+  uint16_t* s_msk = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(smem) + kSchurOffBytes);   // [(k & 3) * 128 + (k >> 2)]: the four entries of a wave's group are one 8-byte read
+  double* s_z = reinterpret_cast<double*>(reinterpret_cast<char*>(smem) + kSchurOffBytes + kSchurMskBytes);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
-  // consecutive chunks share records (host: chunk numbering); workgroups go round-robin over the 8 XCDs, so XCD x
-  // walks the x-th eighth of the chunk list in order and its L2 sees the repeats
-  const int per_xcd = (sv.nchunk + 7) / 8;
-  const int chunk = sv.schur_linear ? (int)blockIdx.x : (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
-  if (chunk >= sv.nchunk) return;
   const int64_t e0 = sv.chunk_e0[chunk];
-  const int n = sv.chunk_n[chunk];
-  for (int k = tid; k < n * NREC; k += 256) {
-    const int e = k / NREC, q = k % NREC;   // slot q of entry e: frame q % FT of its I-side (q < FT) or J-side group
-    s_slot[k] = sv.group_slots[(size_t)sv.ent_groups[2 * (e0 + e) + q / FT] * FT + q % FT];
-  }
-  for (int k = tid; k < n * 3; k += 256) {
-    const int32_t pt = sv.ent_pt[e0 + k / 3];
-    s_z[k] = pt < 0 ? zz[(size_t)(pt & 0x7fffffff) * 3 + k % 3] : 0.0;   // top bit: diagonal entry of the point -> rhs term P z
+  const int n = sv.chunk_n[chunk], n16 = (n + 15) & ~15;
+  long long* tr = sv.schur_trace ? sv.schur_trace + 8 * (size_t)chunk : nullptr;
+  if (tr && tid == 0) { tr[0] = blockIdx.x; tr[1] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); tr[2] = wall_clock64(); tr[6] = n; }   // HW_REG_HW_ID
+  for (int k = tid; k < n16; k += 256) {
+    uint32_t ga = (uint32_t)sv.ngroups, gb = ga;       // the all-zero group behind the last one
+    unsigned pm = 0;
+    if (k < n) {
+      ga = (uint32_t)sv.ent_groups[2 * (e0 + k)]; gb = (uint32_t)sv.ent_groups[2 * (e0 + k) + 1];
+      pm = sv.ent_mask[e0 + k] & kFull;   // 16 x 16 blocks of the entry with a frame that sees the point on both sides (host)
+      if (sv.schur_variant == 5) { ga = (uint32_t)(k & 63); gb = (uint32_t)(64 + (k & 63)); }   // ablation: operands out of the caches
+    }
+    s_off[2 * k] = ga * (uint32_t)GW; s_off[2 * k + 1] = gb * (uint32_t)GW;
+    s_msk[(k & 3) * (kSchurChunk / 4) + (k >> 2)] = (uint16_t)pm;
+    if (DIAG) {
+      const int32_t pt = k < n ? sv.ent_pt[e0 + k] : 0;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) s_z[3 * k + c] = pt < 0 ? zz[(size_t)(pt & 0x7fffffff) * 3 + c] : 0.0;   // top bit: diagonal entry of the point -> rhs term P z
+    }
   }
   __syncthreads();
+  if (tr && tid == 0) tr[3] = wall_clock64();
   // K = 3 per point against 4 per MFMA: four of the wave's entries share three MFMA steps, step t taking the
   // coordinates k = 4t .. 4t+3 of the twelve — lane group g reads coordinate (4t + g) % 3 of entry (4t + g) / 3.
-  int pe[3], comp[3];
+  // The wave's entries are wave, wave + 4, ..: entry e of its group q is k = wave + 16 q + 4 e.
+  int tab[3], opo[3], zof[3];   // per step: byte offset of the entry's table cell in group 0, element offset of the operand inside a group, element offset of z
 #pragma unroll
-  for (int t = 0; t < 3; ++t) { pe[t] = (4 * t + g) / 3; comp[t] = (4 * t + g) % 3; }
-  // which record (frame of the tile) and which of its rows this lane reads for block row Ib
-  int fa[3], off[3];
-#pragma unroll
-  for (int Ib = 0; Ib < 3; ++Ib) { const int row = 16 * Ib + r; fa[Ib] = row / CD; off[Ib] = (row % CD) * 3; }
-
+  for (int t = 0; t < 3; ++t) {
+    const int e = (4 * t + g) / 3, c = (4 * t + g) % 3, k = wave + 4 * e;
+    tab[t] = 8 * k; opo[t] = c * kTile + r; zof[t] = 3 * k + c;
+  }
   dbl4 acc[3][3];
 #pragma unroll
   for (int I = 0; I < 3; ++I)
@@ -398,49 +446,65 @@ __global__ __launch_bounds__(256) void schur_tile_kernel(const SolverDev sv, con
   double racc[3] = {0.0, 0.0, 0.0};
   struct Group { double a[3][3], b[3][3], z[3]; };   // [step][block row]
   Group ring[kDepth];
-  const int nw = n > wave ? (n - wave + 3) / 4 : 0;   // this wave's entries: wave, wave + 4, ..
-  // loads of group q (entries clamped into the chunk: the tail re-reads its last entry instead of branching).
-  // The ring keeps the values as loaded; lanes whose entry does not exist are zeroed where the values are USED —
-  // a select next to the load would make the compiler wait for the load right there and undo the prefetch.
-  auto fetch = [&](int q, Group& G) {
+  const int nq = n16 >> 4;   // groups of four entries per wave
+  const char* lds = reinterpret_cast<const char*>(smem);
+  auto fetch = [&](int q, Group& G) {   // (q is wave-uniform; past the end the last group is read again instead of branching)
+    const int qq = q < nq ? q : nq - 1;
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
-      const int m = 4 * q + pe[t];
-      const int k = m < nw ? wave + 4 * m : (n > 0 ? n - 1 : 0);
-      const int32_t* sl = s_slot + k * NREC;
+      const uint2 o = *reinterpret_cast<const uint2*>(lds + tab[t] + 128 * qq);
+      const double* pa = Pm + ((size_t)o.x + (size_t)opo[t]);
+      const double* pb = Pm + ((size_t)o.y + (size_t)opo[t]);
 #pragma unroll
-      for (int Ib = 0; Ib < 3; ++Ib) {
-        G.a[t][Ib] = Pm[(size_t)((uint32_t)sl[fa[Ib]] * (uint32_t)PW + (uint32_t)(off[Ib] + comp[t]))];
-        G.b[t][Ib] = Pm[(size_t)((uint32_t)sl[FT + fa[Ib]] * (uint32_t)PW + (uint32_t)(off[Ib] + comp[t]))];
-      }
-      G.z[t] = s_z[k * 3 + comp[t]];
+      for (int Ib = 0; Ib < 3; ++Ib) { G.a[t][Ib] = pa[16 * Ib]; G.b[t][Ib] = pb[16 * Ib]; }
+      if (DIAG) G.z[t] = s_z[zof[t] + 48 * qq];
     }
   };
-  const int ngroups = (nw + 3) / 4;
+  unsigned issued = 0;
+  if (nq > 0) {
 #pragma unroll
-  for (int d = 0; d < kDepth; ++d) fetch(d, ring[d]);
-  for (int base = 0; base < ngroups; base += kDepth) {
+    for (int d = 0; d < kDepth; ++d) fetch(d, ring[d]);
+    for (int base = 0; base < nq; base += kDepth) {
 #pragma unroll
-    for (int d = 0; d < kDepth; ++d) {
-      if (base + d < ngroups) {
+      for (int d = 0; d < kDepth; ++d) {
+        if (base + d < nq) {
+          // blocks with something to multiply: OR of the four entries' masks, one 8-byte LDS read at a wave-uniform address
+          const uint2 m4 = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(s_msk) + 2 * (wave * (kSchurChunk / 4) + 4 * (base + d)));
+          unsigned mv = m4.x | m4.y; mv = (mv | (mv >> 16)) & 0x1FFu;
+          unsigned pm = (unsigned)__builtin_amdgcn_readfirstlane((int)mv);
+          if (sv.schur_variant == 4) { pm = 0; asm volatile("" :: "v"(ring[d].a[0][0]), "v"(ring[d].b[2][2]), "v"(ring[d].a[1][1]), "v"(ring[d].b[1][0]), "v"(ring[d].a[2][2]), "v"(ring[d].b[0][1])); }   // ablation: loads only
+          if (pm == kFull) {
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-          const bool live = 4 * (base + d) + pe[t] < nw;
-          double a[3], b[3];
+            for (int t = 0; t < 3; ++t)
 #pragma unroll
-          for (int I = 0; I < 3; ++I) { a[I] = live ? ring[d].a[t][I] : 0.0; b[I] = live ? ring[d].b[t][I] : 0.0; }
+              for (int I = 0; I < 3; ++I)
 #pragma unroll
-          for (int I = 0; I < 3; ++I)
+                for (int J = 0; J < 3; ++J)
+                  if (!DIAG || J <= I) acc[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[d].a[t][I], ring[d].b[t][J], acc[I][J], 0, 0, 0);
+          } else if (pm != 0u) {
 #pragma unroll
-            for (int J = 0; J < 3; ++J) acc[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[I], b[J], acc[I][J], 0, 0, 0);
+            for (int t = 0; t < 3; ++t)
 #pragma unroll
-          for (int I = 0; I < 3; ++I) racc[I] += a[I] * ring[d].z[t];
+              for (int I = 0; I < 3; ++I)
+#pragma unroll
+                for (int J = 0; J < 3; ++J)
+                  if ((!DIAG || J <= I) && ((pm >> (3 * I + J)) & 1u)) acc[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[d].a[t][I], ring[d].b[t][J], acc[I][J], 0, 0, 0);
+          }
+          issued += 3u * (unsigned)__builtin_popcount(pm);
+          if (DIAG) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+              for (int I = 0; I < 3; ++I) racc[I] += ring[d].a[t][I] * ring[d].z[t];
+          }
         }
+        fetch(base + d + kDepth, ring[d]);
       }
-      fetch(base + d + kDepth, ring[d]);
     }
   }
-  __syncthreads();   // everyone is done with the slot table: the same LDS now takes the four partial tiles
+  if (lane == 0 && issued) atomicAdd(sv.schur_mfma_count, (unsigned long long)issued);   // a statistic (bench.py: issued against useful flops), not a result
+  __syncthreads();   // everyone is done with the tables: the same LDS now takes the four partial tiles
+  if (tr && tid == 0) tr[4] = wall_clock64();
   double* buf = smem + wave * (kTile * TPITCH);
 #pragma unroll
   for (int I = 0; I < 3; ++I)
@@ -449,12 +513,14 @@ __global__ __launch_bounds__(256) void schur_tile_kernel(const SolverDev sv, con
 #pragma unroll
       for (int v = 0; v < 4; ++v) buf[(16 * I + g + 4 * v) * TPITCH + 16 * J + r] = acc[I][J][v];
   double* rvec = smem + 4 * kTile * TPITCH + wave * kTile;
+  if (DIAG) {
 #pragma unroll
-  for (int I = 0; I < 3; ++I) {
-    double x = racc[I];
-    x += __shfl_xor(x, 16, 64);
-    x += __shfl_xor(x, 32, 64);
-    if (lane < 16) rvec[16 * I + lane] = x;
+    for (int I = 0; I < 3; ++I) {
+      double x = racc[I];
+      x += __shfl_xor(x, 16, 64);
+      x += __shfl_xor(x, 32, 64);
+      if (lane < 16) rvec[16 * I + lane] = x;
+    }
   }
   __syncthreads();
   double* part = sv.schur_part + (size_t)chunk * (kTile * kTile + kTile);
@@ -462,7 +528,23 @@ __global__ __launch_bounds__(256) void schur_tile_kernel(const SolverDev sv, con
     const int o = (e / kTile) * TPITCH + e % kTile;
     part[e] = (smem[o] + smem[kTile * TPITCH + o]) + (smem[2 * kTile * TPITCH + o] + smem[3 * kTile * TPITCH + o]);
   }
-  if (tid < kTile) { const double* v = smem + 4 * kTile * TPITCH; part[kTile * kTile + tid] = (v[tid] + v[kTile + tid]) + (v[2 * kTile + tid] + v[3 * kTile + tid]); }
+  if (DIAG && tid < kTile) { const double* v = smem + 4 * kTile * TPITCH; part[kTile * kTile + tid] = (v[tid] + v[kTile + tid]) + (v[2 * kTile + tid] + v[3 * kTile + tid]); }
+  if (tr && tid == 0) tr[5] = wall_clock64();
+}
+
+// kDepth = groups of four entries in flight per wave (18 loads each: vmcnt counts to 63).  Two waves per SIMD (two workgroups per CU) fit 256
+// registers with two groups in flight; three need 300.
+template <int kDepth, int kWavesPerSimd>
+__global__ __launch_bounds__(256, kWavesPerSimd) void schur_tile_kernel(const SolverDev sv, const double* __restrict__ Pm, const double* __restrict__ zz) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  // consecutive chunks share records (host: chunk numbering); workgroups go round-robin over the 8 XCDs, so XCD x
+  // walks the x-th eighth of the chunk list in order and its L2 sees the repeats
+  const int per_xcd = (sv.nchunk + 7) / 8;
+  const int chunk = sv.schur_linear ? (int)blockIdx.x : (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  if (chunk >= sv.nchunk) return;
+  const int tp = sv.chunk_tp[chunk];
+  if (sv.tp_I[tp] == sv.tp_J[tp]) schur_chunk<true, kDepth>(sv, Pm, zz, chunk, smem);
+  else schur_chunk<false, kDepth>(sv, Pm, zz, chunk, smem);
 }
 
 // one workgroup per group of a very long chunk list: partial[first] = sum of the group's partials, in list order
@@ -768,7 +850,7 @@ hipError_t launch_point_factor(const DeviceProblem& dp, const SolverDev& sv, dou
 template <int CD, int KC>
 static hipError_t launch_project_as(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {
   constexpr int REC = 8 + 2 * KC, OUT = CD * 3;
-  const size_t lds = (size_t)4 * 64 * ((REC > OUT ? REC : OUT) | 1) * sizeof(double);
+  const size_t lds = (size_t)4 * (64 * ((REC > OUT ? REC : OUT) | 1) + 32) * sizeof(double);
   const int grid = (int)((dp.N + 256 * kProjectChunks - 1) / (256 * kProjectChunks));
   hipError_t e = allow_dynamic_lds(project_kernel<CD, KC>, lds);
   if (e != hipSuccess) return e;
@@ -803,16 +885,16 @@ hipError_t launch_clear_system(const SolverDev& sv, hipStream_t st) {
 hipError_t launch_schur_blocks(const DeviceProblem& dp, const SolverDev& sv, double radius, hipStream_t st) {
   if (sv.nchunk > 0) {
     // dynamic LDS: max(slot table of a chunk, four partial tiles + rhs partials)
-    const size_t table = (size_t)kSchurChunk * (2 * (kTile / sv.CD) * sizeof(int32_t) + 3 * sizeof(double));
+    const size_t table = (size_t)kSchurOffBytes + kSchurMskBytes + (size_t)kSchurChunk * 3 * sizeof(double);
     const size_t tiles = (size_t)(4 * kTile * (kTile + 1) + 4 * kTile) * sizeof(double);
     const size_t lds = table > tiles ? table : tiles;
     const dim3 grid(8 * ((sv.nchunk + 7) / 8));
-    if (sv.CD == 12) {
-      hipError_t e = allow_dynamic_lds(schur_tile_kernel<12>, lds); if (e != hipSuccess) return e;
-      hipLaunchKernelGGL(schur_tile_kernel<12>, grid, dim3(256), lds, st, sv, sv.Pm, sv.z);
+    if (sv.schur_variant == 1) {   // (RSBA_SCHUR_VARIANT=1: three groups in flight, one wave per SIMD; 4 / 5: ablations of variant 0)
+      hipError_t e = allow_dynamic_lds(schur_tile_kernel<3, 1>, lds); if (e != hipSuccess) return e;
+      hipLaunchKernelGGL((schur_tile_kernel<3, 1>), grid, dim3(256), lds, st, sv, sv.Pm, sv.z);
     } else {
-      hipError_t e = allow_dynamic_lds(schur_tile_kernel<6>, lds); if (e != hipSuccess) return e;
-      hipLaunchKernelGGL(schur_tile_kernel<6>, grid, dim3(256), lds, st, sv, sv.Pm, sv.z);
+      hipError_t e = allow_dynamic_lds(schur_tile_kernel<2, 2>, lds); if (e != hipSuccess) return e;
+      hipLaunchKernelGGL((schur_tile_kernel<2, 2>), grid, dim3(256), lds, st, sv, sv.Pm, sv.z);
     }
     { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; }
   }

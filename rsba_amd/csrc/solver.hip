@@ -80,6 +80,7 @@ struct Solver {
   int32_t* d_obs_slot = nullptr;
   double *d_gpose = nullptr, *d_gpoint = nullptr;
   int64_t num_pairs = 0;
+  int64_t schur_launches = 0;                                         // launches of the Schur kernel since the plan was built (statistics)
   int num_reduced_blocks = 0, num_reduced_params = 0, num_priors_reduced = 0;
   double* border = nullptr, *ubuf = nullptr, *ratio4 = nullptr;      // free interFrameRatio: its column of S [npad], the first solve's result, {h, g, b.u, b.v}
   PosePriorDev pp{};                                                  // per-pose priors: linearisation of the priorPoses coordinates
@@ -188,7 +189,6 @@ int32_t build_solver(rsba_handle* h) {
   const int64_t NVG = (int64_t)vgroup_point.size();
   sv.nvgroups = NVG;
   const int64_t NS = N + NVG * NPF;
-  if ((NS + 1) * (int64_t)CD * 3 >= ((int64_t)1 << 32)) return rsba_set_error(RSBA_ERR_UNSUPPORTED, "more than 2^32 doubles of P records: the Schur kernel indexes them with 32 bits");
   std::vector<int32_t> slot_frame(NS), slot_point(NS);
   for (int64_t x = 0; x < N; ++x) slot_frame[x] = real_frame[x];
   for (int j = 0; j < M; ++j) for (int64_t x = point_ptr[j]; x < point_ptr[j + 1]; ++x) slot_point[x] = j;
@@ -211,6 +211,7 @@ int32_t build_solver(rsba_handle* h) {
   // to be 85 % of the symbolic phase): group g of point j covers one tile and one layer and owns FT slot entries.
   std::vector<int64_t> pt_group(M + 1, 0);     // groups of point j: [pt_group[j], pt_group[j+1])
   std::vector<int32_t> g_tile, g_rows;          // tile of each group; FT slots per group (NS = not observed)
+  std::vector<int32_t> slot_gpos(NS);            // group * FT + position of every slot: where its P record goes
   g_tile.reserve((size_t)N / 2); g_rows.reserve((size_t)N * 2);
   std::vector<int64_t> pslots;
   for (int j = 0; j < M; ++j) {
@@ -226,9 +227,12 @@ int32_t build_solver(rsba_handle* h) {
         g_rows.insert(g_rows.end(), FT, (int32_t)NS);   // NS = the all-zero record behind the last slot: "not observed"
       }
       g_rows[(tile_first + layer) * FT + pos] = (int32_t)sl;
+      slot_gpos[sl] = (int32_t)((tile_first + layer) * FT + pos);
     }
     pt_group[j + 1] = (int64_t)g_tile.size();
   }
+  sv.ngroups = (int64_t)g_tile.size();
+  if ((sv.ngroups + 1) * (int64_t)kTile * 3 >= ((int64_t)1 << 32)) return rsba_set_error(RSBA_ERR_UNSUPPORTED, "more than 2^32 doubles of P records: the Schur kernel indexes them with 32 bits");
   const bool dense_keys = (int64_t)nt * nt <= (int64_t)1 << 26;
   std::vector<int64_t> dense_cnt; std::unordered_map<int64_t, int64_t> sparse_cnt;
   if (dense_keys) dense_cnt.assign((size_t)nt * nt, -1);
@@ -514,44 +518,48 @@ int32_t build_solver(rsba_handle* h) {
   for (int l = nlev - 1; l >= 0; --l)
     for (int d = s->lev_diag_ptr[l]; d < s->lev_diag_ptr[l + 1]; ++d) { s->tasks.push_back(kTaskBack); s->tasks.push_back(d); }
   tick("tasks");
-  // Chunks of the Schur kernel (one workgroup each): at most kSchurChunk consecutive entries of one tile pair.
-  // The points of tile row I are cut into blocks of kSchurChunk (the entry list of the diagonal pair (I, I) holds
-  // them all), every pair (I, J) of the row is cut at the same point boundaries, and the chunks are numbered
-  // row by row, block by block, J innermost: consecutive chunks then read the SAME A_j(I) records against
-  // different A_j(J), and the kernel's blockIdx -> chunk map keeps consecutive chunks on one XCD, whose L2 serves
-  // the repeats (each record is otherwise fetched once per tile pair it takes part in: 4.8 GB per 1k-camera
-  // iteration).  Per tile pair the chunk ids are listed in entry order for the merge kernel.
+  // Chunks of the Schur kernel (one workgroup each): at most kSchurChunk consecutive entries of one tile pair, numbered tile
+  // pair by tile pair in (I, J) order — the pairs of one tile row, which read the same A_j(I) groups, next to each other; the
+  // kernel's blockIdx -> chunk map keeps consecutive chunks on one XCD.  What was measured around this choice (C4, round 3):
+  //   * this numbering: 40 % L2 hits, 2.5 GB from the fabric per launch, 4 975 chunks, kernel 0.53 ms — its MFMA loops run at
+  //     88 % of the matrix pipe (two waves per SIMD), the rest is tables / epilogue (14 %) and the ramp-down of the launch;
+  //   * point-block-major (RSBA_SCHUR_BLOCK=<points>: every tile pair cut at the same blocks of consecutive points, all pairs of
+  //     a block next to each other — rsba numbers tracks in the order the video first sees them, so a block spans a few tiles
+  //     and an XCD's L2 holds its records): 80 % L2 hits, 0.76 GB from the fabric, but 8 700 shorter chunks: 0.60 ms;
+  //   * equal parts of up to 1024 entries launched longest first, wherever their records are: 3 100 chunks, 0.67 ms — the
+  //     loops then wait for memory (2.2 us per group of four entries instead of 1.5).
+  // Per tile pair the chunk ids are listed in entry order for the merge kernel.
   std::vector<int32_t> chunk_tp, chunk_n; std::vector<int64_t> chunk_e0;
   std::vector<std::vector<int32_t>> pair_chunks(ntp);
   {
-    std::vector<int32_t> row_pairs;
-    int t = 0;
-    while (t < ntp) {
-      const int I = tp_I[t];
-      row_pairs.clear();
-      int tdiag = -1;
-      for (; t < ntp && tp_I[t] == I; ++t) { row_pairs.push_back(t); if (tp_J[t] == I) tdiag = t; }
-      // point boundaries from the diagonal pair's entry list (every observed point of the row is in it)
-      std::vector<int32_t> bounds;   // first point index of each block
-      if (tdiag >= 0) for (int64_t q = tp_ptr[tdiag]; q < tp_ptr[tdiag + 1]; q += kSchurChunk) bounds.push_back(ent_pt[q] & 0x7fffffff);
-      if (bounds.empty()) bounds.push_back(0);
-      bounds[0] = 0;
-      std::vector<int64_t> cursor(row_pairs.size());
-      for (size_t x = 0; x < row_pairs.size(); ++x) cursor[x] = tp_ptr[row_pairs[x]];
-      for (size_t c = 0; c < bounds.size(); ++c) {
-        const int64_t next_point = c + 1 < bounds.size() ? bounds[c + 1] : std::numeric_limits<int64_t>::max();
-        for (size_t x = row_pairs.size(); x-- > 0;) {          // J descending: the diagonal pair first
-          const int tp_ = row_pairs[x];
-          int64_t q = cursor[x];
-          const int64_t qend = tp_ptr[tp_ + 1];
-          while (q < qend && (ent_pt[q] & 0x7fffffff) < next_point) ++q;
-          for (int64_t q0 = cursor[x]; q0 < q; q0 += kSchurChunk) {
-            pair_chunks[tp_].push_back((int32_t)chunk_tp.size());
-            chunk_tp.push_back(tp_); chunk_e0.push_back(q0); chunk_n.push_back((int32_t)std::min<int64_t>(kSchurChunk, q - q0));
-          }
-          cursor[x] = q;
+    int64_t kBlock = std::max<int64_t>(M, 1);
+    if (const char* e = std::getenv("RSBA_SCHUR_BLOCK")) kBlock = std::max(16, std::atoi(e));   // tuning aid
+    // per tile pair the cursor into its entry list (entries are in point order); pairs that still have entries, in (I, J) order
+    std::vector<int64_t> cursor(tp_ptr.begin(), tp_ptr.end() - 1);
+    std::vector<int32_t> live; live.reserve(64);
+    int next_pair = 0;           // pairs enter `live` when the block reaches their first point
+    std::vector<int32_t> by_first(ntp);
+    for (int t = 0; t < ntp; ++t) by_first[t] = t;
+    auto first_point = [&](int t) { return tp_ptr[t] < tp_ptr[t + 1] ? (ent_pt[tp_ptr[t]] & 0x7fffffff) : std::numeric_limits<int32_t>::max(); };
+    std::stable_sort(by_first.begin(), by_first.end(), [&](int a, int b) { return first_point(a) < first_point(b); });
+    for (int64_t p0 = 0; p0 < M; p0 += kBlock) {
+      const int64_t p1 = std::min<int64_t>(p0 + kBlock, M);
+      while (next_pair < ntp && first_point(by_first[next_pair]) < p1) live.push_back(by_first[next_pair++]);
+      std::sort(live.begin(), live.end());   // (I, J) order inside the block: the pairs of one tile row next to each other
+      size_t keep = 0;
+      for (size_t x = 0; x < live.size(); ++x) {
+        const int tp_ = live[x];
+        int64_t q = cursor[tp_];
+        const int64_t qend = tp_ptr[tp_ + 1];
+        if (p1 >= M) q = qend; else while (q < qend && (ent_pt[q] & 0x7fffffff) < p1) ++q;
+        for (int64_t q0 = cursor[tp_]; q0 < q; q0 += kSchurChunk) {
+          pair_chunks[tp_].push_back((int32_t)chunk_tp.size());
+          chunk_tp.push_back(tp_); chunk_e0.push_back(q0); chunk_n.push_back((int32_t)std::min<int64_t>(kSchurChunk, q - q0));
         }
+        cursor[tp_] = q;
+        if (q < qend) live[keep++] = tp_;
       }
+      live.resize(keep);
     }
   }
   // A pair with very many chunks (the diagonal pair of the intrinsics pseudo tile has one per 512 points of the whole
@@ -573,6 +581,9 @@ int32_t build_solver(rsba_handle* h) {
   sv.npremerge = (int)pm_ptr.size() - 1;
   sv.nchunk = (int)chunk_tp.size(); sv.ntp = ntp; sv.FT = FT;
   { const char* e = std::getenv("RSBA_SCHUR_LINEAR"); sv.schur_linear = e && e[0] == '1'; }
+  { const char* e = std::getenv("RSBA_SCHUR_VARIANT"); sv.schur_variant = e ? std::atoi(e) : 0; }
+  sv.schur_trace = nullptr;
+  if (std::getenv("RSBA_SCHUR_TRACE")) { if (int32_t rc_ = s_alloc(s, &sv.schur_trace, 8 * (size_t)std::max(sv.nchunk, 1))) return rc_; }
   std::vector<uint8_t> has_prior((size_t)FR + 1, 0);
   for (int32_t f : h->prior_frames) has_prior[f] = 1;
   const int64_t ucross_base = ((int64_t)FR + (int64_t)NPF * FR + (int64_t)NIB * NPF * NPF) * CD * CD;   // behind the J^T J blocks in sv.U
@@ -659,7 +670,28 @@ int32_t build_solver(rsba_handle* h) {
   if ((rc = s_upload_const(s, &sv.tp_J, tp_J))) return rc;
   if ((rc = s_upload_const(s, &sv.tp_ptr, tp_ptr))) return rc;
   if ((rc = s_upload_const(s, &sv.ent_groups, ent_groups))) return rc;
-  if ((rc = s_upload_const(s, &sv.group_slots, g_rows))) return rc;
+  if ((rc = s_upload_const(s, &sv.slot_gpos, slot_gpos))) return rc;
+  {
+    std::vector<uint8_t> group_mask((size_t)sv.ngroups + 1, 0);
+    for (int64_t gq = 0; gq < sv.ngroups; ++gq)
+      for (int pos = 0; pos < FT; ++pos) if (g_rows[(size_t)gq * FT + pos] != (int32_t)NS)
+        for (int row = pos * CD; row < (pos + 1) * CD; row += 4) group_mask[gq] |= (uint8_t)(1u << (row / 16));
+    std::vector<uint16_t> ent_mask((size_t)nent);
+    auto fill_masks = [&](int64_t a, int64_t b) {
+      for (int64_t e = a; e < b; ++e) {
+        const unsigned ma = group_mask[ent_groups[2 * (size_t)e]], mb = group_mask[ent_groups[2 * (size_t)e + 1]];
+        unsigned pm = 0;
+        for (int I = 0; I < 3; ++I) if ((ma >> I) & 1u) pm |= mb << (3 * I);
+        ent_mask[(size_t)e] = (uint16_t)pm;
+      }
+    };
+    if (nthreads > 1) {
+      std::vector<std::thread> pool;
+      for (int t = 0; t < nthreads; ++t) pool.emplace_back(fill_masks, nent * t / nthreads, nent * (t + 1) / nthreads);
+      for (auto& th : pool) th.join();
+    } else fill_masks(0, nent);
+    if ((rc = s_upload_const(s, &sv.ent_mask, ent_mask))) return rc;
+  }
   if ((rc = s_upload_const(s, &sv.ent_pt, ent_pt))) return rc;
   if ((rc = s_upload_const(s, &sv.inprog_pose, inprog_pose))) return rc;
   if ((rc = s_upload_const(s, &sv.inprog_point, inprog_point))) return rc;
@@ -752,8 +784,10 @@ int32_t build_solver(rsba_handle* h) {
   if ((rc = s_alloc(s, &sv.diag_p, (size_t)M * 3))) return rc;
   if ((rc = s_alloc(s, &sv.Linv, (size_t)M * 6))) return rc;
   if ((rc = s_alloc(s, &sv.z, (size_t)M * 3))) return rc;
-  if ((rc = s_alloc(s, &sv.Pm, (size_t)(NS + 1) * CD * 3))) return rc;
-  HIP_TRY(hipMemset(sv.Pm + (size_t)NS * CD * 3, 0, (size_t)CD * 3 * sizeof(double)));   // record NS: "not observed"
+  if ((rc = s_alloc(s, &sv.Pm, (size_t)(sv.ngroups + 1) * kTile * 3))) return rc;   // (+ the all-zero group)
+  HIP_TRY(hipMemsetAsync(sv.Pm, 0, (size_t)(sv.ngroups + 1) * kTile * 3 * sizeof(double), h->stream));   // rows of frames that do not see the point stay zero for good: nothing ever writes them
+  if ((rc = s_alloc(s, &sv.schur_mfma_count, 1))) return rc;
+  HIP_TRY(hipMemsetAsync(sv.schur_mfma_count, 0, sizeof(unsigned long long), h->stream));
 
   if ((rc = s_alloc(s, &sv.S, (size_t)sv.nslots * kTile * kTile + (size_t)sv.npad))) return rc;
   sv.rhs = sv.S + (size_t)sv.nslots * kTile * kTile;   // one buffer = exchange payload (2)
@@ -932,6 +966,7 @@ int32_t reduce_system(rsba_handle* h, double radius) {
     PhaseScope ps(h, RSBA_PHASE_SCHUR);
     HIP_TRY(launch_clear_system(sv, st));
     HIP_TRY(launch_schur_blocks(h->dp, sv, radius, st));
+    ++s->schur_launches;
     if (sv.lead) HIP_TRY(launch_pose_prior_reduce(h->dp, sv, s->pp, radius, st));   // the priorPoses blocks leave the system like points
   }
   // exchange (2): partial reduced camera systems -> the full one on every rank (then factored redundantly)
@@ -999,6 +1034,11 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 
 void rsba_destroy_solver(rsba_handle* h) {
   if (!h || !h->solver) return;
+  if (const char* path = h->solver->sv.schur_trace ? std::getenv("RSBA_SCHUR_TRACE") : nullptr) {   // debugging aid: stamps of the last Schur launch
+    std::vector<long long> tr(8 * (size_t)h->solver->sv.nchunk);
+    if (hipMemcpy(tr.data(), h->solver->sv.schur_trace, tr.size() * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess)
+      if (FILE* f = std::fopen(path, "wb")) { std::fwrite(tr.data(), sizeof(long long), tr.size(), f); std::fclose(f); }
+  }
   for (void* p : h->solver->allocs) (void)hipFree(p);
   delete h->solver;
   h->solver = nullptr;
@@ -1077,6 +1117,10 @@ extern "C" int32_t rsba_get_plan_stats(rsba_handle* h, rsba_plan_stats* out) {
   int32_t rc = build_solver(h);
   if (rc) return rc;
   *out = h->solver->stats;
+  unsigned long long issued = 0;
+  HIP_TRY(hipMemcpyAsync(&issued, h->solver->sv.schur_mfma_count, sizeof issued, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  out->schur_mfma_issued = (int64_t)issued; out->schur_launches = h->solver->schur_launches;
   return RSBA_OK;
 }
 

@@ -49,9 +49,13 @@ struct SolverDev {
   const int32_t* tp_J;
   const int64_t* tp_ptr;        // [ntp+1] into the entry list
   const int32_t* ent_groups;    // [nent][2] the point's (tile, layer) group on the I side and on the J side
-  const int32_t* group_slots;   // [groups][FT] observation slot of the point in each frame of the group's tile (the zero record if none)
+  const int32_t* slot_gpos;     // [N + virtual] group * FT + position in the tile: where the slot's P record lives in Pm
+  int64_t ngroups;              // (point, tile, layer) groups: each owns one kTile x 3 block of Pm (one more, all zero, sits behind the last: padding entries of the Schur chunks)
+  const uint16_t* ent_mask;     // [nent] bit 3 I + J: block rows 16 I .. of the I-side group and 16 J .. of the J-side group both contain a frame that sees the point
   const int32_t* ent_pt;        // [nent] point index; top bit set = the entry carries the rhs term P z
   int schur_linear;             // debugging (RSBA_SCHUR_LINEAR=1): blockIdx -> chunk without the XCD map
+  long long* schur_trace;       // debugging (RSBA_SCHUR_TRACE=<file>): [nchunk][8] {workgroup, xcc/cu id, start, tables staged, loop done, end (100 MHz ticks), entries, -} of the last launch
+  int schur_variant;            // tuning aid (RSBA_SCHUR_VARIANT): 0 = two groups in flight, two waves per SIMD; 1 = three groups, one wave
   int nchunk;                   // workgroups of the Schur kernel: kSchurChunk entries each
   const int32_t* chunk_tp;      // [nchunk]
   const int64_t* chunk_e0;      // [nchunk] first entry of the chunk
@@ -77,7 +81,10 @@ struct SolverDev {
   double* diag_p;               // [M*3]
   double* Linv;                 // [M][6]  lower-triangular inverse of chol(V')
   double* z;                    // [M][3]
-  double* Pm;                   // [N + M*NPF][CD*3]  point-major, virtual records behind the real ones
+  double* Pm;                   // [ngroups][3][kTile]  P records by (point, tile) group, component-major: row c of group g holds coordinate c of the
+                                //   point against the kTile camera-side rows of the tile (FT frames x CD; zero where a frame does not see the point) —
+                                //   one 16-row operand slice of the Schur kernel's MFMAs is ONE aligned 128-B line
+  unsigned long long* schur_mfma_count;   // MFMAs the Schur kernel actually issued, summed over its launches (all-zero 16 x 16 operand blocks are skipped)
   double* S;                    // [nslots][kTile][kTile] packed tiles of the reduced camera system / its factor
   double* Lf;                   // [nslots][kTile][kTile] the factor's sub-diagonal tiles (S keeps the reduced system itself)
   double* zv;                   // [npad] forward solve z, directly followed by
