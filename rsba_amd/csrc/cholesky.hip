@@ -228,6 +228,80 @@ __device__ __forceinline__ dbl4_t ldl16_follow(const double* msg, int lane, long
   return w;
 }
 
+// Second wave, round-3 form.  The MFMA form above applies a pivot's multipliers to the identity with one rank-1 MFMA whose B operand
+// is a row of its own result: a chain of dependent MFMAs (81 cycles each) with an LDS message wait in every link — 285 cycles per
+// pivot against the 206 of the eliminating wave, so W trailed the last pivot of every 16-pivot block by ~2 400 cycles: a third of the
+// tile's time (tools/tile_factor_bench, round 2).  Nothing here needs the matrix pipe.  Lane c (< 16) keeps COLUMN c of
+// E = L'^-1 in sixteen registers; pivot jj adds (-m_i) E[jj][c] to the rows i > jj — its own register jj times multipliers that are
+// the same for every lane and come as broadcast reads of the message — 15 - jj independent FMAs, so the wave keeps pace with the
+// eliminating one; row jj is final the moment pivot jj has been applied and goes to W (scaled by d_jj^-1/2, whose Newton steps hide
+// the LDS latency of the next message) right away: what trails the last pivot is one reciprocal square root and one row.
+// Writes the full 16 x 16 block W(o.., o..) (zeros above the diagonal) into Wl.
+// 1/sqrt(x) from the hardware estimate y0 (good to ~2^-23) by one cubic step: e = 1 - x y0^2, y = y0 (1 + e/2 + 3 e^2/8); e^3 is far
+// below rounding.  Four dependent operations behind v_rsq_f64 (the two Newton steps of rsqrt_nr are ten).
+__device__ __forceinline__ double rsqrt_cubic(double x) {
+  const double y0 = __builtin_amdgcn_rsq(x);
+  const double e = fma(-x * y0, y0, 1.0);
+  return fma(y0 * e, fma(0.375, e, 0.5), y0);
+}
+__device__ __forceinline__ void ldl16_follow_rows(const double* msg, double* Wl, int o, int lane) {
+  typedef const volatile __attribute__((address_space(3))) double* lds_cvptr;
+  typedef double dbl2_t __attribute__((ext_vector_type(2)));
+  typedef const __attribute__((address_space(3))) dbl2_t* lds_c2ptr;
+  typedef __attribute__((address_space(3))) double* lds_ptr;
+  lds_cvptr vm = (lds_cvptr)msg;
+  lds_ptr wl = (lds_ptr)Wl;
+  if (lane >= 16) return;   // (the other lanes would only repeat the sixteen columns)
+  const int c = lane;
+  double e[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) e[i] = (i == c) ? 1.0 : 0.0;
+  // Software pipeline, one pivot deep: when message jj is seen its multipliers are REQUESTED (same address in every lane: broadcast
+  // reads, two cells each) and, while they travel, pivot jj - 1 — whose multipliers came in during the step before — is applied and
+  // row jj - 2 (final since then) scaled and stored.  The eliminating wave writes a message with ONE LDS store and the sixteen cells of
+  // lane group jj % 4 belong to one pass of it: once the pivot is there so are the multipliers; the compiler must not move their
+  // loads above the polling loop, though.
+  dbl2_t m2[2][8];
+  double pv[16];
+  double next = vm[msg_off(0)];   // the pivot of message jj sits in the cell of lane 16 (jj % 4) + jj; requested one step ahead, looked at when needed
+#pragma unroll
+  for (int jj = 0; jj <= 16; ++jj) {
+    if (jj < 16) {
+      const int cell = msg_off(jj) + 16 * (jj & 3);
+      double piv = next;
+      while (__ballot(!filled(piv)) != 0ull) piv = vm[cell + jj];
+      pv[jj] = piv;
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int h = 0; h < 8; ++h) if (2 * h + 1 > jj) m2[jj & 1][h] = *(lds_c2ptr)(msg + cell + 2 * h);
+      if (jj < 15) next = vm[msg_off(jj + 1) + 16 * ((jj + 1) & 3) + jj + 1];
+    }
+    if (jj >= 1) {   // pivot jj - 1
+      const int k = jj - 1;
+      // d_k^-1/2 (rsqrt_cubic, spelled out) is threaded through the row updates: its four dependent steps wait out their latencies
+      // behind independent FMAs.  Everything is pinned where it stands: left alone, the compiler turns the fifteen independent
+      // updates of a pivot into one dependent sum per row, formed right before the row is used — k FMA latencies on the chain.
+      const double x = pv[k];
+      double y0 = __builtin_amdgcn_rsq(x), t0 = 0.0, q0 = 0.0, p0 = 0.0;
+      asm volatile("" : "+v"(y0));
+#pragma unroll
+      for (int i = k + 1; i < 16; ++i) {
+        e[i] = fma(m2[k & 1][i >> 1][i & 1], e[k], e[i]); asm volatile("" : "+v"(e[i]));
+        const int step = i - k;
+        if (step == 2) { t0 = -x * y0; asm volatile("" : "+v"(t0)); }
+        if (step == 4) { t0 = fma(t0, y0, 1.0); asm volatile("" : "+v"(t0)); }                       // e = 1 - x y0^2
+        if (step == 6) { q0 = y0 * t0; p0 = fma(0.375, t0, 0.5); asm volatile("" : "+v"(q0), "+v"(p0)); }
+      }
+      const int nstep = 15 - k;   // (the pivots near the end of the block have too few updates to hide behind: the rest of the chain follows here)
+      if (nstep < 2) t0 = -x * y0;
+      if (nstep < 4) t0 = fma(t0, y0, 1.0);
+      if (nstep < 6) { q0 = y0 * t0; p0 = fma(0.375, t0, 0.5); }
+      const double rs = fma(q0, p0, y0);
+      wl[(o + k) * TP + o + c] = rs * e[k];   // row k has been final since pivot k - 1 (exact zeros right of the diagonal: E is lower triangular)
+    }
+  }
+}
+
 // the 16 x 16 block at (o, o) of a tile whose lower triangle is valid (LDS, pitch TP), mirrored into the accumulator layout
 __device__ __forceinline__ dbl4_t load_sym16(const double* D, int o, int lane) {
   const int c = lane & 15, g = lane >> 4;
@@ -270,7 +344,7 @@ __device__ __forceinline__ dbl4_t mm16_nn(const double* X, int xr, int xc, const
 // D, Wl, Tm, Lp must be the task's LDS buffers 0 .. 3 (the pivot messages live in idle rows of Tm and Lp, see the LDS map) and the
 // messages armed (arm_pivot_messages) before the barrier in front of this call.  All threads must call; ends with a barrier.  Returns (in the first wave)
 // false on a non-positive pivot.
-template <bool TRACE = false>
+template <bool TRACE = false, bool MFMA_FOLLOWER = false>
 __device__ __forceinline__ bool factor_invert_tile(double* D, double* Wl, double* Tm, double* Lp, int tid, long long* stamps = nullptr) {
   const int wave = tid >> 6, lane = tid & 63;
   const dbl4_t zero = {0.0, 0.0, 0.0, 0.0};
@@ -280,13 +354,13 @@ __device__ __forceinline__ bool factor_invert_tile(double* D, double* Wl, double
   double* msg = D;   // (D is the first LDS buffer of the task; the messages sit at msg_off() behind it)
   stamp();
   if (wave == 0) ok = ldl16_eliminate(load_sym16(D, 0, lane), msg, lane);
-  else if (wave == 1) put16(Wl, 0, 0, ldl16_follow(msg, lane, TRACE ? stamps + 16 : nullptr), lane);
+  else if (wave == 1) { if (MFMA_FOLLOWER) put16(Wl, 0, 0, ldl16_follow(msg, lane, TRACE ? stamps + 16 : nullptr), lane); else ldl16_follow_rows(msg, Wl, 0, lane); }
   stamp(); lds_barrier(); stamp();
   if (wave < 2) put16(Lp, 16 + 16 * wave, 0, mm16_nt(D, 16 + 16 * wave, 0, Wl, 0, 0, zero, 1.0, lane), lane);   // L_10, L_20
   else rearm_pivot_messages(D, lane, 8 * (wave - 2), 8 * (wave - 1));   // (both waves of block 0 are done with them; block 1 starts behind the next barrier)
   stamp(); lds_barrier(); stamp();
   if (wave == 0) ok = ldl16_eliminate(mm16_nt(Lp, 16, 0, Lp, 16, 0, load_sym16(D, 16, lane), -1.0, lane), msg, lane) && ok;
-  else if (wave == 1) put16(Wl, 16, 16, ldl16_follow(msg, lane), lane);
+  else if (wave == 1) { if (MFMA_FOLLOWER) put16(Wl, 16, 16, ldl16_follow(msg, lane), lane); else ldl16_follow_rows(msg, Wl, 16, lane); }
   else if (wave == 2) {
     put16(D, 32, 16, mm16_nt(Lp, 32, 0, Lp, 16, 0, load16(D, 32, 16, lane), -1.0, lane), lane);
     put16(Tm, 16, 0, mm16_nn(Lp, 16, 0, Wl, 0, 0, zero, 1.0, lane), lane);                                         // T_10 = L_10 W_00
@@ -298,7 +372,7 @@ __device__ __forceinline__ bool factor_invert_tile(double* D, double* Wl, double
   else rearm_pivot_messages(D, lane, 0, 16);
   stamp(); lds_barrier(); stamp();
   if (wave == 0) ok = ldl16_eliminate(mm16_nt(Lp, 32, 16, Lp, 32, 16, load_sym16(D, 32, lane), -1.0, lane), msg, lane) && ok;
-  else if (wave == 1) put16(Wl, 32, 32, ldl16_follow(msg, lane), lane);
+  else if (wave == 1) { if (MFMA_FOLLOWER) put16(Wl, 32, 32, ldl16_follow(msg, lane), lane); else ldl16_follow_rows(msg, Wl, 32, lane); }
   else if (wave == 2) put16(Tm, 32, 16, mm16_nn(Lp, 32, 16, Wl, 16, 16, zero, 1.0, lane), lane);                    // T_21 = L_21 W_11
   else put16(Tm, 32, 0, mm16_nn(Lp, 32, 16, Wl, 16, 0, load16(Tm, 32, 0, lane), 1.0, lane), lane);                  // T_20 += L_21 W_10
   stamp(); lds_barrier(); stamp();

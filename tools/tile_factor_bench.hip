@@ -31,7 +31,9 @@ __global__ __launch_bounds__(256) void tile_kernel(const double* __restrict__ Di
       lds_barrier();
       invert_lower_blocked(D, dinv, Wl, Tm, tid);
     } else {
-      if (VARIANT == 2) factor_invert_tile<true>(D, Wl, Tm, Lp, tid, stamps); else factor_invert_tile(D, Wl, Tm, Lp, tid);   // 2: with phase stamps (every repetition: warm code)
+      if (VARIANT == 2) factor_invert_tile<true>(D, Wl, Tm, Lp, tid, stamps);   // 2: with phase stamps (every repetition: warm code)
+      else if (VARIANT == 3) factor_invert_tile<false, true>(D, Wl, Tm, Lp, tid);   // 3: round 2's second wave (rank-1 MFMAs on the identity)
+      else factor_invert_tile(D, Wl, Tm, Lp, tid);
     }
     const long long t1 = wall_clock64();
     total += t1 - t0;
@@ -44,7 +46,7 @@ __global__ __launch_bounds__(256) void tile_kernel(const double* __restrict__ Di
 
 // the two waves of one 16 x 16 diagonal block step on their own: MODE 0 both, 1 the eliminating wave alone, 2 the following wave alone
 // on messages that are already there.  FW = which wave of the workgroup follows.
-template <int MODE, int FW>
+template <int MODE, int FW, bool ROWS = false>
 __global__ __launch_bounds__(256) void pair_kernel(const double* __restrict__ Din, double* __restrict__ out, long long* t, int reps) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -60,7 +62,10 @@ __global__ __launch_bounds__(256) void pair_kernel(const double* __restrict__ Di
     if (MODE == 2 && it == 0) { if (wave == 0) ldl16_eliminate(d0, msg, lane); __syncthreads(); }
     const long long c0 = clock64();
     if (wave == 0 && MODE != 2) { dbl4_t d = d0; asm volatile("" : "+v"(d)); const bool ok = ldl16_eliminate(d, msg, lane); acc[0] += ok; lead += clock64() - c0; }
-    if (wave == FW && MODE != 1) { acc += ldl16_follow(msg, lane); foll += clock64() - c0; }
+    if (wave == FW && MODE != 1) {
+      if (ROWS) { ldl16_follow_rows(msg, smem + kBuf, 0, lane); acc[0] += smem[kBuf + lane]; } else acc += ldl16_follow(msg, lane);
+      foll += clock64() - c0;
+    }
     __syncthreads();
     total += clock64() - c0;
   }
@@ -95,12 +100,14 @@ int main() {
   hipFuncSetAttribute(reinterpret_cast<const void*>(tile_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipFuncSetAttribute(reinterpret_cast<const void*>(tile_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipFuncSetAttribute(reinterpret_cast<const void*>(tile_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(tile_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int reps = 2000;
-  for (int variant = 0; variant < 3; ++variant) {
+  for (int variant = 0; variant < 4; ++variant) {
     for (int pass = 0; pass < 2; ++pass) {   // first pass warms up
       if (variant == 0) hipLaunchKernelGGL(tile_kernel<0>, dim3(1), dim3(256), lds, 0, dA, dW, dT, reps, dS);
       else if (variant == 1) hipLaunchKernelGGL(tile_kernel<1>, dim3(1), dim3(256), lds, 0, dA, dW, dT, reps, dS);
-      else hipLaunchKernelGGL(tile_kernel<2>, dim3(1), dim3(256), lds, 0, dA, dW, dT, reps, dS);
+      else if (variant == 2) hipLaunchKernelGGL(tile_kernel<2>, dim3(1), dim3(256), lds, 0, dA, dW, dT, reps, dS);
+      else hipLaunchKernelGGL(tile_kernel<3>, dim3(1), dim3(256), lds, 0, dA, dW, dT, reps, dS);
       hipDeviceSynchronize();
     }
     std::vector<double> W(n * n); long long ticks = 0;
@@ -114,7 +121,7 @@ int main() {
       err_ref = std::fmax(err_ref, std::fabs(W[i * n + j] - Wref[i * n + j])); wmax = std::fmax(wmax, std::fabs(Wref[i * n + j]));
     }
     std::printf("%s: %.3f us per tile (%d reps), |W A W^T - I| = %.2e, |W - W_host| = %.2e (|W| = %.2e), %s\n",
-                variant == 0 ? "lane-per-row potrf + blocked inverse" : variant == 1 ? "MFMA-pivot LDL^T on two waves       " : "  the same with phase stamps        ", ticks * 0.01 / reps, reps, err_id, err_ref, wmax,
+                variant == 0 ? "lane-per-row potrf + blocked inverse" : variant == 1 ? "MFMA-pivot LDL^T, W by rows (round 3)" : variant == 2 ? "  the same with phase stamps        " : "MFMA-pivot LDL^T, W by MFMAs (round 2)", ticks * 0.01 / reps, reps, err_id, err_ref, wmax,
                 hipGetErrorString(hipGetLastError()));
   }
   {
@@ -131,6 +138,8 @@ int main() {
     run_pair(pair_kernel<0, 1>, "both, wave 1 follows");
     run_pair(pair_kernel<0, 2>, "both, wave 2 follows");
     run_pair(pair_kernel<0, 3>, "both, wave 3 follows");
+    run_pair(pair_kernel<2, 1, true>, "W by rows: following wave alone (messages there)");
+    run_pair(pair_kernel<0, 1, true>, "W by rows: both, wave 1 follows");
   }
   long long hs[64]; hipMemcpy(hs, dS, sizeof hs, hipMemcpyDeviceToHost);
   std::printf("phases of the last MFMA-pivot tile (clock64 ticks since entry; pairs = before / after each barrier):");
