@@ -141,6 +141,19 @@ def roofline_lm(prob, dp, iters, capi):
     for r in rows:
         if r["phase"] in notes:
             r["note"] = notes[r["phase"]]
+    # matrix-pipe utilisation by counter (north_star: "MFMA utilisation against gfx950 peak"): SQ_VALU_MFMA_BUSY_CYCLES of the phase's
+    # kernel over the SIMD cycles of its dispatch, from the committed PMC pass (a separate rocprofv3 --pmc run; tools/profile_round.sh)
+    cfg = "C5" if prob.num_frames >= 4000 else ("C4" if prob.num_frames >= 1000 else "C2")
+    for pr in sorted((p for p in os.listdir(os.path.join(ROOT, "profiles")) if os.path.exists(os.path.join(ROOT, "profiles", p, "pmc_mfma_summary.json"))), reverse=True):
+        with open(os.path.join(ROOT, "profiles", pr, "pmc_mfma_summary.json")) as fh:
+            pm = json.load(fh).get(cfg, {})
+        for r in rows:
+            k = {"schur": "schur_tile_kernel", "cholesky": "chol_dag_kernel", "eval_lm": "eval_kernel"}.get(r["phase"])
+            hit = next((v for name, v in pm.items() if k and k in name and (r["phase"] != "eval_lm" or ", 2>" in name)), None)
+            if hit:
+                r["mfma_busy_frac"] = hit["mfma_busy_frac"]
+                r["mfma_busy_source"] = f"profiles/{pr}/pmc_mfma_summary.json (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE per XCD x 1024 SIMDs))"
+        break
     return {"phases": rows, "plan": st, "sum_ms_per_lm_iteration": sum(r["ms_per_lm_iteration"] for r in rows)}
 
 
@@ -159,6 +172,35 @@ def next_rows(prob, dp, device):
             r = fn()
         return (time.perf_counter() - t0) / reps, r
 
+    try:   # BASELINE configs 2-3 (100 frames, 10k points): evaluation kernel, LM iteration, and the whole BA() call of a fresh handle
+        from rsba_amd.scene import make_config
+        c2 = make_config("C2").problem
+        p0, x0 = c2.poses.copy(), c2.points.copy()
+        t0 = time.perf_counter()
+        d2 = capi.DeviceProblem(c2, device=device)
+        t_create = time.perf_counter() - t0
+        opt20 = capi.default_options(max_num_iterations=20)     # what VideoSfMHandler::BA asks for (VideoSfMHandler.cc:582)
+        t0 = time.perf_counter()
+        s_first, _ = d2.solve(opt20)
+        t_first = time.perf_counter() - t0
+        eval_ms = d2.time_evaluate(True, warmup=20, iters=50)
+        c2.poses[:], c2.points[:] = p0, x0
+        d2.upload_parameters()
+        fixed = capi.default_options(max_num_iterations=12, function_tolerance=0.0, parameter_tolerance=0.0, gradient_tolerance=0.0)
+        d2.solve(fixed)
+        c2.poses[:], c2.points[:] = p0, x0
+        d2.upload_parameters()
+        t0 = time.perf_counter()
+        s2, _ = d2.solve(fixed)
+        t_steady = time.perf_counter() - t0
+        d2.close()
+        out["c2"] = {"observations": int(c2.num_observations), "eval_kernel_ms": eval_ms, "obs_evals_per_s": c2.num_observations / (eval_ms * 1e-3),
+                     "ms_per_lm_iteration": t_steady / max(1, s2.num_iterations - 1) * 1e3,
+                     "end_to_end_ba": {"rsba_create_ms": t_create * 1e3, "first_solve_ms": t_first * 1e3, "iterations": int(s_first.num_iterations - 1),
+                                       "total_ms": (t_create + t_first) * 1e3, "final_cost": s_first.final_cost,
+                                       "note": "fresh handle: upload + index check, symbolic phase, allocations, up to 20 LM iterations with Ceres' default tolerances, parameters back on the host"}}
+    except Exception as e:  # noqa: BLE001
+        out["c2"] = {"error": repr(e)}
     try:   # f2: validate every observation of the workload (kernel + the [N] flag copy back)
         dt, flags = timed(lambda: dp.validate_observations(16.0, 0.0))
         out["f2_validate"] = {"ms_per_call": dt * 1e3, "observations": int(prob.num_observations), "valid": int(flags.sum())}

@@ -6,6 +6,7 @@
 // array of the 1k-camera scene is 2.4 MB), and every output component is one coalesced 512-B store
 // per wave into the component-major res/jac arrays.  HBM-bound: 280 B/observation, ~0.6 kflop.
 #include "device_state.hpp"
+#include "lm_record.hpp"
 #include "obs_math.hpp"
 
 namespace rsba {
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(kEvalBlock) void eval_kernel(const DeviceProblem dp
     const double2 xy = dp.xy[ic];
     const int f = dp.obs_frame[ic];
     const int j = dp.obs_point[ic];
-    double pose[CD], X[3], cam[9];
+    double pose[CD];
     if (staged) {
 #pragma unroll
       for (int k = 0; k < CD; ++k) pose[k] = s_pose[(f - f_lo) * CD + k];
@@ -73,59 +74,42 @@ __global__ __launch_bounds__(kEvalBlock) void eval_kernel(const DeviceProblem dp
 #pragma unroll
       for (int k = 0; k < CD; ++k) pose[k] = dp.poses[(size_t)f * CD + k];
     }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) X[k] = dp.points[(size_t)j * 3 + k];
-    const int ci = (dp.NI == 1) ? 0 : dp.frame_intr[f];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) cam[k] = dp.intr[(size_t)ci * 9 + k];
-
-    const Model m = {dp.shutter, dp.scan0, dp.scan1, dp.interp_rotation};
     ObsOut<CAL, P> o;
-    eval_observation<CAL, P, MODE != kResidualOnly>(m, cam, pose, X, xy.x, xy.y, o);
-
-    if (valid && !o.ok) nfail = 1.0;
-    // Ceres 1.9 ResidualBlock::Evaluate: cost = rho0/2 from the uncorrected residual
-    const double s = o.r[0] * o.r[0] + o.r[1] * o.r[1];
-    double rho[3] = {s, 1.0, 0.0};
-    if (dp.huber_a > 0.0) huber_rho(dp.huber_a, s, rho);
-    double half_rho = (o.ok && valid) ? 0.5 * rho[0] : 0.0;
-
+    double half_rho = 0.0;
     if (MODE == kLmJacobian) {
-      double sc[K];
-      if (!CAL) {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) sc[k] = dp.scale_intr[(size_t)ci * 9 + k];
-      }
+      double psc[CD];
       if (staged) {
 #pragma unroll
-        for (int k = 0; k < CD; ++k) sc[OFF_POSE + k] = s_scale[(f - f_lo) * CD + k];
+        for (int k = 0; k < CD; ++k) psc[k] = s_scale[(f - f_lo) * CD + k];
       } else {
 #pragma unroll
-        for (int k = 0; k < CD; ++k) sc[OFF_POSE + k] = dp.scale_pose[(size_t)f * CD + k];
+        for (int k = 0; k < CD; ++k) psc[k] = dp.scale_pose[(size_t)f * CD + k];
       }
-#pragma unroll
-      for (int k = 0; k < 3; ++k) sc[OFF_PT + k] = dp.scale_point[(size_t)j * 3 + k];
-      // a residual block whose parameter blocks are all constant leaves the reduced program; its
-      // cost is carried as fixed_cost.  Column scale 0 <=> fixed coordinate.
-      bool dropped = true;
-#pragma unroll
-      for (int k = 0; k < K; ++k) dropped = dropped && (sc[k] == 0.0);
-      // Corrector (Ceres 1.9 corrector.cc) for rho'' <= 0, which always holds for Huber: residual
-      // and Jacobian rows are scaled by sqrt(rho').
-      const double sr1 = sqrt(rho[1]);
-      o.r[0] *= sr1; o.r[1] *= sr1;
-#pragma unroll
-      for (int k = 0; k < K; ++k) { const double c = sr1 * sc[k]; o.J[0][k] *= c; o.J[1][k] *= c; }
+      bool dropped;
+      lm_observation<CAL, P>(dp, f, j, xy.x, xy.y, pose, psc, o, half_rho, dropped);   // loss-corrected, masked, scaled (lm_record.hpp)
+      if (valid && !o.ok) nfail = 1.0;
+      if (!valid) half_rho = 0.0;
       if (dropped) { fixed = half_rho; half_rho = 0.0; }
-      // point-major copy of the corrected record (see device_state.hpp)
+    } else {
+      double X[3], cam[9];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) X[k] = dp.points[(size_t)j * 3 + k];
+      const int ci = (dp.NI == 1) ? 0 : dp.frame_intr[f];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) cam[k] = dp.intr[(size_t)ci * 9 + k];
+      const Model m = {dp.shutter, dp.scan0, dp.scan1, dp.interp_rotation};
+      eval_observation<CAL, P, MODE != kResidualOnly>(m, cam, pose, X, xy.x, xy.y, o);
+      if (valid && !o.ok) nfail = 1.0;
+      // Ceres 1.9 ResidualBlock::Evaluate: cost = rho0/2 from the uncorrected residual
+      const double s = o.r[0] * o.r[0] + o.r[1] * o.r[1];
+      double rho[3] = {s, 1.0, 0.0};
+      if (dp.huber_a > 0.0) huber_rho(dp.huber_a, s, rho);
+      half_rho = (o.ok && valid) ? 0.5 * rho[0] : 0.0;
+    }
+
+    if (MODE == kLmJacobian && dp.rec) {   // point-major copy of the corrected record (device_state.hpp); calibrated problems recompute it instead (dp.rec == nullptr)
       constexpr int REC = 2 + 2 * K;
       constexpr int KC = K - 3;
-      // a failed block contributes zeros everywhere below (record, camera blocks, tiled output)
-      if (!o.ok) {
-        o.r[0] = 0.0; o.r[1] = 0.0;
-#pragma unroll
-        for (int k = 0; k < K; ++k) { o.J[0][k] = 0.0; o.J[1][k] = 0.0; }
-      }
       // record layout [r0 r1 | Jp row0 (3) Jp row1 (3) | Jc row0 (KC) Jc row1 (KC)]: entry k of the record
       auto rec_entry = [&](int k) -> double {
         if (k < 2) return o.r[k];

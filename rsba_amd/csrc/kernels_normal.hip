@@ -7,6 +7,7 @@
 // /root/reference/src/rsba/CeresHandler.h:419).  They are HBM/latency-bound block operations on 12x12,
 // 12x3 and 3x3 blocks — deliberately NOT reshaped into MFMA GEMMs: on gfx950 the fp64 MFMA rate equals
 // the fp64 VALU rate, and padding 12 -> 16 would waste 44 % of it.
+#include "lm_record.hpp"
 #include "obs_math.hpp"
 #include "solver_state.hpp"
 
@@ -703,6 +704,184 @@ __global__ __launch_bounds__(256) void point_step_kernel(const DeviceProblem dp,
   if (threadIdx.x == 0) sv.partial[blockIdx.x] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
 }
 
+// ---------------------------------------------------------------------------------------------
+// Calibrated problems: the point-side passes RECOMPUTE every observation's record (lm_record.hpp) instead of reading the
+// point-major copy the evaluation kernel used to leave for them — 24 B of observation + cached poses in, not 256 B of record.
+// Same arithmetic as the record-based kernels above (which the uncalibrated problems keep: their virtual intrinsics records
+// need the 9 intrinsics columns of every record of a point at once).
+// ---------------------------------------------------------------------------------------------
+__global__ void slot_xy_kernel(const DeviceProblem dp, double2* __restrict__ slot_xy) {   // once per plan: observations in slot (point-major) order
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < dp.N) slot_xy[dp.obs_slot[i]] = dp.xy[i];
+}
+
+// the record of slot s (clamped by the caller): pose and scales straight from L2 (F x 192 B: resident)
+template <int P>
+__device__ __forceinline__ void slot_record(const DeviceProblem& dp, const SolverDev& sv, int64_t s, ObsOut<true, P>& o, int& frame, int& point) {
+  constexpr int CD = 6 * P;
+  frame = sv.slot_frame[s]; point = sv.slot_point[s];
+  const double2 xy = sv.slot_xy[s];
+  double pose[CD], psc[CD];
+#pragma unroll
+  for (int k = 0; k < CD; ++k) { pose[k] = dp.poses[(size_t)frame * CD + k]; psc[k] = dp.scale_pose[(size_t)frame * CD + k]; }
+  double half_rho; bool dropped;
+  lm_observation<true, P>(dp, frame, point, xy.x, xy.y, pose, psc, o, half_rho, dropped);
+}
+
+// K5b without records: P = Jc^T (Jp L^-T) of 64 consecutive slots per wave and step, into the group layout (see project_kernel)
+template <int P>
+__global__ __launch_bounds__(256) void project_rc_kernel(const DeviceProblem dp, const SolverDev sv) {
+  constexpr int CD = 6 * P, OUT = CD * 3, FT = kTile / CD, PITCH = OUT | 1, kPer = 64 / CD;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* buf = smem + (size_t)wave * (64 * PITCH + 32);
+  int32_t* s_gpos = reinterpret_cast<int32_t*>(buf + 64 * PITCH);
+  const int64_t sb = ((int64_t)blockIdx.x * 4 + wave) * 64 * kProjectChunks;
+  if (sb >= dp.N) return;
+  const int64_t se = sb + 64 * kProjectChunks < dp.N ? sb + 64 * kProjectChunks : dp.N;
+  for (int64_t s0 = sb; s0 < se; s0 += 64) {
+    const int64_t nslot = se - s0 < 64 ? se - s0 : 64;
+    const int64_t s = s0 + lane < se ? s0 + lane : se - 1;   // (lanes past the end repeat the last slot; nothing of theirs is stored)
+    ObsOut<true, P> o;
+    int frame, j;
+    slot_record<P>(dp, sv, s, o, frame, j);
+    const double* li = sv.Linv + (size_t)j * 6;
+    const double i00 = li[0], i10 = li[1], i11 = li[2], i20 = li[3], i21 = li[4], i22 = li[5];
+    double B[2][3];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const double p0 = o.J[r][CD], p1 = o.J[r][CD + 1], p2 = o.J[r][CD + 2];
+      B[r][0] = p0 * i00; B[r][1] = p0 * i10 + p1 * i11; B[r][2] = p0 * i20 + p1 * i21 + p2 * i22;
+    }
+#pragma unroll
+    for (int a = 0; a < CD; ++a)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) buf[lane * PITCH + k * CD + a] = o.J[0][a] * B[0][k] + o.J[1][a] * B[1][k];
+    s_gpos[lane] = sv.slot_gpos[s];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int my = lane / CD, w = lane % CD;
+    if (my < kPer) {
+#pragma unroll 2
+      for (int i = 0; i * kPer < 64; ++i) {
+        const int sl = i * kPer + my;
+        if (sl < nslot) {
+          const int gpos = s_gpos[sl];
+          double* dst = sv.Pm + ((size_t)(gpos / FT) * (kTile * 3) + (size_t)((gpos % FT) * CD + w));
+          const double* src = buf + sl * PITCH + w;
+#pragma unroll
+          for (int comp = 0; comp < 3; ++comp) dst[comp * kTile] = src[comp * CD];
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
+// One wave owns kSweepPoints consecutive points = one contiguous slot range and walks it 64 slots at a time: every lane reduces ITS
+// slot's recomputed record to NC numbers (per_slot), and the lane that owns a point adds its slots' numbers in slot order (fixed
+// order: deterministic) before per_point finishes the point.  -> what per_point returns, summed over the workgroup (fixed order).
+// (Sixteen points — a few hundred slots — per wave: the records are computed, not streamed, so the pass wants many waves in flight,
+// not long ones; 64 points per wave left the 100-camera scene with 40 workgroups.)
+constexpr int kSweepPoints = 16;
+template <int P, int NC, class PerSlot, class PerPoint>
+__device__ __forceinline__ double point_sweep(const DeviceProblem& dp, const SolverDev& sv, double* smem, PerSlot per_slot, PerPoint per_point) {
+  __shared__ double s_red[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* cbuf = smem + (size_t)wave * (64 * NC);
+  const int64_t j0 = ((int64_t)blockIdx.x * 4 + wave) * kSweepPoints;
+  double ret = 0.0;
+  if (j0 < dp.M) {   // wave-uniform
+    const int jn = (int)(dp.M - j0 < kSweepPoints ? dp.M - j0 : kSweepPoints);
+    const bool mine = lane < jn;
+    const int64_t j = j0 + (mine ? lane : 0);
+    const int64_t lo = mine ? sv.point_ptr[j] : 0, hi = mine ? sv.point_ptr[j + 1] : 0;
+    const int64_t sb = sv.point_ptr[j0], se = sv.point_ptr[j0 + jn];
+    double acc[NC];
+#pragma unroll
+    for (int q = 0; q < NC; ++q) acc[q] = 0.0;
+    for (int64_t c0 = sb; c0 < se; c0 += 64) {
+      const int nrec = (int)(se - c0 < 64 ? se - c0 : 64);
+      {
+        const int64_t s = c0 + lane < se ? c0 + lane : se - 1;
+        ObsOut<true, P> o;
+        int frame, pt;
+        slot_record<P>(dp, sv, s, o, frame, pt);
+        double c[NC];
+        per_slot(o, frame, c);
+#pragma unroll
+        for (int q = 0; q < NC; ++q) cbuf[lane * NC + q] = c[q];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int64_t s_lo = lo > c0 ? lo : c0, s_hi = hi < c0 + nrec ? hi : c0 + nrec;
+      for (int64_t sidx = s_lo; sidx < s_hi; ++sidx) {
+        const double* c = cbuf + (sidx - c0) * NC;
+#pragma unroll
+        for (int q = 0; q < NC; ++q) acc[q] += c[q];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (mine) ret = per_point(j, acc);
+  }
+  ret = wsum(ret);
+  if (lane == 0) s_red[wave] = ret;
+  __syncthreads();
+  return s_red[0] + s_red[1] + s_red[2] + s_red[3];
+}
+
+// K2b without records: V_j, g_p,j
+template <int P>
+__global__ __launch_bounds__(256) void point_blocks_rc_kernel(const DeviceProblem dp, const SolverDev sv) {
+  constexpr int CD = 6 * P;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  point_sweep<P, 9>(dp, sv, smem,
+    [&](const ObsOut<true, P>& o, int, double c[9]) {
+      const double r0 = o.r[0], r1 = o.r[1], p0[3] = {o.J[0][CD], o.J[0][CD + 1], o.J[0][CD + 2]}, p1[3] = {o.J[1][CD], o.J[1][CD + 1], o.J[1][CD + 2]};
+      c[0] = p0[0] * p0[0] + p1[0] * p1[0]; c[1] = p0[0] * p0[1] + p1[0] * p1[1]; c[2] = p0[0] * p0[2] + p1[0] * p1[2];
+      c[3] = p0[1] * p0[1] + p1[1] * p1[1]; c[4] = p0[1] * p0[2] + p1[1] * p1[2]; c[5] = p0[2] * p0[2] + p1[2] * p1[2];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) c[6 + k] = p0[k] * r0 + p1[k] * r1;
+    },
+    [&](int64_t j, const double acc[9]) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) sv.V[(size_t)j * 6 + k] = acc[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) sv.gp[(size_t)j * 3 + k] = acc[6 + k];
+      return 0.0;
+    });
+}
+
+// K7 + K8 without records (see point_step_kernel)
+template <int P>
+__global__ __launch_bounds__(256) void point_step_rc_kernel(const DeviceProblem dp, const SolverDev sv) {
+  constexpr int CD = 6 * P;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const double mc = point_sweep<P, 5>(dp, sv, smem,
+    [&](const ObsOut<true, P>& o, int frame, double c[5]) {
+      const double* yc = sv.rhs + (size_t)frame * CD;
+      double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+      for (int a = 0; a < CD; ++a) { const double y = yc[a]; t0 += o.J[0][a] * y; t1 += o.J[1][a] * y; }
+      c[0] = o.J[0][CD] * t0 + o.J[1][CD] * t1; c[1] = o.J[0][CD + 1] * t0 + o.J[1][CD + 1] * t1; c[2] = o.J[0][CD + 2] * t0 + o.J[1][CD + 2] * t1;   // Jp^T t
+      c[3] = t0 * t0 + t1 * t1;
+      c[4] = o.r[0] * t0 + o.r[1] * t1;
+    },
+    [&](int64_t j, const double acc[5]) {
+      const double* li = sv.Linv + (size_t)j * 6;
+      const double* z = sv.z + (size_t)j * 3;
+      const double i00 = li[0], i10 = li[1], i11 = li[2], i20 = li[3], i21 = li[4], i22 = li[5];
+      const double u0 = acc[0], u1 = acc[1], u2 = acc[2];
+      const double w0 = z[0] - i00 * u0, w1 = z[1] - (i10 * u0 + i11 * u1), w2 = z[2] - (i20 * u0 + i21 * u1 + i22 * u2);
+      const double y0 = i00 * w0 + i10 * w1 + i20 * w2, y1 = i11 * w1 + i21 * w2, y2 = i22 * w2;
+      double* yp = sv.yp + (size_t)j * 3;
+      yp[0] = y0; yp[1] = y1; yp[2] = y2;
+      const double* v = sv.V + (size_t)j * 6;   // xx xy xz yy yz zz
+      const double* g = sv.gp + (size_t)j * 3;
+      const double vy0 = v[0] * y0 + v[1] * y1 + v[2] * y2, vy1 = v[1] * y0 + v[3] * y1 + v[4] * y2, vy2 = v[2] * y0 + v[4] * y1 + v[5] * y2;
+      return -acc[4] - (y0 * g[0] + y1 * g[1] + y2 * g[2]) + 0.5 * acc[3] + (y0 * u0 + y1 * u1 + y2 * u2) + 0.5 * (y0 * vy0 + y1 * vy1 + y2 * vy2);
+    });
+  if (threadIdx.x == 0) sv.partial[blockIdx.x] = mc;
+}
+
 __global__ __launch_bounds__(256) void reduce_sum_kernel(const double* partial, int n, double* out, double sign) {
   __shared__ double s_red[4];
   double v = 0.0;
@@ -809,7 +988,19 @@ hipError_t launch_camera_blocks(const DeviceProblem& dp, const SolverDev& sv, hi
   else { if (dp.calibrated) LAUNCH((camera_reduce_kernel<6, true>), dp.F, 256, st, dp, sv); else LAUNCH((camera_reduce_kernel<6, false>), dp.F, 256, st, dp, sv); }
   return hipSuccess;
 }
+hipError_t launch_slot_xy(const DeviceProblem& dp, double2* slot_xy, hipStream_t st) {
+  if (dp.N > 0) LAUNCH(slot_xy_kernel, nblocks256(dp.N), 256, st, dp, slot_xy);
+  return hipSuccess;
+}
 hipError_t launch_point_blocks(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {
+  if (sv.slot_xy) {   // calibrated: from the observations themselves
+    if (dp.M <= 0) return hipSuccess;
+    const size_t lds = (size_t)4 * 64 * 9 * sizeof(double);
+    const int grid = (int)((dp.M + 4 * kSweepPoints - 1) / (4 * kSweepPoints));
+    if (sv.CD == 12) hipLaunchKernelGGL(point_blocks_rc_kernel<2>, dim3(grid), dim3(256), lds, st, dp, sv);
+    else hipLaunchKernelGGL(point_blocks_rc_kernel<1>, dim3(grid), dim3(256), lds, st, dp, sv);
+    return hipGetLastError();
+  }
   LAUNCH(point_blocks_kernel, nblocks256(dp.M), 256, st, dp, sv);
   return hipSuccess;
 }
@@ -860,6 +1051,14 @@ static hipError_t launch_project_as(const DeviceProblem& dp, const SolverDev& sv
 hipError_t launch_project(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {
   if (dp.N == 0) return hipSuccess;
   const int KC = dp.K - 3;
+  if (sv.slot_xy) {
+    const int CD = sv.CD;
+    const size_t lds = (size_t)4 * (64 * ((CD * 3) | 1) + 32) * sizeof(double);
+    const int grid = (int)((dp.N + 256 * kProjectChunks - 1) / (256 * kProjectChunks));
+    if (CD == 12) hipLaunchKernelGGL(project_rc_kernel<2>, dim3(grid), dim3(256), lds, st, dp, sv);
+    else hipLaunchKernelGGL(project_rc_kernel<1>, dim3(grid), dim3(256), lds, st, dp, sv);
+    return hipGetLastError();
+  }
   if (sv.CD == 12 && KC == 12) return launch_project_as<12, 12>(dp, sv, st);
   if (sv.CD == 6 && KC == 6) return launch_project_as<6, 6>(dp, sv, st);
   if (sv.CD == 12 && KC == 21) return launch_project_as<12, 21>(dp, sv, st);
@@ -902,26 +1101,33 @@ hipError_t launch_schur_blocks(const DeviceProblem& dp, const SolverDev& sv, dou
   LAUNCH(schur_merge_kernel, sv.ntp, 256, st, dp, sv, 1.0 / radius);
   return hipSuccess;
 }
-static int point_step_blocks(const DeviceProblem& dp) { return (int)((dp.M + 255) / 256); }
+static int point_step_blocks(const DeviceProblem& dp, const SolverDev& sv) { return sv.slot_xy ? (int)((dp.M + 4 * kSweepPoints - 1) / (4 * kSweepPoints)) : (int)((dp.M + 255) / 256); }
 template <int CD, int KC>
 static hipError_t launch_point_step(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {
   constexpr int REC = 8 + 2 * KC, PITCH = REC | 1;
   const size_t lds = (size_t)4 * (64 * PITCH + 64 * 5) * sizeof(double);
   hipError_t e = allow_dynamic_lds(point_step_kernel<CD, KC>, lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((point_step_kernel<CD, KC>), dim3(point_step_blocks(dp)), dim3(256), lds, st, dp, sv);
+  hipLaunchKernelGGL((point_step_kernel<CD, KC>), dim3(point_step_blocks(dp, sv)), dim3(256), lds, st, dp, sv);
   return hipGetLastError();
 }
 // point steps y_p and the per-workgroup partials of the model cost change (sv.partial)
 hipError_t launch_back_substitute(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {
   if (dp.M <= 0) return hipSuccess;
   const int KC = dp.K - 3;
+  if (sv.slot_xy) {
+    const size_t lds = (size_t)4 * 64 * 5 * sizeof(double);
+    const int grid = point_step_blocks(dp, sv);
+    if (sv.CD == 12) hipLaunchKernelGGL(point_step_rc_kernel<2>, dim3(grid), dim3(256), lds, st, dp, sv);
+    else hipLaunchKernelGGL(point_step_rc_kernel<1>, dim3(grid), dim3(256), lds, st, dp, sv);
+    return hipGetLastError();
+  }
   if (sv.CD == 12) return KC == 12 ? launch_point_step<12, 12>(dp, sv, st) : launch_point_step<12, 21>(dp, sv, st);
   return KC == 6 ? launch_point_step<6, 6>(dp, sv, st) : launch_point_step<6, 15>(dp, sv, st);
 }
 // -> scalars[kModelCostChange]; must follow launch_back_substitute directly (it reduces that kernel's partials)
 hipError_t launch_model_cost_change(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {
-  LAUNCH(reduce_sum_kernel, 1, 256, st, sv.partial, dp.M > 0 ? point_step_blocks(dp) : 0, sv.scalars + kModelCostChange, -1.0);
+  LAUNCH(reduce_sum_kernel, 1, 256, st, sv.partial, dp.M > 0 ? point_step_blocks(dp, sv) : 0, sv.scalars + kModelCostChange, -1.0);
   return hipSuccess;
 }
 hipError_t launch_own_points(const DeviceProblem& dp, const SolverDev& sv, double* buf, hipStream_t st) {

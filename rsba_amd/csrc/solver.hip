@@ -271,7 +271,7 @@ int32_t build_solver(rsba_handle* h) {
   // The two passes over all (point, tile pair) entries — count, then fill — are most of the symbolic phase (2 M entries at 1k cameras):
   // with dense keys they run on a few host threads over contiguous point ranges, each with its own counters per tile pair, and
   // the fill starts every thread where the threads before it end: the entry lists come out exactly as from one thread.
-  const int nthreads = dense_keys && (int64_t)nt * nt <= ((int64_t)1 << 22) && M >= 4096 ? (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())) : 1;   // (per-thread counters: 4 nt^2 bytes each)
+  const int nthreads = dense_keys && (int64_t)nt * nt <= ((int64_t)1 << 22) && M >= 4096 ? (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency())) : 1;   // (per-thread counters: 4 nt^2 bytes each)
   std::vector<std::vector<int32_t>> thread_cnt(nthreads > 1 ? nthreads : 0);
   auto point_range = [&](int t) { return std::pair<int, int>((int)((int64_t)M * t / nthreads), (int)((int64_t)M * (t + 1) / nthreads)); };
   if (nthreads > 1) {
@@ -745,8 +745,18 @@ int32_t build_solver(rsba_handle* h) {
 
   tick("uploads");
   const size_t REC = 2 + 2 * (size_t)dp.K;
-  if ((rc = s_alloc(s, &h->dp.rec, (size_t)N * REC))) return rc;
   h->dp.obs_slot = s->d_obs_slot;
+  // Calibrated problems recompute the records in the point-side passes (lm_record.hpp) from the observations in slot order;
+  // the others (intrinsics as parameter blocks: virtual records) keep the point-major copy.  RSBA_RECORDS=1 forces the copy.
+  bool recompute = dp.calibrated != 0;
+  if (const char* e = std::getenv("RSBA_RECORDS")) recompute = recompute && e[0] != '1';
+  sv.slot_xy = nullptr; h->dp.rec = nullptr;
+  if (recompute) {
+    double2* sxy = nullptr;
+    if ((rc = s_alloc(s, &sxy, (size_t)N))) return rc;
+    HIP_TRY(launch_slot_xy(h->dp, sxy, h->stream));
+    sv.slot_xy = sxy;
+  } else if ((rc = s_alloc(s, &h->dp.rec, (size_t)N * REC))) return rc;
   if (N > 0) {
     // camera (and intrinsics border) blocks inside the evaluation kernel: per (64-observation wave, frame it touches)
     // the 16 x 16 blocks on and below the diagonal of [Ji | Jc | r]^T [Ji | Jc | r]
@@ -797,7 +807,7 @@ int32_t build_solver(rsba_handle* h) {
   if ((rc = s_alloc(s, &sv.trial_poses, (size_t)FR * CD))) return rc;
   if ((rc = s_alloc(s, &sv.trial_points, (size_t)M * 3))) return rc;
   const size_t nb = std::max<size_t>((N + 255) / 256, ((size_t)sv.n + 3 * (size_t)M + 255) / 256);
-  if ((rc = s_alloc(s, &sv.partial, 2 * nb + 2))) return rc;
+  if ((rc = s_alloc(s, &sv.partial, 2 * std::max(nb, ((size_t)M + 63) / 64 + 1) + 2))) return rc;   // (the point sweeps leave one partial per 64 points)
   if ((rc = s_alloc(s, &sv.scalars, 16))) return rc;
   if ((rc = s_alloc(s, &sv.chol_fail, 1))) return rc;
   if ((rc = s_alloc(s, &s->d_gpose, (size_t)F * CD))) return rc;
@@ -867,13 +877,18 @@ int32_t build_solver(rsba_handle* h) {
     ps.tiles = nt; ps.factor_tiles = sv.nslots; ps.levels = s->nlev; ps.tasks = pl.ntasks;
     ps.schur_entries = nent; ps.schur_chunks = sv.nchunk;
     // block products of the Schur complement that are not structurally zero: per entry (frames present on the I side) x (on the J side)
-    int64_t prod = 0;
-    for (int64_t e = 0; e < nent; ++e) {
-      int ca = 0, cb = 0;
-      for (int x = 0; x < FT; ++x) { ca += g_rows[(size_t)ent_groups[2 * (size_t)e] * FT + x] != (int32_t)NS; cb += g_rows[(size_t)ent_groups[2 * (size_t)e + 1] * FT + x] != (int32_t)NS; }
-      prod += (int64_t)ca * cb;
-    }
-    ps.schur_block_products = prod;
+    // (frames present per group, then one pass over the entries on the threads of the entry passes: this used to be 5 ms of one thread at 1k cameras)
+    std::vector<uint8_t> present((size_t)sv.ngroups, 0);
+    for (int64_t gq = 0; gq < sv.ngroups; ++gq) for (int x = 0; x < FT; ++x) present[gq] += g_rows[(size_t)gq * FT + x] != (int32_t)NS;
+    std::vector<int64_t> part((size_t)nthreads, 0);
+    auto count = [&](int t) {
+      int64_t prod = 0;
+      for (int64_t e = nent * t / nthreads; e < nent * (t + 1) / nthreads; ++e) prod += (int64_t)present[ent_groups[2 * (size_t)e]] * present[ent_groups[2 * (size_t)e + 1]];
+      part[t] = prod;
+    };
+    if (nthreads > 1) { std::vector<std::thread> pool; for (int t = 0; t < nthreads; ++t) pool.emplace_back(count, t); for (auto& th : pool) th.join(); } else count(0);
+    ps.schur_block_products = 0;
+    for (int64_t v : part) ps.schur_block_products += v;
     // tile factorisation: per DIAG item its contributors (lower half of L L^T: T^3 each) + potrf and inverse (T^3 / 3 each);
     // per SUB item 2 T^3 per contributor + the product with W (T^3); forward / backward solve 2 T^2 per factor tile, twice
     const int64_t T3 = (int64_t)kTile * kTile * kTile;

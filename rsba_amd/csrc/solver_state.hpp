@@ -49,6 +49,7 @@ struct SolverDev {
   const int32_t* tp_J;
   const int64_t* tp_ptr;        // [ntp+1] into the entry list
   const int32_t* ent_groups;    // [nent][2] the point's (tile, layer) group on the I side and on the J side
+  const double2* slot_xy;       // [N] observations in slot order — calibrated problems only: their point-side passes recompute the records (lm_record.hpp); null = records in dp.rec
   const int32_t* slot_gpos;     // [N + virtual] group * FT + position in the tile: where the slot's P record lives in Pm
   int64_t ngroups;              // (point, tile, layer) groups: each owns one kTile x 3 block of Pm (one more, all zero, sits behind the last: padding entries of the Schur chunks)
   const uint16_t* ent_mask;     // [nent] bit 3 I + J: block rows 16 I .. of the I-side group and 16 J .. of the J-side group both contain a frame that sees the point
@@ -155,6 +156,7 @@ hipError_t launch_chol_dag(const SolverDev& sv, const CholPlan& pl, const DagArg
 // kernels_normal.hip
 hipError_t launch_camera_blocks(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);
 hipError_t launch_point_blocks(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);
+hipError_t launch_slot_xy(const DeviceProblem& dp, double2* slot_xy, hipStream_t st);   // slot_xy[obs_slot[i]] = xy[i]
 hipError_t launch_jacobi_scale(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);           // scale = mask / (1 + sqrt(diag))
 hipError_t launch_clamp_diagonal(const DeviceProblem& dp, const SolverDev& sv, double lo, double hi, hipStream_t st);
 hipError_t launch_gradient_max(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);           // -> scalars[kGradMax]

@@ -2,7 +2,7 @@
 # Runs on the GPU box (via gpurun): collects this round's evidence into gpurun_out/$1/ (default r02).
 #   the bench lines (C4 = the metric's workload, C5 = the 4k-camera Huber + shared-intrinsics scene), kernel-trace stats of the
 #   same commands, FETCH_SIZE and WRITE_SIZE in separate --pmc passes (never combined with tracing), the HBM stream calibration.
-R=${1:-r02}
+R=${1:-r03}
 OUT=gpurun_out/$R
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -15,7 +15,40 @@ for C in C4 C5; do
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$C -o f -- $B --no-lm > $OUT/pmc_fetch_$C.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$C -o w -- $B --no-lm > $OUT/pmc_write_$C.log 2>&1
 done
+# matrix-pipe utilisation (SQ_VALU_MFMA_BUSY_CYCLES) and L2 behaviour of the LM kernels, counters only (tools/pmc_pass.sh: one --pmc pass each)
+for C in C4 C5; do
+  IT=4; [ $C = C5 ] && IT=3
+  tools/pmc_pass.sh $OUT/pmc_mfma_$C "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" python tools/lm_time.py $C $IT
+  tools/pmc_pass.sh $OUT/pmc_l2_$C "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" python tools/lm_time.py $C $IT
+done
+python - "$OUT" <<'PY'
+import csv, json, sys
+out = sys.argv[1]
+summary = {"note": "per kernel, mean per dispatch: mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 256 CUs x 4 SIMDs); one fp64 MFMA 16x16x4 keeps its SIMD's "
+                   "matrix pipe busy for 64 cycles (SQ_VALU_MFMA_BUSY_CYCLES / SQ_INSTS_MFMA); SQ_WAVE_CYCLES, SQ_WAIT_* in quad-cycles; l2_hit = TCC_HIT / TCC_REQ, "
+                   "fabric_read_bytes = TCC_EA0_RDREQ x 128 B (Infinity-Cache hits included)"}
+for cfg in ("C4", "C5"):
+    rows = {r["kernel"]: r for r in csv.DictReader(open(f"{out}/pmc_mfma_{cfg}.csv"))}
+    l2 = {r["kernel"]: r for r in csv.DictReader(open(f"{out}/pmc_l2_{cfg}.csv"))}
+    d = {}
+    for k, r in rows.items():
+        gui = float(r["GRBM_GUI_ACTIVE"]) / 8.0
+        if gui <= 0 or not k.startswith("rsba::"): continue
+        e = {"dispatches": int(r["dispatches"]), "mfma_busy_cycles": float(r["SQ_VALU_MFMA_BUSY_CYCLES"]), "mfma_insts": float(r["SQ_INSTS_MFMA"]), "cycles_per_xcd": gui,
+             "mfma_busy_frac": float(r["SQ_VALU_MFMA_BUSY_CYCLES"]) / (gui * 1024.0), "waves_per_simd": 4.0 * float(r["SQ_WAVE_CYCLES"]) / (gui * 1024.0),
+             "wave_time_waiting_for_memory_or_barriers": float(r["SQ_WAIT_ANY"]) / max(1.0, float(r["SQ_WAVE_CYCLES"]))}
+        if k in l2 and float(l2[k]["TCC_REQ_sum"]) > 0:
+            e["l2_hit"] = float(l2[k]["TCC_HIT_sum"]) / float(l2[k]["TCC_REQ_sum"]); e["fabric_read_bytes"] = float(l2[k]["TCC_EA0_RDREQ_sum"]) * 128.0
+        d[k] = e
+    summary[cfg] = d
+json.dump(summary, open(f"{out}/pmc_mfma_summary.json", "w"), indent=1)
+for cfg in ("C4", "C5"):
+    for k, e in summary[cfg].items():
+        if e["mfma_busy_frac"] > 0.01: print(cfg, k, {a: (round(b, 4) if isinstance(b, float) else b) for a, b in e.items()})
+PY
+python bench.py --config C2 --steps 50 --warmup 5 --lm-iters 12 --no-cpu-baseline --no-next-rows > $OUT/bench_c2.json 2> $OUT/bench_c2.err
 ./tools/hbm_calib > $OUT/hbm_calib.txt 2>&1
+./tools/mfma_f64_rate > $OUT/mfma_f64_rate.txt 2>&1
 python - "$OUT" <<'PY'
 import csv, json, sys
 out = sys.argv[1]
