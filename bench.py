@@ -111,13 +111,18 @@ def roofline_lm(prob, dp, iters, capi):
     cd = 6 * prob.poses_per_frame
     rec = 8 * (2 + 2 * k)                       # the point-major record of one observation
     prec = 8 * cd * 3                           # its P record
+    pgroups = st["schur_groups"] * 3 * 48 * 8   # the P records as the Schur kernel reads them: one [3][48] block per (point, frame tile)
+    if prob.calibrated:   # the point-side passes recompute the records from the observations (24 B each, slot order) instead of streaming 256-B copies
+        obs = n * 24 + prob.num_frames * prob.poses_per_frame * 96 + m * 48
+        work_point = {"eval_lm": ("hbm", obs + n * 32), "point_blocks": ("hbm", obs + m * 72), "project": ("hbm", obs + n * 4 + m * 48 + pgroups),
+                      "back_substitute": ("hbm", obs + m * (48 + 24 + 72 + 24))}
+    else:
+        work_point = {"eval_lm": ("hbm", n * (24 + rec + 32) + prob.num_frames * prob.poses_per_frame * 48 + m * 24), "point_blocks": ("hbm", n * 64 + m * 72),
+                      "project": ("hbm", n * rec + pgroups), "back_substitute": ("hbm", n * rec + m * 48)}
     work = {   # phase -> (bound, algorithmic bytes or flops per call)
-        "eval_lm": ("hbm", n * (24 + rec + 32) + prob.num_frames * prob.poses_per_frame * 48 + m * 24),
-        "point_blocks": ("hbm", n * 64 + m * 72),
-        "project": ("hbm", n * (rec + prec)),
+        **work_point,
         "schur": ("mfma", mfma_per_launch * 2048),
         "cholesky": ("mfma", st["cholesky_flops"]),
-        "back_substitute": ("hbm", n * rec + m * 48),
         "eval_trial": ("hbm", n * 24 + prob.num_frames * prob.poses_per_frame * 48 + m * 24),
     }
     rows = []
@@ -138,6 +143,11 @@ def roofline_lm(prob, dp, iters, capi):
                       f"structurally non-zero block products: {st['schur_block_products']} x {2 * cd * cd * 3} flop = {st['schur_block_products'] * 2 * cd * cd * 3 / 1e9:.2f} Gflop useful",
              "cholesky": f"latency-bound dependency chain: {st['levels']} elimination levels, {st['tasks']} tile tasks, {st['factor_tiles']} factor tiles",
              "eval_trial": "residual only: bound by the fp64 projection math, not by HBM"}
+    if prob.calibrated:
+        for ph in ("eval_lm", "point_blocks", "project", "back_substitute"):
+            notes[ph] = "records recomputed from the observations (rsba_amd/csrc/lm_record.hpp): ~0.6 kflop of fp64 per observation instead of a 256-B record from HBM — bound by the fp64 vector unit; bytes are what the pass still has to move"
+        notes["project"] += "; writes the P records in the (point, tile) group layout"
+
     for r in rows:
         if r["phase"] in notes:
             r["note"] = notes[r["phase"]]

@@ -93,7 +93,7 @@ class PhaseTimes(C.Structure):
 
 class PlanStats(C.Structure):
     _fields_ = [(k, C.c_int64) for k in ("tiles", "factor_tiles", "levels", "tasks", "schur_entries", "schur_chunks", "schur_block_products",
-                                         "cholesky_flops", "exchange_doubles", "schur_mfma_issued", "schur_launches")]
+                                         "cholesky_flops", "exchange_doubles", "schur_groups", "schur_mfma_issued", "schur_launches")]
 
 
 def build(force: bool = False) -> str:

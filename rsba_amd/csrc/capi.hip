@@ -185,6 +185,9 @@ int32_t rsba_create(const rsba_problem_desc* d, int32_t device, rsba_handle** ou
   if ((rc = dev_upload(h, &dp.scale_pose, h->mask_pose.data(), npose))) return bail(rc);
   if ((rc = dev_upload(h, &dp.scale_point, h->mask_point.data(), (size_t)dp.M * 3))) return bail(rc);
   if ((rc = dev_upload(h, &dp.scale_intr, h->mask_intr.data(), (size_t)dp.NI * 9))) return bail(rc);
+  if ((rc = dev_upload(h, &h->d_mask_pose, h->mask_pose.data(), npose))) return bail(rc);
+  if ((rc = dev_upload(h, &h->d_mask_point, h->mask_point.data(), (size_t)dp.M * 3))) return bail(rc);
+  if ((rc = dev_upload(h, &h->d_mask_intr, h->mask_intr.data(), (size_t)dp.NI * 9))) return bail(rc);
 
   if ((rc = dev_alloc(h, &dp.res, 2 * (size_t)kEvalBlock * dp.ntiles))) return bail(rc);
   if ((rc = dev_alloc(h, &dp.jac, 2 * (size_t)dp.K * kEvalBlock * dp.ntiles))) return bail(rc);

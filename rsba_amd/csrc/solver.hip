@@ -895,15 +895,16 @@ int32_t build_solver(rsba_handle* h) {
     ps.cholesky_flops = T3 * ((int64_t)(s->diag_list.size() / 2) + 2 * (int64_t)(s->sub_list.size() / 2) + (int64_t)(s->sub_info.size() / 4)) +
                         2 * T3 / 3 * (int64_t)(s->diag_info.size() / 4) + 4 * (int64_t)kTile * kTile * ((int64_t)sv.nslots + nt);
     ps.exchange_doubles = (int64_t)sv.nslots * kTile * kTile + sv.npad;
+    ps.schur_groups = sv.ngroups;
   }
   return RSBA_OK;
 }
 
 int32_t reset_scales(rsba_handle* h) {
   const DeviceProblem& dp = h->dp;
-  HIP_TRY(hipMemcpyAsync(dp.scale_pose, h->mask_pose.data(), h->mask_pose.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(hipMemcpyAsync(dp.scale_point, h->mask_point.data(), h->mask_point.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(hipMemcpyAsync(dp.scale_intr, h->mask_intr.data(), h->mask_intr.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(dp.scale_pose, h->d_mask_pose, h->mask_pose.size() * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(dp.scale_point, h->d_mask_point, h->mask_point.size() * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(dp.scale_intr, h->d_mask_intr, h->mask_intr.size() * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
   if (dp.pp_count > 0) {   // the priorPoses blocks are always free: scale 1
     static const std::vector<double> ones(1 << 16, 1.0);
     for (size_t o = 0; o < 6 * (size_t)dp.pp_count; o += ones.size())
