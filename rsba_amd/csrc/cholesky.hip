@@ -50,6 +50,18 @@ __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// (accessors of the write-once cells in HBM; the scheme itself is described with the task drivers below)
+#define RSBA_GLOBAL __attribute__((address_space(1)))
+template <class V> __device__ __forceinline__ V gl(const V* p) { return *(const RSBA_GLOBAL V*)p; }
+template <bool DAG> __device__ __forceinline__ double ld(const double* p) {
+  if (DAG) return __hip_atomic_load((const RSBA_GLOBAL double*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return gl(p);
+}
+template <bool DAG> __device__ __forceinline__ void st(double* p, double v) {
+  if (DAG) __hip_atomic_store((RSBA_GLOBAL double*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *(RSBA_GLOBAL double*)p = v;
+}
+
 constexpr int NB = 16;   // panel width of the tile factorisation: one MFMA block column
 typedef double dbl4_t __attribute__((ext_vector_type(4)));
 
@@ -344,8 +356,12 @@ __device__ __forceinline__ dbl4_t mm16_nn(const double* X, int xr, int xc, const
 // D, Wl, Tm, Lp must be the task's LDS buffers 0 .. 3 (the pivot messages live in idle rows of Tm and Lp, see the LDS map) and the
 // messages armed (arm_pivot_messages) before the barrier in front of this call.  All threads must call; ends with a barrier.  Returns (in the first wave)
 // false on a non-positive pivot.
-template <bool TRACE = false, bool MFMA_FOLLOWER = false>
-__device__ __forceinline__ bool factor_invert_tile(double* D, double* Wl, double* Tm, double* Lp, int tid, long long* stamps = nullptr) {
+// wout (HBM, row-major T x T; null = keep W in LDS only): the inverse leaves by ROW BLOCKS as they become final — rows 0-15 after the
+// first diagonal block (a third into the factorisation), rows 16-31 after the second, rows 32-47 at the end, stored by waves that
+// have nothing else to do — so that the DIAG task of the next column on the critical chain (task_diag) forms L = X W^T and D -= L L^T
+// column block by column block under the rest of this factorisation; what is left for it when the last rows land is a third of both.
+template <bool TRACE = false, bool MFMA_FOLLOWER = false, bool DAG = false>
+__device__ __forceinline__ bool factor_invert_tile(double* D, double* Wl, double* Tm, double* Lp, int tid, long long* stamps = nullptr, double* wout = nullptr) {
   const int wave = tid >> 6, lane = tid & 63;
   const dbl4_t zero = {0.0, 0.0, 0.0, 0.0};
   bool ok = true;
@@ -356,15 +372,23 @@ __device__ __forceinline__ bool factor_invert_tile(double* D, double* Wl, double
   if (wave == 0) ok = ldl16_eliminate(load_sym16(D, 0, lane), msg, lane);
   else if (wave == 1) { if (MFMA_FOLLOWER) put16(Wl, 0, 0, ldl16_follow(msg, lane, TRACE ? stamps + 16 : nullptr), lane); else ldl16_follow_rows(msg, Wl, 0, lane); }
   stamp(); lds_barrier(); stamp();
+  auto publish_rows = [&](int rb, int nthreads, int t) {   // rows 16 rb .. 16 rb + 15 of W: lower blocks from Wl, exact zeros right of the diagonal block
+    for (int e = t; e < 16 * T; e += nthreads) { const int r = 16 * rb + e / T, c = e % T; st<DAG>(wout + r * T + c, c < 16 * (rb + 1) ? Wl[r * TP + c] : 0.0); }
+  };
   if (wave < 2) put16(Lp, 16 + 16 * wave, 0, mm16_nt(D, 16 + 16 * wave, 0, Wl, 0, 0, zero, 1.0, lane), lane);   // L_10, L_20
-  else rearm_pivot_messages(D, lane, 8 * (wave - 2), 8 * (wave - 1));   // (both waves of block 0 are done with them; block 1 starts behind the next barrier)
+  else {
+    rearm_pivot_messages(D, lane, 8 * (wave - 2), 8 * (wave - 1));   // (both waves of block 0 are done with them; block 1 starts behind the next barrier)
+  }
   stamp(); lds_barrier(); stamp();
   if (wave == 0) ok = ldl16_eliminate(mm16_nt(Lp, 16, 0, Lp, 16, 0, load_sym16(D, 16, lane), -1.0, lane), msg, lane) && ok;
   else if (wave == 1) { if (MFMA_FOLLOWER) put16(Wl, 16, 16, ldl16_follow(msg, lane), lane); else ldl16_follow_rows(msg, Wl, 16, lane); }
   else if (wave == 2) {
     put16(D, 32, 16, mm16_nt(Lp, 32, 0, Lp, 16, 0, load16(D, 32, 16, lane), -1.0, lane), lane);
     put16(Tm, 16, 0, mm16_nn(Lp, 16, 0, Wl, 0, 0, zero, 1.0, lane), lane);                                         // T_10 = L_10 W_00
-  } else put16(D, 32, 32, mm16_nt(Lp, 32, 0, Lp, 32, 0, load16(D, 32, 32, lane), -1.0, lane), lane);              // (its upper half is never read)
+  } else {
+    put16(D, 32, 32, mm16_nt(Lp, 32, 0, Lp, 32, 0, load16(D, 32, 32, lane), -1.0, lane), lane);                     // (its upper half is never read)
+    if (wout) publish_rows(0, 64, lane);   // W_00 has been final since the first barrier; this step is long (sixteen pivots), the one before is not
+  }
   stamp(); lds_barrier(); stamp();
   if (wave == 0) put16(Lp, 32, 16, mm16_nt(D, 32, 16, Wl, 16, 16, zero, 1.0, lane), lane);       // L_21
   else if (wave == 1) put16(Wl, 16, 0, mm16_nn(Wl, 16, 16, Tm, 16, 0, zero, -1.0, lane), lane);  // W_10
@@ -374,11 +398,15 @@ __device__ __forceinline__ bool factor_invert_tile(double* D, double* Wl, double
   if (wave == 0) ok = ldl16_eliminate(mm16_nt(Lp, 32, 16, Lp, 32, 16, load_sym16(D, 32, lane), -1.0, lane), msg, lane) && ok;
   else if (wave == 1) { if (MFMA_FOLLOWER) put16(Wl, 32, 32, ldl16_follow(msg, lane), lane); else ldl16_follow_rows(msg, Wl, 32, lane); }
   else if (wave == 2) put16(Tm, 32, 16, mm16_nn(Lp, 32, 16, Wl, 16, 16, zero, 1.0, lane), lane);                    // T_21 = L_21 W_11
-  else put16(Tm, 32, 0, mm16_nn(Lp, 32, 16, Wl, 16, 0, load16(Tm, 32, 0, lane), 1.0, lane), lane);                  // T_20 += L_21 W_10
+  else {
+    put16(Tm, 32, 0, mm16_nn(Lp, 32, 16, Wl, 16, 0, load16(Tm, 32, 0, lane), 1.0, lane), lane);                       // T_20 += L_21 W_10
+    if (wout) publish_rows(1, 64, lane);   // W_10, W_11 have been final since the barrier above
+  }
   stamp(); lds_barrier(); stamp();
   if (wave == 0) put16(Wl, 32, 16, mm16_nn(Wl, 32, 32, Tm, 32, 16, zero, -1.0, lane), lane);      // W_21
   else if (wave == 1) put16(Wl, 32, 0, mm16_nn(Wl, 32, 32, Tm, 32, 0, zero, -1.0, lane), lane);   // W_20
   stamp(); lds_barrier(); stamp();
+  if (wout) publish_rows(2, 256, tid);
   return ok;
 }
 
@@ -464,16 +492,6 @@ __shared__ long long* s_trace_slot;   // RSBA_CHOL_TRACE: where the running task
 // Every access to HBM below says so explicitly (address space 1).  The persistent kernel reads its pointers out of a device copy
 // of the plan, so the compiler cannot tell where they point: left alone it issues FLAT loads, which count on the LDS counter
 // (lgkmcnt) as well — and every LDS wait and LDS-only barrier of a task then also waits for the prefetches in flight.
-#define RSBA_GLOBAL __attribute__((address_space(1)))
-template <class V> __device__ __forceinline__ V gl(const V* p) { return *(const RSBA_GLOBAL V*)p; }
-template <bool DAG> __device__ __forceinline__ double ld(const double* p) {
-  if (DAG) return __hip_atomic_load((const RSBA_GLOBAL double*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return gl(p);
-}
-template <bool DAG> __device__ __forceinline__ void st(double* p, double v) {
-  if (DAG) __hip_atomic_store((RSBA_GLOBAL double*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else *(RSBA_GLOBAL double*)p = v;
-}
 // Waiting costs memory traffic: a task that found a group of cells incomplete does not keep re-reading the whole group
 // (hundreds of claimed-but-waiting tasks doing that saturate the memory system) — it watches ONE cell of the
 // missing input, with a pause between looks, and reads the group again once that cell has landed.
@@ -742,6 +760,31 @@ __device__ __forceinline__ void times_inverse_transposed(const SolverDev& sv, in
   }
 }
 
+// One column block of the same product for the DIAG task that follows column j on the critical chain: rows 16 I .., columns 16 Jc .. of
+// L = X W_j^T (the instruction sequence of times_inverse_transposed for that block: same bits), polling only the rows 16 Jc .. of W_j it
+// needs — the whole row block is read again straight away until it is complete (only a handful of DIAG tasks wait at any moment).
+template <bool DAG>
+__device__ __forceinline__ dbl4 times_inverse_block(const SolverDev& sv, int tile_j, const double* X, int Jc, int wave, int lane) {
+  const int I = wave, r = lane & 15, g = lane >> 4;
+  const double* Wg = sv.Winv + (size_t)tile_j * (T * T) + (16 * Jc + r) * T + g;
+  double wv[12];
+  bool late = false;
+  for (;;) {
+    bool ok = true;
+#pragma unroll
+    for (int kk = 0; kk < 12; ++kk) if (kk < 4 * (Jc + 1)) { wv[kk] = ld<DAG>(Wg + 4 * kk); ok = ok && filled(wv[kk]); }
+    if (!DAG || __ballot(!ok) == 0ull) break;
+    late = true;
+    __builtin_amdgcn_s_sleep(2);
+  }
+  if (late) note_late_input();
+  dbl4 c = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int kk = 0; kk < 12; ++kk)
+    if (kk < 4 * (Jc + 1)) c = __builtin_amdgcn_mfma_f64_16x16x4f64(X[(16 * I + r) * TP + 4 * kk + g], wv[kk], c, 0, 0, 0);   // (one accumulator, k ascending: the bits of times_inverse_transposed)
+  return c;
+}
+
 // DIAG task, early half: the updates formed so far are in acc / bz (K split over the waves), the tile and rhs (less the partial
 // tiles) in sreg / breg — D = S_jj - updates (lower triangle) and b = rhs - updates go to LDS.  No barrier at the end.
 __device__ __forceinline__ void diag_assemble(double sreg[9], double breg, Acc& acc, double bz[3], double* smem, int tid) {
@@ -772,11 +815,9 @@ __device__ __forceinline__ void diag_factor(const SolverDev& sv, int tile_j, dou
   lds_barrier();
   CHOL_STAMP(4);
   // L_jj itself is never formed: everything downstream uses W_j
-  const bool ok = factor_invert_tile(D, Wl, smem + 2 * kBuf, smem + 3 * kBuf, tid);
+  const bool ok = factor_invert_tile<false, false, DAG>(D, Wl, smem + 2 * kBuf, smem + 3 * kBuf, tid, nullptr, sv.Winv + (size_t)tile_j * (T * T));   // (W leaves by row blocks from inside)
   if (tid == 0 && !ok) atomicExch(sv.chol_fail, 1);
   CHOL_STAMP(6);
-  double* wout = sv.Winv + (size_t)tile_j * (T * T);
-  for (int e = tid; e < T * T; e += 256) { const int r = e / T, c = e % T; st<DAG>(wout + e, (c <= r) ? Wl[r * TP + c] : 0.0); }
   if (tid < T) {   // z_j = W b
     double s0 = 0.0, s1 = 0.0;
 #pragma unroll 8
@@ -837,24 +878,25 @@ __device__ __forceinline__ void task_diag(const SolverDev& sv, const CholPlan& p
       for (int q = 0; q < 9; ++q) { const int e = tid + 256 * q; XB[(e / T) * TP + e % T] = xreg[q]; }
     }
     lds_barrier();   // X and D are in LDS
-    if (wave < 3) {
-      const int r = lane & 15, g = lane >> 4;
-      dbl4 c[3];
-      times_inverse_transposed<DAG, true>(sv, tile_k, XB, c, wave, lane);
+    // W_k* arrives by row blocks (factor_invert_tile): column block Jc of L = X W^T needs rows 16 Jc .. of W only, and D -= L L^T is a sum
+    // over the column blocks of L — so each stage runs as its rows land, under the factorisation that produces the next ones, and only
+    // the last stage (a third of both products) is left on the chain.  Stage Jc: waves 0-2 form their row block of L(:, Jc), barrier,
+    // the six lower blocks of D take the rank-16 update (dealt to the four waves).  z_k* is stored behind the last rows of W.
 #pragma unroll
-      for (int J = 0; J < 3; ++J)
+    for (int Jc = 0; Jc < 3; ++Jc) {
+      if (wave < 3) {
+        const int r = lane & 15, g = lane >> 4;
+        const dbl4 cj = times_inverse_block<DAG>(sv, tile_k, XB, Jc, wave, lane);
 #pragma unroll
-        for (int v = 0; v < 4; ++v) LB[(16 * wave + g + 4 * v) * TP + 16 * J + r] = c[J][v];
-    } else if (lane < T) {   // z_k*, stored right behind W_k*
-      const double* zk = sv.zv + (size_t)tile_k * T + lane;
-      double z = ld<DAG>(zk);
-      while (DAG && !filled(z)) { __builtin_amdgcn_s_sleep(2); z = ld<DAG>(zk); }
-      zs[lane] = z;
-    }
-    lds_barrier();
-    // D -= L L^T on the lower 16 x 16 blocks, dealt to the waves (each block over all of K: no partial tiles to add up
-    // on the critical path); b -= L z_k* by two lanes per row of waves 2 and 3, which only have one block each
-    {
+        for (int v = 0; v < 4; ++v) LB[(16 * wave + g + 4 * v) * TP + 16 * Jc + r] = cj[v];
+      } else if (Jc == 2 && lane < T) {
+        const double* zk = sv.zv + (size_t)tile_k * T + lane;
+        double z = ld<DAG>(zk);
+        while (DAG && !filled(z)) { __builtin_amdgcn_s_sleep(2); z = ld<DAG>(zk); }
+        zs[lane] = z;
+      }
+      if (Jc == 2 && DAG && threadIdx.x == 0 && s_trace_slot) s_trace_slot[5] = wall_clock64();   // trace: the last rows of W_k* are in registers
+      lds_barrier();
       const int mi = lane & 15, mg = lane >> 4;
 #pragma unroll
       for (int blk = 0; blk < 6; ++blk) {
@@ -862,7 +904,7 @@ __device__ __forceinline__ void task_diag(const SolverDev& sv, const CholPlan& p
         const int I = blk < 1 ? 0 : (blk < 3 ? 1 : 2), J = blk - (I * (I + 1)) / 2;
         dbl4 a4 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int kk = 0; kk < T / 4; ++kk)
+        for (int kk = 4 * Jc; kk < 4 * Jc + 4; ++kk)
           a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(LB[(16 * I + mi) * TP + 4 * kk + mg], LB[(16 * J + mi) * TP + 4 * kk + mg], a4, 0, 0, 0);
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
@@ -870,6 +912,9 @@ __device__ __forceinline__ void task_diag(const SolverDev& sv, const CholPlan& p
           if (c <= r) D[r * TP + c] -= a4[v];
         }
       }
+    }
+    // b -= L z_k* by two lanes per row of waves 2 and 3, which only have one block each
+    {
       if (tid >= 128 && tid < 128 + 2 * T) {
         const int row = (tid - 128) >> 1, h = tid & 1;
         double s0 = 0.0;
