@@ -59,6 +59,7 @@ def cpu_baseline(prob, budget_s: float = 8.0, lm_iters: int = 3):
     faster for this memory-light loop, so a short calibration picks the best of {all, half, quarter}.  Also one thread,
     and the oracle's LM iteration (Schur complement in envelope storage + Cholesky) on the same scene."""
     from oracle import oracle as O
+    build = os.path.basename(O.select_build("host"))   # the AVX-512 build of the same source where the host has it
     ncpu = os.cpu_count() or 1
     best = None
     for threads in sorted({ncpu, max(1, ncpu // 2), max(1, ncpu // 4)}, reverse=True):
@@ -82,7 +83,7 @@ def cpu_baseline(prob, budget_s: float = 8.0, lm_iters: int = 3):
            "sample": f"{reps} x full residual+Jacobian evaluation of the {prob.num_observations}-observation scene, "
                      f"Dual<{prob.jacobian_cols}> autodiff, one cost object per observation, OpenMP {threads} threads",
            "ms_per_eval": dt * 1e3, "threads_1": {"value": prob.num_observations / dt1, "ms_per_eval": dt1 * 1e3},
-           "host": host_cpu()}
+           "host": host_cpu(), "build": build + (" (-march=x86-64-v4, AVX-512)" if "v4" in build else " (-march=x86-64-v3, AVX2 + FMA)")}
     try:   # the LM iteration of the same CPU path, bounded: lm_iters iterations of the whole scene
         O.lib().orc_set_num_threads(min(ncpu, 64))
         q = prob.copy()
@@ -112,7 +113,8 @@ def roofline_lm(prob, dp, iters, capi):
     rec = 8 * (2 + 2 * k)                       # the point-major record of one observation
     prec = 8 * cd * 3                           # its P record
     pgroups = st["schur_groups"] * 3 * 48 * 8   # the P records as the Schur kernel reads them: one [3][48] block per (point, frame tile)
-    if prob.calibrated:   # the point-side passes recompute the records from the observations (24 B each, slot order) instead of streaming 256-B copies
+    recompute = prob.calibrated or prob.num_intrinsics == 1
+    if recompute:   # the point-side passes recompute the records from the observations (24 B each, slot order) instead of streaming 256-B copies
         obs = n * 24 + prob.num_frames * prob.poses_per_frame * 96 + m * 48
         work_point = {"eval_lm": ("hbm", obs + n * 32), "point_blocks": ("hbm", obs + m * 72), "project": ("hbm", obs + n * 4 + m * 48 + pgroups),
                       "back_substitute": ("hbm", obs + m * (48 + 24 + 72 + 24))}
@@ -143,7 +145,7 @@ def roofline_lm(prob, dp, iters, capi):
                       f"structurally non-zero block products: {st['schur_block_products']} x {2 * cd * cd * 3} flop = {st['schur_block_products'] * 2 * cd * cd * 3 / 1e9:.2f} Gflop useful",
              "cholesky": f"latency-bound dependency chain: {st['levels']} elimination levels, {st['tasks']} tile tasks, {st['factor_tiles']} factor tiles",
              "eval_trial": "residual only: bound by the fp64 projection math, not by HBM"}
-    if prob.calibrated:
+    if recompute:
         for ph in ("eval_lm", "point_blocks", "project", "back_substitute"):
             notes[ph] = "records recomputed from the observations (rsba_amd/csrc/lm_record.hpp): ~0.6 kflop of fp64 per observation instead of a 256-B record from HBM — bound by the fp64 vector unit; bytes are what the pass still has to move"
         notes["project"] += "; writes the P records in the (point, tile) group layout"

@@ -74,6 +74,25 @@ class OrcSummary(C.Structure):
 _lib = None
 
 
+def select_build(which: str = "host") -> str:
+    """bench.py's cpu_baseline only: switch to the AVX-512 build of the same source when the host supports it ("host"), so that the
+    reported baseline is the box's best; "v3" switches back.  Returns the library path in use.  The parity tests never call this."""
+    global _lib, _LIB_PATH
+    build()
+    path = os.path.join(_HERE, "_build", "liboracle.so")
+    if which == "host":
+        try:
+            flags = next(l for l in open("/proc/cpuinfo") if l.startswith("flags")).split()
+        except Exception:  # noqa: BLE001
+            flags = []
+        v4 = os.path.join(_HERE, "_build", "liboracle_v4.so")
+        if all(f in flags for f in ("avx512f", "avx512bw", "avx512cd", "avx512dq", "avx512vl")) and os.path.exists(v4):
+            path = v4
+    if path != _LIB_PATH or _lib is None:
+        _LIB_PATH, _lib = path, None
+    return path
+
+
 def lib():
     global _lib
     if _lib is None:

@@ -705,10 +705,10 @@ __global__ __launch_bounds__(256) void point_step_kernel(const DeviceProblem dp,
 }
 
 // ---------------------------------------------------------------------------------------------
-// Calibrated problems: the point-side passes RECOMPUTE every observation's record (lm_record.hpp) instead of reading the
-// point-major copy the evaluation kernel used to leave for them — 24 B of observation + cached poses in, not 256 B of record.
-// Same arithmetic as the record-based kernels above (which the uncalibrated problems keep: their virtual intrinsics records
-// need the 9 intrinsics columns of every record of a point at once).
+// The point-side passes RECOMPUTE every observation's record (lm_record.hpp) instead of reading the point-major copy the
+// evaluation kernel used to leave for them — 24 B of observation + cached poses in, not 256 - 400 B of record.  Same arithmetic
+// as the record-based kernels above, which remain for problems with SEVERAL intrinsics parameter blocks (per-frame f.cam:
+// a point then owns one virtual record group per block it is seen through).
 // ---------------------------------------------------------------------------------------------
 __global__ void slot_xy_kernel(const DeviceProblem dp, double2* __restrict__ slot_xy) {   // once per plan: observations in slot (point-major) order
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -716,8 +716,8 @@ __global__ void slot_xy_kernel(const DeviceProblem dp, double2* __restrict__ slo
 }
 
 // the record of slot s (clamped by the caller): pose and scales straight from L2 (F x 192 B: resident)
-template <int P>
-__device__ __forceinline__ void slot_record(const DeviceProblem& dp, const SolverDev& sv, int64_t s, ObsOut<true, P>& o, int& frame, int& point) {
+template <bool CAL, int P>
+__device__ __forceinline__ void slot_record(const DeviceProblem& dp, const SolverDev& sv, int64_t s, ObsOut<CAL, P>& o, int& frame, int& point) {
   constexpr int CD = 6 * P;
   frame = sv.slot_frame[s]; point = sv.slot_point[s];
   const double2 xy = sv.slot_xy[s];
@@ -725,13 +725,13 @@ __device__ __forceinline__ void slot_record(const DeviceProblem& dp, const Solve
 #pragma unroll
   for (int k = 0; k < CD; ++k) { pose[k] = dp.poses[(size_t)frame * CD + k]; psc[k] = dp.scale_pose[(size_t)frame * CD + k]; }
   double half_rho; bool dropped;
-  lm_observation<true, P>(dp, frame, point, xy.x, xy.y, pose, psc, o, half_rho, dropped);
+  lm_observation<CAL, P>(dp, frame, point, xy.x, xy.y, pose, psc, o, half_rho, dropped);
 }
 
 // K5b without records: P = Jc^T (Jp L^-T) of 64 consecutive slots per wave and step, into the group layout (see project_kernel)
-template <int P>
+template <bool CAL, int P>
 __global__ __launch_bounds__(256) void project_rc_kernel(const DeviceProblem dp, const SolverDev sv) {
-  constexpr int CD = 6 * P, OUT = CD * 3, FT = kTile / CD, PITCH = OUT | 1, kPer = 64 / CD;
+  constexpr int CD = 6 * P, OUT = CD * 3, FT = kTile / CD, PITCH = OUT | 1, kPer = 64 / CD, OP = CAL ? 0 : 9;   // OP: the pose columns follow the 9 intrinsics columns
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double* buf = smem + (size_t)wave * (64 * PITCH + 32);
@@ -742,21 +742,21 @@ __global__ __launch_bounds__(256) void project_rc_kernel(const DeviceProblem dp,
   for (int64_t s0 = sb; s0 < se; s0 += 64) {
     const int64_t nslot = se - s0 < 64 ? se - s0 : 64;
     const int64_t s = s0 + lane < se ? s0 + lane : se - 1;   // (lanes past the end repeat the last slot; nothing of theirs is stored)
-    ObsOut<true, P> o;
+    ObsOut<CAL, P> o;
     int frame, j;
-    slot_record<P>(dp, sv, s, o, frame, j);
+    slot_record<CAL, P>(dp, sv, s, o, frame, j);
     const double* li = sv.Linv + (size_t)j * 6;
     const double i00 = li[0], i10 = li[1], i11 = li[2], i20 = li[3], i21 = li[4], i22 = li[5];
     double B[2][3];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-      const double p0 = o.J[r][CD], p1 = o.J[r][CD + 1], p2 = o.J[r][CD + 2];
+      const double p0 = o.J[r][OP + CD], p1 = o.J[r][OP + CD + 1], p2 = o.J[r][OP + CD + 2];
       B[r][0] = p0 * i00; B[r][1] = p0 * i10 + p1 * i11; B[r][2] = p0 * i20 + p1 * i21 + p2 * i22;
     }
 #pragma unroll
     for (int a = 0; a < CD; ++a)
 #pragma unroll
-      for (int k = 0; k < 3; ++k) buf[lane * PITCH + k * CD + a] = o.J[0][a] * B[0][k] + o.J[1][a] * B[1][k];
+      for (int k = 0; k < 3; ++k) buf[lane * PITCH + k * CD + a] = o.J[0][OP + a] * B[0][k] + o.J[1][OP + a] * B[1][k];
     s_gpos[lane] = sv.slot_gpos[s];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int my = lane / CD, w = lane % CD;
@@ -783,7 +783,7 @@ __global__ __launch_bounds__(256) void project_rc_kernel(const DeviceProblem dp,
 // (Sixteen points — a few hundred slots — per wave: the records are computed, not streamed, so the pass wants many waves in flight,
 // not long ones; 64 points per wave left the 100-camera scene with 40 workgroups.)
 constexpr int kSweepPoints = 16;
-template <int P, int NC, class PerSlot, class PerPoint>
+template <bool CAL, int P, int NC, class PerSlot, class PerPoint>
 __device__ __forceinline__ double point_sweep(const DeviceProblem& dp, const SolverDev& sv, double* smem, PerSlot per_slot, PerPoint per_point) {
   __shared__ double s_red[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -803,11 +803,11 @@ __device__ __forceinline__ double point_sweep(const DeviceProblem& dp, const Sol
       const int nrec = (int)(se - c0 < 64 ? se - c0 : 64);
       {
         const int64_t s = c0 + lane < se ? c0 + lane : se - 1;
-        ObsOut<true, P> o;
+        ObsOut<CAL, P> o;
         int frame, pt;
-        slot_record<P>(dp, sv, s, o, frame, pt);
+        slot_record<CAL, P>(dp, sv, s, o, frame, pt);
         double c[NC];
-        per_slot(o, frame, c);
+        per_slot(o, frame, pt, c);
 #pragma unroll
         for (int q = 0; q < NC; ++q) cbuf[lane * NC + q] = c[q];
       }
@@ -829,12 +829,12 @@ __device__ __forceinline__ double point_sweep(const DeviceProblem& dp, const Sol
 }
 
 // K2b without records: V_j, g_p,j
-template <int P>
+template <bool CAL, int P>
 __global__ __launch_bounds__(256) void point_blocks_rc_kernel(const DeviceProblem dp, const SolverDev sv) {
-  constexpr int CD = 6 * P;
+  constexpr int CD = (CAL ? 0 : 9) + 6 * P;   // columns in front of the point's
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  point_sweep<P, 9>(dp, sv, smem,
-    [&](const ObsOut<true, P>& o, int, double c[9]) {
+  point_sweep<CAL, P, 9>(dp, sv, smem,
+    [&](const ObsOut<CAL, P>& o, int, int, double c[9]) {
       const double r0 = o.r[0], r1 = o.r[1], p0[3] = {o.J[0][CD], o.J[0][CD + 1], o.J[0][CD + 2]}, p1[3] = {o.J[1][CD], o.J[1][CD + 1], o.J[1][CD + 2]};
       c[0] = p0[0] * p0[0] + p1[0] * p1[0]; c[1] = p0[0] * p0[1] + p1[0] * p1[1]; c[2] = p0[0] * p0[2] + p1[0] * p1[2];
       c[3] = p0[1] * p0[1] + p1[1] * p1[1]; c[4] = p0[1] * p0[2] + p1[1] * p1[2]; c[5] = p0[2] * p0[2] + p1[2] * p1[2];
@@ -851,17 +851,22 @@ __global__ __launch_bounds__(256) void point_blocks_rc_kernel(const DeviceProble
 }
 
 // K7 + K8 without records (see point_step_kernel)
-template <int P>
+template <bool CAL, int P>
 __global__ __launch_bounds__(256) void point_step_rc_kernel(const DeviceProblem dp, const SolverDev sv) {
-  constexpr int CD = 6 * P;
+  constexpr int CD = 6 * P, OP = CAL ? 0 : 9, OX = OP + CD;
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  const double mc = point_sweep<P, 5>(dp, sv, smem,
-    [&](const ObsOut<true, P>& o, int frame, double c[5]) {
+  const double mc = point_sweep<CAL, P, 5>(dp, sv, smem,
+    [&](const ObsOut<CAL, P>& o, int frame, int, double c[5]) {
       const double* yc = sv.rhs + (size_t)frame * CD;
       double t0 = 0.0, t1 = 0.0;
 #pragma unroll
-      for (int a = 0; a < CD; ++a) { const double y = yc[a]; t0 += o.J[0][a] * y; t1 += o.J[1][a] * y; }
-      c[0] = o.J[0][CD] * t0 + o.J[1][CD] * t1; c[1] = o.J[0][CD + 1] * t0 + o.J[1][CD + 1] * t1; c[2] = o.J[0][CD + 2] * t0 + o.J[1][CD + 2] * t1;   // Jp^T t
+      for (int a = 0; a < CD; ++a) { const double y = yc[a]; t0 += o.J[0][OP + a] * y; t1 += o.J[1][OP + a] * y; }
+      if (!CAL) {
+        const double* yi = sv.rhs + (size_t)sv.F * CD;   // step of the (one) intrinsics block: 9 coordinates across its pseudo frames
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { const double y = yi[k]; t0 += o.J[0][k] * y; t1 += o.J[1][k] * y; }
+      }
+      c[0] = o.J[0][OX] * t0 + o.J[1][OX] * t1; c[1] = o.J[0][OX + 1] * t0 + o.J[1][OX + 1] * t1; c[2] = o.J[0][OX + 2] * t0 + o.J[1][OX + 2] * t1;   // Jp^T t
       c[3] = t0 * t0 + t1 * t1;
       c[4] = o.r[0] * t0 + o.r[1] * t1;
     },
@@ -880,6 +885,49 @@ __global__ __launch_bounds__(256) void point_step_rc_kernel(const DeviceProblem 
       return -acc[4] - (y0 * g[0] + y1 * g[1] + y2 * g[2]) + 0.5 * acc[3] + (y0 * u0 + y1 * u1 + y2 * u2) + 0.5 * (y0 * vy0 + y1 * vy1 + y2 * vy2);
     });
   if (threadIdx.x == 0) sv.partial[blockIdx.x] = mc;
+}
+
+// the virtual records of the intrinsics pseudo frames without records, ONE intrinsics block (the shared sess.cam): per point
+// Q_j = sum_o Ji_o^T (Jp_o L_j^-T) (9 x 3), cut into the NPF pseudo-frame records of the point's virtual slots (see virtual_records_kernel)
+template <int P>
+__global__ __launch_bounds__(256) void virtual_records_rc_kernel(const DeviceProblem dp, const SolverDev sv) {
+  constexpr int CD = 6 * P, OX = 9 + CD, FT = kTile / CD;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  point_sweep<false, P, 27>(dp, sv, smem,
+    [&](const ObsOut<false, P>& o, int, int j, double c[27]) {
+      const double* li = sv.Linv + (size_t)j * 6;
+      const double i00 = li[0], i10 = li[1], i11 = li[2], i20 = li[3], i21 = li[4], i22 = li[5];
+      double B[2][3];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const double p0 = o.J[r][OX], p1 = o.J[r][OX + 1], p2 = o.J[r][OX + 2];
+        B[r][0] = p0 * i00; B[r][1] = p0 * i10 + p1 * i11; B[r][2] = p0 * i20 + p1 * i21 + p2 * i22;
+      }
+#pragma unroll
+      for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int m = 0; m < 3; ++m) c[3 * k + m] = o.J[0][k] * B[0][m] + o.J[1][k] * B[1][m];
+    },
+    [&](int64_t j, const double acc[27]) {
+      const int64_t g = sv.point_vgroup[j];
+      if (g < 0) return 0.0;
+      for (int v = 0; v < sv.NPF; ++v) {
+        const int gpos = sv.slot_gpos[dp.N + g * sv.NPF + v];
+        double* out = sv.Pm + (size_t)(gpos / FT) * (kTile * 3) + (gpos % FT) * CD;
+#pragma unroll
+        for (int rl = 0; rl < CD; ++rl) {
+          const int k = v * CD + rl;
+#pragma unroll
+          for (int m = 0; m < 3; ++m) {
+            double q = 0.0;
+#pragma unroll
+            for (int kk = 0; kk < 9; ++kk) if (kk == k) q = acc[3 * kk + m];
+            out[m * kTile + rl] = q;
+          }
+        }
+      }
+      return 0.0;
+    });
 }
 
 __global__ __launch_bounds__(256) void reduce_sum_kernel(const double* partial, int n, double* out, double sign) {
@@ -997,8 +1045,8 @@ hipError_t launch_point_blocks(const DeviceProblem& dp, const SolverDev& sv, hip
     if (dp.M <= 0) return hipSuccess;
     const size_t lds = (size_t)4 * 64 * 9 * sizeof(double);
     const int grid = (int)((dp.M + 4 * kSweepPoints - 1) / (4 * kSweepPoints));
-    if (sv.CD == 12) hipLaunchKernelGGL(point_blocks_rc_kernel<2>, dim3(grid), dim3(256), lds, st, dp, sv);
-    else hipLaunchKernelGGL(point_blocks_rc_kernel<1>, dim3(grid), dim3(256), lds, st, dp, sv);
+    if (dp.calibrated) { if (sv.CD == 12) hipLaunchKernelGGL((point_blocks_rc_kernel<true, 2>), dim3(grid), dim3(256), lds, st, dp, sv); else hipLaunchKernelGGL((point_blocks_rc_kernel<true, 1>), dim3(grid), dim3(256), lds, st, dp, sv); }
+    else { if (sv.CD == 12) hipLaunchKernelGGL((point_blocks_rc_kernel<false, 2>), dim3(grid), dim3(256), lds, st, dp, sv); else hipLaunchKernelGGL((point_blocks_rc_kernel<false, 1>), dim3(grid), dim3(256), lds, st, dp, sv); }
     return hipGetLastError();
   }
   LAUNCH(point_blocks_kernel, nblocks256(dp.M), 256, st, dp, sv);
@@ -1055,8 +1103,8 @@ hipError_t launch_project(const DeviceProblem& dp, const SolverDev& sv, hipStrea
     const int CD = sv.CD;
     const size_t lds = (size_t)4 * (64 * ((CD * 3) | 1) + 32) * sizeof(double);
     const int grid = (int)((dp.N + 256 * kProjectChunks - 1) / (256 * kProjectChunks));
-    if (CD == 12) hipLaunchKernelGGL(project_rc_kernel<2>, dim3(grid), dim3(256), lds, st, dp, sv);
-    else hipLaunchKernelGGL(project_rc_kernel<1>, dim3(grid), dim3(256), lds, st, dp, sv);
+    if (dp.calibrated) { if (CD == 12) hipLaunchKernelGGL((project_rc_kernel<true, 2>), dim3(grid), dim3(256), lds, st, dp, sv); else hipLaunchKernelGGL((project_rc_kernel<true, 1>), dim3(grid), dim3(256), lds, st, dp, sv); }
+    else { if (CD == 12) hipLaunchKernelGGL((project_rc_kernel<false, 2>), dim3(grid), dim3(256), lds, st, dp, sv); else hipLaunchKernelGGL((project_rc_kernel<false, 1>), dim3(grid), dim3(256), lds, st, dp, sv); }
     return hipGetLastError();
   }
   if (sv.CD == 12 && KC == 12) return launch_project_as<12, 12>(dp, sv, st);
@@ -1074,6 +1122,13 @@ hipError_t launch_intr_blocks(const DeviceProblem& dp, const SolverDev& sv, hipS
 hipError_t launch_virtual_records(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {
   if (sv.NPF == 0) return hipSuccess;
   if (sv.nvgroups == 0) return hipSuccess;
+  if (sv.slot_xy) {   // (one intrinsics block: recomputed like the rest)
+    const size_t lds = (size_t)4 * 64 * 27 * sizeof(double);
+    const int grid = (int)((dp.M + 4 * kSweepPoints - 1) / (4 * kSweepPoints));
+    if (sv.CD == 12) hipLaunchKernelGGL(virtual_records_rc_kernel<2>, dim3(grid), dim3(256), lds, st, dp, sv);
+    else hipLaunchKernelGGL(virtual_records_rc_kernel<1>, dim3(grid), dim3(256), lds, st, dp, sv);
+    return hipGetLastError();
+  }
   if (sv.CD == 12) LAUNCH(virtual_records_kernel<12>, nblocks256(sv.nvgroups), 256, st, dp, sv);
   else LAUNCH(virtual_records_kernel<6>, nblocks256(sv.nvgroups), 256, st, dp, sv);
   return hipSuccess;
@@ -1118,8 +1173,8 @@ hipError_t launch_back_substitute(const DeviceProblem& dp, const SolverDev& sv, 
   if (sv.slot_xy) {
     const size_t lds = (size_t)4 * 64 * 5 * sizeof(double);
     const int grid = point_step_blocks(dp, sv);
-    if (sv.CD == 12) hipLaunchKernelGGL(point_step_rc_kernel<2>, dim3(grid), dim3(256), lds, st, dp, sv);
-    else hipLaunchKernelGGL(point_step_rc_kernel<1>, dim3(grid), dim3(256), lds, st, dp, sv);
+    if (dp.calibrated) { if (sv.CD == 12) hipLaunchKernelGGL((point_step_rc_kernel<true, 2>), dim3(grid), dim3(256), lds, st, dp, sv); else hipLaunchKernelGGL((point_step_rc_kernel<true, 1>), dim3(grid), dim3(256), lds, st, dp, sv); }
+    else { if (sv.CD == 12) hipLaunchKernelGGL((point_step_rc_kernel<false, 2>), dim3(grid), dim3(256), lds, st, dp, sv); else hipLaunchKernelGGL((point_step_rc_kernel<false, 1>), dim3(grid), dim3(256), lds, st, dp, sv); }
     return hipGetLastError();
   }
   if (sv.CD == 12) return KC == 12 ? launch_point_step<12, 12>(dp, sv, st) : launch_point_step<12, 21>(dp, sv, st);

@@ -706,6 +706,9 @@ int32_t build_solver(rsba_handle* h) {
     if ((rc = s_upload_const(s, &sv.intr_frame_list, ifl))) return rc;
     if ((rc = s_upload_const(s, &sv.vgroup_point, vgroup_point))) return rc;
     if ((rc = s_upload_const(s, &sv.vgroup_intr, vgroup_intr))) return rc;
+    std::vector<int64_t> point_vgroup(NIB == 1 ? (size_t)M : 0, -1);
+    for (int j = 0; j < M && NIB == 1; ++j) if (vgroup_ptr[j + 1] > vgroup_ptr[j]) point_vgroup[j] = vgroup_ptr[j];
+    if ((rc = s_upload_const(s, &sv.point_vgroup, point_vgroup))) return rc;
   }
   if ((rc = s_upload(s, &s->d_obs_slot, obs_slot))) return rc;
   if ((rc = s_upload_const(s, &sv.chunk_tp, chunk_tp))) return rc;
@@ -746,9 +749,9 @@ int32_t build_solver(rsba_handle* h) {
   tick("uploads");
   const size_t REC = 2 + 2 * (size_t)dp.K;
   h->dp.obs_slot = s->d_obs_slot;
-  // Calibrated problems recompute the records in the point-side passes (lm_record.hpp) from the observations in slot order;
-  // the others (intrinsics as parameter blocks: virtual records) keep the point-major copy.  RSBA_RECORDS=1 forces the copy.
-  bool recompute = dp.calibrated != 0;
+  // The point-side passes recompute the records (lm_record.hpp) from the observations in slot order; problems with several
+  // intrinsics parameter blocks (per-frame f.cam) keep the point-major copy.  RSBA_RECORDS=1 forces the copy.
+  bool recompute = dp.calibrated != 0 || NIB == 1;
   if (const char* e = std::getenv("RSBA_RECORDS")) recompute = recompute && e[0] != '1';
   sv.slot_xy = nullptr; h->dp.rec = nullptr;
   if (recompute) {

@@ -33,6 +33,7 @@ struct SolverDev {
   int64_t nvgroups;             // (point, intrinsics block it is seen through) pairs: each owns NPF virtual slots N + g*NPF + v
   const int32_t* vgroup_point;  // [nvgroups]
   const int32_t* vgroup_intr;   // [nvgroups]
+  const int64_t* point_vgroup;  // [M] with one intrinsics block: the point's virtual group, -1 = not observed
   int CD;                       // 6 * P
   int64_t n, npad;              // camera unknowns F*CD, padded to a multiple of kTile
   int nt;                       // npad / kTile

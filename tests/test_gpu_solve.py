@@ -285,3 +285,29 @@ def test_a_wrong_dag_result_is_caught_and_redone_on_the_level_schedule(capi, mon
     assert out["corrupt"][2] == 1 and out["levels"][2] == 0 and out["plain"][2] == 0
     for a, b in ((out["corrupt"], out["levels"]), (out["plain"], out["levels"])):
         assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+
+
+@pytest.mark.parametrize("shared_intrinsics", [False, True])
+def test_recomputed_records_equal_the_stored_ones(capi, monkeypatch, shared_intrinsics):
+    """The point-side passes of the solve recompute each observation's LM record (rsba_amd/csrc/lm_record.hpp) instead of reading
+    the point-major copy the evaluation kernel can leave for them (RSBA_RECORDS=1, and always with several intrinsics blocks):
+    the same function of the same inputs — the two solves may differ by the rounding of differently fused multiply-adds only."""
+    from rsba_amd.problem import apply_gauge_masks
+    from rsba_amd.scene import make_scene
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("RSBA_RECORDS", mode)
+        p = make_scene(40, 3000, seed=23, outlier_ratio=0.05).problem
+        p.huber_a = 2.0
+        p.calibrated = not shared_intrinsics
+        apply_gauge_masks(p, fix_first_n_cameras=1)
+        p.pose_fixed_mask[-1, -1] |= 0b111000
+        with capi.DeviceProblem(p) as dp:
+            s, tr = dp.solve(capi.default_options(max_num_iterations=8, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0))
+        res[mode] = (s, tr, p.poses.copy(), p.points.copy())
+    a, b = res["0"], res["1"]
+    assert a[0].num_iterations == b[0].num_iterations
+    for x, y in zip(a[1], b[1]):
+        assert x.step_is_successful == y.step_is_successful
+        assert abs(x.cost - y.cost) <= 1e-11 * y.cost
+    assert np.max(np.abs(a[2] - b[2])) <= 1e-8 and np.max(np.abs(a[3] - b[3])) <= 1e-7
