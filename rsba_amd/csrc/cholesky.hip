@@ -1009,6 +1009,16 @@ __device__ __forceinline__ void task_back(const SolverDev& sv, const CholPlan& p
     for (int u = 0; u < 5; ++u) ok = ok && filled(v[u].x) && filled(v[u].y) && filled(yy[u]);
     return ok;
   };
+  // W_j and z_j (from the DIAG task of this column, long finished as a rule) are requested NOW and looked at behind the y_i the
+  // task really waits for: their round trips used to sit between the last y_i and the store of y_j, on the chain of the backward solve
+  const double* Wg = sv.Winv + (size_t)tile_j * (T * T);
+  double2 wpre[5];
+#pragma unroll
+  for (int u = 0; u < 5; ++u) {
+    const int r = rg + 10 * u;
+    if (worker && r < T) { const double* q = Wg + (size_t)r * T + 2 * c2; wpre[u] = make_double2(ld<DAG>(q), ld<DAG>(q + 1)); } else wpre[u] = make_double2(0.0, 0.0);
+  }
+  double zpre = tid < T ? ld<DAG>(sv.zv + (size_t)tile_j * T + tid) : 0.0;
   double s0 = 0.0, s1 = 0.0;
   if (p0 < p1) {
     // L_ij (forward phase) is long finished; y_i is what the task waits for.  The host lists the tiles of the
@@ -1056,7 +1066,7 @@ __device__ __forceinline__ void task_back(const SolverDev& sv, const CholPlan& p
   lds_barrier();
   CHOL_STAMP(3);
   if (tid < T) {
-    double t = ld<DAG>(sv.zv + (size_t)tile_j * T + tid);   // z_j, from the DIAG task of this column
+    double t = zpre;   // z_j, from the DIAG task of this column
     while (DAG && !filled(t)) { __builtin_amdgcn_s_sleep(8); t = ld<DAG>(sv.zv + (size_t)tile_j * T + tid); }
 #pragma unroll
     for (int g = 0; g < 10; ++g) t -= part[g * T + tid];
@@ -1065,9 +1075,9 @@ __device__ __forceinline__ void task_back(const SolverDev& sv, const CholPlan& p
   lds_barrier();
   // y = W^T t
   {
-    const double* Wg = sv.Winv + (size_t)tile_j * (T * T);
     double2 v[5]; double yy[5];
-    gather(Wg, tvec, v, yy, true);
+#pragma unroll
+    for (int u = 0; u < 5; ++u) { const int r = rg + 10 * u; v[u] = wpre[u]; yy[u] = (worker && r < T) ? tvec[r] : 0.0; }
     while (DAG && !gathered_ok(v, yy)) { __builtin_amdgcn_s_sleep(8); gather(Wg, tvec, v, yy, true); }
     s0 = 0.0; s1 = 0.0;
 #pragma unroll
@@ -1208,13 +1218,7 @@ hipError_t launch_chol_dag(const SolverDev& sv, const CholPlan& pl, const DagArg
   static_assert(kCholLds * sizeof(double) <= (size_t)84 * 1024, "LDS map of the Cholesky tasks");
   hipError_t e = allow_dynamic_lds(chol_dag_kernel, lds_bytes);
   if (e != hipSuccess) return e;
-  e = hipMemsetAsync(pl.ticket, 0, 16, st);
-  // every write-once cell starts out empty (all ones): factor tiles, partial tiles, W, z | y
-  if (e == hipSuccess) e = hipMemsetAsync(sv.Lf, 0xFF, (size_t)sv.nslots * T * T * sizeof(double), st);
-  if (e == hipSuccess) e = hipMemsetAsync(sv.chol_part, 0xFF, (size_t)(pl.nparts > 0 ? pl.nparts : 1) * (T * T + T) * sizeof(double), st);
-  if (e == hipSuccess) e = hipMemsetAsync(sv.Winv, 0xFF, (size_t)sv.nt * T * T * sizeof(double), st);
-  if (e == hipSuccess) e = hipMemsetAsync(sv.zv, 0xFF, 2 * (size_t)sv.npad * sizeof(double), st);
-  if (e == hipSuccess) e = hipMemsetAsync(sv.Xpub, 0xFF, (size_t)sv.nt * T * T * sizeof(double), st);
+  e = hipMemsetAsync(pl.ticket, 0, 16, st);   // (the caller has re-armed the write-once cells: one memset over their common allocation, solver.hip)
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(chol_dag_kernel, dim3(workgroups), dim3(256), lds_bytes, st, device_args);
   return hipGetLastError();

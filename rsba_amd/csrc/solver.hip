@@ -80,6 +80,7 @@ struct Solver {
   int32_t* d_obs_slot = nullptr;
   double *d_gpose = nullptr, *d_gpoint = nullptr;
   int64_t num_pairs = 0;
+  double* cells = nullptr; size_t ncells = 0;                         // the write-once cells of the DAG Cholesky (one allocation: Lf | chol_part | Winv | zv | yv | Xpub)
   int64_t schur_launches = 0;                                         // launches of the Schur kernel since the plan was built (statistics)
   int num_reduced_blocks = 0, num_reduced_params = 0, num_priors_reduced = 0;
   double* border = nullptr, *ubuf = nullptr, *ratio4 = nullptr;      // free interFrameRatio: its column of S [npad], the first solve's result, {h, g, b.u, b.v}
@@ -723,12 +724,17 @@ int32_t build_solver(rsba_handle* h) {
   if ((rc = s_upload_const(s, &sv.tp_add, tp_add))) return rc;
   if ((rc = s_alloc(s, &sv.schur_part, (size_t)std::max(sv.nchunk, 1) * (kTile * kTile + kTile)))) return rc;
   if ((rc = s_upload(s, &s->d_upd, s->upd))) return rc;
-  if ((rc = s_alloc(s, &sv.chol_part, (size_t)std::max(parts, 1) * (kTile * kTile + kTile)))) return rc;
+  // the write-once cells of the persistent Cholesky driver — factor tiles | partial tiles | W | z, y | published X — live in ONE
+  // allocation: one memset re-arms them before a launch (five launches before)
+  {
+    const size_t nLf = (size_t)sv.nslots * kTile * kTile, nPart = (size_t)std::max(parts, 1) * (kTile * kTile + kTile), nW = (size_t)nt * kTile * kTile, nZ = 2 * (size_t)sv.npad;
+    double* cells = nullptr;
+    if ((rc = s_alloc(s, &cells, nLf + nPart + nW + nZ + nW))) return rc;
+    sv.Lf = cells; sv.chol_part = cells + nLf; sv.Winv = sv.chol_part + nPart; sv.zv = sv.Winv + nW; sv.yv = sv.zv + sv.npad; sv.Xpub = sv.zv + nZ;
+    s->cells = cells; s->ncells = nLf + nPart + nW + nZ + nW;
+  }
   if ((rc = s_upload(s, &s->d_tasks, s->tasks))) return rc;
   if ((rc = s_alloc(s, &s->d_dag_sync, 4))) return rc;
-  if ((rc = s_alloc(s, &sv.Lf, (size_t)sv.nslots * kTile * kTile))) return rc;
-  if ((rc = s_alloc(s, &sv.zv, 2 * (size_t)sv.npad))) return rc;
-  sv.yv = sv.zv + sv.npad;
   if ((rc = s_upload(s, &s->d_diag_info, s->diag_info))) return rc;
   if ((rc = s_upload(s, &s->d_diag_ptr, s->diag_ptr))) return rc;
   if ((rc = s_upload(s, &s->d_diag_list, s->diag_list))) return rc;
@@ -739,9 +745,7 @@ int32_t build_solver(rsba_handle* h) {
   if ((rc = s_upload(s, &s->d_diag_own, s->diag_own))) return rc;
   if ((rc = s_upload(s, &s->d_diag_fuse, s->diag_fuse))) return rc;
   if ((rc = s_upload(s, &s->d_sub_pub, s->sub_pub))) return rc;
-  if ((rc = s_alloc(s, &sv.Xpub, (size_t)nt * kTile * kTile))) return rc;
   if ((rc = s_upload(s, &s->d_sub_own, s->sub_own))) return rc;
-  if ((rc = s_alloc(s, &sv.Winv, (size_t)nt * kTile * kTile))) return rc;
   if ((rc = s_upload(s, &s->d_back_info, s->back_info))) return rc;
   if ((rc = s_upload(s, &s->d_back_ptr, s->back_ptr))) return rc;
   if ((rc = s_upload(s, &s->d_back_list, s->back_list))) return rc;
@@ -804,6 +808,7 @@ int32_t build_solver(rsba_handle* h) {
 
   if ((rc = s_alloc(s, &sv.S, (size_t)sv.nslots * kTile * kTile + (size_t)sv.npad))) return rc;
   sv.rhs = sv.S + (size_t)sv.nslots * kTile * kTile;   // one buffer = exchange payload (2)
+  HIP_TRY(hipMemsetAsync(sv.S, 0, ((size_t)sv.nslots * kTile * kTile + (size_t)sv.npad) * sizeof(double), h->stream));   // fill-only tiles stay zero for good
   if ((rc = s_alloc(s, &sv.udiag, (size_t)F * CD))) return rc;
   if ((rc = s_alloc(s, &sv.xbuf, 2 * (size_t)F * CD + 3))) return rc;
   if ((rc = s_alloc(s, &sv.yp, (size_t)M * 3))) return rc;
@@ -983,7 +988,8 @@ int32_t reduce_system(rsba_handle* h, double radius) {
   }
   {
     PhaseScope ps(h, RSBA_PHASE_SCHUR);
-    HIP_TRY(launch_clear_system(sv, st));
+    // (S needs no clearing: the merge kernel overwrites every tile a tile pair maps to, and the fill-only tiles — zeroed when the
+    // plan was built — are never written by anyone: the factorisation keeps its own tiles, the multi-GPU exchange adds zeros)
     HIP_TRY(launch_schur_blocks(h->dp, sv, radius, st));
     ++s->schur_launches;
     if (sv.lead) HIP_TRY(launch_pose_prior_reduce(h->dp, sv, s->pp, radius, st));   // the priorPoses blocks leave the system like points
@@ -1000,6 +1006,7 @@ int32_t solve_reduced_system(rsba_handle* h) {
   Solver* s = h->solver; const SolverDev& sv = s->sv; hipStream_t st = h->stream;
   PhaseScope ps(h, RSBA_PHASE_CHOLESKY);
   if (!s->use_levels) {
+    HIP_TRY(hipMemsetAsync(s->cells, 0xFF, s->ncells * sizeof(double), st));   // every write-once cell starts out empty (all ones)
     HIP_TRY(launch_chol_dag(sv, s->plan, s->d_dag_args, s->dag_workgroups, s->dag_one_per_cu, st));
     if (s->test_corrupt_once) { s->test_corrupt_once = false; HIP_TRY(hipMemsetAsync(sv.yv + (sv.n / 2 / 6) * 6 + 1, 0, sizeof(double), st)); }   // test hook: one entry of the solution (a pose coordinate in mid-video) lost
     if (s->verify_dag) HIP_TRY(launch_chol_verify(sv, s->d_slot_tiles, s->d_verify, s->d_verify + sv.npad, 1e-7, sv.scalars + kDagSuspect, st));
