@@ -10,6 +10,7 @@
 //   ba_session --cache session.cache out.bin [fixFirstN=1] [maxIter=20] [huber=0] [calibrated=1] [useOnlyValidMatches=1] [sqrdThreshold=16] [trustRotation=0] [trustPosition=0]
 //     replays a Session cache written by the reference (VideoSfMCache, Thrift binary; include/rsba/session_cache.hpp)
 //   g++ -std=c++17 -O2 -Iinclude examples/ba_session.cpp -Lrsba_amd/_lib -lrsba_amd -Wl,-rpath,... -o ba_session
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -31,7 +32,9 @@ static int write_result(const char* path, const Session& sess, const ceres::Solv
   const double head[6] = {summary.initial_cost, summary.final_cost, (double)summary.iterations.size(), (double)summary.num_residual_blocks_reduced,
                           (double)(int)summary.termination_type, usable ? 1.0 : 0.0};
   std::fwrite(head, sizeof(double), 6, g);
-  for (const Frame& fr : sess.frames) for (const auto& pose : fr.poses) std::fwrite(pose.data(), sizeof(double), 6, g);
+  size_t pmax = 0;
+  for (const Frame& fr : sess.frames) pmax = std::max(pmax, fr.poses.size());
+  for (const Frame& fr : sess.frames) for (size_t q = 0; q < pmax; ++q) std::fwrite(fr.poses[std::min(q, fr.poses.size() - 1)].data(), sizeof(double), 6, g);   // (a one-pose frame of a two-pose session fills both slots of the [F][P][6] layout)
   for (const Track& t : sess.tracks) std::fwrite(t.pt.data(), sizeof(double), 3, g);
   for (const Frame& fr : sess.frames) if (fr.__isset.priorPoses) for (const auto& pose : fr.priorPoses) std::fwrite(pose.data(), sizeof(double), 6, g);   // solved priorPoses blocks
   if (covf >= 0 && (size_t)covf < covs.size() && covs[(size_t)covf].size() == 108) std::fwrite(covs[(size_t)covf].data(), sizeof(double), 108, g);
@@ -60,7 +63,7 @@ static int replay_cache(int argc, char** argv) {
 
 int main(int argc, char** argv) {
   if (argc >= 4 && !std::strcmp(argv[1], "--cache")) return replay_cache(argc, argv);
-  if (argc < 3) { std::fprintf(stderr, "usage: %s scene.bin out.bin [startFrame] [camEvery] [BA|fullBA|windowedBA] [validTracks] [useOnlyValidMatches]\n", argv[0]); return 2; }
+  if (argc < 3) { std::fprintf(stderr, "usage: %s scene.bin out.bin [startFrame] [camEvery] [BA|fullBA|windowedBA] [validTracks] [useOnlyValidMatches] [gsEvery]\n", argv[0]); return 2; }
   FILE* f = std::fopen(argv[1], "rb");
   if (!f) { std::perror("scene"); return 2; }
   int32_t hd[11]; int64_t N; double huber, reval, covf, motion[3], cam[9];
@@ -105,6 +108,9 @@ int main(int argc, char** argv) {
   const int validTracks = argc > 6 ? std::atoi(argv[6]) : -1;
   for (int j = 0; validTracks >= 0 && j < M; ++j) sess.tracks[j].valid = j < validTracks;
   if (argc > 7) opt.ceres.useOnlyValidMatches = std::atoi(argv[7]) != 0;
+  const int gsEvery = argc > 8 ? std::atoi(argv[8]) : 0;               // > 0: every gsEvery-th frame has ONE pose (its first): CeresHandler::Add then gives it
+  for (int i = 0; gsEvery > 0 && i < F; ++i)                            // the global-shutter functor inside the rolling-shutter session (CeresHandler.h:245-286)
+    if (i % gsEvery == gsEvery - 1 && sess.frames[i].poses.size() == 2) sess.frames[i].poses.resize(1);
   const bool usable = !std::strcmp(entry, "fullBA")       ? fullBA(sess, opt, hd[10], &summary, true, &covs)
                       : !std::strcmp(entry, "windowedBA") ? windowedBA(sess, opt, startFrame, F - 1, hd[10], &summary, true, &covs)
                                                           : BA(sess, startFrame, F - 1, opt, hd[10], &summary, true, &covs);

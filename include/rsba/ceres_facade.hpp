@@ -336,6 +336,7 @@ class Problem {
     std::vector<double> poses, points, intr, xy;
     std::vector<int32_t> obs_frame, obs_point, frame_intr;
     std::vector<uint8_t> pose_mask, point_const, intr_const;
+    std::vector<uint8_t> frame_global;                     // two-pose problems that contain one-pose frames (CeresHandler.h:266-285): 1 per such frame; empty = none
     std::vector<double*> pose_ptr, point_ptr, intr_ptr;   // where each flat block came from (nullptr: data, not a block)
     std::map<double*, Slot> slot_of;
     // motion priors (constant interFrameRatio): lowered to rsba_set_motion_priors
@@ -351,6 +352,10 @@ class Problem {
   static int32_t create_handle(const Flat& f, int device, rsba_handle** h) {
     int32_t st = rsba_create(&f.desc, device, h);
     if (st != RSBA_OK) return st;
+    if (!f.frame_global.empty()) {
+      st = rsba_set_global_shutter_frames(*h, f.frame_global.data());
+      if (st != RSBA_OK) { rsba_destroy(*h); *h = nullptr; return st; }
+    }
     if (!f.prior_frames.empty()) {
       st = rsba_set_motion_priors(*h, f.prior_kind, f.prior_scale, f.prior_ratio, f.prior_frames.data(), (int32_t)f.prior_frames.size());
       if (st == RSBA_OK && f.ratio_free) st = rsba_set_inter_frame_ratio_free(*h, 1);
@@ -387,8 +392,16 @@ class Problem {
     const ReprojectionCost* first = nullptr; LossFunction* loss0 = nullptr;
     for (const Block& b : blocks_) if ((first = dynamic_cast<const ReprojectionCost*>(b.cost))) { loss0 = b.loss; break; }
     if (!first) return fail("only rsba's reprojection cost functions (plus motion priors between their frames) are accelerated");
-    const bool rolling = first->rolling(), with_cam = first->with_cam();
+    // CeresHandler::Add picks the functor per frame (f.poses.size() == 2: RsBundleAdjustment, else ReprojectionError on getPose(...),
+    // CeresHandler.h:245-286): a session may mix them.  The flat problem then has two pose slots per frame; a one-pose frame uses
+    // the first (flagged for rsba_set_global_shutter_frames), its second slot is a constant copy that is not written back.
+    bool rolling = false;
+    for (const Block& b : blocks_) if (const ReprojectionCost* c = dynamic_cast<const ReprojectionCost*>(b.cost)) rolling = rolling || c->rolling();
+    const bool with_cam = first->with_cam();
     const int P = rolling ? 2 : 1;
+    const ReprojectionCost* first_rolling = nullptr;      // shutter / scanlines / interpolateRotation of the session come from a rolling-shutter block
+    for (const Block& b : blocks_) if (const ReprojectionCost* c = dynamic_cast<const ReprojectionCost*>(b.cost)) if (c->rolling()) { first_rolling = c; break; }
+    if (first_rolling) first = first_rolling;
     std::map<std::pair<double*, double*>, int> frame_of;
     std::map<double*, int> point_of, intr_of;
     std::map<std::vector<double>, int> intr_by_value;
@@ -397,16 +410,17 @@ class Problem {
       if (dynamic_cast<const MotionPriorCost*>(b.cost) || dynamic_cast<const PosePriorCost*>(b.cost)) continue;   // later passes, once every frame has its number
       const ReprojectionCost* c = dynamic_cast<const ReprojectionCost*>(b.cost);
       if (!c) return fail("only rsba's reprojection cost functions (plus motion priors between their frames) are accelerated");
-      if (c->rolling() != rolling || c->with_cam() != with_cam) return fail("mixed functor shapes in one problem are not supported");
+      if (c->with_cam() != with_cam) return fail("residual blocks with and without an intrinsics parameter block in one problem are not supported");
+      const bool one_pose = rolling && !c->rolling();
       if (b.loss != loss0) return fail("all residual blocks must share one loss function (as CeresHandler does)");
       if (b.x.size() != c->parameter_block_sizes().size()) return fail("wrong number of parameter blocks");
       int32_t s2[2]; c->scanlines(s2);
-      if (c->shutter() != first->shutter() || s2[0] != sl[0] || s2[1] != sl[1] || c->interpolate_rotation() != first->interpolate_rotation())
+      if (!one_pose && (c->shutter() != first->shutter() || s2[0] != sl[0] || s2[1] != sl[1] || c->interpolate_rotation() != first->interpolate_rotation()))
         return fail("residual blocks disagree on shutter / scanlines / interpolateRotation");
       size_t k = 0;
       double* camp = with_cam ? b.x[k++] : nullptr;
       double* p0 = b.x[k++];
-      double* p1 = rolling ? b.x[k++] : nullptr;
+      double* p1 = c->rolling() ? b.x[k++] : nullptr;
       double* pt = b.x[k++];
       int ci;
       if (with_cam) {
@@ -425,7 +439,12 @@ class Problem {
       if (itf == frame_of.end()) {
         fi = (int)f->frame_intr.size(); frame_of[key] = fi; f->frame_intr.push_back(ci);
         f->pose_ptr.push_back(p0); f->poses.insert(f->poses.end(), p0, p0 + 6); f->slot_of[p0] = Slot{0, fi * P};
-        if (rolling) { f->pose_ptr.push_back(p1); f->poses.insert(f->poses.end(), p1, p1 + 6); f->slot_of[p1] = Slot{0, fi * P + 1}; }
+        if (rolling && p1) { f->pose_ptr.push_back(p1); f->poses.insert(f->poses.end(), p1, p1 + 6); f->slot_of[p1] = Slot{0, fi * P + 1}; }
+        else if (rolling) {   // a one-pose frame in a two-pose problem: the second slot is data (a copy of the pose), not a block
+          f->pose_ptr.push_back(nullptr); f->poses.insert(f->poses.end(), p0, p0 + 6);
+          if (f->frame_global.size() < f->frame_intr.size()) f->frame_global.resize(f->frame_intr.size(), 0);
+          f->frame_global[fi] = 1;
+        }
       } else { fi = itf->second; if (f->frame_intr[fi] != ci) return fail("one frame observed through two different intrinsics"); }
       int pi;
       auto itp = point_of.find(pt);
@@ -490,15 +509,19 @@ class Problem {
       for (int k = 0; k < nf; ++k) identity = identity && order[k] == k;
       if (!identity) {
         std::vector<int32_t> fi2(nf); std::vector<double*> pp2(f->pose_ptr.size()); std::vector<double> po2(f->poses.size());
+        if (!f->frame_global.empty()) f->frame_global.resize((size_t)nf, 0);
+        std::vector<uint8_t> fg2(f->frame_global.size());
         for (int k = 0; k < nf; ++k) {
           const int o = order[k];
           fi2[k] = f->frame_intr[o];
+          if (!fg2.empty()) fg2[k] = f->frame_global[o];
           for (int q = 0; q < P; ++q) {
             pp2[(size_t)k * P + q] = f->pose_ptr[(size_t)o * P + q];
             std::memcpy(&po2[((size_t)k * P + q) * 6], &f->poses[((size_t)o * P + q) * 6], 6 * sizeof(double));
-            f->slot_of[pp2[(size_t)k * P + q]] = Slot{0, k * P + q};
+            if (pp2[(size_t)k * P + q]) f->slot_of[pp2[(size_t)k * P + q]] = Slot{0, k * P + q};
           }
         }
+        f->frame_global.swap(fg2);
         f->frame_intr.swap(fi2); f->pose_ptr.swap(pp2); f->poses.swap(po2);
         for (int32_t& x : f->obs_frame) x = new_of[x];
         for (int32_t& x : f->prior_frames) x = new_of[x];
@@ -529,9 +552,12 @@ class Problem {
     for (size_t k = 0; k < f->pp_ptr.size(); ++k) f->slot_of[f->pp_ptr[k]] = Slot{4, (int)k};
     const int nscalar = (f->prior_frames.empty() ? 0 : 1) + (int)f->pp_ptr.size();
     // a pose pointer may not serve as pose0 of one frame and pose1 of another
-    if ((int)f->slot_of.size() - nscalar != (int)f->pose_ptr.size() + (int)f->point_ptr.size() + (with_cam ? (int)f->intr_ptr.size() : 0))
+    int npose_blocks = 0;
+    for (double* p : f->pose_ptr) npose_blocks += p != nullptr;   // (the second slot of a one-pose frame is data, not a block)
+    if ((int)f->slot_of.size() - nscalar != npose_blocks + (int)f->point_ptr.size() + (with_cam ? (int)f->intr_ptr.size() : 0))
       return fail("a parameter block is used in two different roles");
-    for (double* p : f->pose_ptr) f->pose_mask.push_back((uint8_t)(mask_of(p, 6) & 0x3f));
+    for (double* p : f->pose_ptr) f->pose_mask.push_back(p ? (uint8_t)(mask_of(p, 6) & 0x3f) : (uint8_t)0x3f);
+    if (!f->frame_global.empty()) f->frame_global.resize(f->frame_intr.size(), 0);
     for (double* p : f->point_ptr) f->point_const.push_back(constant_.count(p) ? 1 : 0);
     for (double* p : f->intr_ptr) f->intr_const.push_back(p && constant_.count(p) ? 1 : 0);
     for (const auto& lb : lower_bounds_) { auto it = f->slot_of.find(lb.first.first); if (it != f->slot_of.end() && it->second.kind != 3) return fail("bounds on pose / point / intrinsics blocks are not supported"); }
@@ -553,7 +579,7 @@ class Problem {
   // results of a solve go back into the caller's blocks, as ceres::Solve mutates them in place
   void scatter(const Flat& f) {
     const int nposeblk = (int)f.pose_ptr.size();
-    for (int b = 0; b < nposeblk; ++b) std::memcpy(f.pose_ptr[b], &f.poses[(size_t)b * 6], 6 * sizeof(double));
+    for (int b = 0; b < nposeblk; ++b) if (f.pose_ptr[b]) std::memcpy(f.pose_ptr[b], &f.poses[(size_t)b * 6], 6 * sizeof(double));
     for (size_t j = 0; j < f.point_ptr.size(); ++j) std::memcpy(f.point_ptr[j], &f.points[j * 3], 3 * sizeof(double));
     for (size_t c = 0; c < f.intr_ptr.size(); ++c) if (f.intr_ptr[c]) std::memcpy(f.intr_ptr[c], &f.intr[c * 9], 9 * sizeof(double));
     for (size_t k = 0; k < f.pp_ptr.size(); ++k) std::memcpy(f.pp_ptr[k], &f.pp_values[k * 6], 6 * sizeof(double));   // the priorPoses blocks are solved for too
@@ -640,7 +666,7 @@ class Covariance {
     for (int fr : frames) {
       std::vector<double> cov((size_t)CD * CD);
       if (rsba_pose_covariance(h, fr, cov.data()) != RSBA_OK) { ok = false; break; }
-      for (int q = 0; q < P; ++q) index_[f.pose_ptr[(size_t)fr * P + q]] = std::make_pair(fr, q);
+      for (int q = 0; q < P; ++q) if (f.pose_ptr[(size_t)fr * P + q]) index_[f.pose_ptr[(size_t)fr * P + q]] = std::make_pair(fr, q);
       ready_[fr] = std::move(cov);
     }
     rsba_destroy(h);

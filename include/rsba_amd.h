@@ -278,6 +278,15 @@ int32_t rsba_get_inter_frame_ratio(rsba_handle* h, double* ratio);
 int32_t rsba_set_pose_priors(rsba_handle* h, double rotation, double position, const int32_t* pose_blocks, double* prior_values, int32_t count,
                              int32_t spherical_pose_block);
 
+/* Sessions that mix rolling-shutter frames (two poses) with one-pose frames: CeresHandler::Add picks the functor per frame by
+ * f.poses.size() (CeresHandler.h:245-286) — RsBundleAdjustment over (poses[0], poses[1], point) or ReprojectionError over
+ * (getPose(...), point).  Create the problem with poses_per_frame = 2 and flag the one-pose frames here: is_global [num_frames],
+ * 1 = the frame's observations use poses[f][0] alone (tau = 0; the validation / reprojection filters follow: getPose returns the
+ * single pose, struct/VideoSfM.cc:103-133); the second pose slot of such a frame is not a parameter block — it is held constant and
+ * left untouched.  NULL clears the flags.  Call before the first evaluation / solve.  (Frames with MORE than two poses — "fullDoF",
+ * a pose per scan line — are not supported.) */
+int32_t rsba_set_global_shutter_frames(rsba_handle* h, const uint8_t* is_global);
+
 /* == the RANSAC hypotheses of vision::solveRsPnPRansac (solveRSpnp.cpp:413-524), batched: task t is
  * what pnpTask (:265-335) does for the subset subsets[t][0..m) of the n float points —
  *   skipped (status 0, nothing else written) when drop_coincident != 0 and two of its 3-D points coincide (:283-293;

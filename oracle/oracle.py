@@ -39,7 +39,7 @@ class OrcProblem(C.Structure):
         ("num_pose_priors", C.c_int32), ("pose_prior_block", C.c_void_p), ("pose_prior_values", C.c_void_p),
         ("pose_prior_rotation", C.c_double), ("pose_prior_position", C.c_double),
         ("spherical_pose_block", C.c_int32), ("has_spherical", C.c_int32),
-        ("no_validate", C.c_int32), ("ratio_free", C.c_int32),
+        ("no_validate", C.c_int32), ("ratio_free", C.c_int32), ("frame_global", C.c_void_p),
     ]
 
 
@@ -135,6 +135,7 @@ def desc(prob) -> OrcProblem:
     d.prior_frames = _ptr(prob.prior_frames) if d.prior_kind else None
     d.prior_scale, d.inter_frame_ratio = float(prob.prior_scale), float(prob.inter_frame_ratio)
     d.ratio_free = int(bool(getattr(prob, 'ratio_free', False)))
+    d.frame_global = _ptr(getattr(prob, 'frame_global', None))
     pb = getattr(prob, "pose_prior_block", None)
     if pb is not None and len(pb):
         d.num_pose_priors = len(pb)

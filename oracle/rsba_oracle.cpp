@@ -44,8 +44,8 @@ bool block_eval(const orc_problem* p, int64_t i, double* r, double* J /* [2][K] 
   if (!J) {
     double rr[2];
     bool ok;
-    if (P == 2) ok = rs_residual<double>(cam, pose, pose + 6, X, ox, oy, p->shutter, p->scanlines, p->interpolate_rotation != 0, rr, !p->no_validate);
-    else ok = gs_residual<double>(cam, pose, X, ox, oy, rr, !p->no_validate);
+    if (P == 2 && !(p->frame_global && p->frame_global[f])) ok = rs_residual<double>(cam, pose, pose + 6, X, ox, oy, p->shutter, p->scanlines, p->interpolate_rotation != 0, rr, !p->no_validate);
+    else ok = gs_residual<double>(cam, pose, X, ox, oy, rr, !p->no_validate);   // (a one-pose frame of a two-pose session: CeresHandler.h:266-285)
     if (ok) { r[0] = rr[0]; r[1] = rr[1]; }
     return ok;
   }
@@ -56,7 +56,7 @@ bool block_eval(const orc_problem* p, int64_t i, double* r, double* J /* [2][K] 
   for (int k = 0; k < 6 * P; ++k) dpose[k] = D(pose[k], col++);
   for (int k = 0; k < 3; ++k) dX[k] = D(X[k], col++);
   bool ok;
-  if (P == 2) ok = rs_residual<D>(dcam, dpose, dpose + 6, dX, ox, oy, p->shutter, p->scanlines, p->interpolate_rotation != 0, res, !p->no_validate);
+  if (P == 2 && !(p->frame_global && p->frame_global[f])) ok = rs_residual<D>(dcam, dpose, dpose + 6, dX, ox, oy, p->shutter, p->scanlines, p->interpolate_rotation != 0, res, !p->no_validate);
   else ok = gs_residual<D>(dcam, dpose, dX, ox, oy, res, !p->no_validate);
   if (!ok) return false;
   r[0] = res[0].a; r[1] = res[1].a;

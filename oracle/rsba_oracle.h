@@ -55,6 +55,8 @@ typedef struct orc_problem {
   int32_t no_validate;           /* 1 = the RS-PnP functor RsBA: w2i(..., validate = false) (solveRSpnp.cpp:67) */
   int32_t ratio_free;            /* 1 = interFrameRatio is a free, lower-bounded parameter block (the reference's default, option left at 1:
                                   * CeresHandler.h:161,172,175); orc_solve updates inter_frame_ratio in place */
+  const uint8_t* frame_global;   /* [F] or NULL, poses_per_frame == 2 only: 1 = the frame has ONE pose in the session (CeresHandler.h:266-285: the
+                                  * ReprojectionError functor on poses[f][0]); its second pose slot is not a parameter block (the caller marks it constant) */
 } orc_problem;
 
 /* Ceres 1.9 Solver::Options subset (defaults: SURVEY Appendix C.5) */

@@ -24,7 +24,7 @@ EXPORTS = [
     "rsba_validate_observations", "rsba_reproject", "rsba_pose_covariance", "rsba_set_motion_priors",
     "rsba_pnp_tasks", "rsba_pnp_inliers", "rsba_set_inter_frame_ratio_free", "rsba_get_inter_frame_ratio",
     "rsba_sync_block_structure", "rsba_rccl_get_unique_id", "rsba_rccl_comm_create", "rsba_rccl_comm_destroy", "rsba_set_exchange_rccl",
-    "rsba_get_phase_times", "rsba_phase_name", "rsba_get_plan_stats", "rsba_validate_frame", "rsba_reproject_frame", "rsba_set_pose_priors",
+    "rsba_get_phase_times", "rsba_phase_name", "rsba_get_plan_stats", "rsba_validate_frame", "rsba_reproject_frame", "rsba_set_pose_priors", "rsba_set_global_shutter_frames",
 ]
 NUM_PHASES = 13
 
@@ -177,6 +177,11 @@ class DeviceProblem:
             self.set_motion_priors(prob.prior_kind, prob.prior_scale, prob.inter_frame_ratio, prob.prior_frames)
             if getattr(prob, "ratio_free", False):
                 _check(lib().rsba_set_inter_frame_ratio_free(self._h, C.c_int32(1)))
+        if getattr(prob, "frame_global", None) is not None:      # one-pose frames inside a two-pose session (CeresHandler.h:266-285)
+            fg = np.ascontiguousarray(prob.frame_global, dtype=np.uint8)
+            assert fg.shape == (prob.num_frames,)
+            self._frame_global = fg
+            _check(lib().rsba_set_global_shutter_frames(self._h, _ptr(fg)))
         npp = 0 if prob.pose_prior_block is None else len(prob.pose_prior_block)
         if npp or prob.spherical_pose_block >= 0:
             _check(lib().rsba_set_pose_priors(self._h, C.c_double(float(prob.pose_prior_rotation)), C.c_double(float(prob.pose_prior_position)),

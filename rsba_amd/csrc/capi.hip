@@ -333,6 +333,29 @@ int32_t rsba_set_pose_priors(rsba_handle* h, double rotation, double position, c
   return RSBA_OK;
 }
 
+int32_t rsba_set_global_shutter_frames(rsba_handle* h, const uint8_t* is_global) {
+  if (!h) return fail(RSBA_ERR_INVALID_ARGUMENT, "null handle");
+  if (h->solver) return fail(RSBA_ERR_INVALID_ARGUMENT, "rsba_set_global_shutter_frames must precede the first solve / gradient call");
+  DeviceProblem& dp = h->dp;
+  if (dp.P != 2) return fail(RSBA_ERR_INVALID_ARGUMENT, "one-pose frames are flagged inside problems with poses_per_frame = 2");
+  HIP_TRY(hipSetDevice(h->device));
+  // the masks the caller gave (pose_fixed_mask) with the second pose slot of every flagged frame held constant on top
+  std::vector<double> mask(h->mask_pose_caller.empty() ? h->mask_pose : h->mask_pose_caller);
+  if (h->mask_pose_caller.empty()) h->mask_pose_caller = h->mask_pose;
+  if (!is_global) dp.frame_global = nullptr;
+  else {
+    uint8_t* d_flags = nullptr;
+    int32_t rc = dev_upload(h, &d_flags, is_global, (size_t)dp.F);
+    if (rc) return rc;
+    dp.frame_global = d_flags;
+    for (int f = 0; f < dp.F; ++f) if (is_global[f]) for (int k = 0; k < 6; ++k) mask[((size_t)f * 2 + 1) * 6 + k] = 0.0;
+  }
+  h->mask_pose = mask;
+  HIP_TRY(hipMemcpy(h->d_mask_pose, mask.data(), mask.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dp.scale_pose, mask.data(), mask.size() * sizeof(double), hipMemcpyHostToDevice));
+  return RSBA_OK;
+}
+
 int32_t rsba_set_inter_frame_ratio_free(rsba_handle* h, int32_t is_free) {
   if (!h) return fail(RSBA_ERR_INVALID_ARGUMENT, "null handle");
   if (h->solver) return fail(RSBA_ERR_INVALID_ARGUMENT, "rsba_set_inter_frame_ratio_free must precede the first solve / gradient call");

@@ -31,6 +31,7 @@ struct DeviceProblem {
   double* points;
   double* intr;
   const int32_t* frame_intr;     // [F]
+  const uint8_t* frame_global;   // [F] or null (P == 2 only): 1 = a one-pose (global-shutter) frame of the session: tau = 0, the second pose slot is constant
   // column scales: 0 for a fixed coordinate, otherwise the Jacobi scale (1 before it is estimated)
   double* scale_pose;            // [F][P][6]
   double* scale_point;           // [M][3]

@@ -19,6 +19,7 @@ struct rsba_handle {
   std::vector<int64_t> order;          // internal (frame-major) index -> caller's observation index
   bool identity_order = true;
   std::vector<double> mask_pose, mask_point, mask_intr;   // 0 = fixed coordinate, 1 = free
+  std::vector<double> mask_pose_caller;                  // mask_pose as rsba_create built it (rsba_set_global_shutter_frames holds more slots constant on top)
   double *d_mask_pose = nullptr, *d_mask_point = nullptr, *d_mask_intr = nullptr;   // device copies: the column scales are reset from them (no host traffic per solve)
   std::vector<int32_t> obs_frame, obs_point;            // host copies, internal (frame-major) order
   std::vector<int32_t> frame_intr;                       // [F] host copy of the frame -> intrinsics block map

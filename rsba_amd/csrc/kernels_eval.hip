@@ -97,7 +97,7 @@ __global__ __launch_bounds__(kEvalBlock) void eval_kernel(const DeviceProblem dp
       const int ci = (dp.NI == 1) ? 0 : dp.frame_intr[f];
 #pragma unroll
       for (int k = 0; k < 9; ++k) cam[k] = dp.intr[(size_t)ci * 9 + k];
-      const Model m = {dp.shutter, dp.scan0, dp.scan1, dp.interp_rotation};
+      const Model m = {(dp.frame_global && dp.frame_global[f]) ? (int)kGlobal : dp.shutter, dp.scan0, dp.scan1, dp.interp_rotation};
       eval_observation<CAL, P, MODE != kResidualOnly>(m, cam, pose, X, xy.x, xy.y, o);
       if (valid && !o.ok) nfail = 1.0;
       // Ceres 1.9 ResidualBlock::Evaluate: cost = rho0/2 from the uncorrected residual

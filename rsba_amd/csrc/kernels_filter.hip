@@ -42,9 +42,9 @@ template <int P>
 __global__ __launch_bounds__(256) void validate_kernel(const DeviceProblem dp, double sq_threshold, double min_distance, uint8_t* valid) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= dp.N) return;
-  const Model m = {dp.shutter, dp.scan0, dp.scan1, dp.interp_rotation};
   const double2 xy = dp.xy[i];
   const int f = dp.obs_frame[i], j = dp.obs_point[i];
+  const Model m = {(dp.frame_global && dp.frame_global[f]) ? (int)kGlobal : dp.shutter, dp.scan0, dp.scan1, dp.interp_rotation};   // (a one-pose frame: getPose returns poses[0], VideoSfM.cc:103-133)
   const double* cam = dp.intr + (size_t)((dp.NI == 1) ? 0 : dp.frame_intr[f]) * 9;
   double camr[9], pose[6], X[3], proj[2];
 #pragma unroll
@@ -64,8 +64,8 @@ __global__ __launch_bounds__(256) void reproject_kernel(const DeviceProblem dp, 
                                                         double2* xy_out, uint8_t* ok_out) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const Model m = {dp.shutter, dp.scan0, dp.scan1, dp.interp_rotation};
   const int f = frames[i], j = points[i];
+  const Model m = {(dp.frame_global && dp.frame_global[f]) ? (int)kGlobal : dp.shutter, dp.scan0, dp.scan1, dp.interp_rotation};
   const double* cam = dp.intr + (size_t)((dp.NI == 1) ? 0 : dp.frame_intr[f]) * 9;
   double camr[9], pose[6], X[3];
 #pragma unroll

@@ -29,7 +29,7 @@ __device__ __forceinline__ void lm_observation(const DeviceProblem& dp, int f, i
   const int ci = (dp.NI == 1) ? 0 : dp.frame_intr[f];
 #pragma unroll
   for (int k = 0; k < 9; ++k) cam[k] = dp.intr[(size_t)ci * 9 + k];
-  const Model m = {dp.shutter, dp.scan0, dp.scan1, dp.interp_rotation};
+  const Model m = {(dp.frame_global && dp.frame_global[f]) ? (int)kGlobal : dp.shutter, dp.scan0, dp.scan1, dp.interp_rotation};   // (a one-pose frame of a two-pose session: CeresHandler.h:266-285)
   eval_observation<CAL, P, true>(m, cam, pose, X, x, y, o);
   // Ceres 1.9 ResidualBlock::Evaluate: cost = rho0/2 from the uncorrected residual
   const double s = o.r[0] * o.r[0] + o.r[1] * o.r[1];

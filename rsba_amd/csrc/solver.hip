@@ -924,7 +924,13 @@ int32_t reset_scales(rsba_handle* h) {
 // all-reduce across the ranks of a point-partitioned solve (no-op for a single GPU)
 int32_t exchange(rsba_handle* h, double* buf, int64_t count, int op) {
   if (!h->allreduce) return RSBA_OK;   // (a one-rank exchange still goes through its transport: identity, but the path is exercised)
-  if (h->allreduce(h->allreduce_ctx, buf, count, op, h->stream) != 0) return rsba_set_error(RSBA_ERR_COMM, "all-reduce callback failed");
+  (void)rsba_set_error(RSBA_OK, "");   // a transport that fails says why through rsba_set_error (the RCCL one: the ncclResult string); keep what it said
+  if (h->allreduce(h->allreduce_ctx, buf, count, op, h->stream) != 0) {
+    const std::string why = rsba_last_error();
+    char where[96];
+    std::snprintf(where, sizeof where, " (all-reduce of %lld doubles, op %d, rank %d of %d)", (long long)count, op, h->rank, h->world);
+    return rsba_set_error(RSBA_ERR_COMM, ((why.empty() ? std::string("the all-reduce callback reported a failure") : why) + where).c_str());
+  }
   return RSBA_OK;
 }
 

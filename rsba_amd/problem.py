@@ -49,6 +49,7 @@ class BAProblem:
     pose_prior_rotation: float = 0.0    # opt.ceres.trustPriorCamRotation
     pose_prior_position: float = 0.0    # opt.ceres.trustPriorCamPosition
     spherical_pose_block: int = -1      # pose block carrying the SphericalPrior (frame 1 of a session started at the origin), -1 none
+    frame_global: Optional[np.ndarray] = None   # [F] uint8, two-pose sessions only: 1 = the frame has ONE pose in the session (global-shutter functor on poses[f, 0], CeresHandler.h:266-285)
 
     def __post_init__(self):
         self.poses = np.ascontiguousarray(self.poses, dtype=np.float64)

@@ -112,3 +112,22 @@ def test_bench_strong_scaling_two_ranks_on_one_gpu(tmp_path):
     assert abs(two["lm"]["final_cost"] - one["lm"]["final_cost"]) <= 1e-9 * one["lm"]["final_cost"]
     assert abs(two["lm"]["initial_cost"] - one["lm"]["initial_cost"]) <= 1e-12 * one["lm"]["initial_cost"]
     assert {r["phase"] for r in one["roofline_lm"]["phases"]} >= {"eval_lm", "schur", "cholesky", "project"}
+
+
+@pytest.mark.gpu
+def test_a_failed_exchange_says_what_failed():
+    """A transport that fails must not leave the caller with a bare status: the error names the collective (size, operation, rank) and
+    keeps whatever the transport itself reported (the RCCL transport: the ncclResult string)."""
+    import ctypes as C
+    from rsba_amd import capi
+    from rsba_amd.distributed import ALLREDUCE_FN
+    from rsba_amd.scene import make_scene
+    p = make_scene(12, 400, seed=3).problem
+    dp = capi.DeviceProblem(p)
+    cb = ALLREDUCE_FN(lambda ctx, ptr, count, op, stream: 1)
+    capi._check(capi.lib().rsba_set_exchange(dp._h, cb, None, C.c_int32(0), C.c_int32(1)))
+    with pytest.raises(capi.RsbaError) as err:
+        dp.solve(capi.default_options(max_num_iterations=3))
+    dp.close()
+    msg = str(err.value)
+    assert "all-reduce of" in msg and "rank 0 of 1" in msg, msg

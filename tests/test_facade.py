@@ -381,3 +381,26 @@ def test_windowed_ba_switches_fix_scale_off(exe, oracle, tmp_path):
     out = res["windowedBA"]
     assert out["usable"] and abs(out["final_cost"] - s_ref.final_cost) <= 1e-6 * s_ref.final_cost
     assert np.max(np.abs(out["poses"] - q.poses)) <= 1e-5
+
+
+@pytest.mark.gpu
+def test_a_session_that_mixes_two_pose_and_one_pose_frames(exe, oracle, tmp_path):
+    """CeresHandler::Add picks the functor per frame by f.poses.size() (CeresHandler.h:245-286): a rolling-shutter session may
+    contain one-pose frames, which get the global-shutter functor on their single pose.  Through the facade such a Problem is
+    lowered to two pose slots per frame + rsba_set_global_shutter_frames; the oracle solves the same program."""
+    from rsba_amd.problem import apply_gauge_masks
+    p = small_problem(True, 2.0)
+    write_scene_file(tmp_path / "s.bin", p, fix_first_n=1, max_iter=15)
+    r = subprocess.run([exe, str(tmp_path / "s.bin"), str(tmp_path / "o.bin"), "0", "0", "BA", "-1", "1", "3"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr
+    out = read_result_file(tmp_path / "o.bin", p)
+    q = p.copy()
+    apply_gauge_masks(q, fix_first_n_cameras=1)
+    q.frame_global = (np.arange(q.num_frames) % 3 == 2).astype(np.uint8)
+    q.pose_fixed_mask[q.frame_global == 1, 1] = 0x3F
+    s_ref, _ = oracle.solve(q, oracle.default_options(max_num_iterations=15))
+    assert out["usable"] and out["reduced"] == s_ref.num_residual_blocks_reduced
+    assert abs(out["initial_cost"] - s_ref.initial_cost) <= 1e-12 * s_ref.initial_cost
+    assert abs(out["final_cost"] - s_ref.final_cost) <= 1e-6 * s_ref.final_cost
+    gs = q.frame_global == 1
+    assert np.max(np.abs(out["poses"][~gs] - q.poses[~gs])) <= 1e-5 and np.max(np.abs(out["poses"][gs, 0] - q.poses[gs, 0])) <= 1e-5

@@ -311,3 +311,43 @@ def test_recomputed_records_equal_the_stored_ones(capi, monkeypatch, shared_intr
         assert x.step_is_successful == y.step_is_successful
         assert abs(x.cost - y.cost) <= 1e-11 * y.cost
     assert np.max(np.abs(a[2] - b[2])) <= 1e-8 and np.max(np.abs(a[3] - b[3])) <= 1e-7
+
+
+def mixed_session(seed=31):
+    """A rolling-shutter session in which every third frame has ONE pose (CeresHandler::Add gives such a frame the global-shutter
+    functor, CeresHandler.h:245-286): two pose slots per frame, the one-pose frames flagged, their second slot constant."""
+    from rsba_amd.problem import apply_gauge_masks
+    from rsba_amd.scene import make_scene
+    p = make_scene(30, 2000, seed=seed).problem
+    apply_gauge_masks(p, fix_first_n_cameras=1)
+    p.pose_fixed_mask[-1, -1] |= 0b111000
+    p.frame_global = (np.arange(p.num_frames) % 3 == 2).astype(np.uint8)
+    p.pose_fixed_mask[p.frame_global == 1, 1] = 0x3F
+    return p
+
+
+def test_one_pose_frames_inside_a_rolling_shutter_session(capi, oracle):
+    p = mixed_session()
+    r_ref, J_ref, ok_ref = oracle.evaluate_blocks(p)
+    with capi.DeviceProblem(p) as dp:
+        out = dp.evaluate()
+        valid = dp.validate_observations(25.0, 0.0)
+    gs = p.frame_global[p.obs_frame] == 1
+    assert gs.sum() > 1000 and ok_ref.all()
+    assert np.max(np.abs(out["residuals"] - r_ref) / np.maximum(1.0, np.abs(r_ref))) <= 1e-11
+    assert np.max(np.abs(out["jacobians"] - J_ref) / np.maximum(1.0, np.abs(J_ref))) <= 1e-9
+    assert np.all(out["jacobians"][gs][:, :, 6:12] == 0.0) and np.any(out["jacobians"][~gs][:, :, 6:12] != 0.0)   # the second pose slot of a one-pose frame is no parameter
+    ref_valid = np.array([oracle.validate_obs(p.intrinsics[0], p.poses[f, :1] if p.frame_global[f] else p.poses[f], p.shutter, p.scanlines, p.points[j], xy, 25.0, 0.0)
+                          for f, j, xy in zip(p.obs_frame[:3000], p.obs_point[:3000], p.obs_xy[:3000])])
+    assert np.array_equal(valid[:3000], ref_valid)
+    pd, pc = p.copy(), p.copy()
+    with capi.DeviceProblem(pd) as dp:
+        s, tr = dp.solve(capi.default_options(max_num_iterations=12))
+    s_ref, tr_ref = oracle.solve(pc, oracle.default_options(max_num_iterations=12))
+    assert s.num_residual_blocks_reduced == s_ref.num_residual_blocks_reduced and s.num_parameters_reduced == s_ref.num_parameters_reduced
+    assert abs(s.initial_cost - s_ref.initial_cost) <= 1e-12 * s_ref.initial_cost
+    for a, b in zip(tr[:6], tr_ref[:6]):
+        assert abs(a.cost - b.cost) <= 1e-9 * b.cost
+    assert abs(s.final_cost - s_ref.final_cost) <= 1e-6 * s_ref.final_cost
+    assert np.array_equal(pd.poses[p.frame_global == 1, 1], p.poses[p.frame_global == 1, 1])      # untouched
+    assert np.max(np.abs(pd.poses - pc.poses)) <= 1e-5
