@@ -818,11 +818,14 @@ __device__ __forceinline__ void diag_factor(const SolverDev& sv, int tile_j, dou
   const bool ok = factor_invert_tile<false, false, DAG>(D, Wl, smem + 2 * kBuf, smem + 3 * kBuf, tid, nullptr, sv.Winv + (size_t)tile_j * (T * T));   // (W leaves by row blocks from inside)
   if (tid == 0 && !ok) atomicExch(sv.chol_fail, 1);
   CHOL_STAMP(6);
-  if (tid < T) {   // z_j = W b
-    double s0 = 0.0, s1 = 0.0;
-#pragma unroll 8
-    for (int m = 0; m < T; m += 2) { if (m <= tid) s0 += Wl[tid * TP + m] * bvec[m]; if (m + 1 <= tid) s1 += Wl[tid * TP + m + 1] * bvec[m + 1]; }
-    st<DAG>(sv.zv + (size_t)tile_j * T + tid, s0 + s1);
+  if (tid < 4 * T) {   // z_j = W b: four lanes per row, twelve columns each (the next DIAG task of the chain waits for it right behind the last rows of W)
+    const int row = tid >> 2, q = tid & 3;
+    double s0 = 0.0;
+#pragma unroll
+    for (int m = 0; m < T / 4; ++m) { const int c = (T / 4) * q + m; if (c <= row) s0 += Wl[row * TP + c] * bvec[c]; }
+    s0 += __shfl_xor(s0, 1, 64);
+    s0 += __shfl_xor(s0, 2, 64);
+    if (q == 0) st<DAG>(sv.zv + (size_t)tile_j * T + row, s0);
   }
 }
 
@@ -1146,7 +1149,7 @@ __global__ __launch_bounds__(256, 2) void chol_dag_kernel(const DagArgs* __restr
 // level schedule (solver.hip).  Sums are fp64 atomics in arbitrary order: this is a check, not a result.
 // res / den start out zero (the check kernel re-arms them after it has looked): one workgroup per packed tile adds what the
 // tile contributes — thread (r, q) = (tid / 4, tid % 4) takes a quarter of row r resp. column r.
-__global__ __launch_bounds__(256) void chol_residual_kernel(const SolverDev sv, const int32_t* __restrict__ slot_tiles, double* res, double* den) {
+__global__ __launch_bounds__(256) void chol_residual_kernel(const SolverDev sv, const int32_t* __restrict__ slot_tiles, const double* __restrict__ b_rhs, double* res, double* den) {
   __shared__ double tile[T * TP];
   __shared__ double yj[T], yi[T];
   const int slot = blockIdx.x, tid = threadIdx.x, r = tid >> 2, q = tid & 3;
@@ -1161,7 +1164,7 @@ __global__ __launch_bounds__(256) void chol_residual_kernel(const SolverDev sv, 
     double s = 0.0, a = 0.0;
     for (int c = 12 * q; c < 12 * q + 12; ++c) { const double v = tile[max(r, c) * TP + min(r, c)]; s += v * yj[c]; a += fabs(v) * fabs(yj[c]); }
     s = quad_sum(s); a = quad_sum(a);
-    if (q == 0) { const double b = sv.rhs[(size_t)tile_j * T + r]; atomicAdd(res + (size_t)tile_j * T + r, b - s); atomicAdd(den + (size_t)tile_j * T + r, fabs(b) + a); }
+    if (q == 0) { const double b = b_rhs[(size_t)tile_j * T + r]; atomicAdd(res + (size_t)tile_j * T + r, b - s); atomicAdd(den + (size_t)tile_j * T + r, fabs(b) + a); }
     return;
   }
   double s = 0.0, a = 0.0, st = 0.0, at = 0.0;
@@ -1195,8 +1198,8 @@ __global__ __launch_bounds__(1024) void chol_residual_check_kernel(const SolverD
 
 }  // namespace
 
-hipError_t launch_chol_verify(const SolverDev& sv, const int32_t* slot_tiles, double* res, double* den, double tol, double* flag, hipStream_t st) {
-  hipLaunchKernelGGL(chol_residual_kernel, dim3(sv.nslots), dim3(256), 0, st, sv, slot_tiles, res, den);
+hipError_t launch_chol_verify(const SolverDev& sv, const int32_t* slot_tiles, const double* b_rhs, double* res, double* den, double tol, double* flag, hipStream_t st) {
+  hipLaunchKernelGGL(chol_residual_kernel, dim3(sv.nslots), dim3(256), 0, st, sv, slot_tiles, b_rhs, res, den);
   hipLaunchKernelGGL(chol_residual_check_kernel, dim3(1), dim3(1024), 0, st, sv, res, den, tol, flag);
   return hipGetLastError();
 }

@@ -940,6 +940,18 @@ __global__ __launch_bounds__(256) void reduce_sum_kernel(const double* partial, 
   if (threadIdx.x == 0) *out = sign * (s_red[0] + s_red[1] + s_red[2] + s_red[3]);
 }
 
+// two sums in one launch: workgroup b reduces partial[b * n .. b * n + n) into out0 (b = 0) resp. out1 (b = 1), same order as reduce_sum_kernel
+__global__ __launch_bounds__(256) void reduce_sum2_kernel(const double* partial, int n, double* out0, double* out1) {
+  __shared__ double s_red[4];
+  const double* src = partial + (size_t)blockIdx.x * n;
+  double v = 0.0;
+  for (int k = threadIdx.x; k < n; k += 256) v += src[k];
+  v = wsum(v);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) *(blockIdx.x == 0 ? out0 : out1) = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+}
+
 // x_plus_delta = x + scale .* step; |x - x_plus_delta|^2 and |x|^2 over the reduced program's blocks
 __global__ __launch_bounds__(256) void candidate_kernel(const DeviceProblem dp, const SolverDev sv) {
   __shared__ double s_red[2][4];
@@ -994,6 +1006,12 @@ __global__ void pack_linearize_kernel(const DeviceProblem dp, const SolverDev sv
     sv.xbuf[sv.n + t] = u_diag(sv, t);
   }
   if (t == 0) { sv.xbuf[2 * sv.n] = cost2[0]; sv.xbuf[2 * sv.n + 1] = cost2[1]; sv.xbuf[2 * sv.n + 2] = (double)*dp.fail_count; }
+}
+// without an exchange (one rank) the round trip through xbuf is one kernel: udiag = diag(U), the three scalars
+__global__ void local_linearize_kernel(const DeviceProblem dp, const SolverDev sv, const double* cost2) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t < sv.n) sv.udiag[t] = u_diag(sv, t);
+  if (t == 0) { sv.scalars[kCost] = cost2[0]; sv.scalars[kFixedCost] = cost2[1]; sv.scalars[kEvalFailed] = (double)*dp.fail_count; }
 }
 __global__ void unpack_linearize_kernel(const DeviceProblem dp, const SolverDev sv) {
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1068,6 +1086,10 @@ hipError_t launch_gradient_max(const DeviceProblem& dp, const SolverDev& sv, hip
 }
 hipError_t launch_pack_linearize(const DeviceProblem& dp, const SolverDev& sv, const double* cost2, hipStream_t st) {
   LAUNCH(pack_linearize_kernel, nblocks256(sv.n), 256, st, dp, sv, cost2);
+  return hipSuccess;
+}
+hipError_t launch_local_linearize(const DeviceProblem& dp, const SolverDev& sv, const double* cost2, hipStream_t st) {
+  LAUNCH(local_linearize_kernel, nblocks256(sv.n), 256, st, dp, sv, cost2);
   return hipSuccess;
 }
 hipError_t launch_unpack_linearize(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {
@@ -1196,8 +1218,7 @@ hipError_t launch_merge_points(const DeviceProblem& dp, const double* buf, hipSt
 hipError_t launch_candidate(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {
   const int nb = nblocks256(sv.n + 3 * (int64_t)dp.M);
   LAUNCH(candidate_kernel, nb, 256, st, dp, sv);
-  LAUNCH(reduce_sum_kernel, 1, 256, st, sv.partial, nb, sv.scalars + kStepSq, 1.0);
-  LAUNCH(reduce_sum_kernel, 1, 256, st, sv.partial + nb, nb, sv.scalars + kXSq, 1.0);
+  LAUNCH(reduce_sum2_kernel, 2, 256, st, sv.partial, nb, sv.scalars + kStepSq, sv.scalars + kXSq);   // (one launch: workgroup 0 -> |step|^2, workgroup 1 -> |x|^2)
   return hipSuccess;
 }
 

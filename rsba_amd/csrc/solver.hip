@@ -66,6 +66,9 @@ struct Solver {
   DagArgs* d_dag_args = nullptr;
   int32_t* d_slot_tiles = nullptr;                                    // [nslots][2] {row tile, column tile} of every packed tile
   double* d_verify = nullptr;                                         // [2 * npad] residual and yardstick of the DAG verification
+  // The verification runs on a stream of its own, beside the back-substitution / candidate / trial evaluation of the iteration: it
+  // only has to be done when the step scalars are packed.  verify_b = the right-hand side of the solve (sv.rhs is overwritten by the step).
+  hipStream_t vstream = nullptr; hipEvent_t ev_solved = nullptr, ev_verified = nullptr; double* verify_b = nullptr; bool verify_pending = false;
   bool verify_dag = true;                                             // RSBA_CHOL_VERIFY=0 switches the check off
   bool test_corrupt_once = false;                                     // RSBA_CHOL_TEST_CORRUPT=1 (tests): the first DAG solve loses one entry of y
   int dag_fallbacks = 0;                                              // solves repeated on the level schedule after a failed check                                      // device copy of {sv, plan} for the persistent kernel
@@ -874,6 +877,10 @@ int32_t build_solver(rsba_handle* h) {
       if ((rc = s_upload(s, &s->d_slot_tiles, st2))) return rc;
     }
     if ((rc = s_alloc(s, &s->d_verify, 2 * (size_t)sv.npad))) return rc;
+    if ((rc = s_alloc(s, &s->verify_b, (size_t)sv.npad))) return rc;
+    HIP_TRY(hipStreamCreateWithFlags(&s->vstream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&s->ev_solved, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&s->ev_verified, hipEventDisableTiming));
     HIP_TRY(hipMemset(s->d_verify, 0, 2 * (size_t)sv.npad * sizeof(double)));   // the check kernel leaves it zero again
     { const char* v = std::getenv("RSBA_CHOL_VERIFY"); s->verify_dag = !(v && v[0] == '0'); }
     { const char* v = std::getenv("RSBA_CHOL_TEST_CORRUPT"); s->test_corrupt_once = v && v[0] == '1'; }
@@ -937,9 +944,11 @@ int32_t exchange(rsba_handle* h, double* buf, int64_t count, int op) {
 // r, J (loss-corrected, masked, scaled) and the normal-equation blocks at the current parameters;
 // exchange (1): per-camera gradient blocks + diag(U) + cost scalars.  Results: sv.gc / sv.udiag global,
 // scalars[kCost, kFixedCost, kEvalFailed].
-int32_t linearize(rsba_handle* h) {
+// have_eval: the LM-mode evaluation at these parameters (per-wave camera blocks, cost incl. the prior blocks' in d_cost2) has just
+// been run — the trust-region loop evaluates its candidates that way when nothing would be lost by it (see rsba_solve).
+int32_t linearize(rsba_handle* h, bool have_eval = false) {
   Solver* s = h->solver;
-  {
+  if (!have_eval) {
     PhaseScope ps(h, RSBA_PHASE_EVAL_LM);
     HIP_TRY(hipMemsetAsync(h->dp.fail_count, 0, sizeof(int), h->stream));
     HIP_TRY(launch_eval(h->dp, kLmJacobian, h->stream));
@@ -953,14 +962,14 @@ int32_t linearize(rsba_handle* h) {
   if ((s->ucross && s->sv.lead) || s->border) {
     PhaseScope ps(h, RSBA_PHASE_PRIORS);
     if (s->ucross && s->sv.lead) {   // motion priors: replicated terms, contributed by the lead rank
-      HIP_TRY(launch_prior_cost(h->dp, h->d_cost2, h->prior_invalid, h->stream));
+      if (!have_eval) HIP_TRY(launch_prior_cost(h->dp, h->d_cost2, h->prior_invalid, h->stream));
       HIP_TRY(launch_prior_blocks(h->dp, s->sv, s->ucross, h->stream));
     }
     if (s->border) HIP_TRY(launch_prior_border(h->dp, s->sv, s->border, s->ratio4, h->stream));   // every rank: from replicated poses
   }
   if (h->dp.pp_count > 0 || h->dp.pp_spherical >= 0) {   // per-pose priors: replicated terms, contributed by the lead rank;
     PhaseScope ps(h, RSBA_PHASE_PRIORS);                   // the linearisation of the priorPoses coordinates (v0, g0, cross) on every rank: each one steps them itself
-    if (s->sv.lead) HIP_TRY(launch_pose_prior_cost(h->dp, h->d_cost2, h->stream));
+    if (s->sv.lead && !have_eval) HIP_TRY(launch_pose_prior_cost(h->dp, h->d_cost2, h->stream));
     HIP_TRY(launch_pose_prior_blocks(h->dp, s->sv, s->pp, h->stream));
   }
   {
@@ -968,6 +977,7 @@ int32_t linearize(rsba_handle* h) {
     HIP_TRY(launch_point_blocks(h->dp, s->sv, h->stream));
   }
   PhaseScope ps(h, RSBA_PHASE_EXCHANGE);
+  if (!h->allreduce) { HIP_TRY(launch_local_linearize(h->dp, s->sv, h->d_cost2, h->stream)); return RSBA_OK; }   // one rank: nothing to sum
   HIP_TRY(launch_pack_linearize(h->dp, s->sv, h->d_cost2, h->stream));
   int32_t rc = exchange(h, s->sv.xbuf, 2 * s->sv.n + 3, 0);
   if (rc) return rc;
@@ -1008,14 +1018,28 @@ int32_t reduce_system(rsba_handle* h, double radius) {
 // S y = rhs: left-looking tile Cholesky (forward solve rides along), then the backward solve: one persistent DAG
 // launch, or — the schedule it is checked against — one launch per (level, kind).  S and rhs are left as they are
 // (the factor has its own tiles); y lands in sv.yv.
+// the solver's stream waits for a verification still running beside it (before its flag is read, and before the cells it reads are re-armed)
+int32_t await_verification(rsba_handle* h) {
+  Solver* s = h->solver;
+  if (s->verify_pending) { HIP_TRY(hipStreamWaitEvent(h->stream, s->ev_verified, 0)); s->verify_pending = false; }
+  return RSBA_OK;
+}
 int32_t solve_reduced_system(rsba_handle* h) {
   Solver* s = h->solver; const SolverDev& sv = s->sv; hipStream_t st = h->stream;
   PhaseScope ps(h, RSBA_PHASE_CHOLESKY);
+  if (int32_t rc = await_verification(h)) return rc;
   if (!s->use_levels) {
     HIP_TRY(hipMemsetAsync(s->cells, 0xFF, s->ncells * sizeof(double), st));   // every write-once cell starts out empty (all ones)
     HIP_TRY(launch_chol_dag(sv, s->plan, s->d_dag_args, s->dag_workgroups, s->dag_one_per_cu, st));
     if (s->test_corrupt_once) { s->test_corrupt_once = false; HIP_TRY(hipMemsetAsync(sv.yv + (sv.n / 2 / 6) * 6 + 1, 0, sizeof(double), st)); }   // test hook: one entry of the solution (a pose coordinate in mid-video) lost
-    if (s->verify_dag) HIP_TRY(launch_chol_verify(sv, s->d_slot_tiles, s->d_verify, s->d_verify + sv.npad, 1e-7, sv.scalars + kDagSuspect, st));
+    if (s->verify_dag) {
+      HIP_TRY(hipMemcpyAsync(s->verify_b, sv.rhs, (size_t)sv.npad * sizeof(double), hipMemcpyDeviceToDevice, st));
+      HIP_TRY(hipEventRecord(s->ev_solved, st));
+      HIP_TRY(hipStreamWaitEvent(s->vstream, s->ev_solved, 0));
+      HIP_TRY(launch_chol_verify(sv, s->d_slot_tiles, s->verify_b, s->d_verify, s->d_verify + sv.npad, 1e-7, sv.scalars + kDagSuspect, s->vstream));
+      HIP_TRY(hipEventRecord(s->ev_verified, s->vstream));
+      s->verify_pending = true;
+    }
   } else {
     for (int l = 0; l < s->nlev; ++l) {
       const int d0 = s->lev_diag_ptr[l], d1 = s->lev_diag_ptr[l + 1], t0 = s->lev_sub_ptr[l], t1 = s->lev_sub_ptr[l + 1];
@@ -1066,6 +1090,9 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 
 void rsba_destroy_solver(rsba_handle* h) {
   if (!h || !h->solver) return;
+  if (h->solver->vstream) { (void)hipStreamSynchronize(h->solver->vstream); (void)hipStreamDestroy(h->solver->vstream); }
+  if (h->solver->ev_solved) (void)hipEventDestroy(h->solver->ev_solved);
+  if (h->solver->ev_verified) (void)hipEventDestroy(h->solver->ev_verified);
   if (const char* path = h->solver->sv.schur_trace ? std::getenv("RSBA_SCHUR_TRACE") : nullptr) {   // debugging aid: stamps of the last Schur launch
     std::vector<long long> tr(8 * (size_t)h->solver->sv.nchunk);
     if (hipMemcpy(tr.data(), h->solver->sv.schur_trace, tr.size() * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess)
@@ -1251,6 +1278,7 @@ extern "C" int32_t rsba_pose_covariance(rsba_handle* h, int32_t frame, double* c
     HIP_TRY(hipMemcpyAsync(hb, s->ratio4, sizeof hb, hipMemcpyDeviceToHost, st));     // {h, g, b.v}
   }
   double suspect = 0.0;
+  if ((rc = await_verification(h))) return rc;
   HIP_TRY(hipMemcpyAsync(&suspect, sv.scalars + kDagSuspect, sizeof(double), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   if (suspect == 0.0 || s->use_levels) break;
@@ -1395,6 +1423,11 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
     if (sv.NPF > 0) std::swap(dp.intr, sv.trial_intr);
     if (dp.pp_count > 0) std::swap(dp.pp_value, dp.pp_trial);
   };
+  // A candidate is evaluated in LM mode straight away (residuals, Jacobian, per-wave camera blocks) when the problem keeps no
+  // records (they would be overwritten and a rejected step needs the old ones): an accepted step — the rule — then re-uses that
+  // evaluation for its linearisation instead of evaluating twice, a rejected one has computed Jacobians for nothing.
+  bool speculate = dp.rec == nullptr;
+  if (const char* e = std::getenv("RSBA_SPECULATE")) speculate = speculate && e[0] != '0';
   int invalid_streak = 0, iteration = 0;
   const size_t pose_bytes = (size_t)dp.F * dp.P * 6 * sizeof(double), point_bytes = (size_t)dp.M * 3 * sizeof(double);
   (void)pose_bytes; (void)point_bytes;
@@ -1423,7 +1456,7 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
     {
       PhaseScope ps(h, RSBA_PHASE_EVAL_TRIAL);
       HIP_TRY(hipMemsetAsync(dp.fail_count, 0, sizeof(int), st));
-      HIP_TRY(launch_eval(dp, kResidualOnly, st));
+      HIP_TRY(launch_eval(dp, speculate ? kLmJacobian : kResidualOnly, st));
       HIP_TRY(launch_cost_reduce(dp, h->d_cost2, st));
     }
     if (s->ucross && sv.lead) {
@@ -1437,6 +1470,7 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
     // exchange (3): model decrease, |step|^2, |x|^2, (skip the max slot), trial cost, -, failure flags
     {
       PhaseScope ps(h, RSBA_PHASE_EXCHANGE);
+      if ((rc = await_verification(h))) return rc;   // (its flag rides in the scalars below)
       HIP_TRY(launch_pack_trial(dp, sv, h->d_cost2, st));
       if ((rc = exchange(h, sv.scalars, 3, 0))) return rc;
       if ((rc = exchange(h, sv.scalars + kCost, 8, 0))) return rc;   // ... and the verification flag of the Cholesky driver: every rank decides alike
@@ -1479,7 +1513,7 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
         if (free_ratio) { ratio = ratio_new; dp.prior_ratio = ratio; }
         if (sv.NPF > 0) HIP_TRY(hipMemcpyAsync(sv.trial_intr, dp.intr, 9 * (size_t)dp.NI * sizeof(double), hipMemcpyDeviceToDevice, st));   // constant coordinates stay in sync
         t0 = now_s();
-        if ((rc = linearize(h))) return rc;
+        if ((rc = linearize(h, speculate))) return rc;
         if ((rc = gradient_max(h))) return rc;
         if ((rc = read_back())) return rc;
         sum->residual_jacobian_time_s += now_s() - t0;

@@ -150,7 +150,8 @@ hipError_t launch_pose_prior_step(const DeviceProblem& dp, const SolverDev& sv, 
 hipError_t launch_chol_level(const SolverDev& sv, const CholPlan& pl, int kind, int first, int count, hipStream_t st);
 // res = rhs - S y with den = |rhs| + |S||y| over the packed tiles; *flag = 1 when |res| > tol * den somewhere, left alone otherwise (sticky; cholesky.hip)
 // slot_tiles [nslots][2] = {row tile, column tile} (unpermuted tile indices) of every packed tile
-hipError_t launch_chol_verify(const SolverDev& sv, const int32_t* slot_tiles, double* res, double* den, double tol, double* flag, hipStream_t st);
+// b_rhs: the right-hand side the system was solved for (a private copy: the caller overwrites sv.rhs with the step while the check runs on its own stream)
+hipError_t launch_chol_verify(const SolverDev& sv, const int32_t* slot_tiles, const double* b_rhs, double* res, double* den, double tol, double* flag, hipStream_t st);
 struct DagArgs { SolverDev sv; CholPlan pl; };   // device copy the persistent kernel reads its state through (uploaded once per plan)
 hipError_t launch_chol_dag(const SolverDev& sv, const CholPlan& pl, const DagArgs* device_args, int workgroups, bool one_per_cu, hipStream_t st);   // one_per_cu: LDS request above half a CU's, so that two never share one
 
@@ -179,6 +180,7 @@ hipError_t launch_intr_blocks(const DeviceProblem& dp, const SolverDev& sv, hipS
 hipError_t launch_virtual_records(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);
 hipError_t launch_pack_linearize(const DeviceProblem& dp, const SolverDev& sv, const double* cost2, hipStream_t st);
 hipError_t launch_unpack_linearize(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);
+hipError_t launch_local_linearize(const DeviceProblem& dp, const SolverDev& sv, const double* cost2, hipStream_t st);   // pack + unpack of a single rank in one launch
 hipError_t launch_pack_trial(const DeviceProblem& dp, const SolverDev& sv, const double* cost2, hipStream_t st);
 hipError_t launch_own_points(const DeviceProblem& dp, const SolverDev& sv, double* buf4m, hipStream_t st);   // sharded solve: [M][3] owned values | [M] owner flag
 hipError_t launch_merge_points(const DeviceProblem& dp, const double* buf4m, hipStream_t st);
