@@ -83,7 +83,12 @@ struct Solver {
   int32_t* d_obs_slot = nullptr;
   double *d_gpose = nullptr, *d_gpoint = nullptr;
   int64_t num_pairs = 0;
-  double* cells = nullptr; size_t ncells = 0;                         // the write-once cells of the DAG Cholesky (one allocation: Lf | chol_part | Winv | zv | yv | Xpub)
+  // The write-once cells of the DAG Cholesky (Lf | chol_part | Winv | zv | yv | Xpub) exist TWICE: while one set is in use the other
+  // is re-armed (one memset) on a stream of its own, off the iteration's critical path; consecutive solves alternate.
+  double* cells[2] = {nullptr, nullptr}; size_t ncells = 0, cell_off[5] = {0, 0, 0, 0, 0};
+  DagArgs* d_dag_args2[2] = {nullptr, nullptr};
+  int cur_cells = 0;
+  hipStream_t mstream = nullptr; hipEvent_t ev_armed[2] = {nullptr, nullptr}, ev_released = nullptr; bool arm_pending[2] = {false, false};
   int64_t schur_launches = 0;                                         // launches of the Schur kernel since the plan was built (statistics)
   int num_reduced_blocks = 0, num_reduced_params = 0, num_priors_reduced = 0;
   double* border = nullptr, *ubuf = nullptr, *ratio4 = nullptr;      // free interFrameRatio: its column of S [npad], the first solve's result, {h, g, b.u, b.v}
@@ -731,10 +736,17 @@ int32_t build_solver(rsba_handle* h) {
   // allocation: one memset re-arms them before a launch (five launches before)
   {
     const size_t nLf = (size_t)sv.nslots * kTile * kTile, nPart = (size_t)std::max(parts, 1) * (kTile * kTile + kTile), nW = (size_t)nt * kTile * kTile, nZ = 2 * (size_t)sv.npad;
-    double* cells = nullptr;
-    if ((rc = s_alloc(s, &cells, nLf + nPart + nW + nZ + nW))) return rc;
+    s->ncells = nLf + nPart + nW + nZ + nW;
+    s->cell_off[0] = 0; s->cell_off[1] = nLf; s->cell_off[2] = nLf + nPart; s->cell_off[3] = nLf + nPart + nW; s->cell_off[4] = nLf + nPart + nW + nZ;
+    for (int b = 0; b < 2; ++b) {
+      if ((rc = s_alloc(s, &s->cells[b], s->ncells))) return rc;
+      HIP_TRY(hipMemsetAsync(s->cells[b], 0xFF, s->ncells * sizeof(double), h->stream));   // both sets start out armed
+    }
+    HIP_TRY(hipStreamCreateWithFlags(&s->mstream, hipStreamNonBlocking));
+    for (int b = 0; b < 2; ++b) HIP_TRY(hipEventCreateWithFlags(&s->ev_armed[b], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&s->ev_released, hipEventDisableTiming));
+    double* cells = s->cells[0];
     sv.Lf = cells; sv.chol_part = cells + nLf; sv.Winv = sv.chol_part + nPart; sv.zv = sv.Winv + nW; sv.yv = sv.zv + sv.npad; sv.Xpub = sv.zv + nZ;
-    s->cells = cells; s->ncells = nLf + nPart + nW + nZ + nW;
   }
   if ((rc = s_upload(s, &s->d_tasks, s->tasks))) return rc;
   if ((rc = s_alloc(s, &s->d_dag_sync, 4))) return rc;
@@ -884,8 +896,14 @@ int32_t build_solver(rsba_handle* h) {
     HIP_TRY(hipMemset(s->d_verify, 0, 2 * (size_t)sv.npad * sizeof(double)));   // the check kernel leaves it zero again
     { const char* v = std::getenv("RSBA_CHOL_VERIFY"); s->verify_dag = !(v && v[0] == '0'); }
     { const char* v = std::getenv("RSBA_CHOL_TEST_CORRUPT"); s->test_corrupt_once = v && v[0] == '1'; }
-    if ((rc = s_alloc(s, &s->d_dag_args, 1))) return rc;
-    HIP_TRY(hipMemcpy(s->d_dag_args, &host_args, sizeof host_args, hipMemcpyHostToDevice));
+    for (int b = 0; b < 2; ++b) {   // one device copy of {sv, plan} per set of cells
+      double* c = s->cells[b];
+      host_args.sv.Lf = c + s->cell_off[0]; host_args.sv.chol_part = c + s->cell_off[1]; host_args.sv.Winv = c + s->cell_off[2];
+      host_args.sv.zv = c + s->cell_off[3]; host_args.sv.yv = host_args.sv.zv + sv.npad; host_args.sv.Xpub = c + s->cell_off[4];
+      if ((rc = s_alloc(s, &s->d_dag_args2[b], 1))) return rc;
+      HIP_TRY(hipMemcpy(s->d_dag_args2[b], &host_args, sizeof host_args, hipMemcpyHostToDevice));
+    }
+    s->d_dag_args = s->d_dag_args2[0];
   }
   {
     rsba_plan_stats& ps = s->stats;
@@ -912,6 +930,7 @@ int32_t build_solver(rsba_handle* h) {
     ps.exchange_doubles = (int64_t)sv.nslots * kTile * kTile + sv.npad;
     ps.schur_groups = sv.ngroups;
   }
+  HIP_TRY(hipStreamSynchronize(h->stream));   // the plan's one-time fills and scatters are done whatever stream the solves will run on
   return RSBA_OK;
 }
 
@@ -1025,11 +1044,23 @@ int32_t await_verification(rsba_handle* h) {
   return RSBA_OK;
 }
 int32_t solve_reduced_system(rsba_handle* h) {
-  Solver* s = h->solver; const SolverDev& sv = s->sv; hipStream_t st = h->stream;
+  Solver* s = h->solver; SolverDev& sv = s->sv; hipStream_t st = h->stream;
   PhaseScope ps(h, RSBA_PHASE_CHOLESKY);
   if (int32_t rc = await_verification(h)) return rc;
   if (!s->use_levels) {
-    HIP_TRY(hipMemsetAsync(s->cells, 0xFF, s->ncells * sizeof(double), st));   // every write-once cell starts out empty (all ones)
+    // The set of cells the last solve used is released here — everything that reads it has been enqueued on this stream or has been
+    // waited for above — and re-armed (every cell empty: all ones) on the side stream while THIS solve runs on the other set.
+    const int used = s->cur_cells, now = used ^ 1;
+    HIP_TRY(hipEventRecord(s->ev_released, st));
+    HIP_TRY(hipStreamWaitEvent(s->mstream, s->ev_released, 0));
+    HIP_TRY(hipMemsetAsync(s->cells[used], 0xFF, s->ncells * sizeof(double), s->mstream));
+    HIP_TRY(hipEventRecord(s->ev_armed[used], s->mstream));
+    s->arm_pending[used] = true;
+    if (s->arm_pending[now]) { HIP_TRY(hipStreamWaitEvent(st, s->ev_armed[now], 0)); s->arm_pending[now] = false; }
+    s->cur_cells = now;
+    double* c = s->cells[now];
+    sv.Lf = c + s->cell_off[0]; sv.chol_part = c + s->cell_off[1]; sv.Winv = c + s->cell_off[2]; sv.zv = c + s->cell_off[3]; sv.yv = sv.zv + sv.npad; sv.Xpub = c + s->cell_off[4];
+    s->d_dag_args = s->d_dag_args2[now];
     HIP_TRY(launch_chol_dag(sv, s->plan, s->d_dag_args, s->dag_workgroups, s->dag_one_per_cu, st));
     if (s->test_corrupt_once) { s->test_corrupt_once = false; HIP_TRY(hipMemsetAsync(sv.yv + (sv.n / 2 / 6) * 6 + 1, 0, sizeof(double), st)); }   // test hook: one entry of the solution (a pose coordinate in mid-video) lost
     if (s->verify_dag) {
@@ -1091,6 +1122,8 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 void rsba_destroy_solver(rsba_handle* h) {
   if (!h || !h->solver) return;
   if (h->solver->vstream) { (void)hipStreamSynchronize(h->solver->vstream); (void)hipStreamDestroy(h->solver->vstream); }
+  if (h->solver->mstream) { (void)hipStreamSynchronize(h->solver->mstream); (void)hipStreamDestroy(h->solver->mstream); }
+  for (hipEvent_t e : {h->solver->ev_armed[0], h->solver->ev_armed[1], h->solver->ev_released}) if (e) (void)hipEventDestroy(e);
   if (h->solver->ev_solved) (void)hipEventDestroy(h->solver->ev_solved);
   if (h->solver->ev_verified) (void)hipEventDestroy(h->solver->ev_verified);
   if (const char* path = h->solver->sv.schur_trace ? std::getenv("RSBA_SCHUR_TRACE") : nullptr) {   // debugging aid: stamps of the last Schur launch
