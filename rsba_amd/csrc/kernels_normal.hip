@@ -1088,6 +1088,11 @@ hipError_t launch_pack_linearize(const DeviceProblem& dp, const SolverDev& sv, c
   LAUNCH(pack_linearize_kernel, nblocks256(sv.n), 256, st, dp, sv, cost2);
   return hipSuccess;
 }
+__global__ void begin_solve_kernel(const SolverDev sv) { *sv.chol_fail = 0; sv.scalars[kDagSuspect] = 0.0; }
+hipError_t launch_begin_solve(const SolverDev& sv, hipStream_t st) {
+  LAUNCH(begin_solve_kernel, 1, 1, st, sv);
+  return hipSuccess;
+}
 hipError_t launch_local_linearize(const DeviceProblem& dp, const SolverDev& sv, const double* cost2, hipStream_t st) {
   LAUNCH(local_linearize_kernel, nblocks256(sv.n), 256, st, dp, sv, cost2);
   return hipSuccess;

@@ -969,8 +969,7 @@ int32_t linearize(rsba_handle* h, bool have_eval = false) {
   Solver* s = h->solver;
   if (!have_eval) {
     PhaseScope ps(h, RSBA_PHASE_EVAL_LM);
-    HIP_TRY(hipMemsetAsync(h->dp.fail_count, 0, sizeof(int), h->stream));
-    HIP_TRY(launch_eval(h->dp, kLmJacobian, h->stream));
+    HIP_TRY(launch_eval(h->dp, kLmJacobian, h->stream));   // (the cost reduction overwrites dp.fail_count: nothing to clear)
     HIP_TRY(launch_cost_reduce(h->dp, h->d_cost2, h->stream));
   }
   {
@@ -1473,8 +1472,7 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
       HIP_TRY(launch_pose_prior_clamp(dp, s->pp, opt->min_lm_diagonal, opt->max_lm_diagonal, st));
       ratio_diag = std::min(std::max(ratio_scale * ratio_scale * ratio_hg[0], opt->min_lm_diagonal), opt->max_lm_diagonal);
     }
-    HIP_TRY(hipMemsetAsync(sv.chol_fail, 0, sizeof(int), st));
-    HIP_TRY(hipMemsetAsync(sv.scalars + kDagSuspect, 0, sizeof(double), st));   // sticky verification flag of the DAG Cholesky: any solve of this iteration may raise it
+    HIP_TRY(launch_begin_solve(sv, st));   // chol_fail = 0 and the sticky verification flag of the DAG Cholesky = 0 (any solve of this iteration may raise it): one launch
     RatioStep rs{ratio_scale * ratio_scale * ratio_hg[0] + ratio_diag / radius, ratio_scale * ratio_hg[1], ratio_scale, 0.0};
     if ((rc = factor_and_solve(h, radius, free_ratio ? &rs : nullptr))) return rc;
     reuse_diagonal = true;
@@ -1488,7 +1486,6 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
     swap_params();
     {
       PhaseScope ps(h, RSBA_PHASE_EVAL_TRIAL);
-      HIP_TRY(hipMemsetAsync(dp.fail_count, 0, sizeof(int), st));
       HIP_TRY(launch_eval(dp, speculate ? kLmJacobian : kResidualOnly, st));
       HIP_TRY(launch_cost_reduce(dp, h->d_cost2, st));
     }

@@ -180,6 +180,7 @@ hipError_t launch_intr_blocks(const DeviceProblem& dp, const SolverDev& sv, hipS
 hipError_t launch_virtual_records(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);
 hipError_t launch_pack_linearize(const DeviceProblem& dp, const SolverDev& sv, const double* cost2, hipStream_t st);
 hipError_t launch_unpack_linearize(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);
+hipError_t launch_begin_solve(const SolverDev& sv, hipStream_t st);   // the two failure flags of a linear solve cleared in one launch
 hipError_t launch_local_linearize(const DeviceProblem& dp, const SolverDev& sv, const double* cost2, hipStream_t st);   // pack + unpack of a single rank in one launch
 hipError_t launch_pack_trial(const DeviceProblem& dp, const SolverDev& sv, const double* cost2, hipStream_t st);
 hipError_t launch_own_points(const DeviceProblem& dp, const SolverDev& sv, double* buf4m, hipStream_t st);   // sharded solve: [M][3] owned values | [M] owner flag
