@@ -287,6 +287,12 @@ int32_t rsba_set_pose_priors(rsba_handle* h, double rotation, double position, c
  * a pose per scan line — are not supported.) */
 int32_t rsba_set_global_shutter_frames(rsba_handle* h, const uint8_t* is_global);
 
+/* The symbolic phase of a handle's first solve works in ~40 bytes of host memory per observation.  That scratch is kept by the
+ * library between handles (a fresh handle per call is windowedBA's pattern, VideoSfMHandler.cc:185-214, and mapping / unmapping
+ * it per call cost more than the passes that fill it); this call gives it back to the allocator.  Safe at any time; the next
+ * first solve simply allocates it again. */
+void rsba_release_host_scratch(void);
+
 /* == the RANSAC hypotheses of vision::solveRsPnPRansac (solveRSpnp.cpp:413-524), batched: task t is
  * what pnpTask (:265-335) does for the subset subsets[t][0..m) of the n float points —
  *   skipped (status 0, nothing else written) when drop_coincident != 0 and two of its 3-D points coincide (:283-293;

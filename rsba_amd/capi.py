@@ -24,7 +24,7 @@ EXPORTS = [
     "rsba_validate_observations", "rsba_reproject", "rsba_pose_covariance", "rsba_set_motion_priors",
     "rsba_pnp_tasks", "rsba_pnp_inliers", "rsba_set_inter_frame_ratio_free", "rsba_get_inter_frame_ratio",
     "rsba_sync_block_structure", "rsba_rccl_get_unique_id", "rsba_rccl_comm_create", "rsba_rccl_comm_destroy", "rsba_set_exchange_rccl",
-    "rsba_get_phase_times", "rsba_phase_name", "rsba_get_plan_stats", "rsba_validate_frame", "rsba_reproject_frame", "rsba_set_pose_priors", "rsba_set_global_shutter_frames",
+    "rsba_get_phase_times", "rsba_phase_name", "rsba_get_plan_stats", "rsba_validate_frame", "rsba_reproject_frame", "rsba_set_pose_priors", "rsba_set_global_shutter_frames", "rsba_release_host_scratch",
 ]
 NUM_PHASES = 13
 
@@ -121,6 +121,7 @@ def lib():
         _lib.rsba_status_string.restype = C.c_char_p
         _lib.rsba_last_error.restype = C.c_char_p
         _lib.rsba_destroy.restype = None
+        _lib.rsba_release_host_scratch.restype = None
         _lib.rsba_default_solver_options.restype = None
         _lib.rsba_set_stream.argtypes = [C.c_void_p, C.c_void_p]
         _lib.rsba_destroy.argtypes = [C.c_void_p]
@@ -163,6 +164,11 @@ def make_desc(prob: BAProblem) -> ProblemDesc:
     d.intrinsics_constant = _ptr(prob.intrinsics_constant)
     d.huber_a = float(prob.huber_a)
     return d
+
+
+def release_host_scratch():
+    """rsba_release_host_scratch: give the symbolic phase's host scratch (kept between handles) back to the allocator."""
+    lib().rsba_release_host_scratch()
 
 
 class DeviceProblem:

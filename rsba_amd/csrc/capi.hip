@@ -103,6 +103,12 @@ int32_t rsba_device_count(int32_t* count) {
   return RSBA_OK;
 }
 
+// h->order (internal observation -> caller's index) of a handle whose observations came in frame-major order is the identity and
+// is written out on first use only
+static void ensure_order(rsba_handle* h) {
+  if (h->identity_order && (int64_t)h->order.size() != h->dp.N) { h->order.resize(h->dp.N); std::iota(h->order.begin(), h->order.end(), (int64_t)0); }
+}
+
 int32_t rsba_create(const rsba_problem_desc* d, int32_t device, rsba_handle** out) {
   if (!d || !out) return fail(RSBA_ERR_INVALID_ARGUMENT, "null argument");
   *out = nullptr;
@@ -116,9 +122,16 @@ int32_t rsba_create(const rsba_problem_desc* d, int32_t device, rsba_handle** ou
     return fail(RSBA_ERR_INVALID_ARGUMENT, "scanlines[0] == scanlines[1]");
   if (d->num_intrinsics > 1 && !d->frame_intrinsics) return fail(RSBA_ERR_INVALID_ARGUMENT, "frame_intrinsics required when num_intrinsics > 1");
   const int64_t N = d->num_observations;
-  for (int64_t i = 0; i < N; ++i) {
-    if (d->obs_frame[i] < 0 || d->obs_frame[i] >= d->num_frames || d->obs_point[i] < 0 || d->obs_point[i] >= d->num_points)
-      return fail(RSBA_ERR_INVALID_ARGUMENT, "observation index out of range");
+  bool frame_major = true;   // (one pass: index ranges and whether the list is already in frame-major order)
+  {
+    const uint32_t nf = (uint32_t)d->num_frames, np = (uint32_t)d->num_points;
+    bool in_range = true; int32_t prev = 0;
+    for (int64_t i = 0; i < N; ++i) {
+      const int32_t f = d->obs_frame[i];
+      in_range = in_range && (uint32_t)f < nf && (uint32_t)d->obs_point[i] < np;
+      frame_major = frame_major && f >= prev; prev = f;
+    }
+    if (!in_range) return fail(RSBA_ERR_INVALID_ARGUMENT, "observation index out of range");
   }
   if (d->frame_intrinsics) for (int f = 0; f < d->num_frames; ++f)
     if (d->frame_intrinsics[f] < 0 || d->frame_intrinsics[f] >= d->num_intrinsics) return fail(RSBA_ERR_INVALID_ARGUMENT, "frame_intrinsics out of range");
@@ -138,17 +151,22 @@ int32_t rsba_create(const rsba_problem_desc* d, int32_t device, rsba_handle** ou
 
   // frame-major order: the order CeresHandler::Add produces is already frame-major
   // (VideoSfMHandler.cc:587-590); anything else is stably sorted once here.
-  h->order.resize(N);
-  std::iota(h->order.begin(), h->order.end(), (int64_t)0);
-  h->identity_order = std::is_sorted(d->obs_frame, d->obs_frame + N);
-  if (!h->identity_order)
+  // (in that case nothing is permuted: the caller's arrays are uploaded as they are and h->order is only written out when
+  // somebody asks for it — a fresh handle per call is windowedBA's pattern, VideoSfMHandler.cc:185-214)
+  h->identity_order = frame_major;
+  std::vector<double> xy;
+  std::vector<int32_t> of, op;
+  if (frame_major) { of.assign(d->obs_frame, d->obs_frame + N); op.assign(d->obs_point, d->obs_point + N); }
+  else {
+    h->order.resize(N);
+    std::iota(h->order.begin(), h->order.end(), (int64_t)0);
     std::stable_sort(h->order.begin(), h->order.end(), [&](int64_t a, int64_t b) { return d->obs_frame[a] < d->obs_frame[b]; });
-  std::vector<double> xy(2 * (size_t)N);
-  std::vector<int32_t> of(N), op(N);
-  for (int64_t i = 0; i < N; ++i) {
-    const int64_t u = h->order[i];
-    xy[2 * i] = d->obs_xy[2 * u]; xy[2 * i + 1] = d->obs_xy[2 * u + 1];
-    of[i] = d->obs_frame[u]; op[i] = d->obs_point[u];
+    xy.resize(2 * (size_t)N); of.resize(N); op.resize(N);
+    for (int64_t i = 0; i < N; ++i) {
+      const int64_t u = h->order[i];
+      xy[2 * i] = d->obs_xy[2 * u]; xy[2 * i + 1] = d->obs_xy[2 * u + 1];
+      of[i] = d->obs_frame[u]; op[i] = d->obs_point[u];
+    }
   }
 
   DeviceProblem& dp = h->dp;
@@ -163,7 +181,7 @@ int32_t rsba_create(const rsba_problem_desc* d, int32_t device, rsba_handle** ou
   const size_t npose = (size_t)dp.F * dp.P * 6;
 
   double2* dxy = nullptr; int32_t *dof = nullptr, *dop = nullptr, *dfi = nullptr;
-  if ((rc = dev_upload(h, reinterpret_cast<double**>(&dxy), xy.data(), 2 * (size_t)N))) return bail(rc);
+  if ((rc = dev_upload(h, reinterpret_cast<double**>(&dxy), frame_major ? d->obs_xy : xy.data(), 2 * (size_t)N))) return bail(rc);
   if ((rc = dev_upload(h, &dof, of.data(), (size_t)N))) return bail(rc);
   if ((rc = dev_upload(h, &dop, op.data(), (size_t)N))) return bail(rc);
   std::vector<int32_t> fi(dp.F, 0);
@@ -253,6 +271,7 @@ int32_t rsba_get_device_view(rsba_handle* h, rsba_device_view* v) {
   if (!h || !v) return fail(RSBA_ERR_INVALID_ARGUMENT, "null argument");
   std::memset(v, 0, sizeof *v);
   v->residuals = h->dp.res; v->jacobians = h->dp.jac; v->tile = kEvalBlock; v->jacobian_cols = h->dp.K;
+  ensure_order(h);
   v->order_host = h->order.data(); v->poses = h->dp.poses; v->points = h->dp.points; v->intrinsics = h->dp.intr;
   return RSBA_OK;
 }
@@ -333,6 +352,8 @@ int32_t rsba_set_pose_priors(rsba_handle* h, double rotation, double position, c
   return RSBA_OK;
 }
 
+void rsba_release_host_scratch(void) { rsba_release_plan_scratch(); }
+
 int32_t rsba_set_global_shutter_frames(rsba_handle* h, const uint8_t* is_global) {
   if (!h) return fail(RSBA_ERR_INVALID_ARGUMENT, "null handle");
   if (h->solver) return fail(RSBA_ERR_INVALID_ARGUMENT, "rsba_set_global_shutter_frames must precede the first solve / gradient call");
@@ -386,6 +407,7 @@ int32_t rsba_evaluate(rsba_handle* h, double* cost, double* residuals, double* j
     if (!h->d_order) {
       HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_order), (size_t)N * sizeof(int64_t)));
       h->allocs.push_back(h->d_order);
+      ensure_order(h);
       HIP_TRY(hipMemcpyAsync(h->d_order, h->order.data(), (size_t)N * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
       HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_rows), (size_t)N * (2 + 2 * (size_t)K) * sizeof(double)));
       h->allocs.push_back(h->d_rows);

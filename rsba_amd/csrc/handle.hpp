@@ -51,3 +51,4 @@ struct rsba_handle {
 int32_t rsba_set_error(int32_t code, const char* msg);
 int32_t rsba_gradient(rsba_handle* h, double* gradient_host);
 void rsba_destroy_solver(rsba_handle* h);
+void rsba_release_plan_scratch();   // solver.hip: the symbolic phase's host scratch (kept across handles)

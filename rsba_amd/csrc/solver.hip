@@ -14,6 +14,10 @@
 #include <functional>
 #include <limits>
 #include <string>
+#include <condition_variable>
+#include <deque>
+#include <memory>
+#include <mutex>
 #include <thread>
 #include <unordered_map>
 #include <vector>
@@ -134,6 +138,74 @@ int32_t s_upload_const(Solver* s, const T** p, const std::vector<T>& v) {
   return rc;
 }
 
+// The symbolic phase hands its finished arrays to ONE background thread that allocates and copies them while the host goes on
+// with the next pass (a fresh handle's plan is the per-call cost of windowedBA, VideoSfMHandler.cc:185-214: at 1k cameras 60 MB of
+// index arrays, 6 ms of copies from pageable memory that used to sit behind the passes instead of under them).  The vectors must
+// stay untouched until finish(); the allocations end up in Solver::allocs like everyone else's.
+struct Uploader {
+  Solver* s; int device;
+  std::thread th; std::mutex m; std::condition_variable cv; std::deque<std::function<hipError_t()>> q;
+  bool closing = false, joined = false; hipError_t err = hipSuccess; std::string what;
+  std::vector<void*> allocs;
+  Uploader(Solver* s_, int dev) : s(s_), device(dev) {
+    th = std::thread([this]() {
+      (void)hipSetDevice(device);
+      for (;;) {
+        std::function<hipError_t()> job;
+        { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return closing || !q.empty(); }); if (q.empty()) return; job = std::move(q.front()); q.pop_front(); }
+        if (err == hipSuccess) err = job();
+      }
+    });
+  }
+  void push(std::function<hipError_t()> job) { { std::lock_guard<std::mutex> lk(m); q.push_back(std::move(job)); } cv.notify_one(); }
+  template <class T>
+  void upload(T** dst, const std::vector<T>& v) {
+    push([this, dst, &v]() -> hipError_t {
+      void* d = nullptr;
+      hipError_t e = hipMalloc(&d, std::max<size_t>(v.size(), 1) * sizeof(T));
+      if (e != hipSuccess) return e;
+      allocs.push_back(d); *dst = static_cast<T*>(d);
+      return v.empty() ? hipSuccess : hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    });
+  }
+  template <class T>
+  void upload_const(const T** dst, const std::vector<T>& v) { upload(const_cast<T**>(dst), v); }
+  hipError_t finish() {
+    if (!joined) {
+      { std::lock_guard<std::mutex> lk(m); closing = true; } cv.notify_one();
+      th.join(); joined = true;
+      s->allocs.insert(s->allocs.end(), allocs.begin(), allocs.end()); allocs.clear();
+    }
+    return err;
+  }
+  ~Uploader() { (void)finish(); }
+};
+
+// Host scratch of the symbolic phase — everything sized by the observations or the entries (85 MB at 1k cameras).  It lives across
+// calls: as plain locals these vectors cost more than the passes that fill them — every fresh handle page-faulted them in and
+// unmapped them on return (on a 256-core host, after 16 threads had touched them, the unmap alone was 25 ms of a 51 ms plan;
+// measured with glibc told to keep its memory: 14.5 ms).  One build at a time uses the shared set (a second concurrent one gets
+// its own, freed on return); rsba_release_host_scratch() gives the memory back.
+struct PlanScratch {
+  std::vector<int64_t> point_ptr, fill, vgroup_ptr, pt_group;
+  std::vector<int32_t> obs_slot, real_frame, slot_frame, slot_point, slot_gpos, g_tile, g_rows, ent_groups, ent_pt, vgroup_point, vgroup_intr;
+  std::vector<uint8_t> group_mask, group_present;
+  std::vector<uint16_t> ent_mask;
+  std::vector<std::vector<int32_t>> thread_cnt;
+  std::vector<double> inprog_point;
+};
+std::mutex g_plan_scratch_mutex;
+std::unique_ptr<PlanScratch> g_plan_scratch;
+
+// fn(a, b, t) over nthr contiguous ranges of [0, n)
+template <class F>
+void parallel_ranges(int nthr, int64_t n, F&& fn) {
+  if (nthr <= 1) { fn((int64_t)0, n, 0); return; }
+  std::vector<std::thread> pool;
+  for (int t = 0; t < nthr; ++t) pool.emplace_back([&, t]() { fn(n * t / nthr, n * (t + 1) / nthr, t); });
+  for (auto& th : pool) th.join();
+}
+
 struct PhaseScope {
   PhaseTimer* t = nullptr; int phase; hipStream_t st; hipEvent_t a = nullptr;
   PhaseScope(rsba_handle* h, int ph) : phase(ph), st(h->stream) {
@@ -171,20 +243,27 @@ int32_t build_solver(rsba_handle* h) {
   sv.nt = (F + FT - 1) / FT; sv.npad = (int64_t)sv.nt * kTile;
   const std::vector<int32_t>& of = h->obs_frame; const std::vector<int32_t>& op = h->obs_point;
 
-  std::vector<int64_t> frame_ptr(FR + 1, 0), point_ptr(M + 1, 0);
+  std::unique_lock<std::mutex> scratch_lock(g_plan_scratch_mutex, std::try_to_lock);
+  std::unique_ptr<PlanScratch> own_scratch;
+  if (scratch_lock.owns_lock()) { if (!g_plan_scratch) g_plan_scratch.reset(new PlanScratch()); } else own_scratch.reset(new PlanScratch());
+  PlanScratch& scr = scratch_lock.owns_lock() ? *g_plan_scratch : *own_scratch;
+  std::vector<int64_t> frame_ptr(FR + 1, 0);
+  std::vector<int64_t>& point_ptr = scr.point_ptr; point_ptr.assign((size_t)M + 1, 0);
   for (int64_t i = 0; i < N; ++i) { frame_ptr[of[i] + 1]++; point_ptr[op[i] + 1]++; }
   for (int f = 0; f < FR; ++f) frame_ptr[f + 1] += frame_ptr[f];
   for (int j = 0; j < M; ++j) point_ptr[j + 1] += point_ptr[j];
   // slots: stable counting sort of the frame-major list by point -> ascending frame inside a point
-  std::vector<int32_t> obs_slot(N), real_frame(N);
+  std::vector<int32_t>& obs_slot = scr.obs_slot; obs_slot.resize((size_t)N);
+  std::vector<int32_t>& real_frame = scr.real_frame; real_frame.resize((size_t)N);
   {
-    std::vector<int64_t> fill(point_ptr.begin(), point_ptr.end() - 1);
+    std::vector<int64_t>& fill = scr.fill; fill.assign(point_ptr.begin(), point_ptr.end() - 1);
     for (int64_t i = 0; i < N; ++i) { const int64_t sl = fill[op[i]]++; obs_slot[i] = (int32_t)sl; real_frame[sl] = of[i]; }
   }
   // virtual groups: one per (observed point, intrinsics block it is seen through), blocks ascending; each owns NPF virtual
   // slots behind the real ones
-  std::vector<int64_t> vgroup_ptr(M + 1, 0);
-  std::vector<int32_t> vgroup_point, vgroup_intr;
+  std::vector<int64_t>& vgroup_ptr = scr.vgroup_ptr; vgroup_ptr.assign((size_t)M + 1, 0);
+  std::vector<int32_t>& vgroup_point = scr.vgroup_point; std::vector<int32_t>& vgroup_intr = scr.vgroup_intr;
+  vgroup_point.clear(); vgroup_intr.clear();
   if (NIB > 0) {
     std::vector<int32_t> seen;
     for (int j = 0; j < M; ++j) {
@@ -198,17 +277,23 @@ int32_t build_solver(rsba_handle* h) {
   const int64_t NVG = (int64_t)vgroup_point.size();
   sv.nvgroups = NVG;
   const int64_t NS = N + NVG * NPF;
-  std::vector<int32_t> slot_frame(NS), slot_point(NS);
+  std::vector<int32_t>& slot_frame = scr.slot_frame; slot_frame.resize((size_t)NS);
+  std::vector<int32_t>& slot_point = scr.slot_point; slot_point.resize((size_t)NS);
   for (int64_t x = 0; x < N; ++x) slot_frame[x] = real_frame[x];
   for (int j = 0; j < M; ++j) for (int64_t x = point_ptr[j]; x < point_ptr[j + 1]; ++x) slot_point[x] = j;
   for (int64_t g = 0; g < NVG; ++g) for (int v = 0; v < NPF; ++v) { slot_frame[N + g * NPF + v] = FR + vgroup_intr[g] * NPF + v; slot_point[N + g * NPF + v] = vgroup_point[g]; }
-  std::vector<int32_t>().swap(real_frame);
   // the slots of point j in ascending frame order (virtual ones last, by intrinsics block; only for points that are observed)
   auto slots_of = [&](int j, std::vector<int64_t>& out) {
     out.clear();
     for (int64_t x = point_ptr[j]; x < point_ptr[j + 1]; ++x) out.push_back(x);
     for (int64_t g = vgroup_ptr[j]; g < vgroup_ptr[j + 1]; ++g) for (int v = 0; v < NPF; ++v) out.push_back(N + g * NPF + v);
   };
+  Uploader up(s, h->device);
+  up.upload_const(&sv.frame_ptr, frame_ptr);
+  up.upload_const(&sv.point_ptr, point_ptr);
+  up.upload_const(&sv.slot_frame, slot_frame);
+  up.upload_const(&sv.slot_point, slot_point);
+  up.upload(&s->d_obs_slot, obs_slot);
   tick("slots");
   // ---- work list of the point elimination: one ENTRY per (point, pair of frame tiles I >= J) ----
   // An entry lists the point's observation slot in each of the FT frames of tile I (sa) and of tile J (sb),
@@ -218,30 +303,53 @@ int32_t build_solver(rsba_handle* h) {
   const int nt = sv.nt;
   // Per point, the (tile, layer) groups of its slots — computed once, flat (no per-point allocations: this pass used
   // to be 85 % of the symbolic phase): group g of point j covers one tile and one layer and owns FT slot entries.
-  std::vector<int64_t> pt_group(M + 1, 0);     // groups of point j: [pt_group[j], pt_group[j+1])
-  std::vector<int32_t> g_tile, g_rows;          // tile of each group; FT slots per group (NS = not observed)
-  std::vector<int32_t> slot_gpos(NS);            // group * FT + position of every slot: where its P record goes
-  g_tile.reserve((size_t)N / 2); g_rows.reserve((size_t)N * 2);
-  std::vector<int64_t> pslots;
-  for (int j = 0; j < M; ++j) {
-    slots_of(j, pslots);
-    int prev_frame = -1, layer = 0, cur_tile = -1;
-    size_t tile_first = g_tile.size();          // first group (layer 0) of the current tile
-    for (int64_t sl : pslots) {
-      const int f = slot_frame[sl], tile = f / FT, pos = f % FT;
-      layer = (f == prev_frame) ? layer + 1 : 0; prev_frame = f;
-      if (tile != cur_tile) { cur_tile = tile; tile_first = g_tile.size(); }
-      while (g_tile.size() - tile_first <= (size_t)layer) {    // a new layer of this tile
-        g_tile.push_back(tile);
-        g_rows.insert(g_rows.end(), FT, (int32_t)NS);   // NS = the all-zero record behind the last slot: "not observed"
+  std::vector<int64_t>& pt_group = scr.pt_group; pt_group.assign((size_t)M + 1, 0);     // groups of point j: [pt_group[j], pt_group[j+1])
+  std::vector<int32_t>& g_tile = scr.g_tile; std::vector<int32_t>& g_rows = scr.g_rows;   // tile of each group; FT slots per group (NS = not observed)
+  std::vector<int32_t>& slot_gpos = scr.slot_gpos; slot_gpos.resize((size_t)NS);           // group * FT + position of every slot: where its P record goes
+  std::vector<uint8_t>& group_mask = scr.group_mask;        // which of the three 16-row blocks of a group's records can be non-zero
+  std::vector<uint8_t>& group_present = scr.group_present;  // frames of the group's tile that see the point (plan statistics)
+  const int nthr_pts = M >= 4096 ? (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency())) : 1;
+  {
+    // one walk over a point's slots: on_group(g, tile) for every new (tile, layer) group g = 0, 1, .. of the point, on_slot(g, pos, slot)
+    auto walk = [&](int j, std::vector<int64_t>& pslots, auto&& on_group, auto&& on_slot) -> int64_t {
+      slots_of(j, pslots);
+      int prev_frame = -1, layer = 0, cur_tile = -1;
+      int64_t ng = 0, tile_first = 0;            // first group (layer 0) of the current tile
+      for (int64_t sl : pslots) {
+        const int f = slot_frame[sl], tile = f / FT, pos = f % FT;
+        layer = (f == prev_frame) ? layer + 1 : 0; prev_frame = f;
+        if (tile != cur_tile) { cur_tile = tile; tile_first = ng; }
+        while (ng - tile_first <= layer) { on_group(ng, tile); ++ng; }   // a new layer of this tile
+        on_slot(tile_first + layer, pos, sl);
       }
-      g_rows[(tile_first + layer) * FT + pos] = (int32_t)sl;
-      slot_gpos[sl] = (int32_t)((tile_first + layer) * FT + pos);
-    }
-    pt_group[j + 1] = (int64_t)g_tile.size();
+      return ng;
+    };
+    // count, prefix, fill — over contiguous point ranges on a few threads (the lists come out as from one thread)
+    parallel_ranges(nthr_pts, M, [&](int64_t a, int64_t b, int) {
+      std::vector<int64_t> ps;
+      for (int64_t j = a; j < b; ++j) pt_group[j + 1] = walk((int)j, ps, [](int64_t, int) {}, [](int64_t, int, int64_t) {});
+    });
+    for (int j = 0; j < M; ++j) pt_group[j + 1] += pt_group[j];
+    const int64_t NG = pt_group[M];
+    g_tile.resize((size_t)NG); g_rows.assign((size_t)NG * FT, (int32_t)NS);   // NS = the all-zero record behind the last slot: "not observed"
+    group_mask.assign((size_t)NG + 1, 0); group_present.assign((size_t)NG + 1, 0);
+    parallel_ranges(nthr_pts, M, [&](int64_t a, int64_t b, int) {
+      std::vector<int64_t> ps;
+      for (int64_t j = a; j < b; ++j) {
+        const int64_t base = pt_group[j];
+        walk((int)j, ps, [&](int64_t g, int tile) { g_tile[(size_t)(base + g)] = tile; },
+             [&](int64_t g, int pos, int64_t sl) {
+               g_rows[(size_t)(base + g) * FT + pos] = (int32_t)sl;
+               slot_gpos[sl] = (int32_t)((base + g) * FT + pos);
+               ++group_present[(size_t)(base + g)];
+               for (int row = pos * CD; row < (pos + 1) * CD; row += 4) group_mask[(size_t)(base + g)] |= (uint8_t)(1u << (row / 16));
+             });
+      }
+    });
   }
   sv.ngroups = (int64_t)g_tile.size();
   if ((sv.ngroups + 1) * (int64_t)kTile * 3 >= ((int64_t)1 << 32)) return rsba_set_error(RSBA_ERR_UNSUPPORTED, "more than 2^32 doubles of P records: the Schur kernel indexes them with 32 bits");
+  up.upload_const(&sv.slot_gpos, slot_gpos);
   const bool dense_keys = (int64_t)nt * nt <= (int64_t)1 << 26;
   std::vector<int64_t> dense_cnt; std::unordered_map<int64_t, int64_t> sparse_cnt;
   if (dense_keys) dense_cnt.assign((size_t)nt * nt, -1);
@@ -281,7 +389,7 @@ int32_t build_solver(rsba_handle* h) {
   // with dense keys they run on a few host threads over contiguous point ranges, each with its own counters per tile pair, and
   // the fill starts every thread where the threads before it end: the entry lists come out exactly as from one thread.
   const int nthreads = dense_keys && (int64_t)nt * nt <= ((int64_t)1 << 22) && M >= 4096 ? (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency())) : 1;   // (per-thread counters: 4 nt^2 bytes each)
-  std::vector<std::vector<int32_t>> thread_cnt(nthreads > 1 ? nthreads : 0);
+  std::vector<std::vector<int32_t>>& thread_cnt = scr.thread_cnt; thread_cnt.resize(nthreads > 1 ? nthreads : 0);
   auto point_range = [&](int t) { return std::pair<int, int>((int)((int64_t)M * t / nthreads), (int)((int64_t)M * (t + 1) / nthreads)); };
   if (nthreads > 1) {
     std::vector<std::thread> pool;
@@ -318,7 +426,8 @@ int32_t build_solver(rsba_handle* h) {
   auto index_of = [&](int I, int J) -> int32_t { return dense_keys ? dense_index[(size_t)I * nt + J] : tp_index[(int64_t)I * nt + J]; };
   const int64_t nent = tp_ptr.back();
   // an entry is the pair of groups (of tile I, of tile J) plus its point: the kernel looks the slots up in g_rows
-  std::vector<int32_t> ent_groups((size_t)nent * 2), ent_pt(nent);
+  std::vector<int32_t>& ent_groups = scr.ent_groups; ent_groups.resize((size_t)nent * 2);
+  std::vector<int32_t>& ent_pt = scr.ent_pt; ent_pt.resize((size_t)nent);
   {
     std::vector<int64_t> fill(tp_ptr.begin(), tp_ptr.end() - 1);
     if (nthreads > 1) {
@@ -353,6 +462,24 @@ int32_t build_solver(rsba_handle* h) {
   std::vector<int32_t>().swap(dense_index);
   const int ntp = (int)tp_I.size();
   s->num_pairs = nent;
+  up.upload_const(&sv.ent_groups, ent_groups);
+  up.upload_const(&sv.ent_pt, ent_pt);
+  // per entry, which of the 3 x 3 block products of its two groups can be non-zero
+  std::vector<uint16_t>& ent_mask = scr.ent_mask; ent_mask.resize((size_t)nent);
+  std::vector<int64_t> products_part((size_t)std::max(nthreads, 1), 0);   // (plan statistics: block products that are not structurally zero)
+  parallel_ranges(nthreads, nent, [&](int64_t a, int64_t b, int t) {
+    int64_t prod = 0;
+    for (int64_t e = a; e < b; ++e) {
+      const int32_t ga = ent_groups[2 * (size_t)e], gb = ent_groups[2 * (size_t)e + 1];
+      const unsigned ma = group_mask[ga], mb = group_mask[gb];
+      unsigned pm = 0;
+      for (int I = 0; I < 3; ++I) if ((ma >> I) & 1u) pm |= mb << (3 * I);
+      ent_mask[(size_t)e] = (uint16_t)pm;
+      prod += (int64_t)group_present[ga] * group_present[gb];
+    }
+    products_part[t] = prod;
+  });
+  up.upload_const(&sv.ent_mask, ent_mask);
 
   // ---- tile graph of S, fill-reducing / parallelism-exposing ordering, symbolic factorisation ----
   std::vector<std::vector<int32_t>> adj(nt);
@@ -623,7 +750,8 @@ int32_t build_solver(rsba_handle* h) {
   tick("chunks");
   // which coordinates belong to the reduced program (for |x| and |step|): blocks that are not constant
   // and are touched by at least one residual block
-  std::vector<double> inprog_pose((size_t)FR * CD, 0.0), inprog_point((size_t)M * 3, 0.0), inprog_intr((size_t)std::max(NIB * NPF, 1) * CD, 0.0);
+  std::vector<double> inprog_pose((size_t)FR * CD, 0.0), inprog_intr((size_t)std::max(NIB * NPF, 1) * CD, 0.0);
+  std::vector<double>& inprog_point = scr.inprog_point; inprog_point.assign((size_t)M * 3, 0.0);
   int nfree = 0;
   const bool lead = h->rank == 0;
   sv.lead = lead;
@@ -649,11 +777,18 @@ int32_t build_solver(rsba_handle* h) {
   for (int j = 0; j < M; ++j) if (h->mask_point[(size_t)j * 3] != 0.0 && point_ptr[j + 1] > point_ptr[j]) { for (int k = 0; k < 3; ++k) inprog_point[(size_t)j * 3 + k] = 1.0; nfree += 3; }
   s->num_reduced_params = nfree;
   {
+    // residual blocks whose parameter blocks are all constant leave the program: every observation of a free point stays; those
+    // of a constant point stay where the frame's poses or its intrinsics block are free (per point, not per observation)
+    std::vector<uint8_t> frame_const((size_t)FR, 1);
+    for (int f = 0; f < FR; ++f) {
+      bool c = NIB == 0 || h->mask_intr[(size_t)intr_of(f) * 9] == 0.0;
+      for (int k = 0; k < CD && c; ++k) c = h->mask_pose[(size_t)f * CD + k] == 0.0;
+      frame_const[f] = c;
+    }
     int64_t nred = 0;
-    for (int64_t i = 0; i < N; ++i) {
-      bool all_const = h->mask_point[(size_t)op[i] * 3] == 0.0 && (NIB == 0 || h->mask_intr[(size_t)intr_of(of[i]) * 9] == 0.0);
-      for (int k = 0; k < CD && all_const; ++k) all_const = h->mask_pose[(size_t)of[i] * CD + k] == 0.0;
-      nred += !all_const;
+    for (int j = 0; j < M; ++j) {
+      if (h->mask_point[(size_t)j * 3] != 0.0) { nred += point_ptr[j + 1] - point_ptr[j]; continue; }
+      for (int64_t x = point_ptr[j]; x < point_ptr[j + 1]; ++x) nred += !frame_const[slot_frame[x]];
     }
     s->num_priors_reduced = 0;
     if (lead) for (int32_t f : h->prior_frames) {
@@ -671,67 +806,38 @@ int32_t build_solver(rsba_handle* h) {
   }
 
   int32_t rc;
-  if ((rc = s_upload_const(s, &sv.frame_ptr, frame_ptr))) return rc;
-  if ((rc = s_upload_const(s, &sv.point_ptr, point_ptr))) return rc;
-  if ((rc = s_upload_const(s, &sv.slot_frame, slot_frame))) return rc;
-  if ((rc = s_upload_const(s, &sv.slot_point, slot_point))) return rc;
-  if ((rc = s_upload_const(s, &sv.tp_I, tp_I))) return rc;
-  if ((rc = s_upload_const(s, &sv.tp_J, tp_J))) return rc;
-  if ((rc = s_upload_const(s, &sv.tp_ptr, tp_ptr))) return rc;
-  if ((rc = s_upload_const(s, &sv.ent_groups, ent_groups))) return rc;
-  if ((rc = s_upload_const(s, &sv.slot_gpos, slot_gpos))) return rc;
+  up.upload_const(&sv.tp_I, tp_I);
+  up.upload_const(&sv.tp_J, tp_J);
+  up.upload_const(&sv.tp_ptr, tp_ptr);
+  up.upload_const(&sv.inprog_pose, inprog_pose);
+  up.upload_const(&sv.inprog_point, inprog_point);
+  up.upload_const(&sv.inprog_intr, inprog_intr);
+  std::vector<int32_t> ifp((size_t)NIB + 1, 0), ifl;       // (alive until the uploads have finished)
+  std::vector<int64_t> point_vgroup(NIB == 1 ? (size_t)M : 0, -1);
   {
-    std::vector<uint8_t> group_mask((size_t)sv.ngroups + 1, 0);
-    for (int64_t gq = 0; gq < sv.ngroups; ++gq)
-      for (int pos = 0; pos < FT; ++pos) if (g_rows[(size_t)gq * FT + pos] != (int32_t)NS)
-        for (int row = pos * CD; row < (pos + 1) * CD; row += 4) group_mask[gq] |= (uint8_t)(1u << (row / 16));
-    std::vector<uint16_t> ent_mask((size_t)nent);
-    auto fill_masks = [&](int64_t a, int64_t b) {
-      for (int64_t e = a; e < b; ++e) {
-        const unsigned ma = group_mask[ent_groups[2 * (size_t)e]], mb = group_mask[ent_groups[2 * (size_t)e + 1]];
-        unsigned pm = 0;
-        for (int I = 0; I < 3; ++I) if ((ma >> I) & 1u) pm |= mb << (3 * I);
-        ent_mask[(size_t)e] = (uint16_t)pm;
-      }
-    };
-    if (nthreads > 1) {
-      std::vector<std::thread> pool;
-      for (int t = 0; t < nthreads; ++t) pool.emplace_back(fill_masks, nent * t / nthreads, nent * (t + 1) / nthreads);
-      for (auto& th : pool) th.join();
-    } else fill_masks(0, nent);
-    if ((rc = s_upload_const(s, &sv.ent_mask, ent_mask))) return rc;
-  }
-  if ((rc = s_upload_const(s, &sv.ent_pt, ent_pt))) return rc;
-  if ((rc = s_upload_const(s, &sv.inprog_pose, inprog_pose))) return rc;
-  if ((rc = s_upload_const(s, &sv.inprog_point, inprog_point))) return rc;
-  if ((rc = s_upload_const(s, &sv.inprog_intr, inprog_intr))) return rc;
-  {
-    std::vector<int32_t> ifp((size_t)NIB + 1, 0), ifl;
     for (int f = 0; f < FR && NIB > 0; ++f) ifp[intr_of(f) + 1]++;
     for (int c = 0; c < NIB; ++c) ifp[c + 1] += ifp[c];
     ifl.resize(NIB > 0 ? FR : 0);
     { std::vector<int32_t> fill(ifp.begin(), ifp.end() - 1); for (int f = 0; f < FR && NIB > 0; ++f) ifl[fill[intr_of(f)]++] = f; }
-    if ((rc = s_upload_const(s, &sv.intr_frame_ptr, ifp))) return rc;
-    if ((rc = s_upload_const(s, &sv.intr_frame_list, ifl))) return rc;
-    if ((rc = s_upload_const(s, &sv.vgroup_point, vgroup_point))) return rc;
-    if ((rc = s_upload_const(s, &sv.vgroup_intr, vgroup_intr))) return rc;
-    std::vector<int64_t> point_vgroup(NIB == 1 ? (size_t)M : 0, -1);
+    up.upload_const(&sv.intr_frame_ptr, ifp);
+    up.upload_const(&sv.intr_frame_list, ifl);
+    up.upload_const(&sv.vgroup_point, vgroup_point);
+    up.upload_const(&sv.vgroup_intr, vgroup_intr);
     for (int j = 0; j < M && NIB == 1; ++j) if (vgroup_ptr[j + 1] > vgroup_ptr[j]) point_vgroup[j] = vgroup_ptr[j];
-    if ((rc = s_upload_const(s, &sv.point_vgroup, point_vgroup))) return rc;
+    up.upload_const(&sv.point_vgroup, point_vgroup);
   }
-  if ((rc = s_upload(s, &s->d_obs_slot, obs_slot))) return rc;
-  if ((rc = s_upload_const(s, &sv.chunk_tp, chunk_tp))) return rc;
-  if ((rc = s_upload_const(s, &sv.chunk_e0, chunk_e0))) return rc;
-  if ((rc = s_upload_const(s, &sv.tp_chunk0, tp_chunk0))) return rc;
-  if ((rc = s_upload_const(s, &sv.tp_chunk_list, tp_chunk_list))) return rc;
-  if ((rc = s_upload_const(s, &sv.chunk_n, chunk_n))) return rc;
-  if ((rc = s_upload_const(s, &sv.pm_ptr, pm_ptr))) return rc;
-  if ((rc = s_upload_const(s, &sv.pm_list, pm_list))) return rc;
-  if ((rc = s_upload_const(s, &sv.tp_dst, tp_dst))) return rc;
-  if ((rc = s_upload_const(s, &sv.tp_trans, tp_trans))) return rc;
-  if ((rc = s_upload_const(s, &sv.tp_add, tp_add))) return rc;
+  up.upload_const(&sv.chunk_tp, chunk_tp);
+  up.upload_const(&sv.chunk_e0, chunk_e0);
+  up.upload_const(&sv.tp_chunk0, tp_chunk0);
+  up.upload_const(&sv.tp_chunk_list, tp_chunk_list);
+  up.upload_const(&sv.chunk_n, chunk_n);
+  up.upload_const(&sv.pm_ptr, pm_ptr);
+  up.upload_const(&sv.pm_list, pm_list);
+  up.upload_const(&sv.tp_dst, tp_dst);
+  up.upload_const(&sv.tp_trans, tp_trans);
+  up.upload_const(&sv.tp_add, tp_add);
   if ((rc = s_alloc(s, &sv.schur_part, (size_t)std::max(sv.nchunk, 1) * (kTile * kTile + kTile)))) return rc;
-  if ((rc = s_upload(s, &s->d_upd, s->upd))) return rc;
+  up.upload(&s->d_upd, s->upd);
   // the write-once cells of the persistent Cholesky driver — factor tiles | partial tiles | W | z, y | published X — live in ONE
   // allocation: one memset re-arms them before a launch (five launches before)
   {
@@ -748,23 +854,24 @@ int32_t build_solver(rsba_handle* h) {
     double* cells = s->cells[0];
     sv.Lf = cells; sv.chol_part = cells + nLf; sv.Winv = sv.chol_part + nPart; sv.zv = sv.Winv + nW; sv.yv = sv.zv + sv.npad; sv.Xpub = sv.zv + nZ;
   }
-  if ((rc = s_upload(s, &s->d_tasks, s->tasks))) return rc;
+  up.upload(&s->d_tasks, s->tasks);
   if ((rc = s_alloc(s, &s->d_dag_sync, 4))) return rc;
-  if ((rc = s_upload(s, &s->d_diag_info, s->diag_info))) return rc;
-  if ((rc = s_upload(s, &s->d_diag_ptr, s->diag_ptr))) return rc;
-  if ((rc = s_upload(s, &s->d_diag_list, s->diag_list))) return rc;
-  if ((rc = s_upload(s, &s->d_sub_info, s->sub_info))) return rc;
-  if ((rc = s_upload(s, &s->d_sub_ptr, s->sub_ptr))) return rc;
-  if ((rc = s_upload(s, &s->d_sub_list, s->sub_list))) return rc;
-  if ((rc = s_upload(s, &s->d_sub_col, s->sub_col))) return rc;
-  if ((rc = s_upload(s, &s->d_diag_own, s->diag_own))) return rc;
-  if ((rc = s_upload(s, &s->d_diag_fuse, s->diag_fuse))) return rc;
-  if ((rc = s_upload(s, &s->d_sub_pub, s->sub_pub))) return rc;
-  if ((rc = s_upload(s, &s->d_sub_own, s->sub_own))) return rc;
-  if ((rc = s_upload(s, &s->d_back_info, s->back_info))) return rc;
-  if ((rc = s_upload(s, &s->d_back_ptr, s->back_ptr))) return rc;
-  if ((rc = s_upload(s, &s->d_back_list, s->back_list))) return rc;
+  up.upload(&s->d_diag_info, s->diag_info);
+  up.upload(&s->d_diag_ptr, s->diag_ptr);
+  up.upload(&s->d_diag_list, s->diag_list);
+  up.upload(&s->d_sub_info, s->sub_info);
+  up.upload(&s->d_sub_ptr, s->sub_ptr);
+  up.upload(&s->d_sub_list, s->sub_list);
+  up.upload(&s->d_sub_col, s->sub_col);
+  up.upload(&s->d_diag_own, s->diag_own);
+  up.upload(&s->d_diag_fuse, s->diag_fuse);
+  up.upload(&s->d_sub_pub, s->sub_pub);
+  up.upload(&s->d_sub_own, s->sub_own);
+  up.upload(&s->d_back_info, s->back_info);
+  up.upload(&s->d_back_ptr, s->back_ptr);
+  up.upload(&s->d_back_list, s->back_list);
 
+  HIP_TRY(up.finish());
   tick("uploads");
   const size_t REC = 2 + 2 * (size_t)dp.K;
   h->dp.obs_slot = s->d_obs_slot;
@@ -869,10 +976,7 @@ int32_t build_solver(rsba_handle* h) {
     HIP_TRY(hipMemset(s->d_trace, 0, 8 * (size_t)pl.ntasks * sizeof(long long)));
   }
   pl.trace = s->d_trace;
-  if (std::getenv("RSBA_DEBUG_PLAN"))
-    tick("allocations");
-  if (dbg_plan)
-    std::fprintf(stderr, "[rsba plan] host phases:%s\n", phases.c_str());
+  tick("allocations");
   if (dbg_plan)
     std::fprintf(stderr, "[rsba plan] tiles %d, factor tiles %d, levels %d, tasks %d (partials %d); tile pairs %d, entries %lld, schur chunks %d\n", nt, sv.nslots,
                  s->nlev, pl.ntasks, parts, sv.ntp, (long long)s->num_pairs, sv.nchunk);
@@ -909,19 +1013,10 @@ int32_t build_solver(rsba_handle* h) {
     rsba_plan_stats& ps = s->stats;
     ps.tiles = nt; ps.factor_tiles = sv.nslots; ps.levels = s->nlev; ps.tasks = pl.ntasks;
     ps.schur_entries = nent; ps.schur_chunks = sv.nchunk;
-    // block products of the Schur complement that are not structurally zero: per entry (frames present on the I side) x (on the J side)
-    // (frames present per group, then one pass over the entries on the threads of the entry passes: this used to be 5 ms of one thread at 1k cameras)
-    std::vector<uint8_t> present((size_t)sv.ngroups, 0);
-    for (int64_t gq = 0; gq < sv.ngroups; ++gq) for (int x = 0; x < FT; ++x) present[gq] += g_rows[(size_t)gq * FT + x] != (int32_t)NS;
-    std::vector<int64_t> part((size_t)nthreads, 0);
-    auto count = [&](int t) {
-      int64_t prod = 0;
-      for (int64_t e = nent * t / nthreads; e < nent * (t + 1) / nthreads; ++e) prod += (int64_t)present[ent_groups[2 * (size_t)e]] * present[ent_groups[2 * (size_t)e + 1]];
-      part[t] = prod;
-    };
-    if (nthreads > 1) { std::vector<std::thread> pool; for (int t = 0; t < nthreads; ++t) pool.emplace_back(count, t); for (auto& th : pool) th.join(); } else count(0);
+    // block products of the Schur complement that are not structurally zero: per entry (frames present on the I side) x (on the J side),
+    // summed in the pass that forms the entries' block masks
     ps.schur_block_products = 0;
-    for (int64_t v : part) ps.schur_block_products += v;
+    for (int64_t v : products_part) ps.schur_block_products += v;
     // tile factorisation: per DIAG item its contributors (lower half of L L^T: T^3 each) + potrf and inverse (T^3 / 3 each);
     // per SUB item 2 T^3 per contributor + the product with W (T^3); forward / backward solve 2 T^2 per factor tile, twice
     const int64_t T3 = (int64_t)kTile * kTile * kTile;
@@ -930,7 +1025,10 @@ int32_t build_solver(rsba_handle* h) {
     ps.exchange_doubles = (int64_t)sv.nslots * kTile * kTile + sv.npad;
     ps.schur_groups = sv.ngroups;
   }
+  tick("statistics");
   HIP_TRY(hipStreamSynchronize(h->stream));   // the plan's one-time fills and scatters are done whatever stream the solves will run on
+  tick("device fills");
+  if (dbg_plan) std::fprintf(stderr, "[rsba plan] host phases:%s\n", phases.c_str());
   return RSBA_OK;
 }
 
@@ -1117,6 +1215,11 @@ int32_t factor_and_solve(rsba_handle* h, double radius, RatioStep* ratio = nullp
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 }  // namespace
+
+void rsba_release_plan_scratch() {
+  std::lock_guard<std::mutex> lk(g_plan_scratch_mutex);
+  g_plan_scratch.reset();
+}
 
 void rsba_destroy_solver(rsba_handle* h) {
   if (!h || !h->solver) return;

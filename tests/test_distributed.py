@@ -13,26 +13,27 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_two_ranks(mode, outdir):
+def run_two_ranks(mode, outdir, world=2):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"), mode, str(outdir)],
                        capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    return [json.load(open(os.path.join(outdir, f"rank{k}.json"))) for k in range(2)]
+    return [json.load(open(os.path.join(outdir, f"rank{k}.json"))) for k in range(world)]
 
 
-def test_sharding_and_exchange_payloads_gloo(tmp_path, oracle):
-    res = run_two_ranks("cpu", tmp_path)
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharding_and_exchange_payloads_gloo(tmp_path, oracle, world):
+    res = run_two_ranks("cpu", tmp_path, world)
     for o in res:
-        assert o["world"] == 2
+        assert o["world"] == world
         assert o["n_sum"] == o["n_full"] and o["max_owners_per_point"] == 1
         assert o["U_err"] <= 1e-13 and o["gc_err"] <= 1e-13 and o["cost_err"] <= 1e-13
         assert o["V_err"] <= 1e-15 and o["V_foreign"] == 0.0
         assert o["mask_equal"] and o["count_equal"]
-    assert res[0]["n_shard"] + res[1]["n_shard"] == res[0]["n_full"]
+    assert sum(o["n_shard"] for o in res) == res[0]["n_full"] and all(o["n_shard"] > 0 for o in res)
 
 
 @pytest.mark.gpu
@@ -49,6 +50,20 @@ def test_sharded_solve_equals_single_gpu_solve(tmp_path, mode):
     assert a["pose_err"] <= 1e-7 and a["point_err"] <= 1e-6
     assert a["ratio"] == b["ratio"] and abs(a["ratio"] - a["ref_ratio"]) <= 1e-8
     assert (mode == "gpu_free_ratio") == (a["ratio"] not in (1.0, 1.2))
+
+
+@pytest.mark.gpu
+def test_sharded_solve_on_four_ranks_equals_single_gpu_solve(tmp_path):
+    """world_size 4 (four ranks share GPU 0, the exchange staged through gloo): a quarter of the points per rank, three
+    all-reduces per LM iteration over four contributors — the ranks decide identically and land on the single-GPU solve."""
+    res = run_two_ranks("gpu", tmp_path, 4)
+    a = res[0]
+    for o in res[1:]:
+        assert o["final_cost"] == a["final_cost"] and o["iters"] == a["iters"] and o["ratio"] == a["ratio"]
+    assert all(o["native_merge_equals_host_merge"] for o in res)
+    assert a["iters"] == a["ref_iters"] and a["reduced"] == a["ref_reduced"] and a["params"] == a["ref_params"]
+    assert a["traj_err"] <= 1e-9 and abs(a["final_cost"] - a["ref_final"]) <= 1e-9 * a["ref_final"]
+    assert a["pose_err"] <= 1e-7 and a["point_err"] <= 1e-6
 
 
 @pytest.mark.gpu

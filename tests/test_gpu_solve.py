@@ -351,3 +351,29 @@ def test_one_pose_frames_inside_a_rolling_shutter_session(capi, oracle):
     assert abs(s.final_cost - s_ref.final_cost) <= 1e-6 * s_ref.final_cost
     assert np.array_equal(pd.poses[p.frame_global == 1, 1], p.poses[p.frame_global == 1, 1])      # untouched
     assert np.max(np.abs(pd.poses - pc.poses)) <= 1e-5
+
+
+def test_fresh_handles_share_the_plan_scratch_and_plan_alike(capi):
+    """The symbolic phase's host scratch outlives a handle (a fresh handle per call is windowedBA's pattern, VideoSfMHandler.cc:185-214):
+    a big problem, a smaller one in the scratch the big one left, the big one again, and once more after rsba_release_host_scratch —
+    every plan and every solve must come out as from a first-ever handle (no stale entries from the previous problem's arrays)."""
+    big, small = small_scene(frames=40, points=6000, seed=5), small_scene(frames=14, points=500, seed=6)
+    opt = capi.default_options(max_num_iterations=6)
+
+    def run(p):
+        q = p.copy()
+        with capi.DeviceProblem(q) as dp:
+            st = dp.plan_stats()
+            s, tr = dp.solve(opt)
+        return tuple(st[k] for k in ("tiles", "factor_tiles", "tasks", "schur_entries", "schur_chunks", "schur_block_products", "schur_groups")), [t.cost for t in tr], q.poses, q.points
+
+    first_big, first_small = run(big), None
+    capi.release_host_scratch()
+    first_small = run(small)                      # (a first-ever plan of the small one)
+    for p, ref in ((big, first_big), (small, first_small), (big, first_big)):
+        got = run(p)
+        assert got[0] == ref[0] and got[1] == ref[1]
+        assert np.array_equal(got[2], ref[2]) and np.array_equal(got[3], ref[3])
+    capi.release_host_scratch()
+    got = run(big)
+    assert got[0] == first_big[0] and got[1] == first_big[1] and np.array_equal(got[3], first_big[3])
