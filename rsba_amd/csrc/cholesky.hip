@@ -1141,6 +1141,86 @@ __global__ __launch_bounds__(256, 2) void chol_dag_kernel(const DagArgs* __restr
   }
 }
 
+// ---- one more right-hand side through a finished factorisation -----------------------------------------------------
+// S v = b2 with the factor tiles and the W_j the last solve left (the free interFrameRatio's border column, the columns of a
+// covariance block): forward tasks z_j = W_j (b2_j - sum_k L_jk z_k) in the order of the DIAG items, then the BACK tasks of the
+// factorisation on z2 / y2 — one persistent launch over write-once z / y cells of its own, no tile product anywhere.  It used to be a
+// second factorisation (0.76 ms at 1k cameras for 0.1 ms of substitutions).
+__device__ __forceinline__ void task_forward(const SolverDev& sv, const CholPlan& pl, int d, const double* __restrict__ b2, double* z2, double* smem, int tid) {
+  double* zb = smem;            // [5][T] z of the five contributors of a step
+  double* sp = smem + 5 * T;    // [5][T] partial sums
+  double* tv = smem + 10 * T;   // [T]
+  const int g = tid / T, r = tid % T;   // five groups of T threads, a row each; group g takes contributors p0 + g, p0 + g + 5, ..
+  const bool worker = g < 5;
+  const int tile_j = gl(pl.diag_info + 4 * d + 1);
+  const int p0 = gl(pl.diag_ptr + d), p1 = gl(pl.diag_ptr + d + 1);
+  double w[T];
+  if (tid < T) {
+    const double* Wg = sv.Winv + (size_t)tile_j * (T * T) + (size_t)r * T;
+#pragma unroll
+    for (int c = 0; c < T; ++c) w[c] = gl(Wg + c);   // (zeros right of the diagonal)
+  }
+  double s = 0.0;
+  for (int p = p0; p < p1; p += 5) {
+    const int q = p + g;
+    const bool has = worker && q < p1;
+    double lrow[T];
+    if (has) {
+      const double* Lp = factor_ptr(sv, gl(pl.diag_list + 2 * q)) + (size_t)r * T;
+#pragma unroll
+      for (int c = 0; c < T; ++c) lrow[c] = gl(Lp + c);
+      const double* zk = z2 + (size_t)gl(pl.diag_list + 2 * q + 1) * T + r;
+      double z = ld<true>(zk);
+      while (!filled(z)) { __builtin_amdgcn_s_sleep(2); z = ld<true>(zk); }
+      zb[g * T + r] = z;
+    }
+    lds_barrier();
+    if (has) {
+#pragma unroll
+      for (int c = 0; c < T; ++c) s += lrow[c] * zb[g * T + c];
+    }
+    lds_barrier();
+  }
+  if (worker) sp[g * T + r] = s;
+  lds_barrier();
+  if (tid < T) {
+    double t = gl(b2 + (size_t)tile_j * T + r);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) t -= sp[k * T + r];
+    tv[r] = t;
+  }
+  lds_barrier();
+  if (tid < T) {
+    double z = 0.0;
+#pragma unroll
+    for (int c = 0; c < T; ++c) z += w[c] * tv[c];
+    st<true>(z2 + (size_t)tile_j * T + r, z);
+  }
+}
+
+__global__ __launch_bounds__(256) void chol_solve_kernel(const DagArgs* __restrict__ args, const double* __restrict__ b2, double* zy2, unsigned int* ticket) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  __shared__ int s_ticket;
+  const int tid = threadIdx.x;
+  const CholPlan& pl = args->pl;
+  const int nd = pl.ndiag;
+  for (;;) {
+    lds_barrier();
+    if (tid == 0) { s_ticket = (int)__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_trace_slot = nullptr; }
+    lds_barrier();
+    const int t = s_ticket;
+    if (t >= 2 * nd) return;
+    int task_tid = tid;
+    asm volatile("" : "+v"(task_tid));
+    if (t < nd) task_forward(args->sv, pl, t, b2, zy2, smem, task_tid);
+    else {
+      SolverDev sv2 = args->sv;
+      sv2.zv = zy2; sv2.yv = zy2 + sv2.npad;
+      task_back<true>(sv2, pl, gl(pl.tasks + 2 * (pl.ntasks - 2 * nd + t) + 1), smem, task_tid);   // (the BACK tasks close the task list, in their order)
+    }
+  }
+}
+
 // ---- verification of the persistent driver's result -------------------------------------------------------------
 // The task-DAG kernel has no safety net inside: its hand-offs are write-once cells found by polling.  What it returns is
 // therefore checked against the system it was asked to solve: res = rhs - S y over the packed tiles (S symmetric, lower
@@ -1209,6 +1289,19 @@ hipError_t launch_chol_level(const SolverDev& sv, const CholPlan& pl, int kind, 
   hipError_t e = allow_dynamic_lds(chol_level_kernel, kCholLds * sizeof(double));
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(chol_level_kernel, dim3(count), dim3(256), kCholLds * sizeof(double), st, sv, pl, kind, first);
+  return hipGetLastError();
+}
+
+// zy2: [2][npad] doubles (z | y of this right-hand side; y = the solution), ticket: one counter of the caller's
+hipError_t launch_chol_solve(const SolverDev& sv, const CholPlan& pl, const DagArgs* device_args, const double* b2, double* zy2, unsigned int* ticket, int workgroups, hipStream_t st) {
+  if (pl.ndiag <= 0) return hipSuccess;
+  hipError_t e = allow_dynamic_lds(chol_solve_kernel, (size_t)84 * 1024);   // (one workgroup per CU, as the factorisation: polling waves do not share SIMDs with the waves they wait for)
+  if (e != hipSuccess) return e;
+  e = hipMemsetAsync(zy2, 0xFF, 2 * (size_t)sv.npad * sizeof(double), st);
+  if (e != hipSuccess) return e;
+  e = hipMemsetAsync(ticket, 0, sizeof(unsigned int), st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(chol_solve_kernel, dim3(workgroups), dim3(256), (size_t)84 * 1024, st, device_args, b2, zy2, ticket);
   return hipGetLastError();
 }
 

@@ -95,6 +95,7 @@ struct Solver {
   hipStream_t mstream = nullptr; hipEvent_t ev_armed[2] = {nullptr, nullptr}, ev_released = nullptr; bool arm_pending[2] = {false, false};
   int64_t schur_launches = 0;                                         // launches of the Schur kernel since the plan was built (statistics)
   int num_reduced_blocks = 0, num_reduced_params = 0, num_priors_reduced = 0;
+  double* zy2 = nullptr;                                              // [2][npad] z | y of one more right-hand side through the last factorisation (solve_again)
   double* border = nullptr, *ubuf = nullptr, *ratio4 = nullptr;      // free interFrameRatio: its column of S [npad], the first solve's result, {h, g, b.u, b.v}
   PosePriorDev pp{};                                                  // per-pose priors: linearisation of the priorPoses coordinates
   double* merge_buf = nullptr;                                        // sharded solve: [4 M] owned point values | owner flags
@@ -856,6 +857,7 @@ int32_t build_solver(rsba_handle* h) {
   }
   up.upload(&s->d_tasks, s->tasks);
   if ((rc = s_alloc(s, &s->d_dag_sync, 4))) return rc;
+  if ((rc = s_alloc(s, &s->zy2, 2 * (size_t)sv.npad))) return rc;
   up.upload(&s->d_diag_info, s->diag_info);
   up.upload(&s->d_diag_ptr, s->diag_ptr);
   up.upload(&s->d_diag_list, s->diag_list);
@@ -960,7 +962,7 @@ int32_t build_solver(rsba_handle* h) {
   pl.sub_info = s->d_sub_info; pl.sub_ptr = s->d_sub_ptr; pl.sub_list = s->d_sub_list; pl.sub_col = s->d_sub_col; pl.diag_own = s->d_diag_own; pl.sub_own = s->d_sub_own;
   pl.diag_fuse = s->d_diag_fuse; pl.sub_pub = s->d_sub_pub;
   pl.back_info = s->d_back_info; pl.back_ptr = s->d_back_ptr; pl.back_list = s->d_back_list;
-  pl.tasks = s->d_tasks; pl.ntasks = (int)(s->tasks.size() / 2);
+  pl.tasks = s->d_tasks; pl.ntasks = (int)(s->tasks.size() / 2); pl.ndiag = (int)(s->diag_info.size() / 4);
   pl.ticket = s->d_dag_sync;
   pl.nslots = sv.nslots; pl.nparts = parts;
   int cus = 0;
@@ -1184,9 +1186,26 @@ int32_t solve_reduced_system(rsba_handle* h) {
   return RSBA_OK;
 }
 
+// S v = b2 for one more right-hand side, through the factor tiles the last solve_reduced_system left: forward and backward
+// substitution only (cholesky.hip chol_solve_kernel).  *v_out points at the solution ([npad], valid until the next call).  The result
+// is checked like the first one (same sticky flag), here on the solver's own stream: the check is 20 us, the solve 0.2 ms.
+int32_t solve_again(rsba_handle* h, const double* b2, const double** v_out) {
+  Solver* s = h->solver; const SolverDev& sv = s->sv; hipStream_t st = h->stream;
+  PhaseScope ps(h, RSBA_PHASE_CHOLESKY);
+  HIP_TRY(launch_chol_solve(sv, s->plan, s->d_dag_args, b2, s->zy2, s->d_dag_sync + 2, s->dag_workgroups, st));
+  *v_out = s->zy2 + sv.npad;
+  if (!s->use_levels && s->verify_dag) {
+    if (int32_t rc = await_verification(h)) return rc;   // (the accumulators of the check are shared)
+    SolverDev sv2 = sv;
+    sv2.yv = s->zy2 + sv.npad;
+    HIP_TRY(launch_chol_verify(sv2, s->d_slot_tiles, b2, s->d_verify, s->d_verify + sv.npad, 1e-7, sv.scalars + kDagSuspect, st));
+  }
+  return RSBA_OK;
+}
+
 // ratio (free interFrameRatio only): in {h_s + D/radius, g_s, scale of the ratio}, out the ratio's scaled step eta.
 // The ratio's column b of the damped normal equations is a 1-wide dense border of S:  S u = g, S v = b,
-// eta = (g_s - s b.u) / (h_s + D - s^2 b.v),  y = u - (s eta) v  — two solves through the factorisation.
+// eta = (g_s - s b.u) / (h_s + D - s^2 b.v),  y = u - (s eta) v  — two right-hand sides through ONE factorisation.
 struct RatioStep { double diag, gs, scale, eta; };
 int32_t factor_and_solve(rsba_handle* h, double radius, RatioStep* ratio = nullptr) {
   Solver* s = h->solver; const SolverDev& sv = s->sv; hipStream_t st = h->stream;
@@ -1194,16 +1213,14 @@ int32_t factor_and_solve(rsba_handle* h, double radius, RatioStep* ratio = nullp
   if (rc) return rc;
   if ((rc = solve_reduced_system(h))) return rc;
   if (ratio) {
-    const size_t bytes = (size_t)sv.npad * sizeof(double);
-    HIP_TRY(hipMemcpyAsync(s->ubuf, sv.yv, bytes, hipMemcpyDeviceToDevice, st));
-    HIP_TRY(hipMemcpyAsync(sv.rhs, s->border, bytes, hipMemcpyDeviceToDevice, st));
-    if ((rc = solve_reduced_system(h))) return rc;                       // yv = v
-    HIP_TRY(launch_border_dots(s->border, s->ubuf, sv.yv, sv.npad, s->ratio4 + 2, st));
+    const double* v = nullptr;
+    if ((rc = solve_again(h, s->border, &v))) return rc;                 // sv.yv = u stays where it is
+    HIP_TRY(launch_border_dots(s->border, sv.yv, v, sv.npad, s->ratio4 + 2, st));
     double dots[2];
     HIP_TRY(hipMemcpyAsync(dots, s->ratio4 + 2, sizeof dots, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     ratio->eta = (ratio->gs - ratio->scale * dots[0]) / (ratio->diag - ratio->scale * ratio->scale * dots[1]);
-    HIP_TRY(launch_border_combine(sv.rhs, s->ubuf, sv.yv, ratio->scale * ratio->eta, sv.npad, st));
+    HIP_TRY(launch_border_combine(sv.rhs, sv.yv, v, ratio->scale * ratio->eta, sv.npad, st));
   } else {
     HIP_TRY(hipMemcpyAsync(sv.rhs, sv.yv, (size_t)sv.npad * sizeof(double), hipMemcpyDeviceToDevice, st));   // camera step
   }
@@ -1398,18 +1415,20 @@ extern "C" int32_t rsba_pose_covariance(rsba_handle* h, int32_t frame, double* c
   for (int k = 0; k < CD; ++k) {
     HIP_TRY(hipMemsetAsync(sv.rhs, 0, (size_t)sv.npad * sizeof(double), st));
     HIP_TRY(hipMemcpyAsync(sv.rhs + (size_t)frame * CD + k, &one, sizeof(double), hipMemcpyHostToDevice, st));
-    if ((rc = solve_reduced_system(h))) return rc;
-    HIP_TRY(hipMemcpyAsync(&col[(size_t)k * CD], sv.yv + (size_t)frame * CD, (size_t)CD * sizeof(double), hipMemcpyDeviceToHost, st));
+    const double* y = sv.yv;
+    if (k == 0) { if ((rc = solve_reduced_system(h))) return rc; y = sv.yv; }   // the factorisation, once; every other column is a pair of substitutions
+    else if ((rc = solve_again(h, sv.rhs, &y))) return rc;
+    HIP_TRY(hipMemcpyAsync(&col[(size_t)k * CD], y + (size_t)frame * CD, (size_t)CD * sizeof(double), hipMemcpyDeviceToHost, st));
   }
   // A free interFrameRatio is one more parameter block of J^T J, coupled to every pose through its column b (the 1-wide
   // border of the reduced system, diagonal entry h): by the block inverse the pose block of the bordered system is
   // S^-1 + v v^T / (h - b.v) with S v = b — what ceres::Covariance returns for the problem CeresHandler builds by default.
   if (s->border) {
-    HIP_TRY(hipMemcpyAsync(sv.rhs, s->border, (size_t)sv.npad * sizeof(double), hipMemcpyDeviceToDevice, st));
-    if ((rc = solve_reduced_system(h))) return rc;
-    HIP_TRY(launch_border_dots(s->border, sv.yv, sv.yv, sv.npad, s->ratio4 + 2, st));
+    const double* v = nullptr;
+    if ((rc = solve_again(h, s->border, &v))) return rc;
+    HIP_TRY(launch_border_dots(s->border, v, v, sv.npad, s->ratio4 + 2, st));
     vf.resize(CD);
-    HIP_TRY(hipMemcpyAsync(vf.data(), sv.yv + (size_t)frame * CD, (size_t)CD * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(vf.data(), v + (size_t)frame * CD, (size_t)CD * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(hb, s->ratio4, sizeof hb, hipMemcpyDeviceToHost, st));     // {h, g, b.v}
   }
   double suspect = 0.0;

@@ -123,6 +123,7 @@ struct CholPlan {
   const int32_t *upd, *diag_info, *diag_ptr, *diag_list, *sub_info, *sub_ptr, *sub_list, *sub_col, *diag_own, *sub_own, *back_info, *back_ptr, *back_list;
   const int32_t* diag_fuse;  // per DIAG item: the SUB item of its last contributor, whose product with W the DIAG task forms itself (-1: none)
   const int32_t* sub_pub;    // per SUB item: DIAG item that takes its X = S_ij - updates from sv.Xpub (-1: nobody)
+  int ndiag;                 // DIAG items = columns (the last ndiag tasks are the BACK tasks)
   const int32_t* tasks;      // [ntasks][2] {kind, item} in a topological order
   int ntasks;
   unsigned int* ticket;
@@ -153,6 +154,7 @@ hipError_t launch_chol_level(const SolverDev& sv, const CholPlan& pl, int kind, 
 // b_rhs: the right-hand side the system was solved for (a private copy: the caller overwrites sv.rhs with the step while the check runs on its own stream)
 hipError_t launch_chol_verify(const SolverDev& sv, const int32_t* slot_tiles, const double* b_rhs, double* res, double* den, double tol, double* flag, hipStream_t st);
 struct DagArgs { SolverDev sv; CholPlan pl; };   // device copy the persistent kernel reads its state through (uploaded once per plan)
+hipError_t launch_chol_solve(const SolverDev& sv, const CholPlan& pl, const DagArgs* device_args, const double* b2, double* zy2, unsigned int* ticket, int workgroups, hipStream_t st);   // one more right-hand side through the factor of the last launch_chol_dag / level run
 hipError_t launch_chol_dag(const SolverDev& sv, const CholPlan& pl, const DagArgs* device_args, int workgroups, bool one_per_cu, hipStream_t st);   // one_per_cu: LDS request above half a CU's, so that two never share one
 
 // kernels_normal.hip
