@@ -1,7 +1,7 @@
 // solveRsPnPRansac over the C++ mirror (include/rsba/solve_rs_pnp.hpp): reads a flat problem file, writes the result.
 // Used by tests/test_facade.py to check the whole RANSAC flow (host subsets + batched device hypotheses + selection +
 // final refinement) against a sequential replay through the oracle.
-//   in  (binary, little endian): int32 n, shutter, scan0, scan1, iterations, minInliers, minPoints; float reprojError;
+//   in  (binary, little endian): int32 n, shutter, scan0, scan1, iterations (0: solveRsPnP, -1: the DLT of the GS initialisation only), minInliers, minPoints; float reprojError;
 //        uint64 rngState; double cam[9], rvec[3], tvec[3], rvec2[3], tvec2[3]; float opoints[n*3], ipoints[n*2]
 //   out: double rvec[3], tvec[3], rvec2[3], tvec2[3]; int32 numInliers, inliers[numInliers]
 //   g++ -std=c++17 -O2 -Iinclude examples/pnp_ransac.cpp -Lrsba_amd/_lib -lrsba_amd -Wl,-rpath,... -o pnp_ransac
@@ -28,6 +28,16 @@ int main(int argc, char** argv) {
   const int scan[2] = {hd[2], hd[3]};
   std::vector<int> inliers;
   try {
+    if (hd[4] == -1) {  // iterations -1: the direct linear transform of the global-shutter initialisation alone (host glue; no device)
+      const std::vector<double> nrm = pnp_detail::normalised_points(cam, ip.data(), n);
+      std::vector<int32_t> all((size_t)n);
+      for (int i = 0; i < n; ++i) all[(size_t)i] = i;
+      double pose[6];
+      if (!pnp_detail::dlt_pose(op.data(), nrm.data(), all.data(), n, pose)) inliers.assign(1, -1);
+      else { pnp_detail::from_pose(pose, v, v + 3); pnp_detail::from_pose(pose, v + 6, v + 9); }
+    } else if (hd[4] == 0) {   // iterations 0: the single solve (solveRsPnP); -1 inliers = the solution is not usable
+      if (!solveRsPnP(op.data(), ip.data(), n, cam, v, v + 3, v + 6, v + 9, (SHUTTER)hd[1], scan)) inliers.assign(1, -1);
+    } else
     solveRsPnPRansac(op.data(), ip.data(), n, cam, v, v + 3, v + 6, v + 9, (SHUTTER)hd[1], scan, hd[4], err, hd[5], &inliers, hd[6], state);
   } catch (const std::exception& e) {
     std::fprintf(stderr, "%s\n", e.what());

@@ -9,9 +9,13 @@
 // (cv::RNG's multiply-with-carry, restated) walked in the same order, and the winner is chosen by replaying the
 // reference's sequential rule (first strictly better hypothesis wins, stop once minInliersCount is reached) over the
 // batch's inlier counts, so the result is the one the single-threaded reference would return for these subsets.
-// Not provided: the global-shutter initialisation through cv::solvePnP / cv::solvePnPRansac when all four vectors
-// are zero (:111-117, :437-449) — the caller passes an initial guess (std::invalid_argument otherwise).
-// Everything numeric is computed by librsba_amd; a missing device throws std::runtime_error.
+// The global-shutter initialisation the reference takes from OpenCV when all four vectors are zero (cv::solvePnP, :111-117;
+// cv::solvePnPRansac, :437-449) is provided natively, in OpenCV's own shape (SOLVEPNP_ITERATIVE = a direct linear transform
+// followed by a Levenberg-Marquardt refinement of the reprojection error): the DLT of the undistorted, normalised image points is
+// glue on this side (a 12 x 12 symmetric eigenproblem); the refinement, and for the RANSAC form the refinement and inlier count of
+// every sampled hypothesis, run on the device through the same rsba_pnp_tasks with shutter GLOBAL — one launch.  OpenCV's sampling
+// order cannot be replayed without OpenCV, so this half is functionally, not bitwise, the reference's.
+// Everything numeric that decides a result is computed by librsba_amd; a missing device throws std::runtime_error.
 #pragma once
 #include <cmath>
 #include <cstdint>
@@ -68,17 +72,162 @@ struct Rng {
   int uniform(int a, int b) { return a == b ? a : (int)(next() % (unsigned)(b - a) + a); }
 };
 
+// ---- global-shutter initialisation (what cv::solvePnP(ITERATIVE) starts from): direct linear transform ----
+// sfm intrinsics (mat/cam.h:33): fx, fy, k1, k2, p1, p2, k3, cx, cy
+inline void normalised_point(const double cam[NUM_CAM_PARAMS], double u, double v, double out[2]) {
+  const double pn[2] = {(u - cam[7]) / cam[0], (v - cam[8]) / cam[1]};
+  double pu[2] = {pn[0], pn[1]};
+  for (int it = 0; it < 20; ++it) {   // the fixed-point undistortion of mat/cam.h:77-112, a few steps of it
+    const double x = pu[0], y = pu[1], r2 = x * x + y * y, d = 1.0 + r2 * (cam[2] + r2 * (cam[3] + r2 * cam[6])), xy = x * y;
+    const double dx = d * x + 2.0 * cam[4] * xy + cam[5] * (r2 + 2.0 * x * x), dy = d * y + cam[4] * (r2 + 2.0 * y * y) + 2.0 * cam[5] * xy;
+    pu[0] -= dx - pn[0]; pu[1] -= dy - pn[1];
+  }
+  out[0] = pu[0]; out[1] = pu[1];
+}
+// eigenvector of the smallest eigenvalue of a symmetric 12 x 12 matrix (cyclic Jacobi)
+inline void smallest_eigenvector12(double a[12][12], double vec[12]) {
+  double v[12][12] = {};
+  for (int i = 0; i < 12; ++i) v[i][i] = 1.0;
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0.0;
+    for (int i = 0; i < 12; ++i) for (int j = i + 1; j < 12; ++j) off += a[i][j] * a[i][j];
+    if (off < 1e-30) break;
+    for (int p_ = 0; p_ < 12; ++p_) for (int q = p_ + 1; q < 12; ++q) {
+      if (std::fabs(a[p_][q]) < 1e-300) continue;
+      const double theta = (a[q][q] - a[p_][p_]) / (2.0 * a[p_][q]);
+      const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0)), c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+      for (int k = 0; k < 12; ++k) { const double akp = a[k][p_], akq = a[k][q]; a[k][p_] = c * akp - sn * akq; a[k][q] = sn * akp + c * akq; }
+      for (int k = 0; k < 12; ++k) { const double apk = a[p_][k], aqk = a[q][k]; a[p_][k] = c * apk - sn * aqk; a[q][k] = sn * apk + c * aqk; }
+      for (int k = 0; k < 12; ++k) { const double vkp = v[k][p_], vkq = v[k][q]; v[k][p_] = c * vkp - sn * vkq; v[k][q] = sn * vkp + c * vkq; }
+    }
+  }
+  int best = 0;
+  for (int i = 1; i < 12; ++i) if (a[i][i] < a[best][best]) best = i;
+  for (int k = 0; k < 12; ++k) vec[k] = v[k][best];
+}
+// rsba pose (angle-axis world->camera, camera centre) from >= 6 correspondences idx[0..m): false when the points are degenerate
+inline bool dlt_pose(const float* opoints, const double* normalised, const int32_t* idx, int m, double pose[6]) {
+  if (m < 6) return false;
+  double c[3] = {0, 0, 0}, scale = 0.0;
+  for (int i = 0; i < m; ++i) for (int k = 0; k < 3; ++k) c[k] += opoints[3 * (size_t)idx[i] + k] / m;
+  for (int i = 0; i < m; ++i) { double d2 = 0; for (int k = 0; k < 3; ++k) { const double d = opoints[3 * (size_t)idx[i] + k] - c[k]; d2 += d * d; } scale += std::sqrt(d2) / m; }
+  if (!(scale > 0.0)) return false;
+  double ata[12][12] = {};
+  for (int i = 0; i < m; ++i) {
+    const double X[4] = {(opoints[3 * (size_t)idx[i]] - c[0]) / scale, (opoints[3 * (size_t)idx[i] + 1] - c[1]) / scale, (opoints[3 * (size_t)idx[i] + 2] - c[2]) / scale, 1.0};
+    const double u = normalised[2 * (size_t)idx[i]], v = normalised[2 * (size_t)idx[i] + 1];
+    double r0[12] = {}, r1[12] = {};
+    for (int k = 0; k < 4; ++k) { r0[k] = X[k]; r0[8 + k] = -u * X[k]; r1[4 + k] = X[k]; r1[8 + k] = -v * X[k]; }
+    for (int a = 0; a < 12; ++a) for (int b = 0; b < 12; ++b) ata[a][b] += r0[a] * r0[b] + r1[a] * r1[b];
+  }
+  double pvec[12];
+  smallest_eigenvector12(ata, pvec);
+  double M[9], t[3];
+  for (int r = 0; r < 3; ++r) { for (int k = 0; k < 3; ++k) M[3 * r + k] = pvec[4 * r + k]; t[r] = pvec[4 * r + 3]; }
+  // the points must end up in front of the camera (z of the centroid = t[2] in the shifted frame)
+  if (t[2] < 0) { for (double& x : M) x = -x; for (double& x : t) x = -x; }
+  double lambda = 0.0;
+  for (int r = 0; r < 3; ++r) lambda += std::sqrt(M[3 * r] * M[3 * r] + M[3 * r + 1] * M[3 * r + 1] + M[3 * r + 2] * M[3 * r + 2]) / 3.0;
+  if (!(lambda > 1e-300) || !std::isfinite(lambda)) return false;
+  double R[9];
+  for (int k = 0; k < 9; ++k) R[k] = M[k] / lambda;
+  for (int it = 0; it < 30; ++it) {   // nearest rotation: R <- (R + R^-T) / 2
+    const double det = R[0] * (R[4] * R[8] - R[5] * R[7]) - R[1] * (R[3] * R[8] - R[5] * R[6]) + R[2] * (R[3] * R[7] - R[4] * R[6]);
+    if (!(std::fabs(det) > 1e-12)) return false;
+    const double it_[9] = {(R[4] * R[8] - R[5] * R[7]) / det, (R[5] * R[6] - R[3] * R[8]) / det, (R[3] * R[7] - R[4] * R[6]) / det,
+                           (R[2] * R[7] - R[1] * R[8]) / det, (R[0] * R[8] - R[2] * R[6]) / det, (R[1] * R[6] - R[0] * R[7]) / det,
+                           (R[1] * R[5] - R[2] * R[4]) / det, (R[2] * R[3] - R[0] * R[5]) / det, (R[0] * R[4] - R[1] * R[3]) / det};   // R^-T
+    for (int k = 0; k < 9; ++k) R[k] = 0.5 * (R[k] + it_[k]);
+  }
+  if (R[0] * (R[4] * R[8] - R[5] * R[7]) - R[1] * (R[3] * R[8] - R[5] * R[6]) + R[2] * (R[3] * R[7] - R[4] * R[6]) < 0) return false;
+  // x_cam ~ R (X - c) / scale + t / lambda  =>  tvec = scale t / lambda - R c (up to the common factor 1 / scale, which the projection ignores)
+  double tvec[3];
+  for (int r = 0; r < 3; ++r) tvec[r] = scale * t[r] / lambda - (R[3 * r] * c[0] + R[3 * r + 1] * c[1] + R[3 * r + 2] * c[2]);
+  // rotation matrix -> angle-axis
+  double rvec[3];
+  const double tr = R[0] + R[4] + R[8], cs = std::fmin(1.0, std::fmax(-1.0, 0.5 * (tr - 1.0))), th = std::acos(cs);
+  const double ax[3] = {R[7] - R[5], R[2] - R[6], R[3] - R[1]};
+  const double sn = 0.5 * std::sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+  if (sn > 1e-8) for (int k = 0; k < 3; ++k) rvec[k] = ax[k] * (th / (2.0 * sn));
+  else if (cs > 0) for (int k = 0; k < 3; ++k) rvec[k] = 0.5 * ax[k];
+  else {   // a half turn: the axis from the diagonal
+    const double d[3] = {std::sqrt(std::fmax(0.0, 0.5 * (R[0] + 1.0))), std::sqrt(std::fmax(0.0, 0.5 * (R[4] + 1.0))), std::sqrt(std::fmax(0.0, 0.5 * (R[8] + 1.0)))};
+    rvec[0] = th * d[0]; rvec[1] = th * d[1] * (R[1] + R[3] >= 0 ? 1.0 : -1.0); rvec[2] = th * d[2] * (R[2] + R[6] >= 0 ? 1.0 : -1.0);
+  }
+  to_pose(rvec, tvec, pose);
+  for (int k = 0; k < 6; ++k) if (!std::isfinite(pose[k])) return false;
+  return true;
+}
+inline std::vector<double> normalised_points(const double cam[NUM_CAM_PARAMS], const float* ipoints, int n) {
+  std::vector<double> out(2 * (size_t)n);
+  for (int i = 0; i < n; ++i) normalised_point(cam, ipoints[2 * (size_t)i], ipoints[2 * (size_t)i + 1], &out[2 * (size_t)i]);
+  return out;
+}
+
 }  // namespace pnp_detail
+
+// cv::solvePnP(..., SOLVEPNP_ITERATIVE) as the reference uses it at solveRSpnp.cpp:111-117: DLT over all points, then a
+// Levenberg-Marquardt refinement of the global-shutter reprojection error (on the device).  pose = rsba's 6-vector.
+inline bool solveGsPnP(const float* opoints, const float* ipoints, int n, const double cam[NUM_CAM_PARAMS], double pose[6], int device = 0) {
+  const std::vector<double> nrm = pnp_detail::normalised_points(cam, ipoints, n);
+  std::vector<int32_t> all((size_t)n);
+  for (int i = 0; i < n; ++i) all[(size_t)i] = i;
+  double init[12], out[12], cost = 0.0; uint8_t status = 0; int32_t inl = 0;
+  if (!pnp_detail::dlt_pose(opoints, nrm.data(), all.data(), n, init)) return false;
+  for (int k = 0; k < 6; ++k) init[6 + k] = init[k];
+  const int32_t sl[2] = {0, 1};
+  pnp_detail::check(rsba_pnp_tasks(device, cam, (int32_t)GLOBAL, sl, opoints, ipoints, n, all.data(), n, 1, init, 0, 20, 0, 0.0f, out, &status, &cost, &inl));
+  for (int k = 0; k < 6; ++k) pose[k] = status == 1 ? out[k] : init[k];
+  return true;
+}
+
+// cv::solvePnPRansac as the reference uses it at solveRSpnp.cpp:437-449: minimal subsets, a pose per subset, the pose with the most
+// points inside reprojectionError wins.  The subsets' DLT poses are refined and scored on the device in ONE launch.  Returns the
+// number of inliers of the winner (0: none found).
+inline int solveGsPnPRansac(const float* opoints, const float* ipoints, int n, const double cam[NUM_CAM_PARAMS], double pose[6], int iterationsCount,
+                            float reprojectionError, int min_points_count = 6, uint64_t rng_state = 0x9e3779b97f4a7c15ULL, int device = 0) {
+  const int m = min_points_count < 6 ? 6 : min_points_count;
+  if (n < m || iterationsCount <= 0) return 0;
+  const std::vector<double> nrm = pnp_detail::normalised_points(cam, ipoints, n);
+  pnp_detail::Rng gen(rng_state);
+  std::vector<int32_t> subsets; std::vector<double> inits;
+  std::vector<int32_t> pick((size_t)m);
+  for (int it = 0; it < iterationsCount; ++it) {
+    for (int k = 0; k < m;) {   // m distinct indices
+      const int c = gen.uniform(0, n); bool dup = false;
+      for (int j = 0; j < k; ++j) dup = dup || pick[(size_t)j] == c;
+      if (!dup) pick[(size_t)k++] = c;
+    }
+    double p[6];
+    if (!pnp_detail::dlt_pose(opoints, nrm.data(), pick.data(), m, p)) continue;
+    subsets.insert(subsets.end(), pick.begin(), pick.end());
+    inits.insert(inits.end(), p, p + 6); inits.insert(inits.end(), p, p + 6);
+  }
+  const int tasks = (int)(inits.size() / 12);
+  if (tasks == 0) return 0;
+  std::vector<double> poses((size_t)tasks * 12), cost((size_t)tasks);
+  std::vector<uint8_t> status((size_t)tasks);
+  std::vector<int32_t> count((size_t)tasks);
+  const int32_t sl[2] = {0, 1};
+  pnp_detail::check(rsba_pnp_tasks(device, cam, (int32_t)GLOBAL, sl, opoints, ipoints, n, subsets.data(), m, tasks, inits.data(), 12, 5, 0, reprojectionError,
+                                   poses.data(), status.data(), cost.data(), count.data()));
+  int best = -1;
+  for (int t = 0; t < tasks; ++t) if (status[(size_t)t] != 0 && (best < 0 || count[(size_t)t] > count[(size_t)best])) best = t;
+  if (best < 0) return 0;
+  for (int k = 0; k < 6; ++k) pose[k] = poses[(size_t)best * 12 + k];
+  return count[(size_t)best];
+}
 
 // solveRSpnp.cpp:100-192.  Returns summary.IsSolutionUsable(); the four vectors are updated only then.
 inline bool solveRsPnP(const float* opoints, const float* ipoints, int n, const double cam[NUM_CAM_PARAMS], double rvec[3], double tvec[3],
                        double rvec2[3], double tvec2[3], const SHUTTER shutter, const int scanlines[2], int device = 0) {
   double l1 = 0.0;
   for (int i = 0; i < 3; ++i) l1 += std::fabs(rvec[i]) + std::fabs(tvec[i]) + std::fabs(rvec2[i]) + std::fabs(tvec2[i]);
-  if (l1 == 0.0) throw std::invalid_argument("solveRsPnP: the global-shutter initialisation (cv::solvePnP, solveRSpnp.cpp:111-117) is not provided: pass an initial guess");
   double init[12], out[12], cost = 0.0; uint8_t status = 0; int32_t inl = 0;
   pnp_detail::to_pose(rvec, tvec, init);
   pnp_detail::to_pose(rvec2, tvec2, init + 6);
+  if (l1 == 0.0 && solveGsPnP(opoints, ipoints, n, cam, init, device))   // GS Init (:111-117): both poses start from the global-shutter one
+    for (int k = 0; k < 6; ++k) init[6 + k] = init[k];
   std::vector<int32_t> all((size_t)n);
   for (int i = 0; i < n; ++i) all[(size_t)i] = i;
   const int32_t sl[2] = {scanlines[0], scanlines[1]};
@@ -96,12 +245,16 @@ inline void solveRsPnPRansac(const float* opoints, const float* ipoints, int n, 
                              int min_points_count = 6, uint64_t rng_state = 0xffffffffULL, int device = 0) {
   double l1 = 0.0;
   for (int i = 0; i < 3; ++i) l1 += std::fabs(rvec[i]) + std::fabs(tvec[i]) + std::fabs(rvec2[i]) + std::fabs(tvec2[i]);
-  if (l1 == 0.0) throw std::invalid_argument("solveRsPnPRansac: the global-shutter initialisation (cv::solvePnPRansac, solveRSpnp.cpp:437-449) is not provided: pass an initial guess");
-  if (minInliersCount <= 0) minInliersCount = n;                                        // :453-454
-  const int32_t sl[2] = {scanlines[0], scanlines[1]};
   double init[12];
   pnp_detail::to_pose(rvec, tvec, init);
   pnp_detail::to_pose(rvec2, tvec2, init + 6);
+  if (l1 == 0.0) {   // GS Init (:437-449): global-shutter RANSAC at twice the threshold, taken when it finds more than four inliers
+    double gs[6];
+    if (solveGsPnPRansac(opoints, ipoints, n, cam, gs, iterationsCount, reprojectionError * 2, min_points_count, rng_state ^ 0x9e3779b97f4a7c15ULL, device) > 4)
+      for (int k = 0; k < 6; ++k) init[k] = init[6 + k] = gs[k];
+  }
+  if (minInliersCount <= 0) minInliersCount = n;                                        // :453-454
+  const int32_t sl[2] = {scanlines[0], scanlines[1]};
   double best_pose[12];
   for (int k = 0; k < 12; ++k) best_pose[k] = init[k];
   int best_count = 0; bool have_best = false;

@@ -1,4 +1,4 @@
-"""The N > 1 path: point-partitioned shards + all-reduce exchange, world_size 2.
+"""The N > 1 path: point-partitioned shards + all-reduce exchange, world_size 2 (and 4).
 CPU (gloo): sharding and the exchange payloads, with per-shard blocks from the oracle.
 GPU (-m gpu): the full sharded on-device LM solve equals the single-GPU solve (two ranks share GPU 0 and
 the exchange is staged through gloo — the RCCL transport is the same callback with backend "nccl")."""

@@ -404,3 +404,38 @@ def test_a_session_that_mixes_two_pose_and_one_pose_frames(exe, oracle, tmp_path
     assert abs(out["final_cost"] - s_ref.final_cost) <= 1e-6 * s_ref.final_cost
     gs = q.frame_global == 1
     assert np.max(np.abs(out["poses"][~gs] - q.poses[~gs])) <= 1e-5 and np.max(np.abs(out["poses"][gs, 0] - q.poses[gs, 0])) <= 1e-5
+
+
+def test_dlt_of_the_global_shutter_pnp_initialisation_recovers_the_pose(oracle, tmp_path):
+    """include/rsba/solve_rs_pnp.hpp: the direct linear transform that stands in for the start of cv::solvePnP (solveRSpnp.cpp:111-117)
+    is host glue (undistort + normalise, 12 x 12 eigenproblem, nearest rotation) — checked here without a device: exact data (float32
+    inputs, Brown distortion) must give the pose back."""
+    import struct
+    import __graft_entry__ as G
+    exe = os.path.join(ROOT, "examples", "pnp_ransac")
+    if not os.path.exists(exe):
+        G.build()
+    cam = np.array([800.0, 800.0, -0.05, 0.01, 1e-3, -1e-3, 2e-3, 640.0, 360.0])
+    rng = np.random.default_rng(4)
+    for trial in range(4):
+        pose = np.concatenate([rng.normal(0, 0.3, 3), rng.normal(0, 0.5, 3)])
+        X = np.stack([rng.uniform(-5, 5, 400), rng.uniform(-3, 3, 400), rng.uniform(6, 14, 400)], axis=1).astype(np.float32)
+        xy, keep = [], []
+        for j in range(len(X)):
+            ok, p = oracle.reproject(cam, np.stack([pose, pose]), 0, (0, 1), X[j].astype(np.float64), 1e12)
+            if ok and 0 < p[0] < 1280 and 0 < p[1] < 720:
+                keep.append(j); xy.append(p)
+        X, xy = X[keep][:60], np.array(xy)[:60].astype(np.float32)
+        assert len(X) >= 20
+        with open(tmp_path / "p.bin", "wb") as f:
+            f.write(struct.pack("<7i", len(X), 0, 0, 1, -1, 0, 6)); f.write(struct.pack("<f", 3.0)); f.write(struct.pack("<Q", 1))
+            f.write(cam.astype("<f8").tobytes()); f.write(np.zeros(12, dtype="<f8").tobytes())
+            f.write(X.astype("<f4").tobytes()); f.write(xy.astype("<f4").tobytes())
+        r = subprocess.run([exe, str(tmp_path / "p.bin"), str(tmp_path / "o.bin")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        raw = open(tmp_path / "o.bin", "rb").read()
+        v = np.frombuffer(raw[:96], dtype="<f8"); cnt = struct.unpack("<i", raw[96:100])[0]
+        assert cnt == 0
+        rvec, tvec = v[0:3], v[3:6]
+        centre = -oracle.angle_axis_rotate(-rvec, tvec)          # pose = (rvec, -R^T tvec)
+        assert np.max(np.abs(rvec - pose[:3])) <= 2e-3 and np.max(np.abs(centre - pose[3:])) <= 2e-2, (rvec, pose, centre)

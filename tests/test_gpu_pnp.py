@@ -212,3 +212,48 @@ def test_ransac_host_program_matches_sequential_oracle_replay(oracle, tmp_path, 
     got = np.stack([to_pose(oracle, v[0:3], v[3:6]), to_pose(oracle, v[6:9], v[9:12])])
     assert np.max(np.abs(got - ref_poses)) <= 1e-6
     assert cnt >= 0.8 * (~sc["outlier"]).sum() and np.max(np.abs(got - sc["poses"])) <= 0.05
+
+
+def run_pnp_program(tmp_path, sc, shutter, vecs, iterations, err, min_inliers, m, state):
+    import os, struct, subprocess
+    import __graft_entry__ as G
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "pnp_ransac")
+    if not os.path.exists(exe):
+        G.build()
+    with open(tmp_path / "p.bin", "wb") as f:
+        f.write(struct.pack("<7i", len(sc["X"]), shutter, sc["scan"][0], sc["scan"][1], iterations, min(min_inliers, 2 ** 30), m))
+        f.write(struct.pack("<f", err)); f.write(struct.pack("<Q", state))
+        f.write(CAM.astype("<f8").tobytes())
+        f.write(np.asarray(vecs, dtype="<f8").tobytes())
+        f.write(sc["X"].astype("<f4").tobytes()); f.write(sc["xy"].astype("<f4").tobytes())
+    r = subprocess.run([exe, str(tmp_path / "p.bin"), str(tmp_path / "o.bin")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    raw = open(tmp_path / "o.bin", "rb").read()
+    v = np.frombuffer(raw[:96], dtype="<f8"); cnt = struct.unpack("<i", raw[96:100])[0]
+    return v, np.frombuffer(raw[100:100 + 4 * cnt], dtype="<i4")
+
+
+def test_solve_rs_pnp_from_zero_vectors_uses_the_global_shutter_initialisation(oracle, tmp_path):
+    """solveRSpnp.cpp:111-117: all four vectors zero => cv::solvePnP first (here: DLT + device refinement with shutter GLOBAL),
+    both poses start from it; the rolling-shutter solve must then land where it lands from a good guess."""
+    sc = pnp_scene(oracle, HORIZONTAL, n=200, outliers=0.0, seed=12)
+    v0, flag = run_pnp_program(tmp_path, sc, HORIZONTAL, np.zeros(12), 0, 3.0, 0, 6, 1)
+    assert len(flag) == 0                                   # usable
+    init = sc["init"]
+    (r1, t1), (r2, t2) = from_pose(oracle, init[0]), from_pose(oracle, init[1])
+    v1, _ = run_pnp_program(tmp_path, sc, HORIZONTAL, np.concatenate([r1, t1, r2, t2]), 0, 3.0, 0, 6, 1)
+    got0 = np.stack([to_pose(oracle, v0[0:3], v0[3:6]), to_pose(oracle, v0[6:9], v0[9:12])])
+    got1 = np.stack([to_pose(oracle, v1[0:3], v1[3:6]), to_pose(oracle, v1[6:9], v1[9:12])])
+    assert np.max(np.abs(got0 - sc["poses"])) <= 0.05 and np.max(np.abs(got1 - sc["poses"])) <= 0.05
+    assert np.max(np.abs(got0 - got1)) <= 2e-2              # (ten LM iterations from two different starts: the same basin)
+
+
+def test_ransac_from_zero_vectors_finds_the_pose_among_outliers(oracle, tmp_path):
+    """solveRSpnp.cpp:437-449: all four vectors zero => global-shutter RANSAC first (sampled DLT poses refined and scored on the
+    device in one launch), then the rolling-shutter RANSAC from that start."""
+    sc = pnp_scene(oracle, HORIZONTAL, n=220, outliers=0.3, seed=8)
+    v, inl = run_pnp_program(tmp_path, sc, HORIZONTAL, np.zeros(12), 60, 3.0, 100, 6, 0x1234567)
+    got = np.stack([to_pose(oracle, v[0:3], v[3:6]), to_pose(oracle, v[6:9], v[9:12])])
+    assert len(inl) >= 0.8 * (~sc["outlier"]).sum()
+    assert np.mean(sc["outlier"][inl]) <= 0.05
+    assert np.max(np.abs(got - sc["poses"])) <= 0.05

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun) after tools/profile_round.sh: the text evidence profiles/rNN/README.md lists — phase times, LM
+# wall times (DAG driver against the level schedule), the task timeline of the Cholesky, the chunk timeline of the Schur kernel,
+# the tile-factorisation and hand-off micro-benchmarks, the cost of a fresh handle, and the -m gpu suite — into gpurun_out/$1/.
+R=${1:-r03}
+OUT=gpurun_out/$R
+mkdir -p $OUT
+F='grep -v amdgpu.ids'
+{ for C in C4 C5 C2; do IT=12; [ $C = C5 ] && IT=8; python tools/phase_time.py $C $IT 2>&1 | $F; done; python tools/fixed_cost.py 2>&1 | $F; } > $OUT/phase_times.txt
+python tools/lm_time.py C4 12 2>&1 | $F > $OUT/lm_time_c4.txt
+python tools/lm_time.py C5 8 2>&1 | $F > $OUT/lm_time_c5.txt
+python tools/lm_time.py C4 12 free_ratio 2>&1 | $F > $OUT/lm_time_c4_free_ratio.txt
+python tools/chol_trace.py C4 2>&1 | $F > $OUT/chol_trace_c4.txt
+python tools/schur_trace.py C4 2>&1 | $F > $OUT/schur_trace_c4.txt
+timeout 120 tools/tile_factor_bench > $OUT/tile_factor.txt 2>&1
+timeout 120 tools/xcd_handoff > $OUT/xcd_handoff.txt 2>&1
+{ RSBA_DEBUG_PLAN=1 python tools/setup_time.py C4 2>&1 | $F; python tools/setup_time.py C2 2>&1 | $F; } > $OUT/setup_time.txt
+python tools/filter_time.py 2>&1 | $F > $OUT/filter_time.txt
+python -m pytest tests -m gpu -q 2>&1 | $F | tail -15 > $OUT/pytest_gpu.txt
