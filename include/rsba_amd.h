@@ -203,7 +203,7 @@ typedef struct rsba_plan_stats {
   int64_t schur_entries, schur_chunks;              /* (point, tile pair) entries of the Schur work list, workgroups */
   int64_t schur_block_products;                     /* CD x 3 by 3 x CD block products that are not structurally zero */
   int64_t cholesky_flops;                           /* of the tile factorisation incl. fill, forward and backward solve */
-  int64_t exchange_doubles;                         /* payload (2) of the multi-GPU exchange: packed tiles + rhs */
+  int64_t exchange_doubles;                         /* payload (2) of the multi-GPU exchange: the structurally non-zero tiles of S + rhs */
   int64_t schur_groups;                             /* (point, frame tile) groups of P records: 3 x 48 doubles each */
   int64_t schur_mfma_issued, schur_launches;        /* fp64 MFMAs (2048 flop each) the Schur kernel issued so far — all-zero operand blocks are skipped — over so many launches */
 } rsba_plan_stats;

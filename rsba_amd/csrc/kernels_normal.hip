@@ -1227,4 +1227,28 @@ hipError_t launch_candidate(const DeviceProblem& dp, const SolverDev& sv, hipStr
   return hipSuccess;
 }
 
+// exchange (2) of a sharded solve moves only the tiles of S that can be non-zero — the tile pairs of the plan; the fill-in tiles of the
+// factor's layout (44 % of the packed tiles at 1k cameras) are zero on every rank.  pack: buf[b] = S tile slots[b], then the rhs;
+// unpack: the reverse.  One workgroup per tile, the last one takes the rhs.
+namespace {
+template <bool UNPACK>
+__global__ __launch_bounds__(256) void exchange_pack_kernel(SolverDev sv, const int32_t* __restrict__ slots, int ntiles, double* __restrict__ buf) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (b < ntiles) {
+    double* t = sv.S + (size_t)slots[b] * (kTile * kTile);
+    double* q = buf + (size_t)b * (kTile * kTile);
+#pragma unroll
+    for (int k = 0; k < (kTile * kTile) / 256; ++k) { if (UNPACK) t[tid + 256 * k] = q[tid + 256 * k]; else q[tid + 256 * k] = t[tid + 256 * k]; }
+  } else {
+    double* q = buf + (size_t)ntiles * (kTile * kTile);
+    for (int64_t e = tid; e < sv.npad; e += 256) { if (UNPACK) sv.rhs[e] = q[e]; else q[e] = sv.rhs[e]; }
+  }
+}
+}  // namespace
+hipError_t launch_exchange_pack(const SolverDev& sv, const int32_t* slots, int ntiles, double* buf, bool unpack, hipStream_t st) {
+  if (unpack) hipLaunchKernelGGL(exchange_pack_kernel<true>, dim3(ntiles + 1), dim3(256), 0, st, sv, slots, ntiles, buf);
+  else hipLaunchKernelGGL(exchange_pack_kernel<false>, dim3(ntiles + 1), dim3(256), 0, st, sv, slots, ntiles, buf);
+  return hipGetLastError();
+}
+
 }  // namespace rsba

@@ -95,6 +95,7 @@ struct Solver {
   hipStream_t mstream = nullptr; hipEvent_t ev_armed[2] = {nullptr, nullptr}, ev_released = nullptr; bool arm_pending[2] = {false, false};
   int64_t schur_launches = 0;                                         // launches of the Schur kernel since the plan was built (statistics)
   int num_reduced_blocks = 0, num_reduced_params = 0, num_priors_reduced = 0;
+  int32_t* exch_slots = nullptr; double* exch_buf = nullptr; int exch_tiles = 0;   // exchange (2) of a sharded solve: the plan's tile pairs, packed
   double* zy2 = nullptr;                                              // [2][npad] z | y of one more right-hand side through the last factorisation (solve_again)
   double* border = nullptr, *ubuf = nullptr, *ratio4 = nullptr;      // free interFrameRatio: its column of S [npad], the first solve's result, {h, g, b.u, b.v}
   PosePriorDev pp{};                                                  // per-pose priors: linearisation of the priorPoses coordinates
@@ -835,6 +836,13 @@ int32_t build_solver(rsba_handle* h) {
   up.upload_const(&sv.pm_ptr, pm_ptr);
   up.upload_const(&sv.pm_list, pm_list);
   up.upload_const(&sv.tp_dst, tp_dst);
+  std::vector<int32_t> exch_slots(tp_dst);   // (a tile pair has a packed tile of its own: distinct slots; ascending = the order they sit in memory)
+  std::sort(exch_slots.begin(), exch_slots.end());
+  s->exch_tiles = (int)exch_slots.size();
+  if (h->allreduce) {
+    up.upload(&s->exch_slots, exch_slots);
+    if ((rc = s_alloc(s, &s->exch_buf, (size_t)exch_slots.size() * kTile * kTile + (size_t)sv.npad))) return rc;
+  }
   up.upload_const(&sv.tp_trans, tp_trans);
   up.upload_const(&sv.tp_add, tp_add);
   if ((rc = s_alloc(s, &sv.schur_part, (size_t)std::max(sv.nchunk, 1) * (kTile * kTile + kTile)))) return rc;
@@ -1024,7 +1032,7 @@ int32_t build_solver(rsba_handle* h) {
     const int64_t T3 = (int64_t)kTile * kTile * kTile;
     ps.cholesky_flops = T3 * ((int64_t)(s->diag_list.size() / 2) + 2 * (int64_t)(s->sub_list.size() / 2) + (int64_t)(s->sub_info.size() / 4)) +
                         2 * T3 / 3 * (int64_t)(s->diag_info.size() / 4) + 4 * (int64_t)kTile * kTile * ((int64_t)sv.nslots + nt);
-    ps.exchange_doubles = (int64_t)sv.nslots * kTile * kTile + sv.npad;
+    ps.exchange_doubles = (int64_t)s->exch_tiles * kTile * kTile + sv.npad;   // exchange (2) of a sharded solve: the plan's tile pairs | rhs (the fill-in tiles of the factor's layout stay home)
     ps.schur_groups = sv.ngroups;
   }
   tick("statistics");
@@ -1130,6 +1138,13 @@ int32_t reduce_system(rsba_handle* h, double radius) {
   }
   // exchange (2): partial reduced camera systems -> the full one on every rank (then factored redundantly)
   PhaseScope ps(h, RSBA_PHASE_EXCHANGE);
+  if (h->allreduce && s->exch_slots) {   // only the tiles that can be non-zero travel (the fill-in tiles of the layout are zero on every rank)
+    const int64_t count = (int64_t)s->exch_tiles * kTile * kTile + sv.npad;
+    HIP_TRY(launch_exchange_pack(sv, s->exch_slots, s->exch_tiles, s->exch_buf, false, st));
+    if (int32_t rc = exchange(h, s->exch_buf, count, 0)) return rc;
+    HIP_TRY(launch_exchange_pack(sv, s->exch_slots, s->exch_tiles, s->exch_buf, true, st));
+    return RSBA_OK;
+  }
   return exchange(h, sv.S, (int64_t)sv.nslots * kTile * kTile + sv.npad, 0);
 }
 

@@ -176,6 +176,7 @@ hipError_t launch_prior_blocks(const DeviceProblem& dp, const SolverDev& sv, dou
 hipError_t launch_prior_model(const DeviceProblem& dp, const SolverDev& sv, double* model_cost_change, double ratio_step, hipStream_t st);
 // free interFrameRatio: its column of the normal equations (border [F*12], hg = {h, g}), dots and the combined step
 hipError_t launch_prior_border(const DeviceProblem& dp, const SolverDev& sv, double* border, double* hg, hipStream_t st);
+hipError_t launch_exchange_pack(const SolverDev& sv, const int32_t* slots, int ntiles, double* buf, bool unpack, hipStream_t st);   // exchange (2): the structurally non-zero tiles of S | rhs <-> one contiguous buffer
 hipError_t launch_border_dots(const double* b, const double* u, const double* v, int64_t n, double* out2, hipStream_t st);
 hipError_t launch_border_combine(double* y, const double* u, const double* v, double c, int64_t n, hipStream_t st);
 hipError_t launch_intr_blocks(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);
