@@ -160,8 +160,10 @@ struct Uploader {
     });
   }
   void push(std::function<hipError_t()> job) { { std::lock_guard<std::mutex> lk(m); q.push_back(std::move(job)); } cv.notify_one(); }
+  // *_ref: the vector outlives this object and is not touched before finish() (the plan scratch, members of the Solver); the plain
+  // forms take a copy (small tables that are locals of build_solver: an early return destroys them before this object)
   template <class T>
-  void upload(T** dst, const std::vector<T>& v) {
+  void upload_ref(T** dst, const std::vector<T>& v) {
     push([this, dst, &v]() -> hipError_t {
       void* d = nullptr;
       hipError_t e = hipMalloc(&d, std::max<size_t>(v.size(), 1) * sizeof(T));
@@ -171,7 +173,20 @@ struct Uploader {
     });
   }
   template <class T>
+  void upload(T** dst, const std::vector<T>& v) {
+    auto own = std::make_shared<std::vector<T>>(v);
+    push([this, dst, own]() -> hipError_t {
+      void* d = nullptr;
+      hipError_t e = hipMalloc(&d, std::max<size_t>(own->size(), 1) * sizeof(T));
+      if (e != hipSuccess) return e;
+      allocs.push_back(d); *dst = static_cast<T*>(d);
+      return own->empty() ? hipSuccess : hipMemcpy(d, own->data(), own->size() * sizeof(T), hipMemcpyHostToDevice);
+    });
+  }
+  template <class T>
   void upload_const(const T** dst, const std::vector<T>& v) { upload(const_cast<T**>(dst), v); }
+  template <class T>
+  void upload_const_ref(const T** dst, const std::vector<T>& v) { upload_ref(const_cast<T**>(dst), v); }
   hipError_t finish() {
     if (!joined) {
       { std::lock_guard<std::mutex> lk(m); closing = true; } cv.notify_one();
@@ -292,10 +307,10 @@ int32_t build_solver(rsba_handle* h) {
   };
   Uploader up(s, h->device);
   up.upload_const(&sv.frame_ptr, frame_ptr);
-  up.upload_const(&sv.point_ptr, point_ptr);
-  up.upload_const(&sv.slot_frame, slot_frame);
-  up.upload_const(&sv.slot_point, slot_point);
-  up.upload(&s->d_obs_slot, obs_slot);
+  up.upload_const_ref(&sv.point_ptr, point_ptr);
+  up.upload_const_ref(&sv.slot_frame, slot_frame);
+  up.upload_const_ref(&sv.slot_point, slot_point);
+  up.upload_ref(&s->d_obs_slot, obs_slot);
   tick("slots");
   // ---- work list of the point elimination: one ENTRY per (point, pair of frame tiles I >= J) ----
   // An entry lists the point's observation slot in each of the FT frames of tile I (sa) and of tile J (sb),
@@ -351,7 +366,7 @@ int32_t build_solver(rsba_handle* h) {
   }
   sv.ngroups = (int64_t)g_tile.size();
   if ((sv.ngroups + 1) * (int64_t)kTile * 3 >= ((int64_t)1 << 32)) return rsba_set_error(RSBA_ERR_UNSUPPORTED, "more than 2^32 doubles of P records: the Schur kernel indexes them with 32 bits");
-  up.upload_const(&sv.slot_gpos, slot_gpos);
+  up.upload_const_ref(&sv.slot_gpos, slot_gpos);
   const bool dense_keys = (int64_t)nt * nt <= (int64_t)1 << 26;
   std::vector<int64_t> dense_cnt; std::unordered_map<int64_t, int64_t> sparse_cnt;
   if (dense_keys) dense_cnt.assign((size_t)nt * nt, -1);
@@ -464,8 +479,8 @@ int32_t build_solver(rsba_handle* h) {
   std::vector<int32_t>().swap(dense_index);
   const int ntp = (int)tp_I.size();
   s->num_pairs = nent;
-  up.upload_const(&sv.ent_groups, ent_groups);
-  up.upload_const(&sv.ent_pt, ent_pt);
+  up.upload_const_ref(&sv.ent_groups, ent_groups);
+  up.upload_const_ref(&sv.ent_pt, ent_pt);
   // per entry, which of the 3 x 3 block products of its two groups can be non-zero
   std::vector<uint16_t>& ent_mask = scr.ent_mask; ent_mask.resize((size_t)nent);
   std::vector<int64_t> products_part((size_t)std::max(nthreads, 1), 0);   // (plan statistics: block products that are not structurally zero)
@@ -481,7 +496,7 @@ int32_t build_solver(rsba_handle* h) {
     }
     products_part[t] = prod;
   });
-  up.upload_const(&sv.ent_mask, ent_mask);
+  up.upload_const_ref(&sv.ent_mask, ent_mask);
 
   // ---- tile graph of S, fill-reducing / parallelism-exposing ordering, symbolic factorisation ----
   std::vector<std::vector<int32_t>> adj(nt);
@@ -812,7 +827,7 @@ int32_t build_solver(rsba_handle* h) {
   up.upload_const(&sv.tp_J, tp_J);
   up.upload_const(&sv.tp_ptr, tp_ptr);
   up.upload_const(&sv.inprog_pose, inprog_pose);
-  up.upload_const(&sv.inprog_point, inprog_point);
+  up.upload_const_ref(&sv.inprog_point, inprog_point);
   up.upload_const(&sv.inprog_intr, inprog_intr);
   std::vector<int32_t> ifp((size_t)NIB + 1, 0), ifl;       // (alive until the uploads have finished)
   std::vector<int64_t> point_vgroup(NIB == 1 ? (size_t)M : 0, -1);
@@ -823,8 +838,8 @@ int32_t build_solver(rsba_handle* h) {
     { std::vector<int32_t> fill(ifp.begin(), ifp.end() - 1); for (int f = 0; f < FR && NIB > 0; ++f) ifl[fill[intr_of(f)]++] = f; }
     up.upload_const(&sv.intr_frame_ptr, ifp);
     up.upload_const(&sv.intr_frame_list, ifl);
-    up.upload_const(&sv.vgroup_point, vgroup_point);
-    up.upload_const(&sv.vgroup_intr, vgroup_intr);
+    up.upload_const_ref(&sv.vgroup_point, vgroup_point);
+    up.upload_const_ref(&sv.vgroup_intr, vgroup_intr);
     for (int j = 0; j < M && NIB == 1; ++j) if (vgroup_ptr[j + 1] > vgroup_ptr[j]) point_vgroup[j] = vgroup_ptr[j];
     up.upload_const(&sv.point_vgroup, point_vgroup);
   }
@@ -846,7 +861,7 @@ int32_t build_solver(rsba_handle* h) {
   up.upload_const(&sv.tp_trans, tp_trans);
   up.upload_const(&sv.tp_add, tp_add);
   if ((rc = s_alloc(s, &sv.schur_part, (size_t)std::max(sv.nchunk, 1) * (kTile * kTile + kTile)))) return rc;
-  up.upload(&s->d_upd, s->upd);
+  up.upload_ref(&s->d_upd, s->upd);
   // the write-once cells of the persistent Cholesky driver — factor tiles | partial tiles | W | z, y | published X — live in ONE
   // allocation: one memset re-arms them before a launch (five launches before)
   {
@@ -863,23 +878,23 @@ int32_t build_solver(rsba_handle* h) {
     double* cells = s->cells[0];
     sv.Lf = cells; sv.chol_part = cells + nLf; sv.Winv = sv.chol_part + nPart; sv.zv = sv.Winv + nW; sv.yv = sv.zv + sv.npad; sv.Xpub = sv.zv + nZ;
   }
-  up.upload(&s->d_tasks, s->tasks);
+  up.upload_ref(&s->d_tasks, s->tasks);
   if ((rc = s_alloc(s, &s->d_dag_sync, 4))) return rc;
   if ((rc = s_alloc(s, &s->zy2, 2 * (size_t)sv.npad))) return rc;
-  up.upload(&s->d_diag_info, s->diag_info);
-  up.upload(&s->d_diag_ptr, s->diag_ptr);
-  up.upload(&s->d_diag_list, s->diag_list);
-  up.upload(&s->d_sub_info, s->sub_info);
-  up.upload(&s->d_sub_ptr, s->sub_ptr);
-  up.upload(&s->d_sub_list, s->sub_list);
-  up.upload(&s->d_sub_col, s->sub_col);
-  up.upload(&s->d_diag_own, s->diag_own);
-  up.upload(&s->d_diag_fuse, s->diag_fuse);
-  up.upload(&s->d_sub_pub, s->sub_pub);
-  up.upload(&s->d_sub_own, s->sub_own);
-  up.upload(&s->d_back_info, s->back_info);
-  up.upload(&s->d_back_ptr, s->back_ptr);
-  up.upload(&s->d_back_list, s->back_list);
+  up.upload_ref(&s->d_diag_info, s->diag_info);
+  up.upload_ref(&s->d_diag_ptr, s->diag_ptr);
+  up.upload_ref(&s->d_diag_list, s->diag_list);
+  up.upload_ref(&s->d_sub_info, s->sub_info);
+  up.upload_ref(&s->d_sub_ptr, s->sub_ptr);
+  up.upload_ref(&s->d_sub_list, s->sub_list);
+  up.upload_ref(&s->d_sub_col, s->sub_col);
+  up.upload_ref(&s->d_diag_own, s->diag_own);
+  up.upload_ref(&s->d_diag_fuse, s->diag_fuse);
+  up.upload_ref(&s->d_sub_pub, s->sub_pub);
+  up.upload_ref(&s->d_sub_own, s->sub_own);
+  up.upload_ref(&s->d_back_info, s->back_info);
+  up.upload_ref(&s->d_back_ptr, s->back_ptr);
+  up.upload_ref(&s->d_back_list, s->back_list);
 
   HIP_TRY(up.finish());
   tick("uploads");
