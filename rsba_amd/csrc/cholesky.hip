@@ -1146,6 +1146,7 @@ __global__ __launch_bounds__(256, 2) void chol_dag_kernel(const DagArgs* __restr
 // covariance block): forward tasks z_j = W_j (b2_j - sum_k L_jk z_k) in the order of the DIAG items, then the BACK tasks of the
 // factorisation on z2 / y2 — one persistent launch over write-once z / y cells of its own, no tile product anywhere.  It used to be a
 // second factorisation (0.76 ms at 1k cameras for 0.1 ms of substitutions).
+template <bool DAG>
 __device__ __forceinline__ void task_forward(const SolverDev& sv, const CholPlan& pl, int d, const double* __restrict__ b2, double* z2, double* smem, int tid) {
   double* zb = smem;            // [5][T] z of the five contributors of a step
   double* sp = smem + 5 * T;    // [5][T] partial sums
@@ -1170,8 +1171,8 @@ __device__ __forceinline__ void task_forward(const SolverDev& sv, const CholPlan
 #pragma unroll
       for (int c = 0; c < T; ++c) lrow[c] = gl(Lp + c);
       const double* zk = z2 + (size_t)gl(pl.diag_list + 2 * q + 1) * T + r;
-      double z = ld<true>(zk);
-      while (!filled(z)) { __builtin_amdgcn_s_sleep(2); z = ld<true>(zk); }
+      double z = ld<DAG>(zk);
+      while (DAG && !filled(z)) { __builtin_amdgcn_s_sleep(2); z = ld<DAG>(zk); }
       zb[g * T + r] = z;
     }
     lds_barrier();
@@ -1194,7 +1195,18 @@ __device__ __forceinline__ void task_forward(const SolverDev& sv, const CholPlan
     double z = 0.0;
 #pragma unroll
     for (int c = 0; c < T; ++c) z += w[c] * tv[c];
-    st<true>(z2 + (size_t)tile_j * T + r, z);
+    st<DAG>(z2 + (size_t)tile_j * T + r, z);
+  }
+}
+
+// the same tasks one launch per level (no polling): what the persistent form is checked against and falls back to
+__global__ __launch_bounds__(256) void chol_solve_level_kernel(const SolverDev sv, const CholPlan pl, int backward, int first, const double* __restrict__ b2, double* zy2) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  if (!backward) task_forward<false>(sv, pl, first + blockIdx.x, b2, zy2, smem, threadIdx.x);
+  else {
+    SolverDev sv2 = sv;
+    sv2.zv = zy2; sv2.yv = zy2 + sv2.npad;
+    task_back<false>(sv2, pl, first + blockIdx.x, smem, threadIdx.x);
   }
 }
 
@@ -1212,7 +1224,7 @@ __global__ __launch_bounds__(256) void chol_solve_kernel(const DagArgs* __restri
     if (t >= 2 * nd) return;
     int task_tid = tid;
     asm volatile("" : "+v"(task_tid));
-    if (t < nd) task_forward(args->sv, pl, t, b2, zy2, smem, task_tid);
+    if (t < nd) task_forward<true>(args->sv, pl, t, b2, zy2, smem, task_tid);
     else {
       SolverDev sv2 = args->sv;
       sv2.zv = zy2; sv2.yv = zy2 + sv2.npad;
@@ -1302,6 +1314,14 @@ hipError_t launch_chol_solve(const SolverDev& sv, const CholPlan& pl, const DagA
   e = hipMemsetAsync(ticket, 0, sizeof(unsigned int), st);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(chol_solve_kernel, dim3(workgroups), dim3(256), (size_t)84 * 1024, st, device_args, b2, zy2, ticket);
+  return hipGetLastError();
+}
+
+hipError_t launch_chol_solve_level(const SolverDev& sv, const CholPlan& pl, bool backward, int first, int count, const double* b2, double* zy2, hipStream_t st) {
+  if (count <= 0) return hipSuccess;
+  hipError_t e = allow_dynamic_lds(chol_solve_level_kernel, kCholLds * sizeof(double));
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(chol_solve_level_kernel, dim3(count), dim3(256), kCholLds * sizeof(double), st, sv, pl, backward ? 1 : 0, first, b2, zy2);
   return hipGetLastError();
 }
 

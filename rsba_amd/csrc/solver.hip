@@ -1222,7 +1222,11 @@ int32_t solve_reduced_system(rsba_handle* h) {
 int32_t solve_again(rsba_handle* h, const double* b2, const double** v_out) {
   Solver* s = h->solver; const SolverDev& sv = s->sv; hipStream_t st = h->stream;
   PhaseScope ps(h, RSBA_PHASE_CHOLESKY);
-  HIP_TRY(launch_chol_solve(sv, s->plan, s->d_dag_args, b2, s->zy2, s->d_dag_sync + 2, s->dag_workgroups, st));
+  if (!s->use_levels) HIP_TRY(launch_chol_solve(sv, s->plan, s->d_dag_args, b2, s->zy2, s->d_dag_sync + 2, s->dag_workgroups, st));
+  else {   // the same tasks, one launch per level: no polling (what a suspect persistent result is redone with)
+    for (int l = 0; l < s->nlev; ++l) HIP_TRY(launch_chol_solve_level(sv, s->plan, false, s->lev_diag_ptr[l], s->lev_diag_ptr[l + 1] - s->lev_diag_ptr[l], b2, s->zy2, st));
+    for (int l = s->nlev - 1; l >= 0; --l) HIP_TRY(launch_chol_solve_level(sv, s->plan, true, s->lev_diag_ptr[l], s->lev_diag_ptr[l + 1] - s->lev_diag_ptr[l], b2, s->zy2, st));
+  }
   *v_out = s->zy2 + sv.npad;
   if (!s->use_levels && s->verify_dag) {
     if (int32_t rc = await_verification(h)) return rc;   // (the accumulators of the check are shared)

@@ -155,6 +155,7 @@ hipError_t launch_chol_level(const SolverDev& sv, const CholPlan& pl, int kind, 
 hipError_t launch_chol_verify(const SolverDev& sv, const int32_t* slot_tiles, const double* b_rhs, double* res, double* den, double tol, double* flag, hipStream_t st);
 struct DagArgs { SolverDev sv; CholPlan pl; };   // device copy the persistent kernel reads its state through (uploaded once per plan)
 hipError_t launch_chol_solve(const SolverDev& sv, const CholPlan& pl, const DagArgs* device_args, const double* b2, double* zy2, unsigned int* ticket, int workgroups, hipStream_t st);   // one more right-hand side through the factor of the last launch_chol_dag / level run
+hipError_t launch_chol_solve_level(const SolverDev& sv, const CholPlan& pl, bool backward, int first, int count, const double* b2, double* zy2, hipStream_t st);   // the same tasks, one launch per level
 hipError_t launch_chol_dag(const SolverDev& sv, const CholPlan& pl, const DagArgs* device_args, int workgroups, bool one_per_cu, hipStream_t st);   // one_per_cu: LDS request above half a CU's, so that two never share one
 
 // kernels_normal.hip
