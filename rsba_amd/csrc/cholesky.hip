@@ -274,26 +274,30 @@ __device__ __forceinline__ void ldl16_follow_rows(const double* msg, double* Wl,
   // lane group jj % 4 belong to one pass of it: once the pivot is there so are the multipliers; the compiler must not move their
   // loads above the polling loop, though.
   dbl2_t m2[2][8];
-  double pv[16];
+  double piv_prev = 0.0, piv_cur = 0.0;   // the pivots of messages jj - 1 and jj (each is used one step after it is seen)
   double next = vm[msg_off(0)];   // the pivot of message jj sits in the cell of lane 16 (jj % 4) + jj; requested one step ahead, looked at when needed
 #pragma unroll
   for (int jj = 0; jj <= 16; ++jj) {
     if (jj < 16) {
       const int cell = msg_off(jj) + 16 * (jj & 3);
+      // The look at message jj was requested one step ago, BEFORE that step's multipliers: this first test waits for that one read only
+      // (s_waitcnt lgkmcnt(n) with the multipliers still in flight).  Written as a loop the compiler waits for everything at its head —
+      // then a step costs a whole LDS round trip of its five reads, ~230 cycles against the 204 of the eliminating wave, and the wave
+      // ends 1 650 cycles behind it.  The second look (message not there yet) may wait for all it likes.
       double piv = next;
-      while (__ballot(!filled(piv)) != 0ull) piv = vm[cell + jj];
-      pv[jj] = piv;
+      if (__builtin_expect(__ballot(!filled(piv)) != 0ull, 0)) { do { piv = vm[cell + jj]; } while (__ballot(!filled(piv)) != 0ull); }
+      piv_prev = piv_cur; piv_cur = piv;
       asm volatile("" ::: "memory");
+      if (jj < 15) next = vm[msg_off(jj + 1) + 16 * ((jj + 1) & 3) + jj + 1];
 #pragma unroll
       for (int h = 0; h < 8; ++h) if (2 * h + 1 > jj) m2[jj & 1][h] = *(lds_c2ptr)(msg + cell + 2 * h);
-      if (jj < 15) next = vm[msg_off(jj + 1) + 16 * ((jj + 1) & 3) + jj + 1];
     }
     if (jj >= 1) {   // pivot jj - 1
       const int k = jj - 1;
       // d_k^-1/2 (rsqrt_cubic, spelled out) is threaded through the row updates: its four dependent steps wait out their latencies
       // behind independent FMAs.  Everything is pinned where it stands: left alone, the compiler turns the fifteen independent
       // updates of a pivot into one dependent sum per row, formed right before the row is used — k FMA latencies on the chain.
-      const double x = pv[k];
+      const double x = jj < 16 ? piv_prev : piv_cur;   // pivot k (at jj = 16 no new message has shifted the pair)
       double y0 = __builtin_amdgcn_rsq(x), t0 = 0.0, q0 = 0.0, p0 = 0.0;
       asm volatile("" : "+v"(y0));
 #pragma unroll
@@ -368,44 +372,53 @@ __device__ __forceinline__ bool factor_invert_tile(double* D, double* Wl, double
   int nstamp = 0;
   auto stamp = [&]() { if (TRACE && tid == 0) stamps[nstamp++] = clock64(); };   // tools/tile_factor_bench.hip
   double* msg = D;   // (D is the first LDS buffer of the task; the messages sit at msg_off() behind it)
-  stamp();
-  if (wave == 0) ok = ldl16_eliminate(load_sym16(D, 0, lane), msg, lane);
-  else if (wave == 1) { if (MFMA_FOLLOWER) put16(Wl, 0, 0, ldl16_follow(msg, lane, TRACE ? stamps + 16 : nullptr), lane); else ldl16_follow_rows(msg, Wl, 0, lane); }
-  stamp(); lds_barrier(); stamp();
   auto publish_rows = [&](int rb, int nthreads, int t) {   // rows 16 rb .. 16 rb + 15 of W: lower blocks from Wl, exact zeros right of the diagonal block
     for (int e = t; e < 16 * T; e += nthreads) { const int r = 16 * rb + e / T, c = e % T; st<DAG>(wout + r * T + c, c < 16 * (rb + 1) ? Wl[r * TP + c] : 0.0); }
   };
-  if (wave < 2) put16(Lp, 16 + 16 * wave, 0, mm16_nt(D, 16 + 16 * wave, 0, Wl, 0, 0, zero, 1.0, lane), lane);   // L_10, L_20
-  else {
-    rearm_pivot_messages(D, lane, 8 * (wave - 2), 8 * (wave - 1));   // (both waves of block 0 are done with them; block 1 starts behind the next barrier)
+  stamp();
+  // ONE copy of the two sixteen-pivot loops (the bulk of this function's code), gone through three times: inside the solver a task runs
+  // this function once, and its instructions come from memory — with the three diagonal blocks spelled out one after the other the
+  // factorisation took 8.3 us there against 7.1 us in tools/tile_factor_bench.hip's warm loop, and nothing that made the warm loop
+  // faster showed up in the solver.  Blocks 1 and 2 now run from the instruction cache.
+#pragma clang loop unroll(disable)
+  for (int b = 0; b < 3; ++b) {
+    const int o = 16 * b;
+    if (wave == 0) {
+      dbl4_t d = load_sym16(D, o, lane);
+      if (b > 0) d = mm16_nt(Lp, o, o - 16, Lp, o, o - 16, d, -1.0, lane);   // D_bb - L_b,b-1 L_b,b-1^T (block 2 has lost L_20 L_20^T already)
+      ok = ldl16_eliminate(d, msg, lane) && ok;
+    } else if (wave == 1) {
+      if (MFMA_FOLLOWER) put16(Wl, o, o, ldl16_follow(msg, lane, (TRACE && b == 0) ? stamps + 16 : nullptr), lane); else ldl16_follow_rows(msg, Wl, o, lane);
+    } else if (b == 1) {
+      if (wave == 2) {
+        put16(D, 32, 16, mm16_nt(Lp, 32, 0, Lp, 16, 0, load16(D, 32, 16, lane), -1.0, lane), lane);
+        put16(Tm, 16, 0, mm16_nn(Lp, 16, 0, Wl, 0, 0, zero, 1.0, lane), lane);                                         // T_10 = L_10 W_00
+      } else {
+        put16(D, 32, 32, mm16_nt(Lp, 32, 0, Lp, 32, 0, load16(D, 32, 32, lane), -1.0, lane), lane);                     // (its upper half is never read)
+        if (wout) publish_rows(0, 64, lane);   // W_00 has been final since the first barrier; this step is long (sixteen pivots), the one before is not
+      }
+    } else if (b == 2) {
+      if (wave == 2) put16(Tm, 32, 16, mm16_nn(Lp, 32, 16, Wl, 16, 16, zero, 1.0, lane), lane);                        // T_21 = L_21 W_11
+      else {
+        put16(Tm, 32, 0, mm16_nn(Lp, 32, 16, Wl, 16, 0, load16(Tm, 32, 0, lane), 1.0, lane), lane);                     // T_20 += L_21 W_10
+        if (wout) publish_rows(1, 64, lane);   // W_10, W_11 have been final since the barrier above
+      }
+    }
+    stamp(); lds_barrier(); stamp();
+    if (b == 0) {
+      if (wave < 2) put16(Lp, 16 + 16 * wave, 0, mm16_nt(D, 16 + 16 * wave, 0, Wl, 0, 0, zero, 1.0, lane), lane);   // L_10, L_20
+      else rearm_pivot_messages(D, lane, 8 * (wave - 2), 8 * (wave - 1));   // (both waves of block 0 are done with them; block 1 starts behind the next barrier)
+    } else if (b == 1) {
+      if (wave == 0) put16(Lp, 32, 16, mm16_nt(D, 32, 16, Wl, 16, 16, zero, 1.0, lane), lane);       // L_21
+      else if (wave == 1) put16(Wl, 16, 0, mm16_nn(Wl, 16, 16, Tm, 16, 0, zero, -1.0, lane), lane);  // W_10
+      else if (wave == 2) put16(Tm, 32, 0, mm16_nn(Lp, 32, 0, Wl, 0, 0, zero, 1.0, lane), lane);     // T_20 = L_20 W_00
+      else rearm_pivot_messages(D, lane, 0, 16);
+    } else {
+      if (wave == 0) put16(Wl, 32, 16, mm16_nn(Wl, 32, 32, Tm, 32, 16, zero, -1.0, lane), lane);      // W_21
+      else if (wave == 1) put16(Wl, 32, 0, mm16_nn(Wl, 32, 32, Tm, 32, 0, zero, -1.0, lane), lane);   // W_20
+    }
+    stamp(); lds_barrier(); stamp();
   }
-  stamp(); lds_barrier(); stamp();
-  if (wave == 0) ok = ldl16_eliminate(mm16_nt(Lp, 16, 0, Lp, 16, 0, load_sym16(D, 16, lane), -1.0, lane), msg, lane) && ok;
-  else if (wave == 1) { if (MFMA_FOLLOWER) put16(Wl, 16, 16, ldl16_follow(msg, lane), lane); else ldl16_follow_rows(msg, Wl, 16, lane); }
-  else if (wave == 2) {
-    put16(D, 32, 16, mm16_nt(Lp, 32, 0, Lp, 16, 0, load16(D, 32, 16, lane), -1.0, lane), lane);
-    put16(Tm, 16, 0, mm16_nn(Lp, 16, 0, Wl, 0, 0, zero, 1.0, lane), lane);                                         // T_10 = L_10 W_00
-  } else {
-    put16(D, 32, 32, mm16_nt(Lp, 32, 0, Lp, 32, 0, load16(D, 32, 32, lane), -1.0, lane), lane);                     // (its upper half is never read)
-    if (wout) publish_rows(0, 64, lane);   // W_00 has been final since the first barrier; this step is long (sixteen pivots), the one before is not
-  }
-  stamp(); lds_barrier(); stamp();
-  if (wave == 0) put16(Lp, 32, 16, mm16_nt(D, 32, 16, Wl, 16, 16, zero, 1.0, lane), lane);       // L_21
-  else if (wave == 1) put16(Wl, 16, 0, mm16_nn(Wl, 16, 16, Tm, 16, 0, zero, -1.0, lane), lane);  // W_10
-  else if (wave == 2) put16(Tm, 32, 0, mm16_nn(Lp, 32, 0, Wl, 0, 0, zero, 1.0, lane), lane);     // T_20 = L_20 W_00
-  else rearm_pivot_messages(D, lane, 0, 16);
-  stamp(); lds_barrier(); stamp();
-  if (wave == 0) ok = ldl16_eliminate(mm16_nt(Lp, 32, 16, Lp, 32, 16, load_sym16(D, 32, lane), -1.0, lane), msg, lane) && ok;
-  else if (wave == 1) { if (MFMA_FOLLOWER) put16(Wl, 32, 32, ldl16_follow(msg, lane), lane); else ldl16_follow_rows(msg, Wl, 32, lane); }
-  else if (wave == 2) put16(Tm, 32, 16, mm16_nn(Lp, 32, 16, Wl, 16, 16, zero, 1.0, lane), lane);                    // T_21 = L_21 W_11
-  else {
-    put16(Tm, 32, 0, mm16_nn(Lp, 32, 16, Wl, 16, 0, load16(Tm, 32, 0, lane), 1.0, lane), lane);                       // T_20 += L_21 W_10
-    if (wout) publish_rows(1, 64, lane);   // W_10, W_11 have been final since the barrier above
-  }
-  stamp(); lds_barrier(); stamp();
-  if (wave == 0) put16(Wl, 32, 16, mm16_nn(Wl, 32, 32, Tm, 32, 16, zero, -1.0, lane), lane);      // W_21
-  else if (wave == 1) put16(Wl, 32, 0, mm16_nn(Wl, 32, 32, Tm, 32, 0, zero, -1.0, lane), lane);   // W_20
-  stamp(); lds_barrier(); stamp();
   if (wout) publish_rows(2, 256, tid);
   return ok;
 }

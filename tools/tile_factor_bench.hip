@@ -1,3 +1,6 @@
+// NOTE (end of round 3): this file times the code as the compiler lays it out for THESE kernels; inside the solver's persistent kernel
+// the same source is laid out, allocated and fetched differently (tools/chol_trace.py is the measurement that counts): the rolled
+// three-block loop of factor_invert_tile made the tile 0.9 us faster there (8.3 -> 7.4 us) and 1.2 us slower here.
 // Micro-benchmark + check of the serial core of the tile Cholesky (rsba_amd/csrc/cholesky.hip): W = chol(D)^-1 of one
 // 48 x 48 tile by ONE 256-thread workgroup — the step that sits 42 times on the critical path of a 1k-camera solve.
 // Variants: the lane-per-row blocked potrf + blocked triangular inverse (round 1) and the MFMA-pivot LDL^T form.
@@ -14,7 +17,7 @@ hipError_t allow_dynamic_lds_impl(const void* kernel, size_t bytes) { return hip
 namespace {
 
 template <int VARIANT>
-__global__ __launch_bounds__(256) void tile_kernel(const double* __restrict__ Din, double* __restrict__ Wout, long long* ticks, int reps, long long* stamps) {
+__global__ __launch_bounds__(256, 2) void tile_kernel(const double* __restrict__ Din, double* __restrict__ Wout, long long* ticks, int reps, long long* stamps) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x;
   double* D = smem; double* Wl = smem + kBuf; double* Tm = smem + 2 * kBuf; double* Lp = smem + 3 * kBuf;
