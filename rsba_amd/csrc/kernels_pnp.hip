@@ -18,7 +18,7 @@ namespace rsba {
 
 namespace {
 
-constexpr int kPnpBlock = 64;                 // one wave per workgroup: 2 x 78 x 64 doubles of LDS
+constexpr int kPnpBlock = 64;                 // one wave per workgroup: 78 x 64 doubles of LDS (the normal matrix; its factor is in registers)
 constexpr int kTri = 78;                      // lower triangle of 12 x 12
 __device__ __forceinline__ constexpr int tri(int a, int b) { return a * (a + 1) / 2 + b; }   // a >= b
 
@@ -54,7 +54,6 @@ __device__ __forceinline__ double pnp_linearize(const PnpArgs& A, const Model& m
 __global__ __launch_bounds__(kPnpBlock) void pnp_tasks_kernel(const PnpArgs A) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* H = smem;                              // [78][64]
-  double* L = smem + kTri * kPnpBlock;           // [78][64]
   const int lane = threadIdx.x, h = blockIdx.x * kPnpBlock + lane;
   if (h >= A.num_tasks) return;
   const int32_t* sub = A.subsets + (size_t)h * A.m;
@@ -94,31 +93,43 @@ __global__ __launch_bounds__(kPnpBlock) void pnp_tasks_kernel(const PnpArgs A) {
     }
     reuse_diagonal = true;
     // (Hs + D^2) y = gs, Hs = S H S, gs = S g: Cholesky in L
+    // (the factor lives in registers, every loop spelled out: with ONE wave per SIMD — 16 384 hypotheses are one wave per CU — a
+    // factor in LDS meant ~650 dependent LDS round trips per solve, most of the kernel's time; same operations, same order, same bits)
     bool solved = true;
+    double L[kTri];
+#pragma unroll
     for (int a = 0; a < 12; ++a) {
+#pragma unroll
       for (int b = 0; b <= a; ++b) {
         double v = sc[a] * sc[b] * H[tri(a, b) * kPnpBlock + lane];
         if (a == b) v += diag[a] / radius;
-        for (int k = 0; k < b; ++k) v -= L[tri(a, k) * kPnpBlock + lane] * L[tri(b, k) * kPnpBlock + lane];
-        if (a == b) { if (!(v > 0.0)) solved = false; L[tri(a, a) * kPnpBlock + lane] = sqrt(v); }
-        else L[tri(a, b) * kPnpBlock + lane] = v / L[tri(b, b) * kPnpBlock + lane];
+#pragma unroll
+        for (int k = 0; k < b; ++k) v -= L[tri(a, k)] * L[tri(b, k)];
+        if (a == b) { if (!(v > 0.0)) solved = false; L[tri(a, a)] = sqrt(v); }
+        else L[tri(a, b)] = v / L[tri(b, b)];
       }
     }
+#pragma unroll
     for (int a = 0; a < 12; ++a) {
       double v = sc[a] * g[a];
-      for (int k = 0; k < a; ++k) v -= L[tri(a, k) * kPnpBlock + lane] * y[k];
-      y[a] = v / L[tri(a, a) * kPnpBlock + lane];
+#pragma unroll
+      for (int k = 0; k < a; ++k) v -= L[tri(a, k)] * y[k];
+      y[a] = v / L[tri(a, a)];
     }
+#pragma unroll
     for (int a = 11; a >= 0; --a) {
       double v = y[a];
-      for (int k = a + 1; k < 12; ++k) v -= L[tri(k, a) * kPnpBlock + lane] * y[k];
-      y[a] = v / L[tri(a, a) * kPnpBlock + lane];
+#pragma unroll
+      for (int k = a + 1; k < 12; ++k) v -= L[tri(k, a)] * y[k];
+      y[a] = v / L[tri(a, a)];
     }
     // model_cost_change = gs.y - y^T Hs y / 2
     double gy = 0.0, yHy = 0.0;
+#pragma unroll
     for (int a = 0; a < 12; ++a) {
       gy += sc[a] * g[a] * y[a];
       double row = 0.0;
+#pragma unroll
       for (int b = 0; b < 12; ++b) row += sc[b] * y[b] * H[(a >= b ? tri(a, b) : tri(b, a)) * kPnpBlock + lane];
       yHy += sc[a] * y[a] * row;
     }
@@ -209,7 +220,7 @@ __global__ __launch_bounds__(256) void pnp_inliers_kernel(const PnpArgs A, const
 }  // namespace
 
 hipError_t launch_pnp_tasks(const PnpArgs& A, hipStream_t st) {
-  const size_t lds = (size_t)2 * kTri * kPnpBlock * sizeof(double);
+  const size_t lds = (size_t)kTri * kPnpBlock * sizeof(double);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pnp_tasks_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(pnp_tasks_kernel, dim3((A.num_tasks + kPnpBlock - 1) / kPnpBlock), dim3(kPnpBlock), lds, st, A);
