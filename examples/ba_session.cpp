@@ -63,7 +63,7 @@ static int replay_cache(int argc, char** argv) {
 
 int main(int argc, char** argv) {
   if (argc >= 4 && !std::strcmp(argv[1], "--cache")) return replay_cache(argc, argv);
-  if (argc < 3) { std::fprintf(stderr, "usage: %s scene.bin out.bin [startFrame] [camEvery] [BA|fullBA|windowedBA] [validTracks] [useOnlyValidMatches] [gsEvery]\n", argv[0]); return 2; }
+  if (argc < 3) { std::fprintf(stderr, "usage: %s scene.bin out.bin [startFrame] [camEvery] [BA|fullBA|windowedBA] [validTracks] [useOnlyValidMatches] [gsEvery] [manyEvery lines]\n", argv[0]); return 2; }
   FILE* f = std::fopen(argv[1], "rb");
   if (!f) { std::perror("scene"); return 2; }
   int32_t hd[11]; int64_t N; double huber, reval, covf, motion[3], cam[9];
@@ -111,6 +111,16 @@ int main(int argc, char** argv) {
   const int gsEvery = argc > 8 ? std::atoi(argv[8]) : 0;               // > 0: every gsEvery-th frame has ONE pose (its first): CeresHandler::Add then gives it
   for (int i = 0; gsEvery > 0 && i < F; ++i)                            // the global-shutter functor inside the rolling-shutter session (CeresHandler.h:245-286)
     if (i % gsEvery == gsEvery - 1 && sess.frames[i].poses.size() == 2) sess.frames[i].poses.resize(1);
+  const int manyEvery = argc > 9 ? std::atoi(argv[9]) : 0, lines = argc > 10 ? std::atoi(argv[10]) : 0;   // > 0: every manyEvery-th frame carries `lines` poses,
+  for (int i = 0; manyEvery > 0 && lines > 2 && i < F; ++i)             // one per scan line ("fullDoF": samples of its own motion); Add then gives each observation
+    if (i % manyEvery == manyEvery - 1 && sess.frames[i].poses.size() == 2) {   // the global-shutter functor on getPose's pick (struct/VideoSfM.cc:83-97, CeresHandler.h:266-285)
+      const std::vector<double> a = sess.frames[i].poses[0], b = sess.frames[i].poses[1];
+      sess.frames[i].poses.assign((size_t)lines, a);
+      for (int l = 0; l < lines; ++l) {
+        const double t = (double)l / (lines - 1);   // (numpy.linspace: start + l * step with step = 1 / (lines - 1) — written so that both sides round alike)
+        for (int k = 0; k < 6; ++k) sess.frames[i].poses[l][k] = a[k] * (1 - t) + b[k] * t;
+      }
+    }
   const bool usable = !std::strcmp(entry, "fullBA")       ? fullBA(sess, opt, hd[10], &summary, true, &covs)
                       : !std::strcmp(entry, "windowedBA") ? windowedBA(sess, opt, startFrame, F - 1, hd[10], &summary, true, &covs)
                                                           : BA(sess, startFrame, F - 1, opt, hd[10], &summary, true, &covs);

@@ -28,7 +28,7 @@ struct FrameArgs {
   const double* cam;
   int32_t scan[2];
   FrameArgs(const Session& sess, const Frame& f, const std::vector<const double*>& pts, const std::vector<std::array<double, 2>>& obs) {
-    if (f.poses.empty() || f.poses.size() > 2) throw std::runtime_error("validate/reproject: frames with 1 or 2 poses only");
+    if (f.poses.empty()) throw std::runtime_error("empty frame");   // struct/VideoSfM.cc:105 (more than two poses: one per scan line, picked per item on the device as getPose does, :118-132)
     for (const auto& p : f.poses) poses.insert(poses.end(), p.begin(), p.end());
     cam = (f.__isset.cam ? f.cam : sess.cam).data();
     scan[0] = sess.scanlines[0]; scan[1] = sess.scanlines[1];

@@ -224,7 +224,10 @@ int32_t rsba_reproject(rsba_handle* h, const int32_t* frames, const int32_t* poi
 
 /* The same two filters for ONE frame without a handle — the shape vision::sfm::validate / reproject are called in
  * (CeresHandler.h:220-243: the observations of the frame being added against the tracks' points): cam[9], poses
- * [num_poses][6] (1 or 2), points [n][3], obs_xy [n][2]; valid / ok_out [n], xy_out [n][2]; all host arrays.  Each host
+ * [num_poses][6], points [n][3], obs_xy [n][2]; valid / ok_out [n], xy_out [n][2]; all host arrays.  num_poses 1: that pose;
+ * 2: interpolate_rs at the item's scan line; MORE ("fullDoF", a pose per scan line): the pose getPose picks for the item,
+ * poses[round(clamp(line, 0, num_poses - 1))] with line = x for HORIZONTAL, y otherwise (struct/VideoSfM.cc:118-132) — reproject
+ * re-picks it in every step of its fixed point, as the reference does.  Each host
  * thread keeps one device arena, pinned staging buffer and stream between calls, so a call is one upload, one launch and
  * one download. */
 int32_t rsba_validate_frame(int32_t device, const double* cam, const double* poses, int32_t num_poses, int32_t shutter, const int32_t* scanlines,
@@ -283,8 +286,13 @@ int32_t rsba_set_pose_priors(rsba_handle* h, double rotation, double position, c
  * (getPose(...), point).  Create the problem with poses_per_frame = 2 and flag the one-pose frames here: is_global [num_frames],
  * 1 = the frame's observations use poses[f][0] alone (tau = 0; the validation / reprojection filters follow: getPose returns the
  * single pose, struct/VideoSfM.cc:103-133); the second pose slot of such a frame is not a parameter block — it is held constant and
- * left untouched.  NULL clears the flags.  Call before the first evaluation / solve.  (Frames with MORE than two poses — "fullDoF",
- * a pose per scan line — are not supported.) */
+ * left untouched.  NULL clears the flags.  Call before the first evaluation / solve.
+ * Frames with MORE than two poses ("fullDoF", a pose per scan line; struct/VideoSfM.cc:83-97, CeresHandler.h:266-285) are the same
+ * case once more: an observation of such a frame is a ReprojectionError block over ONE pose block, getPose's pick
+ * poses[round(clamp(line, 0, size - 1))].  Every pose block that some observation picks is a "frame" of the flat problem (one-pose
+ * problem, or a flagged frame of a two-pose one), obs_frame names it, pose blocks nobody picks are not part of the problem — as in
+ * Ceres, which never hears of them.  include/rsba/ceres_handler.hpp (getPose + the facade's block-address lowering) and
+ * rsba_amd/problem.py::lower_scanline_poses do exactly this. */
 int32_t rsba_set_global_shutter_frames(rsba_handle* h, const uint8_t* is_global);
 
 /* The symbolic phase of a handle's first solve works in ~40 bytes of host memory per observation.  That scratch is kept by the

@@ -327,6 +327,26 @@ def validate_obs(cam, poses, shutter, scan, X, obs, sq_threshold, min_dist, inte
                                        C.c_int32(int(interp_rotation)), _ptr(_v(X)), _ptr(_v(obs)), C.c_double(sq_threshold), C.c_double(min_dist)))
 
 
+def scanline_pose_index(nposes, shutter, obs):
+    """struct/VideoSfM.cc:83-97: the pose a frame with more than two poses ("fullDoF") lends to an observation."""
+    return int(lib().orc_scanline_pose_index(C.c_int32(nposes), C.c_int32(shutter), _ptr(_v(obs))))
+
+
+def add_loop_pose_blocks(frame_poses, obs_frame, obs_xy, shutter):
+    """Which pose blocks CeresHandler::Add hands to Ceres for the observations of a session whose frames carry 1, 2 or MORE poses
+    (CeresHandler.h:245-286), as a list `blocks` of (frame, pose index or None) in the order Ceres first sees them and, per
+    observation, the index into it.  A two-pose frame is one entry (frame, None): RsBundleAdjustment over both poses; a one-pose
+    frame is (frame, 0); a frame with more contributes getPose's pick per observation — poses nobody picks never reach Ceres."""
+    blocks, index, which = [], {}, []
+    for f, xy in zip(obs_frame, obs_xy):
+        n = len(frame_poses[f])
+        key = (int(f), None) if n == 2 else (int(f), 0 if n == 1 else scanline_pose_index(n, shutter, xy))
+        if key not in index:
+            index[key] = len(blocks); blocks.append(key)
+        which.append(index[key])
+    return blocks, np.asarray(which, dtype=np.int32)
+
+
 class CeresStyleEvaluator:
     """CPU baseline: one heap-allocated cost object per observation, evaluated through Dual<K> by an
     OpenMP parallel-for over residual blocks — how Ceres' evaluator runs rsba's functors

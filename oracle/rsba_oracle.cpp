@@ -1008,6 +1008,7 @@ double orc_norm3(const double v[3]) { return norm3(v); }
 void orc_interpolate_rs(const double p0[6], const double p1[6], int32_t shutter, const int32_t scan[2], const double obs[2], int32_t ir, double out[6]) {
   const int sc[2] = {scan[0], scan[1]}; interpolate_rs(p0, p1, shutter, sc, obs, out, ir != 0); }
 void orc_huber(double a, double s, double rho[3]) { huber(a, s, rho); }
+int32_t orc_scanline_pose_index(int32_t nposes, int32_t shutter, const double obs[2]) { return scanline_pose_index(nposes, shutter, obs); }
 int32_t orc_reproject(const double cam[9], const double* poses, int32_t nposes, int32_t shutter, const int32_t scan[2], int32_t ir, const double X[3], double sq, double obs[2]) {
   const int sc[2] = {scan[0], scan[1]}; return reproject(cam, poses, nposes, shutter, sc, ir != 0, X, sq, obs); }
 int32_t orc_validate_obs(const double cam[9], const double* poses, int32_t nposes, int32_t shutter, const int32_t scan[2], int32_t ir, const double X[3], const double obs[2], double sq, double md) {

@@ -150,7 +150,9 @@ double orc_norm3(const double v[3]);
 void orc_interpolate_rs(const double p0[6], const double p1[6], int32_t shutter, const int32_t scan[2],
                         const double obs[2], int32_t interp_rotation, double out[6]);
 void orc_huber(double a, double s, double rho[3]);
-/* struct/VideoSfM.cc:139-155 reproject; :159-169 validate */
+/* struct/VideoSfM.cc:83-97 getPose, frames with more than two poses: index of the pose an observation uses */
+int32_t orc_scanline_pose_index(int32_t nposes, int32_t shutter, const double obs[2]);
+/* struct/VideoSfM.cc:139-155 reproject; :159-169 validate (nposes 1, 2 or more: getPose's three cases) */
 int32_t orc_reproject(const double cam[9], const double* poses, int32_t nposes, int32_t shutter, const int32_t scan[2],
                       int32_t interp_rotation, const double X[3], double sq_threshold, double obs[2]);
 int32_t orc_validate_obs(const double cam[9], const double* poses, int32_t nposes, int32_t shutter, const int32_t scan[2],

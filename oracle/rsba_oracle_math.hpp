@@ -355,11 +355,23 @@ inline bool rs_residual(const T cam[kCam], const T p0[kPose], const T p1[kPose],
   return gs_residual(cam, pose, X, ox, oy, res, validate);   // validate = false: solveRSpnp.cpp:67 (RsBA)
 }
 
-// struct/VideoSfM.cc:103-133 getPose (copying overload), 1- and 2-pose cases: the non-autodiff twin
+// struct/VideoSfM.cc:83-97 = :118-132, the `default:` branch of both getPose overloads — a frame with MORE than two poses
+// carries one per scan line ("fullDoF") and an observation uses the pose of its rounded, clamped line:
+//   line = obs[0] if sess.rs == HORIZONTAL else obs[1]   (so VERTICAL *and* GLOBAL read y);
+//   line < 0 -> 0;  line > size - 1 -> size - 1 (size_t converted to double);  poses[round(line)]  (halves away from zero)
+inline int scanline_pose_index(int nposes, int shutter, const double obs[2]) {
+  double line = (shutter == HORIZONTAL) ? obs[0] : obs[1];
+  if (line < 0) line = 0;
+  else if (line > (double)(nposes - 1)) line = (double)(nposes - 1);
+  return (int)std::round(line);
+}
+
+// struct/VideoSfM.cc:103-133 getPose (copying overload): the non-autodiff twin
 // used by reproject/validate; unlike the functor it feeds the TRUE (x,y) to interpolate_rs.
 inline void frame_pose_at(const double* poses, int nposes, int shutter, const int scan[2], const double obs[2],
                           bool interp_rotation, double out[kPose]) {
   if (nposes == 1) { for (int i = 0; i < kPose; ++i) out[i] = poses[i]; return; }
+  if (nposes > 2) { const double* q = poses + (size_t)kPose * scanline_pose_index(nposes, shutter, obs); for (int i = 0; i < kPose; ++i) out[i] = q[i]; return; }
   interpolate_rs(poses, poses + kPose, shutter, scan, obs, out, interp_rotation);
 }
 

@@ -14,8 +14,19 @@ namespace rsba {
 namespace {
 
 // interpolate_rs with the true observation (mat/cam.h:315-349): pose at the observation's scan line
+// P == 0: a frame with MORE than two poses — one per scan line ("fullDoF"): the pose whose index is the rounded, clamped scan
+// line of the observation (struct/VideoSfM.cc:118-132: x for HORIZONTAL, y otherwise — a GLOBAL session included; std::round,
+// halves away from zero); np = f.poses.size()
 template <int P>
-__device__ __forceinline__ void pose_at(const Model& m, const double* __restrict__ poses, double ox, double oy, double out[6]) {
+__device__ __forceinline__ void pose_at(const Model& m, const double* __restrict__ poses, double ox, double oy, double out[6], int np = P) {
+  if (P == 0) {
+    double line = (m.shutter == kHorizontal) ? ox : oy;
+    if (line < 0.0) line = 0.0; else if (line > double(np - 1)) line = double(np - 1);
+    const double* q = poses + 6 * (size_t)round(line);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) out[k] = q[k];
+    return;
+  }
   if (P == 1 || m.shutter == kGlobal) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) out[k] = poses[k];
@@ -51,7 +62,7 @@ __global__ __launch_bounds__(256) void validate_kernel(const DeviceProblem dp, d
   for (int k = 0; k < 9; ++k) camr[k] = cam[k];
 #pragma unroll
   for (int k = 0; k < 3; ++k) X[k] = dp.points[(size_t)j * 3 + k];
-  pose_at<P>(m, dp.poses + (size_t)f * 6 * P, xy.x, xy.y, pose);
+  pose_at<P>(m, dp.poses + (size_t)f * 6 * dp.P, xy.x, xy.y, pose, dp.P);
   const double dx = pose[3] - X[0], dy = pose[4] - X[1], dz = pose[5] - X[2];
   const bool far_enough = sqrt(dx * dx + dy * dy + dz * dz) >= min_distance;          // VideoSfM.cc:164-167
   const bool ok = project(camr, pose, X, proj);
@@ -78,10 +89,10 @@ __global__ __launch_bounds__(256) void reproject_kernel(const DeviceProblem dp, 
   for (;;) {
     if (--limit < 1) { ok = false; break; }                              // :146
     const double px = proj[0], py = proj[1];
-    pose_at<P>(m, dp.poses + (size_t)f * 6 * P, px, py, pose);            // :148
+    pose_at<P>(m, dp.poses + (size_t)f * 6 * dp.P, px, py, pose, dp.P);   // :148
     if (!project(camr, pose, X, proj)) { ok = false; break; }            // :149
     const double mx = px - proj[0], my = py - proj[1];
-    if (!(P > 1 && mx * mx + my * my > 1e-6)) break;                      // :151
+    if (!(P != 1 && mx * mx + my * my > 1e-6)) break;                     // :151 (f.poses.size() > 1)
   }
   xy_out[i] = make_double2(proj[0], proj[1]);
   ok_out[i] = ok ? 1 : 0;   // the closing validate (:154) compares the projection with itself: true whenever w2i succeeded
@@ -113,14 +124,16 @@ hipError_t launch_scatter_flags(const uint8_t* in, const int64_t* order, int64_t
 hipError_t launch_validate(const DeviceProblem& dp, double sq_threshold, double min_distance, uint8_t* valid, hipStream_t st) {
   if (dp.N <= 0) return hipSuccess;
   const int grid = (int)((dp.N + 255) / 256);
-  if (dp.P == 2) hipLaunchKernelGGL(validate_kernel<2>, dim3(grid), dim3(256), 0, st, dp, sq_threshold, min_distance, valid);
+  if (dp.P > 2) hipLaunchKernelGGL(validate_kernel<0>, dim3(grid), dim3(256), 0, st, dp, sq_threshold, min_distance, valid);   // (stateless per-frame calls only: a handle has 1 or 2)
+  else if (dp.P == 2) hipLaunchKernelGGL(validate_kernel<2>, dim3(grid), dim3(256), 0, st, dp, sq_threshold, min_distance, valid);
   else hipLaunchKernelGGL(validate_kernel<1>, dim3(grid), dim3(256), 0, st, dp, sq_threshold, min_distance, valid);
   return hipGetLastError();
 }
 hipError_t launch_reproject(const DeviceProblem& dp, const int32_t* frames, const int32_t* points, int64_t n, double* xy_out, uint8_t* ok_out, hipStream_t st) {
   if (n <= 0) return hipSuccess;
   const int grid = (int)((n + 255) / 256);
-  if (dp.P == 2) hipLaunchKernelGGL(reproject_kernel<2>, dim3(grid), dim3(256), 0, st, dp, frames, points, n, reinterpret_cast<double2*>(xy_out), ok_out);
+  if (dp.P > 2) hipLaunchKernelGGL(reproject_kernel<0>, dim3(grid), dim3(256), 0, st, dp, frames, points, n, reinterpret_cast<double2*>(xy_out), ok_out);
+  else if (dp.P == 2) hipLaunchKernelGGL(reproject_kernel<2>, dim3(grid), dim3(256), 0, st, dp, frames, points, n, reinterpret_cast<double2*>(xy_out), ok_out);
   else hipLaunchKernelGGL(reproject_kernel<1>, dim3(grid), dim3(256), 0, st, dp, frames, points, n, reinterpret_cast<double2*>(xy_out), ok_out);
   return hipGetLastError();
 }

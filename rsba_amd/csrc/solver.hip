@@ -234,8 +234,7 @@ struct PhaseScope {
 // Symbolic phase: frame / point adjacency, the per-block pair lists of the reduced camera system and
 // the tile-level fill pattern of its Cholesky factor.  Ceres does the equivalent in its preprocessor
 // (block structure detection, Schur ordering, CHOLMOD analyse) — SURVEY Appendix C.4.
-int32_t build_solver(rsba_handle* h) {
-  if (h->solver) return RSBA_OK;
+int32_t build_solver_impl(rsba_handle* h) {
   const DeviceProblem& dp = h->dp;
   Solver* s = new Solver();
   h->solver = s;   // owned by the handle from here on (freed by rsba_destroy_solver)
@@ -365,6 +364,7 @@ int32_t build_solver(rsba_handle* h) {
     });
   }
   sv.ngroups = (int64_t)g_tile.size();
+  if (std::getenv("RSBA_TEST_FAIL_PLAN")) return rsba_set_error(RSBA_ERR_UNSUPPORTED, "RSBA_TEST_FAIL_PLAN: the plan was made to fail (test hook)");   // after the uploader has started
   if ((sv.ngroups + 1) * (int64_t)kTile * 3 >= ((int64_t)1 << 32)) return rsba_set_error(RSBA_ERR_UNSUPPORTED, "more than 2^32 doubles of P records: the Schur kernel indexes them with 32 bits");
   up.upload_const_ref(&sv.slot_gpos, slot_gpos);
   const bool dense_keys = (int64_t)nt * nt <= (int64_t)1 << 26;
@@ -1054,6 +1054,19 @@ int32_t build_solver(rsba_handle* h) {
   HIP_TRY(hipStreamSynchronize(h->stream));   // the plan's one-time fills and scatters are done whatever stream the solves will run on
   tick("device fills");
   if (dbg_plan) std::fprintf(stderr, "[rsba plan] host phases:%s\n", phases.c_str());
+  return RSBA_OK;
+}
+
+// A plan that failed half-way (out of memory, an unsupported size) must not be taken for a finished one by the next call: the
+// half-built solver is torn down again, so that a retry builds — and fails — afresh instead of launching kernels on null tables.
+int32_t build_solver(rsba_handle* h) {
+  if (h->solver) return RSBA_OK;
+  const int32_t rc = build_solver_impl(h);
+  if (rc != RSBA_OK) {
+    const std::string why = rsba_last_error();   // (the teardown must not lose what went wrong)
+    rsba_destroy_solver(h);
+    return rsba_set_error(rc, why.c_str());
+  }
   return RSBA_OK;
 }
 

@@ -147,3 +147,56 @@ def apply_gauge_masks(prob: BAProblem, *, fix_first_n_cameras: int = 0, fix_scal
         pc[old] = 1
     prob.point_constant = pc
     return prob
+
+
+def lower_scanline_poses(frame_poses, obs_frame, obs_point, obs_xy, *, shutter: int = HORIZONTAL, **problem_kw):
+    """Flat problem of a session whose frames carry one, two or MORE poses.
+
+    CeresHandler::Add picks the functor per frame by ``f.poses.size()`` (src/rsba/CeresHandler.h:245-286): two poses ->
+    RsBundleAdjustment over both; otherwise ReprojectionError over ONE pose block, ``getPose(sess, f, opt, obs)``
+    (src/rsba/struct/VideoSfM.cc:75-99) — for a frame with more than two poses ("fullDoF", a pose per scan line) that is
+    ``poses[round(clamp(line, 0, size - 1))]`` with ``line`` = x for a HORIZONTAL shutter, y otherwise.  Every pose block that
+    some observation picks becomes a frame of the flat problem (flagged ``frame_global`` when the session also has two-pose
+    frames: its second slot is a constant copy); the others never reach the solver, as they never reach Ceres.
+
+    ``frame_poses``: sequence of [P_f, 6] arrays.  Returns ``(problem, blocks)``; ``blocks[d] = (frame, pose index)`` of flat
+    frame d, pose index -1 for a two-pose frame.  Flat frames are numbered in the order the observations first use them.
+    """
+    obs_frame = np.asarray(obs_frame, dtype=np.int64).reshape(-1)
+    obs_xy = np.asarray(obs_xy, dtype=np.float64).reshape(-1, 2)
+    sizes = np.array([len(p) for p in frame_poses], dtype=np.int64)
+    assert sizes.min() >= 1, "empty frame"                               # getPose throws (VideoSfM.cc:77)
+    n_of = sizes[obs_frame]
+    line = obs_xy[:, 0] if shutter == HORIZONTAL else obs_xy[:, 1]
+    line = np.where(line < 0, 0.0, np.where(line > n_of - 1, (n_of - 1).astype(np.float64), line))
+    low = np.floor(line)
+    pick = (low + (line - low >= 0.5)).astype(np.int64)                  # std::round: halves away from zero (line >= 0 here)
+    pick = np.where(n_of == 2, -1, np.where(n_of == 1, 0, pick))
+    key = obs_frame * (int(sizes.max()) + 1) + pick + 1
+    _, first, inverse = np.unique(key, return_index=True, return_inverse=True)
+    order = np.argsort(first, kind="stable")                             # flat frames in the order the observations first use them
+    rank = np.empty_like(order); rank[order] = np.arange(len(order))
+    flat_of_obs = rank[inverse]
+    blocks = np.stack([obs_frame[first[order]], pick[first[order]]], axis=1)
+    P = 2 if (sizes == 2).any() else 1
+    poses = np.zeros((len(blocks), P, 6))
+    frame_global = np.zeros(len(blocks), dtype=np.uint8)
+    for d, (f, q) in enumerate(blocks):
+        fp = np.asarray(frame_poses[f], dtype=np.float64).reshape(-1, 6)
+        if q < 0:
+            poses[d] = fp
+        else:
+            poses[d, :] = fp[q]
+            frame_global[d] = 1
+    prob = BAProblem(poses=poses, obs_xy=obs_xy, obs_frame=flat_of_obs.astype(np.int32), obs_point=obs_point, shutter=shutter,
+                     frame_global=frame_global if (P == 2 and frame_global.any()) else None, **problem_kw)
+    return prob, blocks
+
+
+def scatter_scanline_poses(prob: BAProblem, blocks, frame_poses) -> None:
+    """The solved pose blocks of ``lower_scanline_poses`` back into the session's per-frame pose arrays (in place)."""
+    for d, (f, q) in enumerate(blocks):
+        if q < 0:
+            frame_poses[f][:] = prob.poses[d]
+        else:
+            frame_poses[f][q] = prob.poses[d, 0]

@@ -415,3 +415,24 @@ def test_ragged_scenes_and_degenerate_programs(capi, oracle):
     # (15 unknowns, 6 residuals: the normal equations are singular but for the damping, so rounding is amplified — the step-by-step
     # 1e-9 does not apply; the contract on the final cost does)
     compare_solves(capi, oracle, one, iters=8, final_tol=1e-6, expect_same_path=False)
+
+
+def test_a_failed_plan_is_torn_down_and_a_retry_fails_or_succeeds_afresh(capi, monkeypatch):
+    """A symbolic phase that fails half-way (out of memory, an unsupported size; here RSBA_TEST_FAIL_PLAN) must not leave a half-built
+    solver behind that the next call takes for a finished one (it would launch kernels on null tables): every retry reports the
+    error again, and once the cause is gone the same handle plans and solves as a fresh one does."""
+    p = small_scene(frames=12, points=500)
+    q = p.copy()
+    with capi.DeviceProblem(q) as dp:
+        s_ref, _ = dp.solve(capi.default_options(max_num_iterations=5))
+    with capi.DeviceProblem(p) as dp:
+        monkeypatch.setenv("RSBA_TEST_FAIL_PLAN", "1")
+        for _ in range(2):
+            with pytest.raises(capi.RsbaError, match="RSBA_TEST_FAIL_PLAN"):
+                dp.solve(capi.default_options(max_num_iterations=5))
+        with pytest.raises(capi.RsbaError, match="RSBA_TEST_FAIL_PLAN"):
+            dp.plan_stats()
+        monkeypatch.delenv("RSBA_TEST_FAIL_PLAN")
+        s, _ = dp.solve(capi.default_options(max_num_iterations=5))
+    assert s.final_cost == s_ref.final_cost and s.num_iterations == s_ref.num_iterations
+    assert np.array_equal(p.poses, q.poses) and np.array_equal(p.points, q.points)
