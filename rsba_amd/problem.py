@@ -188,8 +188,11 @@ def lower_scanline_poses(frame_poses, obs_frame, obs_point, obs_xy, *, shutter: 
         else:
             poses[d, :] = fp[q]
             frame_global[d] = 1
+    mask = np.zeros((len(blocks), P), dtype=np.uint8)
+    if P == 2:
+        mask[frame_global == 1, 1] = 0x3F                                # the second slot of a one-pose flat frame is data, not a block
     prob = BAProblem(poses=poses, obs_xy=obs_xy, obs_frame=flat_of_obs.astype(np.int32), obs_point=obs_point, shutter=shutter,
-                     frame_global=frame_global if (P == 2 and frame_global.any()) else None, **problem_kw)
+                     frame_global=frame_global if (P == 2 and frame_global.any()) else None, pose_fixed_mask=mask, **problem_kw)
     return prob, blocks
 
 

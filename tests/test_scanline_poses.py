@@ -112,7 +112,7 @@ def test_frame_filters_with_a_pose_per_scan_line(capi, oracle, shutter):
     pts = p.points[p.obs_point[sel]].copy()
     pts[::17, 2] = -4.0                                      # some items fail in w2i
     cam = p.intrinsics[0].copy()
-    cam[[7, 8]] = [16.0, 16.0]; cam[[0, 1]] = [20.0, 20.0]   # a 32 x 32 "image": projections land on scan lines 0 .. 32 and beyond
+    cam[[7, 8]] = [16.0, 16.0]; cam[[0, 1]] = [30.0, 60.0]   # a 32 x 32 "image": projections land on scan lines 0 .. 32 and beyond, in x and in y
     xy, ok = capi.reproject_frame(cam, poses, shutter, (0, 32), pts)
     nfail = nclamp = 0
     for n in range(len(pts)):
@@ -145,9 +145,7 @@ def test_session_with_pose_per_scan_line_frames_solves_to_the_oracles_trajectory
     want, which = oracle.add_loop_pose_blocks(fp, p0.obs_frame, p0.obs_xy, HORIZONTAL)
     assert len(want) == len(blocks) and np.array_equal(which, prob.obs_frame)
     assert prob.num_frames > 40 and prob.frame_global.sum() == prob.num_frames - sum(len(q) == 2 for q in fp)
-    mask = np.zeros((prob.num_frames, prob.poses_per_frame), dtype=np.uint8)
-    mask[blocks[:, 0] == 0] = 0x3F                                    # fixFirstNCameras = 1 (CeresHandler.h:282-285,342-348)
-    prob.pose_fixed_mask = mask
+    prob.pose_fixed_mask[blocks[:, 0] == 0] = 0x3F                    # fixFirstNCameras = 1 (CeresHandler.h:282-285,342-348)
     p_dev, p_cpu = prob.copy(), prob.copy()
     opts = dict(max_num_iterations=8)
     with capi.DeviceProblem(p_dev) as dp:
@@ -204,8 +202,7 @@ def test_ba_of_a_session_with_pose_per_scan_line_frames_through_the_host_side(ca
     fp = scanline_session(p, every, 0)     # the session the program built: the same sampling of each third frame's motion
     prob, blocks = lower_scanline_poses(fp, p.obs_frame, p.obs_point, p.obs_xy, shutter=p.shutter, points=p.points.copy(), intrinsics=p.intrinsics.copy(),
                                         scanlines=p.scanlines)
-    mask = np.zeros((prob.num_frames, 2), dtype=np.uint8); mask[blocks[:, 0] == 0] = 0x3F
-    prob.pose_fixed_mask = mask
+    prob.pose_fixed_mask[blocks[:, 0] == 0] = 0x3F
     s_ref, _ = oracle.solve(prob, oracle.default_options(max_num_iterations=8))
     assert head[5] == 1.0 and int(head[3]) == s_ref.num_residual_blocks_reduced
     assert abs(head[0] - s_ref.initial_cost) <= 1e-12 * s_ref.initial_cost
