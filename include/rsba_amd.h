@@ -206,6 +206,11 @@ typedef struct rsba_plan_stats {
   int64_t exchange_doubles;                         /* payload (2) of the multi-GPU exchange: the structurally non-zero tiles of S + rhs */
   int64_t schur_groups;                             /* (point, frame tile) groups of P records: 3 x 48 doubles each */
   int64_t schur_mfma_issued, schur_launches;        /* fp64 MFMAs (2048 flop each) the Schur kernel issued so far — all-zero operand blocks are skipped — over so many launches */
+  int64_t sharded_factorisation;                    /* 1: several ranks, each factoring its own part of the elimination tree (the points follow rsba_partition_points);
+                                                     * exchange_doubles is then the separators' tiles | their rhs rows | the gather of the camera step */
+  int64_t separator_tiles, separator_factor_tiles;  /* tile columns in the separators all ranks share, and tiles of the factor inside them (what exchange (2) carries) */
+  int64_t local_tasks, separator_tasks;             /* Cholesky tasks of this rank's part (forward) / of the separators incl. both backward solves */
+  int64_t local_levels, separator_levels;           /* the two dependency chains: elimination levels inside this rank's part / levels that hold a separator column */
 } rsba_plan_stats;
 int32_t rsba_get_plan_stats(rsba_handle* h, rsba_plan_stats* out);   /* runs the symbolic phase if it has not run yet */
 
@@ -346,6 +351,16 @@ int32_t rsba_set_block_structure(rsba_handle* h, const uint8_t* mask, const int6
  * the first solve; the co-visibility masks are OR-ed and the per-frame counts summed through the all-reduce itself, and
  * the partition is checked (RSBA_ERR_INVALID_ARGUMENT when some point has observations on more than one rank). */
 int32_t rsba_sync_block_structure(rsba_handle* h);
+
+/* Which rank should own which point: owner [num_points] (host array), computed on the host from the WHOLE problem's description
+ * (no device needed; every rank of a job computes the same answer from the same description).  Any by-point partition gives a
+ * correct sharded solve; THIS one places the cut along the top separators of the nested dissection that orders the reduced camera
+ * system's 48 x 48 tile columns: every rank's points then touch the tiles of its own subtree (and the separators) only, the columns
+ * of its subtree are complete on that rank, and the solver factors them there — exchange (2) shrinks from every non-zero tile of S
+ * to the separators' tiles, the factorisation's work is shared out (rsba_plan_stats.sharded_factorisation says whether the plan
+ * took that form).  world == 1: all zero.  num_top_tiles (may be NULL): tile columns in the separators the ranks share.
+ * RSBA_ERR_UNSUPPORTED when the co-visibility graph cannot be cut into `world` parts (a handful of frames, or not connected). */
+int32_t rsba_partition_points(const rsba_problem_desc* desc, int32_t world, int32_t* owner, int32_t* num_top_tiles);
 
 /* Native transport: RCCL's ncclAllReduce over xGMI, issued by the solver on its own HIP stream — nothing of the host
  * language runs inside an LM iteration.  librccl is resolved at run time (RSBA_RCCL_LIB, else an RCCL already loaded in

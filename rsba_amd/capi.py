@@ -25,6 +25,7 @@ EXPORTS = [
     "rsba_pnp_tasks", "rsba_pnp_inliers", "rsba_set_inter_frame_ratio_free", "rsba_get_inter_frame_ratio",
     "rsba_sync_block_structure", "rsba_rccl_get_unique_id", "rsba_rccl_comm_create", "rsba_rccl_comm_destroy", "rsba_set_exchange_rccl",
     "rsba_get_phase_times", "rsba_phase_name", "rsba_get_plan_stats", "rsba_validate_frame", "rsba_reproject_frame", "rsba_set_pose_priors", "rsba_set_global_shutter_frames", "rsba_release_host_scratch",
+    "rsba_partition_points",
 ]
 NUM_PHASES = 13
 
@@ -93,7 +94,9 @@ class PhaseTimes(C.Structure):
 
 class PlanStats(C.Structure):
     _fields_ = [(k, C.c_int64) for k in ("tiles", "factor_tiles", "levels", "tasks", "schur_entries", "schur_chunks", "schur_block_products",
-                                         "cholesky_flops", "exchange_doubles", "schur_groups", "schur_mfma_issued", "schur_launches")]
+                                         "cholesky_flops", "exchange_doubles", "schur_groups", "schur_mfma_issued", "schur_launches",
+                                         "sharded_factorisation", "separator_tiles", "separator_factor_tiles", "local_tasks", "separator_tasks",
+                                         "local_levels", "separator_levels")]
 
 
 def build(force: bool = False) -> str:
@@ -164,6 +167,16 @@ def make_desc(prob: BAProblem) -> ProblemDesc:
     d.intrinsics_constant = _ptr(prob.intrinsics_constant)
     d.huber_a = float(prob.huber_a)
     return d
+
+
+def partition_points(prob: BAProblem, world: int):
+    """rsba_partition_points: owner[num_points] of a sharded solve whose reduced camera system can be factored where it is formed
+    (host only; every rank computes the same answer from the whole problem) and the number of tile columns in the shared separators."""
+    d = make_desc(prob)
+    owner = np.zeros(prob.num_points, dtype=np.int32)
+    ntop = C.c_int32(0)
+    _check(lib().rsba_partition_points(C.byref(d), C.c_int32(world), _ptr(owner), C.byref(ntop)))
+    return owner, int(ntop.value)
 
 
 def release_host_scratch():

@@ -1286,14 +1286,14 @@ __global__ __launch_bounds__(256) void chol_residual_kernel(const SolverDev sv, 
 // flag = 1 when some |res_t| exceeds tol * den_t (NaN included) although no pivot failed; res / den are zeroed for the next solve.
 // The flag is STICKY: a clean solve leaves it alone, so that several solves between two host reads (the free interFrameRatio's
 // second right-hand side, the columns of a covariance block) cannot mask each other; the host clears it before the first one.
-__global__ __launch_bounds__(1024) void chol_residual_check_kernel(const SolverDev sv, double* res, double* den, double tol, double* flag) {
+__global__ __launch_bounds__(1024) void chol_residual_check_kernel(const SolverDev sv, double* res, double* den, double tol, double* flag, const uint8_t* __restrict__ row_mine) {
   __shared__ int s_bad;
   if (threadIdx.x == 0) s_bad = 0;
   __syncthreads();
   bool bad = false;
   for (int64_t t = threadIdx.x; t < sv.npad; t += 1024) {
     const double rr = fabs(res[t]), d = den[t];
-    if (!(rr <= tol * d) && !(rr == 0.0)) bad = true;
+    if (!(rr <= tol * d) && !(rr == 0.0) && (!row_mine || row_mine[t / T])) bad = true;
     res[t] = 0.0; den[t] = 0.0;
   }
   if (bad) s_bad = 1;
@@ -1303,9 +1303,9 @@ __global__ __launch_bounds__(1024) void chol_residual_check_kernel(const SolverD
 
 }  // namespace
 
-hipError_t launch_chol_verify(const SolverDev& sv, const int32_t* slot_tiles, const double* b_rhs, double* res, double* den, double tol, double* flag, hipStream_t st) {
+hipError_t launch_chol_verify(const SolverDev& sv, const int32_t* slot_tiles, const double* b_rhs, double* res, double* den, double tol, double* flag, hipStream_t st, const uint8_t* row_mine) {
   hipLaunchKernelGGL(chol_residual_kernel, dim3(sv.nslots), dim3(256), 0, st, sv, slot_tiles, b_rhs, res, den);
-  hipLaunchKernelGGL(chol_residual_check_kernel, dim3(1), dim3(1024), 0, st, sv, res, den, tol, flag);
+  hipLaunchKernelGGL(chol_residual_check_kernel, dim3(1), dim3(1024), 0, st, sv, res, den, tol, flag, row_mine);
   return hipGetLastError();
 }
 

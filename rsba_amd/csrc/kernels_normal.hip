@@ -589,11 +589,12 @@ __global__ __launch_bounds__(256) void schur_merge_kernel(const DeviceProblem dp
     for (int u = 0; ch < c1; ++ch, ++u) ps[u] += sv.schur_part[(size_t)sv.tp_chunk_list[ch] * pstride + e];
     const double sum = ((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7]));
     double val;
-    if (a >= sv.Fx || b >= sv.Fx) val = (a == b && r == c && sv.lead) ? 1.0 : 0.0;     // padding frames of the last tile
+    const bool lead = sv.frame_lead ? sv.frame_lead[a] != 0.0 : sv.lead != 0;   // does this rank add the frame's replicated terms (sharded factorisation: the owner of its part)
+    if (a >= sv.Fx || b >= sv.Fx) val = (a == b && r == c && lead) ? 1.0 : 0.0;     // padding frames of the last tile
     else {
       const int64_t add = sv.tp_add[((size_t)tp * FT + x) * FT + y];
       val = (add >= 0 ? sv.U[add + (size_t)r * CD + c] : 0.0) - sum;
-      if (a == b && r == c && sv.lead) val += sv.diag_c[(size_t)a * CD + r] * inv_radius;
+      if (a == b && r == c && lead) val += sv.diag_c[(size_t)a * CD + r] * inv_radius;
     }
     if (trans) dst[(size_t)ct * kTile + rt] = val; else dst[e] = val;
   }
@@ -607,7 +608,8 @@ __global__ __launch_bounds__(256) void schur_merge_kernel(const DeviceProblem dp
     }
     for (int u = 0; ch < c1; ++ch, ++u) ps[u] += sv.schur_part[(size_t)sv.tp_chunk_list[ch] * pstride + kTile * kTile + tid];
     const double sum = ((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7]));
-    sv.rhs[(size_t)I * kTile + tid] = (a < sv.Fx) ? (sv.lead ? sv.gc[(size_t)I * kTile + tid] : 0.0) - sum : 0.0;
+    const bool lead = sv.frame_lead ? sv.frame_lead[a] != 0.0 : sv.lead != 0;
+    sv.rhs[(size_t)I * kTile + tid] = (a < sv.Fx) ? (lead ? sv.gc[(size_t)I * kTile + tid] : 0.0) - sum : 0.0;
   }
 }
 
@@ -1231,6 +1233,48 @@ hipError_t launch_candidate(const DeviceProblem& dp, const SolverDev& sv, hipStr
 // factor's layout (44 % of the packed tiles at 1k cameras) are zero on every rank.  pack: buf[b] = S tile slots[b], then the rhs;
 // unpack: the reverse.  One workgroup per tile, the last one takes the rhs.
 namespace {
+// ---- sharded factorisation (solver.hip: solve_reduced_system): the exchange between its two launches ----
+// Every rank has factored the columns of its own part; what its part subtracts from the separators' tiles sits in the partial tiles
+// of its UPDATE items (cells of the persistent Cholesky, complete: the launch is over).  Separator tile t of this rank's share:
+//   buf[t] = S_t (its partial from its own points; zero for a fill-only tile) - sum of ITS partial tiles, in list order
+// and for a diagonal tile the same for its rows of the right-hand side — the forward solve rides along.  The all-reduce of buf over
+// the ranks is the separators' system with every part eliminated; top_unpack puts it where the second launch reads S and rhs.
+__global__ __launch_bounds__(256) void top_assemble_kernel(const SolverDev sv, const int32_t* __restrict__ slots, const int32_t* __restrict__ info,
+                                                           const int32_t* __restrict__ asm_ptr, const int32_t* __restrict__ asm_list, const int32_t* __restrict__ top_tiles,
+                                                           int ntop_slots, double* __restrict__ buf) {
+  const int t = blockIdx.x, tid = threadIdx.x;
+  const int slot = slots[t], has_pair = info[2 * t], rhs_row = info[2 * t + 1];
+  const int p0 = asm_ptr[t], p1 = asm_ptr[t + 1];
+  const double* S = sv.S + (size_t)slot * (kTile * kTile);
+  constexpr size_t pstride = kTile * kTile + kTile;
+  for (int e = tid; e < kTile * kTile; e += 256) {
+    double v = has_pair ? S[e] : 0.0;
+    for (int p = p0; p < p1; ++p) v -= sv.chol_part[(size_t)asm_list[p] * pstride + e];
+    buf[(size_t)t * (kTile * kTile) + e] = v;
+  }
+  if (rhs_row >= 0 && tid < kTile) {
+    double v = sv.rhs[(size_t)top_tiles[rhs_row] * kTile + tid];
+    for (int p = p0; p < p1; ++p) v -= sv.chol_part[(size_t)asm_list[p] * pstride + kTile * kTile + tid];
+    buf[(size_t)ntop_slots * (kTile * kTile) + (size_t)rhs_row * kTile + tid] = v;
+  }
+}
+__global__ __launch_bounds__(256) void top_unpack_kernel(const SolverDev sv, const int32_t* __restrict__ slots, const int32_t* __restrict__ info, const int32_t* __restrict__ top_tiles,
+                                                         int ntop_slots, const double* __restrict__ buf) {
+  const int t = blockIdx.x, tid = threadIdx.x;
+  double* S = sv.S + (size_t)slots[t] * (kTile * kTile);
+  for (int e = tid; e < kTile * kTile; e += 256) S[e] = buf[(size_t)t * (kTile * kTile) + e];
+  const int rhs_row = info[2 * t + 1];
+  if (rhs_row >= 0 && tid < kTile) sv.rhs[(size_t)top_tiles[rhs_row] * kTile + tid] = buf[(size_t)ntop_slots * (kTile * kTile) + (size_t)rhs_row * kTile + tid];
+}
+// the gather of the camera step: ybuf = y on the rows this rank contributes (its part; rank 0: the separators), zero elsewhere — summed over the ranks
+__global__ void step_rows_kernel(const double* __restrict__ yv, const uint8_t* __restrict__ row_mine, int64_t npad, double* __restrict__ ybuf) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < npad) ybuf[i] = row_mine[i / kTile] ? yv[i] : 0.0;
+}
+__global__ void zero_tiles_kernel(double* __restrict__ S, const int32_t* __restrict__ slots) {
+  double* t = S + (size_t)slots[blockIdx.x] * (kTile * kTile);
+  for (int e = threadIdx.x; e < kTile * kTile; e += 256) t[e] = 0.0;
+}
 template <bool UNPACK>
 __global__ __launch_bounds__(256) void exchange_pack_kernel(SolverDev sv, const int32_t* __restrict__ slots, int ntiles, double* __restrict__ buf) {
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -1245,6 +1289,23 @@ __global__ __launch_bounds__(256) void exchange_pack_kernel(SolverDev sv, const 
   }
 }
 }  // namespace
+hipError_t launch_top_assemble(const SolverDev& sv, const int32_t* slots, const int32_t* info, const int32_t* asm_ptr, const int32_t* asm_list, const int32_t* top_tiles, int ntop_slots, double* buf, hipStream_t st) {
+  if (ntop_slots > 0) LAUNCH(top_assemble_kernel, ntop_slots, 256, st, sv, slots, info, asm_ptr, asm_list, top_tiles, ntop_slots, buf);
+  return hipSuccess;
+}
+hipError_t launch_top_unpack(const SolverDev& sv, const int32_t* slots, const int32_t* info, const int32_t* top_tiles, int ntop_slots, const double* buf, hipStream_t st) {
+  if (ntop_slots > 0) LAUNCH(top_unpack_kernel, ntop_slots, 256, st, sv, slots, info, top_tiles, ntop_slots, buf);
+  return hipSuccess;
+}
+hipError_t launch_step_rows(const double* yv, const uint8_t* row_mine, int64_t npad, double* ybuf, hipStream_t st) {
+  LAUNCH(step_rows_kernel, (unsigned)((npad + 255) / 256), 256, st, yv, row_mine, npad, ybuf);
+  return hipSuccess;
+}
+hipError_t launch_zero_tiles(double* S, const int32_t* slots, int n, hipStream_t st) {
+  if (n > 0) LAUNCH(zero_tiles_kernel, n, 256, st, S, slots);
+  return hipSuccess;
+}
+
 hipError_t launch_exchange_pack(const SolverDev& sv, const int32_t* slots, int ntiles, double* buf, bool unpack, hipStream_t st) {
   if (unpack) hipLaunchKernelGGL(exchange_pack_kernel<true>, dim3(ntiles + 1), dim3(256), 0, st, sv, slots, ntiles, buf);
   else hipLaunchKernelGGL(exchange_pack_kernel<false>, dim3(ntiles + 1), dim3(256), 0, st, sv, slots, ntiles, buf);

@@ -24,6 +24,7 @@
 
 #include "handle.hpp"
 #include "solver_state.hpp"
+#include "tile_order.hpp"
 
 namespace rsba {
 
@@ -94,6 +95,20 @@ struct Solver {
   int cur_cells = 0;
   hipStream_t mstream = nullptr; hipEvent_t ev_armed[2] = {nullptr, nullptr}, ev_released = nullptr; bool arm_pending[2] = {false, false};
   int64_t schur_launches = 0;                                         // launches of the Schur kernel since the plan was built (statistics)
+  // Sharded factorisation (several ranks whose points respect the cut of tile_order.hpp): this rank factors the columns
+  // of ITS part of the elimination tree from its own partial S (launch A), the ranks all-reduce the separators' tiles less what
+  // their parts subtract from them, every rank factors the separators and solves them backward, then its own part (launch B).
+  bool sharded = false, sharded_off = false;                          // the plan has that form; a suspect solve switched it off for this handle
+  std::vector<int32_t> tasks_a, tasks_b; int32_t *d_tasks_a = nullptr, *d_tasks_b = nullptr;
+  std::vector<int32_t> diag_info_sh, sub_info_sh; int32_t *d_diag_info_sh = nullptr, *d_sub_info_sh = nullptr;   // {.., part0, nparts} of the separators' items without the parts' partials
+  CholPlan plan_a{}, plan_b{}; DagArgs* d_dag_args_a[2] = {nullptr, nullptr}; DagArgs* d_dag_args_b[2] = {nullptr, nullptr};
+  int ntop_slots = 0, ntop_tiles = 0;
+  int32_t *d_top_slots = nullptr, *d_top_info = nullptr, *d_asm_ptr = nullptr, *d_asm_list = nullptr, *d_top_tiles = nullptr;
+  double* topx_buf = nullptr;                                         // exchange (2) of the sharded form: the separators' tiles | their rows of the right-hand side
+  uint8_t* d_row_mine = nullptr;                                      // [nt] tiles (old index) whose rows of y this rank contributes to the gather (its part; rank 0: the separators)
+  uint8_t* d_row_check = nullptr;                                     // [nt] ... and whose residual it can check: its part (every tile of those rows is complete here)
+  double* ybuf = nullptr;                                             // [npad] y of this rank's tiles, zero elsewhere: summed over the ranks
+  int32_t* d_top_fill = nullptr; int ntop_fill = 0;                   // separator tiles that exist through fill only (zero in S; the sharded solve leaves its reduced values there)
   int num_reduced_blocks = 0, num_reduced_params = 0, num_priors_reduced = 0;
   int32_t* exch_slots = nullptr; double* exch_buf = nullptr; int exch_tiles = 0;   // exchange (2) of a sharded solve: the plan's tile pairs, packed
   double* zy2 = nullptr;                                              // [2][npad] z | y of one more right-hand side through the last factorisation (solve_again)
@@ -222,6 +237,8 @@ void parallel_ranges(int nthr, int64_t n, F&& fn) {
   for (int t = 0; t < nthr; ++t) pool.emplace_back([&, t]() { fn(n * t / nthr, n * (t + 1) / nthr, t); });
   for (auto& th : pool) th.join();
 }
+
+int32_t exchange(rsba_handle* h, double* buf, int64_t count, int op);   // (below)
 
 struct PhaseScope {
   PhaseTimer* t = nullptr; int phase; hipStream_t st; hipEvent_t a = nullptr;
@@ -502,57 +519,14 @@ int32_t build_solver_impl(rsba_handle* h) {
   std::vector<std::vector<int32_t>> adj(nt);
   for (int t = 0; t < ntp; ++t) if (tp_I[t] != tp_J[t]) { adj[tp_I[t]].push_back(tp_J[t]); adj[tp_J[t]].push_back(tp_I[t]); }
   tick("entries");
-  // Nested dissection by BFS level structures (George): a video's co-visibility graph is a band, whose BFS
-  // levels are band-wide separators; cutting it into independent segments turns the factorisation's
-  // serial tile chain into a shallow elimination tree that the level-scheduled kernels run in parallel.
-  // Tiles adjacent to (almost) everything — the intrinsics border — are ordered last.
-  std::vector<int32_t> perm; perm.reserve(nt);          // perm[new] = old tile
-  {
-    std::vector<uint8_t> dense(nt, 0), done(nt, 0);
-    for (int t = 0; t < nt; ++t) if (nt > 8 && (int)adj[t].size() > (3 * nt) / 4) dense[t] = 1;
-    std::vector<int32_t> tag(nt, -1);                   // membership of the subgraph being processed
-    int tagc = 0;
-    auto bfs_levels = [&](int root, int mytag, std::vector<std::vector<int32_t>>& lv) {
-      lv.clear(); std::vector<int32_t> cur{root}; std::vector<uint8_t> seen(nt, 0); seen[root] = 1;
-      while (!cur.empty()) { lv.push_back(cur); std::vector<int32_t> nxt; for (int u : cur) for (int v : adj[u]) if (tag[v] == mytag && !seen[v]) { seen[v] = 1; nxt.push_back(v); } std::sort(nxt.begin(), nxt.end()); cur.swap(nxt); }
-    };
-    int kLeaf = 24;
-    if (const char* e = std::getenv("RSBA_CHOL_LEAF")) kLeaf = std::max(2, std::atoi(e));   // tuning aid
-    std::function<void(std::vector<int32_t>)> nd = [&](std::vector<int32_t> nodes) {
-      if (nodes.empty()) return;
-      const int mytag = ++tagc;
-      for (int u : nodes) tag[u] = mytag;
-      // one connected component at a time
-      std::vector<std::vector<int32_t>> lv;
-      int root = nodes[0];
-      for (int u : nodes) if (adj[u].size() < adj[root].size()) root = u;
-      for (int it = 0; it < 2; ++it) { bfs_levels(root, mytag, lv); int best = lv.back()[0]; for (int u : lv.back()) if (adj[u].size() < adj[best].size()) best = u; root = best; }
-      bfs_levels(root, mytag, lv);
-      size_t reached = 0; for (auto& l : lv) reached += l.size();
-      if (reached < nodes.size()) {               // disconnected: split off this component and recurse on both
-        std::vector<uint8_t> in(nt, 0); std::vector<int32_t> comp, rest;
-        for (auto& l : lv) for (int u : l) { in[u] = 1; comp.push_back(u); }
-        for (int u : nodes) if (!in[u]) rest.push_back(u);
-        nd(comp); nd(rest); return;
-      }
-      if ((int)nodes.size() <= kLeaf || lv.size() < 3) { for (auto& l : lv) for (int u : l) perm.push_back(u); return; }
-      size_t half = nodes.size() / 2, acc = 0, cut = 1;
-      for (size_t l = 0; l < lv.size(); ++l) { acc += lv[l].size(); if (acc >= half) { cut = std::min(std::max<size_t>(l, 1), lv.size() - 2); break; } }
-      std::vector<int32_t> left, right;
-      for (size_t l = 0; l < cut; ++l) left.insert(left.end(), lv[l].begin(), lv[l].end());
-      for (size_t l = cut + 1; l < lv.size(); ++l) right.insert(right.end(), lv[l].begin(), lv[l].end());
-      const std::vector<int32_t> sep = lv[cut];
-      nd(left); nd(right);
-      for (int u : sep) perm.push_back(u);
-    };
-    std::vector<int32_t> sparse_nodes;
-    for (int t = 0; t < nt; ++t) if (!dense[t]) sparse_nodes.push_back(t);
-    // dense tiles are invisible to the dissection
-    for (int t = 0; t < nt; ++t) if (dense[t]) tag[t] = -2;
-    nd(sparse_nodes);
-    for (int t = 0; t < nt; ++t) if (dense[t]) perm.push_back(t);
-    (void)done;
-  }
+  // Nested dissection by BFS level structures (tile_order.hpp).  A sharded solve (several ranks, one tile layout: the co-visibility
+  // structure of all ranks is installed) asks for the top of the tree to be cut into one part per rank; whether THIS rank's points
+  // respect the cut — rsba_partition_points places them so — is checked below (sharded plan).
+  const bool want_parts = h->allreduce && h->world > 1 && !h->union_mask.empty();
+  std::vector<double> tile_weight(nt, 0.0);
+  for (int f = 0; f < FR; ++f) tile_weight[f / FT] += (double)(h->frame_obs_total.empty() ? frame_ptr[f + 1] - frame_ptr[f] : h->frame_obs_total[f]);
+  TileOrder tord = nested_dissection(nt, adj, plan_leaf_size(), want_parts ? h->world : 1, &tile_weight);
+  const std::vector<int32_t>& perm = tord.perm;          // perm[new] = old tile
   std::vector<int32_t> iperm(nt);
   for (int k = 0; k < nt; ++k) iperm[perm[k]] = k;
   tick("ordering");
@@ -579,6 +553,30 @@ int32_t build_solver_impl(rsba_handle* h) {
   };
   s->last_diag_slot = slot_base[iperm[nt - 1]];      // the (possibly padded) last tile of the natural order
   tick("symbolic");
+  // ---- sharded factorisation: does every rank's share of the points respect the cut? ----
+  // (part of a column = the rank whose subtree it belongs to, -1 = a separator the ranks share.)  Not with motion / pose priors or
+  // several intrinsics blocks (their replicated terms come from rank 0 alone) — those problems keep the replicated factorisation.
+  std::vector<int32_t> cpart(nt, -1);
+  bool sharded = want_parts && tord.parts_ok && h->prior_frames.empty() && h->pp_blocks.empty() && dp.pp_spherical < 0 && NIB <= 1;
+  if (const char* e = std::getenv("RSBA_SHARDED")) sharded = sharded && e[0] != '0';   // A/B switch
+  if (want_parts) {
+    double bad = sharded ? 0.0 : 1.0;
+    for (int64_t i = 0; i < N && bad == 0.0; ++i) { const int p = tord.part_of[of[i] / FT]; if (p >= 0 && p != h->rank) bad = 1.0; }
+    // every rank must take the same form: one all-reduce (max) of the verdicts
+    double* d_bad = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_bad), sizeof(double)));
+    hipError_t e = hipMemcpyAsync(d_bad, &bad, sizeof bad, hipMemcpyHostToDevice, h->stream);
+    int32_t rcx = RSBA_OK;
+    if (e == hipSuccess) rcx = exchange(h, d_bad, 1, 1);
+    if (e == hipSuccess && rcx == RSBA_OK) e = hipMemcpyAsync(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess && rcx == RSBA_OK) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(d_bad);
+    if (rcx) return rcx;
+    if (e != hipSuccess) return rsba_set_error(RSBA_ERR_HIP, hipGetErrorString(e));
+    sharded = bad == 0.0;
+  }
+  s->sharded = sharded;
+  if (sharded) for (int j = 0; j < nt; ++j) cpart[j] = tord.part_of[perm[j]];
   // level schedule: column j is ready once every column of row[j] is done
   std::vector<int32_t> level(nt, 0);
   int nlev = 0;
@@ -614,31 +612,69 @@ int32_t build_solver_impl(rsba_handle* h) {
   int parts = 0;
   std::vector<std::vector<int32_t>> upd_by_level(nlev);
   std::vector<int32_t> klev;   // level of each contributor of the list being built
+  std::vector<int32_t> upd_owner, diag_colnew, sub_colnew; int cur_part = -1;   // rank that runs each UPDATE item (-1: every rank); column (new order) of each DIAG / SUB item
+  std::vector<std::vector<int32_t>> asm_of_slot((size_t)sv.nslots);   // per separator tile of a sharded plan: {part, partial tile} of the parts' UPDATE items that subtract from it
   for (int l = 0; l < nlev; ++l) {
     const size_t diag0 = s->diag_info.size() / 4, sub0 = s->sub_info.size() / 4;
-    auto chunk_it = [&](int kind, int32_t p0, int32_t p1, std::vector<int32_t>& info, std::vector<int32_t>& own) {
-      if (p1 - p0 <= kChunk) { info.push_back(0); info.push_back(0); own.push_back(p0); return; }
-      const int32_t own0 = p1 - kTail;
-      info.push_back(parts);
+    // contributors [p0, p1) of the list being built (levels in klev, klev[0] belonging to list position lbase); the first nb of them
+    // — sharded plans, separator items only — are the columns of the ranks' parts, grouped by part (pk = their parts): each part's
+    // share is cut into UPDATE items that ITS rank runs, whatever their number; {part0, nparts} covers every partial tile of the item
+    // — what the replicated factorisation subtracts —, info_sh the ones of the separators' own columns only — what is left to
+    // subtract after the exchange has summed the rest in (assemble_top)
+    auto chunk_it = [&](int kind, int32_t p0, int32_t p1, std::vector<int32_t>& info, std::vector<int32_t>& own, int32_t lbase, int nb, const std::vector<int32_t>& pk,
+                        std::vector<int32_t>* info_sh, int32_t tile_slot) {
+      const int32_t first_part = parts;
       int cnt = 0;
-      for (int32_t q = p0; q < own0; q += kChunk) {
-        const int32_t q1 = std::min(q + kChunk, own0);
-        upd_by_level[klev[q1 - 1 - p0] + 1].push_back((int32_t)(s->upd.size() / 4));
-        s->upd.push_back(kind); s->upd.push_back(q); s->upd.push_back(q1); s->upd.push_back(parts++); ++cnt;
+      for (int32_t q = p0; q < p0 + nb;) {   // the parts' shares
+        int32_t qe = q; while (qe < p0 + nb && pk[qe - p0] == pk[q - p0]) ++qe;
+        for (int32_t c = q; c < qe; c += kChunk) {
+          const int32_t c1 = std::min(c + kChunk, qe);
+          upd_by_level[klev[c1 - 1 - lbase] + 1].push_back((int32_t)(s->upd.size() / 4));
+          upd_owner.push_back(pk[q - p0]); asm_of_slot[tile_slot].push_back(pk[q - p0]); asm_of_slot[tile_slot].push_back(parts);
+          s->upd.push_back(kind); s->upd.push_back(c); s->upd.push_back(c1); s->upd.push_back(parts++); ++cnt;
+        }
+        q = qe;
       }
-      info.push_back(cnt);
-      own.push_back(own0);
+      const int nbparts = cnt;
+      p0 += nb;
+      if (p1 - p0 <= kChunk) own.push_back(p0);
+      else {
+        const int32_t own0 = p1 - kTail;
+        for (int32_t q = p0; q < own0; q += kChunk) {
+          const int32_t q1 = std::min(q + kChunk, own0);
+          upd_by_level[klev[q1 - 1 - lbase] + 1].push_back((int32_t)(s->upd.size() / 4));
+          upd_owner.push_back(cur_part);
+          s->upd.push_back(kind); s->upd.push_back(q); s->upd.push_back(q1); s->upd.push_back(parts++); ++cnt;
+        }
+        own.push_back(own0);
+      }
+      info.push_back(cnt ? first_part : 0); info.push_back(cnt);
+      if (info_sh) { info_sh->push_back(cnt - nbparts ? first_part + nbparts : 0); info_sh->push_back(cnt - nbparts); }
+    };
+    // contributors of a separator item of a sharded plan: the parts' columns first, part by part, then the separators' own — each
+    // group in the order its columns finish
+    auto split_parts = [&](std::vector<int32_t>& ks, std::vector<int32_t>& pk) {
+      std::stable_sort(ks.begin(), ks.end(), [&](int32_t x, int32_t y) { const unsigned px = (unsigned)cpart[x], py = (unsigned)cpart[y]; return px < py; });   // (-1 = separators: last)
+      pk.clear();
+      for (int32_t k : ks) if (cpart[k] >= 0) pk.push_back(cpart[k]);
+      return (int)pk.size();
     };
     for (int32_t j : lev_cols[l]) {
       std::vector<int32_t> rj(row[j]);   // contributors in the order they finish
       std::stable_sort(rj.begin(), rj.end(), [&](int32_t x, int32_t y) { return level[x] < level[y]; });
+      const bool topcol = sharded && cpart[j] < 0;
+      cur_part = cpart[j];
+      std::vector<int32_t> pk;
+      const int nbj = topcol ? split_parts(rj, pk) : 0;
       s->diag_info.push_back(slot_base[j]); s->diag_info.push_back(perm[j]);
+      if (sharded) { s->diag_info_sh.push_back(slot_base[j]); s->diag_info_sh.push_back(perm[j]); }
+      diag_colnew.push_back(j);
       const int32_t dp0 = (int32_t)(s->diag_list.size() / 2);
       klev.clear();
       for (int32_t k : rj) { s->diag_list.push_back(slot_of(j, k)); s->diag_list.push_back(perm[k]); klev.push_back(level[k]); }
       s->diag_ptr.push_back((int32_t)(s->diag_list.size() / 2));
-      chunk_it(0, dp0, (int32_t)(s->diag_list.size() / 2), s->diag_info, s->diag_own);
-      if (fuse_last && !rj.empty()) {
+      chunk_it(0, dp0, (int32_t)(s->diag_list.size() / 2), s->diag_info, s->diag_own, dp0, nbj, pk, sharded ? &s->diag_info_sh : nullptr, slot_base[j]);
+      if (fuse_last && !rj.empty() && (!topcol || cpart[rj.back()] < 0)) {   // (a separator column of a sharded plan never takes a part's column by the hand: it lives on another rank)
         const int32_t ks = rj.back();
         const int32_t fs = sub_base[ks] + (int32_t)(std::lower_bound(col[ks].begin(), col[ks].end(), j) - col[ks].begin());
         s->diag_fuse.push_back(fs);
@@ -650,12 +686,14 @@ int32_t build_solver_impl(rsba_handle* h) {
       s->back_ptr.push_back((int32_t)(s->back_list.size() / 2));
       for (int32_t i : col[j]) {
         s->sub_info.push_back(slot_of(i, j)); s->sub_info.push_back(slot_base[j]); s->sub_col.push_back(perm[j]); s->sub_pub.push_back(-1);
+        if (sharded) { s->sub_info_sh.push_back(slot_of(i, j)); s->sub_info_sh.push_back(slot_base[j]); }
+        sub_colnew.push_back(j);
         const int32_t sp0 = (int32_t)(s->sub_list.size() / 2);
-        // k in row[j] with tile (i,k) present
-        klev.clear();
-        for (int32_t k : rj) { const int32_t sik = slot_of(i, k); if (sik >= 0) { s->sub_list.push_back(sik); s->sub_list.push_back(slot_of(j, k)); klev.push_back(level[k]); } }
+        // k in row[j] with tile (i,k) present (rj: for a separator column of a sharded plan the parts' columns first, part by part)
+        klev.clear(); pk.clear();
+        for (int32_t k : rj) { const int32_t sik = slot_of(i, k); if (sik >= 0) { s->sub_list.push_back(sik); s->sub_list.push_back(slot_of(j, k)); klev.push_back(level[k]); if (topcol && cpart[k] >= 0) pk.push_back(cpart[k]); } }
         s->sub_ptr.push_back((int32_t)(s->sub_list.size() / 2));
-        chunk_it(1, sp0, (int32_t)(s->sub_list.size() / 2), s->sub_info, s->sub_own);
+        chunk_it(1, sp0, (int32_t)(s->sub_list.size() / 2), s->sub_info, s->sub_own, sp0, (int)pk.size(), pk, sharded ? &s->sub_info_sh : nullptr, slot_of(i, j));
       }
     }
     s->lev_diag_ptr.push_back((int32_t)(s->diag_info.size() / 4));
@@ -670,6 +708,18 @@ int32_t build_solver_impl(rsba_handle* h) {
   }
   for (int l = nlev - 1; l >= 0; --l)
     for (int d = s->lev_diag_ptr[l]; d < s->lev_diag_ptr[l + 1]; ++d) { s->tasks.push_back(kTaskBack); s->tasks.push_back(d); }
+  if (sharded) {
+    // launch A: this rank's part, forward (the parts' UPDATE items of the separators' tiles included); launch B: the separators,
+    // forward and backward, then this rank's part backward
+    const int me = h->rank;
+    for (int l = 0; l < nlev; ++l) {
+      for (int32_t u : upd_by_level[l]) { std::vector<int32_t>& t = upd_owner[u] == me ? s->tasks_a : s->tasks_b; if (upd_owner[u] == me || upd_owner[u] < 0) { t.push_back(kTaskUpdate); t.push_back(u); } }
+      for (int d = s->lev_diag_ptr[l]; d < s->lev_diag_ptr[l + 1]; ++d) { const int p = cpart[diag_colnew[d]]; if (p == me) { s->tasks_a.push_back(kTaskDiag); s->tasks_a.push_back(d); } else if (p < 0) { s->tasks_b.push_back(kTaskDiag); s->tasks_b.push_back(d); } }
+      for (int t = s->lev_sub_ptr[l]; t < s->lev_sub_ptr[l + 1]; ++t) { const int p = cpart[sub_colnew[t]]; if (p == me) { s->tasks_a.push_back(kTaskSub); s->tasks_a.push_back(t); } else if (p < 0) { s->tasks_b.push_back(kTaskSub); s->tasks_b.push_back(t); } }
+    }
+    for (int l = nlev - 1; l >= 0; --l)
+      for (int d = s->lev_diag_ptr[l]; d < s->lev_diag_ptr[l + 1]; ++d) { const int p = cpart[diag_colnew[d]]; if (p == me || p < 0) { s->tasks_b.push_back(kTaskBack); s->tasks_b.push_back(d); } }
+  }
   tick("tasks");
   // Chunks of the Schur kernel (one workgroup each): at most kSchurChunk consecutive entries of one tile pair, numbered tile
   // pair by tile pair in (I, J) order — the pairs of one tile row, which read the same A_j(I) groups, next to each other; the
@@ -896,6 +946,45 @@ int32_t build_solver_impl(rsba_handle* h) {
   up.upload_ref(&s->d_back_ptr, s->back_ptr);
   up.upload_ref(&s->d_back_list, s->back_list);
 
+  // ---- sharded factorisation: what the exchange between the two launches needs ----
+  std::vector<int32_t> top_slots, top_info, asm_ptr(1, 0), asm_list, top_tiles, top_fill;   // (alive until the uploads have finished)
+  std::vector<uint8_t> row_mine((size_t)nt, 1);
+  std::vector<double> frame_lead;
+  sv.frame_lead = nullptr;
+  if (sharded) {
+    std::vector<uint8_t> has_pair((size_t)sv.nslots, 0);
+    for (int t = 0; t < ntp; ++t) has_pair[tp_dst[t]] = 1;
+    // the separators' tiles, column by column: {slot, has a tile pair (else: fill only, zero in S), index among the separator tiles of its row of the rhs or -1}
+    for (int j = 0; j < nt; ++j) if (cpart[j] < 0) {
+      const int trow = (int)top_tiles.size();
+      top_tiles.push_back(perm[j]);
+      auto add = [&](int32_t slot, int rhs_row) {
+        top_slots.push_back(slot); top_info.push_back(has_pair[slot]); top_info.push_back(rhs_row);
+        const std::vector<int32_t>& a = asm_of_slot[slot];
+        for (size_t q = 0; q + 1 < a.size(); q += 2) if (a[q] == h->rank) asm_list.push_back(a[q + 1]);   // this rank's partial tiles, in list order
+        asm_ptr.push_back((int32_t)asm_list.size());
+        if (!has_pair[slot]) top_fill.push_back(slot);
+      };
+      add(slot_base[j], trow);
+      for (size_t u = 0; u < col[j].size(); ++u) add(slot_base[j] + 1 + (int32_t)u, -1);   // (rows below a separator column are separators too: fill only reaches ancestors)
+    }
+    s->ntop_slots = (int)top_slots.size(); s->ntop_tiles = (int)top_tiles.size(); s->ntop_fill = (int)top_fill.size();
+    // rows of y this rank contributes to the gather (and whose residual it can check: every tile of those rows is complete here):
+    // its own part; the separators' rows come from rank 0
+    for (int t = 0; t < nt; ++t) { const int p = tord.part_of[t]; row_mine[t] = p == h->rank || (p < 0 && h->rank == 0); }
+    // who adds the replicated terms (damping, gradient, identity padding) of a camera-side frame to its partial S: the rank that
+    // owns the frame's part, rank 0 for the separators
+    frame_lead.assign((size_t)nt * FT, 0.0);
+    for (int a = 0; a < nt * FT; ++a) frame_lead[a] = row_mine[a / FT] ? 1.0 : 0.0;
+    up.upload(&s->d_top_slots, top_slots); up.upload(&s->d_top_info, top_info); up.upload(&s->d_asm_ptr, asm_ptr); up.upload(&s->d_asm_list, asm_list);
+    up.upload(&s->d_top_tiles, top_tiles); up.upload(&s->d_row_mine, row_mine); up.upload(&s->d_top_fill, top_fill);
+    { std::vector<uint8_t> row_check((size_t)nt, 0); for (int t = 0; t < nt; ++t) row_check[t] = tord.part_of[t] == h->rank; up.upload(&s->d_row_check, row_check); }
+    up.upload_const(&sv.frame_lead, frame_lead);
+    up.upload_ref(&s->d_tasks_a, s->tasks_a); up.upload_ref(&s->d_tasks_b, s->tasks_b);
+    up.upload_ref(&s->d_diag_info_sh, s->diag_info_sh); up.upload_ref(&s->d_sub_info_sh, s->sub_info_sh);
+    if ((rc = s_alloc(s, &s->topx_buf, (size_t)s->ntop_slots * kTile * kTile + (size_t)s->ntop_tiles * kTile))) return rc;
+    if ((rc = s_alloc(s, &s->ybuf, (size_t)sv.npad))) return rc;
+  }
   HIP_TRY(up.finish());
   tick("uploads");
   const size_t REC = 2 + 2 * (size_t)dp.K;
@@ -988,6 +1077,11 @@ int32_t build_solver_impl(rsba_handle* h) {
   pl.tasks = s->d_tasks; pl.ntasks = (int)(s->tasks.size() / 2); pl.ndiag = (int)(s->diag_info.size() / 4);
   pl.ticket = s->d_dag_sync;
   pl.nslots = sv.nslots; pl.nparts = parts;
+  if (sharded) {
+    s->plan_a = pl; s->plan_a.tasks = s->d_tasks_a; s->plan_a.ntasks = (int)(s->tasks_a.size() / 2);
+    s->plan_b = pl; s->plan_b.tasks = s->d_tasks_b; s->plan_b.ntasks = (int)(s->tasks_b.size() / 2);
+    s->plan_b.diag_info = s->d_diag_info_sh; s->plan_b.sub_info = s->d_sub_info_sh;   // (the parts' partial tiles have been summed in by the exchange)
+  }
   int cus = 0;
   HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
   // One persistent workgroup per CU.  Claimed tasks that wait for their inputs hold a workgroup and the schedule is short of them
@@ -1031,6 +1125,14 @@ int32_t build_solver_impl(rsba_handle* h) {
       host_args.sv.zv = c + s->cell_off[3]; host_args.sv.yv = host_args.sv.zv + sv.npad; host_args.sv.Xpub = c + s->cell_off[4];
       if ((rc = s_alloc(s, &s->d_dag_args2[b], 1))) return rc;
       HIP_TRY(hipMemcpy(s->d_dag_args2[b], &host_args, sizeof host_args, hipMemcpyHostToDevice));
+      if (sharded) {
+        DagArgs a = host_args, bb = host_args;
+        a.pl = s->plan_a; bb.pl = s->plan_b;
+        if ((rc = s_alloc(s, &s->d_dag_args_a[b], 1))) return rc;
+        if ((rc = s_alloc(s, &s->d_dag_args_b[b], 1))) return rc;
+        HIP_TRY(hipMemcpy(s->d_dag_args_a[b], &a, sizeof a, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(s->d_dag_args_b[b], &bb, sizeof bb, hipMemcpyHostToDevice));
+      }
     }
     s->d_dag_args = s->d_dag_args2[0];
   }
@@ -1049,6 +1151,17 @@ int32_t build_solver_impl(rsba_handle* h) {
                         2 * T3 / 3 * (int64_t)(s->diag_info.size() / 4) + 4 * (int64_t)kTile * kTile * ((int64_t)sv.nslots + nt);
     ps.exchange_doubles = (int64_t)s->exch_tiles * kTile * kTile + sv.npad;   // exchange (2) of a sharded solve: the plan's tile pairs | rhs (the fill-in tiles of the factor's layout stay home)
     ps.schur_groups = sv.ngroups;
+    ps.sharded_factorisation = sharded ? 1 : 0;
+    if (sharded) {   // ... or, when every rank factors its own part: the separators' tiles | their rows of the rhs, and the gather of the step
+      ps.exchange_doubles = (int64_t)s->ntop_slots * kTile * kTile + (int64_t)s->ntop_tiles * kTile + sv.npad;
+      ps.separator_tiles = s->ntop_tiles; ps.separator_factor_tiles = s->ntop_slots;
+      ps.local_tasks = (int64_t)(s->tasks_a.size() / 2); ps.separator_tasks = (int64_t)(s->tasks_b.size() / 2);
+      // the two dependency chains: elimination levels inside this rank's part, and levels that hold a separator column
+      int lmax = -1; std::vector<uint8_t> sep_level((size_t)nlev, 0);
+      for (int j = 0; j < nt; ++j) { if (cpart[j] == h->rank) lmax = std::max(lmax, level[j]); else if (cpart[j] < 0) sep_level[level[j]] = 1; }
+      ps.local_levels = lmax + 1; ps.separator_levels = 0;
+      for (uint8_t b : sep_level) ps.separator_levels += b;
+    }
   }
   tick("statistics");
   HIP_TRY(hipStreamSynchronize(h->stream));   // the plan's one-time fills and scatters are done whatever stream the solves will run on
@@ -1164,8 +1277,11 @@ int32_t reduce_system(rsba_handle* h, double radius) {
     ++s->schur_launches;
     if (sv.lead) HIP_TRY(launch_pose_prior_reduce(h->dp, sv, s->pp, radius, st));   // the priorPoses blocks leave the system like points
   }
-  // exchange (2): partial reduced camera systems -> the full one on every rank (then factored redundantly)
+  // exchange (2): partial reduced camera systems -> the full one on every rank (then factored redundantly) — unless every rank
+  // factors its own part: then only the separators travel, between the two launches of the factorisation (solve_reduced_system)
+  if (s->sharded && !s->sharded_off && !s->use_levels) return RSBA_OK;
   PhaseScope ps(h, RSBA_PHASE_EXCHANGE);
+  if (s->sharded && s->ntop_fill) HIP_TRY(launch_zero_tiles(sv.S, s->d_top_fill, s->ntop_fill, st));   // (a sharded solve left its reduced values in the fill-only separator tiles)
   if (h->allreduce && s->exch_slots) {   // only the tiles that can be non-zero travel (the fill-in tiles of the layout are zero on every rank)
     const int64_t count = (int64_t)s->exch_tiles * kTile * kTile + sv.npad;
     HIP_TRY(launch_exchange_pack(sv, s->exch_slots, s->exch_tiles, s->exch_buf, false, st));
@@ -1203,13 +1319,35 @@ int32_t solve_reduced_system(rsba_handle* h) {
     double* c = s->cells[now];
     sv.Lf = c + s->cell_off[0]; sv.chol_part = c + s->cell_off[1]; sv.Winv = c + s->cell_off[2]; sv.zv = c + s->cell_off[3]; sv.yv = sv.zv + sv.npad; sv.Xpub = c + s->cell_off[4];
     s->d_dag_args = s->d_dag_args2[now];
+    if (s->sharded && !s->sharded_off) {
+      // launch A: the columns of this rank's part, from its own partial S — complete for them: every point that sees one of its tiles is here
+      HIP_TRY(launch_chol_dag(sv, s->plan_a, s->d_dag_args_a[now], std::min(s->dag_workgroups, std::max(1, s->plan_a.ntasks)), s->dag_one_per_cu, st));
+      // exchange (2'): the separators' tiles, each rank's share less what its part subtracts from them, summed over the ranks
+      const int64_t count = (int64_t)s->ntop_slots * kTile * kTile + (int64_t)s->ntop_tiles * kTile;
+      {
+        PhaseScope pe(h, RSBA_PHASE_EXCHANGE);
+        HIP_TRY(launch_top_assemble(sv, s->d_top_slots, s->d_top_info, s->d_asm_ptr, s->d_asm_list, s->d_top_tiles, s->ntop_slots, s->topx_buf, st));
+        if (int32_t rc = exchange(h, s->topx_buf, count, 0)) return rc;
+        HIP_TRY(launch_top_unpack(sv, s->d_top_slots, s->d_top_info, s->d_top_tiles, s->ntop_slots, s->topx_buf, st));
+      }
+      // launch B: the separators (every rank alike), forward and backward, then this rank's part backward
+      HIP_TRY(launch_chol_dag(sv, s->plan_b, s->d_dag_args_b[now], std::min(s->dag_workgroups, std::max(1, s->plan_b.ntasks)), s->dag_one_per_cu, st));
+      // exchange (4): the camera step — every rank contributes the rows of its part, rank 0 the separators'
+      {
+        PhaseScope pe(h, RSBA_PHASE_EXCHANGE);
+        HIP_TRY(launch_step_rows(sv.yv, s->d_row_mine, sv.npad, s->ybuf, st));
+        if (int32_t rc = exchange(h, s->ybuf, sv.npad, 0)) return rc;
+        HIP_TRY(hipMemcpyAsync(sv.yv, s->ybuf, (size_t)sv.npad * sizeof(double), hipMemcpyDeviceToDevice, st));
+      }
+    } else
     HIP_TRY(launch_chol_dag(sv, s->plan, s->d_dag_args, s->dag_workgroups, s->dag_one_per_cu, st));
     if (s->test_corrupt_once) { s->test_corrupt_once = false; HIP_TRY(hipMemsetAsync(sv.yv + (sv.n / 2 / 6) * 6 + 1, 0, sizeof(double), st)); }   // test hook: one entry of the solution (a pose coordinate in mid-video) lost
     if (s->verify_dag) {
       HIP_TRY(hipMemcpyAsync(s->verify_b, sv.rhs, (size_t)sv.npad * sizeof(double), hipMemcpyDeviceToDevice, st));
       HIP_TRY(hipEventRecord(s->ev_solved, st));
       HIP_TRY(hipStreamWaitEvent(s->vstream, s->ev_solved, 0));
-      HIP_TRY(launch_chol_verify(sv, s->d_slot_tiles, s->verify_b, s->d_verify, s->d_verify + sv.npad, 1e-7, sv.scalars + kDagSuspect, s->vstream));
+      HIP_TRY(launch_chol_verify(sv, s->d_slot_tiles, s->verify_b, s->d_verify, s->d_verify + sv.npad, 1e-7, sv.scalars + kDagSuspect, s->vstream,
+                                 s->sharded && !s->sharded_off ? s->d_row_check : nullptr));   // (a rank of a sharded factorisation holds the whole of its part's rows of S, nothing else)
       HIP_TRY(hipEventRecord(s->ev_verified, s->vstream));
       s->verify_pending = true;
     }
@@ -1450,6 +1588,10 @@ extern "C" int32_t rsba_pose_covariance(rsba_handle* h, int32_t frame, double* c
   HIP_TRY(launch_clamp_diagonal(h->dp, sv, 1e-6, 1e32, st));   // only its floor matters: the decoupled diagonal of fixed coordinates
   HIP_TRY(launch_pose_prior_clamp(h->dp, s->pp, 1e-6, 1e32, st));
   HIP_TRY(hipMemsetAsync(sv.chol_fail, 0, sizeof(int), st));
+  // (CD + 1 right-hand sides through ONE factorisation: the substitution-only solves walk every column's factor tiles, so a sharded
+  // plan takes its replicated form here — the whole of S summed onto every rank)
+  struct ShardedOff { Solver* s; bool was; ~ShardedOff() { s->sharded_off = was; } } sharded_guard{s, s->sharded_off};
+  s->sharded_off = true;
   if ((rc = reduce_system(h, 1e300))) return rc;
   std::vector<double> col((size_t)CD * CD, 0.0);
   const double one = 1.0;
@@ -1679,6 +1821,7 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
       // the persistent driver's solution does not satisfy the system it was given: nothing of this iteration has touched
       // x yet — repeat it, and finish this problem, on the level schedule
       s->use_levels = true; ++s->dag_fallbacks; ++sum->num_dag_fallbacks;
+      s->sharded_off = true;   // (a sharded factorisation goes back to the replicated one: the level schedule needs the whole of S on every rank)
       continue;   // (the flag is cleared at the top of the iteration)
     }
     cost2[1] = 0.0;   // the trial evaluation reports the total in kCost

@@ -98,6 +98,8 @@ struct SolverDev {
   double* udiag;                // [F*CD] diag(U), global after the exchange
   double* xbuf;                 // [2*F*CD + 3] exchange buffer: g_c | diag(U) | cost, fixed cost, failed blocks
   int lead;                     // 1 on the rank that contributes the replicated terms (D_c^2, g_c, camera norms)
+  const double* frame_lead;     // [nt * FT] sharded factorisation: 1 where THIS rank adds the replicated terms of the frame to its partial S (its own part;
+                                //   rank 0: the separators), null = `lead` decides for every frame
   double* yp;                   // [M][3]
   double* trial_poses;          // candidate x + delta
   double* trial_points;
@@ -152,7 +154,8 @@ hipError_t launch_chol_level(const SolverDev& sv, const CholPlan& pl, int kind, 
 // res = rhs - S y with den = |rhs| + |S||y| over the packed tiles; *flag = 1 when |res| > tol * den somewhere, left alone otherwise (sticky; cholesky.hip)
 // slot_tiles [nslots][2] = {row tile, column tile} (unpermuted tile indices) of every packed tile
 // b_rhs: the right-hand side the system was solved for (a private copy: the caller overwrites sv.rhs with the step while the check runs on its own stream)
-hipError_t launch_chol_verify(const SolverDev& sv, const int32_t* slot_tiles, const double* b_rhs, double* res, double* den, double tol, double* flag, hipStream_t st);
+// row_mine (may be null): [nt] 1 = the rows of this tile are checked (sharded factorisation: the rows whose tiles are all on this rank)
+hipError_t launch_chol_verify(const SolverDev& sv, const int32_t* slot_tiles, const double* b_rhs, double* res, double* den, double tol, double* flag, hipStream_t st, const uint8_t* row_mine = nullptr);
 struct DagArgs { SolverDev sv; CholPlan pl; };   // device copy the persistent kernel reads its state through (uploaded once per plan)
 hipError_t launch_chol_solve(const SolverDev& sv, const CholPlan& pl, const DagArgs* device_args, const double* b2, double* zy2, unsigned int* ticket, int workgroups, hipStream_t st);   // one more right-hand side through the factor of the last launch_chol_dag / level run
 hipError_t launch_chol_solve_level(const SolverDev& sv, const CholPlan& pl, bool backward, int first, int count, const double* b2, double* zy2, hipStream_t st);   // the same tasks, one launch per level
@@ -169,6 +172,11 @@ hipError_t launch_point_factor(const DeviceProblem& dp, const SolverDev& sv, dou
 hipError_t launch_project(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);
 hipError_t launch_clear_system(const SolverDev& sv, hipStream_t st);   // S = 0 (fill tiles start from zero)
 hipError_t launch_schur_blocks(const DeviceProblem& dp, const SolverDev& sv, double radius, hipStream_t st);
+// sharded factorisation: the exchange between its two launches (kernels_normal.hip)
+hipError_t launch_top_assemble(const SolverDev& sv, const int32_t* slots, const int32_t* info, const int32_t* asm_ptr, const int32_t* asm_list, const int32_t* top_tiles, int ntop_slots, double* buf, hipStream_t st);
+hipError_t launch_top_unpack(const SolverDev& sv, const int32_t* slots, const int32_t* info, const int32_t* top_tiles, int ntop_slots, const double* buf, hipStream_t st);
+hipError_t launch_step_rows(const double* yv, const uint8_t* row_mine, int64_t npad, double* ybuf, hipStream_t st);
+hipError_t launch_zero_tiles(double* S, const int32_t* slots, int n, hipStream_t st);
 hipError_t launch_back_substitute(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);
 hipError_t launch_model_cost_change(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);      // -> scalars[kModelCostChange]
 hipError_t launch_candidate(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);              // trial params, |step|^2, |x|^2

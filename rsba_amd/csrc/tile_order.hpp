@@ -1,0 +1,127 @@
+// Host side of the symbolic phase that several callers share: the fill-reducing, parallelism-exposing order of the 48 x 48 tile
+// columns of the reduced camera system (what CHOLMOD's analyse step does for Ceres behind
+// /root/reference/src/rsba/CeresHandler.h:403,419) and — multi-GPU — the partition of that order among the ranks.
+//
+// Nested dissection by BFS level structures (George): a video's co-visibility graph is a band, whose BFS levels are band-wide
+// separators; cutting it into independent segments turns the factorisation's serial tile chain into a shallow elimination tree.
+// Tiles adjacent to (almost) everything — the intrinsics border — are ordered last.
+//
+// With nparts > 1 the TOP of the tree is cut for the ranks of a sharded solve: the first ceil(log2 nparts) levels of separators
+// split the tiles into nparts "parts" of about equal weight (observations), one per rank; part_of[tile] = the rank whose subtree
+// the tile belongs to, -1 for the tiles of those top separators (and the dense border).  No point is seen on both sides of a
+// separator (its two sides are not adjacent in the tile graph), so every point that is seen in a part's tile at all belongs to
+// that part alone: the rank that owns the part owns the point (every observation of a point on one rank), the columns
+// of its part of S are complete on that rank without any exchange, and it can factor them on its own.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <functional>
+#include <vector>
+
+namespace rsba {
+
+// tiles per leaf of the dissection (RSBA_CHOL_LEAF: tuning aid; swept 8 - 48 on the 1k- and 4k-camera scenes)
+inline int plan_leaf_size() {
+  int k = 24;
+  if (const char* e = std::getenv("RSBA_CHOL_LEAF")) k = std::max(2, std::atoi(e));
+  return k;
+}
+
+struct TileOrder {
+  std::vector<int32_t> perm;      // perm[new] = old tile
+  std::vector<int32_t> leaf_of;   // per old tile: leaf of the dissection, -1 = a separator / the dense border
+  std::vector<int32_t> part_of;   // per old tile: rank whose subtree holds it, -1 = top separator / dense border (all 0 when nparts == 1)
+  int nleaf = 0;
+  bool parts_ok = true;           // false: the graph could not be cut into nparts parts (disconnected or too short): no sharded factorisation
+};
+
+inline TileOrder nested_dissection(int nt, const std::vector<std::vector<int32_t>>& adj, int kLeaf, int nparts = 1, const std::vector<double>* weight = nullptr) {
+  TileOrder out;
+  out.perm.reserve(nt); out.leaf_of.assign(nt, -1); out.part_of.assign(nt, nparts > 1 ? -1 : 0);
+  std::vector<uint8_t> dense(nt, 0);
+  for (int t = 0; t < nt; ++t) if (nt > 8 && (int)adj[t].size() > (3 * nt) / 4) dense[t] = 1;
+  std::vector<int32_t> tag(nt, -1);                   // membership of the subgraph being processed
+  int tagc = 0, next_part = 0;
+  auto bfs_levels = [&](int root, int mytag, std::vector<std::vector<int32_t>>& lv) {
+    lv.clear(); std::vector<int32_t> cur{root}; std::vector<uint8_t> seen(nt, 0); seen[root] = 1;
+    while (!cur.empty()) { lv.push_back(cur); std::vector<int32_t> nxt; for (int u : cur) for (int v : adj[u]) if (tag[v] == mytag && !seen[v]) { seen[v] = 1; nxt.push_back(v); } std::sort(nxt.begin(), nxt.end()); cur.swap(nxt); }
+  };
+  // the level structure of `nodes` from a pseudo-peripheral root; false when the nodes are not connected
+  auto level_structure = [&](const std::vector<int32_t>& nodes, int mytag, std::vector<std::vector<int32_t>>& lv) {
+    int root = nodes[0];
+    for (int u : nodes) if (adj[u].size() < adj[root].size()) root = u;
+    for (int it = 0; it < 2; ++it) { bfs_levels(root, mytag, lv); int best = lv.back()[0]; for (int u : lv.back()) if (adj[u].size() < adj[best].size()) best = u; root = best; }
+    bfs_levels(root, mytag, lv);
+    size_t reached = 0; for (auto& l : lv) reached += l.size();
+    return reached == nodes.size();
+  };
+  std::function<void(std::vector<int32_t>)> nd = [&](std::vector<int32_t> nodes) {
+    if (nodes.empty()) return;
+    const int mytag = ++tagc;
+    for (int u : nodes) tag[u] = mytag;
+    std::vector<std::vector<int32_t>> lv;
+    if (!level_structure(nodes, mytag, lv)) {     // disconnected: split off this component and recurse on both
+      std::vector<uint8_t> in(nt, 0); std::vector<int32_t> comp, rest;
+      for (auto& l : lv) for (int u : l) { in[u] = 1; comp.push_back(u); }
+      for (int u : nodes) if (!in[u]) rest.push_back(u);
+      nd(comp); nd(rest); return;
+    }
+    if ((int)nodes.size() <= kLeaf || lv.size() < 3) { for (auto& l : lv) for (int u : l) { out.perm.push_back(u); out.leaf_of[u] = out.nleaf; } ++out.nleaf; return; }
+    size_t half = nodes.size() / 2, acc = 0, cut = 1;
+    for (size_t l = 0; l < lv.size(); ++l) { acc += lv[l].size(); if (acc >= half) { cut = std::min(std::max<size_t>(l, 1), lv.size() - 2); break; } }
+    std::vector<int32_t> left, right;
+    for (size_t l = 0; l < cut; ++l) left.insert(left.end(), lv[l].begin(), lv[l].end());
+    for (size_t l = cut + 1; l < lv.size(); ++l) right.insert(right.end(), lv[l].begin(), lv[l].end());
+    const std::vector<int32_t> sep = lv[cut];
+    nd(left); nd(right);
+    for (int u : sep) out.perm.push_back(u);
+  };
+  // the top of the tree, cut for `parts` ranks: the separator sits where the weight left of it is parts_left / parts of the total
+  std::function<void(std::vector<int32_t>, int)> nd_parts = [&](std::vector<int32_t> nodes, int parts) {
+    if (parts <= 1 || nodes.empty()) {
+      const int p = next_part++;
+      for (int u : nodes) out.part_of[u] = p;
+      nd(std::move(nodes));
+      return;
+    }
+    const int mytag = ++tagc;
+    for (int u : nodes) tag[u] = mytag;
+    std::vector<std::vector<int32_t>> lv;
+    if (!level_structure(nodes, mytag, lv) || lv.size() < 3) {   // cannot be cut: everything to one rank (the caller falls back to the replicated factorisation)
+      out.parts_ok = false;
+      const int p = next_part; next_part += parts;
+      for (int u : nodes) out.part_of[u] = p;
+      nd(std::move(nodes));
+      return;
+    }
+    const int pl = parts / 2, pr = parts - pl;
+    auto w = [&](int u) { return weight ? (*weight)[u] : 1.0; };
+    double total = 0.0; for (int u : nodes) total += w(u);
+    // the level whose removal leaves the two sides closest to their shares: weight per rank left of it against weight per rank right of it
+    std::vector<double> lw(lv.size(), 0.0);
+    for (size_t l = 0; l < lv.size(); ++l) for (int u : lv[l]) lw[l] += w(u);
+    double acc = lw[0], best = -1.0; size_t cut = 1;
+    for (size_t l = 1; l + 1 < lv.size(); ++l) {
+      const double miss = std::abs(acc / pl - (total - acc - lw[l]) / pr);
+      if (best < 0.0 || miss < best) { best = miss; cut = l; }
+      acc += lw[l];
+    }
+    std::vector<int32_t> left, right;
+    for (size_t l = 0; l < cut; ++l) left.insert(left.end(), lv[l].begin(), lv[l].end());
+    for (size_t l = cut + 1; l < lv.size(); ++l) right.insert(right.end(), lv[l].begin(), lv[l].end());
+    const std::vector<int32_t> sep = lv[cut];
+    nd_parts(left, pl); nd_parts(right, pr);
+    for (int u : sep) out.perm.push_back(u);
+  };
+  std::vector<int32_t> sparse_nodes;
+  for (int t = 0; t < nt; ++t) if (!dense[t]) sparse_nodes.push_back(t);
+  for (int t = 0; t < nt; ++t) if (dense[t]) tag[t] = -2;   // dense tiles are invisible to the dissection
+  if (nparts > 1) nd_parts(sparse_nodes, nparts); else nd(sparse_nodes);
+  for (int t = 0; t < nt; ++t) if (dense[t]) out.perm.push_back(t);
+  if (nparts > 1 && next_part != nparts) out.parts_ok = false;
+  return out;
+}
+
+}  // namespace rsba

@@ -102,11 +102,13 @@ class BAProblem:
             kw[f.name] = v.copy() if isinstance(v, np.ndarray) else v
         return BAProblem(**kw)
 
-    def shard(self, rank: int, world: int) -> "BAProblem":
+    def shard(self, rank: int, world: int, owner: Optional[np.ndarray] = None) -> "BAProblem":
         """Point-partitioned shard for multi-GPU runs: rank r keeps every observation of
-        the points j with j % world == r; frames / intrinsics are replicated; points keep their global
+        the points it owns — owner[j] == r (rsba_amd.capi.partition_points: the cut along the top separators of
+        the reduced system's elimination tree, which lets every rank factor its own part), or j % world == r without
+        an owner array; frames / intrinsics are replicated; points keep their global
         numbering so parameter arrays stay comparable across ranks."""
-        keep = (self.obs_point % world) == rank
+        keep = ((self.obs_point % world) == rank) if owner is None else (np.asarray(owner)[self.obs_point] == rank)
         p = self.copy()
         p.obs_xy = np.ascontiguousarray(self.obs_xy[keep])
         p.obs_frame = np.ascontiguousarray(self.obs_frame[keep])

@@ -23,12 +23,50 @@ def scene():
     return p
 
 
+def nd_mode(mode, outdir, rank, world, dist, torch):
+    """"nd:<config>:<iterations>[:huber]": a BASELINE configuration sharded along the top separators of the reduced system's elimination tree
+    (rsba_partition_points) — every rank factors its own part, the separators' tiles are what travels — against the single-GPU solve."""
+    from rsba_amd import capi
+    from rsba_amd.distributed import attach
+    from rsba_amd.scene import make_config
+    _, cfg, iters = mode.split(":")[:3]
+    full = make_config(cfg).problem
+    owner, ntop = capi.partition_points(full, world)
+    shard = full.shard(rank, world, owner)
+    torch.cuda.set_device(0)
+    opts = dict(max_num_iterations=int(iters), function_tolerance=0.0, parameter_tolerance=0.0, gradient_tolerance=0.0)
+    dp = capi.DeviceProblem(shard, device=0)
+    attach(dp)
+    s, tr = dp.solve(capi.default_options(**opts))
+    st = dp.plan_stats()
+    dp.close()
+    out = {"rank": rank, "world": world, "n_full": int(full.num_observations), "n_shard": int(shard.num_observations), "top_tile_columns": ntop,
+           "final_cost": s.final_cost, "initial_cost": s.initial_cost, "iters": s.num_iterations, "dag_fallbacks": s.num_dag_fallbacks,
+           "reduced": s.num_residual_blocks_reduced, "params": s.num_parameters_reduced, "costs": [t.cost for t in tr], "plan": st,
+           "poses_sum": float(np.abs(shard.poses).sum()), "points_sum": float(np.abs(shard.points).sum())}
+    if rank == 0:
+        ref = full.copy()
+        with capi.DeviceProblem(ref) as d1:
+            s1, tr1 = d1.solve(capi.default_options(**opts))
+            st1 = d1.plan_stats()
+        out.update(ref_final=s1.final_cost, ref_initial=s1.initial_cost, ref_iters=s1.num_iterations, ref_reduced=s1.num_residual_blocks_reduced, ref_params=s1.num_parameters_reduced,
+                   pose_err=float(np.abs(ref.poses - shard.poses).max()), point_err=float(np.abs(ref.points - shard.points).max()),
+                   traj_err=float(max(abs(a.cost - b.cost) / b.cost for a, b in zip(tr, tr1))), ref_plan=st1,
+                   decisions_equal=bool(all(a.step_is_successful == b.step_is_successful for a, b in zip(tr, tr1))))
+    with open(os.path.join(outdir, f"rank{rank}.json"), "w") as f:
+        json.dump(out, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     mode, outdir = sys.argv[1], sys.argv[2]
     import torch
     import torch.distributed as dist
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
+    if mode.startswith("nd:"):
+        return nd_mode(mode, outdir, rank, world, dist, torch)
     full = scene()
     if mode in ("gpu_priors", "gpu_free_ratio"):   # motion priors are replicated terms: every rank lists them, rank 0 contributes them
         full.prior_kind, full.prior_scale, full.inter_frame_ratio = 2, 25.0, 1.2

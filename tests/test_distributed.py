@@ -8,6 +8,7 @@ import socket
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -146,3 +147,75 @@ def test_a_failed_exchange_says_what_failed():
     dp.close()
     msg = str(err.value)
     assert "all-reduce of" in msg and "rank 0 of 1" in msg, msg
+
+
+# ---- the sharded factorisation: points partitioned along the top separators of the reduced system's elimination tree ----
+
+@pytest.mark.parametrize("config,worlds", [("C2", (2,)), ("C4", (2, 4, 8))])
+def test_partition_points_cuts_along_separators(config, worlds):
+    """rsba_partition_points (host only): every point on one rank by construction; the observations are balanced; the tile columns
+    (4 rolling-shutter frames each) that more than one rank's points are seen in are exactly the separators' — every other column of
+    the reduced camera system is complete on one rank, which is what lets that rank factor it alone."""
+    from rsba_amd import capi
+    from rsba_amd.scene import make_config
+    p = make_config(config).problem
+    FT = 4
+    nt = (p.num_frames + FT - 1) // FT
+    for world in worlds:
+        owner, ntop = capi.partition_points(p, world)
+        assert owner.shape == (p.num_points,) and owner.min() >= 0 and owner.max() == world - 1
+        load = np.bincount(owner[p.obs_point], minlength=world)
+        assert load.min() > 0 and load.max() <= 1.35 * load.mean()
+        touched = np.zeros((world, nt), dtype=bool)
+        touched[owner[p.obs_point], p.obs_frame // FT] = True
+        shared = int((touched.sum(0) > 1).sum())
+        assert 0 < shared <= ntop and ntop <= {2: 0.35, 4: 0.2, 8: 0.2}[world] * nt + 8
+        # shards built from it: disjoint, complete
+        n = sum(p.shard(r, world, owner).num_observations for r in range(world))
+        assert n == p.num_observations
+    one, ntop = capi.partition_points(p, 1)
+    assert not one.any() and ntop == 0
+
+
+def test_partition_points_refuses_what_cannot_be_cut():
+    from rsba_amd import capi
+    from rsba_amd.scene import make_scene
+    p = make_scene(8, 200, seed=3).problem        # two tile columns: nothing to cut
+    with pytest.raises(capi.RsbaError, match="cannot be cut"):
+        capi.partition_points(p, 2)
+
+
+def check_nd(res, world, sharded=True):
+    a = res[0]
+    for o in res[1:]:
+        assert o["final_cost"] == a["final_cost"] and o["iters"] == a["iters"] and o["costs"] == a["costs"]        # ranks decide identically
+        assert o["poses_sum"] == a["poses_sum"] and o["points_sum"] == a["points_sum"]                               # ... and leave with the same parameters
+    assert all(o["dag_fallbacks"] == 0 for o in res)
+    assert sum(o["n_shard"] for o in res) == a["n_full"]
+    assert all(o["plan"]["sharded_factorisation"] == int(sharded) for o in res)
+    assert a["iters"] == a["ref_iters"] and a["reduced"] == a["ref_reduced"] and a["params"] == a["ref_params"] and a["decisions_equal"]
+    assert abs(a["initial_cost"] - a["ref_initial"]) <= 1e-12 * a["ref_initial"]
+    assert a["traj_err"] <= 1e-9 and abs(a["final_cost"] - a["ref_final"]) <= 1e-9 * a["ref_final"]
+    assert a["pose_err"] <= 1e-7 and a["point_err"] <= 1e-6
+    return a
+
+
+@pytest.mark.gpu
+def test_sharded_factorisation_two_ranks_c2(tmp_path):
+    """BASELINE configs 2-3 on two ranks (one GPU, gloo): each rank factors its own part of the reduced system, the separators' tiles
+    are all-reduced between the two launches of the factorisation — the LM trajectory is the single-GPU one to 1e-9."""
+    res = run_two_ranks("nd:C2:8", tmp_path, 2)
+    a = check_nd(res, 2)
+    assert a["plan"]["exchange_doubles"] < a["ref_plan"]["exchange_doubles"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_sharded_factorisation_at_c4_size(tmp_path, world):
+    """The headline configuration (1000 frames, 100k points, 2.04 M observations) on 2, 4 and 8 ranks sharing one GPU: the sharded
+    factorisation reproduces the single-GPU LM trajectory to 1e-9, and exchange (2) carries the separators only."""
+    res = run_two_ranks("nd:C4:4", tmp_path, world)
+    a = check_nd(res, world)
+    full = a["ref_plan"]["exchange_doubles"]                 # the replicated factorisation's payload: every non-zero tile of S | rhs
+    assert a["plan"]["exchange_doubles"] <= {2: 0.12, 4: 0.25, 8: 0.6}[world] * full
+    assert a["plan"]["separator_tiles"] == a["top_tile_columns"]
