@@ -261,7 +261,10 @@ def next_rows(prob, dp, device):
         init = poses + np.concatenate([rng.normal(0, 0.01, (2, 3)), rng.normal(0, 0.08, (2, 3))], axis=1)
         dt, r = timed(lambda: capi.pnp_tasks(cam, 1, (0, 1280), X, xy, subs, init, 10, 3.0, device=device))
         out["f3_pnp_hypotheses"] = {"ms_per_call": dt * 1e3, "hypotheses": H, "subset": m, "points_scored": int(len(X)), "hypotheses_per_s": H / dt,
-                                    "best_inliers": int(r["num_inliers"].max()), "true_inliers": int((~bad).sum())}
+                                    "best_inliers": int(r["num_inliers"].max()), "true_inliers": int((~bad).sum()),
+                                    "roofline": {"bound": "latency", "waves_per_cu": H / 64 / 256,
+                                                 "note": "a hypothesis per lane: 16 384 hypotheses are ONE wave per CU — one SIMD of four, running ten dependent LM iterations of "
+                                                         "fp64 code each; neither HBM nor the matrix pipe is near a limit (0.31 ms kernel by rocprofv3, DESIGN.md §6); more hypotheses per call fill the idle SIMDs"}}
     except Exception as e:  # noqa: BLE001
         out["f3_pnp_hypotheses"] = {"error": repr(e)}
     return out
@@ -301,14 +304,33 @@ def main():
     from rsba_amd.scene import SEED, make_config
 
     full = make_config(args.config, seed=SEED).problem       # the same scene on every rank
-    prob = full.shard(rank, world) if world > 1 else full     # this rank's observations: by point, cameras replicated
+    # this rank's observations: by point, cameras replicated — the points cut along the top separators of the reduced system's
+    # elimination tree (rsba_partition_points: every rank then factors its own part of S, only the separators' tiles travel);
+    # RSBA_BENCH_PARTITION=modulo keeps the round-robin partition of the replicated factorisation for A/B runs
+    partition = "single GPU"
+    if world > 1:
+        owner = None
+        if os.environ.get("RSBA_BENCH_PARTITION", "separators") != "modulo":
+            try:
+                owner, ntop = capi.partition_points(full, world)
+                partition = f"by point along the top separators of the elimination tree ({ntop} shared tile columns), cameras replicated"
+            except capi.RsbaError as e:
+                partition = f"by point (round robin: {e}), cameras replicated"
+        else:
+            partition = "by point (round robin), cameras replicated"
+        prob = full.shard(rank, world, owner)
+    else:
+        prob = full
     dp = capi.DeviceProblem(prob, device=local_rank)
     comm = None
+    serialize = False
     transport = "none (single GPU)"
     if world > 1 and not args.no_lm:
         from rsba_amd.distributed import attach, attach_rccl
         if one_gpu:
-            attach(dp); transport = "callback: torch.distributed gloo staged through the host (test hook)"
+            serialize = os.environ.get("RSBA_BENCH_SERIALIZE", "1") == "1"   # ranks sharing the GPU take turns: per-rank device times as on a node
+            attach(dp, serialize=serialize)
+            transport = "callback: torch.distributed gloo staged through the host (test hook" + ("; ranks take turns on the shared GPU)" if serialize else ")")
         else:
             comm = attach_rccl(dp, local_rank); transport = "native: ncclAllReduce (RCCL over xGMI) issued by librsba_amd on its stream"
 
@@ -371,16 +393,22 @@ def main():
                 # first_solve_wall_s is what a fresh HANDLE costs — symbolic phase + allocations + the solve — in a process that has
                 # solved before (windowedBA builds a handle per frame, VideoSfMHandler.cc:185-214): another handle on the same scene
                 # takes the process's own first-time costs (kernel images, first streams, the plan's host scratch being mapped)
+                t_cold = time.perf_counter()
                 with capi.DeviceProblem(prob.copy(), device=local_rank) as warm:
                     if world > 1:   # (the same exchange as the timed handle; every rank does this, so the collectives pair up)
                         if comm is not None:
                             warm.set_exchange_rccl(comm, rank, world); warm.sync_block_structure()
                         else:
                             from rsba_amd.distributed import attach
-                            attach(warm)
+                            attach(warm, serialize=serialize)
                     warm.solve(capi.default_options(max_num_iterations=1))
+                    t_cold = time.perf_counter() - t_cold
                 box["lm"] = solve_timed(dp, prob, world, args.lm_iters)
+                box["lm"]["first_handle_of_the_process_s"] = t_cold     # create + symbolic phase + ONE iteration, incl. kernel images, first streams, the plan's host scratch
+                box["lm"]["first_solve_wall_s_note"] = "a fresh handle in a process that has solved before (what windowedBA pays per call): symbolic phase + allocations + the solve"
                 box["roof"] = roofline_lm(prob, dp, args.lm_iters, capi)
+                if world > 1:
+                    box["collectives"] = dp.exchange_stats()
             except Exception as e:  # noqa: BLE001 - reported in the JSON line
                 box.setdefault("lm", {"error": repr(e)})
                 box.setdefault("roof", {"error": repr(e)})
@@ -394,6 +422,28 @@ def main():
         if isinstance(lm, dict) and "error" not in lm:
             lm["exchange"] = transport
             lm["observations_total"] = int(total_obs)
+        if world > 1 and not lm_hung:
+            # a first multi-rank run should be diagnosable from its line alone: every rank's device time per phase (HIP events of its
+            # own solve), what each kind of collective carried, and the communicator as the library's RCCL sees it
+            mine = {"rank": rank, "observations": int(prob.num_observations)}
+            roof = box.get("roof")
+            if isinstance(roof, dict) and "phases" in roof:
+                mine["phase_ms_per_lm_iteration"] = {r["phase"]: r["ms_per_lm_iteration"] for r in roof["phases"]}
+                mine["device_ms_per_lm_iteration_without_exchange"] = sum(r["ms_per_lm_iteration"] for r in roof["phases"] if r["phase"] != "exchange")
+                mine["plan"] = {k: roof["plan"][k] for k in ("sharded_factorisation", "exchange_doubles", "separator_tiles", "separator_factor_tiles", "local_tasks", "separator_tasks",
+                                                                 "local_levels", "separator_levels", "levels", "tasks", "schur_chunks")}
+            if isinstance(box.get("collectives"), dict):
+                n_it = max(1, (lm or {}).get("iterations", 1)) if isinstance(lm, dict) else 1
+                mine["collectives_of_the_profiled_solve"] = box["collectives"]["collectives"]
+            if comm is not None:
+                mine["rccl"] = capi.rccl_describe(comm)
+            rows = [None] * world
+            dist.all_gather_object(rows, mine)
+            if rank == 0 and isinstance(lm, dict):
+                lm["per_rank"] = rows
+                if serialize:
+                    lm["note_one_gpu_hook"] = ("all ranks share ONE GPU and take turns between collectives: per_rank phase times are each rank's own device time "
+                                               "(what its GPU would be busy for on a node); ms_per_lm_iteration and the collectives' ms include the waiting for the other ranks' turns")
 
     out = None
     if rank == 0:
@@ -406,13 +456,19 @@ def main():
                                    f"{full.num_points} points, {full.num_observations} observations, HORIZONTAL shutter, "
                                    + ("calibrated" if full.calibrated else f"shared intrinsics as a parameter block, Huber({full.huber_a:g})"),
                        "observations_total": int(total_obs), "observations_this_rank": int(prob.num_observations), "jacobian_cols": prob.jacobian_cols,
-                       "partition": "by point, cameras replicated" if world > 1 else "single GPU"},
+                       "partition": partition},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel": kname, "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": abytes, "bytes_per_observation": abytes / max(1, prob.num_observations),
                          "rank": 0},
             "lm": lm, "roofline_lm": lm_roof,
         }
+        try:
+            free_b, total_b = torch.cuda.mem_get_info(local_rank)
+            out["device_memory"] = {"in_use_bytes": int(total_b - free_b), "total_bytes": int(total_b),
+                                    "note": "hipMemGetInfo at the end of the run: the problem's handle (observations, parameters, evaluation outputs, plan, both sets of the Cholesky's write-once cells) plus the runtime's own"}
+        except Exception as e:  # noqa: BLE001
+            out["device_memory"] = {"error": repr(e)}
         if not args.no_next_rows and world == 1 and not lm_hung and args.config == "C4":
             out["next_rows"] = next_rows(prob, dp, local_rank)
         if not args.no_cpu_baseline and world == 1:

@@ -85,7 +85,7 @@ inline void normalised_point(const double cam[NUM_CAM_PARAMS], double u, double 
   out[0] = pu[0]; out[1] = pu[1];
 }
 // eigenvector of the smallest eigenvalue of a symmetric 12 x 12 matrix (cyclic Jacobi)
-inline void smallest_eigenvector12(double a[12][12], double vec[12]) {
+inline void smallest_eigenvector12(double a[12][12], double vec[12], double gap[3] = nullptr) {
   double v[12][12] = {};
   for (int i = 0; i < 12; ++i) v[i][i] = 1.0;
   for (int sweep = 0; sweep < 60; ++sweep) {
@@ -104,6 +104,11 @@ inline void smallest_eigenvector12(double a[12][12], double vec[12]) {
   int best = 0;
   for (int i = 1; i < 12; ++i) if (a[i][i] < a[best][best]) best = i;
   for (int k = 0; k < 12; ++k) vec[k] = v[k][best];
+  if (gap) {   // the two smallest eigenvalues and the largest: is the null space ONE direction?
+    double second = -1.0, largest = 0.0;
+    for (int i = 0; i < 12; ++i) { if (i != best && (second < 0.0 || a[i][i] < second)) second = a[i][i]; largest = std::fmax(largest, a[i][i]); }
+    gap[0] = a[best][best]; gap[1] = second; gap[2] = largest;
+  }
 }
 // rsba pose (angle-axis world->camera, camera centre) from >= 6 correspondences idx[0..m): false when the points are degenerate
 inline bool dlt_pose(const float* opoints, const double* normalised, const int32_t* idx, int m, double pose[6]) {
@@ -112,6 +117,27 @@ inline bool dlt_pose(const float* opoints, const double* normalised, const int32
   for (int i = 0; i < m; ++i) for (int k = 0; k < 3; ++k) c[k] += opoints[3 * (size_t)idx[i] + k] / m;
   for (int i = 0; i < m; ++i) { double d2 = 0; for (int k = 0; k < 3; ++k) { const double d = opoints[3 * (size_t)idx[i] + k] - c[k]; d2 += d * d; } scale += std::sqrt(d2) / m; }
   if (!(scale > 0.0)) return false;
+  // Coplanar (or collinear) object points: the DLT's null space then has more than one dimension and the eigenvector picked from it
+  // is arbitrary — OpenCV's solvePnP switches to a homography there; this initialisation simply declines (the caller starts from the
+  // zero pose, as the reference does whenever the GS initialisation fails).  Flatness = smallest over largest eigenvalue of the
+  // points' 3 x 3 scatter matrix (closed form for a symmetric 3 x 3).
+  {
+    double sc[6] = {0, 0, 0, 0, 0, 0};   // xx xy xz yy yz zz
+    for (int i = 0; i < m; ++i) {
+      const double d[3] = {(opoints[3 * (size_t)idx[i]] - c[0]) / scale, (opoints[3 * (size_t)idx[i] + 1] - c[1]) / scale, (opoints[3 * (size_t)idx[i] + 2] - c[2]) / scale};
+      sc[0] += d[0] * d[0]; sc[1] += d[0] * d[1]; sc[2] += d[0] * d[2]; sc[3] += d[1] * d[1]; sc[4] += d[1] * d[2]; sc[5] += d[2] * d[2];
+    }
+    const double q = (sc[0] + sc[3] + sc[5]) / 3.0, p1 = sc[1] * sc[1] + sc[2] * sc[2] + sc[4] * sc[4];
+    const double p2 = (sc[0] - q) * (sc[0] - q) + (sc[3] - q) * (sc[3] - q) + (sc[5] - q) * (sc[5] - q) + 2.0 * p1, pp = std::sqrt(p2 / 6.0);
+    double lmin = q, lmax = q;
+    if (pp > 0.0) {
+      const double b[6] = {(sc[0] - q) / pp, sc[1] / pp, sc[2] / pp, (sc[3] - q) / pp, sc[4] / pp, (sc[5] - q) / pp};
+      const double detb = b[0] * (b[3] * b[5] - b[4] * b[4]) - b[1] * (b[1] * b[5] - b[4] * b[2]) + b[2] * (b[1] * b[4] - b[3] * b[2]);
+      const double phi = std::acos(std::fmin(1.0, std::fmax(-1.0, 0.5 * detb))) / 3.0;
+      lmax = q + 2.0 * pp * std::cos(phi); lmin = q + 2.0 * pp * std::cos(phi + 2.0943951023931953);
+    }
+    if (!(lmin > 1e-6 * lmax)) return false;
+  }
   double ata[12][12] = {};
   for (int i = 0; i < m; ++i) {
     const double X[4] = {(opoints[3 * (size_t)idx[i]] - c[0]) / scale, (opoints[3 * (size_t)idx[i] + 1] - c[1]) / scale, (opoints[3 * (size_t)idx[i] + 2] - c[2]) / scale, 1.0};
@@ -120,8 +146,9 @@ inline bool dlt_pose(const float* opoints, const double* normalised, const int32
     for (int k = 0; k < 4; ++k) { r0[k] = X[k]; r0[8 + k] = -u * X[k]; r1[4 + k] = X[k]; r1[8 + k] = -v * X[k]; }
     for (int a = 0; a < 12; ++a) for (int b = 0; b < 12; ++b) ata[a][b] += r0[a] * r0[b] + r1[a] * r1[b];
   }
-  double pvec[12];
-  smallest_eigenvector12(ata, pvec);
+  double pvec[12], gap[3];
+  smallest_eigenvector12(ata, pvec, gap);
+  if (!(gap[1] > 1e-9 * gap[2]) || !(gap[0] < 0.05 * gap[1])) return false;   // a second (near-)null direction, or no null direction to speak of: an ambiguous DLT is not an initialisation
   double M[9], t[3];
   for (int r = 0; r < 3; ++r) { for (int k = 0; k < 3; ++k) M[3 * r + k] = pvec[4 * r + k]; t[r] = pvec[4 * r + 3]; }
   // the points must end up in front of the camera (z of the centroid = t[2] in the shifted frame)

@@ -352,6 +352,29 @@ int32_t rsba_set_block_structure(rsba_handle* h, const uint8_t* mask, const int6
  * the partition is checked (RSBA_ERR_INVALID_ARGUMENT when some point has observations on more than one rank). */
 int32_t rsba_sync_block_structure(rsba_handle* h);
 
+/* What the exchange of a sharded solve carried (a first multi-rank run should be diagnosable from its numbers alone): per kind of
+ * collective the calls and fp64 elements since the handle was created, and — after an rsba_solve with options.profile_phases — the
+ * HIP-event time of those of that solve, measured on the solver's stream around each collective. */
+enum {
+  RSBA_EXCHANGE_SETUP = 0,      /* co-visibility structure, problem-size counts, the form of the plan (once per handle / solve) */
+  RSBA_EXCHANGE_CAMERA = 1,     /* (1) per-camera gradient blocks g_c | diag(U) | cost scalars, once per linearisation */
+  RSBA_EXCHANGE_SYSTEM = 2,     /* (2) the reduced camera system: every structurally non-zero tile | rhs (replicated factorisation) or the
+                                 *     separators' tiles | their rhs rows between the two launches of a sharded factorisation */
+  RSBA_EXCHANGE_SCALARS = 3,    /* (3) step scalars (two calls) and the gradient max-norm, once per iteration */
+  RSBA_EXCHANGE_STEP = 4,       /* (4) the gather of the camera step (sharded factorisation only) */
+  RSBA_EXCHANGE_POINTS = 5,     /* the merge of the solved points at the end of a solve */
+  RSBA_NUM_EXCHANGES = 6
+};
+typedef struct rsba_exchange_stats {
+  int64_t calls[RSBA_NUM_EXCHANGES], doubles[RSBA_NUM_EXCHANGES];
+  double ms[RSBA_NUM_EXCHANGES];
+  int32_t rank, world;
+} rsba_exchange_stats;
+int32_t rsba_get_exchange_stats(rsba_handle* h, rsba_exchange_stats* out);
+const char* rsba_exchange_name(int32_t kind);
+/* == ncclGetVersion / ncclCommCount / ncclCommUserRank of a communicator, as the library's own RCCL sees it (-1 where the symbol is missing) */
+int32_t rsba_rccl_describe(void* nccl_comm, int32_t* version, int32_t* nranks, int32_t* rank);
+
 /* Which rank should own which point: owner [num_points] (host array), computed on the host from the WHOLE problem's description
  * (no device needed; every rank of a job computes the same answer from the same description).  Any by-point partition gives a
  * correct sharded solve; THIS one places the cut along the top separators of the nested dissection that orders the reduced camera

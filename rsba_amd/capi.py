@@ -25,8 +25,9 @@ EXPORTS = [
     "rsba_pnp_tasks", "rsba_pnp_inliers", "rsba_set_inter_frame_ratio_free", "rsba_get_inter_frame_ratio",
     "rsba_sync_block_structure", "rsba_rccl_get_unique_id", "rsba_rccl_comm_create", "rsba_rccl_comm_destroy", "rsba_set_exchange_rccl",
     "rsba_get_phase_times", "rsba_phase_name", "rsba_get_plan_stats", "rsba_validate_frame", "rsba_reproject_frame", "rsba_set_pose_priors", "rsba_set_global_shutter_frames", "rsba_release_host_scratch",
-    "rsba_partition_points",
+    "rsba_partition_points", "rsba_get_exchange_stats", "rsba_exchange_name", "rsba_rccl_describe",
 ]
+NUM_EXCHANGES = 6
 NUM_PHASES = 13
 
 
@@ -97,6 +98,10 @@ class PlanStats(C.Structure):
                                          "cholesky_flops", "exchange_doubles", "schur_groups", "schur_mfma_issued", "schur_launches",
                                          "sharded_factorisation", "separator_tiles", "separator_factor_tiles", "local_tasks", "separator_tasks",
                                          "local_levels", "separator_levels")]
+
+
+class ExchangeStats(C.Structure):
+    _fields_ = [("calls", C.c_int64 * NUM_EXCHANGES), ("doubles", C.c_int64 * NUM_EXCHANGES), ("ms", C.c_double * NUM_EXCHANGES), ("rank", C.c_int32), ("world", C.c_int32)]
 
 
 def build(force: bool = False) -> str:
@@ -303,7 +308,10 @@ class DeviceProblem:
         """ceres::Covariance blocks of one frame (VideoSfMHandler.cc:602-621) -> [CD, CD]"""
         cd = 6 * self.prob.poses_per_frame
         out = np.zeros((cd, cd))
-        _check(lib().rsba_pose_covariance(self._h, C.c_int32(frame), _ptr(out)))
+        try:
+            _check(lib().rsba_pose_covariance(self._h, C.c_int32(frame), _ptr(out)))
+        finally:
+            self._exchanged()
         return out
 
     def set_exchange_rccl(self, comm, rank: int, world: int):
@@ -312,7 +320,10 @@ class DeviceProblem:
 
     def sync_block_structure(self):
         """All ranks: union of the co-visibility structures over the installed exchange (before the first solve)."""
-        _check(lib().rsba_sync_block_structure(self._h))
+        try:
+            _check(lib().rsba_sync_block_structure(self._h))
+        finally:
+            self._exchanged()
 
     def phase_times(self) -> dict:
         """HIP-event time per phase of the last solve run with profile_phases=1 -> {name: (ms, calls)}"""
@@ -320,10 +331,29 @@ class DeviceProblem:
         _check(lib().rsba_get_phase_times(self._h, C.byref(t)))
         return {lib().rsba_phase_name(C.c_int32(p)).decode(): (t.ms[p], t.calls[p]) for p in range(NUM_PHASES)}
 
+    def exchange_stats(self) -> dict:
+        """Per kind of collective: calls and bytes since the handle was created, HIP-event ms of the last solve with profile_phases."""
+        L = lib()
+        st = ExchangeStats()
+        _check(L.rsba_get_exchange_stats(self._h, C.byref(st)))
+        L.rsba_exchange_name.restype = C.c_char_p
+        return {"rank": st.rank, "world": st.world,
+                "collectives": {L.rsba_exchange_name(C.c_int32(k)).decode(): {"calls": int(st.calls[k]), "bytes": int(st.doubles[k]) * 8, "ms": float(st.ms[k])} for k in range(NUM_EXCHANGES)}}
+
     def plan_stats(self) -> dict:
         st = PlanStats()
-        _check(lib().rsba_get_plan_stats(self._h, C.byref(st)))
+        try:
+            _check(lib().rsba_get_plan_stats(self._h, C.byref(st)))
+        finally:
+            self._exchanged()
         return {k: int(getattr(st, k)) for k, _ in PlanStats._fields_}
+
+    def _exchanged(self):
+        """After an API call that may have run collectives: the hook of a transport that makes ranks sharing a GPU take turns
+        (rsba_amd.distributed.attach(serialize=True)); nothing otherwise."""
+        hook = getattr(self, "_after_exchange", None)
+        if hook is not None:
+            hook()
 
     def device_view(self) -> DeviceView:
         v = DeviceView()
@@ -335,7 +365,10 @@ class DeviceProblem:
         o = options or default_options()
         s = SolverSummary()
         tr = (Iteration * trace_cap)()
-        st = lib().rsba_solve(self._h, C.byref(o), C.byref(s), tr, C.c_int32(trace_cap))
+        try:
+            st = lib().rsba_solve(self._h, C.byref(o), C.byref(s), tr, C.c_int32(trace_cap))
+        finally:
+            self._exchanged()
         _check(st)
         if getattr(self.prob, "ratio_free", False) and self.prob.prior_kind:
             self.prob.inter_frame_ratio = self.inter_frame_ratio()       # a free ratio block is solved for, like every parameter
@@ -375,6 +408,13 @@ def rccl_comm_create(uid: bytes, rank: int, world: int, device: int) -> int:
     comm = C.c_void_p()
     _check(lib().rsba_rccl_comm_create(C.c_char_p(uid), C.c_int32(rank), C.c_int32(world), C.c_int32(device), C.byref(comm)))
     return comm.value
+
+
+def rccl_describe(comm: int | None = None) -> dict:
+    """ncclGetVersion / ncclCommCount / ncclCommUserRank as the library's own RCCL sees them (-1 where a symbol is missing)."""
+    v, n, r = C.c_int32(-1), C.c_int32(-1), C.c_int32(-1)
+    _check(lib().rsba_rccl_describe(C.c_void_p(comm) if comm else None, C.byref(v), C.byref(n), C.byref(r)))
+    return {"rccl_version": int(v.value), "comm_ranks": int(n.value), "comm_rank": int(r.value)}
 
 
 def rccl_comm_destroy(comm: int):

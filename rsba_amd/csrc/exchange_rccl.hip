@@ -21,6 +21,9 @@ typedef enum { ncclInt8 = 0, ncclUint8 = 1, ncclInt32 = 2, ncclUint32 = 3, ncclI
 ncclResult_t ncclGetUniqueId(ncclUniqueId* uniqueId);
 ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId commId, int rank);
 ncclResult_t ncclCommDestroy(ncclComm_t comm);
+ncclResult_t ncclGetVersion(int* version);
+ncclResult_t ncclCommCount(const ncclComm_t comm, int* count);
+ncclResult_t ncclCommUserRank(const ncclComm_t comm, int* rank);
 ncclResult_t ncclAllReduce(const void* sendbuff, void* recvbuff, size_t count, ncclDataType_t datatype, ncclRedOp_t op, ncclComm_t comm, hipStream_t stream);
 const char* ncclGetErrorString(ncclResult_t result);
 }
@@ -41,6 +44,9 @@ struct Rccl {
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
   decltype(&ncclAllReduce) AllReduce = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclGetVersion) GetVersion = nullptr;      // (optional: only rsba_rccl_describe asks)
+  decltype(&ncclCommCount) CommCount = nullptr;
+  decltype(&ncclCommUserRank) CommUserRank = nullptr;
   std::string error;
   bool ok = false;
 };
@@ -64,6 +70,9 @@ Rccl& rccl() {
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
     r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(lib, "ncclAllReduce"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+    r.GetVersion = reinterpret_cast<decltype(r.GetVersion)>(dlsym(lib, "ncclGetVersion"));
+    r.CommCount = reinterpret_cast<decltype(r.CommCount)>(dlsym(lib, "ncclCommCount"));
+    r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(dlsym(lib, "ncclCommUserRank"));
     r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce && r.GetErrorString;
     if (!r.ok) r.error = "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllReduce";
   });
@@ -112,6 +121,19 @@ int32_t rsba_rccl_comm_create(const void* id, int32_t rank, int32_t world, int32
 
 void rsba_rccl_comm_destroy(void* comm) {
   if (comm && rccl().ok) (void)rccl().CommDestroy(static_cast<ncclComm_t>(comm));
+}
+
+int32_t rsba_rccl_describe(void* nccl_comm, int32_t* version, int32_t* nranks, int32_t* rank) {
+  Rccl& r = rccl();
+  if (!r.ok) return rsba_set_error(RSBA_ERR_COMM, r.error.c_str());
+  int v = -1, n = -1, k = -1;
+  if (r.GetVersion && r.GetVersion(&v) != ncclSuccess) v = -1;
+  if (nccl_comm && r.CommCount && r.CommCount(static_cast<ncclComm_t>(nccl_comm), &n) != ncclSuccess) n = -1;
+  if (nccl_comm && r.CommUserRank && r.CommUserRank(static_cast<ncclComm_t>(nccl_comm), &k) != ncclSuccess) k = -1;
+  if (version) *version = v;
+  if (nranks) *nranks = n;
+  if (rank) *rank = k;
+  return RSBA_OK;
 }
 
 int32_t rsba_set_exchange_rccl(rsba_handle* h, void* nccl_comm, int32_t rank, int32_t world) {

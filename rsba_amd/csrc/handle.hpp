@@ -43,6 +43,7 @@ struct rsba_handle {
   rsba_allreduce_fn allreduce = nullptr;
   void* allreduce_ctx = nullptr;
   int rank = 0, world = 1;
+  int64_t x_calls[RSBA_NUM_EXCHANGES] = {}, x_doubles[RSBA_NUM_EXCHANGES] = {};   // collectives issued since the handle was created, by kind (rsba_get_exchange_stats)
   std::vector<uint8_t> union_mask;     // [F*F] structure installed by the host, empty = local structure
   std::vector<int64_t> frame_obs_total;// [F] global observation count per frame
 };

@@ -49,6 +49,7 @@ struct PhaseTimer {
 
 struct Solver {
   PhaseTimer timer;
+  PhaseTimer xtimer;   // the same for the collectives of a sharded solve, by kind (RSBA_EXCHANGE_*)
   rsba_plan_stats stats{};
   SolverDev sv{};
   std::vector<void*> allocs;
@@ -238,7 +239,7 @@ void parallel_ranges(int nthr, int64_t n, F&& fn) {
   for (auto& th : pool) th.join();
 }
 
-int32_t exchange(rsba_handle* h, double* buf, int64_t count, int op);   // (below)
+int32_t exchange(rsba_handle* h, double* buf, int64_t count, int op, int kind);   // (below)
 
 struct PhaseScope {
   PhaseTimer* t = nullptr; int phase; hipStream_t st; hipEvent_t a = nullptr;
@@ -567,7 +568,7 @@ int32_t build_solver_impl(rsba_handle* h) {
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_bad), sizeof(double)));
     hipError_t e = hipMemcpyAsync(d_bad, &bad, sizeof bad, hipMemcpyHostToDevice, h->stream);
     int32_t rcx = RSBA_OK;
-    if (e == hipSuccess) rcx = exchange(h, d_bad, 1, 1);
+    if (e == hipSuccess) rcx = exchange(h, d_bad, 1, 1, RSBA_EXCHANGE_SETUP);
     if (e == hipSuccess && rcx == RSBA_OK) e = hipMemcpyAsync(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess && rcx == RSBA_OK) e = hipStreamSynchronize(h->stream);
     (void)hipFree(d_bad);
@@ -1196,14 +1197,20 @@ int32_t reset_scales(rsba_handle* h) {
   return RSBA_OK;
 }
 
-// all-reduce across the ranks of a point-partitioned solve (no-op for a single GPU)
-int32_t exchange(rsba_handle* h, double* buf, int64_t count, int op) {
+// all-reduce across the ranks of a point-partitioned solve (no-op for a single GPU); kind: RSBA_EXCHANGE_* (statistics)
+int32_t exchange(rsba_handle* h, double* buf, int64_t count, int op, int kind) {
   if (!h->allreduce) return RSBA_OK;   // (a one-rank exchange still goes through its transport: identity, but the path is exercised)
   (void)rsba_set_error(RSBA_OK, "");   // a transport that fails says why through rsba_set_error (the RCCL one: the ncclResult string); keep what it said
-  if (h->allreduce(h->allreduce_ctx, buf, count, op, h->stream) != 0) {
+  ++h->x_calls[kind]; h->x_doubles[kind] += count;
+  PhaseTimer* xt = h->solver && h->solver->xtimer.on ? &h->solver->xtimer : nullptr;
+  hipEvent_t a = nullptr;
+  if (xt) { a = xt->get(); (void)hipEventRecord(a, h->stream); }
+  const int failed = h->allreduce(h->allreduce_ctx, buf, count, op, h->stream);
+  if (xt) { hipEvent_t b = xt->get(); (void)hipEventRecord(b, h->stream); xt->pending.push_back({kind, a, b}); }
+  if (failed != 0) {
     const std::string why = rsba_last_error();
-    char where[96];
-    std::snprintf(where, sizeof where, " (all-reduce of %lld doubles, op %d, rank %d of %d)", (long long)count, op, h->rank, h->world);
+    char where[112];
+    std::snprintf(where, sizeof where, " (all-reduce %s of %lld doubles, op %d, rank %d of %d)", rsba_exchange_name(kind), (long long)count, op, h->rank, h->world);
     return rsba_set_error(RSBA_ERR_COMM, ((why.empty() ? std::string("the all-reduce callback reported a failure") : why) + where).c_str());
   }
   return RSBA_OK;
@@ -1246,7 +1253,7 @@ int32_t linearize(rsba_handle* h, bool have_eval = false) {
   PhaseScope ps(h, RSBA_PHASE_EXCHANGE);
   if (!h->allreduce) { HIP_TRY(launch_local_linearize(h->dp, s->sv, h->d_cost2, h->stream)); return RSBA_OK; }   // one rank: nothing to sum
   HIP_TRY(launch_pack_linearize(h->dp, s->sv, h->d_cost2, h->stream));
-  int32_t rc = exchange(h, s->sv.xbuf, 2 * s->sv.n + 3, 0);
+  int32_t rc = exchange(h, s->sv.xbuf, 2 * s->sv.n + 3, 0, RSBA_EXCHANGE_CAMERA);
   if (rc) return rc;
   HIP_TRY(launch_unpack_linearize(h->dp, s->sv, h->stream));
   return RSBA_OK;
@@ -1257,7 +1264,7 @@ int32_t gradient_max(rsba_handle* h) {
   PhaseScope ps(h, RSBA_PHASE_OTHER);
   HIP_TRY(launch_gradient_max(h->dp, s->sv, h->stream));
   if (s->sv.lead) HIP_TRY(launch_pose_prior_gradmax(h->dp, s->sv, s->pp, h->stream));
-  return exchange(h, s->sv.scalars + kGradMax, 1, 1);
+  return exchange(h, s->sv.scalars + kGradMax, 1, 1, RSBA_EXCHANGE_SCALARS);
 }
 
 // reduced camera system S and rhs at the given trust-region radius (point elimination), summed over the ranks
@@ -1285,11 +1292,11 @@ int32_t reduce_system(rsba_handle* h, double radius) {
   if (h->allreduce && s->exch_slots) {   // only the tiles that can be non-zero travel (the fill-in tiles of the layout are zero on every rank)
     const int64_t count = (int64_t)s->exch_tiles * kTile * kTile + sv.npad;
     HIP_TRY(launch_exchange_pack(sv, s->exch_slots, s->exch_tiles, s->exch_buf, false, st));
-    if (int32_t rc = exchange(h, s->exch_buf, count, 0)) return rc;
+    if (int32_t rc = exchange(h, s->exch_buf, count, 0, RSBA_EXCHANGE_SYSTEM)) return rc;
     HIP_TRY(launch_exchange_pack(sv, s->exch_slots, s->exch_tiles, s->exch_buf, true, st));
     return RSBA_OK;
   }
-  return exchange(h, sv.S, (int64_t)sv.nslots * kTile * kTile + sv.npad, 0);
+  return exchange(h, sv.S, (int64_t)sv.nslots * kTile * kTile + sv.npad, 0, RSBA_EXCHANGE_SYSTEM);
 }
 
 // S y = rhs: left-looking tile Cholesky (forward solve rides along), then the backward solve: one persistent DAG
@@ -1327,7 +1334,7 @@ int32_t solve_reduced_system(rsba_handle* h) {
       {
         PhaseScope pe(h, RSBA_PHASE_EXCHANGE);
         HIP_TRY(launch_top_assemble(sv, s->d_top_slots, s->d_top_info, s->d_asm_ptr, s->d_asm_list, s->d_top_tiles, s->ntop_slots, s->topx_buf, st));
-        if (int32_t rc = exchange(h, s->topx_buf, count, 0)) return rc;
+        if (int32_t rc = exchange(h, s->topx_buf, count, 0, RSBA_EXCHANGE_SYSTEM)) return rc;
         HIP_TRY(launch_top_unpack(sv, s->d_top_slots, s->d_top_info, s->d_top_tiles, s->ntop_slots, s->topx_buf, st));
       }
       // launch B: the separators (every rank alike), forward and backward, then this rank's part backward
@@ -1336,7 +1343,7 @@ int32_t solve_reduced_system(rsba_handle* h) {
       {
         PhaseScope pe(h, RSBA_PHASE_EXCHANGE);
         HIP_TRY(launch_step_rows(sv.yv, s->d_row_mine, sv.npad, s->ybuf, st));
-        if (int32_t rc = exchange(h, s->ybuf, sv.npad, 0)) return rc;
+        if (int32_t rc = exchange(h, s->ybuf, sv.npad, 0, RSBA_EXCHANGE_STEP)) return rc;
         HIP_TRY(hipMemcpyAsync(sv.yv, s->ybuf, (size_t)sv.npad * sizeof(double), hipMemcpyDeviceToDevice, st));
       }
     } else
@@ -1502,6 +1509,17 @@ extern "C" int32_t rsba_get_phase_times(rsba_handle* h, rsba_phase_times* out) {
   for (int p = 0; p < RSBA_NUM_PHASES; ++p) { out->ms[p] = h->solver->timer.ms[p]; out->calls[p] = h->solver->timer.calls[p]; }
   return RSBA_OK;
 }
+extern "C" const char* rsba_exchange_name(int32_t kind) {
+  static const char* names[RSBA_NUM_EXCHANGES] = {"setup", "(1) camera blocks", "(2) reduced system", "(3) step scalars", "(4) camera step", "point merge"};
+  return kind >= 0 && kind < RSBA_NUM_EXCHANGES ? names[kind] : "?";
+}
+extern "C" int32_t rsba_get_exchange_stats(rsba_handle* h, rsba_exchange_stats* out) {
+  if (!h || !out) return rsba_set_error(RSBA_ERR_INVALID_ARGUMENT, "null argument");
+  std::memset(out, 0, sizeof *out);
+  out->rank = h->rank; out->world = h->world;
+  for (int k = 0; k < RSBA_NUM_EXCHANGES; ++k) { out->calls[k] = h->x_calls[k]; out->doubles[k] = h->x_doubles[k]; if (h->solver) out->ms[k] = h->solver->xtimer.ms[k]; }
+  return RSBA_OK;
+}
 extern "C" const char* rsba_phase_name(int32_t phase) {
   static const char* names[RSBA_NUM_PHASES] = {"eval_lm", "camera_blocks", "point_blocks", "point_factor", "project", "schur", "cholesky",
                                                "back_substitute", "candidate", "eval_trial", "priors", "exchange", "other"};
@@ -1537,7 +1555,7 @@ extern "C" int32_t rsba_sync_block_structure(rsba_handle* h) {
   double* dev = nullptr;
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dev), count * sizeof(double)));
   hipError_t e = hipMemcpyAsync(dev, host.data(), count * sizeof(double), hipMemcpyHostToDevice, h->stream);
-  if (e == hipSuccess) { rc = exchange(h, dev, (int64_t)count, 0); if (rc) { (void)hipFree(dev); return rc; } }
+  if (e == hipSuccess) { rc = exchange(h, dev, (int64_t)count, 0, RSBA_EXCHANGE_SETUP); if (rc) { (void)hipFree(dev); return rc; } }
   if (e == hipSuccess) e = hipMemcpyAsync(host.data(), dev, count * sizeof(double), hipMemcpyDeviceToHost, h->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
   (void)hipFree(dev);
@@ -1658,10 +1676,12 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
   sum->termination_type = RSBA_NO_CONVERGENCE;
   s->timer.on = opt->profile_phases != 0;
   if (s->timer.on) s->timer.reset();
+  s->xtimer.on = s->timer.on && h->allreduce;
+  if (s->xtimer.on) s->xtimer.reset();
   struct TimerGuard {   // whichever way this call returns, later rsba_gradient / covariance calls must not keep queueing phase records
-    PhaseTimer& t;
-    ~TimerGuard() { if (t.on) { t.on = false; t.pending.clear(); t.next = 0; } }
-  } timer_guard{s->timer};
+    PhaseTimer& t; PhaseTimer& x;
+    ~TimerGuard() { for (PhaseTimer* q : {&t, &x}) if (q->on) { q->on = false; q->pending.clear(); q->next = 0; } }
+  } timer_guard{s->timer, s->xtimer};
   { const char* lv = std::getenv("RSBA_CHOL_LEVELS"); s->use_levels = opt->level_scheduled_cholesky != 0 || (lv && lv[0] == '1'); }
   {
     // problem-size figures of the whole (all-rank) problem
@@ -1669,7 +1689,7 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
     double cnt[3] = {(double)dp.N + npri, (double)(s->num_reduced_blocks + s->num_priors_reduced), (double)s->num_reduced_params};
     if (h->allreduce) {
       HIP_TRY(hipMemcpyAsync(sv.scalars + 8, cnt, sizeof cnt, hipMemcpyHostToDevice, st));
-      if ((rc = exchange(h, sv.scalars + 8, 3, 0))) return rc;
+      if ((rc = exchange(h, sv.scalars + 8, 3, 0, RSBA_EXCHANGE_SETUP))) return rc;
       HIP_TRY(hipMemcpyAsync(cnt, sv.scalars + 8, sizeof cnt, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipMemsetAsync(sv.scalars + 8, 0, 4 * sizeof(double), st));   // slots 8-11 ride in the per-iteration sum from here on
       HIP_TRY(hipStreamSynchronize(st));
@@ -1696,6 +1716,7 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
     if (free_ratio) HIP_TRY(hipMemcpyAsync(ratio_hg, s->ratio4, sizeof ratio_hg, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (s->timer.on) s->timer.resolve();
+    if (s->xtimer.on) s->xtimer.resolve();
     cost2[0] = host_sc[kCost]; cost2[1] = host_sc[kFixedCost];
     nfail = host_sc[kEvalFailed] != 0.0; cfail = host_sc[kSolveFailed] != 0.0;
     return RSBA_OK;
@@ -1707,7 +1728,7 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
     const size_t npose = (size_t)dp.F * dp.P * 6, npt = (size_t)dp.M * 3;
     if (h->allreduce && h->world > 1) {   // every rank leaves with the complete point array: each point from its owner
       HIP_TRY(launch_own_points(dp, sv, s->merge_buf, st));
-      int32_t rc2 = exchange(h, s->merge_buf, 4 * (int64_t)dp.M, 0);
+      int32_t rc2 = exchange(h, s->merge_buf, 4 * (int64_t)dp.M, 0, RSBA_EXCHANGE_POINTS);
       if (rc2) return rc2;
       HIP_TRY(launch_merge_points(dp, s->merge_buf, st));
     }
@@ -1717,6 +1738,7 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
     if (dp.pp_count > 0 && h->pp_host) HIP_TRY(hipMemcpyAsync(h->pp_host, dp.pp_value, 6 * (size_t)dp.pp_count * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (s->timer.on) { s->timer.resolve(); s->timer.on = false; }
+    if (s->xtimer.on) { s->xtimer.resolve(); s->xtimer.on = false; }
     h->prior_ratio_result = dp.prior_ratio;
     sum->total_time_s = now_s() - t_start;
     if (const char* path = h->solver->d_trace ? std::getenv("RSBA_CHOL_TRACE") : nullptr) {   // debugging aid, off by default
@@ -1813,8 +1835,8 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
       PhaseScope ps(h, RSBA_PHASE_EXCHANGE);
       if ((rc = await_verification(h))) return rc;   // (its flag rides in the scalars below)
       HIP_TRY(launch_pack_trial(dp, sv, h->d_cost2, st));
-      if ((rc = exchange(h, sv.scalars, 3, 0))) return rc;
-      if ((rc = exchange(h, sv.scalars + kCost, 8, 0))) return rc;   // ... and the verification flag of the Cholesky driver: every rank decides alike
+      if ((rc = exchange(h, sv.scalars, 3, 0, RSBA_EXCHANGE_SCALARS))) return rc;
+      if ((rc = exchange(h, sv.scalars + kCost, 8, 0, RSBA_EXCHANGE_SCALARS))) return rc;   // ... and the verification flag of the Cholesky driver: every rank decides alike
     }
     if ((rc = read_back())) return rc;
     if (host_sc[kDagSuspect] != 0.0 && !s->use_levels) {

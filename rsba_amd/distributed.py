@@ -27,15 +27,30 @@ class _DevicePtr:
         self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 2}
 
 
-def make_allreduce(group=None):
-    """Build the rsba_allreduce_fn callback over a torch.distributed process group."""
+def make_allreduce(group=None, serialize: bool = False):
+    """Build the rsba_allreduce_fn callback over a torch.distributed process group.
+
+    serialize (one-GPU test hook only): ranks that SHARE a GPU take turns between two collectives — rank 0 runs its stretch of
+    device work, then rank 1, ... — so that the HIP-event phase times each rank records are those of a rank that has the GPU to
+    itself, as on a real node (the collectives themselves then measure the waiting, not a transport).  The callback object gets a
+    ``finish()`` that lets the other ranks through after the last collective of an API call."""
     import torch
     import torch.distributed as dist
 
     backend = dist.get_backend(group)
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
     # the device of the process at attach time; the callback may run on another thread (bench.py's watchdog), whose
     # "current device" would otherwise default to 0
     dev = torch.device("cuda", torch.cuda.current_device())
+    state = {"running": False}
+
+    def _turns_done():
+        """My stretch is over (the stream is idle): release the ranks behind me and wait until they are through as well."""
+        if state["running"]:
+            torch.cuda.synchronize(dev)
+            for _turn in range(rank, world):
+                dist.barrier(group=group)
+            state["running"] = False
 
     def _cb(_ctx, ptr, count, op, _stream):
         try:
@@ -45,6 +60,8 @@ def make_allreduce(group=None):
             with torch.cuda.stream(torch.cuda.ExternalStream(int(_stream), device=dev)):
                 t = torch.as_tensor(_DevicePtr(int(ptr), int(count)), device=dev)
                 red = dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX
+                if serialize:
+                    _turns_done()
                 if backend == "nccl":
                     dist.all_reduce(t, op=red, group=group)      # RCCL over xGMI
                 else:
@@ -52,12 +69,18 @@ def make_allreduce(group=None):
                     dist.all_reduce(host, op=red, group=group)
                     t.copy_(host)
                     torch.cuda.current_stream().synchronize()
+                if serialize:                                    # my turn comes after the ranks in front of me
+                    for _turn in range(rank):
+                        dist.barrier(group=group)
+                    state["running"] = True
             return 0
         except Exception as e:  # never let an exception cross the C boundary
             print(f"rsba_amd exchange failed: {e!r}", flush=True)
             return 1
 
-    return ALLREDUCE_FN(_cb)
+    fn = ALLREDUCE_FN(_cb)
+    fn.finish = _turns_done if serialize else (lambda: None)
+    return fn
 
 
 def union_structure(mask: np.ndarray, counts: np.ndarray, group=None):
@@ -73,14 +96,15 @@ def union_structure(mask: np.ndarray, counts: np.ndarray, group=None):
     return m.cpu().numpy().astype(np.uint8), c.cpu().numpy().astype(np.int64)
 
 
-def attach(dp, group=None):
+def attach(dp, group=None, serialize: bool = False):
     """Install the CALLBACK exchange (torch.distributed serves the all-reduce; gloo in the tests) on a DeviceProblem
-    holding this rank's shard.  Call before the first solve.  Production runs use attach_rccl."""
+    holding this rank's shard.  Call before the first solve.  Production runs use attach_rccl.  serialize: see make_allreduce."""
     import torch.distributed as dist
     from . import capi
 
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    dp._exchange_cb = make_allreduce(group)       # keep the callback object alive as long as the handle
+    dp._exchange_cb = make_allreduce(group, serialize)       # keep the callback object alive as long as the handle
+    dp._after_exchange = dp._exchange_cb.finish   # (called by the DeviceProblem after every API call that may have exchanged)
     capi._check(capi.lib().rsba_set_exchange(dp._h, dp._exchange_cb, None, C.c_int32(rank), C.c_int32(world)))
     dp.sync_block_structure()                     # union of the ranks' co-visibility structures, through the exchange itself
     return dp

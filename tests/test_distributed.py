@@ -146,7 +146,7 @@ def test_a_failed_exchange_says_what_failed():
         dp.solve(capi.default_options(max_num_iterations=3))
     dp.close()
     msg = str(err.value)
-    assert "all-reduce of" in msg and "rank 0 of 1" in msg, msg
+    assert "all-reduce" in msg and "doubles" in msg and "rank 0 of 1" in msg, msg
 
 
 # ---- the sharded factorisation: points partitioned along the top separators of the reduced system's elimination tree ----

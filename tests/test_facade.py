@@ -439,3 +439,47 @@ def test_dlt_of_the_global_shutter_pnp_initialisation_recovers_the_pose(oracle, 
         rvec, tvec = v[0:3], v[3:6]
         centre = -oracle.angle_axis_rotate(-rvec, tvec)          # pose = (rvec, -R^T tvec)
         assert np.max(np.abs(rvec - pose[:3])) <= 2e-3 and np.max(np.abs(centre - pose[3:])) <= 2e-2, (rvec, pose, centre)
+
+
+def test_dlt_declines_planar_targets(oracle, tmp_path):
+    """Coplanar object points (a checkerboard, a wall) leave the DLT's null space two-dimensional: the eigenvector picked from it is
+    arbitrary, and an arbitrary pose must not be handed on as the global-shutter initialisation (OpenCV's solvePnP switches to a
+    homography there).  The host glue declines — exactly planar, nearly planar (1e-4 of the extent), collinear — and still accepts
+    a shallow but genuinely three-dimensional cloud."""
+    import struct
+    import __graft_entry__ as G
+    exe = os.path.join(ROOT, "examples", "pnp_ransac")
+    if not os.path.exists(exe):
+        G.build()
+    cam = np.array([800.0, 800.0, -0.05, 0.01, 1e-3, -1e-3, 2e-3, 640.0, 360.0])
+    rng = np.random.default_rng(9)
+    pose = np.concatenate([rng.normal(0, 0.2, 3), rng.normal(0, 0.3, 3)])
+
+    def run(X):
+        X = X.astype(np.float32)
+        xy = []
+        for j in range(len(X)):
+            ok, p = oracle.reproject(cam, np.stack([pose, pose]), 0, (0, 1), X[j].astype(np.float64), 1e12)
+            assert ok
+            xy.append(p)
+        with open(tmp_path / "p.bin", "wb") as f:
+            f.write(struct.pack("<7i", len(X), 0, 0, 1, -1, 0, 6)); f.write(struct.pack("<f", 3.0)); f.write(struct.pack("<Q", 1))
+            f.write(cam.astype("<f8").tobytes()); f.write(np.zeros(12, dtype="<f8").tobytes())
+            f.write(X.astype("<f4").tobytes()); f.write(np.array(xy).astype("<f4").tobytes())
+        r = subprocess.run([exe, str(tmp_path / "p.bin"), str(tmp_path / "o.bin")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        raw = open(tmp_path / "o.bin", "rb").read()
+        cnt = struct.unpack("<i", raw[96:100])[0]
+        return cnt == 0, np.frombuffer(raw[:96], dtype="<f8")     # (accepted?, vectors)
+
+    uv = rng.uniform(-2, 2, (40, 2))
+    normal, origin = np.array([0.2, -0.1, 1.0]), np.array([0.0, 0.0, 9.0])
+    e1 = np.cross(normal, [1.0, 0, 0]); e1 /= np.linalg.norm(e1); e2 = np.cross(normal, e1); e2 /= np.linalg.norm(e2)
+    plane = origin + uv[:, :1] * e1 + uv[:, 1:] * e2
+    assert not run(plane)[0]                                                        # exactly planar
+    assert not run(plane + 2e-4 * rng.normal(size=(40, 1)) * normal / np.linalg.norm(normal))[0]   # planar up to 1e-4 of its extent
+    assert not run(origin + uv[:, :1] * e1 + 1e-3 * uv[:, 1:] * e2)[0]              # (almost) collinear
+    ok, v = run(plane + 0.3 * rng.normal(size=(40, 1)) * normal / np.linalg.norm(normal))   # shallow, but three-dimensional
+    assert ok
+    centre = -oracle.angle_axis_rotate(-v[0:3], v[3:6])
+    assert np.max(np.abs(v[0:3] - pose[:3])) <= 5e-3 and np.max(np.abs(centre - pose[3:])) <= 5e-2
