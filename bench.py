@@ -406,9 +406,13 @@ def main():
                 box["lm"] = solve_timed(dp, prob, world, args.lm_iters)
                 box["lm"]["first_handle_of_the_process_s"] = t_cold     # create + symbolic phase + ONE iteration, incl. kernel images, first streams, the plan's host scratch
                 box["lm"]["first_solve_wall_s_note"] = "a fresh handle in a process that has solved before (what windowedBA pays per call): symbolic phase + allocations + the solve"
+                before = dp.exchange_stats() if world > 1 else None
                 box["roof"] = roofline_lm(prob, dp, args.lm_iters, capi)
-                if world > 1:
-                    box["collectives"] = dp.exchange_stats()
+                if world > 1:   # calls / bytes of THAT solve alone (the library counts since the handle was created); its ms are the solve's own
+                    after = dp.exchange_stats()
+                    for k, v in after["collectives"].items():
+                        v["calls"] -= before["collectives"][k]["calls"]; v["bytes"] -= before["collectives"][k]["bytes"]
+                    box["collectives"] = after
             except Exception as e:  # noqa: BLE001 - reported in the JSON line
                 box.setdefault("lm", {"error": repr(e)})
                 box.setdefault("roof", {"error": repr(e)})

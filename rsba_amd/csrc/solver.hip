@@ -244,9 +244,12 @@ int32_t exchange(rsba_handle* h, double* buf, int64_t count, int op, int kind); 
 struct PhaseScope {
   PhaseTimer* t = nullptr; int phase; hipStream_t st; hipEvent_t a = nullptr;
   PhaseScope(rsba_handle* h, int ph) : phase(ph), st(h->stream) {
-    if (h->solver && h->solver->timer.on) { t = &h->solver->timer; a = t->get(); (void)hipEventRecord(a, st); }
+    if (h->solver && h->solver->timer.on) { t = &h->solver->timer; start(); }
   }
-  ~PhaseScope() { if (t) { hipEvent_t b = t->get(); (void)hipEventRecord(b, st); t->pending.push_back({phase, a, b}); } }
+  // a phase that another one interrupts (the exchange between the two launches of a sharded factorisation): stop() ... start()
+  void start() { if (t && !a) { a = t->get(); (void)hipEventRecord(a, st); } }
+  void stop() { if (t && a) { hipEvent_t b = t->get(); (void)hipEventRecord(b, st); t->pending.push_back({phase, a, b}); a = nullptr; } }
+  ~PhaseScope() { stop(); }
 };
 
 // Symbolic phase: frame / point adjacency, the per-block pair lists of the reduced camera system and
@@ -1331,21 +1334,25 @@ int32_t solve_reduced_system(rsba_handle* h) {
       HIP_TRY(launch_chol_dag(sv, s->plan_a, s->d_dag_args_a[now], std::min(s->dag_workgroups, std::max(1, s->plan_a.ntasks)), s->dag_one_per_cu, st));
       // exchange (2'): the separators' tiles, each rank's share less what its part subtracts from them, summed over the ranks
       const int64_t count = (int64_t)s->ntop_slots * kTile * kTile + (int64_t)s->ntop_tiles * kTile;
+      ps.stop();
       {
         PhaseScope pe(h, RSBA_PHASE_EXCHANGE);
         HIP_TRY(launch_top_assemble(sv, s->d_top_slots, s->d_top_info, s->d_asm_ptr, s->d_asm_list, s->d_top_tiles, s->ntop_slots, s->topx_buf, st));
         if (int32_t rc = exchange(h, s->topx_buf, count, 0, RSBA_EXCHANGE_SYSTEM)) return rc;
         HIP_TRY(launch_top_unpack(sv, s->d_top_slots, s->d_top_info, s->d_top_tiles, s->ntop_slots, s->topx_buf, st));
       }
+      ps.start();
       // launch B: the separators (every rank alike), forward and backward, then this rank's part backward
       HIP_TRY(launch_chol_dag(sv, s->plan_b, s->d_dag_args_b[now], std::min(s->dag_workgroups, std::max(1, s->plan_b.ntasks)), s->dag_one_per_cu, st));
       // exchange (4): the camera step — every rank contributes the rows of its part, rank 0 the separators'
+      ps.stop();
       {
         PhaseScope pe(h, RSBA_PHASE_EXCHANGE);
         HIP_TRY(launch_step_rows(sv.yv, s->d_row_mine, sv.npad, s->ybuf, st));
         if (int32_t rc = exchange(h, s->ybuf, sv.npad, 0, RSBA_EXCHANGE_STEP)) return rc;
         HIP_TRY(hipMemcpyAsync(sv.yv, s->ybuf, (size_t)sv.npad * sizeof(double), hipMemcpyDeviceToDevice, st));
       }
+      ps.start();
     } else
     HIP_TRY(launch_chol_dag(sv, s->plan, s->d_dag_args, s->dag_workgroups, s->dag_one_per_cu, st));
     if (s->test_corrupt_once) { s->test_corrupt_once = false; HIP_TRY(hipMemsetAsync(sv.yv + (sv.n / 2 / 6) * 6 + 1, 0, sizeof(double), st)); }   // test hook: one entry of the solution (a pose coordinate in mid-video) lost
