@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "handle.hpp"
+#include "devmem.hpp"
 
 using namespace rsba;
 
@@ -31,7 +32,7 @@ int32_t rsba_set_error(int32_t code, const char* msg) { return fail(code, msg); 
 template <class T>
 static int32_t dev_alloc(rsba_handle* h, T** p, size_t count) {
   void* q = nullptr;
-  HIP_TRY(hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)));
+  HIP_TRY(rsba::dev_malloc(&q, std::max<size_t>(count, 1) * sizeof(T)));
   h->allocs.push_back(q);
   *p = static_cast<T*>(q);
   return RSBA_OK;
@@ -48,7 +49,7 @@ static int32_t dev_upload(rsba_handle* h, T** p, const T* src, size_t count) {
 template <class T>
 static int32_t grow(rsba_handle* h, T** p, int64_t* cap, int64_t need) {
   if (need <= *cap && *p) return RSBA_OK;
-  if (*p) { (void)hipFree(*p); h->allocs.erase(std::remove(h->allocs.begin(), h->allocs.end(), static_cast<void*>(*p)), h->allocs.end()); *p = nullptr; }
+  if (*p) { (void)hipStreamSynchronize(h->stream); rsba::dev_free(*p); h->allocs.erase(std::remove(h->allocs.begin(), h->allocs.end(), static_cast<void*>(*p)), h->allocs.end()); *p = nullptr; }
   int32_t rc = dev_alloc(h, p, (size_t)need);
   if (rc == RSBA_OK) *cap = need;
   return rc;
@@ -225,7 +226,9 @@ void rsba_destroy(rsba_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   rsba_destroy_solver(h);
-  for (void* p : h->allocs) (void)hipFree(p);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);   // nothing on the device touches the blocks any more: they go back to the cache (devmem.hpp)
+  if (h->own_stream && h->own_stream != h->stream) (void)hipStreamSynchronize(h->own_stream);
+  for (void* p : h->allocs) rsba::dev_free(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -352,7 +355,7 @@ int32_t rsba_set_pose_priors(rsba_handle* h, double rotation, double position, c
   return RSBA_OK;
 }
 
-void rsba_release_host_scratch(void) { rsba_release_plan_scratch(); }
+void rsba_release_host_scratch(void) { rsba_release_plan_scratch(); rsba::dev_release_cache(); }
 
 int32_t rsba_set_global_shutter_frames(rsba_handle* h, const uint8_t* is_global) {
   if (!h) return fail(RSBA_ERR_INVALID_ARGUMENT, "null handle");
@@ -405,11 +408,11 @@ int32_t rsba_evaluate(rsba_handle* h, double* cost, double* residuals, double* j
   HIP_TRY(hipMemcpyAsync(&nfail, dp.fail_count, sizeof nfail, hipMemcpyDeviceToHost, h->stream));
   if ((residuals || jacobians) && N > 0) {
     if (!h->d_order) {
-      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_order), (size_t)N * sizeof(int64_t)));
+      HIP_TRY(rsba::dev_malloc(reinterpret_cast<void**>(&h->d_order), (size_t)N * sizeof(int64_t)));
       h->allocs.push_back(h->d_order);
       ensure_order(h);
       HIP_TRY(hipMemcpyAsync(h->d_order, h->order.data(), (size_t)N * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
-      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_rows), (size_t)N * (2 + 2 * (size_t)K) * sizeof(double)));
+      HIP_TRY(rsba::dev_malloc(reinterpret_cast<void**>(&h->d_rows), (size_t)N * (2 + 2 * (size_t)K) * sizeof(double)));
       h->allocs.push_back(h->d_rows);
     }
     double* d_res = h->d_rows; double* d_jac = h->d_rows + 2 * (size_t)N;

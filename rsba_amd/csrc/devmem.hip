@@ -1,0 +1,101 @@
+#include "devmem.hpp"
+
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <unordered_map>
+
+namespace rsba {
+
+namespace {
+
+struct Block { size_t bytes; int device; };
+struct Cache {
+  std::mutex m;
+  std::unordered_map<void*, Block> live;                    // blocks handed out (their rounded size)
+  std::map<int, std::multimap<size_t, void*>> free_blocks;   // per device, by size
+  size_t cached_bytes = 0, cap_bytes = 0;
+  bool cap_read = false;
+};
+Cache& cache() { static Cache* c = new Cache(); return *c; }   // (never destroyed: handles may outlive static destructors)
+
+// sizes in steps of 1/8 octave above 64 KB (a problem a frame longer than the last one still finds its blocks), 256 B below
+size_t round_size(size_t bytes) {
+  if (bytes <= 256) return 256;
+  if (bytes <= (64u << 10)) return (bytes + 255) & ~(size_t)255;
+  size_t step = 1;
+  while ((step << 4) <= bytes) step <<= 1;   // step = 2^(floor(log2 bytes) - 3)
+  return (bytes + step - 1) & ~(step - 1);
+}
+
+}  // namespace
+
+hipError_t dev_malloc(void** p, size_t bytes) {
+  Cache& c = cache();
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const size_t want = round_size(bytes);
+  {
+    std::lock_guard<std::mutex> lk(c.m);
+    auto& fl = c.free_blocks[dev];
+    auto it = fl.lower_bound(want);
+    if (it != fl.end() && it->first <= want + want / 4) {   // (at most a quarter wasted)
+      *p = it->second;
+      c.live[*p] = Block{it->first, dev};
+      c.cached_bytes -= it->first;
+      fl.erase(it);
+      return hipSuccess;
+    }
+  }
+  e = hipMalloc(p, want);
+  if (e == hipErrorOutOfMemory) {   // give the cache back and try once more
+    dev_release_cache();
+    e = hipMalloc(p, want);
+  }
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lk(c.m);
+  c.live[*p] = Block{want, dev};
+  return hipSuccess;
+}
+
+void dev_free(void* p) {
+  if (!p) return;
+  Cache& c = cache();
+  {
+    std::lock_guard<std::mutex> lk(c.m);
+    if (!c.cap_read) {
+      c.cap_read = true;
+      size_t mb = 2048;
+      if (const char* e = std::getenv("RSBA_DEVICE_CACHE_MB")) mb = (size_t)std::strtoull(e, nullptr, 10);
+      c.cap_bytes = mb << 20;
+    }
+    auto it = c.live.find(p);
+    if (it != c.live.end()) {
+      const Block b = it->second;
+      c.live.erase(it);
+      if (c.cached_bytes + b.bytes <= c.cap_bytes) { c.free_blocks[b.device].emplace(b.bytes, p); c.cached_bytes += b.bytes; return; }
+    }
+  }
+  (void)hipFree(p);
+}
+
+void dev_release_cache() {
+  Cache& c = cache();
+  std::map<int, std::multimap<size_t, void*>> take;
+  {
+    std::lock_guard<std::mutex> lk(c.m);
+    take.swap(c.free_blocks);
+    c.cached_bytes = 0;
+  }
+  int cur = 0;
+  const bool have = hipGetDevice(&cur) == hipSuccess;
+  for (auto& d : take) {
+    if (d.second.empty()) continue;
+    (void)hipSetDevice(d.first);
+    for (auto& kv : d.second) (void)hipFree(kv.second);
+  }
+  if (have) (void)hipSetDevice(cur);
+}
+
+}  // namespace rsba

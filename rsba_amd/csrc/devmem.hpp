@@ -1,0 +1,18 @@
+// Device memory of handles and plans through a process-wide cache of freed blocks.
+// windowedBA builds a new problem per frame (/root/reference/src/rsba/VideoSfMHandler.cc:185-214 -> CeresHandler per call): a handle
+// of 100 cameras makes ~90 allocations and frees them a few milliseconds later — 4 ms of hipFree (each one synchronises the device)
+// and ~1 ms of hipMalloc per call, a quarter of the whole BA() of that size.  Freed blocks are kept (per device, up to
+// RSBA_DEVICE_CACHE_MB, default 2048) and handed out again to requests of about their size; rsba_release_host_scratch() returns them
+// to the driver.  A block goes back to the cache only when nothing on the device can still touch it: the owners synchronise their
+// streams first (rsba_destroy, rsba_destroy_solver) — hipFree did that implicitly.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+
+namespace rsba {
+
+hipError_t dev_malloc(void** p, size_t bytes);
+void dev_free(void* p);
+void dev_release_cache();   // hipFree every cached block (all devices)
+
+}  // namespace rsba

@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "handle.hpp"
+#include "devmem.hpp"
 #include "solver_state.hpp"
 #include "tile_order.hpp"
 
@@ -136,7 +137,7 @@ namespace {
 template <class T>
 int32_t s_alloc(Solver* s, T** p, size_t count) {
   void* q = nullptr;
-  HIP_TRY(hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)));
+  HIP_TRY(dev_malloc(&q, std::max<size_t>(count, 1) * sizeof(T)));
   s->allocs.push_back(q);
   *p = static_cast<T*>(q);
   return RSBA_OK;
@@ -182,7 +183,7 @@ struct Uploader {
   void upload_ref(T** dst, const std::vector<T>& v) {
     push([this, dst, &v]() -> hipError_t {
       void* d = nullptr;
-      hipError_t e = hipMalloc(&d, std::max<size_t>(v.size(), 1) * sizeof(T));
+      hipError_t e = dev_malloc(&d, std::max<size_t>(v.size(), 1) * sizeof(T));
       if (e != hipSuccess) return e;
       allocs.push_back(d); *dst = static_cast<T*>(d);
       return v.empty() ? hipSuccess : hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
@@ -193,7 +194,7 @@ struct Uploader {
     auto own = std::make_shared<std::vector<T>>(v);
     push([this, dst, own]() -> hipError_t {
       void* d = nullptr;
-      hipError_t e = hipMalloc(&d, std::max<size_t>(own->size(), 1) * sizeof(T));
+      hipError_t e = dev_malloc(&d, std::max<size_t>(own->size(), 1) * sizeof(T));
       if (e != hipSuccess) return e;
       allocs.push_back(d); *dst = static_cast<T*>(d);
       return own->empty() ? hipSuccess : hipMemcpy(d, own->data(), own->size() * sizeof(T), hipMemcpyHostToDevice);
@@ -345,7 +346,11 @@ int32_t build_solver_impl(rsba_handle* h) {
   std::vector<int32_t>& slot_gpos = scr.slot_gpos; slot_gpos.resize((size_t)NS);           // group * FT + position of every slot: where its P record goes
   std::vector<uint8_t>& group_mask = scr.group_mask;        // which of the three 16-row blocks of a group's records can be non-zero
   std::vector<uint8_t>& group_present = scr.group_present;  // frames of the group's tile that see the point (plan statistics)
-  const int nthr_pts = M >= 4096 ? (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency())) : 1;
+  // host threads of the passes over points / entries: worth their start-up (16 threads cost ~1 ms on a busy 256-thread host) from a
+  // few hundred thousand observations on; a 100-camera window (187 k) plans faster on one (RSBA_PLAN_THREADS overrides: A/B)
+  int plan_threads = N >= 400000 ? (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency())) : 1;
+  if (const char* e = std::getenv("RSBA_PLAN_THREADS")) plan_threads = std::max(1, std::min(64, std::atoi(e)));
+  const int nthr_pts = M >= 4096 ? plan_threads : 1;
   {
     // one walk over a point's slots: on_group(g, tile) for every new (tile, layer) group g = 0, 1, .. of the point, on_slot(g, pos, slot)
     auto walk = [&](int j, std::vector<int64_t>& pslots, auto&& on_group, auto&& on_slot) -> int64_t {
@@ -426,7 +431,7 @@ int32_t build_solver_impl(rsba_handle* h) {
   // The two passes over all (point, tile pair) entries — count, then fill — are most of the symbolic phase (2 M entries at 1k cameras):
   // with dense keys they run on a few host threads over contiguous point ranges, each with its own counters per tile pair, and
   // the fill starts every thread where the threads before it end: the entry lists come out exactly as from one thread.
-  const int nthreads = dense_keys && (int64_t)nt * nt <= ((int64_t)1 << 22) && M >= 4096 ? (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency())) : 1;   // (per-thread counters: 4 nt^2 bytes each)
+  const int nthreads = dense_keys && (int64_t)nt * nt <= ((int64_t)1 << 22) && M >= 4096 ? plan_threads : 1;   // (per-thread counters: 4 nt^2 bytes each)
   std::vector<std::vector<int32_t>>& thread_cnt = scr.thread_cnt; thread_cnt.resize(nthreads > 1 ? nthreads : 0);
   auto point_range = [&](int t) { return std::pair<int, int>((int)((int64_t)M * t / nthreads), (int)((int64_t)M * (t + 1) / nthreads)); };
   if (nthreads > 1) {
@@ -1449,7 +1454,8 @@ void rsba_destroy_solver(rsba_handle* h) {
     if (hipMemcpy(tr.data(), h->solver->sv.schur_trace, tr.size() * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess)
       if (FILE* f = std::fopen(path, "wb")) { std::fwrite(tr.data(), sizeof(long long), tr.size(), f); std::fclose(f); }
   }
-  for (void* p : h->solver->allocs) (void)hipFree(p);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);   // (the side streams above are idle too: the blocks go back to the cache, devmem.hpp)
+  for (void* p : h->solver->allocs) dev_free(p);
   delete h->solver;
   h->solver = nullptr;
   h->dp.rec = nullptr; h->dp.obs_slot = nullptr; h->dp.cam_part = nullptr; h->dp.wave_seg_base = nullptr; h->dp.frame_rank = nullptr;

@@ -436,3 +436,29 @@ def test_a_failed_plan_is_torn_down_and_a_retry_fails_or_succeeds_afresh(capi, m
         s, _ = dp.solve(capi.default_options(max_num_iterations=5))
     assert s.final_cost == s_ref.final_cost and s.num_iterations == s_ref.num_iterations
     assert np.array_equal(p.poses, q.poses) and np.array_equal(p.points, q.points)
+
+
+def test_device_blocks_are_cached_between_handles_and_given_back(capi):
+    """windowedBA builds a handle per frame (VideoSfMHandler.cc:185-214): the device blocks of a destroyed handle are kept by the
+    library (rsba_amd/csrc/devmem.hpp) and handed to the next one — same results, no growth from handle to handle — and
+    rsba_release_host_scratch() returns them to the driver."""
+    import torch
+    def in_use():
+        torch.cuda.synchronize()
+        free_b, total_b = torch.cuda.mem_get_info(0)
+        return total_b - free_b
+    capi.release_host_scratch()
+    base = in_use()
+    results, levels = [], []
+    for rep in range(4):
+        p = small_scene(frames=24, points=1500, seed=9)
+        with capi.DeviceProblem(p) as dp:
+            s, _ = dp.solve(capi.default_options(max_num_iterations=6))
+        results.append((s.final_cost, p.poses.copy(), p.points.copy()))
+        levels.append(in_use())
+    for r in results[1:]:
+        assert r[0] == results[0][0] and np.array_equal(r[1], results[0][1]) and np.array_equal(r[2], results[0][2])
+    assert levels[0] > base                                  # the first handle's blocks are still with the library ...
+    assert max(levels[1:]) - levels[0] <= 4 << 20           # ... the next handles live in them
+    capi.release_host_scratch()
+    assert in_use() - base <= 8 << 20                        # ... and they go back on request
