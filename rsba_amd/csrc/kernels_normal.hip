@@ -398,12 +398,8 @@ constexpr unsigned kLowerBlocks = 0x1D9;   // bits 3 I + J with J <= I
 // (no tail selects), the table holds ready element offsets (one 64-bit add per operand triple, the three 16-row blocks ride
 // on the load's immediate offset), and which of the nine 16 x 16 blocks of a group of four entries have anything to multiply
 // is ONE scalar read of host-computed masks (a full mask — the common case — runs 27 MFMAs without a branch).
-// One RUN: pieces [p_begin, p_end) — consecutive stretches of up to kSchurChunk entries of ONE tile pair (piece_e0 / piece_n) — are
-// accumulated into the same registers, and the run's partial tile goes to slot `part_slot`.  The chunk kernel runs one piece per
-// workgroup (a chunk); the range kernel gives every workgroup an equal share of ALL entries and flushes only where the pair changes.
 template <bool DIAG, int kDepth>
-__device__ __forceinline__ void schur_chunk(const SolverDev& sv, const double* __restrict__ Pm, const double* __restrict__ zz, const int64_t* __restrict__ piece_e0,
-                                            const int32_t* __restrict__ piece_n, int p_begin, int p_end, int part_slot, double* smem) {
+__device__ __forceinline__ void schur_chunk(const SolverDev& sv, const double* __restrict__ Pm, const double* __restrict__ zz, int chunk, double* smem) {
   constexpr int GW = kTile * 3;                        // doubles per group
   constexpr int TPITCH = kTile + 1;
   constexpr unsigned kFull = DIAG ? kLowerBlocks : 0x1FFu;
@@ -412,28 +408,10 @@ __device__ __forceinline__ void schur_chunk(const SolverDev& sv, const double* _
   double* s_z = reinterpret_cast<double*>(reinterpret_cast<char*>(smem) + kSchurOffBytes + kSchurMskBytes);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
-  long long* tr = sv.schur_trace ? sv.schur_trace + 8 * (size_t)part_slot : nullptr;
-  if (tr && tid == 0) { tr[0] = blockIdx.x; tr[1] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); tr[2] = wall_clock64(); tr[6] = 0; }   // HW_REG_HW_ID
-  // K = 3 per point against 4 per MFMA: four of the wave's entries share three MFMA steps, step t taking the
-  // coordinates k = 4t .. 4t+3 of the twelve — lane group g reads coordinate (4t + g) % 3 of entry (4t + g) / 3.
-  // The wave's entries are wave, wave + 4, ..: entry e of its group q is k = wave + 16 q + 4 e.
-  int tab[3], opo[3], zof[3];   // per step: byte offset of the entry's table cell in group 0, element offset of the operand inside a group, element offset of z
-#pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    const int e = (4 * t + g) / 3, c = (4 * t + g) % 3, k = wave + 4 * e;
-    tab[t] = 8 * k; opo[t] = c * kTile + r; zof[t] = 3 * k + c;
-  }
-  dbl4 acc[3][3];
-#pragma unroll
-  for (int I = 0; I < 3; ++I)
-#pragma unroll
-    for (int J = 0; J < 3; ++J) acc[I][J] = dbl4{0.0, 0.0, 0.0, 0.0};
-  double racc[3] = {0.0, 0.0, 0.0};
-  unsigned issued = 0;
-  for (int pc = p_begin; pc < p_end; ++pc) {
-  const int64_t e0 = piece_e0[pc];
-  const int n = piece_n[pc], n16 = (n + 15) & ~15;
-  if (tr && tid == 0) tr[6] += n;
+  const int64_t e0 = sv.chunk_e0[chunk];
+  const int n = sv.chunk_n[chunk], n16 = (n + 15) & ~15;
+  long long* tr = sv.schur_trace ? sv.schur_trace + 8 * (size_t)chunk : nullptr;
+  if (tr && tid == 0) { tr[0] = blockIdx.x; tr[1] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); tr[2] = wall_clock64(); tr[6] = n; }   // HW_REG_HW_ID
   for (int k = tid; k < n16; k += 256) {
     uint32_t ga = (uint32_t)sv.ngroups, gb = ga;       // the all-zero group behind the last one
     unsigned pm = 0;
@@ -452,6 +430,21 @@ __device__ __forceinline__ void schur_chunk(const SolverDev& sv, const double* _
   }
   __syncthreads();
   if (tr && tid == 0) tr[3] = wall_clock64();
+  // K = 3 per point against 4 per MFMA: four of the wave's entries share three MFMA steps, step t taking the
+  // coordinates k = 4t .. 4t+3 of the twelve — lane group g reads coordinate (4t + g) % 3 of entry (4t + g) / 3.
+  // The wave's entries are wave, wave + 4, ..: entry e of its group q is k = wave + 16 q + 4 e.
+  int tab[3], opo[3], zof[3];   // per step: byte offset of the entry's table cell in group 0, element offset of the operand inside a group, element offset of z
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int e = (4 * t + g) / 3, c = (4 * t + g) % 3, k = wave + 4 * e;
+    tab[t] = 8 * k; opo[t] = c * kTile + r; zof[t] = 3 * k + c;
+  }
+  dbl4 acc[3][3];
+#pragma unroll
+  for (int I = 0; I < 3; ++I)
+#pragma unroll
+    for (int J = 0; J < 3; ++J) acc[I][J] = dbl4{0.0, 0.0, 0.0, 0.0};
+  double racc[3] = {0.0, 0.0, 0.0};
   struct Group { double a[3][3], b[3][3], z[3]; };   // [step][block row]
   Group ring[kDepth];
   const int nq = n16 >> 4;   // groups of four entries per wave
@@ -468,6 +461,7 @@ __device__ __forceinline__ void schur_chunk(const SolverDev& sv, const double* _
       if (DIAG) G.z[t] = s_z[zof[t] + 48 * qq];
     }
   };
+  unsigned issued = 0;
   if (nq > 0) {
 #pragma unroll
     for (int d = 0; d < kDepth; ++d) fetch(d, ring[d]);
@@ -509,9 +503,8 @@ __device__ __forceinline__ void schur_chunk(const SolverDev& sv, const double* _
       }
     }
   }
-  __syncthreads();   // everyone is done with the tables: the same LDS takes the next piece's, or the four partial tiles
-  }
   if (lane == 0 && issued) atomicAdd(sv.schur_mfma_count, (unsigned long long)issued);   // a statistic (bench.py: issued against useful flops), not a result
+  __syncthreads();   // everyone is done with the tables: the same LDS now takes the four partial tiles
   if (tr && tid == 0) tr[4] = wall_clock64();
   double* buf = smem + wave * (kTile * TPITCH);
 #pragma unroll
@@ -531,7 +524,7 @@ __device__ __forceinline__ void schur_chunk(const SolverDev& sv, const double* _
     }
   }
   __syncthreads();
-  double* part = sv.schur_part + (size_t)part_slot * (kTile * kTile + kTile);
+  double* part = sv.schur_part + (size_t)chunk * (kTile * kTile + kTile);
   for (int e = tid; e < kTile * kTile; e += 256) {
     const int o = (e / kTile) * TPITCH + e % kTile;
     part[e] = (smem[o] + smem[kTile * TPITCH + o]) + (smem[2 * kTile * TPITCH + o] + smem[3 * kTile * TPITCH + o]);
@@ -551,25 +544,8 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void schur_tile_kernel(const So
   const int chunk = sv.schur_linear ? (int)blockIdx.x : (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
   if (chunk >= sv.nchunk) return;
   const int tp = sv.chunk_tp[chunk];
-  if (sv.tp_I[tp] == sv.tp_J[tp]) schur_chunk<true, kDepth>(sv, Pm, zz, sv.chunk_e0, sv.chunk_n, chunk, chunk + 1, chunk, smem);
-  else schur_chunk<false, kDepth>(sv, Pm, zz, sv.chunk_e0, sv.chunk_n, chunk, chunk + 1, chunk, smem);
-}
-
-// The range form: a RESIDENT set of workgroups (two per CU), each with an equal share — by MFMA count — of the whole entry list, walks
-// its share run by run (sv.wg_run_ptr; a run = its pieces of one tile pair, sv.run_piece_ptr).  Against the chunk kernel: no tail (all
-// shares end together), no dispatch between chunks, and a tile pair that spans several pieces of one workgroup is reduced through LDS
-// and written ONCE — half the epilogues and half the partial tiles for the merge.
-template <int kDepth, int kWavesPerSimd>
-__global__ __launch_bounds__(256, kWavesPerSimd) void schur_range_kernel(const SolverDev sv, const double* __restrict__ Pm, const double* __restrict__ zz) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  // consecutive shares sit on one XCD (workgroups go round-robin over the 8 XCDs): XCD x holds shares [x * per, (x + 1) * per)
-  const int per = (int)gridDim.x >> 3, w = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-  for (int run = sv.wg_run_ptr[w]; run < sv.wg_run_ptr[w + 1]; ++run) {
-    const int tp = sv.run_tp[run], p0 = sv.run_piece_ptr[run], p1 = sv.run_piece_ptr[run + 1];
-    if (sv.tp_I[tp] == sv.tp_J[tp]) schur_chunk<true, kDepth>(sv, Pm, zz, sv.piece_e0, sv.piece_n, p0, p1, run, smem);
-    else schur_chunk<false, kDepth>(sv, Pm, zz, sv.piece_e0, sv.piece_n, p0, p1, run, smem);
-    __syncthreads();   // (the run's partial tile has left LDS)
-  }
+  if (sv.tp_I[tp] == sv.tp_J[tp]) schur_chunk<true, kDepth>(sv, Pm, zz, chunk, smem);
+  else schur_chunk<false, kDepth>(sv, Pm, zz, chunk, smem);
 }
 
 // one workgroup per group of a very long chunk list: partial[first] = sum of the group's partials, in list order
