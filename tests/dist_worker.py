@@ -30,7 +30,13 @@ def nd_mode(mode, outdir, rank, world, dist, torch):
     from rsba_amd.distributed import attach
     from rsba_amd.scene import make_config
     _, cfg, iters = mode.split(":")[:3]
+    flags = mode.split(":")[3:]
     full = make_config(cfg).problem
+    if "intr" in flags:      # shared intrinsics as a parameter block + Huber, as BASELINE config 5 has them: a dense border of the reduced system
+        full.calibrated = False; full.huber_a = 2.0
+        full.intrinsics = full.intrinsics * (1.0 + 1e-3 * np.array([[1, -1, 20, -20, 10, 10, -10, 0.5, -0.5]]))
+    if "corrupt" in flags:   # the first persistent-driver solve loses an entry of its result (test hook of the library): every rank must notice through exchange (3)
+        os.environ["RSBA_CHOL_TEST_CORRUPT"] = "1"
     owner, ntop = capi.partition_points(full, world)
     shard = full.shard(rank, world, owner)
     torch.cuda.set_device(0)
@@ -44,10 +50,11 @@ def nd_mode(mode, outdir, rank, world, dist, torch):
            "final_cost": s.final_cost, "initial_cost": s.initial_cost, "iters": s.num_iterations, "dag_fallbacks": s.num_dag_fallbacks,
            "reduced": s.num_residual_blocks_reduced, "params": s.num_parameters_reduced, "costs": [t.cost for t in tr], "plan": st,
            "poses_sum": float(np.abs(shard.poses).sum()), "points_sum": float(np.abs(shard.points).sum())}
+    os.environ.pop("RSBA_CHOL_TEST_CORRUPT", None)
     if rank == 0:
         ref = full.copy()
         with capi.DeviceProblem(ref) as d1:
-            s1, tr1 = d1.solve(capi.default_options(**opts))
+            s1, tr1 = d1.solve(capi.default_options(**dict(opts, level_scheduled_cholesky=int("corrupt" in flags))))
             st1 = d1.plan_stats()
         out.update(ref_final=s1.final_cost, ref_initial=s1.initial_cost, ref_iters=s1.num_iterations, ref_reduced=s1.num_residual_blocks_reduced, ref_params=s1.num_parameters_reduced,
                    pose_err=float(np.abs(ref.poses - shard.poses).max()), point_err=float(np.abs(ref.points - shard.points).max()),

@@ -185,12 +185,12 @@ def test_partition_points_refuses_what_cannot_be_cut():
         capi.partition_points(p, 2)
 
 
-def check_nd(res, world, sharded=True):
+def check_nd(res, world, sharded=True, fallbacks=0):
     a = res[0]
     for o in res[1:]:
         assert o["final_cost"] == a["final_cost"] and o["iters"] == a["iters"] and o["costs"] == a["costs"]        # ranks decide identically
         assert o["poses_sum"] == a["poses_sum"] and o["points_sum"] == a["points_sum"]                               # ... and leave with the same parameters
-    assert all(o["dag_fallbacks"] == 0 for o in res)
+    assert all(o["dag_fallbacks"] == fallbacks for o in res)
     assert sum(o["n_shard"] for o in res) == a["n_full"]
     assert all(o["plan"]["sharded_factorisation"] == int(sharded) for o in res)
     assert a["iters"] == a["ref_iters"] and a["reduced"] == a["ref_reduced"] and a["params"] == a["ref_params"] and a["decisions_equal"]
@@ -219,3 +219,21 @@ def test_sharded_factorisation_at_c4_size(tmp_path, world):
     full = a["ref_plan"]["exchange_doubles"]                 # the replicated factorisation's payload: every non-zero tile of S | rhs
     assert a["plan"]["exchange_doubles"] <= {2: 0.12, 4: 0.25, 8: 0.6}[world] * full
     assert a["plan"]["separator_tiles"] == a["top_tile_columns"]
+
+
+@pytest.mark.gpu
+def test_sharded_factorisation_with_shared_intrinsics_block(tmp_path):
+    """Shared intrinsics as a parameter block + Huber (what BASELINE config 5 adds): the block's 9 unknowns are a dense border of the
+    reduced system — one more separator every rank shares — and its rows are complete where their frames' parts are."""
+    res = run_two_ranks("nd:C2:8:intr", tmp_path, 2)
+    check_nd(res, 2)
+
+
+@pytest.mark.gpu
+def test_a_suspect_sharded_solve_sends_every_rank_back_to_the_replicated_factorisation(tmp_path):
+    """RSBA_CHOL_TEST_CORRUPT makes the first persistent-driver solve of every rank lose an entry of its result.  The residual check
+    (each rank: the rows of its own part) raises the flag, exchange (3) carries it to all ranks, and ALL of them repeat the iteration —
+    and finish the problem — with the replicated factorisation on the level schedule: one fallback each, and the trajectory of the
+    single-GPU level-scheduled solve."""
+    res = run_two_ranks("nd:C2:6:corrupt", tmp_path, 2)
+    check_nd(res, 2, fallbacks=1)
