@@ -1133,6 +1133,7 @@ __global__ __launch_bounds__(256, 2) void chol_dag_kernel(const DagArgs* __restr
   __shared__ int s_ticket;
   const int tid = threadIdx.x;
   const CholPlan& pl = args->pl;
+  if (lm_stopped(args->sv.ctl)) return;   // (device-side trust region: the solve is over, iterations enqueued ahead fall through)
   for (;;) {
     lds_barrier();   // the previous task's LDS is free, s_ticket has been read by everyone
     if (tid == 0) {

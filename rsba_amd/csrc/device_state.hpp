@@ -72,7 +72,23 @@ struct DeviceProblem {
   int pp_spherical;              // pose block carrying the SphericalPrior, -1 = none
   double* prior_partial;         // [2 * ceil(F / 64)] per-wave partial sums of the prior reductions
   unsigned* prior_ticket;        // arrival counter of those reductions (zero between launches)
+  const double* ctl;             // trust-region state on the device (LmCtlSlot; solver.hip: the LM loop's decisions taken by a kernel), null = the host decides
 };
+
+// Trust-region control on the device: the scalars of Ceres' TrustRegionMinimizer loop live in HBM, a single-thread
+// kernel takes its decisions (kernels_normal.hip: lm_decide_*), and the kernels of an iteration look at them instead of waiting for
+// the host: the host enqueues iterations AHEAD and only reads the state back every few of them.
+enum LmCtlSlot : int {
+  kCtlRadius = 0, kCtlDecrease = 1,       // trust-region radius, the factor of the next shrink (2, 4, ..)
+  kCtlCost = 2, kCtlFixed = 3, kCtlGmax = 4,
+  kCtlAccept = 5,                          // 1: the candidate of this iteration became x (its linearisation follows), 0: it did not
+  kCtlStatus = 6,                          // 0: running; 1 + termination type: done; -1: the host must take over (a suspect factorisation)
+  kCtlIteration = 7, kCtlInvalidStreak = 8, kCtlSuccessful = 9, kCtlUnsuccessful = 10, kCtlFinalCost = 11, kCtlNumTrace = 12,
+  kCtlPending = 16,                        // [4] relative decrease, cost change, step norm, model cost change of an accepted step whose record waits for its gradient
+  kCtlSize = 24
+};
+__device__ __forceinline__ bool lm_stopped(const double* ctl) { return ctl && ctl[kCtlStatus] != 0.0; }
+__device__ __forceinline__ bool lm_not_accepted(const double* ctl) { return ctl && (ctl[kCtlStatus] != 0.0 || ctl[kCtlAccept] == 0.0); }
 
 constexpr int kEvalBlock = 256;
 constexpr int kStageFrames = 16;   // camera blocks staged through LDS per workgroup

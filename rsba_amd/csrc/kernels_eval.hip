@@ -26,6 +26,7 @@ __device__ __forceinline__ double swap_pair(double v) {
 
 template <bool CAL, int P, int MODE>
 __global__ __launch_bounds__(kEvalBlock) void eval_kernel(const DeviceProblem dp) {
+  if (MODE == kLmJacobian && lm_stopped(dp.ctl)) return;   // (device-side trust region: the solve is over, iterations enqueued ahead fall through)
   constexpr int CD = 6 * P;
   constexpr int K = ObsOut<CAL, P>::K;
   constexpr int OFF_POSE = CAL ? 0 : 9;

@@ -63,6 +63,7 @@ __device__ __forceinline__ double u_diag(const SolverDev& sv, int64_t t) {
 // ---------------------------------------------------------------------------------------------
 template <int CD, bool CAL>
 __global__ __launch_bounds__(256) void camera_reduce_kernel(const DeviceProblem dp, const SolverDev sv) {
+  if (lm_not_accepted(sv.ctl)) return;   // (device-side trust region: a rejected candidate is not linearised)
   constexpr int NI = CAL ? 0 : 9, NCOL = NI + CD + 1, NCB = (NCOL + 15) / 16, NBLK = NCB * (NCB + 1) / 2;
   __shared__ double G[NBLK][256];
   const int f = blockIdx.x, e = threadIdx.x;
@@ -105,6 +106,7 @@ __global__ __launch_bounds__(256) void camera_reduce_kernel(const DeviceProblem 
 // one workgroup per (intrinsics block c, entry t of the 45 + 9 sums): lanes stride the frames that use the block (in
 // frame order), fixed-order wave / workgroup reduction
 __global__ __launch_bounds__(256) void intr_reduce_kernel(const DeviceProblem dp, const SolverDev sv) {
+  if (lm_not_accepted(sv.ctl)) return;
   __shared__ double s_red[4];
   const int c = blockIdx.x / 54, t = blockIdx.x % 54, tid = threadIdx.x;
   double v = 0.0;
@@ -256,6 +258,7 @@ __global__ void unscaled_gradient_kernel(const DeviceProblem dp, const SolverDev
 // (SchurEliminator::Eliminate inverts each e-block)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void point_factor_kernel(const DeviceProblem dp, const SolverDev sv, double inv_radius) {
+  if (sv.ctl) inv_radius = 1.0 / sv.ctl[kCtlRadius];   // (device-side trust region: the radius lives in HBM)
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= dp.M) return;
   const double* v = sv.V + (size_t)j * 6;
@@ -537,6 +540,7 @@ __device__ __forceinline__ void schur_chunk(const SolverDev& sv, const double* _
 // registers with two groups in flight; three need 300.
 template <int kDepth, int kWavesPerSimd>
 __global__ __launch_bounds__(256, kWavesPerSimd) void schur_tile_kernel(const SolverDev sv, const double* __restrict__ Pm, const double* __restrict__ zz) {
+  if (lm_stopped(sv.ctl)) return;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   // consecutive chunks share records (host: chunk numbering); workgroups go round-robin over the 8 XCDs, so XCD x
   // walks the x-th eighth of the chunk list in order and its L2 sees the repeats
@@ -568,6 +572,7 @@ __global__ __launch_bounds__(256) void schur_premerge_kernel(const SolverDev sv)
 // one workgroup per tile pair: sum the chunk partials in order, add U / D_c^2 / g_c, identity padding, and
 // store into the packed tile slot (transposed when the tile ordering swapped the pair)
 __global__ __launch_bounds__(256) void schur_merge_kernel(const DeviceProblem dp, const SolverDev sv, double inv_radius) {
+  if (sv.ctl) inv_radius = 1.0 / sv.ctl[kCtlRadius];
   const int tp = blockIdx.x, tid = threadIdx.x;
   const int I = sv.tp_I[tp], J = sv.tp_J[tp], CD = sv.CD, FT = sv.FT;
   const int c0 = sv.tp_chunk0[tp], c1 = sv.tp_chunk0[tp + 1];
@@ -733,6 +738,7 @@ __device__ __forceinline__ void slot_record(const DeviceProblem& dp, const Solve
 // K5b without records: P = Jc^T (Jp L^-T) of 64 consecutive slots per wave and step, into the group layout (see project_kernel)
 template <bool CAL, int P>
 __global__ __launch_bounds__(256) void project_rc_kernel(const DeviceProblem dp, const SolverDev sv) {
+  if (lm_stopped(sv.ctl)) return;   // (device-side trust region: the solve is over, iterations enqueued ahead fall through)
   constexpr int CD = 6 * P, OUT = CD * 3, FT = kTile / CD, PITCH = OUT | 1, kPer = 64 / CD, OP = CAL ? 0 : 9;   // OP: the pose columns follow the 9 intrinsics columns
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -833,6 +839,7 @@ __device__ __forceinline__ double point_sweep(const DeviceProblem& dp, const Sol
 // K2b without records: V_j, g_p,j
 template <bool CAL, int P>
 __global__ __launch_bounds__(256) void point_blocks_rc_kernel(const DeviceProblem dp, const SolverDev sv) {
+  if (lm_not_accepted(sv.ctl)) return;
   constexpr int CD = (CAL ? 0 : 9) + 6 * P;   // columns in front of the point's
   extern __shared__ __attribute__((aligned(16))) double smem[];
   point_sweep<CAL, P, 9>(dp, sv, smem,
@@ -855,6 +862,7 @@ __global__ __launch_bounds__(256) void point_blocks_rc_kernel(const DeviceProble
 // K7 + K8 without records (see point_step_kernel)
 template <bool CAL, int P>
 __global__ __launch_bounds__(256) void point_step_rc_kernel(const DeviceProblem dp, const SolverDev sv) {
+  if (lm_stopped(sv.ctl)) return;
   constexpr int CD = 6 * P, OP = CAL ? 0 : 9, OX = OP + CD;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const double mc = point_sweep<CAL, P, 5>(dp, sv, smem,
@@ -1001,6 +1009,102 @@ __global__ void merge_points_kernel(const DeviceProblem dp, const double* buf) {
 }
 
 // exchange buffer (1): g_c | diag(U) | cost, fixed cost, failed blocks
+// ---- trust-region control on the device ----
+// Ceres 1.9's TrustRegionMinimizer loop body behind the linear solve, the same rules in the same
+// order as the host form in solver.hip (rsba_solve) — one thread; every operation is an IEEE add / multiply / divide / sqrt /
+// compare, so the two forms take bit-identical decisions.  Scalars of the iteration: sv.scalars (ScalarSlot), state: ctl (LmCtlSlot).
+__device__ __forceinline__ void lm_push(double* ctl, rsba_iteration* trace, int cap, const rsba_iteration& it) {
+  const int n = (int)ctl[kCtlNumTrace];
+  if (trace && n < cap) trace[n] = it;
+  ctl[kCtlNumTrace] = (double)(n + 1);
+}
+__global__ void lm_decide_step_kernel(const SolverDev sv, double* ctl, const LmRules R, rsba_iteration* trace, int cap) {
+#pragma clang fp contract(off)   // every product and sum rounded on its own, as the host form's are (1 - (t t) t would become an fma: one ulp of the radius)
+  if (ctl[kCtlStatus] != 0.0) return;
+  ctl[kCtlAccept] = 0.0;
+  const double* sc = sv.scalars;
+  if (sc[kDagSuspect] != 0.0) { ctl[kCtlStatus] = -1.0; return; }   // nothing of this iteration has touched x: the host repeats it on the level schedule
+  double radius = ctl[kCtlRadius], decrease = ctl[kCtlDecrease];
+  const double cost = ctl[kCtlCost], fixed = ctl[kCtlFixed], gmax = ctl[kCtlGmax];
+  const int iteration = (int)ctl[kCtlIteration] + 1;
+  ctl[kCtlIteration] = (double)iteration;
+  rsba_iteration it;
+  it.iteration = iteration; it.step_is_valid = 0; it.step_is_successful = 0; it.reserved = 0;
+  it.cost = 0.0; it.cost_change = 0.0; it.gradient_max_norm = 0.0; it.step_norm = 0.0; it.relative_decrease = 0.0; it.trust_region_radius = 0.0; it.model_cost_change = 0.0;
+  const double model_cost_change = sc[kModelCostChange];
+  const bool cfail = sc[kSolveFailed] != 0.0, nfail = sc[kEvalFailed] != 0.0;
+  const bool solved = !cfail && isfinite(model_cost_change) && isfinite(sc[kStepSq]);
+  const bool valid = solved && model_cost_change >= 0.0;
+  it.model_cost_change = solved ? model_cost_change : 0.0;
+  auto done = [&](int term) { it.cost = cost + fixed; it.trust_region_radius = radius; lm_push(ctl, trace, cap, it); ctl[kCtlStatus] = 1.0 + term; };
+  if (!valid) {
+    const int streak = (int)ctl[kCtlInvalidStreak] + 1;
+    ctl[kCtlInvalidStreak] = (double)streak;
+    if (streak >= R.max_num_consecutive_invalid_steps) { done(RSBA_FAILURE); return; }
+    radius /= decrease; decrease *= 2.0;
+    ctl[kCtlUnsuccessful] += 1.0;
+    it.gradient_max_norm = gmax;
+  } else {
+    ctl[kCtlInvalidStreak] = 0.0; it.step_is_valid = 1;
+    const double new_cost = nfail ? 1.7976931348623157e308 : (sc[kCost] + 0.0) - fixed;   // (the trial evaluation reports the total in kCost)
+    it.step_norm = sqrt(sc[kStepSq]);
+    const double x_norm = sqrt(sc[kXSq]);
+    if (it.step_norm <= R.parameter_tolerance * (x_norm + R.parameter_tolerance)) { done(RSBA_CONVERGENCE); return; }
+    it.cost_change = cost - new_cost;
+    if (fabs(it.cost_change) < R.function_tolerance * cost) { done(RSBA_CONVERGENCE); return; }
+    it.relative_decrease = it.cost_change / model_cost_change;
+    if (it.relative_decrease > R.min_relative_decrease) {
+      it.step_is_successful = 1; ctl[kCtlSuccessful] += 1.0;
+      const double t = 2.0 * it.relative_decrease - 1.0;
+      radius = radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
+      radius = fmin(R.max_trust_region_radius, radius); decrease = 2.0;
+      ctl[kCtlRadius] = radius; ctl[kCtlDecrease] = decrease; ctl[kCtlAccept] = 1.0;
+      // (the iteration's record is finished by lm_decide_gradient_kernel once the accepted point is linearised)
+      ctl[kCtlPending] = it.relative_decrease; ctl[kCtlPending + 1] = it.cost_change; ctl[kCtlPending + 2] = it.step_norm; ctl[kCtlPending + 3] = it.model_cost_change;
+      return;
+    }
+    ctl[kCtlUnsuccessful] += 1.0; it.gradient_max_norm = gmax;
+    radius /= decrease; decrease *= 2.0;
+  }
+  ctl[kCtlRadius] = radius; ctl[kCtlDecrease] = decrease;
+  it.cost = cost + fixed; it.trust_region_radius = radius;
+  lm_push(ctl, trace, cap, it);
+  if (radius < R.min_trust_region_radius) ctl[kCtlStatus] = 1.0 + RSBA_CONVERGENCE;
+  else if (iteration >= R.max_num_iterations) ctl[kCtlStatus] = 1.0 + RSBA_NO_CONVERGENCE;
+}
+// after the linearisation of an accepted step: its cost, the gradient test, the iteration's record
+__global__ void lm_decide_gradient_kernel(const SolverDev sv, double* ctl, const LmRules R, rsba_iteration* trace, int cap) {
+#pragma clang fp contract(off)
+  if (ctl[kCtlStatus] != 0.0 || ctl[kCtlAccept] == 0.0) return;
+  const double* sc = sv.scalars;
+  rsba_iteration it;
+  it.iteration = (int)ctl[kCtlIteration]; it.step_is_valid = 1; it.step_is_successful = 1; it.reserved = 0;
+  it.relative_decrease = ctl[kCtlPending]; it.cost_change = ctl[kCtlPending + 1]; it.step_norm = ctl[kCtlPending + 2]; it.model_cost_change = ctl[kCtlPending + 3];
+  const double fixed = ctl[kCtlFixed], radius = ctl[kCtlRadius];
+  if (sc[kEvalFailed] != 0.0) {   // the evaluation at the accepted point failed: the host reports it (RSBA_ERR_EVALUATION_FAILED)
+    it.cost = 0.0; it.gradient_max_norm = 0.0; it.trust_region_radius = 0.0;
+    lm_push(ctl, trace, cap, it);
+    ctl[kCtlStatus] = -2.0;
+    return;
+  }
+  const double cost = sc[kCost], gmax = sc[kGradMax];
+  ctl[kCtlCost] = cost; ctl[kCtlGmax] = gmax;
+  ctl[kCtlFinalCost] = fmin(ctl[kCtlFinalCost], cost + fixed);
+  it.gradient_max_norm = gmax; it.cost = cost + fixed; it.trust_region_radius = radius;
+  lm_push(ctl, trace, cap, it);
+  if (gmax <= R.gradient_tolerance) ctl[kCtlStatus] = 1.0 + RSBA_CONVERGENCE;
+  else if (radius < R.min_trust_region_radius) ctl[kCtlStatus] = 1.0 + RSBA_CONVERGENCE;
+  else if (it.iteration >= R.max_num_iterations) ctl[kCtlStatus] = 1.0 + RSBA_NO_CONVERGENCE;
+}
+// x = x + delta: the candidate the last decision accepted becomes the current point (the host form swaps the two buffers)
+__global__ void lm_take_candidate_kernel(const DeviceProblem dp, const SolverDev sv, int64_t npose, int64_t npoint, int64_t nintr) {
+  if (lm_not_accepted(sv.ctl)) return;
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t < npose) dp.poses[t] = sv.trial_poses[t];
+  else if (t < npose + npoint) dp.points[t - npose] = sv.trial_points[t - npose];
+  else if (t < npose + npoint + nintr) dp.intr[t - npose - npoint] = sv.trial_intr[t - npose - npoint];
+}
+
 __global__ void pack_linearize_kernel(const DeviceProblem dp, const SolverDev sv, const double* cost2) {
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (t < sv.n) {
@@ -1011,6 +1115,7 @@ __global__ void pack_linearize_kernel(const DeviceProblem dp, const SolverDev sv
 }
 // without an exchange (one rank) the round trip through xbuf is one kernel: udiag = diag(U), the three scalars
 __global__ void local_linearize_kernel(const DeviceProblem dp, const SolverDev sv, const double* cost2) {
+  if (lm_not_accepted(sv.ctl)) return;
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (t < sv.n) sv.udiag[t] = u_diag(sv, t);
   if (t == 0) { sv.scalars[kCost] = cost2[0]; sv.scalars[kFixedCost] = cost2[1]; sv.scalars[kEvalFailed] = (double)*dp.fail_count; }
@@ -1220,6 +1325,19 @@ hipError_t launch_own_points(const DeviceProblem& dp, const SolverDev& sv, doubl
 }
 hipError_t launch_merge_points(const DeviceProblem& dp, const double* buf, hipStream_t st) {
   LAUNCH(merge_points_kernel, nblocks256(dp.M), 256, st, dp, buf);
+  return hipSuccess;
+}
+hipError_t launch_lm_decide_step(const SolverDev& sv, double* ctl, const LmRules& rules, rsba_iteration* trace, int trace_cap, hipStream_t st) {
+  LAUNCH(lm_decide_step_kernel, 1, 1, st, sv, ctl, rules, trace, trace_cap);
+  return hipSuccess;
+}
+hipError_t launch_lm_decide_gradient(const SolverDev& sv, double* ctl, const LmRules& rules, rsba_iteration* trace, int trace_cap, hipStream_t st) {
+  LAUNCH(lm_decide_gradient_kernel, 1, 1, st, sv, ctl, rules, trace, trace_cap);
+  return hipSuccess;
+}
+hipError_t launch_lm_take_candidate(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {
+  const int64_t npose = (int64_t)dp.F * dp.P * 6, npoint = 3 * (int64_t)dp.M, nintr = sv.NPF > 0 ? 9 * (int64_t)dp.NI : 0;
+  LAUNCH(lm_take_candidate_kernel, (unsigned)((npose + npoint + nintr + 255) / 256), 256, st, dp, sv, npose, npoint, nintr);
   return hipSuccess;
 }
 hipError_t launch_candidate(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {

@@ -97,6 +97,8 @@ struct Solver {
   int cur_cells = 0;
   hipStream_t mstream = nullptr; hipEvent_t ev_armed[2] = {nullptr, nullptr}, ev_released = nullptr; bool arm_pending[2] = {false, false};
   int64_t schur_launches = 0;                                         // launches of the Schur kernel since the plan was built (statistics)
+  double* d_ctl = nullptr;                                            // trust-region state on the device (device_state.hpp: LmCtlSlot; all zero while the host decides)
+  rsba_iteration* d_trace_it = nullptr; int trace_it_cap = 0;         // the iteration records the deciding kernels write
   // Sharded factorisation (several ranks whose points respect the cut of tile_order.hpp): this rank factors the columns
   // of ITS part of the elimination tree from its own partial S (launch A), the ranks all-reduce the separators' tiles less what
   // their parts subtract from them, every rank factors the separators and solves them backward, then its own part (launch B).
@@ -1062,6 +1064,9 @@ int32_t build_solver_impl(rsba_handle* h) {
   const size_t nb = std::max<size_t>((N + 255) / 256, ((size_t)sv.n + 3 * (size_t)M + 255) / 256);
   if ((rc = s_alloc(s, &sv.partial, 2 * std::max(nb, ((size_t)M + 63) / 64 + 1) + 2))) return rc;   // (the point sweeps leave one partial per 64 points)
   if ((rc = s_alloc(s, &sv.scalars, 16))) return rc;
+  if ((rc = s_alloc(s, &s->d_ctl, kCtlSize))) return rc;
+  HIP_TRY(hipMemset(s->d_ctl, 0, kCtlSize * sizeof(double)));
+  sv.ctl = s->d_ctl;   // (in the device copies of the plan: the persistent Cholesky looks at the status word — zero while the host decides; launches by value get null then)
   if ((rc = s_alloc(s, &sv.chol_fail, 1))) return rc;
   if ((rc = s_alloc(s, &s->d_gpose, (size_t)F * CD))) return rc;
   if ((rc = s_alloc(s, &s->d_gpoint, (size_t)M * 3))) return rc;
@@ -1172,6 +1177,7 @@ int32_t build_solver_impl(rsba_handle* h) {
       for (uint8_t b : sep_level) ps.separator_levels += b;
     }
   }
+  sv.ctl = nullptr;
   tick("statistics");
   HIP_TRY(hipStreamSynchronize(h->stream));   // the plan's one-time fills and scatters are done whatever stream the solves will run on
   tick("device fills");
@@ -1809,6 +1815,77 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
   int invalid_streak = 0, iteration = 0;
   const size_t pose_bytes = (size_t)dp.F * dp.P * 6 * sizeof(double), point_bytes = (size_t)dp.M * 3 * sizeof(double);
   (void)pose_bytes; (void)point_bytes;
+  // ---- trust-region control on the device ----
+  // The loop body below, decisions included, as a sequence of launches that never waits for the host: radius, accept / reject and the
+  // convergence tests live in HBM (s->d_ctl), two single-thread kernels take the decisions by the same rules in the same order, the
+  // kernels of an iteration read the radius there and skip themselves where the host form would not have launched them (a rejected
+  // candidate is not linearised; iterations enqueued AHEAD of a termination fall through).  The host reads the state back every
+  // `ahead` iterations.  What the reference calls per frame — windowedBA over ~100 cameras (VideoSfMClient.cc:241-246) — is bound
+  // by launch and sync latency here, not by the kernels: with the queue kept full the small kernels run back to back.
+  // Calibrated single-GPU problems without priors; everything else — and a suspect factorisation — goes through the host form.
+  bool device_ctl = speculate && !h->allreduce && !free_ratio && !s->ucross && dp.pp_count == 0 && dp.pp_spherical < 0 && sv.NPF == 0 && !s->use_levels &&
+                    !s->timer.on && opt->max_num_iterations > 0 && dp.N > 0;
+  if (const char* e = std::getenv("RSBA_DEVICE_LM")) device_ctl = device_ctl && e[0] != '0';   // A/B switch: 0 = the host decides
+  if (device_ctl) {
+    const int cap = opt->max_num_iterations + 2;
+    if (cap > s->trace_it_cap) { if ((rc = s_alloc(s, &s->d_trace_it, (size_t)cap))) return rc; s->trace_it_cap = cap; }
+    const LmRules R{opt->max_num_iterations, opt->max_num_consecutive_invalid_steps, opt->max_trust_region_radius, opt->min_trust_region_radius, opt->min_relative_decrease,
+                    opt->function_tolerance, opt->gradient_tolerance, opt->parameter_tolerance};
+    double hc[kCtlSize] = {};
+    hc[kCtlRadius] = radius; hc[kCtlDecrease] = decrease_factor; hc[kCtlCost] = cost; hc[kCtlFixed] = fixed; hc[kCtlGmax] = gmax; hc[kCtlFinalCost] = sum->final_cost;
+    HIP_TRY(hipMemcpyAsync(s->d_ctl, hc, sizeof hc, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));   // (hc is a local)
+    struct CtlGuard {   // whichever way this block is left, the host form finds the state it expects: nobody skips, the radius comes by value
+      rsba_handle* h; Solver* s;
+      ~CtlGuard() { s->sv.ctl = nullptr; h->dp.ctl = nullptr; (void)hipMemsetAsync(s->d_ctl, 0, kCtlSize * sizeof(double), h->stream); }
+    } ctl_guard{h, s};
+    sv.ctl = s->d_ctl; dp.ctl = s->d_ctl;
+    int ahead = 2;
+    if (const char* e = std::getenv("RSBA_LM_AHEAD")) ahead = std::max(1, std::atoi(e));
+    std::vector<rsba_iteration> recs((size_t)cap);
+    int enqueued = 0, seen = 0;
+    t0 = now_s();
+    for (;;) {
+      const int batch = std::max(1, std::min(ahead, opt->max_num_iterations - enqueued));
+      for (int b = 0; b < batch; ++b, ++enqueued) {
+        HIP_TRY(launch_clamp_diagonal(dp, sv, opt->min_lm_diagonal, opt->max_lm_diagonal, st));   // (after a rejected step this recomputes what is there: same linearisation)
+        HIP_TRY(launch_begin_solve(sv, st));
+        if ((rc = factor_and_solve(h, 1.0))) return rc;   // (the radius argument is ignored: the kernels read ctl)
+        HIP_TRY(launch_model_cost_change(dp, sv, st));
+        HIP_TRY(launch_candidate(dp, sv, st));
+        swap_params();
+        HIP_TRY(launch_eval(dp, kLmJacobian, st));
+        HIP_TRY(launch_cost_reduce(dp, h->d_cost2, st));
+        swap_params();
+        if ((rc = await_verification(h))) return rc;
+        HIP_TRY(launch_pack_trial(dp, sv, h->d_cost2, st));
+        HIP_TRY(launch_lm_decide_step(sv, s->d_ctl, R, s->d_trace_it, cap, st));
+        HIP_TRY(launch_lm_take_candidate(dp, sv, st));
+        if ((rc = linearize(h, true))) return rc;
+        if ((rc = gradient_max(h))) return rc;
+        HIP_TRY(launch_lm_decide_gradient(sv, s->d_ctl, R, s->d_trace_it, cap, st));
+      }
+      HIP_TRY(hipMemcpyAsync(hc, s->d_ctl, sizeof hc, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      const int have = std::min((int)hc[kCtlNumTrace], cap);
+      if (have > seen) {
+        HIP_TRY(hipMemcpy(recs.data() + seen, s->d_trace_it + seen, (size_t)(have - seen) * sizeof(rsba_iteration), hipMemcpyDeviceToHost));
+        for (; seen < have; ++seen) push(recs[(size_t)seen]);
+      }
+      if (hc[kCtlStatus] != 0.0) break;
+    }
+    sum->linear_solver_time_s += now_s() - t0;
+    radius = hc[kCtlRadius]; decrease_factor = hc[kCtlDecrease]; cost = hc[kCtlCost]; gmax = hc[kCtlGmax];
+    iteration = (int)hc[kCtlIteration]; invalid_streak = (int)hc[kCtlInvalidStreak];
+    sum->num_successful_steps = (int)hc[kCtlSuccessful]; sum->num_unsuccessful_steps = (int)hc[kCtlUnsuccessful]; sum->final_cost = hc[kCtlFinalCost];
+    const double status = hc[kCtlStatus];
+    if (status > 0.0) return finish((int32_t)status - 1);
+    if (status == -2.0) { (void)finish(RSBA_FAILURE); return rsba_set_error(RSBA_ERR_EVALUATION_FAILED, "residual and Jacobian evaluation failed"); }
+    // status -1: the persistent driver's solution of the last iteration does not satisfy its system.  Nothing of that iteration has
+    // touched x or the state: the host form below repeats it, and finishes the problem, on the level schedule.
+    s->use_levels = true; ++s->dag_fallbacks; ++sum->num_dag_fallbacks;
+    reuse_diagonal = true;   // (the diagonal is in place)
+  }
   while (true) {
     if (iteration >= opt->max_num_iterations) return finish(RSBA_NO_CONVERGENCE);
     t0 = now_s();
@@ -1884,7 +1961,8 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
       it.relative_decrease = it.cost_change / model_cost_change;
       if (it.relative_decrease > opt->min_relative_decrease) {
         it.step_is_successful = 1; ++sum->num_successful_steps;
-        radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * it.relative_decrease - 1.0, 3));
+        const double t3 = 2.0 * it.relative_decrease - 1.0;   // (the cube by two multiplications — what the deciding kernel of the device-side loop computes, bit for bit)
+        radius = radius / std::max(1.0 / 3.0, 1.0 - t3 * t3 * t3);
         radius = std::min(opt->max_trust_region_radius, radius); decrease_factor = 2.0; reuse_diagonal = false;
         swap_params();   // x = x_plus_delta
         if (free_ratio) { ratio = ratio_new; dp.prior_ratio = ratio; }

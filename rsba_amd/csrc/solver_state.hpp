@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 
+#include "../../include/rsba_amd.h"
 #include "device_state.hpp"
 
 namespace rsba {
@@ -97,6 +98,7 @@ struct SolverDev {
   double* rhs;                  // [npad] directly behind S (one exchange buffer) -> z (forward) -> y_c (backward)
   double* udiag;                // [F*CD] diag(U), global after the exchange
   double* xbuf;                 // [2*F*CD + 3] exchange buffer: g_c | diag(U) | cost, fixed cost, failed blocks
+  const double* ctl;            // trust-region state on the device (device_state.hpp: LmCtlSlot), null = the host decides and passes the radius by value
   int lead;                     // 1 on the rank that contributes the replicated terms (D_c^2, g_c, camera norms)
   const double* frame_lead;     // [nt * FT] sharded factorisation: 1 where THIS rank adds the replicated terms of the frame to its partial S (its own part;
                                 //   rank 0: the separators), null = `lead` decides for every frame
@@ -180,6 +182,12 @@ hipError_t launch_zero_tiles(double* S, const int32_t* slots, int n, hipStream_t
 hipError_t launch_back_substitute(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);
 hipError_t launch_model_cost_change(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);      // -> scalars[kModelCostChange]
 hipError_t launch_candidate(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);              // trial params, |step|^2, |x|^2
+// trust-region control on the device: the two decisions of an iteration (after the candidate's evaluation; after an accepted step's
+// linearisation) and the hand-over of an accepted candidate (kernels_normal.hip)
+struct LmRules { int32_t max_num_iterations, max_num_consecutive_invalid_steps; double max_trust_region_radius, min_trust_region_radius, min_relative_decrease, function_tolerance, gradient_tolerance, parameter_tolerance; };
+hipError_t launch_lm_decide_step(const SolverDev& sv, double* ctl, const LmRules& rules, rsba_iteration* trace, int trace_cap, hipStream_t st);
+hipError_t launch_lm_decide_gradient(const SolverDev& sv, double* ctl, const LmRules& rules, rsba_iteration* trace, int trace_cap, hipStream_t st);
+hipError_t launch_lm_take_candidate(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);   // x = x + delta where ctl says "accepted"
 // motion priors (kernels_prior.hip): U_f, g_f += their J^T J / J^T r, ucross[f] = the (f, f-1) block; model cost change
 hipError_t launch_prior_blocks(const DeviceProblem& dp, const SolverDev& sv, double* ucross, hipStream_t st);
 hipError_t launch_prior_model(const DeviceProblem& dp, const SolverDev& sv, double* model_cost_change, double ratio_step, hipStream_t st);

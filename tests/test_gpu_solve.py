@@ -462,3 +462,54 @@ def test_device_blocks_are_cached_between_handles_and_given_back(capi):
     assert max(levels[1:]) - levels[0] <= 4 << 20           # ... the next handles live in them
     capi.release_host_scratch()
     assert in_use() - base <= 8 << 20                        # ... and they go back on request
+
+
+@pytest.mark.parametrize("case", ["c2", "rejections", "failure", "tolerances", "max_iterations", "huber"])
+def test_device_side_trust_region_equals_the_host_form(capi, monkeypatch, case):
+    """accept / reject, the radius update and the convergence tests of the LM loop run in a single-thread kernel, the
+    iteration's kernels read the radius from HBM and skip themselves where the host form would not have launched them, the host
+    enqueues iterations ahead and looks at the state every other iteration.  Same rules in the same order on IEEE operations: the two
+    forms must agree bit for bit — every field of every iteration record, the summary, the parameters — whatever happens on the way
+    (rejected steps, termination by each tolerance, by the iteration limit), and whatever the look-ahead."""
+    from rsba_amd.scene import make_config
+    def problem():
+        if case == "c2":
+            return make_config("C2").problem, dict(max_num_iterations=12)
+        p = small_scene(frames=24, points=1500, seed=13, outlier_ratio=0.1 if case == "huber" else 0.0)
+        if case == "huber":
+            p.huber_a = 1.5
+            return p, dict(max_num_iterations=25)
+        if case in ("rejections", "failure"):      # a start far from the minimum and a huge first radius: Gauss-Newton steps that overshoot (or never recover)
+            rng = np.random.default_rng(2)
+            sc = 2.0 if case == "rejections" else 3.0
+            p.points += rng.normal(0, 0.6 * sc, p.points.shape); p.poses[1:, :, 3:] += rng.normal(0, 0.25 * sc, p.poses[1:, :, 3:].shape)
+            p.poses[1:, :, :3] += rng.normal(0, 0.05 * sc, p.poses[1:, :, :3].shape)
+            return p, dict(max_num_iterations=30, initial_trust_region_radius=1e12)
+        if case == "tolerances":
+            return p, dict(max_num_iterations=50)
+        return p, dict(max_num_iterations=3)
+    out = {}
+    for mode, env in (("host", {"RSBA_DEVICE_LM": "0"}), ("device", {}), ("device_ahead_1", {"RSBA_LM_AHEAD": "1"}), ("device_ahead_5", {"RSBA_LM_AHEAD": "5"})):
+        for k in ("RSBA_DEVICE_LM", "RSBA_LM_AHEAD"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        p, kw = problem()
+        with capi.DeviceProblem(p) as dp:
+            s, tr = dp.solve(capi.default_options(**kw))
+        rec = [(t.iteration, t.step_is_valid, t.step_is_successful, t.cost, t.cost_change, t.gradient_max_norm, t.step_norm, t.relative_decrease, t.trust_region_radius, t.model_cost_change) for t in tr]
+        out[mode] = (rec, (s.termination_type, s.num_successful_steps, s.num_unsuccessful_steps, s.num_iterations, s.initial_cost, s.final_cost, s.is_solution_usable), p.poses.copy(), p.points.copy())
+    ref = out["host"]
+    for mode in ("device", "device_ahead_1", "device_ahead_5"):
+        got = out[mode]
+        assert got[0] == ref[0], mode
+        assert got[1] == ref[1], (mode, got[1], ref[1])
+        assert np.array_equal(got[2], ref[2]) and np.array_equal(got[3], ref[3]), mode
+    if case == "rejections":
+        assert ref[1][1] >= 5 and ref[1][2] >= 3          # the case does accept and reject steps
+    if case == "failure":
+        assert ref[1][2] >= 3                              # ... and this one only rejects (invalid or unsuccessful steps to the end)
+    if case == "max_iterations":
+        assert ref[1][0] == 1 and ref[1][3] == 4      # NO_CONVERGENCE after 3 iterations (+ the record of iteration 0)
+    if case == "tolerances":
+        assert ref[1][0] == 0
