@@ -1144,7 +1144,15 @@ __global__ __launch_bounds__(256, 2) void chol_dag_kernel(const DagArgs* __restr
     }
     lds_barrier();
     const int t = s_ticket;
-    if (t >= pl.ntasks) return;
+    if (t >= pl.ntasks) {
+      // The last workgroup to leave re-arms the ticket counters for the next launch (a 16-byte fill per solve was a launch of its
+      // own: ~6 us of kernel boundary on a solve of a few hundred): counter [3] counts the leavers.
+      if (tid == 0 && __hip_atomic_fetch_add(pl.ticket + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+        __hip_atomic_store(pl.ticket + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(pl.ticket + 3, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      return;
+    }
     // every task recomputes what it derives from the thread index: left alone, the compiler hoists dozens of per-thread LDS
     // offsets out of this loop, keeps them live across all task bodies and spills them to scratch — whose reloads (vmcnt)
     // then stall on every prefetch in flight
@@ -1348,8 +1356,8 @@ hipError_t launch_chol_dag(const SolverDev& sv, const CholPlan& pl, const DagArg
   static_assert(kCholLds * sizeof(double) <= (size_t)84 * 1024, "LDS map of the Cholesky tasks");
   hipError_t e = allow_dynamic_lds(chol_dag_kernel, lds_bytes);
   if (e != hipSuccess) return e;
-  e = hipMemsetAsync(pl.ticket, 0, 16, st);   // (the caller has re-armed the write-once cells: one memset over their common allocation, solver.hip)
-  if (e != hipSuccess) return e;
+  // (the ticket counters are zero: set so when the plan was made, and re-armed by the last workgroup of every launch; the caller has
+  // re-armed the write-once cells: one memset over their common allocation, solver.hip)
   hipLaunchKernelGGL(chol_dag_kernel, dim3(workgroups), dim3(256), lds_bytes, st, device_args);
   return hipGetLastError();
 }

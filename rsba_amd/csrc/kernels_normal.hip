@@ -667,12 +667,12 @@ __global__ __launch_bounds__(256) void point_step_kernel(const DeviceProblem dp,
       if (c0 + 64 < se) issue(c0 + 64);
       if (lane < nrec) {
         const double* rec = buf + lane * PITCH;
-        const double* yc = sv.rhs + (size_t)frame * CD;
+        const double* yc = sv.step + (size_t)frame * CD;
         double t0 = 0.0, t1 = 0.0;
 #pragma unroll
         for (int a = 0; a < CD; ++a) { const double y = yc[a]; t0 += rec[8 + off + a] * y; t1 += rec[8 + KC + off + a] * y; }
         if (off > 0) {
-          const double* yi = sv.rhs + ((size_t)sv.F + (size_t)(sv.NIB > 1 ? dp.frame_intr[frame] : 0) * sv.NPF) * CD;   // step of the frame's intrinsics block: 9 coordinates across its pseudo frames
+          const double* yi = sv.step + ((size_t)sv.F + (size_t)(sv.NIB > 1 ? dp.frame_intr[frame] : 0) * sv.NPF) * CD;   // step of the frame's intrinsics block: 9 coordinates across its pseudo frames
 #pragma unroll
           for (int k = 0; k < off; ++k) { const double y = yi[k]; t0 += rec[8 + k] * y; t1 += rec[8 + KC + k] * y; }
         }
@@ -867,12 +867,12 @@ __global__ __launch_bounds__(256) void point_step_rc_kernel(const DeviceProblem 
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const double mc = point_sweep<CAL, P, 5>(dp, sv, smem,
     [&](const ObsOut<CAL, P>& o, int frame, int, double c[5]) {
-      const double* yc = sv.rhs + (size_t)frame * CD;
+      const double* yc = sv.step + (size_t)frame * CD;
       double t0 = 0.0, t1 = 0.0;
 #pragma unroll
       for (int a = 0; a < CD; ++a) { const double y = yc[a]; t0 += o.J[0][OP + a] * y; t1 += o.J[1][OP + a] * y; }
       if (!CAL) {
-        const double* yi = sv.rhs + (size_t)sv.F * CD;   // step of the (one) intrinsics block: 9 coordinates across its pseudo frames
+        const double* yi = sv.step + (size_t)sv.F * CD;   // step of the (one) intrinsics block: 9 coordinates across its pseudo frames
 #pragma unroll
         for (int k = 0; k < 9; ++k) { const double y = yi[k]; t0 += o.J[0][k] * y; t1 += o.J[1][k] * y; }
       }
@@ -977,7 +977,7 @@ __global__ __launch_bounds__(256) void candidate_kernel(const DeviceProblem dp, 
     else {
     const double x = cam ? (intr ? dp.intr[ii] : dp.poses[u]) : dp.points[u];
     const double sc = cam ? cam_scale(dp, sv, t) : dp.scale_point[u];
-    const double y = cam ? sv.rhs[t] : sv.yp[u];
+    const double y = cam ? sv.step[t] : sv.yp[u];
     const double in = cam ? (intr ? sv.inprog_intr[u] : sv.inprog_pose[u]) : sv.inprog_point[u];
     const double xn = (sc > 0.0) ? x + (-y * sc) : x;
     if (intr) sv.trial_intr[ii] = xn; else if (cam) sv.trial_poses[u] = xn; else sv.trial_points[u] = xn;

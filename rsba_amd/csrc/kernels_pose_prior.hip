@@ -145,7 +145,7 @@ __global__ void pose_prior_reduce_kernel(const DeviceProblem dp, const SolverDev
   sv.rhs[cc] -= cross[t] * g0[t] / vp;
 }
 
-// after the camera step (sv.rhs) is known: y0, the candidate prior values, and the blocks' share of the model cost change,
+// after the camera step (sv.step) is known: y0, the candidate prior values, and the blocks' share of the model cost change,
 // |step|^2 and |x|^2 (added to the scalars the point / camera kernels have already written)
 __global__ __launch_bounds__(kPPThreads) void pose_prior_step_kernel(const DeviceProblem dp, const SolverDev sv, const double* v0, const double* g0,
                                                                       const double* cross, const double* diag, double inv_radius) {
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(kPPThreads) void pose_prior_step_kernel(const Devic
     const double* pose = dp.poses + (size_t)b * 6; const double* p0 = dp.pp_value + (size_t)k * 6;
     for (int i = 0; i < 6; ++i) {
       const int t = k * 6 + i;
-      const double yp = sv.rhs[(size_t)b * 6 + i];
+      const double yp = sv.step[(size_t)b * 6 + i];
       const double y0 = (g0[t] - cross[t] * yp) / (v0[t] + diag[t] * inv_radius);
       const double w = pp_weight(dp, i), s0 = dp.pp_scale[t], sp = dp.scale_pose[(size_t)b * 6 + i];
       const double r = (p0[i] - pose[i]) * w;
@@ -175,8 +175,8 @@ __global__ __launch_bounds__(kPPThreads) void pose_prior_step_kernel(const Devic
     const Spherical s = spherical_at(dp.poses + (size_t)b * 6);
     double m0 = 0.0, m1 = 0.0;
     for (int i = 0; i < 3; ++i) {
-      m0 += s.j0[i] * dp.scale_pose[(size_t)b * 6 + i] * -sv.rhs[(size_t)b * 6 + i];
-      m1 += s.j1[i] * dp.scale_pose[(size_t)b * 6 + 3 + i] * -sv.rhs[(size_t)b * 6 + 3 + i];
+      m0 += s.j0[i] * dp.scale_pose[(size_t)b * 6 + i] * -sv.step[(size_t)b * 6 + i];
+      m1 += s.j1[i] * dp.scale_pose[(size_t)b * 6 + 3 + i] * -sv.step[(size_t)b * 6 + 3 + i];
     }
     acc += m0 * (s.r0 + 0.5 * m0) + m1 * (s.r1 + 0.5 * m1);
   }

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(64) void prior_cost_kernel(const DeviceProblem dp, 
   if (invalid) *dp.fail_count += invalid;   // the functors return false for this interFrameRatio
 }
 
-// model cost change of the prior blocks for the camera step in sv.rhs:  -sum m.(r~ + m/2),  m = -J~ y
+// model cost change of the prior blocks for the camera step in sv.step:  -sum m.(r~ + m/2),  m = -J~ y
 __global__ __launch_bounds__(64) void prior_model_kernel(const DeviceProblem dp, const SolverDev sv, double* out, double ratio_step) {
   const int f = blockIdx.x * 64 + threadIdx.x;
   double acc = 0.0;
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(64) void prior_model_kernel(const DeviceProblem dp,
     prior_coefficients(dp, Ca, Cb);
     const PriorValue v = prior_value(dp, f);
     const double sw = sqrt(v.weight);
-    const double* y = sv.rhs + (size_t)(f - 1) * 12; const double* sc = dp.scale_pose + (size_t)(f - 1) * 12;   // [prev | cur]
+    const double* y = sv.step + (size_t)(f - 1) * 12; const double* sc = dp.scale_pose + (size_t)(f - 1) * 12;   // [prev | cur]
     double dr[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) dr[i] = 0.0;

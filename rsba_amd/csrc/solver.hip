@@ -941,6 +941,7 @@ int32_t build_solver_impl(rsba_handle* h) {
   }
   up.upload_ref(&s->d_tasks, s->tasks);
   if ((rc = s_alloc(s, &s->d_dag_sync, 4))) return rc;
+  HIP_TRY(hipMemsetAsync(s->d_dag_sync, 0, 4 * sizeof(unsigned int), h->stream));   // (the persistent kernel leaves its counters at zero behind every launch)
   if ((rc = s_alloc(s, &s->zy2, 2 * (size_t)sv.npad))) return rc;
   up.upload_ref(&s->d_diag_info, s->diag_info);
   up.upload_ref(&s->d_diag_ptr, s->diag_ptr);
@@ -1322,7 +1323,7 @@ int32_t await_verification(rsba_handle* h) {
   if (s->verify_pending) { HIP_TRY(hipStreamWaitEvent(h->stream, s->ev_verified, 0)); s->verify_pending = false; }
   return RSBA_OK;
 }
-int32_t solve_reduced_system(rsba_handle* h) {
+int32_t solve_reduced_system(rsba_handle* h, bool rhs_stays = false) {
   Solver* s = h->solver; SolverDev& sv = s->sv; hipStream_t st = h->stream;
   PhaseScope ps(h, RSBA_PHASE_CHOLESKY);
   if (int32_t rc = await_verification(h)) return rc;
@@ -1368,10 +1369,12 @@ int32_t solve_reduced_system(rsba_handle* h) {
     HIP_TRY(launch_chol_dag(sv, s->plan, s->d_dag_args, s->dag_workgroups, s->dag_one_per_cu, st));
     if (s->test_corrupt_once) { s->test_corrupt_once = false; HIP_TRY(hipMemsetAsync(sv.yv + (sv.n / 2 / 6) * 6 + 1, 0, sizeof(double), st)); }   // test hook: one entry of the solution (a pose coordinate in mid-video) lost
     if (s->verify_dag) {
-      HIP_TRY(hipMemcpyAsync(s->verify_b, sv.rhs, (size_t)sv.npad * sizeof(double), hipMemcpyDeviceToDevice, st));
+      // (rhs_stays: nobody writes sv.rhs before the check has been waited for — the LM iteration without a free ratio; otherwise the check gets a copy)
+      const double* b_rhs = sv.rhs;
+      if (!rhs_stays) { HIP_TRY(hipMemcpyAsync(s->verify_b, sv.rhs, (size_t)sv.npad * sizeof(double), hipMemcpyDeviceToDevice, st)); b_rhs = s->verify_b; }
       HIP_TRY(hipEventRecord(s->ev_solved, st));
       HIP_TRY(hipStreamWaitEvent(s->vstream, s->ev_solved, 0));
-      HIP_TRY(launch_chol_verify(sv, s->d_slot_tiles, s->verify_b, s->d_verify, s->d_verify + sv.npad, 1e-7, sv.scalars + kDagSuspect, s->vstream,
+      HIP_TRY(launch_chol_verify(sv, s->d_slot_tiles, b_rhs, s->d_verify, s->d_verify + sv.npad, 1e-7, sv.scalars + kDagSuspect, s->vstream,
                                  s->sharded && !s->sharded_off ? s->d_row_check : nullptr));   // (a rank of a sharded factorisation holds the whole of its part's rows of S, nothing else)
       HIP_TRY(hipEventRecord(s->ev_verified, s->vstream));
       s->verify_pending = true;
@@ -1421,7 +1424,7 @@ int32_t factor_and_solve(rsba_handle* h, double radius, RatioStep* ratio = nullp
   Solver* s = h->solver; const SolverDev& sv = s->sv; hipStream_t st = h->stream;
   int32_t rc = reduce_system(h, radius);
   if (rc) return rc;
-  if ((rc = solve_reduced_system(h))) return rc;
+  if ((rc = solve_reduced_system(h, /*rhs_stays=*/!ratio))) return rc;
   if (ratio) {
     const double* v = nullptr;
     if ((rc = solve_again(h, s->border, &v))) return rc;                 // sv.yv = u stays where it is
@@ -1431,9 +1434,8 @@ int32_t factor_and_solve(rsba_handle* h, double radius, RatioStep* ratio = nullp
     HIP_TRY(hipStreamSynchronize(st));
     ratio->eta = (ratio->gs - ratio->scale * dots[0]) / (ratio->diag - ratio->scale * ratio->scale * dots[1]);
     HIP_TRY(launch_border_combine(sv.rhs, sv.yv, v, ratio->scale * ratio->eta, sv.npad, st));
-  } else {
-    HIP_TRY(hipMemcpyAsync(sv.rhs, sv.yv, (size_t)sv.npad * sizeof(double), hipMemcpyDeviceToDevice, st));   // camera step
-  }
+    s->sv.step = sv.rhs;
+  } else s->sv.step = sv.yv;   // the camera step is read where the solve left it (the cells of this solve stay armed until the next one)
   PhaseScope ps(h, RSBA_PHASE_BACK_SUBSTITUTE);
   HIP_TRY(launch_back_substitute(h->dp, sv, st));
   return RSBA_OK;

@@ -95,7 +95,9 @@ struct SolverDev {
   double* Winv;                 // [nt][kTile][kTile] inverses of the factored diagonal tiles (by tile index)
   double* chol_part;            // [all chunks][kTile*kTile + kTile] partial update tiles (+ rhs partials)
   double* Xpub;                 // [nt][kTile][kTile] by DIAG item: tile (j, k*) less its updates, published by its SUB task for the DIAG task of column j
-  double* rhs;                  // [npad] directly behind S (one exchange buffer) -> z (forward) -> y_c (backward)
+  double* rhs;                  // [npad] directly behind S (one exchange buffer): the right-hand side of the reduced system
+  const double* step;           // [npad] the camera step y_c the point-side passes and the candidate read: the solve's y where it landed (sv.yv), or
+                                //   rhs when the free interFrameRatio combined two solves there
   double* udiag;                // [F*CD] diag(U), global after the exchange
   double* xbuf;                 // [2*F*CD + 3] exchange buffer: g_c | diag(U) | cost, fixed cost, failed blocks
   const double* ctl;            // trust-region state on the device (device_state.hpp: LmCtlSlot), null = the host decides and passes the radius by value
