@@ -188,13 +188,24 @@ def next_rows(prob, dp, device):
         from rsba_amd.scene import make_config
         c2 = make_config("C2").problem
         p0, x0 = c2.poses.copy(), c2.points.copy()
-        t0 = time.perf_counter()
-        d2 = capi.DeviceProblem(c2, device=device)
-        t_create = time.perf_counter() - t0
         opt20 = capi.default_options(max_num_iterations=20)     # what VideoSfMHandler::BA asks for (VideoSfMHandler.cc:582)
-        t0 = time.perf_counter()
-        s_first, _ = d2.solve(opt20)
-        t_first = time.perf_counter() - t0
+        # a fresh handle per call is windowedBA's pattern; the symbolic phase is host work on a shared, busy host (one sample in five
+        # is off by milliseconds), so: three fresh handles, the fastest is quoted, all are listed
+        runs = []
+        for _rep in range(3):
+            c2.poses[:], c2.points[:] = p0, x0
+            t0 = time.perf_counter()
+            d2 = capi.DeviceProblem(c2, device=device)
+            t_create = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            s_first, _ = d2.solve(opt20)
+            t_first = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            if _rep < 2:
+                d2.close()
+            t_destroy = time.perf_counter() - t0
+            runs.append((t_create + t_first, t_create, t_first, t_destroy))
+        t_total, t_create, t_first, _ = min(runs)
         eval_ms = d2.time_evaluate(True, warmup=20, iters=50)
         c2.poses[:], c2.points[:] = p0, x0
         d2.upload_parameters()
@@ -210,6 +221,7 @@ def next_rows(prob, dp, device):
                      "ms_per_lm_iteration": t_steady / max(1, s2.num_iterations - 1) * 1e3,
                      "end_to_end_ba": {"rsba_create_ms": t_create * 1e3, "first_solve_ms": t_first * 1e3, "iterations": int(s_first.num_iterations - 1),
                                        "total_ms": (t_create + t_first) * 1e3, "final_cost": s_first.final_cost,
+                                       "all_runs_ms": [{"create": r[1] * 1e3, "plan_and_solve": r[2] * 1e3, "destroy": r[3] * 1e3} for r in runs],
                                        "note": "fresh handle: upload + index check, symbolic phase, allocations, up to 20 LM iterations with Ceres' default tolerances, parameters back on the host"}}
     except Exception as e:  # noqa: BLE001
         out["c2"] = {"error": repr(e)}
