@@ -791,22 +791,35 @@ __global__ __launch_bounds__(256) void project_rc_kernel(const DeviceProblem dp,
 // (Sixteen points — a few hundred slots — per wave: the records are computed, not streamed, so the pass wants many waves in flight,
 // not long ones; 64 points per wave left the 100-camera scene with 40 workgroups.)
 constexpr int kSweepPoints = 16;
+// The sums are taken by ALL 64 lanes: the wave's (point, component) pairs — 16 x NC — are dealt to the lanes, each adding its pairs'
+// numbers over the point's slots in slot order (the same order as ever: same bits) — when only the 16 lanes that own a point did
+// this, the other 48 waited through 20 x NC dependent LDS reads and adds per point: most of the sweep's time (the virtual-record sweep
+// of a shared intrinsics block, NC = 27, took 0.91 ms at 4k cameras against 0.35 for NC = 9 over the same records).
 template <bool CAL, int P, int NC, class PerSlot, class PerPoint>
 __device__ __forceinline__ double point_sweep(const DeviceProblem& dp, const SolverDev& sv, double* smem, PerSlot per_slot, PerPoint per_point) {
+  constexpr int NPAIR = kSweepPoints * NC, PER = (NPAIR + 63) / 64;
   __shared__ double s_red[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double* cbuf = smem + (size_t)wave * (64 * NC);
   const int64_t j0 = ((int64_t)blockIdx.x * 4 + wave) * kSweepPoints;
   double ret = 0.0;
+  auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
   if (j0 < dp.M) {   // wave-uniform
     const int jn = (int)(dp.M - j0 < kSweepPoints ? dp.M - j0 : kSweepPoints);
     const bool mine = lane < jn;
     const int64_t j = j0 + (mine ? lane : 0);
     const int64_t lo = mine ? sv.point_ptr[j] : 0, hi = mine ? sv.point_ptr[j + 1] : 0;
     const int64_t sb = sv.point_ptr[j0], se = sv.point_ptr[j0 + jn];
-    double acc[NC];
+    // this lane's pairs: pair = lane + 64 i -> point pair / NC of the wave, component pair % NC; the point's slot range from its owner lane
+    double acc[PER]; int64_t plo[PER], phi[PER]; int pq[PER];
 #pragma unroll
-    for (int q = 0; q < NC; ++q) acc[q] = 0.0;
+    for (int i = 0; i < PER; ++i) {
+      const int pair = lane + 64 * i, pj = pair / NC;
+      acc[i] = 0.0; pq[i] = pair % NC;
+      const long long l = __shfl((long long)lo, pj < kSweepPoints ? pj : 0, 64), h = __shfl((long long)hi, pj < kSweepPoints ? pj : 0, 64);
+      const bool live = pair < jn * NC;
+      plo[i] = live ? l : 0; phi[i] = live ? h : 0;
+    }
     for (int64_t c0 = sb; c0 < se; c0 += 64) {
       const int nrec = (int)(se - c0 < 64 ? se - c0 : 64);
       {
@@ -819,16 +832,24 @@ __device__ __forceinline__ double point_sweep(const DeviceProblem& dp, const Sol
 #pragma unroll
         for (int q = 0; q < NC; ++q) cbuf[lane * NC + q] = c[q];
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const int64_t s_lo = lo > c0 ? lo : c0, s_hi = hi < c0 + nrec ? hi : c0 + nrec;
-      for (int64_t sidx = s_lo; sidx < s_hi; ++sidx) {
-        const double* c = cbuf + (sidx - c0) * NC;
+      wave_sync();
 #pragma unroll
-        for (int q = 0; q < NC; ++q) acc[q] += c[q];
+      for (int i = 0; i < PER; ++i) {
+        const int64_t s_lo = plo[i] > c0 ? plo[i] : c0, s_hi = phi[i] < c0 + nrec ? phi[i] : c0 + nrec;
+        for (int64_t sidx = s_lo; sidx < s_hi; ++sidx) acc[i] += cbuf[(sidx - c0) * NC + pq[i]];
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      wave_sync();
     }
-    if (mine) ret = per_point(j, acc);
+    // the sums of a point back to the lane that owns it
+#pragma unroll
+    for (int i = 0; i < PER; ++i) if (lane + 64 * i < NPAIR) cbuf[lane + 64 * i] = acc[i];
+    wave_sync();
+    if (mine) {
+      double a[NC];
+#pragma unroll
+      for (int q = 0; q < NC; ++q) a[q] = cbuf[lane * NC + q];
+      ret = per_point(j, a);
+    }
   }
   ret = wsum(ret);
   if (lane == 0) s_red[wave] = ret;
