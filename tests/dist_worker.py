@@ -31,7 +31,14 @@ def nd_mode(mode, outdir, rank, world, dist, torch):
     from rsba_amd.scene import make_config
     _, cfg, iters = mode.split(":")[:3]
     flags = mode.split(":")[3:]
-    full = make_config(cfg).problem
+    if cfg.startswith("S"):   # "S<frames>": a scene of that many rolling-shutter frames, 70 points per frame
+        from rsba_amd.problem import apply_gauge_masks
+        from rsba_amd.scene import make_scene
+        full = make_scene(int(cfg[1:]), 70 * int(cfg[1:]), seed=3).problem
+        apply_gauge_masks(full, fix_first_n_cameras=1)
+        full.pose_fixed_mask[-1, -1] |= 0b111000
+    else:
+        full = make_config(cfg).problem
     if "intr" in flags:      # shared intrinsics as a parameter block + Huber, as BASELINE config 5 has them: a dense border of the reduced system
         full.calibrated = False; full.huber_a = 2.0
         full.intrinsics = full.intrinsics * (1.0 + 1e-3 * np.array([[1, -1, 20, -20, 10, 10, -10, 0.5, -0.5]]))

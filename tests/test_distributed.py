@@ -237,3 +237,11 @@ def test_a_suspect_sharded_solve_sends_every_rank_back_to_the_replicated_factori
     single-GPU level-scheduled solve."""
     res = run_two_ranks("nd:C2:6:corrupt", tmp_path, 2)
     check_nd(res, 2, fallbacks=1)
+
+
+@pytest.mark.gpu
+def test_sharded_factorisation_on_three_ranks(tmp_path):
+    """A rank count that is not a power of two: the top of the dissection is cut 1 + 2 (tile_order.hpp: the separator sits where the
+    weight per rank balances), three parts, two levels of separators — the same trajectory as one GPU."""
+    res = run_two_ranks("nd:S300:6", tmp_path, 3)
+    check_nd(res, 3)
