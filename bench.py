@@ -337,6 +337,7 @@ def main():
     comm = None
     serialize = False
     transport = "none (single GPU)"
+    transport_error = None
     if world > 1 and not args.no_lm:
         from rsba_amd.distributed import attach, attach_rccl
         if one_gpu:
@@ -344,7 +345,17 @@ def main():
             attach(dp, serialize=serialize)
             transport = "callback: torch.distributed gloo staged through the host (test hook" + ("; ranks take turns on the shared GPU)" if serialize else ")")
         else:
-            comm = attach_rccl(dp, local_rank); transport = "native: ncclAllReduce (RCCL over xGMI) issued by librsba_amd on its stream"
+            # the library's own communicator beside torch's: if ANY rank cannot set it up, every rank leaves the LM leg out (agreed through
+            # torch's process group) and says why — the evaluation, which needs no collective, is still timed and reported
+            try:
+                comm = attach_rccl(dp, local_rank); transport = "native: ncclAllReduce (RCCL over xGMI) issued by librsba_amd on its stream"
+            except Exception as e:  # noqa: BLE001 - reported in the JSON line
+                transport_error = repr(e)
+            ok = torch.tensor([0.0 if transport_error else 1.0], device="cuda")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if float(ok.item()) == 0.0:
+                transport_error = transport_error or "another rank could not set up the library's RCCL communicator"
+                args.no_lm = True
 
     def barrier():
         if world > 1:
@@ -479,6 +490,8 @@ def main():
                          "rank": 0},
             "lm": lm, "roofline_lm": lm_roof,
         }
+        if transport_error:
+            out["lm"] = {"error": "LM leg left out: the library's RCCL communicator could not be set up on every rank", "transport_error": transport_error}
         try:
             free_b, total_b = torch.cuda.mem_get_info(local_rank)
             out["device_memory"] = {"in_use_bytes": int(total_b - free_b), "total_bytes": int(total_b),

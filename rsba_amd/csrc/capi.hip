@@ -401,7 +401,7 @@ int32_t rsba_evaluate(rsba_handle* h, double* cost, double* residuals, double* j
   HIP_TRY(hipMemsetAsync(dp.fail_count, 0, sizeof(int), h->stream));
   HIP_TRY(launch_eval(dp, jacobians ? kRawJacobian : kResidualOnly, h->stream));
   HIP_TRY(launch_cost_reduce(dp, h->d_cost2, h->stream));
-  if (dp.prior_of && h->rank == 0) HIP_TRY(launch_prior_cost(dp, h->d_cost2, h->prior_invalid, h->stream));
+  if (dp.prior_of && (h->rank == 0 || h->prior_split)) HIP_TRY(launch_prior_cost(dp, h->d_cost2, h->prior_invalid, h->stream));
   if (h->rank == 0) HIP_TRY(launch_pose_prior_cost(dp, h->d_cost2, h->stream));
   double c2[2] = {0, 0}; int nfail = 0;
   HIP_TRY(hipMemcpyAsync(c2, h->d_cost2, sizeof c2, hipMemcpyDeviceToHost, h->stream));

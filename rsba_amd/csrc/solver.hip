@@ -565,10 +565,11 @@ int32_t build_solver_impl(rsba_handle* h) {
   s->last_diag_slot = slot_base[iperm[nt - 1]];      // the (possibly padded) last tile of the natural order
   tick("symbolic");
   // ---- sharded factorisation: does every rank's share of the points respect the cut? ----
-  // (part of a column = the rank whose subtree it belongs to, -1 = a separator the ranks share.)  Not with motion / pose priors or
-  // several intrinsics blocks (their replicated terms come from rank 0 alone) — those problems keep the replicated factorisation.
+  // (part of a column = the rank whose subtree it belongs to, -1 = a separator the ranks share.)  Not with pose priors, a free
+  // interFrameRatio or several intrinsics blocks (their replicated terms come from rank 0 alone) — those problems keep the
+  // replicated factorisation.  Motion priors with a known ratio are shared out like the frames: see below.
   std::vector<int32_t> cpart(nt, -1);
-  bool sharded = want_parts && tord.parts_ok && h->prior_frames.empty() && h->pp_blocks.empty() && dp.pp_spherical < 0 && NIB <= 1;
+  bool sharded = want_parts && tord.parts_ok && !(h->prior_free && !h->prior_frames.empty()) && h->pp_blocks.empty() && dp.pp_spherical < 0 && NIB <= 1;
   if (const char* e = std::getenv("RSBA_SHARDED")) sharded = sharded && e[0] != '0';   // A/B switch
   if (want_parts) {
     double bad = sharded ? 0.0 : 1.0;
@@ -588,6 +589,25 @@ int32_t build_solver_impl(rsba_handle* h) {
   }
   s->sharded = sharded;
   if (sharded) for (int j = 0; j < nt; ++j) cpart[j] = tord.part_of[perm[j]];
+  if (sharded && !h->prior_frames.empty() && !h->prior_split) {
+    // The prior between frames f and f - 1 (CeresHandler.h:147-185) adds to U_f, U_f-1, the (f, f-1) block and both gradients: it
+    // belongs to the rank that owns the part either frame is in (two adjacent frames are never in two different parts: their tiles
+    // are the same or neighbours), rank 0 when both sit in separators — so every tile of a part's columns stays complete on its rank.
+    auto part_of_frame = [&](int f) { return tord.part_of[f / FT]; };
+    std::vector<int32_t> own((size_t)FR + 1, 0);
+    int mine = 0;
+    for (int32_t f : h->prior_frames) {
+      int r = part_of_frame(f);
+      if (r < 0) r = part_of_frame(f - 1);
+      if (r < 0) r = 0;
+      if (r == h->rank) { own[f] = 1; ++mine; }
+    }
+    int32_t* d_own = nullptr;
+    if (int32_t rc_ = s_upload(s, &d_own, own)) return rc_;
+    h->dp.prior_of = d_own;
+    if (h->prior_invalid > 0) h->prior_invalid = mine;
+    h->prior_split = true;
+  }
   // level schedule: column j is ready once every column of row[j] is done
   std::vector<int32_t> level(nt, 0);
   int nlev = 0;
@@ -1248,9 +1268,10 @@ int32_t linearize(rsba_handle* h, bool have_eval = false) {
     HIP_TRY(launch_camera_blocks(h->dp, s->sv, h->stream));
     HIP_TRY(launch_intr_blocks(h->dp, s->sv, h->stream));
   }
-  if ((s->ucross && s->sv.lead) || s->border) {
+  const bool my_priors = s->ucross && (s->sv.lead || h->prior_split);   // motion priors: replicated terms from the lead rank — or, sharded factorisation, every rank its share
+  if (my_priors || s->border) {
     PhaseScope ps(h, RSBA_PHASE_PRIORS);
-    if (s->ucross && s->sv.lead) {   // motion priors: replicated terms, contributed by the lead rank
+    if (my_priors) {
       if (!have_eval) HIP_TRY(launch_prior_cost(h->dp, h->d_cost2, h->prior_invalid, h->stream));
       HIP_TRY(launch_prior_blocks(h->dp, s->sv, s->ucross, h->stream));
     }
@@ -1904,7 +1925,7 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
     const double ratio_step = free_ratio ? ratio_scale * rs.eta : 0.0;      // the ratio's step in its own units is -ratio_step
     ratio_new = free_ratio ? std::max(ratio_lb, ratio - ratio_step) : ratio;
     { PhaseScope ps(h, RSBA_PHASE_BACK_SUBSTITUTE); HIP_TRY(launch_model_cost_change(dp, sv, st)); }
-    if (s->ucross && sv.lead) { PhaseScope ps(h, RSBA_PHASE_PRIORS); HIP_TRY(launch_prior_model(dp, sv, sv.scalars + kModelCostChange, std::isfinite(ratio_step) ? ratio_step : 0.0, st)); }
+    if (s->ucross && (sv.lead || h->prior_split)) { PhaseScope ps(h, RSBA_PHASE_PRIORS); HIP_TRY(launch_prior_model(dp, sv, sv.scalars + kModelCostChange, std::isfinite(ratio_step) ? ratio_step : 0.0, st)); }
     { PhaseScope ps(h, RSBA_PHASE_CANDIDATE); HIP_TRY(launch_candidate(dp, sv, st)); }
     if (dp.pp_count > 0 || dp.pp_spherical >= 0) { PhaseScope ps(h, RSBA_PHASE_PRIORS); HIP_TRY(launch_pose_prior_step(dp, sv, s->pp, radius, st)); }   // every rank: candidate priorPoses values (scalars from the lead rank only)
     // residuals only at the candidate (T = double path)
@@ -1914,7 +1935,7 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
       HIP_TRY(launch_eval(dp, speculate ? kLmJacobian : kResidualOnly, st));
       HIP_TRY(launch_cost_reduce(dp, h->d_cost2, st));
     }
-    if (s->ucross && sv.lead) {
+    if (s->ucross && (sv.lead || h->prior_split)) {
       PhaseScope ps(h, RSBA_PHASE_PRIORS);
       dp.prior_ratio = std::isfinite(ratio_new) ? ratio_new : ratio;
       HIP_TRY(launch_prior_cost(dp, h->d_cost2, h->prior_invalid, st));

@@ -42,6 +42,9 @@ def nd_mode(mode, outdir, rank, world, dist, torch):
     if "intr" in flags:      # shared intrinsics as a parameter block + Huber, as BASELINE config 5 has them: a dense border of the reduced system
         full.calibrated = False; full.huber_a = 2.0
         full.intrinsics = full.intrinsics * (1.0 + 1e-3 * np.array([[1, -1, 20, -20, 10, 10, -10, 0.5, -0.5]]))
+    if "priors" in flags:    # a motion prior between every two consecutive frames (CeresHandler.h:147-185), known interFrameRatio: each rank contributes the priors of its part
+        full.prior_kind, full.prior_scale, full.inter_frame_ratio = 2, 25.0, 1.2
+        full.prior_frames = np.arange(1, full.num_frames, dtype=np.int32)
     if "corrupt" in flags:   # the first persistent-driver solve loses an entry of its result (test hook of the library): every rank must notice through exchange (3)
         os.environ["RSBA_CHOL_TEST_CORRUPT"] = "1"
     owner, ntop = capi.partition_points(full, world)

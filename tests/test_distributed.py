@@ -245,3 +245,14 @@ def test_sharded_factorisation_on_three_ranks(tmp_path):
     weight per rank balances), three parts, two levels of separators — the same trajectory as one GPU."""
     res = run_two_ranks("nd:S300:6", tmp_path, 3)
     check_nd(res, 3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,world", [("nd:C2:8:priors", 2), ("nd:S300:6:priors", 3), ("nd:S300:6:priors:intr", 4)])
+def test_sharded_factorisation_with_motion_priors(tmp_path, mode, world):
+    """A motion prior between every two consecutive frames with a known interFrameRatio (the reference's usual video configuration,
+    CeresHandler.h:147-185).  The prior between frames f and f - 1 goes to the rank whose part holds either frame (rank 0 when both
+    sit in separators), so a part's columns are still complete on its rank; every rank adds its own priors' cost, blocks and model
+    change.  Same trajectory as one GPU, where all priors are on the one rank."""
+    res = run_two_ranks(mode, tmp_path, world)
+    check_nd(res, world)
