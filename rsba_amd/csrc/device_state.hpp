@@ -77,7 +77,8 @@ struct DeviceProblem {
 
 // Trust-region control on the device: the scalars of Ceres' TrustRegionMinimizer loop live in HBM, a single-thread
 // kernel takes its decisions (kernels_normal.hip: lm_decide_*), and the kernels of an iteration look at them instead of waiting for
-// the host: the host enqueues iterations AHEAD and only reads the state back every few of them.
+// the host: the host enqueues iterations AHEAD and reads the state of each from a slot of host memory the last kernel of the iteration
+// writes it to (stamped with the iteration's sequence number: no event, no copy in the stream).
 enum LmCtlSlot : int {
   kCtlRadius = 0, kCtlDecrease = 1,       // trust-region radius, the factor of the next shrink (2, 4, ..)
   kCtlCost = 2, kCtlFixed = 3, kCtlGmax = 4,
@@ -85,6 +86,7 @@ enum LmCtlSlot : int {
   kCtlStatus = 6,                          // 0: running; 1 + termination type: done; -1: the host must take over (a suspect factorisation)
   kCtlIteration = 7, kCtlInvalidStreak = 8, kCtlSuccessful = 9, kCtlUnsuccessful = 10, kCtlFinalCost = 11, kCtlNumTrace = 12,
   kCtlPending = 16,                        // [4] relative decrease, cost change, step norm, model cost change of an accepted step whose record waits for its gradient
+  kCtlSeq = 23,                            // in a snapshot on the host only: the sequence number of the iteration it was taken behind, written last
   kCtlSize = 24
 };
 __device__ __forceinline__ bool lm_stopped(const double* ctl) { return ctl && ctl[kCtlStatus] != 0.0; }

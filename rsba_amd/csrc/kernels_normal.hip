@@ -64,6 +64,13 @@ __device__ __forceinline__ double u_diag(const SolverDev& sv, int64_t t) {
 template <int CD, bool CAL>
 __global__ __launch_bounds__(256) void camera_reduce_kernel(const DeviceProblem dp, const SolverDev sv) {
   if (lm_not_accepted(sv.ctl)) return;   // (device-side trust region: a rejected candidate is not linearised)
+  if ((int)blockIdx.x >= dp.F) {          // workgroups behind the frames' (launch_camera_blocks with take_candidate): lm_take_candidate_kernel's job — this kernel reads no parameters
+    const int64_t t = ((int64_t)blockIdx.x - dp.F) * 256 + threadIdx.x, npose = (int64_t)dp.F * dp.P * 6, npoint = 3 * (int64_t)dp.M, nintr = sv.NPF > 0 ? (int64_t)dp.NI * 9 : 0;
+    if (t < npose) dp.poses[t] = sv.trial_poses[t];
+    else if (t < npose + npoint) dp.points[t - npose] = sv.trial_points[t - npose];
+    else if (t < npose + npoint + nintr) dp.intr[t - npose - npoint] = sv.trial_intr[t - npose - npoint];
+    return;
+  }
   constexpr int NI = CAL ? 0 : 9, NCOL = NI + CD + 1, NCB = (NCOL + 15) / 16, NBLK = NCB * (NCB + 1) / 2;
   __shared__ double G[NBLK][256];
   const int f = blockIdx.x, e = threadIdx.x;
@@ -257,12 +264,21 @@ __global__ void unscaled_gradient_kernel(const DeviceProblem dp, const SolverDev
 // K5a  per point: V' = V + D_p^2 (D^2 = diagonal_/radius), 3x3 Cholesky, L^-1, z = L^-1 g_p
 // (SchurEliminator::Eliminate inverts each e-block)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void point_factor_kernel(const DeviceProblem dp, const SolverDev sv, double inv_radius) {
+// CLAMP: clamp_diagonal_kernel's job done on the way (the loop that runs without the host recomputes the diagonal every iteration —
+// after a rejected step that is what is there already — and saves the launch): the point's own three entries by its thread, the
+// camera side by the first sv.n threads of the grid.
+template <bool CLAMP>
+__global__ __launch_bounds__(256) void point_factor_kernel(const DeviceProblem dp, const SolverDev sv, double inv_radius, double lo, double hi) {
   if (sv.ctl) inv_radius = 1.0 / sv.ctl[kCtlRadius];   // (device-side trust region: the radius lives in HBM)
   const int j = blockIdx.x * 256 + threadIdx.x;
+  if (CLAMP && j < sv.n) sv.diag_c[j] = fmin(fmax(sv.udiag[j], lo), hi);
   if (j >= dp.M) return;
   const double* v = sv.V + (size_t)j * 6;
-  const double* dg = sv.diag_p + (size_t)j * 3;
+  double dg[3];
+  if (CLAMP) {
+    dg[0] = fmin(fmax(v[0], lo), hi); dg[1] = fmin(fmax(v[3], lo), hi); dg[2] = fmin(fmax(v[5], lo), hi);
+    sv.diag_p[(size_t)j * 3] = dg[0]; sv.diag_p[(size_t)j * 3 + 1] = dg[1]; sv.diag_p[(size_t)j * 3 + 2] = dg[2];
+  } else { dg[0] = sv.diag_p[(size_t)j * 3]; dg[1] = sv.diag_p[(size_t)j * 3 + 1]; dg[2] = sv.diag_p[(size_t)j * 3 + 2]; }
   const double a00 = v[0] + dg[0] * inv_radius, a10 = v[1], a20 = v[2], a11 = v[3] + dg[1] * inv_radius, a21 = v[4], a22 = v[5] + dg[2] * inv_radius;
   const double l00 = sqrt(a00), l10 = a10 / l00, l20 = a20 / l00;
   const double d11 = a11 - l10 * l10, l11 = sqrt(d11), l21 = (a21 - l20 * l10) / l11;
@@ -569,8 +585,11 @@ __global__ __launch_bounds__(256) void schur_premerge_kernel(const SolverDev sv)
   }
 }
 
-// one workgroup per tile pair: sum the chunk partials in order, add U / D_c^2 / g_c, identity padding, and
-// store into the packed tile slot (transposed when the tile ordering swapped the pair)
+// kMergeSplit workgroups per tile pair (an element per thread: with few tile pairs — 100 cameras have 140 — a workgroup walking its
+// tile in nine dependent rounds of loads was 25 us of latency): sum the chunk partials in order, add U / D_c^2 / g_c, identity
+// padding, and store into the packed tile slot (transposed when the tile ordering swapped the pair)
+constexpr int kMergeSplit = kTile * kTile / 256;
+static_assert(kMergeSplit * 256 == kTile * kTile, "an element per thread");
 __global__ __launch_bounds__(256) void schur_merge_kernel(const DeviceProblem dp, const SolverDev sv, double inv_radius) {
   if (sv.ctl) inv_radius = 1.0 / sv.ctl[kCtlRadius];
   const int tp = blockIdx.x, tid = threadIdx.x;
@@ -579,7 +598,8 @@ __global__ __launch_bounds__(256) void schur_merge_kernel(const DeviceProblem dp
   double* dst = sv.S + (size_t)sv.tp_dst[tp] * (kTile * kTile);
   const bool trans = sv.tp_trans[tp] != 0;
   const size_t pstride = kTile * kTile + kTile;
-  for (int e = tid; e < kTile * kTile; e += 256) {
+  {
+    const int e = blockIdx.y * 256 + tid;
     const int rt = e / kTile, ct = e % kTile;
     const int x = rt / CD, y = ct / CD, r = rt % CD, c = ct % CD;
     const int a = I * FT + x, b = J * FT + y;
@@ -603,7 +623,7 @@ __global__ __launch_bounds__(256) void schur_merge_kernel(const DeviceProblem dp
     }
     if (trans) dst[(size_t)ct * kTile + rt] = val; else dst[e] = val;
   }
-  if (I == J && tid < kTile) {
+  if (I == J && blockIdx.y == 0 && tid < kTile) {
     const int a = I * FT + tid / CD;
     double ps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int ch = c0;
@@ -983,8 +1003,23 @@ __global__ __launch_bounds__(256) void reduce_sum2_kernel(const double* partial,
   if (threadIdx.x == 0) *(blockIdx.x == 0 ? out0 : out1) = s_red[0] + s_red[1] + s_red[2] + s_red[3];
 }
 
+// reduce_sum_kernel(pa, na, outa, -1) and reduce_sum2_kernel(pb, nb, out0, out1) by one launch of three workgroups
+__global__ __launch_bounds__(256) void reduce_sum3_kernel(const double* pa, int na, double* outa, const double* pb, int nb, double* out0, double* out1) {
+  __shared__ double s_red[4];
+  const double* src = blockIdx.x == 0 ? pa : pb + (size_t)(blockIdx.x - 1) * nb;
+  const int n = blockIdx.x == 0 ? na : nb;
+  double v = 0.0;
+  for (int k = threadIdx.x; k < n; k += 256) v += src[k];
+  v = wsum(v);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  const double sum = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+  if (blockIdx.x == 0) *outa = -1.0 * sum; else *(blockIdx.x == 1 ? out0 : out1) = sum;
+}
+
 // x_plus_delta = x + scale .* step; |x - x_plus_delta|^2 and |x|^2 over the reduced program's blocks
-__global__ __launch_bounds__(256) void candidate_kernel(const DeviceProblem dp, const SolverDev sv) {
+__global__ __launch_bounds__(256) void candidate_kernel(const DeviceProblem dp, const SolverDev sv, double* __restrict__ part) {
   __shared__ double s_red[2][4];
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x, nc = sv.n, np = 3 * (int64_t)dp.M;
   double st = 0.0, xx = 0.0;
@@ -1009,8 +1044,8 @@ __global__ __launch_bounds__(256) void candidate_kernel(const DeviceProblem dp, 
   if ((threadIdx.x & 63) == 0) { s_red[0][threadIdx.x >> 6] = st; s_red[1][threadIdx.x >> 6] = xx; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    sv.partial[blockIdx.x] = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
-    sv.partial[gridDim.x + blockIdx.x] = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
+    part[blockIdx.x] = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+    part[gridDim.x + blockIdx.x] = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
   }
 }
 
@@ -1039,7 +1074,7 @@ __device__ __forceinline__ void lm_push(double* ctl, rsba_iteration* trace, int 
   if (trace && n < cap) trace[n] = it;
   ctl[kCtlNumTrace] = (double)(n + 1);
 }
-__global__ void lm_decide_step_kernel(const SolverDev sv, double* ctl, const LmRules R, rsba_iteration* trace, int cap) {
+__device__ __forceinline__ void lm_decide_step(const SolverDev& sv, double* ctl, const LmRules& R, rsba_iteration* trace, int cap) {
 #pragma clang fp contract(off)   // every product and sum rounded on its own, as the host form's are (1 - (t t) t would become an fma: one ulp of the radius)
   if (ctl[kCtlStatus] != 0.0) return;
   ctl[kCtlAccept] = 0.0;
@@ -1093,8 +1128,9 @@ __global__ void lm_decide_step_kernel(const SolverDev sv, double* ctl, const LmR
   if (radius < R.min_trust_region_radius) ctl[kCtlStatus] = 1.0 + RSBA_CONVERGENCE;
   else if (iteration >= R.max_num_iterations) ctl[kCtlStatus] = 1.0 + RSBA_NO_CONVERGENCE;
 }
+__global__ void lm_decide_step_kernel(const SolverDev sv, double* ctl, const LmRules R, rsba_iteration* trace, int cap) { lm_decide_step(sv, ctl, R, trace, cap); }
 // after the linearisation of an accepted step: its cost, the gradient test, the iteration's record
-__global__ void lm_decide_gradient_kernel(const SolverDev sv, double* ctl, const LmRules R, rsba_iteration* trace, int cap) {
+__device__ __forceinline__ void lm_decide_gradient(const SolverDev& sv, double* ctl, const LmRules& R, rsba_iteration* trace, int cap) {
 #pragma clang fp contract(off)
   if (ctl[kCtlStatus] != 0.0 || ctl[kCtlAccept] == 0.0) return;
   const double* sc = sv.scalars;
@@ -1117,6 +1153,68 @@ __global__ void lm_decide_gradient_kernel(const SolverDev sv, double* ctl, const
   else if (radius < R.min_trust_region_radius) ctl[kCtlStatus] = 1.0 + RSBA_CONVERGENCE;
   else if (it.iteration >= R.max_num_iterations) ctl[kCtlStatus] = 1.0 + RSBA_NO_CONVERGENCE;
 }
+__global__ void lm_decide_gradient_kernel(const SolverDev sv, double* ctl, const LmRules R, rsba_iteration* trace, int cap) { lm_decide_gradient(sv, ctl, R, trace, cap); }
+
+// ---- the same steps in fewer launches (the loop that never waits for the host pays ~4 us per launch of a dependent chain; at 100
+// cameras that was a seventh of the iteration: profiles/r04/iteration_gaps.txt).  Same arithmetic in the same order as the kernels
+// they stand for: the two forms of the trust-region loop still take bit-identical decisions. ----
+// reduce_cost_kernel (kernels_eval.hip) + pack_trial_kernel + lm_decide_step_kernel
+__global__ __launch_bounds__(256) void lm_verdict_step_kernel(const DeviceProblem dp, const SolverDev sv, double* cost2, int n, double* ctl, const LmRules R, rsba_iteration* trace, int cap) {
+  if (ctl[kCtlStatus] != 0.0) return;
+  __shared__ double s_red[3][4];
+  double c = 0.0, f = 0.0, nf = 0.0;
+  for (int k = threadIdx.x; k < n; k += 256) { c += dp.cost_partial[k]; f += dp.fixed_partial[k]; nf += dp.fail_partial[k]; }
+  c = wsum(c); f = wsum(f); nf = wsum(nf);
+  if ((threadIdx.x & 63) == 0) { s_red[0][threadIdx.x >> 6] = c; s_red[1][threadIdx.x >> 6] = f; s_red[2][threadIdx.x >> 6] = nf; }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  const double cost = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3], fixed = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
+  const int fails = (int)(s_red[2][0] + s_red[2][1] + s_red[2][2] + s_red[2][3]);
+  cost2[0] = cost; cost2[1] = fixed; *dp.fail_count = fails;
+  sv.scalars[kCost] = cost + fixed; sv.scalars[kFixedCost] = 0.0; sv.scalars[kEvalFailed] = (double)fails; sv.scalars[kSolveFailed] = (double)*sv.chol_fail;
+  lm_decide_step(sv, ctl, R, trace, cap);
+}
+// local_linearize_kernel + gradient_max_kernel
+__global__ __launch_bounds__(256) void lm_linearize_gradient_kernel(const DeviceProblem dp, const SolverDev sv, const double* cost2) {
+  __shared__ double s_red[4];
+  const int64_t nc = sv.n, np = 3 * (int64_t)dp.M;
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (!lm_not_accepted(sv.ctl)) {
+    if (t < nc) sv.udiag[t] = u_diag(sv, t);
+    if (t == 0) { sv.scalars[kCost] = cost2[0]; sv.scalars[kFixedCost] = cost2[1]; sv.scalars[kEvalFailed] = (double)*dp.fail_count; }
+  }
+  double m = 0.0;
+  if (t < nc + np) {
+    const double sc = (t < nc) ? cam_scale(dp, sv, t) : dp.scale_point[t - nc];
+    const double g = (t < nc) ? sv.gc[t] : sv.gp[t - nc];
+    if (sc > 0.0) m = fabs(g / sc);
+  }
+  m = wmax(m);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) sv.partial[blockIdx.x] = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
+}
+// reduce_max_kernel + lm_decide_gradient_kernel; the state after the iteration goes to the host's slot for it
+__global__ __launch_bounds__(256) void lm_verdict_gradient_kernel(const SolverDev sv, int n, double* ctl, const LmRules R, rsba_iteration* trace, int cap, double* snapshot, double seq) {
+  __shared__ double s_red[4];
+  double v = 0.0;
+  for (int k = threadIdx.x; k < n; k += 256) v = fmax(v, sv.partial[k]);
+  v = wmax(v);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    sv.scalars[kGradMax] = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
+    lm_decide_gradient(sv, ctl, R, trace, cap);
+    *sv.chol_fail = 0; sv.scalars[kDagSuspect] = 0.0;   // begin_solve_kernel's job for the NEXT iteration: both flags were read by this iteration's first verdict
+  }
+  __syncthreads();
+  // the state to the host's slot: a word per lane (stores to host memory one after the other cost a bus round trip each), the stamp behind them
+  if (threadIdx.x < kCtlSeq) __hip_atomic_store(snapshot + threadIdx.x, ctl[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(snapshot + kCtlSeq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // the host polls this word: everything above is there when it shows
+}
+
 // x = x + delta: the candidate the last decision accepted becomes the current point (the host form swaps the two buffers)
 __global__ void lm_take_candidate_kernel(const DeviceProblem dp, const SolverDev sv, int64_t npose, int64_t npoint, int64_t nintr) {
   if (lm_not_accepted(sv.ctl)) return;
@@ -1164,8 +1262,10 @@ inline int nblocks256(int64_t n) { return (int)((n + 255) / 256); }
     if (e_ != hipSuccess) return e_;                               \
   } while (0)
 
-hipError_t launch_camera_blocks(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {
+hipError_t launch_camera_blocks(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st, bool take_candidate) {
   const size_t CD2 = (size_t)sv.CD * sv.CD;
+  const int64_t nparam = (int64_t)dp.F * dp.P * 6 + 3 * (int64_t)dp.M + (sv.NPF > 0 ? 9 * (int64_t)dp.NI : 0);
+  const unsigned grid = (unsigned)dp.F + (take_candidate ? (unsigned)((nparam + 255) / 256) : 0u);   // (launch_lm_take_candidate's copy by extra workgroups of the same launch)
   if (sv.NPF > 0) {   // the padding coordinates of the pseudo frames stay zero
     hipError_t e = hipMemsetAsync(sv.U + (size_t)sv.F * CD2, 0, ((size_t)sv.NPF * sv.F + (size_t)sv.NIB * sv.NPF * sv.NPF) * CD2 * sizeof(double), st);
     if (e != hipSuccess) return e;
@@ -1173,13 +1273,14 @@ hipError_t launch_camera_blocks(const DeviceProblem& dp, const SolverDev& sv, hi
     if (e != hipSuccess) return e;
   }
   if (!dp.cam_part) {   // no observations on this rank: nothing was accumulated
+    if (take_candidate) { hipError_t e = launch_lm_take_candidate(dp, sv, st); if (e != hipSuccess) return e; }
     hipError_t e = hipMemsetAsync(sv.U, 0, (size_t)sv.F * CD2 * sizeof(double), st);
     if (e == hipSuccess) e = hipMemsetAsync(sv.gc, 0, (size_t)sv.F * sv.CD * sizeof(double), st);
     if (e == hipSuccess && sv.NPF > 0) e = hipMemsetAsync(sv.intr_part, 0, (size_t)sv.F * 54 * sizeof(double), st);
     return e;
   }
-  if (sv.CD == 12) { if (dp.calibrated) LAUNCH((camera_reduce_kernel<12, true>), dp.F, 256, st, dp, sv); else LAUNCH((camera_reduce_kernel<12, false>), dp.F, 256, st, dp, sv); }
-  else { if (dp.calibrated) LAUNCH((camera_reduce_kernel<6, true>), dp.F, 256, st, dp, sv); else LAUNCH((camera_reduce_kernel<6, false>), dp.F, 256, st, dp, sv); }
+  if (sv.CD == 12) { if (dp.calibrated) LAUNCH((camera_reduce_kernel<12, true>), grid, 256, st, dp, sv); else LAUNCH((camera_reduce_kernel<12, false>), grid, 256, st, dp, sv); }
+  else { if (dp.calibrated) LAUNCH((camera_reduce_kernel<6, true>), grid, 256, st, dp, sv); else LAUNCH((camera_reduce_kernel<6, false>), grid, 256, st, dp, sv); }
   return hipSuccess;
 }
 hipError_t launch_slot_xy(const DeviceProblem& dp, double2* slot_xy, hipStream_t st) {
@@ -1237,8 +1338,9 @@ hipError_t launch_unscaled_gradient(const DeviceProblem& dp, const SolverDev& sv
   LAUNCH(unscaled_gradient_kernel, nblocks256(sv.n + 3 * (int64_t)dp.M), 256, st, dp, sv, g_pose, g_point);
   return hipSuccess;
 }
-hipError_t launch_point_factor(const DeviceProblem& dp, const SolverDev& sv, double radius, hipStream_t st) {
-  LAUNCH(point_factor_kernel, nblocks256(dp.M), 256, st, dp, sv, 1.0 / radius);
+hipError_t launch_point_factor(const DeviceProblem& dp, const SolverDev& sv, double radius, hipStream_t st, const double* clamp) {
+  if (clamp) LAUNCH(point_factor_kernel<true>, nblocks256(std::max<int64_t>(dp.M, sv.n)), 256, st, dp, sv, 1.0 / radius, clamp[0], clamp[1]);
+  else LAUNCH(point_factor_kernel<false>, nblocks256(dp.M), 256, st, dp, sv, 1.0 / radius, 0.0, 0.0);
   return hipSuccess;
 }
 template <int CD, int KC>
@@ -1308,7 +1410,7 @@ hipError_t launch_schur_blocks(const DeviceProblem& dp, const SolverDev& sv, dou
     { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; }
   }
   if (sv.npremerge > 0) LAUNCH(schur_premerge_kernel, sv.npremerge, 256, st, sv);
-  LAUNCH(schur_merge_kernel, sv.ntp, 256, st, dp, sv, 1.0 / radius);
+  LAUNCH(schur_merge_kernel, dim3(sv.ntp, kMergeSplit), 256, st, dp, sv, 1.0 / radius);
   return hipSuccess;
 }
 static int point_step_blocks(const DeviceProblem& dp, const SolverDev& sv) { return sv.slot_xy ? (int)((dp.M + 4 * kSweepPoints - 1) / (4 * kSweepPoints)) : (int)((dp.M + 255) / 256); }
@@ -1348,6 +1450,18 @@ hipError_t launch_merge_points(const DeviceProblem& dp, const double* buf, hipSt
   LAUNCH(merge_points_kernel, nblocks256(dp.M), 256, st, dp, buf);
   return hipSuccess;
 }
+hipError_t launch_lm_verdict_step(const DeviceProblem& dp, const SolverDev& sv, double* cost2, double* ctl, const LmRules& rules, rsba_iteration* trace, int trace_cap, hipStream_t st) {
+  LAUNCH(lm_verdict_step_kernel, 1, 256, st, dp, sv, cost2, eval_num_blocks(dp.N), ctl, rules, trace, trace_cap);
+  return hipSuccess;
+}
+hipError_t launch_lm_linearize_gradient(const DeviceProblem& dp, const SolverDev& sv, const double* cost2, hipStream_t st) {
+  LAUNCH(lm_linearize_gradient_kernel, nblocks256(sv.n + 3 * (int64_t)dp.M), 256, st, dp, sv, cost2);
+  return hipSuccess;
+}
+hipError_t launch_lm_verdict_gradient(const DeviceProblem& dp, const SolverDev& sv, double* ctl, const LmRules& rules, rsba_iteration* trace, int trace_cap, double* snapshot, double seq, hipStream_t st) {
+  LAUNCH(lm_verdict_gradient_kernel, 1, 256, st, sv, nblocks256(sv.n + 3 * (int64_t)dp.M), ctl, rules, trace, trace_cap, snapshot, seq);
+  return hipSuccess;
+}
 hipError_t launch_lm_decide_step(const SolverDev& sv, double* ctl, const LmRules& rules, rsba_iteration* trace, int trace_cap, hipStream_t st) {
   LAUNCH(lm_decide_step_kernel, 1, 1, st, sv, ctl, rules, trace, trace_cap);
   return hipSuccess;
@@ -1363,8 +1477,14 @@ hipError_t launch_lm_take_candidate(const DeviceProblem& dp, const SolverDev& sv
 }
 hipError_t launch_candidate(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {
   const int nb = nblocks256(sv.n + 3 * (int64_t)dp.M);
-  LAUNCH(candidate_kernel, nb, 256, st, dp, sv);
+  LAUNCH(candidate_kernel, nb, 256, st, dp, sv, sv.partial);
   LAUNCH(reduce_sum2_kernel, 2, 256, st, sv.partial, nb, sv.scalars + kStepSq, sv.scalars + kXSq);   // (one launch: workgroup 0 -> |step|^2, workgroup 1 -> |x|^2)
+  return hipSuccess;
+}
+hipError_t launch_candidate_and_model_cost(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {
+  const int nb = nblocks256(sv.n + 3 * (int64_t)dp.M);
+  LAUNCH(candidate_kernel, nb, 256, st, dp, sv, sv.partial_c);   // (its sums beside the back-substitution's, which are still waiting in sv.partial)
+  LAUNCH(reduce_sum3_kernel, 3, 256, st, sv.partial, dp.M > 0 ? point_step_blocks(dp, sv) : 0, sv.scalars + kModelCostChange, sv.partial_c, nb, sv.scalars + kStepSq, sv.scalars + kXSq);
   return hipSuccess;
 }
 

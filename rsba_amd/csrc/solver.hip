@@ -99,6 +99,10 @@ struct Solver {
   int64_t schur_launches = 0;                                         // launches of the Schur kernel since the plan was built (statistics)
   double* d_ctl = nullptr;                                            // trust-region state on the device (device_state.hpp: LmCtlSlot; all zero while the host decides)
   rsba_iteration* d_trace_it = nullptr; int trace_it_cap = 0;         // the iteration records the deciding kernels write
+  static constexpr int kCtlRing = 4;                                  // snapshots of d_ctl in flight (one per enqueued iteration): pinned host memory + the event behind each copy
+  bool clamp_with_factor = false; double clamp_lo_hi[2] = {0.0, 0.0};   // device-side trust region: the diagonal's clamp rides in the point factor's launch
+  double* h_ctl = nullptr; double* h_ctl_dev = nullptr;   // (h_ctl_dev: the same memory as the deciding kernel addresses it)
+  double ctl_seq = 0.0;                                   // stamp of the last snapshot asked for (never repeats within a handle: a stale slot cannot be mistaken for a new one)
   // Sharded factorisation (several ranks whose points respect the cut of tile_order.hpp): this rank factors the columns
   // of ITS part of the elimination tree from its own partial S (launch A), the ranks all-reduce the separators' tiles less what
   // their parts subtract from them, every rank factors the separators and solves them backward, then its own part (launch B).
@@ -1084,6 +1088,7 @@ int32_t build_solver_impl(rsba_handle* h) {
   if ((rc = s_alloc(s, &sv.trial_points, (size_t)M * 3))) return rc;
   const size_t nb = std::max<size_t>((N + 255) / 256, ((size_t)sv.n + 3 * (size_t)M + 255) / 256);
   if ((rc = s_alloc(s, &sv.partial, 2 * std::max(nb, ((size_t)M + 63) / 64 + 1) + 2))) return rc;   // (the point sweeps leave one partial per 64 points)
+  if ((rc = s_alloc(s, &sv.partial_c, 2 * (((size_t)sv.n + 3 * (size_t)M + 255) / 256) + 2))) return rc;
   if ((rc = s_alloc(s, &sv.scalars, 16))) return rc;
   if ((rc = s_alloc(s, &s->d_ctl, kCtlSize))) return rc;
   HIP_TRY(hipMemset(s->d_ctl, 0, kCtlSize * sizeof(double)));
@@ -1306,7 +1311,7 @@ int32_t gradient_max(rsba_handle* h) {
 // reduced camera system S and rhs at the given trust-region radius (point elimination), summed over the ranks
 int32_t reduce_system(rsba_handle* h, double radius) {
   Solver* s = h->solver; const SolverDev& sv = s->sv; hipStream_t st = h->stream;
-  { PhaseScope ps(h, RSBA_PHASE_POINT_FACTOR); HIP_TRY(launch_point_factor(h->dp, sv, radius, st)); }
+  { PhaseScope ps(h, RSBA_PHASE_POINT_FACTOR); HIP_TRY(launch_point_factor(h->dp, sv, radius, st, s->clamp_with_factor ? s->clamp_lo_hi : nullptr)); }
   {
     PhaseScope ps(h, RSBA_PHASE_PROJECT);
     HIP_TRY(launch_project(h->dp, sv, st));
@@ -1478,6 +1483,7 @@ void rsba_destroy_solver(rsba_handle* h) {
   for (hipEvent_t e : {h->solver->ev_armed[0], h->solver->ev_armed[1], h->solver->ev_released}) if (e) (void)hipEventDestroy(e);
   if (h->solver->ev_solved) (void)hipEventDestroy(h->solver->ev_solved);
   if (h->solver->ev_verified) (void)hipEventDestroy(h->solver->ev_verified);
+  if (h->solver->h_ctl) (void)hipHostFree(h->solver->h_ctl);
   if (const char* path = h->solver->sv.schur_trace ? std::getenv("RSBA_SCHUR_TRACE") : nullptr) {   // debugging aid: stamps of the last Schur launch
     std::vector<long long> tr(8 * (size_t)h->solver->sv.nchunk);
     if (hipMemcpy(tr.data(), h->solver->sv.schur_trace, tr.size() * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess)
@@ -1842,9 +1848,9 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
   // The loop body below, decisions included, as a sequence of launches that never waits for the host: radius, accept / reject and the
   // convergence tests live in HBM (s->d_ctl), two single-thread kernels take the decisions by the same rules in the same order, the
   // kernels of an iteration read the radius there and skip themselves where the host form would not have launched them (a rejected
-  // candidate is not linearised; iterations enqueued AHEAD of a termination fall through).  The host reads the state back every
-  // `ahead` iterations.  What the reference calls per frame — windowedBA over ~100 cameras (VideoSfMClient.cc:241-246) — is bound
-  // by launch and sync latency here, not by the kernels: with the queue kept full the small kernels run back to back.
+  // candidate is not linearised).  What the reference calls per frame — windowedBA over ~100 cameras (VideoSfMClient.cc:241-246) —
+  // is where this counts: an iteration there is 0.5 ms, and the host form's 22 dependent launches, two read-backs and their gaps were
+  // 0.09 ms of it.  Here an iteration is 14 launches on this stream (the small steps share launches: kernels_normal.hip) and no wait.
   // Calibrated single-GPU problems without priors; everything else — and a suspect factorisation — goes through the host form.
   bool device_ctl = speculate && !h->allreduce && !free_ratio && !s->ucross && dp.pp_count == 0 && dp.pp_spherical < 0 && sv.NPF == 0 && !s->use_levels &&
                     !s->timer.on && opt->max_num_iterations > 0 && dp.N > 0;
@@ -1854,48 +1860,78 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
     if (cap > s->trace_it_cap) { if ((rc = s_alloc(s, &s->d_trace_it, (size_t)cap))) return rc; s->trace_it_cap = cap; }
     const LmRules R{opt->max_num_iterations, opt->max_num_consecutive_invalid_steps, opt->max_trust_region_radius, opt->min_trust_region_radius, opt->min_relative_decrease,
                     opt->function_tolerance, opt->gradient_tolerance, opt->parameter_tolerance};
-    double hc[kCtlSize] = {};
-    hc[kCtlRadius] = radius; hc[kCtlDecrease] = decrease_factor; hc[kCtlCost] = cost; hc[kCtlFixed] = fixed; hc[kCtlGmax] = gmax; hc[kCtlFinalCost] = sum->final_cost;
-    HIP_TRY(hipMemcpyAsync(s->d_ctl, hc, sizeof hc, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));   // (hc is a local)
+    if (!s->h_ctl) {
+      HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_ctl), (size_t)(Solver::kCtlRing + 1) * kCtlSize * sizeof(double), hipHostMallocDefault));
+      HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&s->h_ctl_dev), s->h_ctl, 0));
+      std::fill(s->h_ctl, s->h_ctl + (size_t)(Solver::kCtlRing + 1) * kCtlSize, 0.0);
+    }
+    double* const hc0 = s->h_ctl + (size_t)Solver::kCtlRing * kCtlSize;   // the initial state (pinned: the upload does not wait for the host)
+    std::fill(hc0, hc0 + kCtlSize, 0.0);
+    hc0[kCtlRadius] = radius; hc0[kCtlDecrease] = decrease_factor; hc0[kCtlCost] = cost; hc0[kCtlFixed] = fixed; hc0[kCtlGmax] = gmax; hc0[kCtlFinalCost] = sum->final_cost;
+    HIP_TRY(hipMemcpyAsync(s->d_ctl, hc0, kCtlSize * sizeof(double), hipMemcpyHostToDevice, st));
     struct CtlGuard {   // whichever way this block is left, the host form finds the state it expects: nobody skips, the radius comes by value
       rsba_handle* h; Solver* s;
-      ~CtlGuard() { s->sv.ctl = nullptr; h->dp.ctl = nullptr; (void)hipMemsetAsync(s->d_ctl, 0, kCtlSize * sizeof(double), h->stream); }
+      ~CtlGuard() { (void)hipStreamSynchronize(h->stream); s->sv.ctl = nullptr; h->dp.ctl = nullptr; s->clamp_with_factor = false; (void)hipMemsetAsync(s->d_ctl, 0, kCtlSize * sizeof(double), h->stream); }
     } ctl_guard{h, s};
     sv.ctl = s->d_ctl; dp.ctl = s->d_ctl;
-    int ahead = 2;
-    if (const char* e = std::getenv("RSBA_LM_AHEAD")) ahead = std::max(1, std::atoi(e));
-    std::vector<rsba_iteration> recs((size_t)cap);
-    int enqueued = 0, seen = 0;
+    s->clamp_with_factor = true; s->clamp_lo_hi[0] = opt->min_lm_diagonal; s->clamp_lo_hi[1] = opt->max_lm_diagonal;
+    HIP_TRY(launch_begin_solve(sv, st));   // (from here on the last kernel of an iteration clears the two flags for the next)
+    // The last kernel of an iteration writes the state to a slot of pinned host memory and stamps it; the host polls the stamp (no
+    // event, no copy in the stream) and enqueues the next iteration the moment it shows.  RSBA_LM_AHEAD = k keeps k iterations
+    // enqueued beyond the one whose outcome the host has seen (those behind a termination fall through: every kernel looks at the
+    // status word); measured at 100 and 1 000 cameras the queue does not need it — 0.492 / 0.498 / 0.500 ms per iteration for
+    // k = 0 / 1 / 2 (profiles/r04/iteration_gaps.txt) — so the default enqueues nothing that might not be wanted.
+    int ahead = 0;
+    if (const char* e = std::getenv("RSBA_LM_AHEAD")) ahead = std::min(Solver::kCtlRing - 2, std::max(0, std::atoi(e)));   // (a slot is written again only after the host has moved on from it)
+    const double* hc = hc0;
+    int enqueued = 0, looked = 0;
+    bool stopped = false;
     t0 = now_s();
-    for (;;) {
-      const int batch = std::max(1, std::min(ahead, opt->max_num_iterations - enqueued));
-      for (int b = 0; b < batch; ++b, ++enqueued) {
-        HIP_TRY(launch_clamp_diagonal(dp, sv, opt->min_lm_diagonal, opt->max_lm_diagonal, st));   // (after a rejected step this recomputes what is there: same linearisation)
-        HIP_TRY(launch_begin_solve(sv, st));
-        if ((rc = factor_and_solve(h, 1.0))) return rc;   // (the radius argument is ignored: the kernels read ctl)
-        HIP_TRY(launch_model_cost_change(dp, sv, st));
-        HIP_TRY(launch_candidate(dp, sv, st));
-        swap_params();
-        HIP_TRY(launch_eval(dp, kLmJacobian, st));
-        HIP_TRY(launch_cost_reduce(dp, h->d_cost2, st));
-        swap_params();
-        if ((rc = await_verification(h))) return rc;
-        HIP_TRY(launch_pack_trial(dp, sv, h->d_cost2, st));
-        HIP_TRY(launch_lm_decide_step(sv, s->d_ctl, R, s->d_trace_it, cap, st));
-        HIP_TRY(launch_lm_take_candidate(dp, sv, st));
-        if ((rc = linearize(h, true))) return rc;
-        if ((rc = gradient_max(h))) return rc;
-        HIP_TRY(launch_lm_decide_gradient(sv, s->d_ctl, R, s->d_trace_it, cap, st));
+    const double seq0 = s->ctl_seq;
+    auto look = [&]() -> int32_t {   // the state behind iteration `looked`: wait for its stamp (the deciding kernel writes it last)
+      const double* slot = s->h_ctl + (size_t)(looked % Solver::kCtlRing) * kCtlSize;
+      const double want = seq0 + (double)(looked + 1);
+      for (unsigned spins = 0;; ++spins) {
+        if (__atomic_load_n(reinterpret_cast<const uint64_t*>(slot + kCtlSeq), __ATOMIC_ACQUIRE) == *reinterpret_cast<const uint64_t*>(&want)) break;
+        if ((spins & 0xFFFu) == 0xFFFu) {   // now and then: is the stream still alive?  (an idle stream whose stamp never came is an error, not a wait)
+          const hipError_t q = hipStreamQuery(st);
+          if (q == hipSuccess) { if (__atomic_load_n(reinterpret_cast<const uint64_t*>(slot + kCtlSeq), __ATOMIC_ACQUIRE) == *reinterpret_cast<const uint64_t*>(&want)) break; return rsba_set_error(RSBA_ERR_HIP, "the trust-region state of an iteration never reached the host"); }
+          if (q != hipErrorNotReady) return rsba_set_error(RSBA_ERR_HIP, hipGetErrorString(q));
+        }
+        __builtin_ia32_pause();
       }
-      HIP_TRY(hipMemcpyAsync(hc, s->d_ctl, sizeof hc, hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipStreamSynchronize(st));
+      hc = slot;
+      ++looked;
+      stopped = hc[kCtlStatus] != 0.0;
+      return RSBA_OK;
+    };
+    while (!stopped && enqueued < opt->max_num_iterations) {
+      // (fourteen launches on this stream; the steps the host form spreads over twenty-two, in its order: kernels_normal.hip, "the same steps in
+      // fewer launches".  The diagonal's clamp rides in the point factor's launch — after a rejected step it recomputes what is there.)
+      if ((rc = factor_and_solve(h, 1.0))) return rc;   // (the radius argument is ignored: the kernels read ctl)
+      HIP_TRY(launch_candidate_and_model_cost(dp, sv, st));
+      swap_params();
+      HIP_TRY(launch_eval(dp, kLmJacobian, st));
+      swap_params();
+      if ((rc = await_verification(h))) return rc;
+      HIP_TRY(launch_lm_verdict_step(dp, sv, h->d_cost2, s->d_ctl, R, s->d_trace_it, cap, st));
+      HIP_TRY(launch_camera_blocks(dp, sv, st, /*take_candidate=*/true));
+      HIP_TRY(launch_intr_blocks(dp, sv, st));
+      HIP_TRY(launch_point_blocks(dp, sv, st));
+      HIP_TRY(launch_lm_linearize_gradient(dp, sv, h->d_cost2, st));
+      s->ctl_seq += 1.0;
+      HIP_TRY(launch_lm_verdict_gradient(dp, sv, s->d_ctl, R, s->d_trace_it, cap, s->h_ctl_dev + (size_t)(enqueued % Solver::kCtlRing) * kCtlSize, s->ctl_seq, st));
+      ++enqueued;
+      if (enqueued - looked > ahead) { if ((rc = look())) return rc; }
+    }
+    while (!stopped && looked < enqueued) { if ((rc = look())) return rc; }
+    // (iterations enqueued behind the termination fall through; the stream is drained below, before anything of the loop is read or torn down)
+    {
       const int have = std::min((int)hc[kCtlNumTrace], cap);
-      if (have > seen) {
-        HIP_TRY(hipMemcpy(recs.data() + seen, s->d_trace_it + seen, (size_t)(have - seen) * sizeof(rsba_iteration), hipMemcpyDeviceToHost));
-        for (; seen < have; ++seen) push(recs[(size_t)seen]);
-      }
-      if (hc[kCtlStatus] != 0.0) break;
+      std::vector<rsba_iteration> recs((size_t)std::max(have, 1));
+      if (have > 0) HIP_TRY(hipMemcpyAsync(recs.data(), s->d_trace_it, (size_t)have * sizeof(rsba_iteration), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      for (int k = 0; k < have; ++k) push(recs[(size_t)k]);
     }
     sum->linear_solver_time_s += now_s() - t0;
     radius = hc[kCtlRadius]; decrease_factor = hc[kCtlDecrease]; cost = hc[kCtlCost]; gmax = hc[kCtlGmax];

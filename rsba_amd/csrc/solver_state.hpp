@@ -110,6 +110,7 @@ struct SolverDev {
   const double* inprog_pose;    // [F*CD] 1 if the coordinate's block is part of the reduced program
   const double* inprog_point;   // [M*3]
   double* partial;              // scratch for block partial sums
+  double* partial_c;            // the candidate's two sums when they are reduced together with the model cost change (device-side trust region)
   double* scalars;              // [16] results of reductions (see ScalarSlot)
   int* chol_fail;               // set when a pivot is not positive / not finite
 };
@@ -166,13 +167,13 @@ hipError_t launch_chol_solve_level(const SolverDev& sv, const CholPlan& pl, bool
 hipError_t launch_chol_dag(const SolverDev& sv, const CholPlan& pl, const DagArgs* device_args, int workgroups, bool one_per_cu, hipStream_t st);   // one_per_cu: LDS request above half a CU's, so that two never share one
 
 // kernels_normal.hip
-hipError_t launch_camera_blocks(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);
+hipError_t launch_camera_blocks(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st, bool take_candidate = false);   // take_candidate: launch_lm_take_candidate's copy rides along
 hipError_t launch_point_blocks(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);
 hipError_t launch_slot_xy(const DeviceProblem& dp, double2* slot_xy, hipStream_t st);   // slot_xy[obs_slot[i]] = xy[i]
 hipError_t launch_jacobi_scale(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);           // scale = mask / (1 + sqrt(diag))
 hipError_t launch_clamp_diagonal(const DeviceProblem& dp, const SolverDev& sv, double lo, double hi, hipStream_t st);
 hipError_t launch_gradient_max(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);           // -> scalars[kGradMax]
-hipError_t launch_point_factor(const DeviceProblem& dp, const SolverDev& sv, double radius, hipStream_t st);
+hipError_t launch_point_factor(const DeviceProblem& dp, const SolverDev& sv, double radius, hipStream_t st, const double* clamp = nullptr);   // clamp = {lo, hi}: launch_clamp_diagonal's job rides along
 hipError_t launch_project(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);
 hipError_t launch_clear_system(const SolverDev& sv, hipStream_t st);   // S = 0 (fill tiles start from zero)
 hipError_t launch_schur_blocks(const DeviceProblem& dp, const SolverDev& sv, double radius, hipStream_t st);
@@ -190,6 +191,11 @@ struct LmRules { int32_t max_num_iterations, max_num_consecutive_invalid_steps; 
 hipError_t launch_lm_decide_step(const SolverDev& sv, double* ctl, const LmRules& rules, rsba_iteration* trace, int trace_cap, hipStream_t st);
 hipError_t launch_lm_decide_gradient(const SolverDev& sv, double* ctl, const LmRules& rules, rsba_iteration* trace, int trace_cap, hipStream_t st);
 hipError_t launch_lm_take_candidate(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);   // x = x + delta where ctl says "accepted"
+// the same steps in fewer launches, for the loop that runs without the host (solver.hip: device-side trust region) — same arithmetic, same order:
+hipError_t launch_candidate_and_model_cost(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);   // launch_model_cost_change + launch_candidate: the three sums by one launch
+hipError_t launch_lm_verdict_step(const DeviceProblem& dp, const SolverDev& sv, double* cost2, double* ctl, const LmRules& rules, rsba_iteration* trace, int trace_cap, hipStream_t st);   // launch_cost_reduce + launch_pack_trial + launch_lm_decide_step
+hipError_t launch_lm_linearize_gradient(const DeviceProblem& dp, const SolverDev& sv, const double* cost2, hipStream_t st);   // launch_local_linearize + the per-workgroup maxima of launch_gradient_max
+hipError_t launch_lm_verdict_gradient(const DeviceProblem& dp, const SolverDev& sv, double* ctl, const LmRules& rules, rsba_iteration* trace, int trace_cap, double* snapshot, double seq, hipStream_t st);   // the maxima reduced + launch_lm_decide_gradient; ctl copied to `snapshot` (device-visible host memory), stamped `seq` last
 // motion priors (kernels_prior.hip): U_f, g_f += their J^T J / J^T r, ucross[f] = the (f, f-1) block; model cost change
 hipError_t launch_prior_blocks(const DeviceProblem& dp, const SolverDev& sv, double* ucross, hipStream_t st);
 hipError_t launch_prior_model(const DeviceProblem& dp, const SolverDev& sv, double* model_cost_change, double ratio_step, hipStream_t st);
