@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <chrono>
 #include <cstring>
 #include <numeric>
 #include <mutex>
@@ -147,7 +148,7 @@ int32_t rsba_create(const rsba_problem_desc* d, int32_t device, rsba_handle** ou
   h->device = device;
   h->desc = *d;
   auto bail = [&](int32_t code) { rsba_destroy(h); return code; };
-  if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) { delete h; return fail(RSBA_ERR_HIP, "hipStreamCreate"); }
+  if (rsba::dev_stream_acquire(&h->own_stream) != hipSuccess) { delete h; return fail(RSBA_ERR_HIP, "hipStreamCreate"); }
   h->stream = h->own_stream;
 
   // frame-major order: the order CeresHandler::Add produces is already frame-major
@@ -217,7 +218,7 @@ int32_t rsba_create(const rsba_problem_desc* d, int32_t device, rsba_handle** ou
   if ((rc = dev_alloc(h, &dp.fail_count, 1))) return bail(rc);
   if ((rc = dev_alloc(h, &h->d_cost2, 2))) return bail(rc);
   if (hipMemset(dp.fail_count, 0, sizeof(int)) != hipSuccess) return bail(fail(RSBA_ERR_HIP, "hipMemset"));
-  if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) return bail(fail(RSBA_ERR_HIP, "hipEventCreate"));
+  if (rsba::dev_event_acquire(&h->ev0, true) != hipSuccess || rsba::dev_event_acquire(&h->ev1, true) != hipSuccess) return bail(fail(RSBA_ERR_HIP, "hipEventCreate"));
   *out = h;
   return RSBA_OK;
 }
@@ -225,14 +226,21 @@ int32_t rsba_create(const rsba_problem_desc* d, int32_t device, rsba_handle** ou
 void rsba_destroy(rsba_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
+  const bool dbg = std::getenv("RSBA_DEBUG_PLAN") != nullptr;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = dbg ? now() : 0.0;
   rsba_destroy_solver(h);
+  const double t1 = dbg ? now() : 0.0;
   if (h->stream) (void)hipStreamSynchronize(h->stream);   // nothing on the device touches the blocks any more: they go back to the cache (devmem.hpp)
   if (h->own_stream && h->own_stream != h->stream) (void)hipStreamSynchronize(h->own_stream);
   for (void* p : h->allocs) rsba::dev_free(p);
-  if (h->ev0) (void)hipEventDestroy(h->ev0);
-  if (h->ev1) (void)hipEventDestroy(h->ev1);
-  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  const double t2 = dbg ? now() : 0.0;
+  rsba::dev_event_release(h->ev0, true);      // (both streams are idle: synchronised above)
+  rsba::dev_event_release(h->ev1, true);
+  if (h->own_stream) { (void)hipStreamSynchronize(h->own_stream); rsba::dev_stream_release(h->own_stream); }
+  const double t3 = dbg ? now() : 0.0;
   delete h;
+  if (dbg) std::fprintf(stderr, "[rsba destroy] handle: plan %.2f ms; blocks to the cache %.2f ms; events + stream to the pool %.2f ms; host state %.2f ms\n", t1 - t0, t2 - t1, t3 - t2, now() - t3);
 }
 
 int32_t rsba_set_stream(rsba_handle* h, void* s) {

@@ -4,6 +4,7 @@
 #include <map>
 #include <mutex>
 #include <unordered_map>
+#include <vector>
 
 namespace rsba {
 
@@ -16,7 +17,11 @@ struct Cache {
   std::map<int, std::multimap<size_t, void*>> free_blocks;   // per device, by size
   size_t cached_bytes = 0, cap_bytes = 0;
   bool cap_read = false;
+  std::map<int, std::vector<hipStream_t>> streams;           // idle, per device
+  std::map<int, std::vector<hipEvent_t>> events[2];          // [timing]
+  std::map<int, std::vector<void*>> pinned;                  // 4 KB blocks
 };
+constexpr size_t kMaxStreams = 16, kMaxEvents = 64, kMaxPinned = 8, kPinnedBytes = 4096;
 Cache& cache() { static Cache* c = new Cache(); return *c; }   // (never destroyed: handles may outlive static destructors)
 
 // sizes in steps of 1/8 octave above 64 KB (a problem a frame longer than the last one still finds its blocks), 256 B below
@@ -83,10 +88,14 @@ void dev_free(void* p) {
 void dev_release_cache() {
   Cache& c = cache();
   std::map<int, std::multimap<size_t, void*>> take;
+  std::map<int, std::vector<hipStream_t>> streams;
+  std::map<int, std::vector<hipEvent_t>> events[2];
+  std::map<int, std::vector<void*>> pinned;
   {
     std::lock_guard<std::mutex> lk(c.m);
     take.swap(c.free_blocks);
     c.cached_bytes = 0;
+    streams.swap(c.streams); events[0].swap(c.events[0]); events[1].swap(c.events[1]); pinned.swap(c.pinned);
   }
   int cur = 0;
   const bool have = hipGetDevice(&cur) == hipSuccess;
@@ -95,7 +104,81 @@ void dev_release_cache() {
     (void)hipSetDevice(d.first);
     for (auto& kv : d.second) (void)hipFree(kv.second);
   }
+  for (auto& d : streams) { (void)hipSetDevice(d.first); for (hipStream_t s : d.second) (void)hipStreamDestroy(s); }
+  for (auto& ev : events) for (auto& d : ev) { (void)hipSetDevice(d.first); for (hipEvent_t e : d.second) (void)hipEventDestroy(e); }
+  for (auto& d : pinned) { (void)hipSetDevice(d.first); for (void* p : d.second) (void)hipHostFree(p); }
   if (have) (void)hipSetDevice(cur);
+}
+
+hipError_t dev_stream_acquire(hipStream_t* s) {
+  Cache& c = cache();
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  {
+    std::lock_guard<std::mutex> lk(c.m);
+    auto& v = c.streams[dev];
+    if (!v.empty()) { *s = v.back(); v.pop_back(); return hipSuccess; }
+  }
+  return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
+void dev_stream_release(hipStream_t s) {
+  if (!s) return;
+  Cache& c = cache();
+  int dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    std::lock_guard<std::mutex> lk(c.m);
+    auto& v = c.streams[dev];
+    if (v.size() < kMaxStreams) { v.push_back(s); return; }
+  }
+  (void)hipStreamDestroy(s);
+}
+hipError_t dev_event_acquire(hipEvent_t* ev, bool timing) {
+  Cache& c = cache();
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  {
+    std::lock_guard<std::mutex> lk(c.m);
+    auto& v = c.events[timing ? 1 : 0][dev];
+    if (!v.empty()) { *ev = v.back(); v.pop_back(); return hipSuccess; }
+  }
+  return timing ? hipEventCreate(ev) : hipEventCreateWithFlags(ev, hipEventDisableTiming);
+}
+void dev_event_release(hipEvent_t ev, bool timing) {
+  if (!ev) return;
+  Cache& c = cache();
+  int dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    std::lock_guard<std::mutex> lk(c.m);
+    auto& v = c.events[timing ? 1 : 0][dev];
+    if (v.size() < kMaxEvents) { v.push_back(ev); return; }
+  }
+  (void)hipEventDestroy(ev);
+}
+hipError_t dev_pinned_acquire(void** p, size_t bytes) {
+  if (bytes > kPinnedBytes) return hipErrorInvalidValue;
+  Cache& c = cache();
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  {
+    std::lock_guard<std::mutex> lk(c.m);
+    auto& v = c.pinned[dev];
+    if (!v.empty()) { *p = v.back(); v.pop_back(); return hipSuccess; }
+  }
+  return hipHostMalloc(p, kPinnedBytes, hipHostMallocDefault);
+}
+void dev_pinned_release(void* p) {
+  if (!p) return;
+  Cache& c = cache();
+  int dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    std::lock_guard<std::mutex> lk(c.m);
+    auto& v = c.pinned[dev];
+    if (v.size() < kMaxPinned) { v.push_back(p); return; }
+  }
+  (void)hipHostFree(p);
 }
 
 }  // namespace rsba

@@ -13,6 +13,16 @@ namespace rsba {
 
 hipError_t dev_malloc(void** p, size_t bytes);
 void dev_free(void* p);
-void dev_release_cache();   // hipFree every cached block (all devices)
+void dev_release_cache();   // hipFree every cached block, destroy every pooled stream / event / pinned block (all devices)
+
+// The same for the streams, events and the small pinned block a handle and its plan need (three streams and seven events per handle of
+// a window: creating and destroying them was 1.0 of the 1.1 ms of rsba_destroy and ~0.4 ms of rsba_create + plan).  Streams are
+// hipStreamNonBlocking; a stream or event goes back only when its owner has synchronised it.  Events: with / without timing.
+hipError_t dev_stream_acquire(hipStream_t* s);
+void dev_stream_release(hipStream_t s);
+hipError_t dev_event_acquire(hipEvent_t* e, bool timing);
+void dev_event_release(hipEvent_t e, bool timing);
+hipError_t dev_pinned_acquire(void** p, size_t bytes);   // hipHostMalloc'd, device-visible; bytes <= 4096 (one size class)
+void dev_pinned_release(void* p);
 
 }  // namespace rsba

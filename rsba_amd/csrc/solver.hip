@@ -352,9 +352,11 @@ int32_t build_solver_impl(rsba_handle* h) {
   std::vector<int32_t>& slot_gpos = scr.slot_gpos; slot_gpos.resize((size_t)NS);           // group * FT + position of every slot: where its P record goes
   std::vector<uint8_t>& group_mask = scr.group_mask;        // which of the three 16-row blocks of a group's records can be non-zero
   std::vector<uint8_t>& group_present = scr.group_present;  // frames of the group's tile that see the point (plan statistics)
-  // host threads of the passes over points / entries: worth their start-up (16 threads cost ~1 ms on a busy 256-thread host) from a
-  // few hundred thousand observations on; a 100-camera window (187 k) plans faster on one (RSBA_PLAN_THREADS overrides: A/B)
-  int plan_threads = N >= 400000 ? (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency())) : 1;
+  // host threads of the passes over points / entries: sixteen are worth their start-up (~1 ms on a busy 256-thread host) from a few
+  // hundred thousand observations on; a 100-camera window (187 k) plans fastest on four — symbolic phase 4.1 / 3.9 / 2.8 / 3.4 ms on
+  // 1 / 2 / 4 / 8 threads (RSBA_PLAN_THREADS overrides: A/B)
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  int plan_threads = N >= 400000 ? (int)std::min(16u, hw) : N >= 50000 ? (int)std::min(4u, hw) : 1;
   if (const char* e = std::getenv("RSBA_PLAN_THREADS")) plan_threads = std::max(1, std::min(64, std::atoi(e)));
   const int nthr_pts = M >= 4096 ? plan_threads : 1;
   {
@@ -957,9 +959,9 @@ int32_t build_solver_impl(rsba_handle* h) {
       if ((rc = s_alloc(s, &s->cells[b], s->ncells))) return rc;
       HIP_TRY(hipMemsetAsync(s->cells[b], 0xFF, s->ncells * sizeof(double), h->stream));   // both sets start out armed
     }
-    HIP_TRY(hipStreamCreateWithFlags(&s->mstream, hipStreamNonBlocking));
-    for (int b = 0; b < 2; ++b) HIP_TRY(hipEventCreateWithFlags(&s->ev_armed[b], hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&s->ev_released, hipEventDisableTiming));
+    HIP_TRY(dev_stream_acquire(&s->mstream));
+    for (int b = 0; b < 2; ++b) HIP_TRY(dev_event_acquire(&s->ev_armed[b], false));
+    HIP_TRY(dev_event_acquire(&s->ev_released, false));
     double* cells = s->cells[0];
     sv.Lf = cells; sv.chol_part = cells + nLf; sv.Winv = sv.chol_part + nPart; sv.zv = sv.Winv + nW; sv.yv = sv.zv + sv.npad; sv.Xpub = sv.zv + nZ;
   }
@@ -1153,9 +1155,9 @@ int32_t build_solver_impl(rsba_handle* h) {
     }
     if ((rc = s_alloc(s, &s->d_verify, 2 * (size_t)sv.npad))) return rc;
     if ((rc = s_alloc(s, &s->verify_b, (size_t)sv.npad))) return rc;
-    HIP_TRY(hipStreamCreateWithFlags(&s->vstream, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&s->ev_solved, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&s->ev_verified, hipEventDisableTiming));
+    HIP_TRY(dev_stream_acquire(&s->vstream));
+    HIP_TRY(dev_event_acquire(&s->ev_solved, false));
+    HIP_TRY(dev_event_acquire(&s->ev_verified, false));
     HIP_TRY(hipMemset(s->d_verify, 0, 2 * (size_t)sv.npad * sizeof(double)));   // the check kernel leaves it zero again
     { const char* v = std::getenv("RSBA_CHOL_VERIFY"); s->verify_dag = !(v && v[0] == '0'); }
     { const char* v = std::getenv("RSBA_CHOL_TEST_CORRUPT"); s->test_corrupt_once = v && v[0] == '1'; }
@@ -1478,20 +1480,26 @@ void rsba_release_plan_scratch() {
 
 void rsba_destroy_solver(rsba_handle* h) {
   if (!h || !h->solver) return;
-  if (h->solver->vstream) { (void)hipStreamSynchronize(h->solver->vstream); (void)hipStreamDestroy(h->solver->vstream); }
-  if (h->solver->mstream) { (void)hipStreamSynchronize(h->solver->mstream); (void)hipStreamDestroy(h->solver->mstream); }
-  for (hipEvent_t e : {h->solver->ev_armed[0], h->solver->ev_armed[1], h->solver->ev_released}) if (e) (void)hipEventDestroy(e);
-  if (h->solver->ev_solved) (void)hipEventDestroy(h->solver->ev_solved);
-  if (h->solver->ev_verified) (void)hipEventDestroy(h->solver->ev_verified);
-  if (h->solver->h_ctl) (void)hipHostFree(h->solver->h_ctl);
+  const bool dbg = std::getenv("RSBA_DEBUG_PLAN") != nullptr;
+  const double td0 = dbg ? now_s() : 0.0;
+  // streams, events and the pinned block go back to the pool (devmem.hpp): idle first — the main stream too, whose last waits name these events
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->solver->vstream) { (void)hipStreamSynchronize(h->solver->vstream); dev_stream_release(h->solver->vstream); }
+  if (h->solver->mstream) { (void)hipStreamSynchronize(h->solver->mstream); dev_stream_release(h->solver->mstream); }
+  for (hipEvent_t e : {h->solver->ev_armed[0], h->solver->ev_armed[1], h->solver->ev_released, h->solver->ev_solved, h->solver->ev_verified}) dev_event_release(e, false);
+  dev_pinned_release(h->solver->h_ctl);
   if (const char* path = h->solver->sv.schur_trace ? std::getenv("RSBA_SCHUR_TRACE") : nullptr) {   // debugging aid: stamps of the last Schur launch
     std::vector<long long> tr(8 * (size_t)h->solver->sv.nchunk);
     if (hipMemcpy(tr.data(), h->solver->sv.schur_trace, tr.size() * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess)
       if (FILE* f = std::fopen(path, "wb")) { std::fwrite(tr.data(), sizeof(long long), tr.size(), f); std::fclose(f); }
   }
+  const double td1 = dbg ? now_s() : 0.0;
   if (h->stream) (void)hipStreamSynchronize(h->stream);   // (the side streams above are idle too: the blocks go back to the cache, devmem.hpp)
+  const double td2 = dbg ? now_s() : 0.0;
   for (void* p : h->solver->allocs) dev_free(p);
+  const double td3 = dbg ? now_s() : 0.0;
   delete h->solver;
+  if (dbg) std::fprintf(stderr, "[rsba destroy] plan: streams + events to the pool %.2f ms; stream sync %.2f ms; blocks to the cache %.2f ms; host state %.2f ms\n", 1e3 * (td1 - td0), 1e3 * (td2 - td1), 1e3 * (td3 - td2), 1e3 * (now_s() - td3));
   h->solver = nullptr;
   h->dp.rec = nullptr; h->dp.obs_slot = nullptr; h->dp.cam_part = nullptr; h->dp.wave_seg_base = nullptr; h->dp.frame_rank = nullptr;
 }
@@ -1861,7 +1869,8 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
     const LmRules R{opt->max_num_iterations, opt->max_num_consecutive_invalid_steps, opt->max_trust_region_radius, opt->min_trust_region_radius, opt->min_relative_decrease,
                     opt->function_tolerance, opt->gradient_tolerance, opt->parameter_tolerance};
     if (!s->h_ctl) {
-      HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_ctl), (size_t)(Solver::kCtlRing + 1) * kCtlSize * sizeof(double), hipHostMallocDefault));
+      static_assert((size_t)(Solver::kCtlRing + 1) * kCtlSize * sizeof(double) <= 4096, "one pooled pinned block");
+      HIP_TRY(dev_pinned_acquire(reinterpret_cast<void**>(&s->h_ctl), (size_t)(Solver::kCtlRing + 1) * kCtlSize * sizeof(double)));
       HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&s->h_ctl_dev), s->h_ctl, 0));
       std::fill(s->h_ctl, s->h_ctl + (size_t)(Solver::kCtlRing + 1) * kCtlSize, 0.0);
     }

@@ -462,6 +462,14 @@ def test_device_blocks_are_cached_between_handles_and_given_back(capi):
     assert max(levels[1:]) - levels[0] <= 4 << 20           # ... the next handles live in them
     capi.release_host_scratch()
     assert in_use() - base <= 8 << 20                        # ... and they go back on request
+    # streams, events and the loop's pinned block are pooled the same way (they were 1.0 of the 1.1 ms of a destroy): a handle
+    # built from the pool, after the pool was given back, and two handles alive at once (each its own streams) solve alike
+    p = small_scene(frames=24, points=1500, seed=9)
+    q = small_scene(frames=24, points=1500, seed=9)
+    with capi.DeviceProblem(p) as dp, capi.DeviceProblem(q) as dq:
+        s, _ = dp.solve(capi.default_options(max_num_iterations=6))
+        t, _ = dq.solve(capi.default_options(max_num_iterations=6))
+    assert s.final_cost == t.final_cost == results[0][0] and np.array_equal(p.poses, results[0][1]) and np.array_equal(q.points, results[0][2])
 
 
 @pytest.mark.parametrize("case", ["c2", "rejections", "failure", "tolerances", "max_iterations", "huber"])
