@@ -357,10 +357,11 @@ int32_t rsba_sync_block_structure(rsba_handle* h);
  * HIP-event time of those of that solve, measured on the solver's stream around each collective. */
 enum {
   RSBA_EXCHANGE_SETUP = 0,      /* co-visibility structure, problem-size counts, the form of the plan (once per handle / solve) */
-  RSBA_EXCHANGE_CAMERA = 1,     /* (1) per-camera gradient blocks g_c | diag(U) | cost scalars, once per linearisation */
+  RSBA_EXCHANGE_CAMERA = 1,     /* (1) per-camera gradient blocks g_c | diag(U) | cost scalars | every rank's max |g_i| over its points, once per linearisation */
   RSBA_EXCHANGE_SYSTEM = 2,     /* (2) the reduced camera system: every structurally non-zero tile | rhs (replicated factorisation) or the
                                  *     separators' tiles | their rhs rows between the two launches of a sharded factorisation */
-  RSBA_EXCHANGE_SCALARS = 3,    /* (3) step scalars (two calls) and the gradient max-norm, once per iteration */
+  RSBA_EXCHANGE_SCALARS = 3,    /* (3) step scalars and the verification flag: one sum of 12 doubles per iteration (the gradient max-norm rides in (1);
+                                 *     with per-pose priors it still takes a MAX all-reduce of its own) */
   RSBA_EXCHANGE_STEP = 4,       /* (4) the gather of the camera step (sharded factorisation only) */
   RSBA_EXCHANGE_POINTS = 5,     /* the merge of the solved points at the end of a solve */
   RSBA_NUM_EXCHANGES = 6

@@ -229,12 +229,14 @@ __global__ void clamp_diagonal_kernel(const DeviceProblem dp, const SolverDev sv
 }
 
 // max |g_i| of the UNSCALED gradient (Ceres evaluates the gradient before ScaleColumns): g = g_scaled / scale
-__global__ __launch_bounds__(256) void gradient_max_kernel(const DeviceProblem dp, const SolverDev sv) {
+// part: 0 = every coordinate, 1 = the points' only, 2 = the cameras' only (several ranks: a rank's own points before the camera exchange —
+// their maximum travels in it —, the cameras' from the summed gradient behind it)
+__global__ __launch_bounds__(256) void gradient_max_kernel(const DeviceProblem dp, const SolverDev sv, int part) {
   __shared__ double s_red[4];
   double m = 0.0;
   const int64_t nc = sv.n, np = 3 * (int64_t)dp.M;
-  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (t < nc + np) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x + (part == 1 ? nc : 0);
+  if (t < (part == 2 ? nc : nc + np)) {
     const double sc = (t < nc) ? cam_scale(dp, sv, t) : dp.scale_point[t - nc];
     const double g = (t < nc) ? sv.gc[t] : sv.gp[t - nc];
     if (sc > 0.0) m = fabs(g / sc);
@@ -244,10 +246,12 @@ __global__ __launch_bounds__(256) void gradient_max_kernel(const DeviceProblem d
   __syncthreads();
   if (threadIdx.x == 0) sv.partial[blockIdx.x] = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
 }
-__global__ __launch_bounds__(256) void reduce_max_kernel(const double* partial, int n, double* out) {
+// (+ `nextra` more values at `extra`: the other ranks' maxima that came with the camera exchange)
+__global__ __launch_bounds__(256) void reduce_max_kernel(const double* partial, int n, double* out, const double* extra = nullptr, int nextra = 0) {
   __shared__ double s_red[4];
   double v = 0.0;
   for (int k = threadIdx.x; k < n; k += 256) v = fmax(v, partial[k]);
+  for (int k = threadIdx.x; k < nextra; k += 256) v = fmax(v, extra[k]);
   v = wmax(v);
   if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
   __syncthreads();
@@ -1224,8 +1228,9 @@ __global__ void lm_take_candidate_kernel(const DeviceProblem dp, const SolverDev
   else if (t < npose + npoint + nintr) dp.intr[t - npose - npoint] = sv.trial_intr[t - npose - npoint];
 }
 
-__global__ void pack_linearize_kernel(const DeviceProblem dp, const SolverDev sv, const double* cost2) {
+__global__ void pack_linearize_kernel(const DeviceProblem dp, const SolverDev sv, const double* cost2, int nslots) {
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t < nslots) sv.xbuf[2 * sv.n + 3 + t] = 0.0;   // the ranks' gradient maxima (launch_gradient_max_points fills this rank's)
   if (t < sv.n) {
     sv.xbuf[t] = sv.gc[t];
     sv.xbuf[sv.n + t] = u_diag(sv, t);
@@ -1249,6 +1254,7 @@ __global__ void pack_trial_kernel(const DeviceProblem dp, const SolverDev sv, co
   sv.scalars[kFixedCost] = 0.0;
   sv.scalars[kEvalFailed] = (double)*dp.fail_count;
   sv.scalars[kSolveFailed] = (double)*sv.chol_fail;
+  if (!sv.lead) sv.scalars[kGradMax] = 0.0;   // several ranks: slots 0 - 11 travel in ONE sum; the maximum (the same on every rank) comes back as the lead rank's
 }
 
 inline int nblocks256(int64_t n) { return (int)((n + 255) / 256); }
@@ -1309,12 +1315,27 @@ hipError_t launch_clamp_diagonal(const DeviceProblem& dp, const SolverDev& sv, d
 }
 hipError_t launch_gradient_max(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {
   const int nb = nblocks256(sv.n + 3 * (int64_t)dp.M);
-  LAUNCH(gradient_max_kernel, nb, 256, st, dp, sv);
-  LAUNCH(reduce_max_kernel, 1, 256, st, sv.partial, nb, sv.scalars + kGradMax);
+  LAUNCH(gradient_max_kernel, nb, 256, st, dp, sv, 0);
+  LAUNCH(reduce_max_kernel, 1, 256, st, sv.partial, nb, sv.scalars + kGradMax, nullptr, 0);
   return hipSuccess;
 }
-hipError_t launch_pack_linearize(const DeviceProblem& dp, const SolverDev& sv, const double* cost2, hipStream_t st) {
-  LAUNCH(pack_linearize_kernel, nblocks256(sv.n), 256, st, dp, sv, cost2);
+// several ranks: max |g| over this rank's own points -> its slot behind the camera exchange's payload (xbuf[2n + 3 + rank]; the other
+// ranks' slots are zeroed by launch_pack_linearize, which runs first: a SUM all-reduce then carries every rank's maximum) ...
+hipError_t launch_gradient_max_points(const DeviceProblem& dp, const SolverDev& sv, int rank, hipStream_t st) {
+  const int nb = std::max(1, nblocks256(3 * (int64_t)dp.M));
+  LAUNCH(gradient_max_kernel, nb, 256, st, dp, sv, 1);
+  LAUNCH(reduce_max_kernel, 1, 256, st, sv.partial, nb, sv.xbuf + 2 * sv.n + 3 + rank, nullptr, 0);
+  return hipSuccess;
+}
+// ... and behind the exchange: the cameras' maximum from the summed gradient, with the ranks' point maxima -> scalars[kGradMax]
+hipError_t launch_gradient_max_cameras(const DeviceProblem& dp, const SolverDev& sv, int world, hipStream_t st) {
+  const int nb = std::max(1, nblocks256(sv.n));
+  LAUNCH(gradient_max_kernel, nb, 256, st, dp, sv, 2);
+  LAUNCH(reduce_max_kernel, 1, 256, st, sv.partial, nb, sv.scalars + kGradMax, sv.xbuf + 2 * sv.n + 3, world);
+  return hipSuccess;
+}
+hipError_t launch_pack_linearize(const DeviceProblem& dp, const SolverDev& sv, const double* cost2, hipStream_t st, int nslots) {
+  LAUNCH(pack_linearize_kernel, nblocks256(std::max<int64_t>(sv.n, nslots)), 256, st, dp, sv, cost2, nslots);
   return hipSuccess;
 }
 __global__ void begin_solve_kernel(const SolverDev sv) { *sv.chol_fail = 0; sv.scalars[kDagSuspect] = 0.0; }

@@ -102,6 +102,7 @@ struct Solver {
   static constexpr int kCtlRing = 4;                                  // snapshots of d_ctl in flight (one per enqueued iteration): pinned host memory + the event behind each copy
   bool clamp_with_factor = false; double clamp_lo_hi[2] = {0.0, 0.0};   // device-side trust region: the diagonal's clamp rides in the point factor's launch
   double* h_ctl = nullptr; double* h_ctl_dev = nullptr;   // (h_ctl_dev: the same memory as the deciding kernel addresses it)
+  bool gradmax_done = false;                              // the last linearisation's camera exchange carried max |g_i| (several ranks): gradient_max() has nothing left to do
   double ctl_seq = 0.0;                                   // stamp of the last snapshot asked for (never repeats within a handle: a stale slot cannot be mistaken for a new one)
   // Sharded factorisation (several ranks whose points respect the cut of tile_order.hpp): this rank factors the columns
   // of ITS part of the elimination tree from its own partial S (launch A), the ranks all-reduce the separators' tiles less what
@@ -1084,7 +1085,7 @@ int32_t build_solver_impl(rsba_handle* h) {
   sv.rhs = sv.S + (size_t)sv.nslots * kTile * kTile;   // one buffer = exchange payload (2)
   HIP_TRY(hipMemsetAsync(sv.S, 0, ((size_t)sv.nslots * kTile * kTile + (size_t)sv.npad) * sizeof(double), h->stream));   // fill-only tiles stay zero for good
   if ((rc = s_alloc(s, &sv.udiag, (size_t)F * CD))) return rc;
-  if ((rc = s_alloc(s, &sv.xbuf, 2 * (size_t)F * CD + 3))) return rc;
+  if ((rc = s_alloc(s, &sv.xbuf, 2 * (size_t)F * CD + 3 + kMaxRankSlots))) return rc;   // (+ the ranks' gradient maxima)
   if ((rc = s_alloc(s, &sv.yp, (size_t)M * 3))) return rc;
   if ((rc = s_alloc(s, &sv.trial_poses, (size_t)FR * CD))) return rc;
   if ((rc = s_alloc(s, &sv.trial_points, (size_t)M * 3))) return rc;
@@ -1263,7 +1264,7 @@ int32_t exchange(rsba_handle* h, double* buf, int64_t count, int op, int kind) {
 // scalars[kCost, kFixedCost, kEvalFailed].
 // have_eval: the LM-mode evaluation at these parameters (per-wave camera blocks, cost incl. the prior blocks' in d_cost2) has just
 // been run — the trust-region loop evaluates its candidates that way when nothing would be lost by it (see rsba_solve).
-int32_t linearize(rsba_handle* h, bool have_eval = false) {
+int32_t linearize(rsba_handle* h, bool have_eval = false, bool want_gradmax = false) {
   Solver* s = h->solver;
   if (!have_eval) {
     PhaseScope ps(h, RSBA_PHASE_EVAL_LM);
@@ -1294,16 +1295,25 @@ int32_t linearize(rsba_handle* h, bool have_eval = false) {
     HIP_TRY(launch_point_blocks(h->dp, s->sv, h->stream));
   }
   PhaseScope ps(h, RSBA_PHASE_EXCHANGE);
+  s->gradmax_done = false;
   if (!h->allreduce) { HIP_TRY(launch_local_linearize(h->dp, s->sv, h->d_cost2, h->stream)); return RSBA_OK; }   // one rank: nothing to sum
-  HIP_TRY(launch_pack_linearize(h->dp, s->sv, h->d_cost2, h->stream));
-  int32_t rc = exchange(h, s->sv.xbuf, 2 * s->sv.n + 3, 0, RSBA_EXCHANGE_CAMERA);
+  // max |g_i| (the gradient test that follows an accepted step) rides in this exchange instead of taking a MAX all-reduce of its own —
+  // every collective is tens of microseconds of latency on a node: each rank's maximum over ITS points (they are nobody else's) in a
+  // slot of its own behind the payload, the other ranks' slots zero, so the SUM delivers all of them; the cameras' maximum is taken
+  // from the summed gradient behind the exchange.  (Not with per-pose priors: their blocks' maximum is the lead rank's alone.)
+  const bool ride = want_gradmax && h->world <= kMaxRankSlots && h->dp.pp_count == 0 && h->dp.pp_spherical < 0;
+  HIP_TRY(launch_pack_linearize(h->dp, s->sv, h->d_cost2, h->stream, ride ? h->world : 0));
+  if (ride) HIP_TRY(launch_gradient_max_points(h->dp, s->sv, h->rank, h->stream));
+  int32_t rc = exchange(h, s->sv.xbuf, 2 * s->sv.n + 3 + (ride ? h->world : 0), 0, RSBA_EXCHANGE_CAMERA);
   if (rc) return rc;
   HIP_TRY(launch_unpack_linearize(h->dp, s->sv, h->stream));
+  if (ride) { HIP_TRY(launch_gradient_max_cameras(h->dp, s->sv, h->world, h->stream)); s->gradmax_done = true; }
   return RSBA_OK;
 }
 
 int32_t gradient_max(rsba_handle* h) {
   Solver* s = h->solver;
+  if (s->gradmax_done) { s->gradmax_done = false; return RSBA_OK; }   // (came with the camera exchange of the linearisation just before)
   PhaseScope ps(h, RSBA_PHASE_OTHER);
   HIP_TRY(launch_gradient_max(h->dp, s->sv, h->stream));
   if (s->sv.lead) HIP_TRY(launch_pose_prior_gradmax(h->dp, s->sv, s->pp, h->stream));
@@ -1815,7 +1825,7 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
   // ---- iteration 0: initial evaluation ----
   double t0 = now_s();
   if ((rc = reset_scales(h))) return rc;
-  if ((rc = linearize(h))) return rc;
+  if ((rc = linearize(h, false, true))) return rc;
   if ((rc = gradient_max(h))) return rc;
   if ((rc = read_back())) return rc;
   sum->residual_jacobian_time_s += now_s() - t0;
@@ -1993,8 +2003,7 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
       PhaseScope ps(h, RSBA_PHASE_EXCHANGE);
       if ((rc = await_verification(h))) return rc;   // (its flag rides in the scalars below)
       HIP_TRY(launch_pack_trial(dp, sv, h->d_cost2, st));
-      if ((rc = exchange(h, sv.scalars, 3, 0, RSBA_EXCHANGE_SCALARS))) return rc;
-      if ((rc = exchange(h, sv.scalars + kCost, 8, 0, RSBA_EXCHANGE_SCALARS))) return rc;   // ... and the verification flag of the Cholesky driver: every rank decides alike
+      if ((rc = exchange(h, sv.scalars, 12, 0, RSBA_EXCHANGE_SCALARS))) return rc;   // one sum: ... and the verification flag of the Cholesky driver (every rank decides alike); slot kGradMax comes back as it was (pack_trial: the lead rank's copy, zeros from the others)
     }
     if ((rc = read_back())) return rc;
     if (host_sc[kDagSuspect] != 0.0 && !s->use_levels) {
@@ -2036,7 +2045,7 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
         if (free_ratio) { ratio = ratio_new; dp.prior_ratio = ratio; }
         if (sv.NPF > 0) HIP_TRY(hipMemcpyAsync(sv.trial_intr, dp.intr, 9 * (size_t)dp.NI * sizeof(double), hipMemcpyDeviceToDevice, st));   // constant coordinates stay in sync
         t0 = now_s();
-        if ((rc = linearize(h, speculate))) return rc;
+        if ((rc = linearize(h, speculate, true))) return rc;
         if ((rc = gradient_max(h))) return rc;
         if ((rc = read_back())) return rc;
         sum->residual_jacobian_time_s += now_s() - t0;

@@ -17,6 +17,7 @@
 namespace rsba {
 
 constexpr int kSchurChunk = 512;   // entries per workgroup of the Schur kernel (its four waves take every fourth)
+constexpr int kMaxRankSlots = 64;   // per-rank slots behind the camera exchange's payload (more ranks than this: the gradient maximum takes its own all-reduce)
 constexpr int kTile = 48;   // Cholesky tile: 4 rolling-shutter frames (12 unknowns) or 8 global-shutter frames
 
 // Intrinsics as parameter blocks (opt.model.calibrated == false: the shared sess.cam and / or per-frame f.cam blocks,
@@ -206,7 +207,9 @@ hipError_t launch_border_dots(const double* b, const double* u, const double* v,
 hipError_t launch_border_combine(double* y, const double* u, const double* v, double c, int64_t n, hipStream_t st);
 hipError_t launch_intr_blocks(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);
 hipError_t launch_virtual_records(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);
-hipError_t launch_pack_linearize(const DeviceProblem& dp, const SolverDev& sv, const double* cost2, hipStream_t st);
+hipError_t launch_pack_linearize(const DeviceProblem& dp, const SolverDev& sv, const double* cost2, hipStream_t st, int nslots = 0);   // nslots: zeroed slots behind the payload (the ranks' gradient maxima)
+hipError_t launch_gradient_max_points(const DeviceProblem& dp, const SolverDev& sv, int rank, hipStream_t st);     // -> xbuf[2n + 3 + rank]
+hipError_t launch_gradient_max_cameras(const DeviceProblem& dp, const SolverDev& sv, int world, hipStream_t st);  // -> scalars[kGradMax], with the ranks' slots
 hipError_t launch_unpack_linearize(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);
 hipError_t launch_begin_solve(const SolverDev& sv, hipStream_t st);   // the two failure flags of a linear solve cleared in one launch
 hipError_t launch_local_linearize(const DeviceProblem& dp, const SolverDev& sv, const double* cost2, hipStream_t st);   // pack + unpack of a single rank in one launch
