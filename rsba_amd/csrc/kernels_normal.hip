@@ -1163,8 +1163,16 @@ __global__ void lm_decide_gradient_kernel(const SolverDev sv, double* ctl, const
 // cameras that was a seventh of the iteration: profiles/r04/iteration_gaps.txt).  Same arithmetic in the same order as the kernels
 // they stand for: the two forms of the trust-region loop still take bit-identical decisions. ----
 // reduce_cost_kernel (kernels_eval.hip) + pack_trial_kernel + lm_decide_step_kernel
+// (n < 0: the cost was reduced already — and the motion priors' added to it — by kernels of their own)
 __global__ __launch_bounds__(256) void lm_verdict_step_kernel(const DeviceProblem dp, const SolverDev sv, double* cost2, int n, double* ctl, const LmRules R, rsba_iteration* trace, int cap) {
   if (ctl[kCtlStatus] != 0.0) return;
+  if (n < 0) {
+    if (threadIdx.x == 0) {
+      sv.scalars[kCost] = cost2[0] + cost2[1]; sv.scalars[kFixedCost] = 0.0; sv.scalars[kEvalFailed] = (double)*dp.fail_count; sv.scalars[kSolveFailed] = (double)*sv.chol_fail;
+      lm_decide_step(sv, ctl, R, trace, cap);
+    }
+    return;
+  }
   __shared__ double s_red[3][4];
   double c = 0.0, f = 0.0, nf = 0.0;
   for (int k = threadIdx.x; k < n; k += 256) { c += dp.cost_partial[k]; f += dp.fixed_partial[k]; nf += dp.fail_partial[k]; }
@@ -1471,8 +1479,8 @@ hipError_t launch_merge_points(const DeviceProblem& dp, const double* buf, hipSt
   LAUNCH(merge_points_kernel, nblocks256(dp.M), 256, st, dp, buf);
   return hipSuccess;
 }
-hipError_t launch_lm_verdict_step(const DeviceProblem& dp, const SolverDev& sv, double* cost2, double* ctl, const LmRules& rules, rsba_iteration* trace, int trace_cap, hipStream_t st) {
-  LAUNCH(lm_verdict_step_kernel, 1, 256, st, dp, sv, cost2, eval_num_blocks(dp.N), ctl, rules, trace, trace_cap);
+hipError_t launch_lm_verdict_step(const DeviceProblem& dp, const SolverDev& sv, double* cost2, double* ctl, const LmRules& rules, rsba_iteration* trace, int trace_cap, hipStream_t st, bool cost_reduced) {
+  LAUNCH(lm_verdict_step_kernel, 1, 256, st, dp, sv, cost2, cost_reduced ? -1 : eval_num_blocks(dp.N), ctl, rules, trace, trace_cap);
   return hipSuccess;
 }
 hipError_t launch_lm_linearize_gradient(const DeviceProblem& dp, const SolverDev& sv, const double* cost2, hipStream_t st) {

@@ -86,6 +86,7 @@ __device__ __forceinline__ void prior_ratio_column(const DeviceProblem& dp, int 
 
 // U_f, g_f and the (f, f-1) cross block: one thread per frame
 __global__ __launch_bounds__(64) void prior_blocks_kernel(const DeviceProblem dp, const SolverDev sv, double* __restrict__ ucross) {
+  if (lm_not_accepted(sv.ctl)) return;   // (device-side trust region: a rejected candidate is not linearised)
   const int f = blockIdx.x * 64 + threadIdx.x;
   if (f >= dp.F) return;
   const bool heads = dp.prior_of[f] != 0, referred = dp.prior_of[f + 1] != 0;
@@ -141,6 +142,7 @@ __device__ __forceinline__ bool last_wave_of_grid(const DeviceProblem& dp) {
 // cost of the prior blocks at dp.poses, added to {cost, fixed cost}; a block whose four poses are all constant (and whose
 // ratio block is constant too) is not part of the reduced program and its cost is "fixed" (Ceres: Program::RemoveFixedBlocks)
 __global__ __launch_bounds__(64) void prior_cost_kernel(const DeviceProblem dp, double* cost2, int invalid) {
+  if (lm_stopped(dp.ctl)) return;        // (device-side trust region: iterations behind a termination fall through — every wave alike: the ticket stays armed)
   const int f = blockIdx.x * 64 + threadIdx.x;
   double c = 0.0, cf = 0.0;
   if (f < dp.F && dp.prior_of[f]) {
@@ -162,6 +164,7 @@ __global__ __launch_bounds__(64) void prior_cost_kernel(const DeviceProblem dp, 
 
 // model cost change of the prior blocks for the camera step in sv.step:  -sum m.(r~ + m/2),  m = -J~ y
 __global__ __launch_bounds__(64) void prior_model_kernel(const DeviceProblem dp, const SolverDev sv, double* out, double ratio_step) {
+  if (lm_stopped(dp.ctl)) return;
   const int f = blockIdx.x * 64 + threadIdx.x;
   double acc = 0.0;
   if (f < dp.F && dp.prior_of[f]) {

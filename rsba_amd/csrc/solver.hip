@@ -1869,8 +1869,9 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
   // candidate is not linearised).  What the reference calls per frame — windowedBA over ~100 cameras (VideoSfMClient.cc:241-246) —
   // is where this counts: an iteration there is 0.5 ms, and the host form's 22 dependent launches, two read-backs and their gaps were
   // 0.09 ms of it.  Here an iteration is 14 launches on this stream (the small steps share launches: kernels_normal.hip) and no wait.
-  // Calibrated single-GPU problems without priors; everything else — and a suspect factorisation — goes through the host form.
-  bool device_ctl = speculate && !h->allreduce && !free_ratio && !s->ucross && dp.pp_count == 0 && dp.pp_spherical < 0 && sv.NPF == 0 && !s->use_levels &&
+  // Calibrated single-GPU problems, with or without motion priors of a known interFrameRatio; everything else (a free ratio, per-pose
+  // priors, an intrinsics block, several ranks) — and a suspect factorisation — goes through the host form.
+  bool device_ctl = speculate && !h->allreduce && !free_ratio && dp.pp_count == 0 && dp.pp_spherical < 0 && sv.NPF == 0 && !s->use_levels &&
                     !s->timer.on && opt->max_num_iterations > 0 && dp.N > 0;
   if (const char* e = std::getenv("RSBA_DEVICE_LM")) device_ctl = device_ctl && e[0] != '0';   // A/B switch: 0 = the host decides
   if (device_ctl) {
@@ -1929,12 +1930,18 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
       // fewer launches".  The diagonal's clamp rides in the point factor's launch — after a rejected step it recomputes what is there.)
       if ((rc = factor_and_solve(h, 1.0))) return rc;   // (the radius argument is ignored: the kernels read ctl)
       HIP_TRY(launch_candidate_and_model_cost(dp, sv, st));
+      if (s->ucross) HIP_TRY(launch_prior_model(dp, sv, sv.scalars + kModelCostChange, 0.0, st));   // motion priors (known interFrameRatio): their share of the model cost change ...
       swap_params();
       HIP_TRY(launch_eval(dp, kLmJacobian, st));
+      if (s->ucross) {                                                                                 // ... their cost at the candidate, behind the observations' ...
+        HIP_TRY(launch_cost_reduce(dp, h->d_cost2, st));
+        HIP_TRY(launch_prior_cost(dp, h->d_cost2, h->prior_invalid, st));
+      }
       swap_params();
       if ((rc = await_verification(h))) return rc;
-      HIP_TRY(launch_lm_verdict_step(dp, sv, h->d_cost2, s->d_ctl, R, s->d_trace_it, cap, st));
+      HIP_TRY(launch_lm_verdict_step(dp, sv, h->d_cost2, s->d_ctl, R, s->d_trace_it, cap, st, /*cost_reduced=*/s->ucross != nullptr));
       HIP_TRY(launch_camera_blocks(dp, sv, st, /*take_candidate=*/true));
+      if (s->ucross) HIP_TRY(launch_prior_blocks(dp, sv, s->ucross, st));                              // ... and their blocks of an accepted step's linearisation
       HIP_TRY(launch_intr_blocks(dp, sv, st));
       HIP_TRY(launch_point_blocks(dp, sv, st));
       HIP_TRY(launch_lm_linearize_gradient(dp, sv, h->d_cost2, st));

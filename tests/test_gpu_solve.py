@@ -472,7 +472,7 @@ def test_device_blocks_are_cached_between_handles_and_given_back(capi):
     assert s.final_cost == t.final_cost == results[0][0] and np.array_equal(p.poses, results[0][1]) and np.array_equal(q.points, results[0][2])
 
 
-@pytest.mark.parametrize("case", ["c2", "rejections", "failure", "tolerances", "max_iterations", "huber"])
+@pytest.mark.parametrize("case", ["c2", "rejections", "failure", "tolerances", "max_iterations", "huber", "priors", "priors_rejections", "c2_priors"])
 def test_device_side_trust_region_equals_the_host_form(capi, monkeypatch, case):
     """accept / reject, the radius update and the convergence tests of the LM loop run in a single-thread kernel, the
     iteration's kernels read the radius from HBM and skip themselves where the host form would not have launched them, the host
@@ -481,20 +481,29 @@ def test_device_side_trust_region_equals_the_host_form(capi, monkeypatch, case):
     (rejected steps, termination by each tolerance, by the iteration limit), and whatever the look-ahead."""
     from rsba_amd.scene import make_config
     def problem():
-        if case == "c2":
-            return make_config("C2").problem, dict(max_num_iterations=12)
+        if case in ("c2", "c2_priors"):
+            p = make_config("C2").problem
+            if case == "c2_priors":
+                p.prior_kind, p.prior_scale, p.inter_frame_ratio = 2, 25.0, 1.2
+                p.prior_frames = np.arange(1, p.num_frames, dtype=np.int32)
+            return p, dict(max_num_iterations=12)
         p = small_scene(frames=24, points=1500, seed=13, outlier_ratio=0.1 if case == "huber" else 0.0)
         if case == "huber":
             p.huber_a = 1.5
             return p, dict(max_num_iterations=25)
-        if case in ("rejections", "failure"):      # a start far from the minimum and a huge first radius: Gauss-Newton steps that overshoot (or never recover)
+        if case.startswith("priors"):                # motion priors with a known interFrameRatio (CeresHandler.h:147-185): their cost, blocks and model change are part of every decision
+            p.prior_kind, p.prior_scale, p.inter_frame_ratio = 1, 1.0 if case == "priors_rejections" else 10.0, 0.8
+            p.prior_frames = np.arange(1, p.num_frames, dtype=np.int32)
+        if case in ("rejections", "failure", "priors_rejections"):      # a start far from the minimum and a huge first radius: Gauss-Newton steps that overshoot (or never recover)
             rng = np.random.default_rng(2)
-            sc = 2.0 if case == "rejections" else 3.0
+            sc = 3.0 if case == "failure" else 2.0
             p.points += rng.normal(0, 0.6 * sc, p.points.shape); p.poses[1:, :, 3:] += rng.normal(0, 0.25 * sc, p.poses[1:, :, 3:].shape)
             p.poses[1:, :, :3] += rng.normal(0, 0.05 * sc, p.poses[1:, :, :3].shape)
             return p, dict(max_num_iterations=30, initial_trust_region_radius=1e12)
         if case == "tolerances":
             return p, dict(max_num_iterations=50)
+        if case == "priors":
+            return p, dict(max_num_iterations=15)
         return p, dict(max_num_iterations=3)
     out = {}
     for mode, env in (("host", {"RSBA_DEVICE_LM": "0"}), ("device", {}), ("device_ahead_1", {"RSBA_LM_AHEAD": "1"}), ("device_ahead_5", {"RSBA_LM_AHEAD": "5"})):
@@ -513,7 +522,7 @@ def test_device_side_trust_region_equals_the_host_form(capi, monkeypatch, case):
         assert got[0] == ref[0], mode
         assert got[1] == ref[1], (mode, got[1], ref[1])
         assert np.array_equal(got[2], ref[2]) and np.array_equal(got[3], ref[3]), mode
-    if case == "rejections":
+    if case in ("rejections", "priors_rejections"):
         assert ref[1][1] >= 5 and ref[1][2] >= 3          # the case does accept and reject steps
     if case == "failure":
         assert ref[1][2] >= 3                              # ... and this one only rejects (invalid or unsuccessful steps to the end)
