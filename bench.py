@@ -166,7 +166,10 @@ def roofline_lm(prob, dp, iters, capi):
                 r["mfma_busy_frac"] = hit["mfma_busy_frac"]
                 r["mfma_busy_source"] = f"profiles/{pr}/pmc_mfma_summary.json (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE per XCD x 1024 SIMDs))"
         break
-    return {"phases": rows, "plan": st, "sum_ms_per_lm_iteration": sum(r["ms_per_lm_iteration"] for r in rows)}
+    return {"phases": rows, "plan": st, "sum_ms_per_lm_iteration": sum(r["ms_per_lm_iteration"] for r in rows),
+            "note": "phases are timed with HIP events around each step of the loop's HOST form (rsba_solve with profile_phases: the host decides, a pair of "
+                    "events per step, ~10 us each); lm.ms_per_lm_iteration is the unprofiled solve — on one GPU the device-side loop with fewer launches — "
+                    "and is therefore below this sum"}
 
 
 def next_rows(prob, dp, device):
