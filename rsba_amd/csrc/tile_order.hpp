@@ -6,8 +6,9 @@
 // separators; cutting it into independent segments turns the factorisation's serial tile chain into a shallow elimination tree.
 // Tiles adjacent to (almost) everything — the intrinsics border — are ordered last.
 //
-// With nparts > 1 the TOP of the tree is cut for the ranks of a sharded solve: the first ceil(log2 nparts) levels of separators
-// split the tiles into nparts "parts" of about equal weight (observations), one per rank; part_of[tile] = the rank whose subtree
+// With nparts > 1 the TOP of the tree is cut for the ranks of a sharded solve: ceil(log2 nparts) levels of separators — the frontier of
+// a prefix of the level-by-level order, placed tile by tile where the loads balance — split the tiles into nparts "parts" of about
+// equal weight (observations), one per rank; part_of[tile] = the rank whose subtree
 // the tile belongs to, -1 for the tiles of those top separators (and the dense border).  No point is seen on both sides of a
 // separator (its two sides are not adjacent in the tile graph), so every point that is seen in a part's tile at all belongs to
 // that part alone: the rank that owns the part owns the point (every observation of a point on one rank), the columns
@@ -78,8 +79,15 @@ inline TileOrder nested_dissection(int nt, const std::vector<std::vector<int32_t
     nd(left); nd(right);
     for (int u : sep) out.perm.push_back(u);
   };
-  // the top of the tree, cut for `parts` ranks: the separator sits where the weight left of it is parts_left / parts of the total
-  std::function<void(std::vector<int32_t>, int)> nd_parts = [&](std::vector<int32_t> nodes, int parts) {
+  // The top of the tree, cut for `parts` ranks.  The nodes are laid out level by level (Cuthill-McKee from a pseudo-peripheral root);
+  // a cut at position p of that order leaves the first p nodes on the left, and the separator is their FRONTIER — the later nodes
+  // that touch one of them — so every position is a candidate, not only the level boundaries (a level of a video's tile graph is as
+  // wide as its band: six tiles of the thirty-one a rank gets at 1 000 cameras on 8 ranks).  A side's load is what its rank will
+  // own: its tiles' weight, half of the separator's (a point seen in a separator tile belongs to whichever side it is also seen
+  // on), and the halves of the outer separators (`outer`: node set, half weight) that lie against it.  The cut is where the two
+  // sides' loads per rank are closest.
+  struct OuterSep { std::vector<int32_t> nodes; double half; };
+  std::function<void(std::vector<int32_t>, int, std::vector<OuterSep>)> nd_parts = [&](std::vector<int32_t> nodes, int parts, std::vector<OuterSep> outer) {
     if (parts <= 1 || nodes.empty()) {
       const int p = next_part++;
       for (int u : nodes) out.part_of[u] = p;
@@ -98,27 +106,78 @@ inline TileOrder nested_dissection(int nt, const std::vector<std::vector<int32_t
     }
     const int pl = parts / 2, pr = parts - pl;
     auto w = [&](int u) { return weight ? (*weight)[u] : 1.0; };
-    double total = 0.0; for (int u : nodes) total += w(u);
-    // the level whose removal leaves the two sides closest to their shares: weight per rank left of it against weight per rank right of it
-    std::vector<double> lw(lv.size(), 0.0);
-    for (size_t l = 0; l < lv.size(); ++l) for (int u : lv[l]) lw[l] += w(u);
-    double acc = lw[0], best = -1.0; size_t cut = 1;
-    for (size_t l = 1; l + 1 < lv.size(); ++l) {
-      const double miss = std::abs(acc / pl - (total - acc - lw[l]) / pr);
-      if (best < 0.0 || miss < best) { best = miss; cut = l; }
-      acc += lw[l];
+    const int n = (int)nodes.size();
+    std::vector<int32_t> order; order.reserve(n);
+    for (auto& l : lv) order.insert(order.end(), l.begin(), l.end());
+    std::vector<int32_t> pos(nt, -1);
+    for (int i = 0; i < n; ++i) pos[order[i]] = i;
+    // Inside a level the nodes come by index, which is the wrong way round whenever the root sits at the high end (a frontier then
+    // holds the rest of one level AND the next): a few barycentre sweeps — every node to the mean position of itself and its
+    // neighbours, ties by the old position — turn the level order into a proper linear arrangement (for a band: the natural one).
+    for (int sweep = 0; sweep < 4; ++sweep) {
+      std::vector<std::pair<double, int32_t>> key(n);
+      for (int i = 0; i < n; ++i) {
+        double sum = i; int cnt = 1;
+        for (int v : adj[order[i]]) if (tag[v] == mytag && pos[v] >= 0) { sum += pos[v]; ++cnt; }
+        key[i] = {sum / cnt, (int32_t)i};
+      }
+      std::sort(key.begin(), key.end());
+      std::vector<int32_t> next(n);
+      for (int i = 0; i < n; ++i) next[i] = order[key[i].second];
+      order.swap(next);
+      for (int i = 0; i < n; ++i) pos[order[i]] = i;
     }
-    std::vector<int32_t> left, right;
-    for (size_t l = 0; l < cut; ++l) left.insert(left.end(), lv[l].begin(), lv[l].end());
-    for (size_t l = cut + 1; l < lv.size(); ++l) right.insert(right.end(), lv[l].begin(), lv[l].end());
-    const std::vector<int32_t> sep = lv[cut];
-    nd_parts(left, pl); nd_parts(right, pr);
+    // first_nb[i]: the earliest position of a neighbour of the node at position i; the node is in the frontier of every cut p with first_nb < p <= i
+    std::vector<int32_t> first_nb(n);
+    std::vector<double> sep_delta((size_t)n + 2, 0.0), prefix((size_t)n + 1, 0.0);
+    for (int i = 0; i < n; ++i) {
+      int f = n;
+      for (int v : adj[order[i]]) if (tag[v] == mytag && pos[v] >= 0) f = std::min(f, (int)pos[v]);
+      first_nb[i] = f;
+      prefix[i + 1] = prefix[i] + w(order[i]);
+      if (f < i) { sep_delta[f + 1] += w(order[i]); sep_delta[i + 1] -= w(order[i]); }
+    }
+    const double total = prefix[n];
+    // where the outer separators lie: the median position of their neighbours among these nodes (none: they do not count here)
+    std::vector<std::pair<int, double>> outer_at;   // (position, half weight)
+    std::vector<int> outer_pos(outer.size(), -1);
+    for (size_t q = 0; q < outer.size(); ++q) {
+      std::vector<int32_t> at;
+      for (int u : outer[q].nodes) for (int v : adj[u]) if (tag[v] == mytag && pos[v] >= 0) at.push_back(pos[v]);
+      if (at.empty()) continue;
+      std::nth_element(at.begin(), at.begin() + at.size() / 2, at.end());
+      outer_pos[q] = at[at.size() / 2];
+      outer_at.emplace_back(outer_pos[q], outer[q].half);
+    }
+    double outer_total = 0.0; for (auto& o : outer_at) outer_total += o.second;
+    int cut = -1; double best = -1.0, ws = 0.0, ws_at_cut = 0.0;
+    for (int p = 1; p < n; ++p) {
+      ws += sep_delta[p];
+      const double wl = prefix[p], wr = total - wl - ws;
+      if (wr <= 0.0) break;                                    // nothing would be left on the right
+      double bl = 0.0; for (auto& o : outer_at) if (o.first < p) bl += o.second;
+      const double miss = std::abs((wl + 0.5 * ws + bl) / pl - (wr + 0.5 * ws + (outer_total - bl)) / pr);
+      if (best < 0.0 || miss < best) { best = miss; cut = p; ws_at_cut = ws; }
+    }
+    if (cut < 0) {   // (a complete graph: no cut leaves two sides)
+      out.parts_ok = false;
+      const int p = next_part; next_part += parts;
+      for (int u : nodes) out.part_of[u] = p;
+      nd(std::move(nodes));
+      return;
+    }
+    std::vector<int32_t> left(order.begin(), order.begin() + cut), right, sep;
+    for (int i = cut; i < n; ++i) (first_nb[i] < cut ? sep : right).push_back(order[i]);
+    std::vector<OuterSep> outer_l, outer_r;
+    for (size_t q = 0; q < outer.size(); ++q) if (outer_pos[q] >= 0) (outer_pos[q] < cut ? outer_l : outer_r).push_back(outer[q]);
+    outer_l.push_back(OuterSep{sep, 0.5 * ws_at_cut}); outer_r.push_back(OuterSep{sep, 0.5 * ws_at_cut});
+    nd_parts(std::move(left), pl, std::move(outer_l)); nd_parts(std::move(right), pr, std::move(outer_r));
     for (int u : sep) out.perm.push_back(u);
   };
   std::vector<int32_t> sparse_nodes;
   for (int t = 0; t < nt; ++t) if (!dense[t]) sparse_nodes.push_back(t);
   for (int t = 0; t < nt; ++t) if (dense[t]) tag[t] = -2;   // dense tiles are invisible to the dissection
-  if (nparts > 1) nd_parts(sparse_nodes, nparts); else nd(sparse_nodes);
+  if (nparts > 1) nd_parts(sparse_nodes, nparts, {}); else nd(sparse_nodes);
   for (int t = 0; t < nt; ++t) if (dense[t]) out.perm.push_back(t);
   if (nparts > 1 && next_part != nparts) out.parts_ok = false;
   return out;

@@ -165,7 +165,7 @@ def test_partition_points_cuts_along_separators(config, worlds):
         owner, ntop = capi.partition_points(p, world)
         assert owner.shape == (p.num_points,) and owner.min() >= 0 and owner.max() == world - 1
         load = np.bincount(owner[p.obs_point], minlength=world)
-        assert load.min() > 0 and load.max() <= 1.35 * load.mean()
+        assert load.min() > 0 and load.max() <= (1.02 if nt >= 30 * world else 1.35) * load.mean()   # (cut tile by tile: equal to a per cent when a rank has tiles to choose from)
         touched = np.zeros((world, nt), dtype=bool)
         touched[owner[p.obs_point], p.obs_frame // FT] = True
         shared = int((touched.sum(0) > 1).sum())
