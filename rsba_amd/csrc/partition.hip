@@ -49,7 +49,7 @@ extern "C" int32_t rsba_partition_points(const rsba_problem_desc* d, int32_t wor
   std::vector<std::vector<int32_t>> adj(nt);
   for (int a = 0; a < nt; ++a) for (int b = 0; b < a; ++b) if (pair[(size_t)a * nt + b]) { adj[a].push_back(b); adj[b].push_back(a); }
   for (auto& l : adj) std::sort(l.begin(), l.end());
-  const TileOrder ord = nested_dissection(nt, adj, plan_leaf_size(world), world, &weight);
+  const TileOrder ord = nested_dissection(nt, adj, plan_leaf_size(world, nt), world, &weight);
   if (!ord.parts_ok) return rsba_set_error(RSBA_ERR_UNSUPPORTED, "the co-visibility graph cannot be cut into that many parts (too few frames, or not connected)");
   int ntop = 0;
   for (int t = 0; t < nt; ++t) ntop += ord.part_of[t] < 0;

@@ -543,7 +543,7 @@ int32_t build_solver_impl(rsba_handle* h) {
   const bool want_parts = h->allreduce && h->world > 1 && !h->union_mask.empty();
   std::vector<double> tile_weight(nt, 0.0);
   for (int f = 0; f < FR; ++f) tile_weight[f / FT] += (double)(h->frame_obs_total.empty() ? frame_ptr[f + 1] - frame_ptr[f] : h->frame_obs_total[f]);
-  TileOrder tord = nested_dissection(nt, adj, plan_leaf_size(want_parts ? h->world : 1), want_parts ? h->world : 1, &tile_weight);
+  TileOrder tord = nested_dissection(nt, adj, plan_leaf_size(want_parts ? h->world : 1, nt), want_parts ? h->world : 1, &tile_weight);
   const std::vector<int32_t>& perm = tord.perm;          // perm[new] = old tile
   std::vector<int32_t> iperm(nt);
   for (int k = 0; k < nt; ++k) iperm[perm[k]] = k;

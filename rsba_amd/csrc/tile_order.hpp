@@ -23,12 +23,14 @@
 
 namespace rsba {
 
-// tiles per leaf of the dissection (RSBA_CHOL_LEAF: tuning aid).  One GPU: 24 (swept 8 - 48 on the 1k- and 4k-camera scenes, DESIGN.md
-// §3).  A sharded factorisation (nparts ranks): 12 — a rank's share of the tasks leaves most of its GPU idle, so the shorter chain
-// of smaller leaves wins over their extra fill: factorisation 0.756 -> 0.662 ms at 1k cameras on 8 ranks, 0.672 -> 0.647 on 2,
-// 1.164 -> 1.131 at 4k cameras on 4 (profiles/r04/shard_leaf_sweep.txt).  Every rank — and rsba_partition_points — must use the same.
-inline int plan_leaf_size(int nparts = 1) {
-  int k = nparts > 1 ? 12 : 24;
+// tiles per leaf of the dissection (RSBA_CHOL_LEAF: tuning aid).  The factorisation is a latency chain as long as the GPU has idle
+// workgroups — smaller leaves shorten it at the price of fill — and a throughput problem beyond: on one GPU 8 tiles up to 64 tile
+// columns (100 cameras: 0.285 -> 0.270 ms), 12 up to 500 (1k cameras: 0.758 -> 0.745), 24 above (4k cameras: 2.38 against 2.43 with
+// 12).  A sharded factorisation (nparts ranks): 12 whatever the size — a rank's share of the tasks leaves most of its
+// GPU idle: 0.756 -> 0.662 ms at 1k cameras on 8 ranks, 0.672 -> 0.647 on 2, 1.164 -> 1.131 at 4k cameras on 4
+// (profiles/r04/shard_leaf_sweep.txt).  Every rank — and rsba_partition_points — must use the same.
+inline int plan_leaf_size(int nparts, int nt) {
+  int k = nparts > 1 ? 12 : nt <= 64 ? 8 : nt <= 500 ? 12 : 24;
   if (const char* e = std::getenv("RSBA_CHOL_LEAF")) k = std::max(2, std::atoi(e));
   return k;
 }
