@@ -302,8 +302,9 @@ int32_t rsba_set_global_shutter_frames(rsba_handle* h, const uint8_t* is_global)
 
 /* The symbolic phase of a handle's first solve works in ~40 bytes of host memory per observation.  That scratch is kept by the
  * library between handles (a fresh handle per call is windowedBA's pattern, VideoSfMHandler.cc:185-214, and mapping / unmapping
- * it per call cost more than the passes that fill it); this call gives it back to the allocator.  Safe at any time; the next
- * first solve simply allocates it again. */
+ * it per call cost more than the passes that fill it), and so are the device blocks, streams, events and the small pinned block of
+ * destroyed handles (rsba_amd/csrc/devmem.hpp; device blocks up to RSBA_DEVICE_CACHE_MB, default 2048); this call gives all of it
+ * back.  Safe at any time; the next handle simply allocates again. */
 void rsba_release_host_scratch(void);
 
 /* == the RANSAC hypotheses of vision::solveRsPnPRansac (solveRSpnp.cpp:413-524), batched: task t is
