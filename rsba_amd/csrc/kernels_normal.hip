@@ -10,6 +10,7 @@
 #include "lm_record.hpp"
 #include "obs_math.hpp"
 #include "solver_state.hpp"
+#include <cstdlib>
 
 namespace rsba {
 
@@ -306,7 +307,12 @@ __global__ __launch_bounds__(256) void point_factor_kernel(const DeviceProblem d
 // position (frame % FT) * CD.  Consecutive slots of a point are consecutive frames, so the runs of one
 // coordinate line up back to back: the wave stores coordinate by coordinate, each store instruction covering
 // (mostly) whole 128-B lines.
-constexpr int kProjectChunks = 8;   // consecutive 64-slot chunks per wave of the projection kernel
+constexpr int kProjectChunks = 8;   // consecutive 64-slot chunks per wave of the projection kernel (fewer when the scene is small: project_chunks)
+inline int project_chunks(int64_t N) {   // ~2 k waves or more
+  static const int forced = [] { const char* e = std::getenv("RSBA_PROJECT_CHUNKS"); const int v = e ? std::atoi(e) : 0; return v >= 1 && v <= 64 ? v : 0; }();   // (tuning aid)
+  const int64_t c = N / 64 / 2048;
+  return forced ? forced : (int)(c < 1 ? 1 : c > kProjectChunks ? kProjectChunks : c);
+}
 
 template <int CD, int KC>
 __global__ __launch_bounds__(256) void project_kernel(const DeviceProblem dp, const SolverDev sv) {
@@ -761,16 +767,16 @@ __device__ __forceinline__ void slot_record(const DeviceProblem& dp, const Solve
 
 // K5b without records: P = Jc^T (Jp L^-T) of 64 consecutive slots per wave and step, into the group layout (see project_kernel)
 template <bool CAL, int P>
-__global__ __launch_bounds__(256) void project_rc_kernel(const DeviceProblem dp, const SolverDev sv) {
+__global__ __launch_bounds__(256) void project_rc_kernel(const DeviceProblem dp, const SolverDev sv, int nch) {
   if (lm_stopped(sv.ctl)) return;   // (device-side trust region: the solve is over, iterations enqueued ahead fall through)
   constexpr int CD = 6 * P, OUT = CD * 3, FT = kTile / CD, PITCH = OUT | 1, kPer = 64 / CD, OP = CAL ? 0 : 9;   // OP: the pose columns follow the 9 intrinsics columns
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double* buf = smem + (size_t)wave * (64 * PITCH + 32);
   int32_t* s_gpos = reinterpret_cast<int32_t*>(buf + 64 * PITCH);
-  const int64_t sb = ((int64_t)blockIdx.x * 4 + wave) * 64 * kProjectChunks;
+  const int64_t sb = ((int64_t)blockIdx.x * 4 + wave) * 64 * nch;
   if (sb >= dp.N) return;
-  const int64_t se = sb + 64 * kProjectChunks < dp.N ? sb + 64 * kProjectChunks : dp.N;
+  const int64_t se = sb + 64 * nch < dp.N ? sb + 64 * nch : dp.N;
   for (int64_t s0 = sb; s0 < se; s0 += 64) {
     const int64_t nslot = se - s0 < 64 ? se - s0 : 64;
     const int64_t s = s0 + lane < se ? s0 + lane : se - 1;   // (lanes past the end repeat the last slot; nothing of theirs is stored)
@@ -815,21 +821,28 @@ __global__ __launch_bounds__(256) void project_rc_kernel(const DeviceProblem dp,
 // (Sixteen points — a few hundred slots — per wave: the records are computed, not streamed, so the pass wants many waves in flight,
 // not long ones; 64 points per wave left the 100-camera scene with 40 workgroups.)
 constexpr int kSweepPoints = 16;
+// ... and fewer when the problem is small: the waves of a pass all run at once (10 000 points are 625 waves of sixteen on 1 024 SIMDs),
+// so what a pass takes is what ONE wave takes — its points' slots, 64 at a time — and a wave with four points is done in a third of
+// the time of a wave with sixteen.  sweep_points(M): 16 from 32 k points, 8 from 16 k, 4 below.
+inline int sweep_points(int64_t M) {
+  static const int forced = [] { const char* e = std::getenv("RSBA_SWEEP_POINTS"); const int v = e ? std::atoi(e) : 0; return v >= 1 && v <= kSweepPoints ? v : 0; }();   // (tuning aid)
+  return forced ? forced : M >= 32768 ? 16 : M >= 16384 ? 8 : 4;
+}
 // The sums are taken by ALL 64 lanes: the wave's (point, component) pairs — 16 x NC — are dealt to the lanes, each adding its pairs'
 // numbers over the point's slots in slot order (the same order as ever: same bits) — when only the 16 lanes that own a point did
 // this, the other 48 waited through 20 x NC dependent LDS reads and adds per point: most of the sweep's time (the virtual-record sweep
 // of a shared intrinsics block, NC = 27, took 0.91 ms at 4k cameras against 0.35 for NC = 9 over the same records).
 template <bool CAL, int P, int NC, class PerSlot, class PerPoint>
-__device__ __forceinline__ double point_sweep(const DeviceProblem& dp, const SolverDev& sv, double* smem, PerSlot per_slot, PerPoint per_point) {
-  constexpr int NPAIR = kSweepPoints * NC, PER = (NPAIR + 63) / 64;
+__device__ __forceinline__ double point_sweep(const DeviceProblem& dp, const SolverDev& sv, double* smem, int sp, PerSlot per_slot, PerPoint per_point) {
+  constexpr int NPAIR = kSweepPoints * NC, PER = (NPAIR + 63) / 64;   // (sized for the most points a wave takes; sp <= kSweepPoints of them this launch)
   __shared__ double s_red[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double* cbuf = smem + (size_t)wave * (64 * NC);
-  const int64_t j0 = ((int64_t)blockIdx.x * 4 + wave) * kSweepPoints;
+  const int64_t j0 = ((int64_t)blockIdx.x * 4 + wave) * sp;
   double ret = 0.0;
   auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
   if (j0 < dp.M) {   // wave-uniform
-    const int jn = (int)(dp.M - j0 < kSweepPoints ? dp.M - j0 : kSweepPoints);
+    const int jn = (int)(dp.M - j0 < sp ? dp.M - j0 : sp);
     const bool mine = lane < jn;
     const int64_t j = j0 + (mine ? lane : 0);
     const int64_t lo = mine ? sv.point_ptr[j] : 0, hi = mine ? sv.point_ptr[j + 1] : 0;
@@ -883,11 +896,11 @@ __device__ __forceinline__ double point_sweep(const DeviceProblem& dp, const Sol
 
 // K2b without records: V_j, g_p,j
 template <bool CAL, int P>
-__global__ __launch_bounds__(256) void point_blocks_rc_kernel(const DeviceProblem dp, const SolverDev sv) {
+__global__ __launch_bounds__(256) void point_blocks_rc_kernel(const DeviceProblem dp, const SolverDev sv, int sp) {
   if (lm_not_accepted(sv.ctl)) return;
   constexpr int CD = (CAL ? 0 : 9) + 6 * P;   // columns in front of the point's
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  point_sweep<CAL, P, 9>(dp, sv, smem,
+  point_sweep<CAL, P, 9>(dp, sv, smem, sp,
     [&](const ObsOut<CAL, P>& o, int, int, double c[9]) {
       const double r0 = o.r[0], r1 = o.r[1], p0[3] = {o.J[0][CD], o.J[0][CD + 1], o.J[0][CD + 2]}, p1[3] = {o.J[1][CD], o.J[1][CD + 1], o.J[1][CD + 2]};
       c[0] = p0[0] * p0[0] + p1[0] * p1[0]; c[1] = p0[0] * p0[1] + p1[0] * p1[1]; c[2] = p0[0] * p0[2] + p1[0] * p1[2];
@@ -906,11 +919,11 @@ __global__ __launch_bounds__(256) void point_blocks_rc_kernel(const DeviceProble
 
 // K7 + K8 without records (see point_step_kernel)
 template <bool CAL, int P>
-__global__ __launch_bounds__(256) void point_step_rc_kernel(const DeviceProblem dp, const SolverDev sv) {
+__global__ __launch_bounds__(256) void point_step_rc_kernel(const DeviceProblem dp, const SolverDev sv, int sp) {
   if (lm_stopped(sv.ctl)) return;
   constexpr int CD = 6 * P, OP = CAL ? 0 : 9, OX = OP + CD;
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  const double mc = point_sweep<CAL, P, 5>(dp, sv, smem,
+  const double mc = point_sweep<CAL, P, 5>(dp, sv, smem, sp,
     [&](const ObsOut<CAL, P>& o, int frame, int, double c[5]) {
       const double* yc = sv.step + (size_t)frame * CD;
       double t0 = 0.0, t1 = 0.0;
@@ -945,10 +958,10 @@ __global__ __launch_bounds__(256) void point_step_rc_kernel(const DeviceProblem 
 // the virtual records of the intrinsics pseudo frames without records, ONE intrinsics block (the shared sess.cam): per point
 // Q_j = sum_o Ji_o^T (Jp_o L_j^-T) (9 x 3), cut into the NPF pseudo-frame records of the point's virtual slots (see virtual_records_kernel)
 template <int P>
-__global__ __launch_bounds__(256) void virtual_records_rc_kernel(const DeviceProblem dp, const SolverDev sv) {
+__global__ __launch_bounds__(256) void virtual_records_rc_kernel(const DeviceProblem dp, const SolverDev sv, int sp) {
   constexpr int CD = 6 * P, OX = 9 + CD, FT = kTile / CD;
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  point_sweep<false, P, 27>(dp, sv, smem,
+  point_sweep<false, P, 27>(dp, sv, smem, sp,
     [&](const ObsOut<false, P>& o, int, int j, double c[27]) {
       const double* li = sv.Linv + (size_t)j * 6;
       const double i00 = li[0], i10 = li[1], i11 = li[2], i20 = li[3], i21 = li[4], i22 = li[5];
@@ -1305,9 +1318,9 @@ hipError_t launch_point_blocks(const DeviceProblem& dp, const SolverDev& sv, hip
   if (sv.slot_xy) {   // calibrated: from the observations themselves
     if (dp.M <= 0) return hipSuccess;
     const size_t lds = (size_t)4 * 64 * 9 * sizeof(double);
-    const int grid = (int)((dp.M + 4 * kSweepPoints - 1) / (4 * kSweepPoints));
-    if (dp.calibrated) { if (sv.CD == 12) hipLaunchKernelGGL((point_blocks_rc_kernel<true, 2>), dim3(grid), dim3(256), lds, st, dp, sv); else hipLaunchKernelGGL((point_blocks_rc_kernel<true, 1>), dim3(grid), dim3(256), lds, st, dp, sv); }
-    else { if (sv.CD == 12) hipLaunchKernelGGL((point_blocks_rc_kernel<false, 2>), dim3(grid), dim3(256), lds, st, dp, sv); else hipLaunchKernelGGL((point_blocks_rc_kernel<false, 1>), dim3(grid), dim3(256), lds, st, dp, sv); }
+    const int sp = sweep_points(dp.M), grid = (int)((dp.M + 4 * sp - 1) / (4 * sp));
+    if (dp.calibrated) { if (sv.CD == 12) hipLaunchKernelGGL((point_blocks_rc_kernel<true, 2>), dim3(grid), dim3(256), lds, st, dp, sv, sp); else hipLaunchKernelGGL((point_blocks_rc_kernel<true, 1>), dim3(grid), dim3(256), lds, st, dp, sv, sp); }
+    else { if (sv.CD == 12) hipLaunchKernelGGL((point_blocks_rc_kernel<false, 2>), dim3(grid), dim3(256), lds, st, dp, sv, sp); else hipLaunchKernelGGL((point_blocks_rc_kernel<false, 1>), dim3(grid), dim3(256), lds, st, dp, sv, sp); }
     return hipGetLastError();
   }
   LAUNCH(point_blocks_kernel, nblocks256(dp.M), 256, st, dp, sv);
@@ -1388,9 +1401,9 @@ hipError_t launch_project(const DeviceProblem& dp, const SolverDev& sv, hipStrea
   if (sv.slot_xy) {
     const int CD = sv.CD;
     const size_t lds = (size_t)4 * (64 * ((CD * 3) | 1) + 32) * sizeof(double);
-    const int grid = (int)((dp.N + 256 * kProjectChunks - 1) / (256 * kProjectChunks));
-    if (dp.calibrated) { if (CD == 12) hipLaunchKernelGGL((project_rc_kernel<true, 2>), dim3(grid), dim3(256), lds, st, dp, sv); else hipLaunchKernelGGL((project_rc_kernel<true, 1>), dim3(grid), dim3(256), lds, st, dp, sv); }
-    else { if (CD == 12) hipLaunchKernelGGL((project_rc_kernel<false, 2>), dim3(grid), dim3(256), lds, st, dp, sv); else hipLaunchKernelGGL((project_rc_kernel<false, 1>), dim3(grid), dim3(256), lds, st, dp, sv); }
+    const int nch = project_chunks(dp.N), grid = (int)((dp.N + 256 * (int64_t)nch - 1) / (256 * (int64_t)nch));
+    if (dp.calibrated) { if (CD == 12) hipLaunchKernelGGL((project_rc_kernel<true, 2>), dim3(grid), dim3(256), lds, st, dp, sv, nch); else hipLaunchKernelGGL((project_rc_kernel<true, 1>), dim3(grid), dim3(256), lds, st, dp, sv, nch); }
+    else { if (CD == 12) hipLaunchKernelGGL((project_rc_kernel<false, 2>), dim3(grid), dim3(256), lds, st, dp, sv, nch); else hipLaunchKernelGGL((project_rc_kernel<false, 1>), dim3(grid), dim3(256), lds, st, dp, sv, nch); }
     return hipGetLastError();
   }
   if (sv.CD == 12 && KC == 12) return launch_project_as<12, 12>(dp, sv, st);
@@ -1410,9 +1423,9 @@ hipError_t launch_virtual_records(const DeviceProblem& dp, const SolverDev& sv, 
   if (sv.nvgroups == 0) return hipSuccess;
   if (sv.slot_xy) {   // (one intrinsics block: recomputed like the rest)
     const size_t lds = (size_t)4 * 64 * 27 * sizeof(double);
-    const int grid = (int)((dp.M + 4 * kSweepPoints - 1) / (4 * kSweepPoints));
-    if (sv.CD == 12) hipLaunchKernelGGL(virtual_records_rc_kernel<2>, dim3(grid), dim3(256), lds, st, dp, sv);
-    else hipLaunchKernelGGL(virtual_records_rc_kernel<1>, dim3(grid), dim3(256), lds, st, dp, sv);
+    const int sp = sweep_points(dp.M), grid = (int)((dp.M + 4 * sp - 1) / (4 * sp));
+    if (sv.CD == 12) hipLaunchKernelGGL(virtual_records_rc_kernel<2>, dim3(grid), dim3(256), lds, st, dp, sv, sp);
+    else hipLaunchKernelGGL(virtual_records_rc_kernel<1>, dim3(grid), dim3(256), lds, st, dp, sv, sp);
     return hipGetLastError();
   }
   if (sv.CD == 12) LAUNCH(virtual_records_kernel<12>, nblocks256(sv.nvgroups), 256, st, dp, sv);
@@ -1442,7 +1455,7 @@ hipError_t launch_schur_blocks(const DeviceProblem& dp, const SolverDev& sv, dou
   LAUNCH(schur_merge_kernel, dim3(sv.ntp, kMergeSplit), 256, st, dp, sv, 1.0 / radius);
   return hipSuccess;
 }
-static int point_step_blocks(const DeviceProblem& dp, const SolverDev& sv) { return sv.slot_xy ? (int)((dp.M + 4 * kSweepPoints - 1) / (4 * kSweepPoints)) : (int)((dp.M + 255) / 256); }
+static int point_step_blocks(const DeviceProblem& dp, const SolverDev& sv) { const int sp = sweep_points(dp.M); return sv.slot_xy ? (int)((dp.M + 4 * sp - 1) / (4 * sp)) : (int)((dp.M + 255) / 256); }
 template <int CD, int KC>
 static hipError_t launch_point_step(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {
   constexpr int REC = 8 + 2 * KC, PITCH = REC | 1;
@@ -1459,8 +1472,9 @@ hipError_t launch_back_substitute(const DeviceProblem& dp, const SolverDev& sv, 
   if (sv.slot_xy) {
     const size_t lds = (size_t)4 * 64 * 5 * sizeof(double);
     const int grid = point_step_blocks(dp, sv);
-    if (dp.calibrated) { if (sv.CD == 12) hipLaunchKernelGGL((point_step_rc_kernel<true, 2>), dim3(grid), dim3(256), lds, st, dp, sv); else hipLaunchKernelGGL((point_step_rc_kernel<true, 1>), dim3(grid), dim3(256), lds, st, dp, sv); }
-    else { if (sv.CD == 12) hipLaunchKernelGGL((point_step_rc_kernel<false, 2>), dim3(grid), dim3(256), lds, st, dp, sv); else hipLaunchKernelGGL((point_step_rc_kernel<false, 1>), dim3(grid), dim3(256), lds, st, dp, sv); }
+    const int sp = sweep_points(dp.M);
+    if (dp.calibrated) { if (sv.CD == 12) hipLaunchKernelGGL((point_step_rc_kernel<true, 2>), dim3(grid), dim3(256), lds, st, dp, sv, sp); else hipLaunchKernelGGL((point_step_rc_kernel<true, 1>), dim3(grid), dim3(256), lds, st, dp, sv, sp); }
+    else { if (sv.CD == 12) hipLaunchKernelGGL((point_step_rc_kernel<false, 2>), dim3(grid), dim3(256), lds, st, dp, sv, sp); else hipLaunchKernelGGL((point_step_rc_kernel<false, 1>), dim3(grid), dim3(256), lds, st, dp, sv, sp); }
     return hipGetLastError();
   }
   if (sv.CD == 12) return KC == 12 ? launch_point_step<12, 12>(dp, sv, st) : launch_point_step<12, 21>(dp, sv, st);

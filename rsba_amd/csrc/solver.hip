@@ -1090,7 +1090,7 @@ int32_t build_solver_impl(rsba_handle* h) {
   if ((rc = s_alloc(s, &sv.trial_poses, (size_t)FR * CD))) return rc;
   if ((rc = s_alloc(s, &sv.trial_points, (size_t)M * 3))) return rc;
   const size_t nb = std::max<size_t>((N + 255) / 256, ((size_t)sv.n + 3 * (size_t)M + 255) / 256);
-  if ((rc = s_alloc(s, &sv.partial, 2 * std::max(nb, ((size_t)M + 63) / 64 + 1) + 2))) return rc;   // (the point sweeps leave one partial per 64 points)
+  if ((rc = s_alloc(s, &sv.partial, 2 * std::max(nb, ((size_t)M + 15) / 16 + 1) + 2))) return rc;   // (the point sweeps leave one partial per workgroup: 16 - 64 points)
   if ((rc = s_alloc(s, &sv.partial_c, 2 * (((size_t)sv.n + 3 * (size_t)M + 255) / 256) + 2))) return rc;
   if ((rc = s_alloc(s, &sv.scalars, 16))) return rc;
   if ((rc = s_alloc(s, &s->d_ctl, kCtlSize))) return rc;
