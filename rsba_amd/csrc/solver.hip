@@ -772,9 +772,12 @@ int32_t build_solver_impl(rsba_handle* h) {
   // Per tile pair the chunk ids are listed in entry order for the merge kernel.
   std::vector<int32_t> chunk_tp, chunk_n; std::vector<int64_t> chunk_e0;
   std::vector<std::vector<int32_t>> pair_chunks(ntp);
-  {
-    int64_t kBlock = std::max<int64_t>(M, 1);
-    if (const char* e = std::getenv("RSBA_SCHUR_BLOCK")) kBlock = std::max(16, std::atoi(e));   // tuning aid
+  //   * round 4, 4k cameras (1 001 tile columns, 29 678 chunks): there the kernel pulls 20.5 GB from the fabric in 3.6 ms — the
+  //     point-block-major numbering with blocks of 2 048 points is worth 3 % (3.59 -> 3.47 ms, 35 502 chunks), so it is the default
+  //     above 500 tile columns — as long as it does not multiply the chunks (point numbers that do not follow the video would).
+  auto number_chunks = [&](int64_t kBlock) {
+    chunk_tp.clear(); chunk_n.clear(); chunk_e0.clear();
+    for (auto& pc : pair_chunks) pc.clear();
     // per tile pair the cursor into its entry list (entries are in point order); pairs that still have entries, in (I, J) order
     std::vector<int64_t> cursor(tp_ptr.begin(), tp_ptr.end() - 1);
     std::vector<int32_t> live; live.reserve(64);
@@ -802,6 +805,14 @@ int32_t build_solver_impl(rsba_handle* h) {
       }
       live.resize(keep);
     }
+  };
+  {
+    int64_t pair_major = 0;
+    for (int t = 0; t < ntp; ++t) pair_major += (tp_ptr[t + 1] - tp_ptr[t] + kSchurChunk - 1) / kSchurChunk;
+    int64_t kBlock = nt > 500 ? 2048 : std::max<int64_t>(M, 1);
+    if (const char* e = std::getenv("RSBA_SCHUR_BLOCK")) kBlock = std::atoi(e) > 0 ? std::max(16, std::atoi(e)) : std::max<int64_t>(M, 1);   // tuning aid (0: tile pair by tile pair)
+    number_chunks(kBlock);
+    if (kBlock < M && !std::getenv("RSBA_SCHUR_BLOCK") && (int64_t)chunk_tp.size() > pair_major + pair_major / 3) number_chunks(std::max<int64_t>(M, 1));
   }
   // A pair with very many chunks (the diagonal pair of the intrinsics pseudo tile has one per 512 points of the whole
   // problem) would be summed by a single workgroup of the merge kernel: its chunk list is pre-reduced in groups of
