@@ -80,11 +80,31 @@ __global__ __launch_bounds__(256) void camera_reduce_kernel(const DeviceProblem 
 #pragma unroll
   for (int q = 0; q < NBLK; ++q) sum[q] = 0.0;
   if (s1 > s0) {
+    // where each of the frame's waves left its partial: looked up by a thread per wave first (three dependent loads), so that the sums
+    // below — in wave order, as ever — issue their loads back to back instead of behind that chain
+    __shared__ int s_seg[256];
     const int rk = dp.frame_rank[f];
-    for (int64_t w = s0 >> 6; w <= (s1 - 1) >> 6; ++w) {
-      const int seg = dp.wave_seg_base[w] + rk - dp.frame_rank[dp.obs_frame[w << 6]];
+    const int64_t w0 = s0 >> 6, w1 = (s1 - 1) >> 6;
+    for (int64_t wb = w0; wb <= w1; wb += 256) {
+      const int nw = (int)(w1 - wb + 1 < 256 ? w1 - wb + 1 : 256);
+      __syncthreads();
+      if (e < nw) s_seg[e] = dp.wave_seg_base[wb + e] + rk - dp.frame_rank[dp.obs_frame[(wb + e) << 6]];
+      __syncthreads();
+      int i = 0;
+      for (; i + 4 <= nw; i += 4) {
+        double v[4][NBLK];
 #pragma unroll
-      for (int q = 0; q < NBLK; ++q) sum[q] += dp.cam_part[((size_t)seg * NBLK + q) * 256 + e];
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int q = 0; q < NBLK; ++q) v[u][q] = dp.cam_part[((size_t)s_seg[i + u] * NBLK + q) * 256 + e];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int q = 0; q < NBLK; ++q) sum[q] += v[u][q];
+      }
+      for (; i < nw; ++i)
+#pragma unroll
+        for (int q = 0; q < NBLK; ++q) sum[q] += dp.cam_part[((size_t)s_seg[i] * NBLK + q) * 256 + e];
     }
   }
 #pragma unroll
