@@ -251,7 +251,17 @@ __global__ __launch_bounds__(256) void reduce_cost_kernel(const double* __restri
                                                           const double* __restrict__ fail_partial, int n, double* out, int* fail_count) {
   __shared__ double s_red[3][4];
   double c = 0.0, f = 0.0, nf = 0.0;
-  for (int k = threadIdx.x; k < n; k += 256) { c += cost_partial[k]; f += fixed_partial[k]; nf += fail_partial[k]; }
+  // (sixteen strides' loads issued together, added in stride order: the sums of the one-load-at-a-time loop, bit for bit — 4k cameras
+  // have 40 000 partials, 157 dependent round trips for this one workgroup: 66 us)
+  int k = threadIdx.x;
+  for (; k + 15 * 256 < n; k += 16 * 256) {
+    double vc[16], vf[16], vn[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { vc[u] = cost_partial[k + 256 * u]; vf[u] = fixed_partial[k + 256 * u]; vn[u] = fail_partial[k + 256 * u]; }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { c += vc[u]; f += vf[u]; nf += vn[u]; }
+  }
+  for (; k < n; k += 256) { c += cost_partial[k]; f += fixed_partial[k]; nf += fail_partial[k]; }
   c = wave_sum(c); f = wave_sum(f); nf = wave_sum(nf);
   if ((threadIdx.x & 63) == 0) { s_red[0][threadIdx.x >> 6] = c; s_red[1][threadIdx.x >> 6] = f; s_red[2][threadIdx.x >> 6] = nf; }
   __syncthreads();

@@ -1208,7 +1208,15 @@ __global__ __launch_bounds__(256) void lm_verdict_step_kernel(const DeviceProble
   }
   __shared__ double s_red[3][4];
   double c = 0.0, f = 0.0, nf = 0.0;
-  for (int k = threadIdx.x; k < n; k += 256) { c += dp.cost_partial[k]; f += dp.fixed_partial[k]; nf += dp.fail_partial[k]; }
+  int k = threadIdx.x;
+  for (; k + 15 * 256 < n; k += 16 * 256) {   // (as reduce_cost_kernel: sixteen strides' loads together, added in stride order)
+    double vc[16], vf[16], vn[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { vc[u] = dp.cost_partial[k + 256 * u]; vf[u] = dp.fixed_partial[k + 256 * u]; vn[u] = dp.fail_partial[k + 256 * u]; }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { c += vc[u]; f += vf[u]; nf += vn[u]; }
+  }
+  for (; k < n; k += 256) { c += dp.cost_partial[k]; f += dp.fixed_partial[k]; nf += dp.fail_partial[k]; }
   c = wsum(c); f = wsum(f); nf = wsum(nf);
   if ((threadIdx.x & 63) == 0) { s_red[0][threadIdx.x >> 6] = c; s_red[1][threadIdx.x >> 6] = f; s_red[2][threadIdx.x >> 6] = nf; }
   __syncthreads();
