@@ -979,6 +979,7 @@ __global__ __launch_bounds__(256) void point_step_rc_kernel(const DeviceProblem 
 // Q_j = sum_o Ji_o^T (Jp_o L_j^-T) (9 x 3), cut into the NPF pseudo-frame records of the point's virtual slots (see virtual_records_kernel)
 template <int P>
 __global__ __launch_bounds__(256) void virtual_records_rc_kernel(const DeviceProblem dp, const SolverDev sv, int sp) {
+  if (lm_stopped(sv.ctl)) return;
   constexpr int CD = 6 * P, OX = 9 + CD, FT = kTile / CD;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   point_sweep<false, P, 27>(dp, sv, smem, sp,
@@ -1317,11 +1318,11 @@ inline int nblocks256(int64_t n) { return (int)((n + 255) / 256); }
     if (e_ != hipSuccess) return e_;                               \
   } while (0)
 
-hipError_t launch_camera_blocks(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st, bool take_candidate) {
+hipError_t launch_camera_blocks(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st, bool take_candidate, bool padding_is_zero) {
   const size_t CD2 = (size_t)sv.CD * sv.CD;
   const int64_t nparam = (int64_t)dp.F * dp.P * 6 + 3 * (int64_t)dp.M + (sv.NPF > 0 ? 9 * (int64_t)dp.NI : 0);
   const unsigned grid = (unsigned)dp.F + (take_candidate ? (unsigned)((nparam + 255) / 256) : 0u);   // (launch_lm_take_candidate's copy by extra workgroups of the same launch)
-  if (sv.NPF > 0) {   // the padding coordinates of the pseudo frames stay zero
+  if (sv.NPF > 0 && !padding_is_zero) {   // the padding coordinates of the pseudo frames stay zero (every other entry of these regions is ASSIGNED by the kernels below: once zero, the padding stays zero — the loop that must not touch U after a rejected step says so)
     hipError_t e = hipMemsetAsync(sv.U + (size_t)sv.F * CD2, 0, ((size_t)sv.NPF * sv.F + (size_t)sv.NIB * sv.NPF * sv.NPF) * CD2 * sizeof(double), st);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(sv.gc + (size_t)sv.F * sv.CD, 0, (size_t)sv.NIB * sv.NPF * sv.CD * sizeof(double), st);

@@ -1880,9 +1880,9 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
   // candidate is not linearised).  What the reference calls per frame — windowedBA over ~100 cameras (VideoSfMClient.cc:241-246) —
   // is where this counts: an iteration there is 0.5 ms, and the host form's 22 dependent launches, two read-backs and their gaps were
   // 0.09 ms of it.  Here an iteration is 14 launches on this stream (the small steps share launches: kernels_normal.hip) and no wait.
-  // Calibrated single-GPU problems, with or without motion priors of a known interFrameRatio; everything else (a free ratio, per-pose
-  // priors, an intrinsics block, several ranks) — and a suspect factorisation — goes through the host form.
-  bool device_ctl = speculate && !h->allreduce && !free_ratio && dp.pp_count == 0 && dp.pp_spherical < 0 && sv.NPF == 0 && !s->use_levels &&
+  // Single-GPU problems that keep no records (calibrated, or ONE shared intrinsics block), with or without motion priors of a known
+  // interFrameRatio; everything else (a free ratio, per-pose priors, per-frame intrinsics blocks, several ranks) — and a suspect factorisation — goes through the host form.
+  bool device_ctl = speculate && !h->allreduce && !free_ratio && dp.pp_count == 0 && dp.pp_spherical < 0 && !s->use_levels &&
                     !s->timer.on && opt->max_num_iterations > 0 && dp.N > 0;
   if (const char* e = std::getenv("RSBA_DEVICE_LM")) device_ctl = device_ctl && e[0] != '0';   // A/B switch: 0 = the host decides
   if (device_ctl) {
@@ -1951,7 +1951,7 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
       swap_params();
       if ((rc = await_verification(h))) return rc;
       HIP_TRY(launch_lm_verdict_step(dp, sv, h->d_cost2, s->d_ctl, R, s->d_trace_it, cap, st, /*cost_reduced=*/s->ucross != nullptr));
-      HIP_TRY(launch_camera_blocks(dp, sv, st, /*take_candidate=*/true));
+      HIP_TRY(launch_camera_blocks(dp, sv, st, /*take_candidate=*/true, /*padding_is_zero=*/true));   // (the initial linearisation zeroed the pseudo frames' padding)
       if (s->ucross) HIP_TRY(launch_prior_blocks(dp, sv, s->ucross, st));                              // ... and their blocks of an accepted step's linearisation
       HIP_TRY(launch_intr_blocks(dp, sv, st));
       HIP_TRY(launch_point_blocks(dp, sv, st));

@@ -168,7 +168,7 @@ hipError_t launch_chol_solve_level(const SolverDev& sv, const CholPlan& pl, bool
 hipError_t launch_chol_dag(const SolverDev& sv, const CholPlan& pl, const DagArgs* device_args, int workgroups, bool one_per_cu, hipStream_t st);   // one_per_cu: LDS request above half a CU's, so that two never share one
 
 // kernels_normal.hip
-hipError_t launch_camera_blocks(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st, bool take_candidate = false);   // take_candidate: launch_lm_take_candidate's copy rides along
+hipError_t launch_camera_blocks(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st, bool take_candidate = false, bool padding_is_zero = false);   // take_candidate: launch_lm_take_candidate's copy rides along
 hipError_t launch_point_blocks(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);
 hipError_t launch_slot_xy(const DeviceProblem& dp, double2* slot_xy, hipStream_t st);   // slot_xy[obs_slot[i]] = xy[i]
 hipError_t launch_jacobi_scale(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);           // scale = mask / (1 + sqrt(diag))

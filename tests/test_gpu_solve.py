@@ -472,7 +472,7 @@ def test_device_blocks_are_cached_between_handles_and_given_back(capi):
     assert s.final_cost == t.final_cost == results[0][0] and np.array_equal(p.poses, results[0][1]) and np.array_equal(q.points, results[0][2])
 
 
-@pytest.mark.parametrize("case", ["c2", "rejections", "failure", "tolerances", "max_iterations", "huber", "priors", "priors_rejections", "c2_priors"])
+@pytest.mark.parametrize("case", ["c2", "rejections", "failure", "tolerances", "max_iterations", "huber", "priors", "priors_rejections", "c2_priors", "intrinsics", "intrinsics_rejections", "intrinsics_priors"])
 def test_device_side_trust_region_equals_the_host_form(capi, monkeypatch, case):
     """accept / reject, the radius update and the convergence tests of the LM loop run in a single-thread kernel, the
     iteration's kernels read the radius from HBM and skip themselves where the host form would not have launched them, the host
@@ -491,10 +491,13 @@ def test_device_side_trust_region_equals_the_host_form(capi, monkeypatch, case):
         if case == "huber":
             p.huber_a = 1.5
             return p, dict(max_num_iterations=25)
-        if case.startswith("priors"):                # motion priors with a known interFrameRatio (CeresHandler.h:147-185): their cost, blocks and model change are part of every decision
+        if case.startswith("intrinsics"):            # the shared intrinsics as a parameter block (what BASELINE config 5 has): pseudo frames in the reduced system, virtual records
+            p.calibrated = False; p.huber_a = 2.0
+            p.intrinsics = p.intrinsics * (1.0 + 1e-3 * np.array([[1, -1, 20, -20, 10, 10, -10, 0.5, -0.5]]))
+        if case.startswith("priors") or case == "intrinsics_priors":                # motion priors with a known interFrameRatio (CeresHandler.h:147-185): their cost, blocks and model change are part of every decision
             p.prior_kind, p.prior_scale, p.inter_frame_ratio = 1, 1.0 if case == "priors_rejections" else 10.0, 0.8
             p.prior_frames = np.arange(1, p.num_frames, dtype=np.int32)
-        if case in ("rejections", "failure", "priors_rejections"):      # a start far from the minimum and a huge first radius: Gauss-Newton steps that overshoot (or never recover)
+        if case in ("rejections", "failure", "priors_rejections", "intrinsics_rejections"):      # a start far from the minimum and a huge first radius: Gauss-Newton steps that overshoot (or never recover)
             rng = np.random.default_rng(2)
             sc = 3.0 if case == "failure" else 2.0
             p.points += rng.normal(0, 0.6 * sc, p.points.shape); p.poses[1:, :, 3:] += rng.normal(0, 0.25 * sc, p.poses[1:, :, 3:].shape)
@@ -502,7 +505,7 @@ def test_device_side_trust_region_equals_the_host_form(capi, monkeypatch, case):
             return p, dict(max_num_iterations=30, initial_trust_region_radius=1e12)
         if case == "tolerances":
             return p, dict(max_num_iterations=50)
-        if case == "priors":
+        if case in ("priors", "intrinsics", "intrinsics_priors"):
             return p, dict(max_num_iterations=15)
         return p, dict(max_num_iterations=3)
     out = {}
@@ -515,14 +518,14 @@ def test_device_side_trust_region_equals_the_host_form(capi, monkeypatch, case):
         with capi.DeviceProblem(p) as dp:
             s, tr = dp.solve(capi.default_options(**kw))
         rec = [(t.iteration, t.step_is_valid, t.step_is_successful, t.cost, t.cost_change, t.gradient_max_norm, t.step_norm, t.relative_decrease, t.trust_region_radius, t.model_cost_change) for t in tr]
-        out[mode] = (rec, (s.termination_type, s.num_successful_steps, s.num_unsuccessful_steps, s.num_iterations, s.initial_cost, s.final_cost, s.is_solution_usable), p.poses.copy(), p.points.copy())
+        out[mode] = (rec, (s.termination_type, s.num_successful_steps, s.num_unsuccessful_steps, s.num_iterations, s.initial_cost, s.final_cost, s.is_solution_usable), p.poses.copy(), p.points.copy(), p.intrinsics.copy())
     ref = out["host"]
     for mode in ("device", "device_ahead_1", "device_ahead_5"):
         got = out[mode]
         assert got[0] == ref[0], mode
         assert got[1] == ref[1], (mode, got[1], ref[1])
-        assert np.array_equal(got[2], ref[2]) and np.array_equal(got[3], ref[3]), mode
-    if case in ("rejections", "priors_rejections"):
+        assert np.array_equal(got[2], ref[2]) and np.array_equal(got[3], ref[3]) and np.array_equal(got[4], ref[4]), mode
+    if case in ("rejections", "priors_rejections", "intrinsics_rejections"):
         assert ref[1][1] >= 5 and ref[1][2] >= 3          # the case does accept and reject steps
     if case == "failure":
         assert ref[1][2] >= 3                              # ... and this one only rejects (invalid or unsuccessful steps to the end)
