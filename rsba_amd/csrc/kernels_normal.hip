@@ -1257,7 +1257,7 @@ __global__ __launch_bounds__(256) void lm_verdict_gradient_kernel(const SolverDe
   if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
   __syncthreads();
   if (threadIdx.x == 0) {
-    sv.scalars[kGradMax] = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
+    if (n >= 0) sv.scalars[kGradMax] = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));   // (n < 0: several ranks — the maximum came with the camera exchange)
     lm_decide_gradient(sv, ctl, R, trace, cap);
     *sv.chol_fail = 0; sv.scalars[kDagSuspect] = 0.0;   // begin_solve_kernel's job for the NEXT iteration: both flags were read by this iteration's first verdict
   }
@@ -1295,6 +1295,7 @@ __global__ void local_linearize_kernel(const DeviceProblem dp, const SolverDev s
   if (t == 0) { sv.scalars[kCost] = cost2[0]; sv.scalars[kFixedCost] = cost2[1]; sv.scalars[kEvalFailed] = (double)*dp.fail_count; }
 }
 __global__ void unpack_linearize_kernel(const DeviceProblem dp, const SolverDev sv) {
+  if (lm_not_accepted(sv.ctl)) return;   // (device-side trust region on several ranks: the exchange of a rejected candidate's iteration carried nothing new)
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (t < sv.n) { sv.gc[t] = sv.xbuf[t]; sv.udiag[t] = sv.xbuf[sv.n + t]; }
   if (t == 0) { sv.scalars[kCost] = sv.xbuf[2 * sv.n]; sv.scalars[kFixedCost] = sv.xbuf[2 * sv.n + 1]; sv.scalars[kEvalFailed] = sv.xbuf[2 * sv.n + 2]; }
@@ -1530,8 +1531,8 @@ hipError_t launch_lm_linearize_gradient(const DeviceProblem& dp, const SolverDev
   LAUNCH(lm_linearize_gradient_kernel, nblocks256(sv.n + 3 * (int64_t)dp.M), 256, st, dp, sv, cost2);
   return hipSuccess;
 }
-hipError_t launch_lm_verdict_gradient(const DeviceProblem& dp, const SolverDev& sv, double* ctl, const LmRules& rules, rsba_iteration* trace, int trace_cap, double* snapshot, double seq, hipStream_t st) {
-  LAUNCH(lm_verdict_gradient_kernel, 1, 256, st, sv, nblocks256(sv.n + 3 * (int64_t)dp.M), ctl, rules, trace, trace_cap, snapshot, seq);
+hipError_t launch_lm_verdict_gradient(const DeviceProblem& dp, const SolverDev& sv, double* ctl, const LmRules& rules, rsba_iteration* trace, int trace_cap, double* snapshot, double seq, hipStream_t st, bool gradmax_done) {
+  LAUNCH(lm_verdict_gradient_kernel, 1, 256, st, sv, gradmax_done ? -1 : nblocks256(sv.n + 3 * (int64_t)dp.M), ctl, rules, trace, trace_cap, snapshot, seq);
   return hipSuccess;
 }
 hipError_t launch_lm_decide_step(const SolverDev& sv, double* ctl, const LmRules& rules, rsba_iteration* trace, int trace_cap, hipStream_t st) {

@@ -1760,18 +1760,22 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
     ~TimerGuard() { for (PhaseTimer* q : {&t, &x}) if (q->on) { q->on = false; q->pending.clear(); q->next = 0; } }
   } timer_guard{s->timer, s->xtimer};
   { const char* lv = std::getenv("RSBA_CHOL_LEVELS"); s->use_levels = opt->level_scheduled_cholesky != 0 || (lv && lv[0] == '1'); }
+  bool any_rank_needs_host = false;
   {
     // problem-size figures of the whole (all-rank) problem
     const double npri = sv.lead ? (double)h->prior_frames.size() + (double)h->pp_blocks.size() + (dp.pp_spherical >= 0 ? 1.0 : 0.0) : 0.0;
-    double cnt[3] = {(double)dp.N + npri, (double)(s->num_reduced_blocks + s->num_priors_reduced), (double)s->num_reduced_params};
+    // (+ how many ranks cannot run the loop without the host — no observations, or phase timers on: every rank must take the same form of the loop)
+    const bool host_form_only = dp.N == 0 || s->timer.on || std::getenv("RSBA_DEVICE_LM_OFF_ON_THIS_RANK") != nullptr;
+    double cnt[4] = {(double)dp.N + npri, (double)(s->num_reduced_blocks + s->num_priors_reduced), (double)s->num_reduced_params, host_form_only ? 1.0 : 0.0};
     if (h->allreduce) {
       HIP_TRY(hipMemcpyAsync(sv.scalars + 8, cnt, sizeof cnt, hipMemcpyHostToDevice, st));
-      if ((rc = exchange(h, sv.scalars + 8, 3, 0, RSBA_EXCHANGE_SETUP))) return rc;
+      if ((rc = exchange(h, sv.scalars + 8, 4, 0, RSBA_EXCHANGE_SETUP))) return rc;
       HIP_TRY(hipMemcpyAsync(cnt, sv.scalars + 8, sizeof cnt, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipMemsetAsync(sv.scalars + 8, 0, 4 * sizeof(double), st));   // slots 8-11 ride in the per-iteration sum from here on
       HIP_TRY(hipStreamSynchronize(st));
     }
     sum->num_residual_blocks = (int32_t)cnt[0]; sum->num_residual_blocks_reduced = (int32_t)cnt[1]; sum->num_parameters_reduced = (int32_t)cnt[2];
+    any_rank_needs_host = cnt[3] != 0.0;
   }
   int ntrace = 0;
   auto push = [&](const rsba_iteration& it) {
@@ -1881,9 +1885,10 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
   // is where this counts: an iteration there is 0.5 ms, and the host form's 22 dependent launches, two read-backs and their gaps were
   // 0.09 ms of it.  Here an iteration is 14 launches on this stream (the small steps share launches: kernels_normal.hip) and no wait.
   // Single-GPU problems that keep no records (calibrated, or ONE shared intrinsics block), with or without motion priors of a known
-  // interFrameRatio; everything else (a free ratio, per-pose priors, per-frame intrinsics blocks, several ranks) — and a suspect factorisation — goes through the host form.
-  bool device_ctl = speculate && !h->allreduce && !free_ratio && dp.pp_count == 0 && dp.pp_spherical < 0 && !s->use_levels &&
-                    !s->timer.on && opt->max_num_iterations > 0 && dp.N > 0;
+  // interFrameRatio — on one rank or several (every rank takes the same form: settled with the problem-size exchange); everything else (a free
+  // ratio, per-pose priors, per-frame intrinsics blocks) — and a suspect factorisation — goes through the host form.
+  bool device_ctl = speculate && !free_ratio && dp.pp_count == 0 && dp.pp_spherical < 0 && !s->use_levels &&
+                    !any_rank_needs_host && opt->max_num_iterations > 0;
   if (const char* e = std::getenv("RSBA_DEVICE_LM")) device_ctl = device_ctl && e[0] != '0';   // A/B switch: 0 = the host decides
   if (device_ctl) {
     const int cap = opt->max_num_iterations + 2;
@@ -1936,28 +1941,49 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
       stopped = hc[kCtlStatus] != 0.0;
       return RSBA_OK;
     };
+    const bool multi = h->allreduce != nullptr;   // several ranks: the same loop with the three exchanges of an iteration enqueued between its kernels (RCCL: stream-ordered, no host wait)
     while (!stopped && enqueued < opt->max_num_iterations) {
       // (fourteen launches on this stream; the steps the host form spreads over twenty-two, in its order: kernels_normal.hip, "the same steps in
       // fewer launches".  The diagonal's clamp rides in the point factor's launch — after a rejected step it recomputes what is there.)
       if ((rc = factor_and_solve(h, 1.0))) return rc;   // (the radius argument is ignored: the kernels read ctl)
       HIP_TRY(launch_candidate_and_model_cost(dp, sv, st));
-      if (s->ucross) HIP_TRY(launch_prior_model(dp, sv, sv.scalars + kModelCostChange, 0.0, st));   // motion priors (known interFrameRatio): their share of the model cost change ...
+      if (s->ucross && (sv.lead || h->prior_split)) HIP_TRY(launch_prior_model(dp, sv, sv.scalars + kModelCostChange, 0.0, st));   // motion priors (known interFrameRatio): their share of the model cost change ...
       swap_params();
       HIP_TRY(launch_eval(dp, kLmJacobian, st));
       if (s->ucross) {                                                                                 // ... their cost at the candidate, behind the observations' ...
         HIP_TRY(launch_cost_reduce(dp, h->d_cost2, st));
-        HIP_TRY(launch_prior_cost(dp, h->d_cost2, h->prior_invalid, st));
+        if (sv.lead || h->prior_split) HIP_TRY(launch_prior_cost(dp, h->d_cost2, h->prior_invalid, st));
       }
       swap_params();
       if ((rc = await_verification(h))) return rc;
-      HIP_TRY(launch_lm_verdict_step(dp, sv, h->d_cost2, s->d_ctl, R, s->d_trace_it, cap, st, /*cost_reduced=*/s->ucross != nullptr));
+      const bool my_priors = s->ucross && (sv.lead || h->prior_split);
+      if (!multi) HIP_TRY(launch_lm_verdict_step(dp, sv, h->d_cost2, s->d_ctl, R, s->d_trace_it, cap, st, /*cost_reduced=*/s->ucross != nullptr));
+      else {   // several ranks: the scalars of the step are summed over the ranks between the reduction and the decision — exchange (3), enqueued like a kernel
+        if (!s->ucross) HIP_TRY(launch_cost_reduce(dp, h->d_cost2, st));
+        HIP_TRY(launch_pack_trial(dp, sv, h->d_cost2, st));
+        if ((rc = exchange(h, sv.scalars, 12, 0, RSBA_EXCHANGE_SCALARS))) return rc;
+        HIP_TRY(launch_lm_decide_step(sv, s->d_ctl, R, s->d_trace_it, cap, st));
+      }
       HIP_TRY(launch_camera_blocks(dp, sv, st, /*take_candidate=*/true, /*padding_is_zero=*/true));   // (the initial linearisation zeroed the pseudo frames' padding)
-      if (s->ucross) HIP_TRY(launch_prior_blocks(dp, sv, s->ucross, st));                              // ... and their blocks of an accepted step's linearisation
+      if (my_priors) HIP_TRY(launch_prior_blocks(dp, sv, s->ucross, st));                             // ... and their blocks of an accepted step's linearisation
       HIP_TRY(launch_intr_blocks(dp, sv, st));
       HIP_TRY(launch_point_blocks(dp, sv, st));
-      HIP_TRY(launch_lm_linearize_gradient(dp, sv, h->d_cost2, st));
       s->ctl_seq += 1.0;
-      HIP_TRY(launch_lm_verdict_gradient(dp, sv, s->d_ctl, R, s->d_trace_it, cap, s->h_ctl_dev + (size_t)(enqueued % Solver::kCtlRing) * kCtlSize, s->ctl_seq, st));
+      double* const slot = s->h_ctl_dev + (size_t)(enqueued % Solver::kCtlRing) * kCtlSize;
+      if (!multi) {
+        HIP_TRY(launch_lm_linearize_gradient(dp, sv, h->d_cost2, st));
+        HIP_TRY(launch_lm_verdict_gradient(dp, sv, s->d_ctl, R, s->d_trace_it, cap, slot, s->ctl_seq, st));
+      } else {   // exchange (1): the camera gradient, diag(U), the cost — and every rank's gradient maximum over its points — whether or not the candidate
+                 // was accepted (the host does not know): the unpacking skips itself after a rejected one, the maximum comes out as it was
+        const bool ride = h->world <= kMaxRankSlots;
+        HIP_TRY(launch_pack_linearize(dp, sv, h->d_cost2, st, ride ? h->world : 0));
+        if (ride) HIP_TRY(launch_gradient_max_points(dp, sv, h->rank, st));
+        if ((rc = exchange(h, sv.xbuf, 2 * sv.n + 3 + (ride ? h->world : 0), 0, RSBA_EXCHANGE_CAMERA))) return rc;
+        HIP_TRY(launch_unpack_linearize(dp, sv, st));
+        if (ride) HIP_TRY(launch_gradient_max_cameras(dp, sv, h->world, st));
+        else { HIP_TRY(launch_gradient_max(dp, sv, st)); if ((rc = exchange(h, sv.scalars + kGradMax, 1, 1, RSBA_EXCHANGE_SCALARS))) return rc; }
+        HIP_TRY(launch_lm_verdict_gradient(dp, sv, s->d_ctl, R, s->d_trace_it, cap, slot, s->ctl_seq, st, /*gradmax_done=*/true));
+      }
       ++enqueued;
       if (enqueued - looked > ahead) { if ((rc = look())) return rc; }
     }
@@ -1980,6 +2006,7 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
     // status -1: the persistent driver's solution of the last iteration does not satisfy its system.  Nothing of that iteration has
     // touched x or the state: the host form below repeats it, and finishes the problem, on the level schedule.
     s->use_levels = true; ++s->dag_fallbacks; ++sum->num_dag_fallbacks;
+    s->sharded_off = true;   // (a sharded factorisation goes back to the replicated one: the level schedule needs the whole of S on every rank)
     reuse_diagonal = true;   // (the diagonal is in place)
   }
   while (true) {

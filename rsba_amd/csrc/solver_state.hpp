@@ -196,7 +196,7 @@ hipError_t launch_lm_take_candidate(const DeviceProblem& dp, const SolverDev& sv
 hipError_t launch_candidate_and_model_cost(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);   // launch_model_cost_change + launch_candidate: the three sums by one launch
 hipError_t launch_lm_verdict_step(const DeviceProblem& dp, const SolverDev& sv, double* cost2, double* ctl, const LmRules& rules, rsba_iteration* trace, int trace_cap, hipStream_t st, bool cost_reduced = false);   // launch_cost_reduce (unless cost_reduced: done, the priors' cost added) + launch_pack_trial + launch_lm_decide_step
 hipError_t launch_lm_linearize_gradient(const DeviceProblem& dp, const SolverDev& sv, const double* cost2, hipStream_t st);   // launch_local_linearize + the per-workgroup maxima of launch_gradient_max
-hipError_t launch_lm_verdict_gradient(const DeviceProblem& dp, const SolverDev& sv, double* ctl, const LmRules& rules, rsba_iteration* trace, int trace_cap, double* snapshot, double seq, hipStream_t st);   // the maxima reduced + launch_lm_decide_gradient; ctl copied to `snapshot` (device-visible host memory), stamped `seq` last
+hipError_t launch_lm_verdict_gradient(const DeviceProblem& dp, const SolverDev& sv, double* ctl, const LmRules& rules, rsba_iteration* trace, int trace_cap, double* snapshot, double seq, hipStream_t st, bool gradmax_done = false);   // the maxima reduced (unless gradmax_done: scalars[kGradMax] is there) + launch_lm_decide_gradient; ctl copied to `snapshot` (device-visible host memory), stamped `seq` last
 // motion priors (kernels_prior.hip): U_f, g_f += their J^T J / J^T r, ucross[f] = the (f, f-1) block; model cost change
 hipError_t launch_prior_blocks(const DeviceProblem& dp, const SolverDev& sv, double* ucross, hipStream_t st);
 hipError_t launch_prior_model(const DeviceProblem& dp, const SolverDev& sv, double* model_cost_change, double ratio_step, hipStream_t st);

@@ -45,6 +45,8 @@ def nd_mode(mode, outdir, rank, world, dist, torch):
     if "priors" in flags:    # a motion prior between every two consecutive frames (CeresHandler.h:147-185), known interFrameRatio: each rank contributes the priors of its part
         full.prior_kind, full.prior_scale, full.inter_frame_ratio = 2, 25.0, 1.2
         full.prior_frames = np.arange(1, full.num_frames, dtype=np.int32)
+    if "hostrank" in flags and rank == 1:   # ONE rank cannot run the loop without the host (test hook of the library; in the field: a rank without observations, or with phase timers on): ALL ranks must then take the host form — their collectives pair up or the solve hangs
+        os.environ["RSBA_DEVICE_LM_OFF_ON_THIS_RANK"] = "1"
     if "corrupt" in flags:   # the first persistent-driver solve loses an entry of its result (test hook of the library): every rank must notice through exchange (3)
         os.environ["RSBA_CHOL_TEST_CORRUPT"] = "1"
     owner, ntop = capi.partition_points(full, world)
@@ -61,6 +63,7 @@ def nd_mode(mode, outdir, rank, world, dist, torch):
            "reduced": s.num_residual_blocks_reduced, "params": s.num_parameters_reduced, "costs": [t.cost for t in tr], "plan": st,
            "poses_sum": float(np.abs(shard.poses).sum()), "points_sum": float(np.abs(shard.points).sum())}
     os.environ.pop("RSBA_CHOL_TEST_CORRUPT", None)
+    os.environ.pop("RSBA_DEVICE_LM_OFF_ON_THIS_RANK", None)
     if rank == 0:
         ref = full.copy()
         with capi.DeviceProblem(ref) as d1:

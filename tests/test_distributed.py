@@ -256,3 +256,13 @@ def test_sharded_factorisation_with_motion_priors(tmp_path, mode, world):
     change.  Same trajectory as one GPU, where all priors are on the one rank."""
     res = run_two_ranks(mode, tmp_path, world)
     check_nd(res, world)
+
+
+@pytest.mark.gpu
+def test_every_rank_takes_the_same_form_of_the_trust_region_loop(tmp_path):
+    """On several ranks the loop whose decisions are taken on the device (the exchanges of an iteration enqueued between its kernels,
+    no host wait: solver.hip) is the default where it applies — the sharded tests above run it.  A rank that cannot run it says so in the
+    problem-size exchange and ALL ranks take the host form: here rank 1 of 2 is made to (test hook), and the solve still pairs its
+    collectives up and reproduces the single-GPU trajectory."""
+    res = run_two_ranks("nd:C2:6:hostrank", tmp_path, 2)
+    check_nd(res, 2)
