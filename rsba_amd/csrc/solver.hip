@@ -1143,6 +1143,9 @@ int32_t build_solver_impl(rsba_handle* h) {
   // registers per lane) — but with 384 or 512 resident workgroups the solve slows down by three orders of magnitude (waves
   // that poll share a SIMD with the waves they wait for); RSBA_CHOL_WGS is there to experiment with, capped at two per CU.
   s->dag_workgroups = std::max(1, std::min(pl.ntasks, std::max(cus, 1)));
+  // A small plan (100 cameras: 267 tasks, ~15 per elimination level) is served better by a quarter as many workgroups as tasks — fewer
+  // pollers around the chain: 0.428 -> 0.418 ms per iteration, three runs each — and leaves the rest of the chip to other streams.
+  if (pl.ntasks <= 512) s->dag_workgroups = std::max(1, std::min(s->dag_workgroups, std::max(64, pl.ntasks / 4)));
   if (const char* e = std::getenv("RSBA_CHOL_WGS")) { s->dag_workgroups = std::max(1, std::min(std::min(pl.ntasks, 2 * std::max(cus, 1)), std::atoi(e))); s->dag_one_per_cu = s->dag_workgroups <= cus; }
   if (std::getenv("RSBA_CHOL_TRACE")) {
     if ((rc = s_alloc(s, &s->d_trace, 8 * (size_t)pl.ntasks))) return rc;
