@@ -49,7 +49,10 @@ def nd_mode(mode, outdir, rank, world, dist, torch):
         os.environ["RSBA_DEVICE_LM_OFF_ON_THIS_RANK"] = "1"
     if "corrupt" in flags:   # the first persistent-driver solve loses an entry of its result (test hook of the library): every rank must notice through exchange (3)
         os.environ["RSBA_CHOL_TEST_CORRUPT"] = "1"
-    owner, ntop = capi.partition_points(full, world)
+    if "emptyrank" in flags:   # the last rank owns no point at all (a host that has fewer pieces of work than ranks): its kernels have nothing to do, its exchanges still pair up
+        owner, ntop = capi.partition_points(full, world - 1)
+    else:
+        owner, ntop = capi.partition_points(full, world)
     shard = full.shard(rank, world, owner)
     torch.cuda.set_device(0)
     opts = dict(max_num_iterations=int(iters), function_tolerance=0.0, parameter_tolerance=0.0, gradient_tolerance=0.0)

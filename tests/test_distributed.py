@@ -266,3 +266,13 @@ def test_every_rank_takes_the_same_form_of_the_trust_region_loop(tmp_path):
     collectives up and reproduces the single-GPU trajectory."""
     res = run_two_ranks("nd:C2:6:hostrank", tmp_path, 2)
     check_nd(res, 2)
+
+
+@pytest.mark.gpu
+def test_a_rank_without_observations(tmp_path):
+    """Three ranks, the points cut for two: rank 2 owns nothing.  Its evaluation, its blocks and its share of every sum are empty, it
+    still takes part in every exchange, says in the problem-size exchange that it needs the host form of the loop (all ranks follow),
+    and the plan falls back to the replicated factorisation (the points do not respect a three-way cut).  Same trajectory as one GPU."""
+    res = run_two_ranks("nd:C2:6:emptyrank", tmp_path, 3)
+    a = check_nd(res, 3, sharded=False)
+    assert sorted(o["n_shard"] for o in res)[0] == 0
