@@ -62,19 +62,18 @@ __device__ __forceinline__ double u_diag(const SolverDev& sv, int64_t t) {
 // blocks on and below the diagonal of G = [Ji | Jc | r]^T [Ji | Jc | r] per frame it touches.  Here one workgroup
 // per frame sums its waves' partials in wave order (fixed order: deterministic) and files the entries of G.
 // ---------------------------------------------------------------------------------------------
+// lm_take_candidate_kernel's copy, by workgroup `block` of a launch that carries it along
+__device__ __forceinline__ void take_candidate_block(const DeviceProblem& dp, const SolverDev& sv, int64_t block) {
+  const int64_t t = block * 256 + threadIdx.x, npose = (int64_t)dp.F * dp.P * 6, npoint = 3 * (int64_t)dp.M, nintr = sv.NPF > 0 ? (int64_t)dp.NI * 9 : 0;
+  if (t < npose) dp.poses[t] = sv.trial_poses[t];
+  else if (t < npose + npoint) dp.points[t - npose] = sv.trial_points[t - npose];
+  else if (t < npose + npoint + nintr) dp.intr[t - npose - npoint] = sv.trial_intr[t - npose - npoint];
+}
 template <int CD, bool CAL>
-__global__ __launch_bounds__(256) void camera_reduce_kernel(const DeviceProblem dp, const SolverDev sv) {
-  if (lm_not_accepted(sv.ctl)) return;   // (device-side trust region: a rejected candidate is not linearised)
-  if ((int)blockIdx.x >= dp.F) {          // workgroups behind the frames' (launch_camera_blocks with take_candidate): lm_take_candidate_kernel's job — this kernel reads no parameters
-    const int64_t t = ((int64_t)blockIdx.x - dp.F) * 256 + threadIdx.x, npose = (int64_t)dp.F * dp.P * 6, npoint = 3 * (int64_t)dp.M, nintr = sv.NPF > 0 ? (int64_t)dp.NI * 9 : 0;
-    if (t < npose) dp.poses[t] = sv.trial_poses[t];
-    else if (t < npose + npoint) dp.points[t - npose] = sv.trial_points[t - npose];
-    else if (t < npose + npoint + nintr) dp.intr[t - npose - npoint] = sv.trial_intr[t - npose - npoint];
-    return;
-  }
+__device__ __forceinline__ void camera_reduce_frame(const DeviceProblem& dp, const SolverDev& sv, const int f) {
   constexpr int NI = CAL ? 0 : 9, NCOL = NI + CD + 1, NCB = (NCOL + 15) / 16, NBLK = NCB * (NCB + 1) / 2;
   __shared__ double G[NBLK][256];
-  const int f = blockIdx.x, e = threadIdx.x;
+  const int e = threadIdx.x;
   const int64_t s0 = sv.frame_ptr[f], s1 = sv.frame_ptr[f + 1];
   double sum[NBLK];
 #pragma unroll
@@ -129,6 +128,12 @@ __global__ __launch_bounds__(256) void camera_reduce_kernel(const DeviceProblem 
       sv.intr_part[(size_t)f * 54 + e] = v;
     }
   }
+}
+template <int CD, bool CAL>
+__global__ __launch_bounds__(256) void camera_reduce_kernel(const DeviceProblem dp, const SolverDev sv) {
+  if (lm_not_accepted(sv.ctl)) return;   // (device-side trust region: a rejected candidate is not linearised)
+  if ((int)blockIdx.x >= dp.F) { take_candidate_block(dp, sv, (int64_t)blockIdx.x - dp.F); return; }   // workgroups behind the frames' (launch_camera_blocks with take_candidate) — this kernel reads no parameters
+  camera_reduce_frame<CD, CAL>(dp, sv, (int)blockIdx.x);
 }
 
 // one workgroup per (intrinsics block c, entry t of the 45 + 9 sums): lanes stride the frames that use the block (in
@@ -853,12 +858,12 @@ inline int sweep_points(int64_t M) {
 // this, the other 48 waited through 20 x NC dependent LDS reads and adds per point: most of the sweep's time (the virtual-record sweep
 // of a shared intrinsics block, NC = 27, took 0.91 ms at 4k cameras against 0.35 for NC = 9 over the same records).
 template <bool CAL, int P, int NC, class PerSlot, class PerPoint>
-__device__ __forceinline__ double point_sweep(const DeviceProblem& dp, const SolverDev& sv, double* smem, int sp, PerSlot per_slot, PerPoint per_point) {
+__device__ __forceinline__ double point_sweep(const DeviceProblem& dp, const SolverDev& sv, double* smem, int sp, int64_t block, PerSlot per_slot, PerPoint per_point) {
   constexpr int NPAIR = kSweepPoints * NC, PER = (NPAIR + 63) / 64;   // (sized for the most points a wave takes; sp <= kSweepPoints of them this launch)
   __shared__ double s_red[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double* cbuf = smem + (size_t)wave * (64 * NC);
-  const int64_t j0 = ((int64_t)blockIdx.x * 4 + wave) * sp;
+  const int64_t j0 = (block * 4 + wave) * sp;
   double ret = 0.0;
   auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
   if (j0 < dp.M) {   // wave-uniform
@@ -916,11 +921,9 @@ __device__ __forceinline__ double point_sweep(const DeviceProblem& dp, const Sol
 
 // K2b without records: V_j, g_p,j
 template <bool CAL, int P>
-__global__ __launch_bounds__(256) void point_blocks_rc_kernel(const DeviceProblem dp, const SolverDev sv, int sp) {
-  if (lm_not_accepted(sv.ctl)) return;
+__device__ __forceinline__ void point_blocks_sweep(const DeviceProblem& dp, const SolverDev& sv, double* smem, int sp, int64_t block) {
   constexpr int CD = (CAL ? 0 : 9) + 6 * P;   // columns in front of the point's
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  point_sweep<CAL, P, 9>(dp, sv, smem, sp,
+  point_sweep<CAL, P, 9>(dp, sv, smem, sp, block,
     [&](const ObsOut<CAL, P>& o, int, int, double c[9]) {
       const double r0 = o.r[0], r1 = o.r[1], p0[3] = {o.J[0][CD], o.J[0][CD + 1], o.J[0][CD + 2]}, p1[3] = {o.J[1][CD], o.J[1][CD + 1], o.J[1][CD + 2]};
       c[0] = p0[0] * p0[0] + p1[0] * p1[0]; c[1] = p0[0] * p0[1] + p1[0] * p1[1]; c[2] = p0[0] * p0[2] + p1[0] * p1[2];
@@ -936,6 +939,24 @@ __global__ __launch_bounds__(256) void point_blocks_rc_kernel(const DeviceProble
       return 0.0;
     });
 }
+template <bool CAL, int P>
+__global__ __launch_bounds__(256) void point_blocks_rc_kernel(const DeviceProblem dp, const SolverDev sv, int sp) {
+  if (lm_not_accepted(sv.ctl)) return;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  point_blocks_sweep<CAL, P>(dp, sv, smem, sp, blockIdx.x);
+}
+// The linearisation of an accepted candidate in ONE launch (the loop that runs without the host): the frames' camera blocks, the copy of
+// the candidate over x, and the points' blocks side by side — neither reads what the other writes; the point sweeps read the candidate
+// where it still lies (dq: dp with the trial buffers for parameters), since the copy over x is in flight beside them.
+template <bool CAL, int P>
+__global__ __launch_bounds__(256) void linearize_blocks_kernel(const DeviceProblem dp, const DeviceProblem dq, const SolverDev sv, int sp, int ntake) {
+  if (lm_not_accepted(sv.ctl)) return;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int b = blockIdx.x;
+  if (b < dp.F) camera_reduce_frame<6 * P, CAL>(dp, sv, b);
+  else if (b < dp.F + ntake) take_candidate_block(dp, sv, b - dp.F);
+  else point_blocks_sweep<CAL, P>(dq, sv, smem, sp, (int64_t)b - dp.F - ntake);
+}
 
 // K7 + K8 without records (see point_step_kernel)
 template <bool CAL, int P>
@@ -943,7 +964,7 @@ __global__ __launch_bounds__(256) void point_step_rc_kernel(const DeviceProblem 
   if (lm_stopped(sv.ctl)) return;
   constexpr int CD = 6 * P, OP = CAL ? 0 : 9, OX = OP + CD;
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  const double mc = point_sweep<CAL, P, 5>(dp, sv, smem, sp,
+  const double mc = point_sweep<CAL, P, 5>(dp, sv, smem, sp, blockIdx.x,
     [&](const ObsOut<CAL, P>& o, int frame, int, double c[5]) {
       const double* yc = sv.step + (size_t)frame * CD;
       double t0 = 0.0, t1 = 0.0;
@@ -982,7 +1003,7 @@ __global__ __launch_bounds__(256) void virtual_records_rc_kernel(const DevicePro
   if (lm_stopped(sv.ctl)) return;
   constexpr int CD = 6 * P, OX = 9 + CD, FT = kTile / CD;
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  point_sweep<false, P, 27>(dp, sv, smem, sp,
+  point_sweep<false, P, 27>(dp, sv, smem, sp, blockIdx.x,
     [&](const ObsOut<false, P>& o, int, int j, double c[27]) {
       const double* li = sv.Linv + (size_t)j * 6;
       const double i00 = li[0], i10 = li[1], i11 = li[2], i20 = li[3], i21 = li[4], i22 = li[5];
@@ -1339,6 +1360,23 @@ hipError_t launch_camera_blocks(const DeviceProblem& dp, const SolverDev& sv, hi
   if (sv.CD == 12) { if (dp.calibrated) LAUNCH((camera_reduce_kernel<12, true>), grid, 256, st, dp, sv); else LAUNCH((camera_reduce_kernel<12, false>), grid, 256, st, dp, sv); }
   else { if (dp.calibrated) LAUNCH((camera_reduce_kernel<6, true>), grid, 256, st, dp, sv); else LAUNCH((camera_reduce_kernel<6, false>), grid, 256, st, dp, sv); }
   return hipSuccess;
+}
+// camera blocks + the accepted candidate's copy over x + point blocks by one launch (linearize_blocks_kernel); *done = false: not for
+// this problem (records kept, or nothing to sweep) — the caller launches them one after the other
+hipError_t launch_linearize_blocks(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st, bool* done) {
+  *done = false;
+  if (!sv.slot_xy || !dp.cam_part || dp.M <= 0 || dp.F <= 0) return hipSuccess;
+  DeviceProblem dq = dp;
+  dq.poses = sv.trial_poses; dq.points = sv.trial_points;
+  if (sv.NPF > 0) dq.intr = sv.trial_intr;
+  const int64_t nparam = (int64_t)dp.F * dp.P * 6 + 3 * (int64_t)dp.M + (sv.NPF > 0 ? 9 * (int64_t)dp.NI : 0);
+  const int ntake = (int)((nparam + 255) / 256), sp = sweep_points(dp.M), npts = (int)((dp.M + 4 * sp - 1) / (4 * sp));
+  const size_t lds = (size_t)4 * 64 * 9 * sizeof(double);
+  const dim3 grid((unsigned)(dp.F + ntake + npts));
+  if (dp.calibrated) { if (sv.CD == 12) hipLaunchKernelGGL((linearize_blocks_kernel<true, 2>), grid, dim3(256), lds, st, dp, dq, sv, sp, ntake); else hipLaunchKernelGGL((linearize_blocks_kernel<true, 1>), grid, dim3(256), lds, st, dp, dq, sv, sp, ntake); }
+  else { if (sv.CD == 12) hipLaunchKernelGGL((linearize_blocks_kernel<false, 2>), grid, dim3(256), lds, st, dp, dq, sv, sp, ntake); else hipLaunchKernelGGL((linearize_blocks_kernel<false, 1>), grid, dim3(256), lds, st, dp, dq, sv, sp, ntake); }
+  *done = true;
+  return hipGetLastError();
 }
 hipError_t launch_slot_xy(const DeviceProblem& dp, double2* slot_xy, hipStream_t st) {
   if (dp.N > 0) LAUNCH(slot_xy_kernel, nblocks256(dp.N), 256, st, dp, slot_xy);

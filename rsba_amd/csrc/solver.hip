@@ -1967,10 +1967,12 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
         if ((rc = exchange(h, sv.scalars, 12, 0, RSBA_EXCHANGE_SCALARS))) return rc;
         HIP_TRY(launch_lm_decide_step(sv, s->d_ctl, R, s->d_trace_it, cap, st));
       }
-      HIP_TRY(launch_camera_blocks(dp, sv, st, /*take_candidate=*/true, /*padding_is_zero=*/true));   // (the initial linearisation zeroed the pseudo frames' padding)
+      bool fused = false;
+      HIP_TRY(launch_linearize_blocks(dp, sv, st, &fused));   // camera blocks, the accepted candidate's copy over x, point blocks: side by side in one launch
+      if (!fused) HIP_TRY(launch_camera_blocks(dp, sv, st, /*take_candidate=*/true, /*padding_is_zero=*/true));   // (the initial linearisation zeroed the pseudo frames' padding)
       if (my_priors) HIP_TRY(launch_prior_blocks(dp, sv, s->ucross, st));                             // ... and their blocks of an accepted step's linearisation
       HIP_TRY(launch_intr_blocks(dp, sv, st));
-      HIP_TRY(launch_point_blocks(dp, sv, st));
+      if (!fused) HIP_TRY(launch_point_blocks(dp, sv, st));
       s->ctl_seq += 1.0;
       double* const slot = s->h_ctl_dev + (size_t)(enqueued % Solver::kCtlRing) * kCtlSize;
       if (!multi) {

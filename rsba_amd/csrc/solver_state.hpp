@@ -191,6 +191,7 @@ hipError_t launch_candidate(const DeviceProblem& dp, const SolverDev& sv, hipStr
 struct LmRules { int32_t max_num_iterations, max_num_consecutive_invalid_steps; double max_trust_region_radius, min_trust_region_radius, min_relative_decrease, function_tolerance, gradient_tolerance, parameter_tolerance; };
 hipError_t launch_lm_decide_step(const SolverDev& sv, double* ctl, const LmRules& rules, rsba_iteration* trace, int trace_cap, hipStream_t st);
 hipError_t launch_lm_decide_gradient(const SolverDev& sv, double* ctl, const LmRules& rules, rsba_iteration* trace, int trace_cap, hipStream_t st);
+hipError_t launch_linearize_blocks(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st, bool* done);   // launch_camera_blocks(take_candidate) + launch_point_blocks by one launch, where that applies
 hipError_t launch_lm_take_candidate(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);   // x = x + delta where ctl says "accepted"
 // the same steps in fewer launches, for the loop that runs without the host (solver.hip: device-side trust region) — same arithmetic, same order:
 hipError_t launch_candidate_and_model_cost(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);   // launch_model_cost_change + launch_candidate: the three sums by one launch
