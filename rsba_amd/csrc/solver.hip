@@ -1899,7 +1899,7 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
   // kernels of an iteration read the radius there and skip themselves where the host form would not have launched them (a rejected
   // candidate is not linearised).  What the reference calls per frame — windowedBA over ~100 cameras (VideoSfMClient.cc:241-246) —
   // is where this counts: an iteration there is 0.5 ms, and the host form's 22 dependent launches, two read-backs and their gaps were
-  // 0.09 ms of it.  Here an iteration is 14 launches on this stream (the small steps share launches: kernels_normal.hip) and no wait.
+  // 0.09 ms of it.  Here an iteration is 13 launches on this stream (the small steps share launches: kernels_normal.hip) and no wait.
   // Single-GPU problems that keep no records (calibrated, or ONE shared intrinsics block), with or without motion priors of a known
   // interFrameRatio — on one rank or several (every rank takes the same form: settled with the problem-size exchange); everything else (a free
   // ratio, per-pose priors, per-frame intrinsics blocks) — and a suspect factorisation — goes through the host form.
@@ -1959,7 +1959,7 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
     };
     const bool multi = h->allreduce != nullptr;   // several ranks: the same loop with the three exchanges of an iteration enqueued between its kernels (RCCL: stream-ordered, no host wait)
     while (!stopped && enqueued < opt->max_num_iterations) {
-      // (fourteen launches on this stream; the steps the host form spreads over twenty-two, in its order: kernels_normal.hip, "the same steps in
+      // (thirteen launches on this stream; the steps the host form spreads over twenty-two, in its order: kernels_normal.hip, "the same steps in
       // fewer launches".  The diagonal's clamp rides in the point factor's launch — after a rejected step it recomputes what is there.)
       if ((rc = factor_and_solve(h, 1.0))) return rc;   // (the radius argument is ignored: the kernels read ctl)
       HIP_TRY(launch_candidate_and_model_cost(dp, sv, st));
