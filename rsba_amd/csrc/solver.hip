@@ -293,15 +293,47 @@ int32_t build_solver_impl(rsba_handle* h) {
   std::unique_ptr<PlanScratch> own_scratch;
   if (scratch_lock.owns_lock()) { if (!g_plan_scratch) g_plan_scratch.reset(new PlanScratch()); } else own_scratch.reset(new PlanScratch());
   PlanScratch& scr = scratch_lock.owns_lock() ? *g_plan_scratch : *own_scratch;
+  // host threads of the passes over observations / points / entries: sixteen are worth their start-up (~1 ms on a busy 256-thread host)
+  // from a few hundred thousand observations on; a 100-camera window (187 k) plans fastest on four — symbolic phase 4.1 / 3.9 / 2.8 /
+  // 3.4 ms on 1 / 2 / 4 / 8 threads (RSBA_PLAN_THREADS overrides: A/B)
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  int plan_threads = N >= 400000 ? (int)std::min(16u, hw) : N >= 50000 ? (int)std::min(4u, hw) : 1;
+  if (const char* e = std::getenv("RSBA_PLAN_THREADS")) plan_threads = std::max(1, std::min(64, std::atoi(e)));
   std::vector<int64_t> frame_ptr(FR + 1, 0);
   std::vector<int64_t>& point_ptr = scr.point_ptr; point_ptr.assign((size_t)M + 1, 0);
-  for (int64_t i = 0; i < N; ++i) { frame_ptr[of[i] + 1]++; point_ptr[op[i] + 1]++; }
-  for (int f = 0; f < FR; ++f) frame_ptr[f + 1] += frame_ptr[f];
-  for (int j = 0; j < M; ++j) point_ptr[j + 1] += point_ptr[j];
-  // slots: stable counting sort of the frame-major list by point -> ascending frame inside a point
+  // slots: stable counting sort of the frame-major list by point -> ascending frame inside a point.  On several threads: every
+  // thread counts the points of ITS range of observations, the counts of the threads before it are where its share of a point's
+  // slots starts — the slots come out exactly as from one thread.
   std::vector<int32_t>& obs_slot = scr.obs_slot; obs_slot.resize((size_t)N);
   std::vector<int32_t>& real_frame = scr.real_frame; real_frame.resize((size_t)N);
-  {
+  const int nthr_obs = (N >= 200000 && (int64_t)plan_threads * M <= ((int64_t)1 << 26)) ? plan_threads : 1;
+  if (nthr_obs > 1) {
+    std::vector<std::vector<int32_t>> cnt((size_t)nthr_obs);
+    std::vector<std::vector<int64_t>> fcnt((size_t)nthr_obs);
+    parallel_ranges(nthr_obs, N, [&](int64_t a, int64_t b, int t) {
+      std::vector<int32_t>& c = cnt[(size_t)t]; c.assign((size_t)M, 0);
+      std::vector<int64_t>& fc = fcnt[(size_t)t]; fc.assign((size_t)FR, 0);
+      for (int64_t i = a; i < b; ++i) { ++c[op[i]]; ++fc[of[i]]; }
+    });
+    for (int f = 0; f < FR; ++f) { int64_t sum = 0; for (int t = 0; t < nthr_obs; ++t) sum += fcnt[(size_t)t][f]; frame_ptr[f + 1] = frame_ptr[f] + sum; }
+    // point_ptr, and per thread the first slot of its share of every point (in place of its count)
+    parallel_ranges(nthr_obs, M, [&](int64_t a, int64_t b, int) {
+      for (int64_t j = a; j < b; ++j) { int64_t sum = 0; for (int t = 0; t < nthr_obs; ++t) sum += cnt[(size_t)t][j]; point_ptr[j + 1] = sum; }
+    });
+    for (int j = 0; j < M; ++j) point_ptr[j + 1] += point_ptr[j];
+    std::vector<std::vector<int64_t>> first((size_t)nthr_obs);
+    for (auto& v : first) v.resize((size_t)M);
+    parallel_ranges(nthr_obs, M, [&](int64_t a, int64_t b, int) {
+      for (int64_t j = a; j < b; ++j) { int64_t at = point_ptr[j]; for (int t = 0; t < nthr_obs; ++t) { first[(size_t)t][j] = at; at += cnt[(size_t)t][j]; } }
+    });
+    parallel_ranges(nthr_obs, N, [&](int64_t a, int64_t b, int t) {
+      std::vector<int64_t>& fill = first[(size_t)t];
+      for (int64_t i = a; i < b; ++i) { const int64_t sl = fill[op[i]]++; obs_slot[i] = (int32_t)sl; real_frame[sl] = of[i]; }
+    });
+  } else {
+    for (int64_t i = 0; i < N; ++i) { frame_ptr[of[i] + 1]++; point_ptr[op[i] + 1]++; }
+    for (int f = 0; f < FR; ++f) frame_ptr[f + 1] += frame_ptr[f];
+    for (int j = 0; j < M; ++j) point_ptr[j + 1] += point_ptr[j];
     std::vector<int64_t>& fill = scr.fill; fill.assign(point_ptr.begin(), point_ptr.end() - 1);
     for (int64_t i = 0; i < N; ++i) { const int64_t sl = fill[op[i]]++; obs_slot[i] = (int32_t)sl; real_frame[sl] = of[i]; }
   }
@@ -310,7 +342,13 @@ int32_t build_solver_impl(rsba_handle* h) {
   std::vector<int64_t>& vgroup_ptr = scr.vgroup_ptr; vgroup_ptr.assign((size_t)M + 1, 0);
   std::vector<int32_t>& vgroup_point = scr.vgroup_point; std::vector<int32_t>& vgroup_intr = scr.vgroup_intr;
   vgroup_point.clear(); vgroup_intr.clear();
-  if (NIB > 0) {
+  if (NIB == 1) {   // one shared block (the usual uncalibrated session): every observed point is seen through it — no lists to sort
+    vgroup_point.reserve((size_t)M); vgroup_intr.reserve((size_t)M);
+    for (int j = 0; j < M; ++j) {
+      if (point_ptr[j + 1] > point_ptr[j]) { vgroup_point.push_back(j); vgroup_intr.push_back(0); }
+      vgroup_ptr[j + 1] = (int64_t)vgroup_point.size();
+    }
+  } else if (NIB > 0) {
     std::vector<int32_t> seen;
     for (int j = 0; j < M; ++j) {
       seen.clear();
@@ -325,8 +363,8 @@ int32_t build_solver_impl(rsba_handle* h) {
   const int64_t NS = N + NVG * NPF;
   std::vector<int32_t>& slot_frame = scr.slot_frame; slot_frame.resize((size_t)NS);
   std::vector<int32_t>& slot_point = scr.slot_point; slot_point.resize((size_t)NS);
-  for (int64_t x = 0; x < N; ++x) slot_frame[x] = real_frame[x];
-  for (int j = 0; j < M; ++j) for (int64_t x = point_ptr[j]; x < point_ptr[j + 1]; ++x) slot_point[x] = j;
+  parallel_ranges(nthr_obs, N, [&](int64_t a, int64_t b, int) { for (int64_t x = a; x < b; ++x) slot_frame[x] = real_frame[x]; });
+  parallel_ranges(nthr_obs, M, [&](int64_t a, int64_t b, int) { for (int64_t j = a; j < b; ++j) for (int64_t x = point_ptr[j]; x < point_ptr[j + 1]; ++x) slot_point[x] = (int32_t)j; });
   for (int64_t g = 0; g < NVG; ++g) for (int v = 0; v < NPF; ++v) { slot_frame[N + g * NPF + v] = FR + vgroup_intr[g] * NPF + v; slot_point[N + g * NPF + v] = vgroup_point[g]; }
   // the slots of point j in ascending frame order (virtual ones last, by intrinsics block; only for points that are observed)
   auto slots_of = [&](int j, std::vector<int64_t>& out) {
@@ -354,12 +392,6 @@ int32_t build_solver_impl(rsba_handle* h) {
   std::vector<int32_t>& slot_gpos = scr.slot_gpos; slot_gpos.resize((size_t)NS);           // group * FT + position of every slot: where its P record goes
   std::vector<uint8_t>& group_mask = scr.group_mask;        // which of the three 16-row blocks of a group's records can be non-zero
   std::vector<uint8_t>& group_present = scr.group_present;  // frames of the group's tile that see the point (plan statistics)
-  // host threads of the passes over points / entries: sixteen are worth their start-up (~1 ms on a busy 256-thread host) from a few
-  // hundred thousand observations on; a 100-camera window (187 k) plans fastest on four — symbolic phase 4.1 / 3.9 / 2.8 / 3.4 ms on
-  // 1 / 2 / 4 / 8 threads (RSBA_PLAN_THREADS overrides: A/B)
-  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-  int plan_threads = N >= 400000 ? (int)std::min(16u, hw) : N >= 50000 ? (int)std::min(4u, hw) : 1;
-  if (const char* e = std::getenv("RSBA_PLAN_THREADS")) plan_threads = std::max(1, std::min(64, std::atoi(e)));
   const int nthr_pts = M >= 4096 ? plan_threads : 1;
   {
     // one walk over a point's slots: on_group(g, tile) for every new (tile, layer) group g = 0, 1, .. of the point, on_slot(g, pos, slot)
