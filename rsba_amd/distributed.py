@@ -143,7 +143,16 @@ def solve_timed(dp, prob, world: int, iters: int):
     prob.poses[:], prob.points[:], prob.intrinsics[:] = saved
     dp.upload_parameters()
     n_it = max(1, s.num_iterations - 1)
-    return {"iterations": n_it, "ms_per_lm_iteration": s.total_time_s / n_it * 1e3, "wall_s": wall, "first_solve_wall_s": wall_first,
+    # what ONE MORE iteration costs: a solve of twice as many iterations against this one (the quotient above also carries iteration 0 —
+    # the initial evaluation, two linearisations, the Jacobi scales — and the write-back)
+    s2, _ = dp.solve(capi.default_options(max_num_iterations=2 * iters, function_tolerance=0.0, parameter_tolerance=0.0, gradient_tolerance=0.0))
+    prob.poses[:], prob.points[:], prob.intrinsics[:] = saved
+    dp.upload_parameters()
+    extra = s2.num_iterations - s.num_iterations
+    marginal = (s2.total_time_s - s.total_time_s) / extra * 1e3 if extra > 0 else None
+    return {"iterations": n_it, "ms_per_lm_iteration": s.total_time_s / n_it * 1e3, "marginal_ms_per_lm_iteration": marginal,
+            "marginal_note": "(time of a solve of twice as many iterations - time of this one) / the extra iterations: the steady-state cost of an iteration",
+            "wall_s": wall, "first_solve_wall_s": wall_first,
             "initial_cost": s.initial_cost, "final_cost": s.final_cost,
             "residual_jacobian_s": s.residual_jacobian_time_s, "linear_solver_s": s.linear_solver_time_s,
             "n_gpus": world, "note": "second solve on the same handle (symbolic phase already done); the first took first_solve_wall_s"}
