@@ -156,6 +156,7 @@ def device_count() -> int:
 
 
 def make_desc(prob: BAProblem) -> ProblemDesc:
+    prob.__post_init__()   # (arrays assigned after construction may have another dtype or layout: the pointers below must be what the C side reads; a no-op when they already are)
     d = ProblemDesc()
     d.shutter = int(prob.shutter)
     d.scanlines[0], d.scanlines[1] = int(prob.scanlines[0]), int(prob.scanlines[1])

@@ -177,6 +177,40 @@ def test_partition_points_cuts_along_separators(config, worlds):
     assert not one.any() and ntop == 0
 
 
+@pytest.mark.parametrize("kind", ["loop_closure", "shuffled_point_numbers"])
+def test_partition_points_on_graphs_that_are_not_a_plain_band(kind):
+    """The cut is a frontier of a linear arrangement of the tile graph, whatever the graph: a video that revisits a place (5 % of the points
+    seen again 200 frames later: long-range edges) is still cut validly — the tile columns that more than one rank's points are seen in are
+    the separators' — and the numbering of the points (here: shuffled, so that a point's number says nothing about where it is seen) does
+    not enter the cut at all."""
+    from rsba_amd import capi
+    from rsba_amd.scene import make_scene
+    rng = np.random.default_rng(0)
+    p = make_scene(400, 20000, seed=5).problem
+    FT, M = 4, p.num_points
+    nt = (p.num_frames + FT - 1) // FT
+    base = {w: capi.partition_points(p, w) for w in (2, 4)}
+    if kind == "loop_closure":
+        first = np.full(M, 10**9); np.minimum.at(first, p.obs_point, p.obs_frame)
+        again = rng.choice(M, M // 20, replace=False)
+        ef = np.concatenate([(first[j] + 200 + np.arange(6)) % p.num_frames for j in again]); ep = np.repeat(again, 6)
+        order = np.argsort(np.concatenate([p.obs_frame, ef]), kind="stable")
+        p.obs_frame = np.concatenate([p.obs_frame, ef])[order]; p.obs_point = np.concatenate([p.obs_point, ep])[order]
+        p.obs_xy = np.concatenate([p.obs_xy, np.zeros((len(ef), 2))])[order]
+    else:
+        perm = rng.permutation(M)
+        p.obs_point = perm[p.obs_point]      # (an int64 array: the binding coerces what it hands to the C side)
+    for world in (2, 4):
+        owner, ntop = capi.partition_points(p, world)
+        load = np.bincount(owner[p.obs_point], minlength=world)
+        touched = np.zeros((world, nt), dtype=bool)
+        touched[owner[p.obs_point], p.obs_frame // FT] = True
+        assert load.min() > 0 and load.max() <= 1.2 * load.mean()
+        assert 0 < int((touched.sum(0) > 1).sum()) <= ntop <= (0.6 if kind == "loop_closure" else 0.4) * nt   # (long-range edges double a separator: both places it touches)
+        if kind == "shuffled_point_numbers":   # same cut, the owners follow the points
+            assert ntop == base[world][1]
+
+
 def test_partition_points_refuses_what_cannot_be_cut():
     from rsba_amd import capi
     from rsba_amd.scene import make_scene
