@@ -247,10 +247,12 @@ class DeviceProblem:
 
     def upload_parameters(self):
         p = self.prob
+        p.__post_init__()   # (arrays assigned since construction: dtype / layout as the C side reads them)
         _check(lib().rsba_upload_parameters(self._h, _ptr(p.poses), _ptr(p.points), _ptr(p.intrinsics)))
 
     def download_parameters(self):
         p = self.prob
+        p.__post_init__()
         _check(lib().rsba_download_parameters(self._h, _ptr(p.poses), _ptr(p.points), _ptr(p.intrinsics)))
 
     def evaluate_device(self, with_jacobians: bool = True):
