@@ -473,10 +473,50 @@ int32_t build_solver_impl(rsba_handle* h) {
   // The two passes over all (point, tile pair) entries — count, then fill — are most of the symbolic phase (2 M entries at 1k cameras):
   // with dense keys they run on a few host threads over contiguous point ranges, each with its own counters per tile pair, and
   // the fill starts every thread where the threads before it end: the entry lists come out exactly as from one thread.
-  const int nthreads = dense_keys && (int64_t)nt * nt <= ((int64_t)1 << 22) && M >= 4096 ? plan_threads : 1;   // (per-thread counters: 4 nt^2 bytes each)
+  // Beyond 2 048 tile columns (8 k cameras) a counter per tile pair and thread would be 4 nt^2 bytes each: the threads first mark which
+  // pairs exist (one shared byte map), the pairs are numbered, and the per-thread counters are as long as that list (~9 nt).
+  const bool small_keys = dense_keys && (int64_t)nt * nt <= ((int64_t)1 << 22) && !std::getenv("RSBA_PLAN_LISTED_KEYS");   // (the variable: the large-problem path at any size — its plan must be the same)
+  const bool listed_keys = dense_keys && !small_keys && plan_threads > 1;
+  const int nthreads = (small_keys || listed_keys) && M >= 4096 ? plan_threads : 1;   // (small_keys: per-thread counters of 4 nt^2 bytes)
   std::vector<std::vector<int32_t>>& thread_cnt = scr.thread_cnt; thread_cnt.resize(nthreads > 1 ? nthreads : 0);
   auto point_range = [&](int t) { return std::pair<int, int>((int)((int64_t)M * t / nthreads), (int)((int64_t)M * (t + 1) / nthreads)); };
-  if (nthreads > 1) {
+  std::vector<int32_t> pair_no;   // listed_keys: key -> number of the pair in (I, J) order (what dense_index will hold further down)
+  if (nthreads > 1 && listed_keys) {
+    std::vector<uint8_t> seen((size_t)nt * nt, 0);
+    {
+      std::vector<std::thread> pool;
+      for (int t = 0; t < nthreads; ++t)
+        pool.emplace_back([&, t]() {
+          const auto r = point_range(t);
+          for (int j = r.first; j < r.second; ++j) for_each_entry(j, [&](int64_t gx, int64_t gy) { __atomic_store_n(&seen[(size_t)g_tile[gx] * nt + g_tile[gy]], (uint8_t)1, __ATOMIC_RELAXED); });
+        });
+      for (auto& th : pool) th.join();
+    }
+    pair_no.assign((size_t)nt * nt, -1);
+    int32_t np = 0;
+    for (int I = 0; I < nt; ++I) for (int J = 0; J <= I; ++J) {
+      const size_t key = (size_t)I * nt + J;
+      if (seen[key] && dense_cnt[key] < 0) dense_cnt[key] = 0;   // the pair exists (its entries are counted below)
+      if (dense_cnt[key] >= 0) pair_no[key] = np++;
+    }
+    std::vector<uint8_t>().swap(seen);
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nthreads; ++t)
+      pool.emplace_back([&, t]() {
+        std::vector<int32_t>& c = thread_cnt[t];
+        c.assign((size_t)np, 0);
+        const auto r = point_range(t);
+        for (int j = r.first; j < r.second; ++j) for_each_entry(j, [&](int64_t gx, int64_t gy) { ++c[pair_no[(size_t)g_tile[gx] * nt + g_tile[gy]]]; });
+      });
+    for (auto& th : pool) th.join();
+    for (int I = 0; I < nt; ++I) for (int J = 0; J <= I; ++J) {
+      const size_t key = (size_t)I * nt + J;
+      if (pair_no[key] < 0) continue;
+      int64_t sum = 0;
+      for (int t = 0; t < nthreads; ++t) sum += thread_cnt[t][pair_no[key]];
+      dense_cnt[key] += sum;
+    }
+  } else if (nthreads > 1) {
     std::vector<std::thread> pool;
     for (int t = 0; t < nthreads; ++t)
       pool.emplace_back([&, t]() {
@@ -519,7 +559,7 @@ int32_t build_solver_impl(rsba_handle* h) {
       // per thread and tile pair: where its entries start (the counters become cursors)
       std::vector<std::vector<int64_t>> cursor(nthreads, std::vector<int64_t>(tp_I.size(), 0));
       for (size_t t_ = 0; t_ < tp_I.size(); ++t_) {
-        const size_t key = (size_t)tp_I[t_] * nt + tp_J[t_];
+        const size_t key = listed_keys ? t_ : (size_t)tp_I[t_] * nt + tp_J[t_];   // (listed_keys: the counters are indexed by the pair's number, which is t_)
         int64_t at = fill[t_];
         for (int t = 0; t < nthreads; ++t) { cursor[t][t_] = at; at += thread_cnt[t][key]; }
       }
