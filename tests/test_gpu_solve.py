@@ -533,3 +533,22 @@ def test_device_side_trust_region_equals_the_host_form(capi, monkeypatch, case):
         assert ref[1][0] == 1 and ref[1][3] == 4      # NO_CONVERGENCE after 3 iterations (+ the record of iteration 0)
     if case == "tolerances":
         assert ref[1][0] == 0
+
+
+def test_the_large_problem_path_of_the_symbolic_phase_builds_the_same_plan(capi, monkeypatch):
+    """Beyond 2 048 tile columns the entry passes of the symbolic phase list the tile pairs that exist before they count (per-thread counters
+    as long as the list instead of 4 nt^2 bytes each).  RSBA_PLAN_LISTED_KEYS=1 takes that path at any size: same plan figures, and a
+    solve whose every bit is the same."""
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.delenv("RSBA_PLAN_LISTED_KEYS", raising=False)
+        if mode == "1":
+            monkeypatch.setenv("RSBA_PLAN_LISTED_KEYS", "1")
+        p = small_scene(frames=60, points=6000, seed=4)     # (4 096 points and more: the passes run on several threads)
+        with capi.DeviceProblem(p) as dp:
+            s, tr = dp.solve(capi.default_options(max_num_iterations=5))
+            st = dp.plan_stats()
+        out[mode] = (s.final_cost, [t.cost for t in tr], p.poses.copy(), p.points.copy(), {k: st[k] for k in ("tiles", "factor_tiles", "tasks", "schur_entries", "schur_chunks", "schur_block_products")})
+    assert out["0"][4] == out["1"][4]
+    assert out["0"][0] == out["1"][0] and out["0"][1] == out["1"][1]
+    assert np.array_equal(out["0"][2], out["1"][2]) and np.array_equal(out["0"][3], out["1"][3])
