@@ -31,6 +31,17 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s
 MFMA_F64_PEAK_TFLOPS = 78.6  # v_mfma_f64_16x16x4_f64: 64 cycles per 2048 flop (tools/mfma_f64_check.hip) x 4 SIMDs x 256 CUs x 2.4 GHz
 
 
+def provenance(summary: dict, path: str) -> dict:
+    """Which code a committed PMC summary was measured on, against the code that is running: the summaries carry the stamp of the
+    device sources (tools/source_stamp.py) and, when they were copied into profiles/, the commit; a summary without a stamp, or
+    with another one, is marked stale — the figure is then last round's, not this build's."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from source_stamp import source_sha16
+    now = source_sha16()
+    then = summary.get("source_sha16")
+    return {"file": path, "measured_on_commit": summary.get("commit"), "measured_on_source_sha16": then, "running_source_sha16": now, "stale": then != now}
+
+
 def algorithmic_bytes(prob) -> float:
     """N*(16 obs + 8 idx + 16 r + 16 K) + F*P*48 + M*24 + 72 (M = the points the observations refer to)."""
     import numpy as np
@@ -158,18 +169,38 @@ def roofline_lm(prob, dp, iters, capi):
     cfg = "C5" if prob.num_frames >= 4000 else ("C4" if prob.num_frames >= 1000 else "C2")
     for pr in sorted((p for p in os.listdir(os.path.join(ROOT, "profiles")) if os.path.exists(os.path.join(ROOT, "profiles", p, "pmc_mfma_summary.json"))), reverse=True):
         with open(os.path.join(ROOT, "profiles", pr, "pmc_mfma_summary.json")) as fh:
-            pm = json.load(fh).get(cfg, {})
+            whole = json.load(fh)
+        pm = whole.get(cfg, {})
+        prov = provenance(whole, f"profiles/{pr}/pmc_mfma_summary.json")
         for r in rows:
             k = {"schur": "schur_tile_kernel", "cholesky": "chol_dag_kernel", "eval_lm": "eval_kernel"}.get(r["phase"])
             hit = next((v for name, v in pm.items() if k and k in name and (r["phase"] != "eval_lm" or ", 2>" in name)), None)
             if hit:
                 r["mfma_busy_frac"] = hit["mfma_busy_frac"]
                 r["mfma_busy_source"] = f"profiles/{pr}/pmc_mfma_summary.json (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE per XCD x 1024 SIMDs))"
+                r["mfma_busy_provenance"] = prov
         break
     return {"phases": rows, "plan": st, "sum_ms_per_lm_iteration": sum(r["ms_per_lm_iteration"] for r in rows),
             "note": "phases are timed with HIP events around each step of the loop's HOST form (rsba_solve with profile_phases: the host decides, a pair of "
                     "events per step, ~10 us each); lm.ms_per_lm_iteration is the unprofiled solve — on one GPU the device-side loop with fewer launches — "
                     "and is therefore below this sum"}
+
+
+def shard_eval(full, world: int, device, capi):
+    """The metric's kernel on ONE rank's shard of an N-rank run, each shard alone on this GPU (rsba_partition_points, BAProblem.shard —
+    what bench.py --gpus N gives rank r): HIP-event kernel time and roofline fraction per shard, and the whole-job rate N GPUs would
+    deliver if each ran its shard as measured here (the evaluation has no collective): scene observations / slowest shard."""
+    owner, _ = capi.partition_points(full, world)
+    rows = []
+    for r in range(world):
+        sh = full.shard(r, world, owner)
+        with capi.DeviceProblem(sh, device=device) as d:
+            ms = d.time_evaluate(True, warmup=100, iters=200)
+        ab = algorithmic_bytes(sh)
+        rows.append({"rank": r, "observations": int(sh.num_observations), "kernel_ms": ms, "algorithmic_bytes": ab, "frac_of_hbm_peak": ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
+    worst = max(x["kernel_ms"] for x in rows)
+    return {"world": world, "shards": rows, "slowest_shard_kernel_ms": worst, "predicted_value": full.num_observations / (worst * 1e-3), "unit": "obs evals/s",
+            "note": "kernel time only (HIP events around back-to-back launches on one stream): what each of N GPUs is busy for per step; the driver's N-GPU line adds launch gaps and the clock around K steps"}
 
 
 def next_rows(prob, dp, device):
@@ -371,12 +402,17 @@ def main():
         dp.evaluate_device(True)
     for _ in range(args.warmup):
         dp.evaluate_device(True)
+    # The timed region: every rank starts behind a barrier + device sync and stops at ITS OWN device sync; the region's length is the
+    # MAX over the ranks (the all-reduce below).  A closing collective barrier inside the region would add 50 - 150 us of rendezvous to
+    # what is 20 x 15 us of kernels at N = 8 and buys nothing: the maximum is taken afterwards anyway.  The evaluation has no
+    # collective on its data path, so a rank's K steps end when its own stream is idle.
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         dp.evaluate_device(True)
-    barrier()
+    torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    barrier()
     cdev = "cpu" if one_gpu else "cuda"
     n_obs = torch.tensor([float(prob.num_observations)], device=cdev, dtype=torch.float64)
     t_max = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
@@ -393,7 +429,7 @@ def main():
     achieved = abytes / (kernel_ms * 1e-3) / 1e9
     # HBM traffic of the same kernel on the same workload from the committed PMC passes (separate
     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this command; tools/profile_round.sh)
-    traffic, traffic_src = None, None
+    traffic, traffic_src, traffic_prov = None, None, None
     if world == 1:
         key = "hbm_bytes_per_launch" if args.config == "C4" else f"hbm_bytes_per_launch_{args.config}"
         prof = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if os.path.exists(os.path.join(ROOT, "profiles", p, "pmc_summary.json")))
@@ -402,6 +438,7 @@ def main():
                 pm = json.load(fh)
             if pm.get(key):
                 traffic, traffic_src = pm[key], f"profiles/{pr}/pmc_summary.json (2*FETCH_SIZE + WRITE_SIZE, calibrated)"
+                traffic_prov = provenance(pm, f"profiles/{pr}/pmc_summary.json")
                 break
 
     lm, lm_roof = None, None
@@ -432,6 +469,23 @@ def main():
                 box["lm"] = solve_timed(dp, prob, world, args.lm_iters)
                 box["lm"]["first_handle_of_the_process_s"] = t_cold     # create + symbolic phase + ONE iteration, incl. kernel images, first streams, the plan's host scratch
                 box["lm"]["first_solve_wall_s_note"] = "a fresh handle in a process that has solved before (what windowedBA pays per call): symbolic phase + allocations + the solve"
+                if world == 1:
+                    # the reference's DEFAULT gauge (SfmOptions.h:66-70: nothing fixed; CeresHandler.h:342-382 marks no block constant): the
+                    # reduced system is rank deficient up to the LM damping — same scene, same iterations, no coordinate held
+                    try:
+                        q = prob.copy(); q.pose_fixed_mask = None
+                        x0 = (q.poses.copy(), q.points.copy(), q.intrinsics.copy())
+                        opt = capi.default_options(max_num_iterations=args.lm_iters, function_tolerance=0.0, parameter_tolerance=0.0, gradient_tolerance=0.0)
+                        with capi.DeviceProblem(q, device=local_rank) as dq:
+                            dq.solve(opt)
+                            q.poses[:], q.points[:], q.intrinsics[:] = x0
+                            dq.upload_parameters()
+                            sf, _ = dq.solve(opt)
+                        box["lm"]["lm_free_gauge"] = {"ms_per_lm_iteration": sf.total_time_s / max(1, sf.num_iterations - 1) * 1e3, "iterations": int(sf.num_iterations - 1),
+                                                      "initial_cost": sf.initial_cost, "final_cost": sf.final_cost, "num_parameters_reduced": int(sf.num_parameters_reduced),
+                                                      "dag_fallbacks": int(sf.num_dag_fallbacks), "successful_steps": int(sf.num_successful_steps)}
+                    except Exception as e:  # noqa: BLE001
+                        box["lm"]["lm_free_gauge"] = {"error": repr(e)}
                 before = dp.exchange_stats() if world > 1 else None
                 box["roof"] = roofline_lm(prob, dp, args.lm_iters, capi)
                 if world > 1:   # calls / bytes of THAT solve alone (the library counts since the handle was created); its ms are the solve's own
@@ -488,13 +542,11 @@ def main():
                        "observations_total": int(total_obs), "observations_this_rank": int(prob.num_observations), "jacobian_cols": prob.jacobian_cols,
                        "partition": partition},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "kernel": kname, "kernel_ms": kernel_ms,
+                         "traffic": traffic, "traffic_source": traffic_src, "traffic_provenance": traffic_prov, "kernel": kname, "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": abytes, "bytes_per_observation": abytes / max(1, prob.num_observations),
                          "rank": 0},
-            "lm": lm, "roofline_lm": lm_roof,
+            "roofline_lm": lm_roof,
         }
-        if transport_error:
-            out["lm"] = {"error": "LM leg left out: the library's RCCL communicator could not be set up on every rank", "transport_error": transport_error}
         try:
             free_b, total_b = torch.cuda.mem_get_info(local_rank)
             out["device_memory"] = {"in_use_bytes": int(total_b - free_b), "total_bytes": int(total_b),
@@ -503,8 +555,29 @@ def main():
             out["device_memory"] = {"error": repr(e)}
         if not args.no_next_rows and world == 1 and not lm_hung and args.config == "C4":
             out["next_rows"] = next_rows(prob, dp, local_rank)
+        if not args.no_next_rows and world == 1 and not lm_hung and args.config in ("C4", "C5"):
+            try:   # what each rank of the 8-GPU run will execute, measured one shard at a time on this GPU
+                out["shard_eval_n8"] = shard_eval(full, 8, local_rank, capi)
+                out["shard_eval_n8"]["predicted_speedup_over_this_run"] = out["shard_eval_n8"]["predicted_value"] / out["value"]
+            except Exception as e:  # noqa: BLE001
+                out["shard_eval_n8"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(prob, lm_iters=3 if prob.num_observations < 5_000_000 else 1)
+        # the LM half of the metric goes LAST (a record that keeps only the tail of this line keeps the scalars): the full block, then
+        # its scalars once more as the very last key
+        out["lm"] = lm
+        if transport_error:
+            out["lm"] = {"error": "LM leg left out: the library's RCCL communicator could not be set up on every rank", "transport_error": transport_error}
+        if isinstance(out["lm"], dict):
+            keep = ("ms_per_lm_iteration", "marginal_ms_per_lm_iteration", "iterations", "initial_cost", "final_cost", "first_solve_wall_s", "n_gpus", "exchange", "error",
+                    "lm_free_gauge", "predicted_value_n8")
+            out["lm_headline"] = {k: out["lm"][k] for k in keep if k in out["lm"]}
+            if isinstance(lm_roof, dict) and "sum_ms_per_lm_iteration" in lm_roof:
+                out["lm_headline"]["host_form_phase_sum_ms"] = lm_roof["sum_ms_per_lm_iteration"]
+            out["lm_headline"]["workload"] = args.config
+            if isinstance(out.get("shard_eval_n8"), dict) and "predicted_value" in out["shard_eval_n8"]:
+                out["lm_headline"]["predicted_value_n8"] = out["shard_eval_n8"]["predicted_value"]
+                out["lm_headline"]["predicted_speedup_n8"] = out["shard_eval_n8"]["predicted_speedup_over_this_run"]
     if lm_hung:                      # do not touch the device or the process group again: report and leave
         if rank == 0:
             print(json.dumps(out), flush=True)

@@ -184,7 +184,7 @@ int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rsba_solver_s
  * kernels' algorithmic bytes / flops follow from.  Phase p covers the launches listed; ms[p] is the HIP-event time summed
  * over the last rsba_solve that ran with options.profile_phases != 0, calls[p] how many times the phase ran. */
 enum {
-  RSBA_PHASE_EVAL_LM = 0,        /* eval_kernel<.., kLmJacobian> + cost reduction: r, J (loss-corrected, scaled), point-major records */
+  RSBA_PHASE_EVAL_LM = 0,        /* eval_kernel<.., kLmJacobian> + cost reduction: r, J (loss-corrected, scaled) as per-wave camera blocks (point-major records only with several intrinsics blocks) */
   RSBA_PHASE_CAMERA_BLOCKS = 1,  /* per-frame J^T J / J^T r blocks (+ intrinsics border) from the per-wave partials */
   RSBA_PHASE_POINT_BLOCKS = 2,   /* V_j, g_p,j */
   RSBA_PHASE_POINT_FACTOR = 3,   /* (V_j + D^2)^-1 factors, z_j */
@@ -193,7 +193,7 @@ enum {
   RSBA_PHASE_CHOLESKY = 6,       /* factor + forward / backward solve of the reduced camera system */
   RSBA_PHASE_BACK_SUBSTITUTE = 7,/* point steps + model cost change */
   RSBA_PHASE_CANDIDATE = 8,      /* x + delta, |step|, |x| */
-  RSBA_PHASE_EVAL_TRIAL = 9,     /* residual-only evaluation of the candidate + cost reduction */
+  RSBA_PHASE_EVAL_TRIAL = 9,     /* evaluation of the candidate + cost reduction: in LM mode (the linearisation an accepted step re-uses) when the problem keeps no records, residual-only otherwise */
   RSBA_PHASE_PRIORS = 10,        /* motion-prior blocks, cost and model terms */
   RSBA_PHASE_EXCHANGE = 11,      /* multi-GPU all-reduces (pack / collective / unpack) */
   RSBA_PHASE_OTHER = 12,         /* diagonal clamp, gradient norm, scalar packing */
@@ -336,9 +336,11 @@ int32_t rsba_pnp_inliers(int32_t device, const double* cam, int32_t shutter, con
  * (the reference is single-process; this is the exchange step SURVEY §8e derives for the path).
  * Every rank creates a handle over its own observations (all frames / points arrays are full size, a rank
  * simply holds no observations of the points it does not own).  Per LM iteration the solver all-reduces
- *   (1) the per-camera gradient blocks g_c and diag(U)  + cost / failure scalars      [2*F*CD + 3 doubles]
- *   (2) the packed non-zero tiles of its partial reduced camera system S and its rhs  [nslots*48*48 + F*CD]
- *   (3) eight step scalars (model decrease, |step|^2, |x|^2, trial cost, failure flags)
+ *   (1) the per-camera gradient blocks g_c and diag(U)  + cost / failure scalars (+ a slot per rank: its gradient maximum)  [2*F*CD + 3 (+ world) doubles]
+ *   (2) the packed non-zero tiles of its partial reduced camera system S and its rhs  [tile pairs*48*48 + F*CD] — or, when the points are cut along
+ *       the top separators of the elimination tree (rsba_partition_points) and every rank factors its own part, (2') the separators' tiles only,
+ *       between the two launches of the factorisation, and (4) the camera step, each rank its rows  [npad]
+ *   (3) twelve step scalars (model decrease, |step|^2, |x|^2, gradient maximum, trial cost, failure flags, the factorisation's verification flag)
  * through RCCL directly (rsba_set_exchange_rccl, below) or through the callback below, for hosts that bring their own
  * transport (the tests stage it through gloo).
  * op: 0 = sum, 1 = max.  The buffer is device memory; the collective must be ordered after prior work

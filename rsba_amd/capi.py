@@ -196,6 +196,9 @@ class DeviceProblem:
     def __init__(self, prob: BAProblem, device: int = 0):
         self.prob = prob
         self._desc = make_desc(prob)
+        # the handle keeps these HOST POINTERS (rsba_solve writes the solved parameters back through them, as ceres::Solve writes into the
+        # blocks it was given): the arrays stay alive with this object, and arrays assigned to the problem later are copied INTO them
+        self._bound = (prob.poses, prob.points, prob.intrinsics)
         self._h = C.c_void_p()
         _check(lib().rsba_create(C.byref(self._desc), C.c_int32(device), C.byref(self._h)))
         if prob.prior_kind and prob.prior_frames is not None and len(prob.prior_frames):
@@ -245,14 +248,29 @@ class DeviceProblem:
     def set_stream(self, raw_stream: int | None):
         _check(lib().rsba_set_stream(self._h, C.c_void_p(raw_stream or 0)))
 
-    def upload_parameters(self):
+    def _rebind(self, take_values: bool):
+        """The problem's parameter arrays must BE the arrays bound at rsba_create (the handle holds their addresses).  An array assigned to
+        the problem since then is copied into the bound one (take_values) and the attribute is pointed back at it; a different shape is an error."""
         p = self.prob
-        p.__post_init__()   # (arrays assigned since construction: dtype / layout as the C side reads them)
+        for name, bound in zip(("poses", "points", "intrinsics"), self._bound):
+            cur = getattr(p, name)
+            if cur is bound:
+                continue
+            cur = np.asarray(cur, dtype=np.float64)
+            if cur.size != bound.size:
+                raise ValueError(f"{name}: {cur.shape} cannot replace the {bound.shape} array this handle was created with")
+            if take_values:
+                np.copyto(bound, cur.reshape(bound.shape))
+            setattr(p, name, bound)
+
+    def upload_parameters(self):
+        self._rebind(take_values=True)
+        p = self.prob
         _check(lib().rsba_upload_parameters(self._h, _ptr(p.poses), _ptr(p.points), _ptr(p.intrinsics)))
 
     def download_parameters(self):
+        self._rebind(take_values=False)
         p = self.prob
-        p.__post_init__()
         _check(lib().rsba_download_parameters(self._h, _ptr(p.poses), _ptr(p.points), _ptr(p.intrinsics)))
 
     def evaluate_device(self, with_jacobians: bool = True):
@@ -373,6 +391,7 @@ class DeviceProblem:
         finally:
             self._exchanged()
         _check(st)
+        self._rebind(take_values=False)   # (the solved parameters are in the arrays bound at create: the problem's attributes are those arrays again)
         if getattr(self.prob, "ratio_free", False) and self.prob.prior_kind:
             self.prob.inter_frame_ratio = self.inter_frame_ratio()       # a free ratio block is solved for, like every parameter
         return s, [tr[i] for i in range(min(s.num_iterations, trace_cap))]

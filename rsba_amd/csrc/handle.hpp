@@ -36,6 +36,7 @@ struct rsba_handle {
   double prior_ratio_result = 0.0;     // its value after the last solve
   int prior_invalid = 0;               // blocks whose functor returns false for the given interFrameRatio
   bool prior_split = false;            // sharded factorisation: dp.prior_of lists THIS rank's share of the priors (every rank contributes its own, not rank 0 all)
+  const int32_t* prior_of_all = nullptr; int prior_invalid_all = 0;   // ... and what the handle had before the plan split them (the table lives in the PLAN's memory: rsba_destroy_solver puts these back)
   // per-pose priors (rsba_set_pose_priors)
   std::vector<int32_t> pp_blocks;      // pose blocks carrying a GoodPosePrior
   double* pp_host = nullptr;           // caller's priorPoses values [count][6], written back by rsba_solve

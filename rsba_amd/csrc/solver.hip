@@ -432,8 +432,13 @@ int32_t build_solver_impl(rsba_handle* h) {
     });
   }
   sv.ngroups = (int64_t)g_tile.size();
-  if (std::getenv("RSBA_TEST_FAIL_PLAN")) return rsba_set_error(RSBA_ERR_UNSUPPORTED, "RSBA_TEST_FAIL_PLAN: the plan was made to fail (test hook)");   // after the uploader has started
-  if ((sv.ngroups + 1) * (int64_t)kTile * 3 >= ((int64_t)1 << 32)) return rsba_set_error(RSBA_ERR_UNSUPPORTED, "more than 2^32 doubles of P records: the Schur kernel indexes them with 32 bits");
+  // A plan that cannot be built on THIS rank must not leave the other ranks waiting in the vote further down (one all-reduce in the
+  // middle of the plan): a rank-local failure is carried into that vote and every rank fails together; a single rank returns here.
+  const bool plan_votes = h->allreduce && h->world > 1 && !h->union_mask.empty();
+  int32_t local_fail = RSBA_OK; const char* local_why = "";
+  if (std::getenv("RSBA_TEST_FAIL_PLAN")) { local_fail = RSBA_ERR_UNSUPPORTED; local_why = "RSBA_TEST_FAIL_PLAN: the plan was made to fail (test hook)"; }   // after the uploader has started
+  else if ((sv.ngroups + 1) * (int64_t)kTile * 3 >= ((int64_t)1 << 32)) { local_fail = RSBA_ERR_UNSUPPORTED; local_why = "more than 2^32 doubles of P records: the Schur kernel indexes them with 32 bits"; }
+  if (local_fail && !plan_votes) return rsba_set_error(local_fail, local_why);
   up.upload_const_ref(&sv.slot_gpos, slot_gpos);
   const bool dense_keys = (int64_t)nt * nt <= (int64_t)1 << 26;
   std::vector<int64_t> dense_cnt; std::unordered_map<int64_t, int64_t> sparse_cnt;
@@ -654,17 +659,18 @@ int32_t build_solver_impl(rsba_handle* h) {
   if (want_parts) {
     double bad = sharded ? 0.0 : 1.0;
     for (int64_t i = 0; i < N && bad == 0.0; ++i) { const int p = tord.part_of[of[i] / FT]; if (p >= 0 && p != h->rank) bad = 1.0; }
-    // every rank must take the same form: one all-reduce (max) of the verdicts
-    double* d_bad = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_bad), sizeof(double)));
+    if (local_fail) bad = 2.0;   // this rank cannot build its plan at all: every rank gives up together
+    // every rank must take the same form: one all-reduce (max) of the verdicts — through the handle's cost slot (allocated with the
+    // handle, rewritten by every evaluation): no allocation here that could fail on one rank and leave the others waiting
+    double* d_bad = h->d_cost2;
     hipError_t e = hipMemcpyAsync(d_bad, &bad, sizeof bad, hipMemcpyHostToDevice, h->stream);
-    int32_t rcx = RSBA_OK;
-    if (e == hipSuccess) rcx = exchange(h, d_bad, 1, 1, RSBA_EXCHANGE_SETUP);
+    const int32_t rcx = exchange(h, d_bad, 1, 1, RSBA_EXCHANGE_SETUP);
     if (e == hipSuccess && rcx == RSBA_OK) e = hipMemcpyAsync(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess && rcx == RSBA_OK) e = hipStreamSynchronize(h->stream);
-    (void)hipFree(d_bad);
     if (rcx) return rcx;
-    if (e != hipSuccess) return rsba_set_error(RSBA_ERR_HIP, hipGetErrorString(e));
+    if (e != hipSuccess) return rsba_set_error(e == hipErrorOutOfMemory ? RSBA_ERR_OUT_OF_MEMORY : RSBA_ERR_HIP, hipGetErrorString(e));
+    if (local_fail) return rsba_set_error(local_fail, local_why);
+    if (bad >= 2.0) return rsba_set_error(RSBA_ERR_UNSUPPORTED, "another rank could not build its plan (its own call says why)");
     sharded = bad == 0.0;
   }
   s->sharded = sharded;
@@ -684,6 +690,7 @@ int32_t build_solver_impl(rsba_handle* h) {
     }
     int32_t* d_own = nullptr;
     if (int32_t rc_ = s_upload(s, &d_own, own)) return rc_;
+    h->prior_of_all = h->dp.prior_of; h->prior_invalid_all = h->prior_invalid;   // (d_own belongs to this plan: rsba_destroy_solver restores the handle's own table)
     h->dp.prior_of = d_own;
     if (h->prior_invalid > 0) h->prior_invalid = mine;
     h->prior_split = true;
@@ -1610,6 +1617,7 @@ void rsba_destroy_solver(rsba_handle* h) {
   delete h->solver;
   if (dbg) std::fprintf(stderr, "[rsba destroy] plan: streams + events to the pool %.2f ms; stream sync %.2f ms; blocks to the cache %.2f ms; host state %.2f ms\n", 1e3 * (td1 - td0), 1e3 * (td2 - td1), 1e3 * (td3 - td2), 1e3 * (now_s() - td3));
   h->solver = nullptr;
+  if (h->prior_split) { h->dp.prior_of = h->prior_of_all; h->prior_invalid = h->prior_invalid_all; h->prior_split = false; }   // the rank's share of the priors was a table of the plan
   h->dp.rec = nullptr; h->dp.obs_slot = nullptr; h->dp.cam_part = nullptr; h->dp.wave_seg_base = nullptr; h->dp.frame_rank = nullptr;
 }
 

@@ -2,11 +2,14 @@
 
 Observations are partitioned BY POINT (BAProblem.shard): every observation of a point lives on one rank,
 so V_j, g_p,j and the point elimination are rank-local; camera parameters are replicated.  Per LM
-iteration the ranks all-reduce (include/rsba_amd.h, "multi-GPU"):
-  (1) per-camera gradient blocks g_c + diag(U) + cost scalars         2*F*CD + 3 doubles
-  (2) the packed non-zero tiles of the partial reduced camera system  nslots*48*48 + F*CD doubles
-  (3) eight step scalars
-and then factor the (identical) reduced system redundantly.  The collective itself is RCCL called by the library on the solver's stream
+iteration the ranks all-reduce (include/rsba_amd.h, "multi-GPU"; DESIGN.md §5):
+  (1) per-camera gradient blocks g_c + diag(U) + cost scalars (+ each rank's gradient maximum)   2*F*CD + 3 (+ world) doubles
+  (2') with points cut along the top separators of the elimination tree (capi.partition_points): the SEPARATORS' tiles of the reduced
+       camera system, between the two launches of the factorisation — every rank factors its own part where it is formed;
+       any other by-point partition: (2) every structurally non-zero tile of the partial system, then a replicated factorisation
+  (3) twelve step scalars
+  (4) sharded form only: the camera step, each rank its rows
+The collective itself is RCCL called by the library on the solver's stream
 (attach_rccl -> rsba_set_exchange_rccl: no Python inside an LM iteration); the callback form (attach) lets a host bring
 its own transport — a "gloo" process group staged through the host is how the exchange logic is tested without several GPUs.
 """

@@ -57,11 +57,21 @@ def nd_mode(mode, outdir, rank, world, dist, torch):
     torch.cuda.set_device(0)
     opts = dict(max_num_iterations=int(iters), function_tolerance=0.0, parameter_tolerance=0.0, gradient_tolerance=0.0)
     dp = capi.DeviceProblem(shard, device=0)
-    attach(dp)
+    comm, transport = None, "callback (gloo, blocking)"
+    if "mock" in flags:      # the library's NATIVE exchange (ncclAllReduce on its own stream, nothing of the host inside an iteration) over tools/libmock_rccl.so:
+        from rsba_amd.distributed import attach_rccl   # a stream-ordered stand-in for RCCL that lets the ranks share one GPU (RSBA_RCCL_LIB, set by the test)
+        comm = attach_rccl(dp, 0)
+        d = capi.rccl_describe(comm)
+        transport = f"native, stream-ordered: nccl version {d['rccl_version']}, {d['comm_ranks']} ranks"
+    else:
+        attach(dp)
     s, tr = dp.solve(capi.default_options(**opts))
     st = dp.plan_stats()
+    xs = dp.exchange_stats()
     dp.close()
-    out = {"rank": rank, "world": world, "n_full": int(full.num_observations), "n_shard": int(shard.num_observations), "top_tile_columns": ntop,
+    if comm is not None:
+        capi.rccl_comm_destroy(comm)
+    out = {"rank": rank, "transport": transport, "collective_calls": {k: v["calls"] for k, v in xs["collectives"].items()}, "world": world, "n_full": int(full.num_observations), "n_shard": int(shard.num_observations), "top_tile_columns": ntop,
            "final_cost": s.final_cost, "initial_cost": s.initial_cost, "iters": s.num_iterations, "dag_fallbacks": s.num_dag_fallbacks,
            "reduced": s.num_residual_blocks_reduced, "params": s.num_parameters_reduced, "costs": [t.cost for t in tr], "plan": st,
            "poses_sum": float(np.abs(shard.poses).sum()), "points_sum": float(np.abs(shard.points).sum())}
@@ -82,6 +92,46 @@ def nd_mode(mode, outdir, rank, world, dist, torch):
     dist.destroy_process_group()
 
 
+def mock_timeout_mode(outdir, rank, world, dist, torch):
+    """Two ranks over tools/libmock_rccl.so: one all-reduce both enter (checked), then one that ONLY RANK 0 enters — its device-side wait
+    must give up after RSBA_MOCK_RCCL_TIMEOUT_S and the communicator must say so when it is destroyed."""
+    import ctypes as C
+    import time
+    lib = C.CDLL(os.environ["RSBA_RCCL_LIB"])
+    lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_char * 128, C.c_int]
+    lib.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.ncclCommDestroy.argtypes = [C.c_void_p]
+    torch.cuda.set_device(0)
+    uid = (C.c_char * 128)()
+    if rank == 0:
+        assert lib.ncclGetUniqueId(C.byref(uid)) == 0
+    box = [bytes(uid) if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    uid = (C.c_char * 128).from_buffer_copy(box[0])
+    comm = C.c_void_p()
+    assert lib.ncclCommInitRank(C.byref(comm), world, uid, rank) == 0
+    x = torch.full((100000,), float(rank + 1), dtype=torch.float64, device="cuda")
+    assert lib.ncclAllReduce(x.data_ptr(), x.data_ptr(), x.numel(), 8, 0, comm, None) == 0
+    torch.cuda.synchronize()
+    out = {"rank": rank, "sum_ok": bool((x == float(sum(range(1, world + 1)))).all().item())}
+    y = torch.full((1000,), float(rank), dtype=torch.float64, device="cuda")
+    assert lib.ncclAllReduce(y.data_ptr(), y.data_ptr(), y.numel(), 8, 2, comm, None) == 0     # max
+    torch.cuda.synchronize()
+    out["max_ok"] = bool((y == float(world - 1)).all().item())
+    t0 = time.time()
+    if rank == 0:
+        assert lib.ncclAllReduce(x.data_ptr(), x.data_ptr(), x.numel(), 8, 0, comm, None) == 0   # enqueued: returns at once
+        out["enqueue_s"] = time.time() - t0
+        torch.cuda.synchronize()                                                                  # ... and gives up on the device
+        out["gave_up_after_s"] = time.time() - t0
+    dist.barrier()
+    out["destroy"] = int(lib.ncclCommDestroy(comm))
+    with open(os.path.join(outdir, f"rank{rank}.json"), "w") as f:
+        json.dump(out, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     mode, outdir = sys.argv[1], sys.argv[2]
     import torch
@@ -90,6 +140,8 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     if mode.startswith("nd:"):
         return nd_mode(mode, outdir, rank, world, dist, torch)
+    if mode == "mock_timeout":
+        return mock_timeout_mode(outdir, rank, world, dist, torch)
     full = scene()
     if mode in ("gpu_priors", "gpu_free_ratio"):   # motion priors are replicated terms: every rank lists them, rank 0 contributes them
         full.prior_kind, full.prior_scale, full.inter_frame_ratio = 2, 25.0, 1.2

@@ -9,9 +9,15 @@ these sizes tractable on a CPU: C4 takes about a minute per LM iteration on 8 co
 the device solver with what is stored here: per-iteration cost / step records, the summary, and a fixed sample of the
 solved parameters.
 
+A name with the suffix "free" (C4free, C5free) is the same scene with NOTHING held fixed — the reference's default options
+(SfmOptions.h:66-70: fixFirstNCameras = 0, fixScale / fixRotation / fixPosition off, so CeresHandler.h:342-382 marks no block
+constant): the reduced camera system is rank deficient by the seven gauge freedoms and only the LM damping makes it definite
+("a second run with nothing fixed (reference default) for parity of the rank-deficient case").  Stored as
+c4_free_gauge_trajectory.json / c5_free_gauge_trajectory.json: the step-by-step trajectory and a shorter long run.
+
 This is a checker-vs-product comparison at the headline size; it does not pin the oracle itself (see
 rsba_oracle_math.hpp: "parity unpinned").  Run (build container, CPU only):
-    python tests/golden/make_trajectories.py C4 [C5]
+    python tests/golden/make_trajectories.py C4 [C5] [C4free] [C5free]
 """
 import json
 import os
@@ -28,7 +34,7 @@ from oracle import oracle as O  # noqa: E402
 from rsba_amd.scene import make_config  # noqa: E402
 
 # (LM iterations of the step-by-step trajectory, iterations of the long run)
-PLAN = {"C4": (6, 40), "C5": (4, 12)}
+PLAN = {"C4": (6, 40), "C5": (4, 12), "C4free": (6, 16), "C5free": (4, 6)}
 POSE_STRIDE = {"C4": 37, "C5": 149}
 POINT_STRIDE = {"C4": 2003, "C5": 10007}
 
@@ -46,9 +52,11 @@ def summary(s):
 
 def run(name):
     iters, iters_min = PLAN[name]
-    sc = make_config(name)
+    free = name.endswith("free")
+    name = name[:-4] if free else name
+    sc = make_config(name, gauge=not free)
     p = sc.problem.copy()
-    out = dict(config=name, num_frames=p.num_frames, num_points=p.num_points, num_observations=p.num_observations,
+    out = dict(config=name, gauge="nothing fixed (SfmOptions.h:66-70 defaults)" if free else "frame 0 constant, translation of the last pose fixed", num_frames=p.num_frames, num_points=p.num_points, num_observations=p.num_observations,
                obs_checksum=float(np.sum(p.obs_xy)), pose_checksum=float(np.sum(p.poses)), point_checksum=float(np.sum(p.points)),
                pose_stride=POSE_STRIDE[name], point_stride=POINT_STRIDE[name])
     ok, cost, g = O.evaluate(p, gradient=True)
@@ -74,7 +82,7 @@ def run(name):
                            pose_sample=q.poses[::POSE_STRIDE[name]].ravel().tolist(), point_sample=q.points[::POINT_STRIDE[name]].ravel().tolist(),
                            intrinsics=q.intrinsics.ravel().tolist())
         print(name, "long", s.final_cost, s.num_iterations, f"{time.time() - t0:.0f} s", flush=True)
-    with open(os.path.join(HERE, f"{name.lower()}_trajectory.json"), "w") as f:
+    with open(os.path.join(HERE, f"{name.lower()}{'_free_gauge' if free else ''}_trajectory.json"), "w") as f:
         json.dump(out, f)
 
 

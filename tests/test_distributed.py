@@ -14,13 +14,16 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_two_ranks(mode, outdir, world=2):
+MOCK_RCCL = os.path.join(ROOT, "tools", "libmock_rccl.so")   # tools/mock_rccl.hip, built by __graft_entry__.build(): test infrastructure
+
+
+def run_two_ranks(mode, outdir, world=2, timeout=900, env_extra=None):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(env_extra or {}))
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"), mode, str(outdir)],
-                       capture_output=True, text=True, env=env, timeout=900)
+                       capture_output=True, text=True, env=env, timeout=timeout)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     return [json.load(open(os.path.join(outdir, f"rank{k}.json"))) for k in range(world)]
 
@@ -256,6 +259,19 @@ def test_sharded_factorisation_at_c4_size(tmp_path, world):
 
 
 @pytest.mark.gpu
+def test_sharded_factorisation_at_c5_size(tmp_path):
+    """BASELINE config 5 as it is quoted — 4000 frames, 500k points, 10.3 M observations, Huber loss, the shared intrinsics block as a
+    parameter block — on EIGHT ranks (sharing one GPU; gloo callback transport): every rank factors its own part of the reduced system,
+    the 9-wide intrinsics border is one more separator all ranks share, and the LM trajectory is the single-GPU one to 1e-9 (which
+    tests/test_gpu_fullsize.py holds against the oracle's)."""
+    res = run_two_ranks("nd:C5:3", tmp_path, 8, timeout=2400)
+    a = check_nd(res, 8)
+    full = a["ref_plan"]["exchange_doubles"]
+    assert a["plan"]["exchange_doubles"] <= 0.15 * full       # (12.2 MB of separators against 156 MB of tiles, DESIGN.md §5)
+    assert a["plan"]["separator_tiles"] >= a["top_tile_columns"]   # (+ the intrinsics pseudo tile)
+
+
+@pytest.mark.gpu
 def test_sharded_factorisation_with_shared_intrinsics_block(tmp_path):
     """Shared intrinsics as a parameter block + Huber (what BASELINE config 5 adds): the block's 9 unknowns are a dense border of the
     reduced system — one more separator every rank shares — and its rows are complete where their frames' parts are."""
@@ -310,3 +326,46 @@ def test_a_rank_without_observations(tmp_path):
     res = run_two_ranks("nd:C2:6:emptyrank", tmp_path, 3)
     a = check_nd(res, 3, sharded=False)
     assert sorted(o["n_shard"] for o in res)[0] == 0
+
+
+# ---- the same over a STREAM-ORDERED transport: the library's native exchange (ncclAllReduce enqueued on the solver's stream, no host code
+# inside an iteration) against tools/libmock_rccl.so, which sums through hipIpc-shared staging blocks with device-side waits — what RCCL
+# does between GPUs, between ranks that share this one.  The loop whose decisions are taken on the device then runs as it will on a node:
+# the host polls a pinned stamp while kernels and collectives of the iteration are in flight.
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_factorisation_at_c4_size_over_a_stream_ordered_transport(tmp_path, world):
+    assert os.path.exists(MOCK_RCCL), "tools/libmock_rccl.so is built by __graft_entry__.build()"
+    res = run_two_ranks("nd:C4:4:mock", tmp_path, world, env_extra={"RSBA_RCCL_LIB": MOCK_RCCL})
+    a = check_nd(res, world)
+    assert all("version 99900" in o["transport"] and f"{world} ranks" in o["transport"] for o in res)
+    it = a["iters"] - 1
+    # per LM iteration: (1) camera blocks, (2') separators, (3) step scalars, (4) camera step — issued by the library itself
+    assert all(o["collective_calls"]["(2) reduced system"] == it and o["collective_calls"]["(4) camera step"] == it for o in res)
+    assert all(o["collective_calls"]["(3) step scalars"] == it for o in res)
+    # ... and the blocking gloo callback gives the same trajectory (two ranks: a + b is the same sum whoever adds — bit for bit; four: the
+    # mock adds in rank order, gloo in its own — the last bits of a sum of four may differ)
+    out2 = tmp_path / "gloo"; out2.mkdir()
+    ref = run_two_ranks("nd:C4:4", out2, world)
+    if world == 2:
+        assert ref[0]["costs"] == a["costs"] and ref[0]["poses_sum"] == a["poses_sum"] and ref[0]["points_sum"] == a["points_sum"]
+    else:
+        assert max(abs(x - y) / y for x, y in zip(a["costs"], ref[0]["costs"])) <= 1e-12
+
+
+@pytest.mark.gpu
+def test_stream_ordered_transport_with_motion_priors_and_shared_intrinsics(tmp_path):
+    res = run_two_ranks("nd:S300:6:priors:intr:mock", tmp_path, 3, env_extra={"RSBA_RCCL_LIB": MOCK_RCCL})
+    check_nd(res, 3)
+
+
+@pytest.mark.gpu
+def test_a_rank_that_never_arrives_is_reported_not_waited_for_forever(tmp_path):
+    """The mock transport's device-side waits are bounded: a collective only ONE rank enters gives up after the timeout and the
+    communicator reports it when it is destroyed — a wedged exchange must never hang the GPU.  (Also the transport's own arithmetic:
+    a sum and a max over two ranks.)"""
+    a, b = run_two_ranks("mock_timeout", tmp_path, 2, env_extra={"RSBA_RCCL_LIB": MOCK_RCCL, "RSBA_MOCK_RCCL_TIMEOUT_S": "0.5"})
+    assert a["sum_ok"] and b["sum_ok"] and a["max_ok"] and b["max_ok"]
+    assert a["enqueue_s"] < 0.25 and 0.4 <= a["gave_up_after_s"] < 10.0
+    assert a["destroy"] == 2 and b["destroy"] == 0      # ncclSystemError on the rank that waited; nothing to report on the one that never called

@@ -552,3 +552,29 @@ def test_the_large_problem_path_of_the_symbolic_phase_builds_the_same_plan(capi,
     assert out["0"][4] == out["1"][4]
     assert out["0"][0] == out["1"][0] and out["0"][1] == out["1"][1]
     assert np.array_equal(out["0"][2], out["1"][2]) and np.array_equal(out["0"][3], out["1"][3])
+
+
+def test_parameter_arrays_assigned_after_create_are_copied_into_the_bound_ones(capi):
+    """The handle keeps the HOST ADDRESSES of the parameter arrays it was created with (rsba_solve writes the result back through them,
+    as ceres::Solve writes into the caller's blocks).  The binding therefore keeps those arrays alive and copies later assignments
+    INTO them: `prob.poses = new; upload_parameters(); solve()` must solve from the new values and leave the result in prob.poses."""
+    p = small_scene()
+    ref = p.copy()
+    x0 = (p.poses.copy(), p.points.copy())
+    opts = dict(max_num_iterations=6)
+    with capi.DeviceProblem(ref) as dr:
+        s_ref, _ = dr.solve(capi.default_options(**opts))
+    with capi.DeviceProblem(p) as dp:
+        dp.solve(capi.default_options(**opts))                       # moves the bound arrays away from x0
+        bound = p.poses
+        p.poses = x0[0].astype(np.float64).copy()                    # NEW arrays, as a caller would assign them
+        p.points = [list(r) for r in x0[1]]                          # ... even something that is not an array yet
+        dp.upload_parameters()
+        assert p.poses is bound and np.array_equal(p.poses, x0[0])   # copied into the array the handle knows
+        s, _ = dp.solve(capi.default_options(**opts))
+        assert s.final_cost == s_ref.final_cost
+        assert np.array_equal(p.poses, ref.poses) and np.array_equal(p.points, ref.points)
+        p.poses = np.zeros((3, 2, 6))
+        with pytest.raises(ValueError):
+            dp.upload_parameters()
+        p.poses = bound

@@ -67,6 +67,7 @@ for cfg, k, key in (("C4", "eval_kernel<true, 2, 1>", "hbm_bytes_per_launch"), (
 json.dump(summary, open(f"{out}/pmc_summary.json", "w"), indent=1)
 print(json.dumps(summary))
 PY
+python tools/source_stamp.py --tag $OUT/pmc_summary.json $OUT/pmc_mfma_summary.json   # the code the counters were taken on (bench.py flags a stale summary)
 cp $OUT/kernel_stats_C4.csv $OUT/kernel_stats.csv
 cat $OUT/bench.json
 # the rows next to the hot path: motion priors (f1), RS-PnP hypotheses (f3), filters (f2)
