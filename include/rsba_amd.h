@@ -208,13 +208,15 @@ typedef struct rsba_plan_stats {
   int64_t schur_block_products;                     /* CD x 3 by 3 x CD block products that are not structurally zero */
   int64_t cholesky_flops;                           /* of the tile factorisation incl. fill, forward and backward solve */
   int64_t exchange_doubles;                         /* payload (2) of the multi-GPU exchange: the structurally non-zero tiles of S + rhs */
-  int64_t schur_groups;                             /* (point, frame tile) groups of P records: 3 x 48 doubles each */
+  int64_t schur_groups;                             /* (point, frame tile) groups of P records */
   int64_t schur_mfma_issued, schur_launches;        /* fp64 MFMAs (2048 flop each) the Schur kernel issued so far — all-zero operand blocks are skipped — over so many launches */
   int64_t sharded_factorisation;                    /* 1: several ranks, each factoring its own part of the elimination tree (the points follow rsba_partition_points);
                                                      * exchange_doubles is then the separators' tiles | their rhs rows | the gather of the camera step */
   int64_t separator_tiles, separator_factor_tiles;  /* tile columns in the separators all ranks share, and tiles of the factor inside them (what exchange (2) carries) */
   int64_t local_tasks, separator_tasks;             /* Cholesky tasks of this rank's part (forward) / of the separators incl. both backward solves */
   int64_t local_levels, separator_levels;           /* the two dependency chains: elimination levels inside this rank's part / levels that hold a separator column */
+  int64_t schur_group_bytes, schur_factored_groups; /* bytes of all groups: 3 x 48 doubles each in full form; 80 doubles for the groups stored FACTORED (two-pose frame tiles: the
+                                                     * 6-row factor q = Jq^T Jp L^-T per frame + tau instead of the 12 rows (1 - tau) q | tau q), and how many those are */
 } rsba_plan_stats;
 int32_t rsba_get_plan_stats(rsba_handle* h, rsba_plan_stats* out);   /* runs the symbolic phase if it has not run yet */
 

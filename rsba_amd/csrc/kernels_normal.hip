@@ -9,6 +9,8 @@
 // the fp64 VALU rate, and padding 12 -> 16 would waste 44 % of it.
 #include "lm_record.hpp"
 #include "obs_math.hpp"
+#include <type_traits>
+
 #include "solver_state.hpp"
 #include <cstdlib>
 
@@ -158,6 +160,11 @@ __global__ __launch_bounds__(256) void intr_reduce_kernel(const DeviceProblem dp
   sv.U[u_self_off(sv, c, b / CD, a / CD) + (size_t)(b % CD) * CD + (a % CD)] = v;
 }
 
+// where a slot's P record goes (solver_state.hpp: slot_gpos = element offset of its group | position of its frame in the tile << 1 | kind)
+__device__ __forceinline__ size_t gpos_group(uint32_t gpos) { return (size_t)(gpos & ~15u); }
+__device__ __forceinline__ int gpos_pos(uint32_t gpos) { return (int)((gpos >> 1) & 7u); }
+__device__ __forceinline__ bool gpos_factored(uint32_t gpos) { return (gpos & 1u) != 0; }
+
 // virtual observation records of the pseudo frames: one group per (point j, intrinsics block c the point is seen through),
 // Q_j,c = sum_{o of j in frames that use c} Ji_o^T (Jp_o L_j^-T)   (9 x 3), cut into the NPF pseudo-frame records of the group
 template <int CD>
@@ -187,10 +194,9 @@ __global__ __launch_bounds__(256) void virtual_records_kernel(const DeviceProble
       for (int m = 0; m < 3; ++m) Q[k][m] += a0 * B[0][m] + a1 * B[1][m];
     }
   }
-  constexpr int FT = kTile / CD;
   for (int v = 0; v < sv.NPF; ++v) {
-    const int gpos = sv.slot_gpos[dp.N + g * sv.NPF + v];   // the virtual slot's place: group gpos / FT, frame position gpos % FT of its tile
-    double* out = sv.Pm + (size_t)(gpos / FT) * (kTile * 3) + (gpos % FT) * CD;
+    const uint32_t gpos = sv.slot_gpos[dp.N + g * sv.NPF + v];   // the virtual slot's place: its group (always full form: a pseudo frame's tile), frame position of its tile
+    double* out = sv.Pm + gpos_group(gpos) + gpos_pos(gpos) * CD;
 #pragma unroll
     for (int rl = 0; rl < CD; ++rl) {
       const int k = v * CD + rl;
@@ -341,20 +347,20 @@ inline int project_chunks(int64_t N) {   // ~2 k waves or more
 
 template <int CD, int KC>
 __global__ __launch_bounds__(256) void project_kernel(const DeviceProblem dp, const SolverDev sv) {
-  constexpr int REC = 8 + 2 * KC, OUT = CD * 3, FT = kTile / CD;
+  constexpr int REC = 8 + 2 * KC, OUT = CD * 3;
   constexpr int PITCH = (REC > OUT ? REC : OUT) | 1;          // odd
   constexpr int off = KC - CD;                                  // 9 when intrinsics columns precede the pose
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double* buf = smem + (size_t)wave * (64 * PITCH + 32);
-  int32_t* s_gpos = reinterpret_cast<int32_t*>(buf + 64 * PITCH);   // [64] where each slot of the chunk goes
+  uint32_t* s_gpos = reinterpret_cast<uint32_t*>(buf + 64 * PITCH);   // [64] where each slot of the chunk goes (problems that keep records store every group in full form)
   const int64_t sb = ((int64_t)blockIdx.x * 4 + wave) * 64 * kProjectChunks;
   if (sb >= dp.N) return;
   const int64_t se = sb + 64 * kProjectChunks < dp.N ? sb + 64 * kProjectChunks : dp.N;
   // the next chunk's records (and the point of each slot) travel in registers while this one is worked on; indices
   // are clamped rather than predicated so that nothing next to the loads waits for them
   double pre[REC];
-  int pre_point = 0, pre_gpos = 0;
+  int pre_point = 0; uint32_t pre_gpos = 0;
   auto issue = [&](int64_t c0) {
     const int64_t last = (se - c0) * REC - 1;
     const double* src = dp.rec + (size_t)c0 * REC;
@@ -403,8 +409,8 @@ __global__ __launch_bounds__(256) void project_kernel(const DeviceProblem dp, co
       for (int i = 0; i * kPer < 64; ++i) {
         const int sl = i * kPer + my;
         if (sl < nslot) {
-          const int gpos = s_gpos[sl];
-          double* dst = sv.Pm + ((size_t)(gpos / FT) * (kTile * 3) + (size_t)((gpos % FT) * CD + w));
+          const uint32_t gpos = s_gpos[sl];
+          double* dst = sv.Pm + (gpos_group(gpos) + (size_t)(gpos_pos(gpos) * CD + w));
           const double* src = buf + sl * PITCH + w;
 #pragma unroll
           for (int comp = 0; comp < 3; ++comp) dst[comp * kTile] = src[comp * CD];
@@ -449,12 +455,44 @@ constexpr unsigned kLowerBlocks = 0x1D9;   // bits 3 I + J with J <= I
 // so every vector / scalar instruction around them is time the matrix pipe idles (round 2's loop spent 6 scalar and 5 vector
 // instructions per MFMA on 64-bit gather addresses, tail selects and per-step votes: the pipe was busy 39 % of the time,
 // SQ_VALU_MFMA_BUSY_CYCLES).  Here: entry counts are padded to a multiple of 16 with entries that point at an all-zero group
-// (no tail selects), the table holds ready element offsets (one 64-bit add per operand triple, the three 16-row blocks ride
-// on the load's immediate offset), and which of the nine 16 x 16 blocks of a group of four entries have anything to multiply
+// (no tail selects), the table holds ready element offsets (one 64-bit add per operand, the blocks ride on the load's immediate
+// offset), and which of the nine 16 x 16 blocks of a group of four entries have anything to multiply
 // is ONE scalar read of host-computed masks (a full mask — the common case — runs 27 MFMAs without a branch).
-template <bool DIAG, int kDepth>
+//
+// FA / FB: the groups of the I / J side are stored FACTORED (solver_state.hpp: kGroupFactored; round 5).  The 48 camera-side rows of
+// a two-pose frame tile are, frame by frame, (1 - tau) q | tau q with q = Jq^T Jp L^-T (6 x 3): such a group holds the 24 "sources"
+// q per coordinate and the four tau, 640 B instead of 1152, and the operand rows are formed here — one multiply per operand double.
+// The rows of a factored side are taken in an order of this kernel's own (the epilogue puts every result where it belongs, so
+// nothing outside sees it): blocks 0 and 1 are the pose-0 and pose-1 rows of sources 0..15 — ONE loaded double feeds both — and block
+// 2 the rows of sources 16..23 (lanes 0..7 pose 0, lanes 8..15 pose 1).  Per lane and group of four entries: 6 source doubles + 2 tau
+// per side instead of 9 operand doubles.  The column scales (Jacobi scales, masks of fixed coordinates) factor out of the sum over
+// the points: they are applied once, where the partial tiles are merged.
+struct FactoredLane {   // per-lane constants of the row order above
+  int main, left, tau_m, tau_l;   // element offsets inside a group (coordinate 0; + 16 / + 8 per coordinate)
+  double a0, b0, a1, b1, a2, b2;  // weight of block b = a_b + b_b * tau
+};
+__device__ __forceinline__ FactoredLane factored_lane(int r, bool lerp_rot) {
+  FactoredLane f;
+  const int sl = 16 + (r & 7);
+  f.main = r; f.left = 48 + (r & 7); f.tau_m = 72 + r / 6; f.tau_l = 72 + sl / 6;
+  const bool rot_m = (r % 6) < 3 && !lerp_rot, rot_l = (sl % 6) < 3 && !lerp_rot;   // rotation rows without interpolateRotation: pose 0 carries them whole, pose 1 nothing (cam.h:303-304)
+  f.a0 = 1.0; f.b0 = rot_m ? 0.0 : -1.0;
+  f.a1 = 0.0; f.b1 = rot_m ? 0.0 : 1.0;
+  const bool p1 = (r >> 3) != 0;
+  f.a2 = p1 ? 0.0 : 1.0; f.b2 = rot_l ? 0.0 : (p1 ? 1.0 : -1.0);
+  return f;
+}
+// the tile row of operand position (block Ib, row i of the block) of a factored side
+__device__ __forceinline__ int factored_row(int Ib, int i) {
+  const int s = Ib < 2 ? i : 16 + (i & 7), p = Ib == 0 ? 0 : Ib == 1 ? 1 : (i >> 3);
+  return 12 * (s / 6) + 6 * p + s % 6;
+}
+template <bool F> struct SchurSide;
+template <> struct SchurSide<true> { double qm[3], ql[3], tm, tl; };   // [coordinate]
+template <> struct SchurSide<false> { double v[3][3]; };               // [coordinate][block]
+
+template <bool DIAG, int kDepth, bool FA, bool FB>
 __device__ __forceinline__ void schur_chunk(const SolverDev& sv, const double* __restrict__ Pm, const double* __restrict__ zz, int chunk, double* smem) {
-  constexpr int GW = kTile * 3;                        // doubles per group
   constexpr int TPITCH = kTile + 1;
   constexpr unsigned kFull = DIAG ? kLowerBlocks : 0x1FFu;
   uint32_t* s_off = reinterpret_cast<uint32_t*>(smem);
@@ -467,14 +505,14 @@ __device__ __forceinline__ void schur_chunk(const SolverDev& sv, const double* _
   long long* tr = sv.schur_trace ? sv.schur_trace + 8 * (size_t)chunk : nullptr;
   if (tr && tid == 0) { tr[0] = blockIdx.x; tr[1] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); tr[2] = wall_clock64(); tr[6] = n; }   // HW_REG_HW_ID
   for (int k = tid; k < n16; k += 256) {
-    uint32_t ga = (uint32_t)sv.ngroups, gb = ga;       // the all-zero group behind the last one
+    uint32_t ga = sv.zero_off, gb = ga;       // the all-zero group behind the last one
     unsigned pm = 0;
     if (k < n) {
-      ga = (uint32_t)sv.ent_groups[2 * (e0 + k)]; gb = (uint32_t)sv.ent_groups[2 * (e0 + k) + 1];
+      ga = sv.ent_groups[2 * (e0 + k)] & ~15u; gb = sv.ent_groups[2 * (e0 + k) + 1] & ~15u;   // (the kind bit: the same for every entry of a tile pair — FA, FB)
       pm = sv.ent_mask[e0 + k] & kFull;   // 16 x 16 blocks of the entry with a frame that sees the point on both sides (host)
-      if (sv.schur_variant == 5) { ga = (uint32_t)(k & 63); gb = (uint32_t)(64 + (k & 63)); }   // ablation: operands out of the caches
+      if (sv.schur_variant == 5) { ga = (uint32_t)(k & 63) * kGroupFull; gb = (uint32_t)(64 + (k & 63)) * kGroupFull; }   // ablation: operands out of the caches
     }
-    s_off[2 * k] = ga * (uint32_t)GW; s_off[2 * k + 1] = gb * (uint32_t)GW;
+    s_off[2 * k] = ga; s_off[2 * k + 1] = gb;
     s_msk[(k & 3) * (kSchurChunk / 4) + (k >> 2)] = (uint16_t)pm;
     if (DIAG) {
       const int32_t pt = k < n ? sv.ent_pt[e0 + k] : 0;
@@ -484,36 +522,49 @@ __device__ __forceinline__ void schur_chunk(const SolverDev& sv, const double* _
   }
   __syncthreads();
   if (tr && tid == 0) tr[3] = wall_clock64();
-  // K = 3 per point against 4 per MFMA: four of the wave's entries share three MFMA steps, step t taking the
-  // coordinates k = 4t .. 4t+3 of the twelve — lane group g reads coordinate (4t + g) % 3 of entry (4t + g) / 3.
-  // The wave's entries are wave, wave + 4, ..: entry e of its group q is k = wave + 16 q + 4 e.
-  int tab[3], opo[3], zof[3];   // per step: byte offset of the entry's table cell in group 0, element offset of the operand inside a group, element offset of z
-#pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    const int e = (4 * t + g) / 3, c = (4 * t + g) % 3, k = wave + 4 * e;
-    tab[t] = 8 * k; opo[t] = c * kTile + r; zof[t] = 3 * k + c;
-  }
+  // K = 3 per point against 4 per MFMA: four of the wave's entries share three MFMA steps — step t takes coordinate t of the four,
+  // lane group g holding entry g of them (one table cell per lane and group of four).  The wave's entries are wave, wave + 4, ..:
+  // entry e of its group q is k = wave + 16 q + 4 e.
+  const int tab = 8 * (wave + 4 * g), zof = 3 * (wave + 4 * g);
+  const FactoredLane fl = factored_lane(r, sv.lerp_rot != 0);
   dbl4 acc[3][3];
 #pragma unroll
   for (int I = 0; I < 3; ++I)
 #pragma unroll
     for (int J = 0; J < 3; ++J) acc[I][J] = dbl4{0.0, 0.0, 0.0, 0.0};
   double racc[3] = {0.0, 0.0, 0.0};
-  struct Group { double a[3][3], b[3][3], z[3]; };   // [step][block row]
+  struct Group { SchurSide<FA> a; SchurSide<FB> b; double z[3]; };
   Group ring[kDepth];
   const int nq = n16 >> 4;   // groups of four entries per wave
   const char* lds = reinterpret_cast<const char*>(smem);
+  auto fetch_side = [&](const double* p, auto& S) {
+    using T = typename std::remove_reference<decltype(S)>::type;
+    if constexpr (std::is_same<T, SchurSide<true>>::value) {
+      S.tm = p[fl.tau_m]; S.tl = p[fl.tau_l];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) { S.qm[t] = p[fl.main + 16 * t]; S.ql[t] = p[fl.left + 8 * t]; }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int Ib = 0; Ib < 3; ++Ib) S.v[t][Ib] = p[t * kTile + 16 * Ib + r];
+    }
+  };
   auto fetch = [&](int q, Group& G) {   // (q is wave-uniform; past the end the last group is read again instead of branching)
     const int qq = q < nq ? q : nq - 1;
+    const uint2 o = *reinterpret_cast<const uint2*>(lds + tab + 128 * qq);
+    fetch_side(Pm + (size_t)o.x, G.a);
+    fetch_side(Pm + (size_t)o.y, G.b);
+    if (DIAG) {
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      const uint2 o = *reinterpret_cast<const uint2*>(lds + tab[t] + 128 * qq);
-      const double* pa = Pm + ((size_t)o.x + (size_t)opo[t]);
-      const double* pb = Pm + ((size_t)o.y + (size_t)opo[t]);
-#pragma unroll
-      for (int Ib = 0; Ib < 3; ++Ib) { G.a[t][Ib] = pa[16 * Ib]; G.b[t][Ib] = pb[16 * Ib]; }
-      if (DIAG) G.z[t] = s_z[zof[t] + 48 * qq];
+      for (int t = 0; t < 3; ++t) G.z[t] = s_z[zof + t + 48 * qq];
     }
+  };
+  // the three operand doubles of coordinate t (blocks 0, 1, 2)
+  auto operands = [&](const auto& S, int t, double w0, double w1, double w2, double out[3]) {
+    using T = typename std::remove_const<typename std::remove_reference<decltype(S)>::type>::type;
+    if constexpr (std::is_same<T, SchurSide<true>>::value) { out[0] = S.qm[t] * w0; out[1] = S.qm[t] * w1; out[2] = S.ql[t] * w2; }
+    else { out[0] = S.v[t][0]; out[1] = S.v[t][1]; out[2] = S.v[t][2]; }
   };
   unsigned issued = 0;
   if (nq > 0) {
@@ -527,31 +578,46 @@ __device__ __forceinline__ void schur_chunk(const SolverDev& sv, const double* _
           const uint2 m4 = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(s_msk) + 2 * (wave * (kSchurChunk / 4) + 4 * (base + d)));
           unsigned mv = m4.x | m4.y; mv = (mv | (mv >> 16)) & 0x1FFu;
           unsigned pm = (unsigned)__builtin_amdgcn_readfirstlane((int)mv);
-          if (sv.schur_variant == 4) { pm = 0; asm volatile("" :: "v"(ring[d].a[0][0]), "v"(ring[d].b[2][2]), "v"(ring[d].a[1][1]), "v"(ring[d].b[1][0]), "v"(ring[d].a[2][2]), "v"(ring[d].b[0][1])); }   // ablation: loads only
+          const Group& G = ring[d];
+          // the weights of a factored side's three blocks for this lane's entry: a + b tau (1 - tau and tau; 1 and 0 for rotation rows without interpolateRotation)
+          double wa0 = 0, wa1 = 0, wa2 = 0, wb0 = 0, wb1 = 0, wb2 = 0;
+          if constexpr (FA) { wa0 = __builtin_fma(fl.b0, G.a.tm, fl.a0); wa1 = __builtin_fma(fl.b1, G.a.tm, fl.a1); wa2 = __builtin_fma(fl.b2, G.a.tl, fl.a2); }
+          if constexpr (FB) { wb0 = __builtin_fma(fl.b0, G.b.tm, fl.a0); wb1 = __builtin_fma(fl.b1, G.b.tm, fl.a1); wb2 = __builtin_fma(fl.b2, G.b.tl, fl.a2); }
+          if (sv.schur_variant == 4) pm = 0;   // ablation: loads only
           if (pm == kFull) {
 #pragma unroll
-            for (int t = 0; t < 3; ++t)
+            for (int t = 0; t < 3; ++t) {
+              double a[3], b[3];
+              operands(G.a, t, wa0, wa1, wa2, a); operands(G.b, t, wb0, wb1, wb2, b);
 #pragma unroll
               for (int I = 0; I < 3; ++I)
 #pragma unroll
                 for (int J = 0; J < 3; ++J)
-                  if (!DIAG || J <= I) acc[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[d].a[t][I], ring[d].b[t][J], acc[I][J], 0, 0, 0);
-          } else if (pm != 0u) {
+                  if (!DIAG || J <= I) acc[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[I], b[J], acc[I][J], 0, 0, 0);
+              if (DIAG) {
 #pragma unroll
-            for (int t = 0; t < 3; ++t)
+                for (int I = 0; I < 3; ++I) racc[I] += a[I] * G.z[t];
+              }
+            }
+          } else {
 #pragma unroll
-              for (int I = 0; I < 3; ++I)
+            for (int t = 0; t < 3; ++t) {
+              double a[3], b[3];
+              operands(G.a, t, wa0, wa1, wa2, a); operands(G.b, t, wb0, wb1, wb2, b);
+              if (pm != 0u) {
 #pragma unroll
-                for (int J = 0; J < 3; ++J)
-                  if ((!DIAG || J <= I) && ((pm >> (3 * I + J)) & 1u)) acc[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[d].a[t][I], ring[d].b[t][J], acc[I][J], 0, 0, 0);
+                for (int I = 0; I < 3; ++I)
+#pragma unroll
+                  for (int J = 0; J < 3; ++J)
+                    if ((!DIAG || J <= I) && ((pm >> (3 * I + J)) & 1u)) acc[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[I], b[J], acc[I][J], 0, 0, 0);
+              }
+              if (DIAG) {
+#pragma unroll
+                for (int I = 0; I < 3; ++I) racc[I] += a[I] * G.z[t];
+              }
+            }
           }
           issued += 3u * (unsigned)__builtin_popcount(pm);
-          if (DIAG) {
-#pragma unroll
-            for (int t = 0; t < 3; ++t)
-#pragma unroll
-              for (int I = 0; I < 3; ++I) racc[I] += ring[d].a[t][I] * ring[d].z[t];
-          }
         }
         fetch(base + d + kDepth, ring[d]);
       }
@@ -561,12 +627,22 @@ __device__ __forceinline__ void schur_chunk(const SolverDev& sv, const double* _
   __syncthreads();   // everyone is done with the tables: the same LDS now takes the four partial tiles
   if (tr && tid == 0) tr[4] = wall_clock64();
   double* buf = smem + wave * (kTile * TPITCH);
+  // every result to its place in the tile: a factored side's rows were taken in this kernel's own order (factored_row).  A factored tile
+  // paired with itself formed the blocks J <= I of that order: each lands twice, as (row, column) and as (column, row) — the tile comes
+  // out symmetric in full (S_ij and S_ji are the same products summed in the same order: the same bits).
 #pragma unroll
   for (int I = 0; I < 3; ++I)
 #pragma unroll
-    for (int J = 0; J < 3; ++J)
+    for (int J = 0; J < 3; ++J) {
+      if (DIAG && FA && J > I) continue;
+      const int cb = FB ? factored_row(J, r) : 16 * J + r;
 #pragma unroll
-      for (int v = 0; v < 4; ++v) buf[(16 * I + g + 4 * v) * TPITCH + 16 * J + r] = acc[I][J][v];
+      for (int v = 0; v < 4; ++v) {
+        const int ra = FA ? factored_row(I, g + 4 * v) : 16 * I + g + 4 * v;
+        buf[ra * TPITCH + cb] = acc[I][J][v];
+        if (DIAG && FA && J < I) buf[cb * TPITCH + ra] = acc[I][J][v];
+      }
+    }
   double* rvec = smem + 4 * kTile * TPITCH + wave * kTile;
   if (DIAG) {
 #pragma unroll
@@ -574,7 +650,7 @@ __device__ __forceinline__ void schur_chunk(const SolverDev& sv, const double* _
       double x = racc[I];
       x += __shfl_xor(x, 16, 64);
       x += __shfl_xor(x, 32, 64);
-      if (lane < 16) rvec[16 * I + lane] = x;
+      if (lane < 16) rvec[FA ? factored_row(I, lane) : 16 * I + lane] = x;
     }
   }
   __syncthreads();
@@ -587,8 +663,8 @@ __device__ __forceinline__ void schur_chunk(const SolverDev& sv, const double* _
   if (tr && tid == 0) tr[5] = wall_clock64();
 }
 
-// kDepth = groups of four entries in flight per wave (18 loads each: vmcnt counts to 63).  Two waves per SIMD (two workgroups per CU) fit 256
-// registers with two groups in flight; three need 300.
+// kDepth = groups of four entries in flight per wave (18 loads each in full form, 16 factored: vmcnt counts to 63).  Two waves per SIMD (two workgroups
+// per CU) fit 256 registers with two groups in flight; three need 300.
 template <int kDepth, int kWavesPerSimd>
 __global__ __launch_bounds__(256, kWavesPerSimd) void schur_tile_kernel(const SolverDev sv, const double* __restrict__ Pm, const double* __restrict__ zz) {
   if (lm_stopped(sv.ctl)) return;
@@ -599,8 +675,13 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void schur_tile_kernel(const So
   const int chunk = sv.schur_linear ? (int)blockIdx.x : (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
   if (chunk >= sv.nchunk) return;
   const int tp = sv.chunk_tp[chunk];
-  if (sv.tp_I[tp] == sv.tp_J[tp]) schur_chunk<true, kDepth>(sv, Pm, zz, chunk, smem);
-  else schur_chunk<false, kDepth>(sv, Pm, zz, chunk, smem);
+  const int I = sv.tp_I[tp], J = sv.tp_J[tp];
+  const bool fa = sv.tile_factored && sv.tile_factored[I], fb = sv.tile_factored && sv.tile_factored[J];
+  if (I == J) { if (fa) schur_chunk<true, kDepth, true, true>(sv, Pm, zz, chunk, smem); else schur_chunk<true, kDepth, false, false>(sv, Pm, zz, chunk, smem); }
+  else if (fa && fb) schur_chunk<false, kDepth, true, true>(sv, Pm, zz, chunk, smem);
+  else if (fb) schur_chunk<false, kDepth, false, true>(sv, Pm, zz, chunk, smem);        // an intrinsics pseudo tile (full form) against a frame tile
+  else if (fa) schur_chunk<false, kDepth, true, false>(sv, Pm, zz, chunk, smem);        // (a frame tile against a lower-numbered full-form tile: not produced by the plan today)
+  else schur_chunk<false, kDepth, false, false>(sv, Pm, zz, chunk, smem);
 }
 
 // one workgroup per group of a very long chunk list: partial[first] = sum of the group's partials, in list order
@@ -647,7 +728,12 @@ __global__ __launch_bounds__(256) void schur_merge_kernel(const DeviceProblem dp
       for (int u = 0; u < 8; ++u) ps[u] += sv.schur_part[(size_t)sv.tp_chunk_list[ch + u] * pstride + e];
     }
     for (int u = 0; ch < c1; ++ch, ++u) ps[u] += sv.schur_part[(size_t)sv.tp_chunk_list[ch] * pstride + e];
-    const double sum = ((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7]));
+    double sum = ((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7]));
+    // a factored side left its column scales out of the products (they do not depend on the point): applied here, once per element
+    if (sv.tile_factored) {
+      if (sv.tile_factored[I]) sum *= a < sv.F ? dp.scale_pose[(size_t)a * CD + r] : 0.0;
+      if (sv.tile_factored[J]) sum *= b < sv.F ? dp.scale_pose[(size_t)b * CD + c] : 0.0;
+    }
     double val;
     const bool lead = sv.frame_lead ? sv.frame_lead[a] != 0.0 : sv.lead != 0;   // does this rank add the frame's replicated terms (sharded factorisation: the owner of its part)
     if (a >= sv.Fx || b >= sv.Fx) val = (a == b && r == c && lead) ? 1.0 : 0.0;     // padding frames of the last tile
@@ -667,7 +753,8 @@ __global__ __launch_bounds__(256) void schur_merge_kernel(const DeviceProblem dp
       for (int u = 0; u < 8; ++u) ps[u] += sv.schur_part[(size_t)sv.tp_chunk_list[ch + u] * pstride + kTile * kTile + tid];
     }
     for (int u = 0; ch < c1; ++ch, ++u) ps[u] += sv.schur_part[(size_t)sv.tp_chunk_list[ch] * pstride + kTile * kTile + tid];
-    const double sum = ((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7]));
+    double sum = ((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7]));
+    if (sv.tile_factored && sv.tile_factored[I]) sum *= a < sv.F ? dp.scale_pose[(size_t)I * kTile + tid] : 0.0;
     const bool lead = sv.frame_lead ? sv.frame_lead[a] != 0.0 : sv.lead != 0;
     sv.rhs[(size_t)I * kTile + tid] = (a < sv.Fx) ? (lead ? sv.gc[(size_t)I * kTile + tid] : 0.0) - sum : 0.0;
   }
@@ -790,15 +877,20 @@ __device__ __forceinline__ void slot_record(const DeviceProblem& dp, const Solve
   lm_observation<CAL, P>(dp, frame, point, xy.x, xy.y, pose, psc, o, half_rho, dropped);
 }
 
-// K5b without records: P = Jc^T (Jp L^-T) of 64 consecutive slots per wave and step, into the group layout (see project_kernel)
+// K5b without records: P = Jc^T (Jp L^-T) of 64 consecutive slots per wave and step, into the group layout (see project_kernel).
+// A slot whose group is stored FACTORED (two-pose frame tiles, solver_state.hpp: kGroupFactored) leaves q = Jq^T (Jp L^-T), 6 x 3 — the
+// block with respect to the interpolated pose, loss-corrected, WITHOUT the (1 - tau) / tau weights and without the column scales — and
+// tau: the twelve rows (1 - tau) q | tau q are formed by the Schur kernel in registers, the column scales are applied where its partial
+// tiles are merged.  Half the bytes written here (the pass is bound by its stores) and read there.
+//   group layout: [c][16] sources s = 0..15 of coordinate c | [c][8] sources 16..23 | tau[4];  source s = 6 (frame position in the tile) + pose coordinate
 template <bool CAL, int P>
 __global__ __launch_bounds__(256) void project_rc_kernel(const DeviceProblem dp, const SolverDev sv, int nch) {
   if (lm_stopped(sv.ctl)) return;   // (device-side trust region: the solve is over, iterations enqueued ahead fall through)
-  constexpr int CD = 6 * P, OUT = CD * 3, FT = kTile / CD, PITCH = OUT | 1, kPer = 64 / CD, OP = CAL ? 0 : 9;   // OP: the pose columns follow the 9 intrinsics columns
+  constexpr int CD = 6 * P, OUT = CD * 3, PITCH = OUT | 1, kPer = 64 / CD, OP = CAL ? 0 : 9;   // OP: the pose columns follow the 9 intrinsics columns
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double* buf = smem + (size_t)wave * (64 * PITCH + 32);
-  int32_t* s_gpos = reinterpret_cast<int32_t*>(buf + 64 * PITCH);
+  uint32_t* s_gpos = reinterpret_cast<uint32_t*>(buf + 64 * PITCH);
   const int64_t sb = ((int64_t)blockIdx.x * 4 + wave) * 64 * nch;
   if (sb >= dp.N) return;
   const int64_t se = sb + 64 * nch < dp.N ? sb + 64 * nch : dp.N;
@@ -816,23 +908,60 @@ __global__ __launch_bounds__(256) void project_rc_kernel(const DeviceProblem dp,
       const double p0 = o.J[r][OP + CD], p1 = o.J[r][OP + CD + 1], p2 = o.J[r][OP + CD + 2];
       B[r][0] = p0 * i00; B[r][1] = p0 * i10 + p1 * i11; B[r][2] = p0 * i20 + p1 * i21 + p2 * i22;
     }
+    const uint32_t gpos = sv.slot_gpos[s];
+    if (P == 2 && gpos_factored(gpos)) {
 #pragma unroll
-    for (int a = 0; a < CD; ++a)
+      for (int a = 0; a < 6; ++a)
 #pragma unroll
-      for (int k = 0; k < 3; ++k) buf[lane * PITCH + k * CD + a] = o.J[0][OP + a] * B[0][k] + o.J[1][OP + a] * B[1][k];
-    s_gpos[lane] = sv.slot_gpos[s];
+        for (int k = 0; k < 3; ++k) buf[lane * PITCH + k * 6 + a] = o.Jq[0][a] * B[0][k] + o.Jq[1][a] * B[1][k];
+      buf[lane * PITCH + 18] = o.tau;
+    } else {
+#pragma unroll
+      for (int a = 0; a < CD; ++a)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) buf[lane * PITCH + k * CD + a] = o.J[0][OP + a] * B[0][k] + o.J[1][OP + a] * B[1][k];
+    }
+    s_gpos[lane] = gpos;
+    const bool any_factored = P == 2 && __ballot(gpos_factored(gpos)) != 0ull, any_full = __ballot(!(P == 2 && gpos_factored(gpos))) != 0ull;   // (wave-uniform: a wave's slots are almost always of one kind)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int my = lane / CD, w = lane % CD;
-    if (my < kPer) {
+    if (any_factored) {
+      // factored slots: six lanes per slot (a pose coordinate each), ten slots per pass; the lane of coordinate 0 also stores tau
+      constexpr int kPerF = 10;
+      const int my = lane / 6, w = lane % 6;
+      if (my < kPerF) {
 #pragma unroll 2
-      for (int i = 0; i * kPer < 64; ++i) {
-        const int sl = i * kPer + my;
-        if (sl < nslot) {
-          const int gpos = s_gpos[sl];
-          double* dst = sv.Pm + ((size_t)(gpos / FT) * (kTile * 3) + (size_t)((gpos % FT) * CD + w));
-          const double* src = buf + sl * PITCH + w;
+        for (int i = 0; i * kPerF < 64; ++i) {
+          const int sl = i * kPerF + my;
+          if (sl < nslot) {
+            const uint32_t gp = s_gpos[sl];
+            if (gpos_factored(gp)) {
+              const int src_no = 6 * gpos_pos(gp) + w;   // source 0..23 of the group
+              double* dst = sv.Pm + gpos_group(gp) + (src_no < 16 ? src_no : 48 + (src_no - 16));
+              const int stride = src_no < 16 ? 16 : 8;
+              const double* src = buf + sl * PITCH + w;
 #pragma unroll
-          for (int comp = 0; comp < 3; ++comp) dst[comp * kTile] = src[comp * CD];
+              for (int comp = 0; comp < 3; ++comp) dst[comp * stride] = src[comp * 6];
+              if (w == 0) sv.Pm[gpos_group(gp) + 72 + gpos_pos(gp)] = buf[sl * PITCH + 18];
+            }
+          }
+        }
+      }
+    }
+    if (any_full) {
+      const int my = lane / CD, w = lane % CD;
+      if (my < kPer) {
+#pragma unroll 2
+        for (int i = 0; i * kPer < 64; ++i) {
+          const int sl = i * kPer + my;
+          if (sl < nslot) {
+            const uint32_t gp = s_gpos[sl];
+            if (!gpos_factored(gp)) {
+              double* dst = sv.Pm + (gpos_group(gp) + (size_t)(gpos_pos(gp) * CD + w));
+              const double* src = buf + sl * PITCH + w;
+#pragma unroll
+              for (int comp = 0; comp < 3; ++comp) dst[comp * kTile] = src[comp * CD];
+            }
+          }
         }
       }
     }
@@ -1001,7 +1130,7 @@ __global__ __launch_bounds__(256) void point_step_rc_kernel(const DeviceProblem 
 template <int P>
 __global__ __launch_bounds__(256) void virtual_records_rc_kernel(const DeviceProblem dp, const SolverDev sv, int sp) {
   if (lm_stopped(sv.ctl)) return;
-  constexpr int CD = 6 * P, OX = 9 + CD, FT = kTile / CD;
+  constexpr int CD = 6 * P, OX = 9 + CD;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   point_sweep<false, P, 27>(dp, sv, smem, sp, blockIdx.x,
     [&](const ObsOut<false, P>& o, int, int j, double c[27]) {
@@ -1022,8 +1151,8 @@ __global__ __launch_bounds__(256) void virtual_records_rc_kernel(const DevicePro
       const int64_t g = sv.point_vgroup[j];
       if (g < 0) return 0.0;
       for (int v = 0; v < sv.NPF; ++v) {
-        const int gpos = sv.slot_gpos[dp.N + g * sv.NPF + v];
-        double* out = sv.Pm + (size_t)(gpos / FT) * (kTile * 3) + (gpos % FT) * CD;
+        const uint32_t gpos = sv.slot_gpos[dp.N + g * sv.NPF + v];   // (a pseudo frame's tile: full form)
+        double* out = sv.Pm + gpos_group(gpos) + gpos_pos(gpos) * CD;
 #pragma unroll
         for (int rl = 0; rl < CD; ++rl) {
           const int k = v * CD + rl;

@@ -56,11 +56,19 @@ __device__ __forceinline__ void lm_observation(const DeviceProblem& dp, int f, i
   o.r[0] *= sr1; o.r[1] *= sr1;
 #pragma unroll
   for (int k = 0; k < K; ++k) { const double c = sr1 * sc[k]; o.J[0][k] *= c; o.J[1][k] *= c; }
+  if (P == 2) {   // the unscaled pose block gets the loss correction only: its column scales are applied where the Schur partials are merged
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { o.Jq[0][k] *= sr1; o.Jq[1][k] *= sr1; }
+  }
   // a failed block contributes zeros everywhere (record, camera blocks)
   if (!o.ok) {
     o.r[0] = 0.0; o.r[1] = 0.0;
 #pragma unroll
     for (int k = 0; k < K; ++k) { o.J[0][k] = 0.0; o.J[1][k] = 0.0; }
+    if (P == 2) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { o.Jq[0][k] = 0.0; o.Jq[1][k] = 0.0; }
+    }
   }
 }
 

@@ -32,6 +32,11 @@ struct ObsOut {
   double r[2];
   double J[2][K];
   bool ok;
+  // P == 2, WANT_J: the block BEFORE the (1 - tau) / tau scaling — the 2 x 6 Jacobian with respect to the interpolated pose
+  // [d/dr | d/dt] — and tau itself: the factored P records of the point elimination (kernels_normal.hip, project_rc_kernel) store
+  // Jq^T Jp L^-T once per observation instead of its two scaled copies.  Dead code wherever nobody reads them.
+  double Jq[2][6];
+  double tau;
 };
 
 // R = exp([w]x), p = R q, and D = d(R q)/dw.  Same branch as AngleAxisRotatePoint: Rodrigues when
@@ -159,6 +164,9 @@ __device__ __forceinline__ void eval_observation(const Model& m, const double* _
     if (P == 2) {
       const double s0 = 1.0 - tau, s1 = tau;
       const bool lerp_rot = m.interp_rotation && m.shutter != kGlobal;
+      o.tau = tau;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { o.Jq[rr][j] = Jw[rr][j]; o.Jq[rr][3 + j] = -JX[rr][j]; }
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         o.J[rr][OFF_POSE + j] = lerp_rot ? s0 * Jw[rr][j] : Jw[rr][j];       // d/d r0

@@ -230,7 +230,9 @@ struct Uploader {
 // its own, freed on return); rsba_release_host_scratch() gives the memory back.
 struct PlanScratch {
   std::vector<int64_t> point_ptr, fill, vgroup_ptr, pt_group;
-  std::vector<int32_t> obs_slot, real_frame, slot_frame, slot_point, slot_gpos, g_tile, g_rows, ent_groups, ent_pt, vgroup_point, vgroup_intr;
+  std::vector<int32_t> obs_slot, real_frame, slot_frame, slot_point, g_tile, g_rows, ent_pt, vgroup_point, vgroup_intr;
+  std::vector<uint32_t> slot_gpos, ent_groups, g_off;
+  std::vector<int64_t> pt_goff;
   std::vector<uint8_t> group_mask, group_present;
   std::vector<uint16_t> ent_mask;
   std::vector<std::vector<int32_t>> thread_cnt;
@@ -389,9 +391,20 @@ int32_t build_solver_impl(rsba_handle* h) {
   // to be 85 % of the symbolic phase): group g of point j covers one tile and one layer and owns FT slot entries.
   std::vector<int64_t>& pt_group = scr.pt_group; pt_group.assign((size_t)M + 1, 0);     // groups of point j: [pt_group[j], pt_group[j+1])
   std::vector<int32_t>& g_tile = scr.g_tile; std::vector<int32_t>& g_rows = scr.g_rows;   // tile of each group; FT slots per group (NS = not observed)
-  std::vector<int32_t>& slot_gpos = scr.slot_gpos; slot_gpos.resize((size_t)NS);           // group * FT + position of every slot: where its P record goes
+  std::vector<uint32_t>& slot_gpos = scr.slot_gpos; slot_gpos.resize((size_t)NS);         // where every slot's P record goes: group offset | position << 1 | kind (solver_state.hpp)
   std::vector<uint8_t>& group_mask = scr.group_mask;        // which of the three 16-row blocks of a group's records can be non-zero
   std::vector<uint8_t>& group_present = scr.group_present;  // frames of the group's tile that see the point (plan statistics)
+  // Which frame tiles store their groups FACTORED (solver_state.hpp: kGroupFactored): two-pose frames of a problem whose point-side passes
+  // recompute the records — the 12 camera-side rows of a frame are (1 - tau) q | tau q, so 6 rows and tau say it all —
+  // except a tile that holds an intrinsics pseudo frame (its virtual records have no such structure).  RSBA_FACTORED=0: none (A/B).
+  bool recompute = dp.calibrated != 0 || NIB == 1;
+  if (const char* e = std::getenv("RSBA_RECORDS")) recompute = recompute && e[0] != '1';
+  bool factored = recompute && dp.P == 2;
+  if (const char* e = std::getenv("RSBA_FACTORED")) factored = factored && e[0] != '0';
+  std::vector<uint8_t> tile_factored((size_t)nt, 0);
+  for (int t = 0; t < nt && factored; ++t) tile_factored[t] = !((int64_t)(t + 1) * FT > FR && (int64_t)t * FT < F && F > FR);   // (no pseudo frame in [t FT, (t + 1) FT))
+  std::vector<uint32_t>& g_off = scr.g_off;                 // element offset of every group in Pm
+  std::vector<int64_t>& pt_goff = scr.pt_goff; pt_goff.assign((size_t)M + 1, 0);   // doubles of the groups of the points before j
   const int nthr_pts = M >= 4096 ? plan_threads : 1;
   {
     // one walk over a point's slots: on_group(g, tile) for every new (tile, layer) group g = 0, 1, .. of the point, on_slot(g, pos, slot)
@@ -411,25 +424,36 @@ int32_t build_solver_impl(rsba_handle* h) {
     // count, prefix, fill — over contiguous point ranges on a few threads (the lists come out as from one thread)
     parallel_ranges(nthr_pts, M, [&](int64_t a, int64_t b, int) {
       std::vector<int64_t> ps;
-      for (int64_t j = a; j < b; ++j) pt_group[j + 1] = walk((int)j, ps, [](int64_t, int) {}, [](int64_t, int, int64_t) {});
+      for (int64_t j = a; j < b; ++j) {
+        int64_t doubles = 0;
+        pt_group[j + 1] = walk((int)j, ps, [&](int64_t, int tile) { doubles += tile_factored[tile] ? kGroupFactored : kGroupFull; }, [](int64_t, int, int64_t) {});
+        pt_goff[j + 1] = doubles;
+      }
     });
-    for (int j = 0; j < M; ++j) pt_group[j + 1] += pt_group[j];
+    for (int j = 0; j < M; ++j) { pt_group[j + 1] += pt_group[j]; pt_goff[j + 1] += pt_goff[j]; }
     const int64_t NG = pt_group[M];
+    // (more than 2^32 doubles of groups: the offsets below wrap; the plan is given up right behind this pass — on several ranks through the vote)
     g_tile.resize((size_t)NG); g_rows.assign((size_t)NG * FT, (int32_t)NS);   // NS = the all-zero record behind the last slot: "not observed"
+    g_off.resize((size_t)NG + 1);
     group_mask.assign((size_t)NG + 1, 0); group_present.assign((size_t)NG + 1, 0);
     parallel_ranges(nthr_pts, M, [&](int64_t a, int64_t b, int) {
       std::vector<int64_t> ps;
       for (int64_t j = a; j < b; ++j) {
         const int64_t base = pt_group[j];
-        walk((int)j, ps, [&](int64_t g, int tile) { g_tile[(size_t)(base + g)] = tile; },
+        int64_t at = pt_goff[j];
+        walk((int)j, ps, [&](int64_t g, int tile) { g_tile[(size_t)(base + g)] = tile; g_off[(size_t)(base + g)] = (uint32_t)at; at += tile_factored[tile] ? kGroupFactored : kGroupFull; },
              [&](int64_t g, int pos, int64_t sl) {
-               g_rows[(size_t)(base + g) * FT + pos] = (int32_t)sl;
-               slot_gpos[sl] = (int32_t)((base + g) * FT + pos);
-               ++group_present[(size_t)(base + g)];
-               for (int row = pos * CD; row < (pos + 1) * CD; row += 4) group_mask[(size_t)(base + g)] |= (uint8_t)(1u << (row / 16));
+               const size_t gg = (size_t)(base + g);
+               const bool fac = tile_factored[g_tile[gg]] != 0;
+               g_rows[gg * FT + pos] = (int32_t)sl;
+               slot_gpos[sl] = g_off[gg] | ((uint32_t)pos << 1) | (fac ? 1u : 0u);
+               ++group_present[gg];
+               if (fac) group_mask[gg] |= (uint8_t)(pos < 2 ? 0b011 : pos == 2 ? 0b111 : 0b100);   // (factored: blocks 0 / 1 hold sources 0..15 = frames 0, 1 and two thirds of 2; block 2 the rest)
+               else for (int row = pos * CD; row < (pos + 1) * CD; row += 4) group_mask[gg] |= (uint8_t)(1u << (row / 16));
              });
       }
     });
+    g_off[(size_t)NG] = (uint32_t)pt_goff[M];
   }
   sv.ngroups = (int64_t)g_tile.size();
   // A plan that cannot be built on THIS rank must not leave the other ranks waiting in the vote further down (one all-reduce in the
@@ -437,7 +461,7 @@ int32_t build_solver_impl(rsba_handle* h) {
   const bool plan_votes = h->allreduce && h->world > 1 && !h->union_mask.empty();
   int32_t local_fail = RSBA_OK; const char* local_why = "";
   if (std::getenv("RSBA_TEST_FAIL_PLAN")) { local_fail = RSBA_ERR_UNSUPPORTED; local_why = "RSBA_TEST_FAIL_PLAN: the plan was made to fail (test hook)"; }   // after the uploader has started
-  else if ((sv.ngroups + 1) * (int64_t)kTile * 3 >= ((int64_t)1 << 32)) { local_fail = RSBA_ERR_UNSUPPORTED; local_why = "more than 2^32 doubles of P records: the Schur kernel indexes them with 32 bits"; }
+  else if (pt_goff[M] + kGroupFull >= ((int64_t)1 << 32)) { local_fail = RSBA_ERR_UNSUPPORTED; local_why = "more than 2^32 doubles of P records: the Schur kernel indexes them with 32 bits"; }
   if (local_fail && !plan_votes) return rsba_set_error(local_fail, local_why);
   up.upload_const_ref(&sv.slot_gpos, slot_gpos);
   const bool dense_keys = (int64_t)nt * nt <= (int64_t)1 << 26;
@@ -556,8 +580,21 @@ int32_t build_solver_impl(rsba_handle* h) {
   auto index_of = [&](int I, int J) -> int32_t { return dense_keys ? dense_index[(size_t)I * nt + J] : tp_index[(int64_t)I * nt + J]; };
   const int64_t nent = tp_ptr.back();
   // an entry is the pair of groups (of tile I, of tile J) plus its point: the kernel looks the slots up in g_rows
-  std::vector<int32_t>& ent_groups = scr.ent_groups; ent_groups.resize((size_t)nent * 2);
+  std::vector<uint32_t>& ent_groups = scr.ent_groups; ent_groups.resize((size_t)nent * 2);   // (where the two groups start in Pm | kind: solver_state.hpp)
   std::vector<int32_t>& ent_pt = scr.ent_pt; ent_pt.resize((size_t)nent);
+  // ... and, per entry, which of the 3 x 3 block products of its two groups can be non-zero
+  std::vector<uint16_t>& ent_mask = scr.ent_mask; ent_mask.resize((size_t)nent);
+  std::vector<int64_t> products_part((size_t)std::max(nthreads, 1), 0);   // (plan statistics: block products that are not structurally zero)
+  auto put_entry = [&](int64_t w, int64_t gx, int64_t gy, int j, int64_t& prod) {
+    ent_groups[2 * (size_t)w] = g_off[(size_t)gx] | (tile_factored[g_tile[(size_t)gx]] ? 1u : 0u);
+    ent_groups[2 * (size_t)w + 1] = g_off[(size_t)gy] | (tile_factored[g_tile[(size_t)gy]] ? 1u : 0u);
+    ent_pt[w] = j | (gx == gy ? (int32_t)0x80000000 : 0);   // top bit: the entry carries the rhs term P z
+    const unsigned ma = group_mask[(size_t)gx], mb = group_mask[(size_t)gy];
+    unsigned pm = 0;
+    for (int I = 0; I < 3; ++I) if ((ma >> I) & 1u) pm |= mb << (3 * I);
+    ent_mask[(size_t)w] = (uint16_t)pm;
+    prod += (int64_t)group_present[(size_t)gx] * group_present[(size_t)gy];
+  };
   {
     std::vector<int64_t> fill(tp_ptr.begin(), tp_ptr.end() - 1);
     if (nthreads > 1) {
@@ -573,42 +610,23 @@ int32_t build_solver_impl(rsba_handle* h) {
         pool.emplace_back([&, t]() {
           std::vector<int64_t>& cur = cursor[t];
           const auto r = point_range(t);
+          int64_t prod = 0;
           for (int j = r.first; j < r.second; ++j)
-            for_each_entry(j, [&](int64_t gx, int64_t gy) {
-              const int64_t w = cur[dense_index[(size_t)g_tile[gx] * nt + g_tile[gy]]]++;
-              ent_groups[2 * (size_t)w] = (int32_t)gx; ent_groups[2 * (size_t)w + 1] = (int32_t)gy;
-              ent_pt[w] = j | (gx == gy ? (int32_t)0x80000000 : 0);
-            });
+            for_each_entry(j, [&](int64_t gx, int64_t gy) { put_entry(cur[dense_index[(size_t)g_tile[gx] * nt + g_tile[gy]]]++, gx, gy, j, prod); });
+          products_part[t] = prod;
         });
       for (auto& th : pool) th.join();
-    } else
-    for (int j = 0; j < M; ++j)
-      for_each_entry(j, [&](int64_t gx, int64_t gy) {
-        const int64_t w = fill[index_of(g_tile[gx], g_tile[gy])]++;
-        ent_groups[2 * (size_t)w] = (int32_t)gx; ent_groups[2 * (size_t)w + 1] = (int32_t)gy;
-        ent_pt[w] = j | (gx == gy ? (int32_t)0x80000000 : 0);   // top bit: the entry carries the rhs term P z
-      });
+    } else {
+      int64_t prod = 0;
+      for (int j = 0; j < M; ++j) for_each_entry(j, [&](int64_t gx, int64_t gy) { put_entry(fill[index_of(g_tile[gx], g_tile[gy])]++, gx, gy, j, prod); });
+      products_part[0] = prod;
+    }
   }
   std::vector<int32_t>().swap(dense_index);
   const int ntp = (int)tp_I.size();
   s->num_pairs = nent;
   up.upload_const_ref(&sv.ent_groups, ent_groups);
   up.upload_const_ref(&sv.ent_pt, ent_pt);
-  // per entry, which of the 3 x 3 block products of its two groups can be non-zero
-  std::vector<uint16_t>& ent_mask = scr.ent_mask; ent_mask.resize((size_t)nent);
-  std::vector<int64_t> products_part((size_t)std::max(nthreads, 1), 0);   // (plan statistics: block products that are not structurally zero)
-  parallel_ranges(nthreads, nent, [&](int64_t a, int64_t b, int t) {
-    int64_t prod = 0;
-    for (int64_t e = a; e < b; ++e) {
-      const int32_t ga = ent_groups[2 * (size_t)e], gb = ent_groups[2 * (size_t)e + 1];
-      const unsigned ma = group_mask[ga], mb = group_mask[gb];
-      unsigned pm = 0;
-      for (int I = 0; I < 3; ++I) if ((ma >> I) & 1u) pm |= mb << (3 * I);
-      ent_mask[(size_t)e] = (uint16_t)pm;
-      prod += (int64_t)group_present[ga] * group_present[gb];
-    }
-    products_part[t] = prod;
-  });
   up.upload_const_ref(&sv.ent_mask, ent_mask);
 
   // ---- tile graph of S, fill-reducing / parallelism-exposing ordering, symbolic factorisation ----
@@ -1002,6 +1020,8 @@ int32_t build_solver_impl(rsba_handle* h) {
   }
 
   int32_t rc;
+  sv.tile_factored = nullptr;
+  if (factored) up.upload_const(&sv.tile_factored, tile_factored);
   up.upload_const(&sv.tp_I, tp_I);
   up.upload_const(&sv.tp_J, tp_J);
   up.upload_const(&sv.tp_ptr, tp_ptr);
@@ -1123,9 +1143,7 @@ int32_t build_solver_impl(rsba_handle* h) {
   h->dp.obs_slot = s->d_obs_slot;
   // The point-side passes recompute the records (lm_record.hpp) from the observations in slot order; problems with several
   // intrinsics parameter blocks (per-frame f.cam) keep the point-major copy.  RSBA_RECORDS=1 forces the copy.
-  bool recompute = dp.calibrated != 0 || NIB == 1;
-  if (const char* e = std::getenv("RSBA_RECORDS")) recompute = recompute && e[0] != '1';
-  sv.slot_xy = nullptr; h->dp.rec = nullptr;
+  sv.slot_xy = nullptr; h->dp.rec = nullptr;   // (recompute: settled with the group layout above)
   if (recompute) {
     double2* sxy = nullptr;
     if ((rc = s_alloc(s, &sxy, (size_t)N))) return rc;
@@ -1169,8 +1187,11 @@ int32_t build_solver_impl(rsba_handle* h) {
   if ((rc = s_alloc(s, &sv.diag_p, (size_t)M * 3))) return rc;
   if ((rc = s_alloc(s, &sv.Linv, (size_t)M * 6))) return rc;
   if ((rc = s_alloc(s, &sv.z, (size_t)M * 3))) return rc;
-  if ((rc = s_alloc(s, &sv.Pm, (size_t)(sv.ngroups + 1) * kTile * 3))) return rc;   // (+ the all-zero group)
-  HIP_TRY(hipMemsetAsync(sv.Pm, 0, (size_t)(sv.ngroups + 1) * kTile * 3 * sizeof(double), h->stream));   // rows of frames that do not see the point stay zero for good: nothing ever writes them
+  const size_t pm_doubles = (size_t)pt_goff[M] + kGroupFull;   // (+ the all-zero group)
+  sv.zero_off = (uint32_t)pt_goff[M];
+  sv.lerp_rot = dp.interp_rotation && dp.shutter != 0;
+  if ((rc = s_alloc(s, &sv.Pm, pm_doubles))) return rc;
+  HIP_TRY(hipMemsetAsync(sv.Pm, 0, pm_doubles * sizeof(double), h->stream));   // rows of frames that do not see the point stay zero for good: nothing ever writes them
   if ((rc = s_alloc(s, &sv.schur_mfma_count, 1))) return rc;
   HIP_TRY(hipMemsetAsync(sv.schur_mfma_count, 0, sizeof(unsigned long long), h->stream));
 
@@ -1290,6 +1311,9 @@ int32_t build_solver_impl(rsba_handle* h) {
                         2 * T3 / 3 * (int64_t)(s->diag_info.size() / 4) + 4 * (int64_t)kTile * kTile * ((int64_t)sv.nslots + nt);
     ps.exchange_doubles = (int64_t)s->exch_tiles * kTile * kTile + sv.npad;   // exchange (2) of a sharded solve: the plan's tile pairs | rhs (the fill-in tiles of the factor's layout stay home)
     ps.schur_groups = sv.ngroups;
+    ps.schur_group_bytes = pt_goff[M] * (int64_t)sizeof(double);
+    ps.schur_factored_groups = 0;
+    for (int64_t g = 0; g < sv.ngroups; ++g) ps.schur_factored_groups += tile_factored[g_tile[(size_t)g]];
     ps.sharded_factorisation = sharded ? 1 : 0;
     if (sharded) {   // ... or, when every rank factors its own part: the separators' tiles | their rows of the rhs, and the gather of the step
       ps.exchange_doubles = (int64_t)s->ntop_slots * kTile * kTile + (int64_t)s->ntop_tiles * kTile + sv.npad;

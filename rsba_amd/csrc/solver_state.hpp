@@ -19,6 +19,10 @@ namespace rsba {
 constexpr int kSchurChunk = 512;   // entries per workgroup of the Schur kernel (its four waves take every fourth)
 constexpr int kMaxRankSlots = 64;   // per-rank slots behind the camera exchange's payload (more ranks than this: the gradient maximum takes its own all-reduce)
 constexpr int kTile = 48;   // Cholesky tile: 4 rolling-shutter frames (12 unknowns) or 8 global-shutter frames
+constexpr int kGroupFull = 3 * kTile;   // doubles of a P-record group in full form: [3][kTile]
+// ... and factored (two-pose frames: the 12 camera-side rows of a frame are (1 - tau) q | tau q with q = Jq^T Jp L^-T, 6 x 3):
+//   [c][16] sources 0..15 of coordinate c = 0, 1, 2 (source s = 6 x frame-in-tile + pose coordinate) | [c][8] sources 16..23 | tau[4] | pad[4]
+constexpr int kGroupFactored = 80;
 
 // Intrinsics as parameter blocks (opt.model.calibrated == false: the shared sess.cam and / or per-frame f.cam blocks,
 // CeresHandler.h:256-264,273-280): the 9 coordinates of block c ride as NPF = ceil(9/CD) extra "pseudo frames"
@@ -51,10 +55,14 @@ struct SolverDev {
   const int32_t* tp_I;          // [ntp]
   const int32_t* tp_J;
   const int64_t* tp_ptr;        // [ntp+1] into the entry list
-  const int32_t* ent_groups;    // [nent][2] the point's (tile, layer) group on the I side and on the J side
+  const uint32_t* ent_groups;   // [nent][2] where the point's (tile, layer) group on the I side and on the J side starts in Pm: element offset (a multiple of 16) | kind in bit 0 (1 = factored)
   const double2* slot_xy;       // [N] observations in slot order — calibrated problems only: their point-side passes recompute the records (lm_record.hpp); null = records in dp.rec
-  const int32_t* slot_gpos;     // [N + virtual] group * FT + position in the tile: where the slot's P record lives in Pm
-  int64_t ngroups;              // (point, tile, layer) groups: each owns one kTile x 3 block of Pm (one more, all zero, sits behind the last: padding entries of the Schur chunks)
+  const uint32_t* slot_gpos;    // [N + virtual] where the slot's P record goes: element offset of its group in Pm (a multiple of 16) | position of its frame in the tile << 1 | kind of the group (bit 0: factored)
+  int64_t ngroups;              // (point, tile, layer) groups: each owns one block of Pm — kGroupFull doubles ([3][kTile]) or, a two-pose frame tile of a problem that recomputes
+                                //   its records, kGroupFactored (the 6-row factor per frame + tau: see kernels_normal.hip) — one more, all zero, sits behind the last: padding entries of the Schur chunks
+  uint32_t zero_off;            // element offset of that all-zero group
+  const uint8_t* tile_factored; // [nt] 1 = the groups of this frame tile are stored factored (null: none is)
+  int lerp_rot;                 // interpolateRotation of a rolling-shutter model: the rotation rows of a factored group carry (1 - tau) / tau like the translation rows (else 1 / 0)
   const uint16_t* ent_mask;     // [nent] bit 3 I + J: block rows 16 I .. of the I-side group and 16 J .. of the J-side group both contain a frame that sees the point
   const int32_t* ent_pt;        // [nent] point index; top bit set = the entry carries the rhs term P z
   int schur_linear;             // debugging (RSBA_SCHUR_LINEAR=1): blockIdx -> chunk without the XCD map
@@ -85,7 +93,7 @@ struct SolverDev {
   double* diag_p;               // [M*3]
   double* Linv;                 // [M][6]  lower-triangular inverse of chol(V')
   double* z;                    // [M][3]
-  double* Pm;                   // [ngroups][3][kTile]  P records by (point, tile) group, component-major: row c of group g holds coordinate c of the
+  double* Pm;                   // P records by (point, tile) group; full form [3][kTile], component-major: row c of group g holds coordinate c of the
                                 //   point against the kTile camera-side rows of the tile (FT frames x CD; zero where a frame does not see the point) —
                                 //   one 16-row operand slice of the Schur kernel's MFMAs is ONE aligned 128-B line
   unsigned long long* schur_mfma_count;   // MFMAs the Schur kernel actually issued, summed over its launches (all-zero 16 x 16 operand blocks are skipped)

@@ -97,17 +97,19 @@ def mock_timeout_mode(outdir, rank, world, dist, torch):
     must give up after RSBA_MOCK_RCCL_TIMEOUT_S and the communicator must say so when it is destroyed."""
     import ctypes as C
     import time
+    class UniqueId(C.Structure):   # ncclUniqueId travels BY VALUE (a 128-byte struct)
+        _fields_ = [("internal", C.c_char * 128)]
     lib = C.CDLL(os.environ["RSBA_RCCL_LIB"])
-    lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_char * 128, C.c_int]
+    lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
     lib.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     lib.ncclCommDestroy.argtypes = [C.c_void_p]
     torch.cuda.set_device(0)
-    uid = (C.c_char * 128)()
+    uid = UniqueId()
     if rank == 0:
         assert lib.ncclGetUniqueId(C.byref(uid)) == 0
     box = [bytes(uid) if rank == 0 else None]
     dist.broadcast_object_list(box, src=0)
-    uid = (C.c_char * 128).from_buffer_copy(box[0])
+    uid = UniqueId.from_buffer_copy(box[0])
     comm = C.c_void_p()
     assert lib.ncclCommInitRank(C.byref(comm), world, uid, rank) == 0
     x = torch.full((100000,), float(rank + 1), dtype=torch.float64, device="cuda")
