@@ -1035,6 +1035,7 @@ __device__ __forceinline__ void task_back(const SolverDev& sv, const CholPlan& p
     if (worker && r < T) { const double* q = Wg + (size_t)r * T + 2 * c2; wpre[u] = make_double2(ld<DAG>(q), ld<DAG>(q + 1)); } else wpre[u] = make_double2(0.0, 0.0);
   }
   double zpre = tid < T ? ld<DAG>(sv.zv + (size_t)tile_j * T + tid) : 0.0;
+  double z2pre = (tid < T && sv.zv2) ? ld<DAG>(sv.zv2 + (size_t)tile_j * T + tid) : 0.0;
   double s0 = 0.0, s1 = 0.0;
   if (p0 < p1) {
     // L_ij (forward phase) is long finished; y_i is what the task waits for.  The host lists the tiles of the
@@ -1084,6 +1085,13 @@ __device__ __forceinline__ void task_back(const SolverDev& sv, const CholPlan& p
   if (tid < T) {
     double t = zpre;   // z_j, from the DIAG task of this column
     while (DAG && !filled(t)) { __builtin_amdgcn_s_sleep(8); t = ld<DAG>(sv.zv + (size_t)tile_j * T + tid); }
+    if (sv.zv2) {   // two right-hand sides through one backward solve: L^T y = z - (s eta) z2 (the ETA task leaves s eta in its cell)
+#pragma clang fp contract(off)
+      double c = ld<DAG>(sv.ceta), z2 = z2pre;
+      while (DAG && !filled(c)) { __builtin_amdgcn_s_sleep(8); c = ld<DAG>(sv.ceta); }
+      while (DAG && !filled(z2)) { __builtin_amdgcn_s_sleep(8); z2 = ld<DAG>(sv.zv2 + (size_t)tile_j * T + tid); }
+      t = t - c * z2;
+    }
 #pragma unroll
     for (int g = 0; g < 10; ++g) t -= part[g * T + tid];
     tvec[tid] = t;
@@ -1111,12 +1119,20 @@ __device__ __forceinline__ void task_back(const SolverDev& sv, const CholPlan& p
   CHOL_STAMP(4);
 }
 
+// (defined with the substitution-only driver further down)
+template <bool DAG>
+__device__ __forceinline__ void task_forward(const SolverDev& sv, const CholPlan& pl, int d, int p0, int p1, const double* __restrict__ b2, const double* __restrict__ minus, double* z2, double* smem, int tid);
+template <bool DAG>
+__device__ __forceinline__ void task_eta(const SolverDev& sv, double* smem, int tid);
+
 template <bool DAG>
 __device__ __forceinline__ void run_task(const SolverDev& sv, const CholPlan& pl, int kind, int item, double* smem, int tid) {
   switch (kind) {
     case kTaskUpdate: task_update<DAG>(sv, pl, item, smem, tid); break;
     case kTaskDiag: task_diag<DAG>(sv, pl, item, smem, tid); break;
     case kTaskSub: task_sub<DAG>(sv, pl, item, smem, tid); break;
+    case kTaskFwd2: task_forward<DAG>(sv, pl, item, gl(pl.diag_ptr + item), gl(pl.diag_ptr + item + 1), sv.border2, nullptr, sv.zv2, smem, tid); break;
+    case kTaskEta: task_eta<DAG>(sv, smem, tid); break;
     default: task_back<DAG>(sv, pl, item, smem, tid); break;
   }
 }
@@ -1168,66 +1184,110 @@ __global__ __launch_bounds__(256, 2) void chol_dag_kernel(const DagArgs* __restr
 // covariance block): forward tasks z_j = W_j (b2_j - sum_k L_jk z_k) in the order of the DIAG items, then the BACK tasks of the
 // factorisation on z2 / y2 — one persistent launch over write-once z / y cells of its own, no tile product anywhere.  It used to be a
 // second factorisation (0.76 ms at 1k cameras for 0.1 ms of substitutions).
+// z2_j = W_j (b2_j - minus_j - sum_{p in [p0, p1)} L_jk z2_k) over the contributors p of DIAG item d's list: thread (row r = tid % T, column
+// group cg = tid / T < 5) takes ten columns of its row of every tile — 240 threads, ten loads each per contributor, the next contributor's
+// tile travelling while this one is multiplied.  Everything it reads is a write-once cell: beside a running factorisation (FWD2 tasks of
+// the persistent driver) the rows of L_jk, z2_k and W_j are polled; behind a finished one (chol_solve_kernel, the level schedule) they are
+// simply there.  minus (may be null): what other ranks' columns contribute to this column (sharded factorisation: summed by the exchange).
 template <bool DAG>
-__device__ __forceinline__ void task_forward(const SolverDev& sv, const CholPlan& pl, int d, const double* __restrict__ b2, double* z2, double* smem, int tid) {
-  double* zb = smem;            // [5][T] z of the five contributors of a step
-  double* sp = smem + 5 * T;    // [5][T] partial sums
-  double* tv = smem + 10 * T;   // [T]
-  const int g = tid / T, r = tid % T;   // five groups of T threads, a row each; group g takes contributors p0 + g, p0 + g + 5, ..
-  const bool worker = g < 5;
+__device__ __forceinline__ void task_forward(const SolverDev& sv, const CholPlan& pl, int d, int p0, int p1, const double* __restrict__ b2, const double* __restrict__ minus, double* z2,
+                                             double* smem, int tid) {
+  constexpr int CG = 10;        // columns per thread
+  double* zb = smem;            // [T] z2 of the contributor being multiplied
+  double* sp = smem + T;        // [5][T] partial sums
+  double* tv = smem + 6 * T;    // [T]
+  const int cg = tid / T, r = tid % T, c0 = CG * cg;
+  const bool worker = cg < 5;
   const int tile_j = gl(pl.diag_info + 4 * d + 1);
-  const int p0 = gl(pl.diag_ptr + d), p1 = gl(pl.diag_ptr + d + 1);
-  double w[T];
-  if (tid < T) {
-    const double* Wg = sv.Winv + (size_t)tile_j * (T * T) + (size_t)r * T;
+  auto load_row = [&](const double* tile, double v[CG]) {
 #pragma unroll
-    for (int c = 0; c < T; ++c) w[c] = gl(Wg + c);   // (zeros right of the diagonal)
-  }
+    for (int m = 0; m < CG; ++m) v[m] = (worker && c0 + m < T) ? ld<DAG>(tile + (size_t)r * T + c0 + m) : 0.0;
+  };
+  auto row_ok = [&](const double v[CG]) { bool ok = true;
+#pragma unroll
+    for (int m = 0; m < CG; ++m) ok = ok && filled(v[m]);
+    return ok; };
   double s = 0.0;
-  for (int p = p0; p < p1; p += 5) {
-    const int q = p + g;
-    const bool has = worker && q < p1;
-    double lrow[T];
-    if (has) {
-      const double* Lp = factor_ptr(sv, gl(pl.diag_list + 2 * q)) + (size_t)r * T;
-#pragma unroll
-      for (int c = 0; c < T; ++c) lrow[c] = gl(Lp + c);
-      const double* zk = z2 + (size_t)gl(pl.diag_list + 2 * q + 1) * T + r;
+  double cur[CG], nxt[CG];
+  if (p0 < p1) load_row(factor_ptr(sv, gl(pl.diag_list + 2 * p0)), cur);
+  for (int p = p0; p < p1; ++p) {
+    if (p + 1 < p1) load_row(factor_ptr(sv, gl(pl.diag_list + 2 * (p + 1))), nxt);
+    if (tid < T) {
+      const double* zk = z2 + (size_t)gl(pl.diag_list + 2 * p + 1) * T + tid;
       double z = ld<DAG>(zk);
       while (DAG && !filled(z)) { __builtin_amdgcn_s_sleep(2); z = ld<DAG>(zk); }
-      zb[g * T + r] = z;
+      zb[tid] = z;
     }
+    while (DAG && !row_ok(cur)) { __builtin_amdgcn_s_sleep(2); load_row(factor_ptr(sv, gl(pl.diag_list + 2 * p)), cur); }
     lds_barrier();
-    if (has) {
 #pragma unroll
-      for (int c = 0; c < T; ++c) s += lrow[c] * zb[g * T + c];
-    }
+    for (int m = 0; m < CG; ++m) if (worker && c0 + m < T) s += cur[m] * zb[c0 + m];
     lds_barrier();
+#pragma unroll
+    for (int m = 0; m < CG; ++m) cur[m] = nxt[m];
   }
-  if (worker) sp[g * T + r] = s;
+  // W_j: requested before the sums meet (the DIAG task of this column has just produced it, or is about to)
+  const double* Wg = sv.Winv + (size_t)tile_j * (T * T);
+  double w[CG];
+  load_row(Wg, w);
+  if (worker) sp[cg * T + r] = s;
   lds_barrier();
   if (tid < T) {
     double t = gl(b2 + (size_t)tile_j * T + r);
+    if (minus) t -= gl(minus + r);
 #pragma unroll
     for (int k = 0; k < 5; ++k) t -= sp[k * T + r];
     tv[r] = t;
   }
+  while (DAG && !row_ok(w)) { __builtin_amdgcn_s_sleep(2); load_row(Wg, w); }
+  lds_barrier();
+  s = 0.0;
+#pragma unroll
+  for (int m = 0; m < CG; ++m) if (worker && c0 + m < T && c0 + m <= r) s += w[m] * tv[c0 + m];   // (W is lower triangular: exact zeros right of the diagonal)
+  lds_barrier();
+  if (worker) sp[cg * T + r] = s;
   lds_barrier();
   if (tid < T) {
     double z = 0.0;
 #pragma unroll
-    for (int c = 0; c < T; ++c) z += w[c] * tv[c];
+    for (int k = 0; k < 5; ++k) z += sp[k * T + r];
     st<DAG>(z2 + (size_t)tile_j * T + r, z);
+  }
+}
+
+// The ratio's step from the two forward solves (solver_state.hpp): d1 = z2.z, d2 = z2.z2 over the columns [t0, t1) of this plan (+ what
+// `extra` carries: sharded factorisation — the other ranks' parts, summed by the exchange), eta = (g_s - s d1) / (h_s + D - s^2 d2); s eta goes to
+// the cell the BACK tasks wait for.  One workgroup, sums in a fixed order.
+template <bool DAG>
+__device__ __forceinline__ void task_eta(const SolverDev& sv, double* smem, int tid) {
+#pragma clang fp contract(off)
+  double a = 0.0, b = 0.0;
+  for (int64_t t = tid; t < sv.npad; t += 256) {
+    double z = ld<DAG>(sv.zv + t), w = ld<DAG>(sv.zv2 + t);
+    while (DAG && !(filled(z) && filled(w))) { __builtin_amdgcn_s_sleep(8); z = ld<DAG>(sv.zv + t); w = ld<DAG>(sv.zv2 + t); }
+    a += w * z; b += w * w;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off, 64); b += __shfl_down(b, off, 64); }
+  if ((tid & 63) == 0) { smem[tid >> 6] = a; smem[4 + (tid >> 6)] = b; }
+  lds_barrier();
+  if (tid == 0) {
+    const double d1 = (smem[0] + smem[1]) + (smem[2] + smem[3]), d2 = (smem[4] + smem[5]) + (smem[6] + smem[7]);
+    const double sc = sv.rt[kRtScale];
+    const double eta = (sv.rt[kRtGs] - sc * d1) / (sv.rt[kRtDiagTerm] - sc * sc * d2);
+    const double c = sc * eta;
+    sv.rt[kRtDot1] = d1; sv.rt[kRtDot2] = d2; sv.rt[kRtEta] = eta; sv.rt[kRtC] = c;
+    st<DAG>(sv.ceta, c);
   }
 }
 
 // the same tasks one launch per level (no polling): what the persistent form is checked against and falls back to
 __global__ __launch_bounds__(256) void chol_solve_level_kernel(const SolverDev sv, const CholPlan pl, int backward, int first, const double* __restrict__ b2, double* zy2) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  if (!backward) task_forward<false>(sv, pl, first + blockIdx.x, b2, zy2, smem, threadIdx.x);
+  if (!backward) { const int d = first + blockIdx.x; task_forward<false>(sv, pl, d, pl.diag_ptr[d], pl.diag_ptr[d + 1], b2, nullptr, zy2, smem, threadIdx.x); }
   else {
     SolverDev sv2 = sv;
-    sv2.zv = zy2; sv2.yv = zy2 + sv2.npad;
+    sv2.zv = zy2; sv2.yv = zy2 + sv2.npad; sv2.zv2 = nullptr;
     task_back<false>(sv2, pl, first + blockIdx.x, smem, threadIdx.x);
   }
 }
@@ -1246,10 +1306,10 @@ __global__ __launch_bounds__(256) void chol_solve_kernel(const DagArgs* __restri
     if (t >= 2 * nd) return;
     int task_tid = tid;
     asm volatile("" : "+v"(task_tid));
-    if (t < nd) task_forward<true>(args->sv, pl, t, b2, zy2, smem, task_tid);
+    if (t < nd) task_forward<true>(args->sv, pl, t, gl(pl.diag_ptr + t), gl(pl.diag_ptr + t + 1), b2, nullptr, zy2, smem, task_tid);
     else {
       SolverDev sv2 = args->sv;
-      sv2.zv = zy2; sv2.yv = zy2 + sv2.npad;
+      sv2.zv = zy2; sv2.yv = zy2 + sv2.npad; sv2.zv2 = nullptr;
       task_back<true>(sv2, pl, gl(pl.tasks + 2 * (pl.ntasks - 2 * nd + t) + 1), smem, task_tid);   // (the BACK tasks close the task list, in their order)
     }
   }

@@ -60,6 +60,7 @@ struct DeviceProblem {
   const int32_t* prior_of;       // [F + 1] 1 = frame f carries a prior against frame f - 1 (entry F is 0)
   int prior_kind;                // 1 RsConstVeloPrior, 2 RsConstAccelerationPrior
   double prior_scale, prior_ratio;
+  const double* prior_ratio_ptr; // where the interFrameRatio lives on the device (the loop whose decisions are taken on the device: the free ratio is part of its state); null = prior_ratio
   int prior_free;                // the interFrameRatio is a free parameter block: no prior block is "all constant" then
   // per-pose prior blocks (kernels_pose_prior.hip): GoodPosePrior on the listed pose blocks, each with its own
   // free priorPoses parameter block, and at most one SphericalPrior

@@ -1277,7 +1277,12 @@ __device__ __forceinline__ void lm_decide_step(const SolverDev& sv, double* ctl,
   it.cost = 0.0; it.cost_change = 0.0; it.gradient_max_norm = 0.0; it.step_norm = 0.0; it.relative_decrease = 0.0; it.trust_region_radius = 0.0; it.model_cost_change = 0.0;
   const double model_cost_change = sc[kModelCostChange];
   const bool cfail = sc[kSolveFailed] != 0.0, nfail = sc[kEvalFailed] != 0.0;
-  const bool solved = !cfail && isfinite(model_cost_change) && isfinite(sc[kStepSq]);
+  double step_sq = sc[kStepSq], x_sq = sc[kXSq];
+  if (sv.rt) {   // a free interFrameRatio is one more coordinate of x (its candidate: ratio_candidate_kernel)
+    const double ratio = sv.rt[kRtRatio], rn = sv.rt[kRtRatioNew];
+    step_sq += (ratio - rn) * (ratio - rn); x_sq += ratio * ratio;
+  }
+  const bool solved = !cfail && isfinite(model_cost_change) && isfinite(step_sq);
   const bool valid = solved && model_cost_change >= 0.0;
   it.model_cost_change = solved ? model_cost_change : 0.0;
   auto done = [&](int term) { it.cost = cost + fixed; it.trust_region_radius = radius; lm_push(ctl, trace, cap, it); ctl[kCtlStatus] = 1.0 + term; };
@@ -1291,8 +1296,8 @@ __device__ __forceinline__ void lm_decide_step(const SolverDev& sv, double* ctl,
   } else {
     ctl[kCtlInvalidStreak] = 0.0; it.step_is_valid = 1;
     const double new_cost = nfail ? 1.7976931348623157e308 : (sc[kCost] + 0.0) - fixed;   // (the trial evaluation reports the total in kCost)
-    it.step_norm = sqrt(sc[kStepSq]);
-    const double x_norm = sqrt(sc[kXSq]);
+    it.step_norm = sqrt(step_sq);
+    const double x_norm = sqrt(x_sq);
     if (it.step_norm <= R.parameter_tolerance * (x_norm + R.parameter_tolerance)) { done(RSBA_CONVERGENCE); return; }
     it.cost_change = cost - new_cost;
     if (fabs(it.cost_change) < R.function_tolerance * cost) { done(RSBA_CONVERGENCE); return; }
@@ -1303,6 +1308,7 @@ __device__ __forceinline__ void lm_decide_step(const SolverDev& sv, double* ctl,
       radius = radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
       radius = fmin(R.max_trust_region_radius, radius); decrease = 2.0;
       ctl[kCtlRadius] = radius; ctl[kCtlDecrease] = decrease; ctl[kCtlAccept] = 1.0;
+      if (sv.rt) sv.rt[kRtRatio] = sv.rt[kRtRatioNew];
       // (the iteration's record is finished by lm_decide_gradient_kernel once the accepted point is linearised)
       ctl[kCtlPending] = it.relative_decrease; ctl[kCtlPending + 1] = it.cost_change; ctl[kCtlPending + 2] = it.step_norm; ctl[kCtlPending + 3] = it.model_cost_change;
       return;
@@ -1332,7 +1338,9 @@ __device__ __forceinline__ void lm_decide_gradient(const SolverDev& sv, double* 
     ctl[kCtlStatus] = -2.0;
     return;
   }
-  const double cost = sc[kCost], gmax = sc[kGradMax];
+  double gmax = sc[kGradMax];
+  if (sv.rt) { const double ratio = sv.rt[kRtRatio]; gmax = fmax(gmax, fabs(ratio - fmax(sv.rt[kRtLb], ratio - sv.rt[kRtG]))); }   // the ratio's projected gradient (its block is bounded below)
+  const double cost = sc[kCost];
   ctl[kCtlCost] = cost; ctl[kCtlGmax] = gmax;
   ctl[kCtlFinalCost] = fmin(ctl[kCtlFinalCost], cost + fixed);
   it.gradient_max_norm = gmax; it.cost = cost + fixed; it.trust_region_radius = radius;

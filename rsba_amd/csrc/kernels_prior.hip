@@ -24,9 +24,11 @@ __device__ __forceinline__ double wsum64(double v) {
   return v;
 }
 
+__device__ __forceinline__ double prior_q(const DeviceProblem& dp) { return dp.prior_ratio_ptr ? *dp.prior_ratio_ptr : dp.prior_ratio; }
+
 // Jacobian coefficients of the two residual rows with respect to x_i (what Jet arithmetic leaves in the functors)
 __device__ __forceinline__ void prior_coefficients(const DeviceProblem& dp, double Ca[4], double Cb[4]) {
-  const double q = dp.prior_ratio, inv = 1.0 / q;
+  const double q = prior_q(dp), inv = 1.0 / q;
   if (dp.prior_kind == 1) {
     Ca[0] = 1.0; Ca[1] = 0.0; Ca[2] = q; Ca[3] = -(1.0 + q);
     if (q > 2.220446049250313e-16) { Cb[0] = -(1.0 + inv); Cb[1] = 1.0; Cb[2] = 0.0; Cb[3] = inv; }
@@ -42,7 +44,7 @@ struct PriorValue { double r[12]; double weight, cost; };
 __device__ __forceinline__ PriorValue prior_value(const DeviceProblem& dp, int f) {
   PriorValue v;
   const double* cur = dp.poses + (size_t)f * 12; const double* prev = cur - 12;
-  const double q = dp.prior_ratio;
+  const double q = prior_q(dp);
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
     const double c0 = cur[i], c1 = cur[6 + i], p0 = prev[i], p1 = prev[6 + i];
@@ -72,7 +74,7 @@ __device__ __forceinline__ PriorValue prior_value(const DeviceProblem& dp, int f
 // d r / d interFrameRatio of the 12 residuals (the Jacobian column of the ratio block when it is a free parameter)
 __device__ __forceinline__ void prior_ratio_column(const DeviceProblem& dp, int f, double dr[12]) {
   const double* cur = dp.poses + (size_t)f * 12; const double* prev = cur - 12;
-  const double q = dp.prior_ratio, iq2 = 1.0 / (q * q);
+  const double q = prior_q(dp), iq2 = 1.0 / (q * q);
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
     const double c0 = cur[i], p0 = prev[i], p1 = prev[6 + i];
@@ -163,8 +165,9 @@ __global__ __launch_bounds__(64) void prior_cost_kernel(const DeviceProblem dp, 
 }
 
 // model cost change of the prior blocks for the camera step in sv.step:  -sum m.(r~ + m/2),  m = -J~ y
-__global__ __launch_bounds__(64) void prior_model_kernel(const DeviceProblem dp, const SolverDev sv, double* out, double ratio_step) {
+__global__ __launch_bounds__(64) void prior_model_kernel(const DeviceProblem dp, const SolverDev sv, double* out, double ratio_step, const double* ratio_step_ptr) {
   if (lm_stopped(dp.ctl)) return;
+  if (ratio_step_ptr) { const double c = *ratio_step_ptr; ratio_step = isfinite(c) ? c : 0.0; }   // (device-side trust region: the ETA task of the factorisation left s eta there)
   const int f = blockIdx.x * 64 + threadIdx.x;
   double acc = 0.0;
   if (f < dp.F && dp.prior_of[f]) {
@@ -198,6 +201,7 @@ __global__ __launch_bounds__(64) void prior_model_kernel(const DeviceProblem dp,
 // coordinate t (camera scales applied, the ratio's own scale is the host's), hg = {J~_ratio^T J~_ratio, J~_ratio^T r~}.
 // One thread per frame gathers the prior it heads and the one referring back to it; hg by the last-wave reduction.
 __global__ __launch_bounds__(64) void prior_border_kernel(const DeviceProblem dp, const SolverDev sv, double* __restrict__ border, double* __restrict__ hg) {
+  if (lm_not_accepted(sv.ctl)) return;   // (device-side trust region: a rejected candidate is not linearised — every wave alike: the ticket stays armed)
   const int f = blockIdx.x * 64 + threadIdx.x;
   double hh = 0.0, gg = 0.0;
   if (f < dp.F) {
@@ -254,10 +258,35 @@ __global__ __launch_bounds__(1024) void border_dots_kernel(const double* __restr
     out[0] = a; out[1] = c;
   }
 }
-// y = u - c v
-__global__ void border_combine_kernel(double* __restrict__ y, const double* __restrict__ u, const double* __restrict__ v, double c, int64_t n) {
+// y = u - c v  (c by value, or where the ETA task of the factorisation left it)
+__global__ void border_combine_kernel(double* __restrict__ y, const double* __restrict__ u, const double* __restrict__ v, double c, const double* c_ptr, int64_t n) {
+#pragma clang fp contract(off)
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c_ptr) c = *c_ptr;
   if (t < n) y[t] = u[t] - c * v[t];
+}
+__global__ void ratio_init_kernel(double* rt, double ratio, double scale, double lb) { rt[kRtRatio] = ratio; rt[kRtRatioNew] = ratio; rt[kRtRatioEval] = ratio; rt[kRtScale] = scale; rt[kRtLb] = lb; }
+// the ratio's scalars the ETA task reads, by value (the loop the host decides) ...
+__global__ void ratio_prepare_kernel(double* rt, double diag_term, double gs, double scale) { rt[kRtDiagTerm] = diag_term; rt[kRtGs] = gs; rt[kRtScale] = scale; }
+// ... or from the state on the device (the loop that runs without the host): LM diagonal clamp(s^2 h) as LevenbergMarquardtStrategy takes it for
+// every column, the damped pivot s^2 h + D / radius, the scaled gradient s g — the host form's operations in the host form's order
+__global__ void ratio_prepare_ctl_kernel(double* rt, const double* ctl, double lo, double hi) {
+#pragma clang fp contract(off)
+  if (ctl[kCtlStatus] != 0.0) return;
+  const double sc = rt[kRtScale], h = rt[kRtH], g = rt[kRtG], radius = ctl[kCtlRadius];
+  const double diag = fmin(fmax(sc * sc * h, lo), hi);
+  rt[kRtDiag] = diag;
+  rt[kRtDiagTerm] = sc * sc * h + diag / radius;
+  rt[kRtGs] = sc * g;
+}
+// the ratio's candidate: projected onto its lower bound (ParameterBlock::Plus); what the candidate's prior blocks are evaluated with
+__global__ void ratio_candidate_kernel(double* rt, const double* ctl) {
+#pragma clang fp contract(off)
+  if (ctl[kCtlStatus] != 0.0) return;
+  const double ratio = rt[kRtRatio], lb = rt[kRtLb];
+  const double rn = fmax(lb, ratio - rt[kRtC]);
+  rt[kRtRatioNew] = rn;
+  rt[kRtRatioEval] = isfinite(rn) ? rn : ratio;
 }
 
 }  // namespace
@@ -270,8 +299,24 @@ hipError_t launch_border_dots(const double* b, const double* u, const double* v,
   hipLaunchKernelGGL(border_dots_kernel, dim3(1), dim3(1024), 0, st, b, u, v, n, out2);
   return hipGetLastError();
 }
-hipError_t launch_border_combine(double* y, const double* u, const double* v, double c, int64_t n, hipStream_t st) {
-  hipLaunchKernelGGL(border_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, y, u, v, c, n);
+hipError_t launch_border_combine(double* y, const double* u, const double* v, double c, int64_t n, hipStream_t st, const double* c_ptr) {
+  hipLaunchKernelGGL(border_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, y, u, v, c, c_ptr, n);
+  return hipGetLastError();
+}
+hipError_t launch_ratio_init(double* rt, double ratio, double scale, double lb, hipStream_t st) {
+  hipLaunchKernelGGL(ratio_init_kernel, dim3(1), dim3(1), 0, st, rt, ratio, scale, lb);
+  return hipGetLastError();
+}
+hipError_t launch_ratio_prepare(double* rt, double diag_term, double gs, double scale, hipStream_t st) {
+  hipLaunchKernelGGL(ratio_prepare_kernel, dim3(1), dim3(1), 0, st, rt, diag_term, gs, scale);
+  return hipGetLastError();
+}
+hipError_t launch_ratio_prepare_ctl(double* rt, const double* ctl, double lo, double hi, hipStream_t st) {
+  hipLaunchKernelGGL(ratio_prepare_ctl_kernel, dim3(1), dim3(1), 0, st, rt, ctl, lo, hi);
+  return hipGetLastError();
+}
+hipError_t launch_ratio_candidate(double* rt, const double* ctl, hipStream_t st) {
+  hipLaunchKernelGGL(ratio_candidate_kernel, dim3(1), dim3(1), 0, st, rt, ctl);
   return hipGetLastError();
 }
 
@@ -283,8 +328,8 @@ hipError_t launch_prior_cost(const DeviceProblem& dp, double* cost2, int invalid
   hipLaunchKernelGGL(prior_cost_kernel, dim3((dp.F + 63) / 64), dim3(64), 0, st, dp, cost2, invalid_blocks);
   return hipGetLastError();
 }
-hipError_t launch_prior_model(const DeviceProblem& dp, const SolverDev& sv, double* model_cost_change, double ratio_step, hipStream_t st) {
-  hipLaunchKernelGGL(prior_model_kernel, dim3((dp.F + 63) / 64), dim3(64), 0, st, dp, sv, model_cost_change, ratio_step);
+hipError_t launch_prior_model(const DeviceProblem& dp, const SolverDev& sv, double* model_cost_change, double ratio_step, hipStream_t st, const double* ratio_step_ptr) {
+  hipLaunchKernelGGL(prior_model_kernel, dim3((dp.F + 63) / 64), dim3(64), 0, st, dp, sv, model_cost_change, ratio_step, ratio_step_ptr);
   return hipGetLastError();
 }
 

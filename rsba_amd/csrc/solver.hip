@@ -86,6 +86,7 @@ struct Solver {
   int dag_workgroups = 0;
   bool dag_one_per_cu = true;                                         // LDS request above half a CU's: two persistent workgroups never share a CU (RSBA_CHOL_WGS above the CU count lifts it)
   bool use_levels = false;                                            // RSBA_CHOL_LEVELS=1: one launch per (level, kind)
+  bool two_rhs = false;                                               // the plan carries a second right-hand side through the factorisation (free interFrameRatio: FWD2 / ETA tasks)
   int last_diag_slot = 0;
   int32_t* d_obs_slot = nullptr;
   double *d_gpose = nullptr, *d_gpoint = nullptr;
@@ -122,7 +123,7 @@ struct Solver {
   int num_reduced_blocks = 0, num_reduced_params = 0, num_priors_reduced = 0;
   int32_t* exch_slots = nullptr; double* exch_buf = nullptr; int exch_tiles = 0;   // exchange (2) of a sharded solve: the plan's tile pairs, packed
   double* zy2 = nullptr;                                              // [2][npad] z | y of one more right-hand side through the last factorisation (solve_again)
-  double* border = nullptr, *ubuf = nullptr, *ratio4 = nullptr;      // free interFrameRatio: its column of S [npad], the first solve's result, {h, g, b.u, b.v}
+  double* border = nullptr, *ratio4 = nullptr;                       // free interFrameRatio: its column of S [npad]; its scalars on the device (solver_state.hpp: RatioSlot)
   PosePriorDev pp{};                                                  // per-pose priors: linearisation of the priorPoses coordinates
   double* merge_buf = nullptr;                                        // sharded solve: [4 M] owned point values | owner flags
   double* ucross = nullptr;                                           // [F][CD][CD] motion-prior blocks (f, f-1), behind sv.U's J^T J blocks
@@ -837,11 +838,18 @@ int32_t build_solver_impl(rsba_handle* h) {
     s->lev_upd_ptr.push_back((int32_t)(s->upd.size() / 4));
     (void)diag0; (void)sub0;
   }
+  // A free interFrameRatio brings a second right-hand side (its column of the normal equations): z2 = L^-1 b is formed by FWD2 tasks
+  // right behind the DIAG tasks of their columns — light tasks for workgroups the factorisation leaves idle — and ONE ETA task between
+  // the forward and the backward phase turns both forward solves into the ratio's step (solver_state.hpp; cholesky.hip)
+  const bool two_rhs = h->prior_free && !h->prior_frames.empty();
+  s->two_rhs = two_rhs;
   for (int l = 0; l < nlev; ++l) {
     for (int32_t u : upd_by_level[l]) { s->tasks.push_back(kTaskUpdate); s->tasks.push_back(u); }
     for (int d = s->lev_diag_ptr[l]; d < s->lev_diag_ptr[l + 1]; ++d) { s->tasks.push_back(kTaskDiag); s->tasks.push_back(d); }
+    if (two_rhs) for (int d = s->lev_diag_ptr[l]; d < s->lev_diag_ptr[l + 1]; ++d) { s->tasks.push_back(kTaskFwd2); s->tasks.push_back(d); }
     for (int t = s->lev_sub_ptr[l]; t < s->lev_sub_ptr[l + 1]; ++t) { s->tasks.push_back(kTaskSub); s->tasks.push_back(t); }
   }
+  if (two_rhs) { s->tasks.push_back(kTaskEta); s->tasks.push_back(0); }
   for (int l = nlev - 1; l >= 0; --l)
     for (int d = s->lev_diag_ptr[l]; d < s->lev_diag_ptr[l + 1]; ++d) { s->tasks.push_back(kTaskBack); s->tasks.push_back(d); }
   if (sharded) {
@@ -1064,7 +1072,7 @@ int32_t build_solver_impl(rsba_handle* h) {
   // the write-once cells of the persistent Cholesky driver — factor tiles | partial tiles | W | z, y | published X — live in ONE
   // allocation: one memset re-arms them before a launch (five launches before)
   {
-    const size_t nLf = (size_t)sv.nslots * kTile * kTile, nPart = (size_t)std::max(parts, 1) * (kTile * kTile + kTile), nW = (size_t)nt * kTile * kTile, nZ = 2 * (size_t)sv.npad;
+    const size_t nLf = (size_t)sv.nslots * kTile * kTile, nPart = (size_t)std::max(parts, 1) * (kTile * kTile + kTile), nW = (size_t)nt * kTile * kTile, nZ = 3 * (size_t)sv.npad + 8;   // z | y | z2 | {s eta}
     s->ncells = nLf + nPart + nW + nZ + nW;
     s->cell_off[0] = 0; s->cell_off[1] = nLf; s->cell_off[2] = nLf + nPart; s->cell_off[3] = nLf + nPart + nW; s->cell_off[4] = nLf + nPart + nW + nZ;
     for (int b = 0; b < 2; ++b) {
@@ -1078,6 +1086,7 @@ int32_t build_solver_impl(rsba_handle* h) {
     HIP_TRY(dev_event_acquire(&s->ev_join, false));
     double* cells = s->cells[0];
     sv.Lf = cells; sv.chol_part = cells + nLf; sv.Winv = sv.chol_part + nPart; sv.zv = sv.Winv + nW; sv.yv = sv.zv + sv.npad; sv.Xpub = sv.zv + nZ;
+    sv.zv2 = nullptr; sv.ceta = nullptr; sv.border2 = nullptr; sv.rt = nullptr;   // (set with the border, below)
   }
   up.upload_ref(&s->d_tasks, s->tasks);
   if ((rc = s_alloc(s, &s->d_dag_sync, 4))) return rc;
@@ -1172,9 +1181,10 @@ int32_t build_solver_impl(rsba_handle* h) {
   if (ucross_len) { s->ucross = sv.U + ucross_base; HIP_TRY(hipMemset(s->ucross, 0, ucross_len * sizeof(double))); }   // stays zero on the other ranks
   if (ucross_len && h->prior_free) {   // the ratio is one more camera-side unknown: a 1-wide dense border of S, handled by a second solve
     if ((rc = s_alloc(s, &s->border, (size_t)sv.npad))) return rc;
-    if ((rc = s_alloc(s, &s->ubuf, (size_t)sv.npad))) return rc;
-    if ((rc = s_alloc(s, &s->ratio4, 4))) return rc;
+    if ((rc = s_alloc(s, &s->ratio4, kRtSize))) return rc;
+    HIP_TRY(hipMemset(s->ratio4, 0, kRtSize * sizeof(double)));
     HIP_TRY(hipMemset(s->border, 0, (size_t)sv.npad * sizeof(double)));
+    sv.zv2 = sv.zv + 2 * sv.npad; sv.ceta = sv.zv + 3 * sv.npad; sv.border2 = s->border; sv.rt = s->ratio4;
     if (lead) s->num_reduced_params += 1;
   }
   if ((rc = s_alloc(s, &sv.gc, (size_t)F * CD))) return rc;
@@ -1283,6 +1293,7 @@ int32_t build_solver_impl(rsba_handle* h) {
       double* c = s->cells[b];
       host_args.sv.Lf = c + s->cell_off[0]; host_args.sv.chol_part = c + s->cell_off[1]; host_args.sv.Winv = c + s->cell_off[2];
       host_args.sv.zv = c + s->cell_off[3]; host_args.sv.yv = host_args.sv.zv + sv.npad; host_args.sv.Xpub = c + s->cell_off[4];
+      if (sv.zv2) { host_args.sv.zv2 = host_args.sv.zv + 2 * sv.npad; host_args.sv.ceta = host_args.sv.zv + 3 * sv.npad; }
       if ((rc = s_alloc(s, &s->d_dag_args2[b], 1))) return rc;
       HIP_TRY(hipMemcpy(s->d_dag_args2[b], &host_args, sizeof host_args, hipMemcpyHostToDevice));
       if (sharded) {
@@ -1508,6 +1519,7 @@ int32_t solve_reduced_system(rsba_handle* h, bool rhs_stays = false) {
     s->cur_cells = now;
     double* c = s->cells[now];
     sv.Lf = c + s->cell_off[0]; sv.chol_part = c + s->cell_off[1]; sv.Winv = c + s->cell_off[2]; sv.zv = c + s->cell_off[3]; sv.yv = sv.zv + sv.npad; sv.Xpub = c + s->cell_off[4];
+    if (sv.zv2) { sv.zv2 = sv.zv + 2 * sv.npad; sv.ceta = sv.zv + 3 * sv.npad; }
     s->d_dag_args = s->d_dag_args2[now];
     if (s->sharded && !s->sharded_off) {
       // launch A: the columns of this rank's part, from its own partial S — complete for them: every point that sees one of its tiles is here
@@ -1539,7 +1551,8 @@ int32_t solve_reduced_system(rsba_handle* h, bool rhs_stays = false) {
     if (s->verify_dag) {
       // (rhs_stays: nobody writes sv.rhs before the check has been waited for — the LM iteration without a free ratio; otherwise the check gets a copy)
       const double* b_rhs = sv.rhs;
-      if (!rhs_stays) { HIP_TRY(hipMemcpyAsync(s->verify_b, sv.rhs, (size_t)sv.npad * sizeof(double), hipMemcpyDeviceToDevice, st)); b_rhs = s->verify_b; }
+      if (s->two_rhs) { HIP_TRY(launch_border_combine(s->verify_b, sv.rhs, s->border, 0.0, sv.npad, st, s->ratio4 + kRtC)); b_rhs = s->verify_b; }   // what was solved for: g - (s eta) b
+      else if (!rhs_stays) { HIP_TRY(hipMemcpyAsync(s->verify_b, sv.rhs, (size_t)sv.npad * sizeof(double), hipMemcpyDeviceToDevice, st)); b_rhs = s->verify_b; }
       HIP_TRY(hipEventRecord(s->ev_solved, st));
       HIP_TRY(hipStreamWaitEvent(s->vstream, s->ev_solved, 0));
       HIP_TRY(launch_chol_verify(sv, s->d_slot_tiles, b_rhs, s->d_verify, s->d_verify + sv.npad, 1e-7, sv.scalars + kDagSuspect, s->vstream,
@@ -1553,8 +1566,10 @@ int32_t solve_reduced_system(rsba_handle* h, bool rhs_stays = false) {
       const int u0 = s->lev_upd_ptr[l], u1 = s->lev_upd_ptr[l + 1];
       HIP_TRY(launch_chol_level(sv, s->plan, kTaskUpdate, u0, u1 - u0, st));
       HIP_TRY(launch_chol_level(sv, s->plan, kTaskDiag, d0, d1 - d0, st));
+      if (s->two_rhs) HIP_TRY(launch_chol_level(sv, s->plan, kTaskFwd2, d0, d1 - d0, st));
       HIP_TRY(launch_chol_level(sv, s->plan, kTaskSub, t0, t1 - t0, st));
     }
+    if (s->two_rhs) HIP_TRY(launch_chol_level(sv, s->plan, kTaskEta, 0, 1, st));
     for (int l = s->nlev - 1; l >= 0; --l) {
       const int d0 = s->lev_diag_ptr[l], d1 = s->lev_diag_ptr[l + 1];
       HIP_TRY(launch_chol_level(sv, s->plan, kTaskBack, d0, d1 - d0, st));
@@ -1585,25 +1600,23 @@ int32_t solve_again(rsba_handle* h, const double* b2, const double** v_out) {
 }
 
 // ratio (free interFrameRatio only): in {h_s + D/radius, g_s, scale of the ratio}, out the ratio's scaled step eta.
-// The ratio's column b of the damped normal equations is a 1-wide dense border of S:  S u = g, S v = b,
-// eta = (g_s - s b.u) / (h_s + D - s^2 b.v),  y = u - (s eta) v  — two right-hand sides through ONE factorisation.
+// The ratio's column b of the damped normal equations is a 1-wide dense border of S.  With S = L L^T, z = L^-1 g, z2 = L^-1 b:
+//   eta = (g_s - s z2.z) / (h_s + D - s^2 z2.z2),   L^T y = z - (s eta) z2
+// — both forward solves inside the factorisation's own launch (FWD2 tasks beside the DIAG tasks, cholesky.hip), the ETA task between
+// the phases, ONE backward solve.  (Until round 4 the second right-hand side took a launch of its own: S u = g, S v = b, y = u - s eta v.)
+// ratio == nullptr with a two-column plan: the device-side loop — the ratio's scalars are on the device already (ratio_prepare_ctl).
 struct RatioStep { double diag, gs, scale, eta; };
 int32_t factor_and_solve(rsba_handle* h, double radius, RatioStep* ratio = nullptr) {
   Solver* s = h->solver; const SolverDev& sv = s->sv; hipStream_t st = h->stream;
+  if (ratio) HIP_TRY(launch_ratio_prepare(s->ratio4, ratio->diag, ratio->gs, ratio->scale, st));
   int32_t rc = reduce_system(h, radius);
   if (rc) return rc;
-  if ((rc = solve_reduced_system(h, /*rhs_stays=*/!ratio))) return rc;
+  if ((rc = solve_reduced_system(h, /*rhs_stays=*/!s->two_rhs))) return rc;
   if (ratio) {
-    const double* v = nullptr;
-    if ((rc = solve_again(h, s->border, &v))) return rc;                 // sv.yv = u stays where it is
-    HIP_TRY(launch_border_dots(s->border, sv.yv, v, sv.npad, s->ratio4 + 2, st));
-    double dots[2];
-    HIP_TRY(hipMemcpyAsync(dots, s->ratio4 + 2, sizeof dots, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&ratio->eta, s->ratio4 + kRtEta, sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    ratio->eta = (ratio->gs - ratio->scale * dots[0]) / (ratio->diag - ratio->scale * ratio->scale * dots[1]);
-    HIP_TRY(launch_border_combine(sv.rhs, sv.yv, v, ratio->scale * ratio->eta, sv.npad, st));
-    s->sv.step = sv.rhs;
-  } else s->sv.step = sv.yv;   // the camera step is read where the solve left it (the cells of this solve stay armed until the next one)
+  }
+  s->sv.step = sv.yv;   // the camera step is read where the solve left it (the cells of this solve stay armed until the next one)
   PhaseScope ps(h, RSBA_PHASE_BACK_SUBSTITUTE);
   HIP_TRY(launch_back_substitute(h->dp, sv, st));
   return RSBA_OK;
@@ -1808,6 +1821,7 @@ extern "C" int32_t rsba_pose_covariance(rsba_handle* h, int32_t frame, double* c
   struct ShardedOff { Solver* s; bool was; ~ShardedOff() { s->sharded_off = was; } } sharded_guard{s, s->sharded_off};
   s->sharded_off = true;
   if ((rc = reduce_system(h, 1e300))) return rc;
+  if (s->two_rhs) HIP_TRY(launch_ratio_prepare(s->ratio4, 1.0, 0.0, 0.0, st));   // (a plan that carries the ratio's column through its factorisation: s eta = 0 here — the plain solves S y = e_k)
   std::vector<double> col((size_t)CD * CD, 0.0);
   const double one = 1.0;
   // CD (+1 with the border) solves through the factorisation; the DAG driver's verification flag is sticky, so one read after
@@ -2007,7 +2021,7 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
   // Single-GPU problems that keep no records (calibrated, or ONE shared intrinsics block), with or without motion priors of a known
   // interFrameRatio — on one rank or several (every rank takes the same form: settled with the problem-size exchange); everything else (a free
   // ratio, per-pose priors, per-frame intrinsics blocks) — and a suspect factorisation — goes through the host form.
-  bool device_ctl = speculate && !free_ratio && dp.pp_count == 0 && dp.pp_spherical < 0 && !s->use_levels &&
+  bool device_ctl = speculate && dp.pp_count == 0 && dp.pp_spherical < 0 && !s->use_levels &&
                     !any_rank_needs_host && opt->max_num_iterations > 0;
   if (const char* e = std::getenv("RSBA_DEVICE_LM")) device_ctl = device_ctl && e[0] != '0';   // A/B switch: 0 = the host decides
   if (device_ctl) {
@@ -2025,11 +2039,15 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
     std::fill(hc0, hc0 + kCtlSize, 0.0);
     hc0[kCtlRadius] = radius; hc0[kCtlDecrease] = decrease_factor; hc0[kCtlCost] = cost; hc0[kCtlFixed] = fixed; hc0[kCtlGmax] = gmax; hc0[kCtlFinalCost] = sum->final_cost;
     HIP_TRY(hipMemcpyAsync(s->d_ctl, hc0, kCtlSize * sizeof(double), hipMemcpyHostToDevice, st));
-    struct CtlGuard {   // whichever way this block is left, the host form finds the state it expects: nobody skips, the radius comes by value
+    struct CtlGuard {   // whichever way this block is left, the host form finds the state it expects: nobody skips, the radius (and the ratio) come by value
       rsba_handle* h; Solver* s;
-      ~CtlGuard() { (void)hipStreamSynchronize(h->stream); s->sv.ctl = nullptr; h->dp.ctl = nullptr; s->clamp_with_factor = false; (void)hipMemsetAsync(s->d_ctl, 0, kCtlSize * sizeof(double), h->stream); }
+      ~CtlGuard() { (void)hipStreamSynchronize(h->stream); s->sv.ctl = nullptr; h->dp.ctl = nullptr; h->dp.prior_ratio_ptr = nullptr; s->clamp_with_factor = false; (void)hipMemsetAsync(s->d_ctl, 0, kCtlSize * sizeof(double), h->stream); }
     } ctl_guard{h, s};
     sv.ctl = s->d_ctl; dp.ctl = s->d_ctl;
+    if (free_ratio) {   // the ratio joins the state on the device: value, Jacobi scale, lower bound ({h, g} of the last linearisation are there)
+      HIP_TRY(launch_ratio_init(s->ratio4, ratio, ratio_scale, ratio_lb, st));
+      dp.prior_ratio_ptr = s->ratio4 + kRtRatio;
+    }
     s->clamp_with_factor = true; s->clamp_lo_hi[0] = opt->min_lm_diagonal; s->clamp_lo_hi[1] = opt->max_lm_diagonal;
     HIP_TRY(launch_begin_solve(sv, st));   // (from here on the last kernel of an iteration clears the two flags for the next)
     // The last kernel of an iteration writes the state to a slot of pinned host memory and stamps it; the host polls the stamp (no
@@ -2065,14 +2083,20 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
     while (!stopped && enqueued < opt->max_num_iterations) {
       // (thirteen launches on this stream; the steps the host form spreads over twenty-two, in its order: kernels_normal.hip, "the same steps in
       // fewer launches".  The diagonal's clamp rides in the point factor's launch — after a rejected step it recomputes what is there.)
+      if (free_ratio) HIP_TRY(launch_ratio_prepare_ctl(s->ratio4, s->d_ctl, opt->min_lm_diagonal, opt->max_lm_diagonal, st));   // the ratio's damped pivot and gradient for the ETA task of the factorisation
       if ((rc = factor_and_solve(h, 1.0))) return rc;   // (the radius argument is ignored: the kernels read ctl)
+      if (free_ratio) HIP_TRY(launch_ratio_candidate(s->ratio4, s->d_ctl, st));
       HIP_TRY(launch_candidate_and_model_cost(dp, sv, st));
-      if (s->ucross && (sv.lead || h->prior_split)) HIP_TRY(launch_prior_model(dp, sv, sv.scalars + kModelCostChange, 0.0, st));   // motion priors (known interFrameRatio): their share of the model cost change ...
+      if (s->ucross && (sv.lead || h->prior_split)) HIP_TRY(launch_prior_model(dp, sv, sv.scalars + kModelCostChange, 0.0, st, free_ratio ? s->ratio4 + kRtC : nullptr));   // motion priors: their share of the model cost change (a free ratio's step included) ...
       swap_params();
       HIP_TRY(launch_eval(dp, kLmJacobian, st));
       if (s->ucross) {                                                                                 // ... their cost at the candidate, behind the observations' ...
         HIP_TRY(launch_cost_reduce(dp, h->d_cost2, st));
-        if (sv.lead || h->prior_split) HIP_TRY(launch_prior_cost(dp, h->d_cost2, h->prior_invalid, st));
+        if (sv.lead || h->prior_split) {
+          DeviceProblem dq = dp;
+          if (free_ratio) dq.prior_ratio_ptr = s->ratio4 + kRtRatioEval;   // (... at the candidate's ratio)
+          HIP_TRY(launch_prior_cost(dq, h->d_cost2, h->prior_invalid, st));
+        }
       }
       swap_params();
       if ((rc = await_verification(h))) return rc;
@@ -2088,6 +2112,7 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
       HIP_TRY(launch_linearize_blocks(dp, sv, st, &fused));   // camera blocks, the accepted candidate's copy over x, point blocks: side by side in one launch
       if (!fused) HIP_TRY(launch_camera_blocks(dp, sv, st, /*take_candidate=*/true, /*padding_is_zero=*/true));   // (the initial linearisation zeroed the pseudo frames' padding)
       if (my_priors) HIP_TRY(launch_prior_blocks(dp, sv, s->ucross, st));                             // ... and their blocks of an accepted step's linearisation
+      if (free_ratio) HIP_TRY(launch_prior_border(dp, sv, s->border, s->ratio4, st));                 // (the ratio's column at the accepted point: every rank, from replicated poses)
       HIP_TRY(launch_intr_blocks(dp, sv, st));
       if (!fused) HIP_TRY(launch_point_blocks(dp, sv, st));
       s->ctl_seq += 1.0;
@@ -2119,6 +2144,12 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
       for (int k = 0; k < have; ++k) push(recs[(size_t)k]);
     }
     sum->linear_solver_time_s += now_s() - t0;
+    if (free_ratio) {   // the ratio's state back to the host (the stream is idle)
+      double rt[kRtSize];
+      HIP_TRY(hipMemcpy(rt, s->ratio4, sizeof rt, hipMemcpyDeviceToHost));
+      ratio = rt[kRtRatio]; ratio_new = ratio; ratio_diag = rt[kRtDiag]; ratio_hg[0] = rt[kRtH]; ratio_hg[1] = rt[kRtG];
+      dp.prior_ratio = ratio;
+    }
     radius = hc[kCtlRadius]; decrease_factor = hc[kCtlDecrease]; cost = hc[kCtlCost]; gmax = hc[kCtlGmax];
     iteration = (int)hc[kCtlIteration]; invalid_streak = (int)hc[kCtlInvalidStreak];
     sum->num_successful_steps = (int)hc[kCtlSuccessful]; sum->num_unsuccessful_steps = (int)hc[kCtlUnsuccessful]; sum->final_cost = hc[kCtlFinalCost];

@@ -101,6 +101,13 @@ struct SolverDev {
   double* Lf;                   // [nslots][kTile][kTile] the factor's sub-diagonal tiles (S keeps the reduced system itself)
   double* zv;                   // [npad] forward solve z, directly followed by
   double* yv;                   // [npad] the camera step y (copied to rhs when the solve is done)
+  // A second right-hand side that shares the factorisation (the free interFrameRatio's column b of the normal equations, a 1-wide border of S):
+  // z2 = L^-1 b is formed by FWD2 tasks beside the factorisation, the ETA task turns the two forward solves into the ratio's step
+  // eta = (g_s - s z2.z) / (h_s + D - s^2 z2.z2) and the BACK tasks solve L^T y = z - (s eta) z2 — ONE backward solve, no launch of its own.
+  double* zv2;                  // [npad] write-once cells of z2 (null: one right-hand side)
+  double* ceta;                 // [8] write-once cell {s eta} the BACK tasks wait for
+  const double* border2;        // [npad] b
+  double* rt;                   // [kRtSize] the ratio's scalars on the device (RatioSlot)
   double* Winv;                 // [nt][kTile][kTile] inverses of the factored diagonal tiles (by tile index)
   double* chol_part;            // [all chunks][kTile*kTile + kTile] partial update tiles (+ rhs partials)
   double* Xpub;                 // [nt][kTile][kTile] by DIAG item: tile (j, k*) less its updates, published by its SUB task for the DIAG task of column j
@@ -122,6 +129,16 @@ struct SolverDev {
   double* partial_c;            // the candidate's two sums when they are reduced together with the model cost change (device-side trust region)
   double* scalars;              // [16] results of reductions (see ScalarSlot)
   int* chol_fail;               // set when a pivot is not positive / not finite
+};
+
+enum RatioSlot : int {
+  kRtH = 0, kRtG = 1,            // J~_ratio^T J~_ratio, J~_ratio^T r~ of the last linearisation (prior_border_kernel)
+  kRtDot1 = 2, kRtDot2 = 3,      // z2.z, z2.z2 of the last solve (ETA task)
+  kRtDiagTerm = 4, kRtGs = 5, kRtScale = 6,   // h_s + D / radius, g_s, the ratio's Jacobi scale: what the ETA task reads
+  kRtEta = 7, kRtC = 8,          // the ratio's scaled step eta and s eta (its step in its own units is -s eta)
+  kRtRatio = 9, kRtRatioNew = 10, kRtDiag = 11, kRtLb = 12,   // device-side trust region: the ratio, its candidate, its clamped LM diagonal, its lower bound
+  kRtRatioEval = 13,             // the candidate as the prior blocks are evaluated with it (the ratio itself when the candidate is not finite)
+  kRtSize = 16
 };
 
 enum ScalarSlot : int {
@@ -147,7 +164,7 @@ struct CholPlan {
   int nslots, nparts;
 };
 
-enum : int { kTaskUpdate = 0, kTaskDiag = 1, kTaskSub = 2, kTaskBack = 3 };
+enum : int { kTaskUpdate = 0, kTaskDiag = 1, kTaskSub = 2, kTaskBack = 3, kTaskFwd2 = 4, kTaskEta = 5 };   // FWD2: item = DIAG item whose column's z2 it forms
 
 // per-pose priors (kernels_pose_prior.hip): linearisation of the priorPoses coordinates [pp_count][6] and where the pose
 // entries sit in the packed tiles
@@ -208,12 +225,16 @@ hipError_t launch_lm_linearize_gradient(const DeviceProblem& dp, const SolverDev
 hipError_t launch_lm_verdict_gradient(const DeviceProblem& dp, const SolverDev& sv, double* ctl, const LmRules& rules, rsba_iteration* trace, int trace_cap, double* snapshot, double seq, hipStream_t st, bool gradmax_done = false);   // the maxima reduced (unless gradmax_done: scalars[kGradMax] is there) + launch_lm_decide_gradient; ctl copied to `snapshot` (device-visible host memory), stamped `seq` last
 // motion priors (kernels_prior.hip): U_f, g_f += their J^T J / J^T r, ucross[f] = the (f, f-1) block; model cost change
 hipError_t launch_prior_blocks(const DeviceProblem& dp, const SolverDev& sv, double* ucross, hipStream_t st);
-hipError_t launch_prior_model(const DeviceProblem& dp, const SolverDev& sv, double* model_cost_change, double ratio_step, hipStream_t st);
+hipError_t launch_prior_model(const DeviceProblem& dp, const SolverDev& sv, double* model_cost_change, double ratio_step, hipStream_t st, const double* ratio_step_ptr = nullptr);
 // free interFrameRatio: its column of the normal equations (border [F*12], hg = {h, g}), dots and the combined step
 hipError_t launch_prior_border(const DeviceProblem& dp, const SolverDev& sv, double* border, double* hg, hipStream_t st);
 hipError_t launch_exchange_pack(const SolverDev& sv, const int32_t* slots, int ntiles, double* buf, bool unpack, hipStream_t st);   // exchange (2): the structurally non-zero tiles of S | rhs <-> one contiguous buffer
 hipError_t launch_border_dots(const double* b, const double* u, const double* v, int64_t n, double* out2, hipStream_t st);
-hipError_t launch_border_combine(double* y, const double* u, const double* v, double c, int64_t n, hipStream_t st);
+hipError_t launch_border_combine(double* y, const double* u, const double* v, double c, int64_t n, hipStream_t st, const double* c_ptr = nullptr);   // y = u - c v
+hipError_t launch_ratio_init(double* rt, double ratio, double scale, double lb, hipStream_t st);               // device-side trust region: the ratio joins the state on the device
+hipError_t launch_ratio_prepare(double* rt, double diag_term, double gs, double scale, hipStream_t st);         // what the ETA task of the factorisation reads (RatioSlot), by value ...
+hipError_t launch_ratio_prepare_ctl(double* rt, const double* ctl, double lo, double hi, hipStream_t st);     // ... or from the trust-region state on the device
+hipError_t launch_ratio_candidate(double* rt, const double* ctl, hipStream_t st);                              // ratio_new = max(lb, ratio - s eta)
 hipError_t launch_intr_blocks(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);
 hipError_t launch_virtual_records(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);
 hipError_t launch_pack_linearize(const DeviceProblem& dp, const SolverDev& sv, const double* cost2, hipStream_t st, int nslots = 0);   // nslots: zeroed slots behind the payload (the ranks' gradient maxima)

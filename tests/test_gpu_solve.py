@@ -472,7 +472,8 @@ def test_device_blocks_are_cached_between_handles_and_given_back(capi):
     assert s.final_cost == t.final_cost == results[0][0] and np.array_equal(p.poses, results[0][1]) and np.array_equal(q.points, results[0][2])
 
 
-@pytest.mark.parametrize("case", ["c2", "rejections", "failure", "tolerances", "max_iterations", "huber", "priors", "priors_rejections", "c2_priors", "intrinsics", "intrinsics_rejections", "intrinsics_priors"])
+@pytest.mark.parametrize("case", ["c2", "rejections", "failure", "tolerances", "max_iterations", "huber", "priors", "priors_rejections", "c2_priors", "intrinsics", "intrinsics_rejections", "intrinsics_priors",
+                                  "free_ratio", "free_ratio_rejections", "free_ratio_acceleration", "c2_free_ratio"])
 def test_device_side_trust_region_equals_the_host_form(capi, monkeypatch, case):
     """accept / reject, the radius update and the convergence tests of the LM loop run in a single-thread kernel, the
     iteration's kernels read the radius from HBM and skip themselves where the host form would not have launched them, the host
@@ -481,11 +482,13 @@ def test_device_side_trust_region_equals_the_host_form(capi, monkeypatch, case):
     (rejected steps, termination by each tolerance, by the iteration limit), and whatever the look-ahead."""
     from rsba_amd.scene import make_config
     def problem():
-        if case in ("c2", "c2_priors"):
+        if case in ("c2", "c2_priors", "c2_free_ratio"):
             p = make_config("C2").problem
-            if case == "c2_priors":
+            if case != "c2":
                 p.prior_kind, p.prior_scale, p.inter_frame_ratio = 2, 25.0, 1.2
                 p.prior_frames = np.arange(1, p.num_frames, dtype=np.int32)
+            if case == "c2_free_ratio":
+                p.inter_frame_ratio, p.ratio_free = 1.0, True
             return p, dict(max_num_iterations=12)
         p = small_scene(frames=24, points=1500, seed=13, outlier_ratio=0.1 if case == "huber" else 0.0)
         if case == "huber":
@@ -497,7 +500,11 @@ def test_device_side_trust_region_equals_the_host_form(capi, monkeypatch, case):
         if case.startswith("priors") or case == "intrinsics_priors":                # motion priors with a known interFrameRatio (CeresHandler.h:147-185): their cost, blocks and model change are part of every decision
             p.prior_kind, p.prior_scale, p.inter_frame_ratio = 1, 1.0 if case == "priors_rejections" else 10.0, 0.8
             p.prior_frames = np.arange(1, p.num_frames, dtype=np.int32)
-        if case in ("rejections", "failure", "priors_rejections", "intrinsics_rejections"):      # a start far from the minimum and a huge first radius: Gauss-Newton steps that overshoot (or never recover)
+        if case.startswith("free_ratio"):   # the reference's default with motion priors (CeresHandler.h:161,172,175): the interFrameRatio is a free, lower-bounded block — one more
+            p.prior_kind = 2 if case == "free_ratio_acceleration" else 1   # unknown of every decision (its step out of the factorisation's second right-hand side, its candidate, its projected gradient)
+            p.prior_scale, p.inter_frame_ratio, p.ratio_free = 1.0 if case == "free_ratio_rejections" else 10.0, 1.0, True
+            p.prior_frames = np.arange(1, p.num_frames, dtype=np.int32)
+        if case in ("rejections", "failure", "priors_rejections", "intrinsics_rejections", "free_ratio_rejections"):      # a start far from the minimum and a huge first radius: Gauss-Newton steps that overshoot (or never recover)
             rng = np.random.default_rng(2)
             sc = 3.0 if case == "failure" else 2.0
             p.points += rng.normal(0, 0.6 * sc, p.points.shape); p.poses[1:, :, 3:] += rng.normal(0, 0.25 * sc, p.poses[1:, :, 3:].shape)
@@ -505,7 +512,7 @@ def test_device_side_trust_region_equals_the_host_form(capi, monkeypatch, case):
             return p, dict(max_num_iterations=30, initial_trust_region_radius=1e12)
         if case == "tolerances":
             return p, dict(max_num_iterations=50)
-        if case in ("priors", "intrinsics", "intrinsics_priors"):
+        if case in ("priors", "intrinsics", "intrinsics_priors", "free_ratio", "free_ratio_acceleration"):
             return p, dict(max_num_iterations=15)
         return p, dict(max_num_iterations=3)
     out = {}
@@ -518,15 +525,18 @@ def test_device_side_trust_region_equals_the_host_form(capi, monkeypatch, case):
         with capi.DeviceProblem(p) as dp:
             s, tr = dp.solve(capi.default_options(**kw))
         rec = [(t.iteration, t.step_is_valid, t.step_is_successful, t.cost, t.cost_change, t.gradient_max_norm, t.step_norm, t.relative_decrease, t.trust_region_radius, t.model_cost_change) for t in tr]
-        out[mode] = (rec, (s.termination_type, s.num_successful_steps, s.num_unsuccessful_steps, s.num_iterations, s.initial_cost, s.final_cost, s.is_solution_usable), p.poses.copy(), p.points.copy(), p.intrinsics.copy())
+        out[mode] = (rec, (s.termination_type, s.num_successful_steps, s.num_unsuccessful_steps, s.num_iterations, s.initial_cost, s.final_cost, s.is_solution_usable, float(p.inter_frame_ratio)),
+                     p.poses.copy(), p.points.copy(), p.intrinsics.copy())
     ref = out["host"]
     for mode in ("device", "device_ahead_1", "device_ahead_5"):
         got = out[mode]
         assert got[0] == ref[0], mode
         assert got[1] == ref[1], (mode, got[1], ref[1])
         assert np.array_equal(got[2], ref[2]) and np.array_equal(got[3], ref[3]) and np.array_equal(got[4], ref[4]), mode
-    if case in ("rejections", "priors_rejections", "intrinsics_rejections"):
+    if case in ("rejections", "priors_rejections", "intrinsics_rejections", "free_ratio_rejections"):
         assert ref[1][1] >= 5 and ref[1][2] >= 3          # the case does accept and reject steps
+    if "free_ratio" in case:
+        assert ref[1][7] != 1.0                            # the ratio was solved for
     if case == "failure":
         assert ref[1][2] >= 3                              # ... and this one only rejects (invalid or unsuccessful steps to the end)
     if case == "max_iterations":
