@@ -1121,9 +1121,10 @@ __device__ __forceinline__ void task_back(const SolverDev& sv, const CholPlan& p
 
 // (defined with the substitution-only driver further down)
 template <bool DAG>
-__device__ __forceinline__ void task_forward(const SolverDev& sv, const CholPlan& pl, int d, int p0, int p1, const double* __restrict__ b2, const double* __restrict__ minus, double* z2, double* smem, int tid);
+__device__ __forceinline__ void task_forward(const SolverDev& sv, const CholPlan& pl, int d, int p0, int p1, const double* __restrict__ b2, const double* __restrict__ minus, double* z2, double* smem, int tid,
+                                             double* partial_out = nullptr);
 template <bool DAG>
-__device__ __forceinline__ void task_eta(const SolverDev& sv, double* smem, int tid);
+__device__ __forceinline__ void task_eta(const SolverDev& sv, const CholPlan& pl, double* smem, int tid);
 
 template <bool DAG>
 __device__ __forceinline__ void run_task(const SolverDev& sv, const CholPlan& pl, int kind, int item, double* smem, int tid) {
@@ -1131,8 +1132,10 @@ __device__ __forceinline__ void run_task(const SolverDev& sv, const CholPlan& pl
     case kTaskUpdate: task_update<DAG>(sv, pl, item, smem, tid); break;
     case kTaskDiag: task_diag<DAG>(sv, pl, item, smem, tid); break;
     case kTaskSub: task_sub<DAG>(sv, pl, item, smem, tid); break;
-    case kTaskFwd2: task_forward<DAG>(sv, pl, item, gl(pl.diag_ptr + item), gl(pl.diag_ptr + item + 1), sv.border2, nullptr, sv.zv2, smem, tid); break;
-    case kTaskEta: task_eta<DAG>(sv, smem, tid); break;
+    case kTaskFwd2: { const int tr = gl(pl.diag_toprow + item);
+      task_forward<DAG>(sv, pl, item, gl(pl.fwd_range + 2 * item), gl(pl.fwd_range + 2 * item + 1), sv.border2, (pl.fwd2_minus && tr >= 0) ? pl.fwd2_minus + (size_t)tr * T : nullptr, sv.zv2, smem, tid); } break;
+    case kTaskFwd2P: task_forward<DAG>(sv, pl, item, gl(pl.fwd_range + 2 * item), gl(pl.fwd_range + 2 * item + 1), sv.border2, nullptr, sv.zv2, smem, tid, pl.fwd2_partial + (size_t)gl(pl.diag_toprow + item) * T); break;
+    case kTaskEta: task_eta<DAG>(sv, pl, smem, tid); break;
     default: task_back<DAG>(sv, pl, item, smem, tid); break;
   }
 }
@@ -1191,7 +1194,7 @@ __global__ __launch_bounds__(256, 2) void chol_dag_kernel(const DagArgs* __restr
 // simply there.  minus (may be null): what other ranks' columns contribute to this column (sharded factorisation: summed by the exchange).
 template <bool DAG>
 __device__ __forceinline__ void task_forward(const SolverDev& sv, const CholPlan& pl, int d, int p0, int p1, const double* __restrict__ b2, const double* __restrict__ minus, double* z2,
-                                             double* smem, int tid) {
+                                             double* smem, int tid, double* partial_out) {
   constexpr int CG = 10;        // columns per thread
   double* zb = smem;            // [T] z2 of the contributor being multiplied
   double* sp = smem + T;        // [5][T] partial sums
@@ -1226,6 +1229,15 @@ __device__ __forceinline__ void task_forward(const SolverDev& sv, const CholPlan
 #pragma unroll
     for (int m = 0; m < CG; ++m) cur[m] = nxt[m];
   }
+  if (partial_out) {   // FWD2P: only the sum over this rank's part — it travels (plain stores: read behind this launch)
+    if (worker) sp[cg * T + r] = s;
+    lds_barrier();
+    if (tid < T) { double t = 0.0;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) t += sp[k * T + r];
+      partial_out[r] = t; }
+    return;
+  }
   // W_j: requested before the sums meet (the DIAG task of this column has just produced it, or is about to)
   const double* Wg = sv.Winv + (size_t)tile_j * (T * T);
   double w[CG];
@@ -1259,10 +1271,11 @@ __device__ __forceinline__ void task_forward(const SolverDev& sv, const CholPlan
 // `extra` carries: sharded factorisation — the other ranks' parts, summed by the exchange), eta = (g_s - s d1) / (h_s + D - s^2 d2); s eta goes to
 // the cell the BACK tasks wait for.  One workgroup, sums in a fixed order.
 template <bool DAG>
-__device__ __forceinline__ void task_eta(const SolverDev& sv, double* smem, int tid) {
+__device__ __forceinline__ void task_eta(const SolverDev& sv, const CholPlan& pl, double* smem, int tid) {
 #pragma clang fp contract(off)
   double a = 0.0, b = 0.0;
   for (int64_t t = tid; t < sv.npad; t += 256) {
+    if (pl.eta_tiles && !gl(pl.eta_tiles + t / T)) continue;   // (a sharded factorisation: this launch's columns only)
     double z = ld<DAG>(sv.zv + t), w = ld<DAG>(sv.zv2 + t);
     while (DAG && !(filled(z) && filled(w))) { __builtin_amdgcn_s_sleep(8); z = ld<DAG>(sv.zv + t); w = ld<DAG>(sv.zv2 + t); }
     a += w * z; b += w * w;
@@ -1272,7 +1285,9 @@ __device__ __forceinline__ void task_eta(const SolverDev& sv, double* smem, int 
   if ((tid & 63) == 0) { smem[tid >> 6] = a; smem[4 + (tid >> 6)] = b; }
   lds_barrier();
   if (tid == 0) {
-    const double d1 = (smem[0] + smem[1]) + (smem[2] + smem[3]), d2 = (smem[4] + smem[5]) + (smem[6] + smem[7]);
+    double d1 = (smem[0] + smem[1]) + (smem[2] + smem[3]), d2 = (smem[4] + smem[5]) + (smem[6] + smem[7]);
+    if (pl.eta_partial) { pl.eta_partial[0] = d1; pl.eta_partial[1] = d2; return; }   // launch A of a sharded factorisation: this rank's part, to be summed by the exchange
+    if (pl.eta_extra) { d1 += gl(pl.eta_extra); d2 += gl(pl.eta_extra + 1); }        // launch B: the separators' share (every rank alike) + all parts'
     const double sc = sv.rt[kRtScale];
     const double eta = (sv.rt[kRtGs] - sc * d1) / (sv.rt[kRtDiagTerm] - sc * sc * d2);
     const double c = sc * eta;

@@ -86,6 +86,8 @@ struct Solver {
   int dag_workgroups = 0;
   bool dag_one_per_cu = true;                                         // LDS request above half a CU's: two persistent workgroups never share a CU (RSBA_CHOL_WGS above the CU count lifts it)
   bool use_levels = false;                                            // RSBA_CHOL_LEVELS=1: one launch per (level, kind)
+  std::vector<int32_t> fwd_full, fwd_a, fwd_b, diag_toprow; int32_t *d_fwd_full = nullptr, *d_fwd_a = nullptr, *d_fwd_b = nullptr, *d_diag_toprow = nullptr;   // second right-hand side: contributor ranges per DIAG item and plan
+  uint8_t* d_row_sep = nullptr;                                       // [nt] tile columns (old index) in the separators
   bool two_rhs = false;                                               // the plan carries a second right-hand side through the factorisation (free interFrameRatio: FWD2 / ETA tasks)
   int last_diag_slot = 0;
   int32_t* d_obs_slot = nullptr;
@@ -673,7 +675,7 @@ int32_t build_solver_impl(rsba_handle* h) {
   // interFrameRatio or several intrinsics blocks (their replicated terms come from rank 0 alone) — those problems keep the
   // replicated factorisation.  Motion priors with a known ratio are shared out like the frames: see below.
   std::vector<int32_t> cpart(nt, -1);
-  bool sharded = want_parts && tord.parts_ok && !(h->prior_free && !h->prior_frames.empty()) && h->pp_blocks.empty() && dp.pp_spherical < 0 && NIB <= 1;
+  bool sharded = want_parts && tord.parts_ok && h->pp_blocks.empty() && dp.pp_spherical < 0 && NIB <= 1;   // (a free interFrameRatio is in: its column's forward solve runs part by part, FWD2P / ETA below)
   if (const char* e = std::getenv("RSBA_SHARDED")) sharded = sharded && e[0] != '0';   // A/B switch
   if (want_parts) {
     double bad = sharded ? 0.0 : 1.0;
@@ -810,6 +812,19 @@ int32_t build_solver_impl(rsba_handle* h) {
       klev.clear();
       for (int32_t k : rj) { s->diag_list.push_back(slot_of(j, k)); s->diag_list.push_back(perm[k]); klev.push_back(level[k]); }
       s->diag_ptr.push_back((int32_t)(s->diag_list.size() / 2));
+      {
+        // the contributors a second right-hand side's forward task sums over (FWD2 / FWD2P, cholesky.hip): all of them; in a sharded plan a
+        // separator column takes THIS rank's part in launch A (its share travels) and the separators' own columns in launch B
+        const int32_t dp1 = (int32_t)(s->diag_list.size() / 2);
+        s->fwd_full.push_back(dp0); s->fwd_full.push_back(dp1);
+        if (sharded) {
+          int32_t lo = dp0, hi = dp0;
+          if (topcol) { int q = 0; while (q < nbj && pk[q] != h->rank) ++q; lo = dp0 + q; while (q < nbj && pk[q] == h->rank) ++q; hi = dp0 + q; }
+          else { lo = dp0; hi = dp1; }
+          s->fwd_a.push_back(lo); s->fwd_a.push_back(hi);
+          s->fwd_b.push_back(topcol ? dp0 + nbj : dp0); s->fwd_b.push_back(topcol ? dp1 : dp0);
+        }
+      }
       chunk_it(0, dp0, (int32_t)(s->diag_list.size() / 2), s->diag_info, s->diag_own, dp0, nbj, pk, sharded ? &s->diag_info_sh : nullptr, slot_base[j]);
       if (fuse_last && !rj.empty() && (!topcol || cpart[rj.back()] < 0)) {   // (a separator column of a sharded plan never takes a part's column by the hand: it lives on another rank)
         const int32_t ks = rj.back();
@@ -859,7 +874,15 @@ int32_t build_solver_impl(rsba_handle* h) {
     for (int l = 0; l < nlev; ++l) {
       for (int32_t u : upd_by_level[l]) { std::vector<int32_t>& t = upd_owner[u] == me ? s->tasks_a : s->tasks_b; if (upd_owner[u] == me || upd_owner[u] < 0) { t.push_back(kTaskUpdate); t.push_back(u); } }
       for (int d = s->lev_diag_ptr[l]; d < s->lev_diag_ptr[l + 1]; ++d) { const int p = cpart[diag_colnew[d]]; if (p == me) { s->tasks_a.push_back(kTaskDiag); s->tasks_a.push_back(d); } else if (p < 0) { s->tasks_b.push_back(kTaskDiag); s->tasks_b.push_back(d); } }
+      if (two_rhs) for (int d = s->lev_diag_ptr[l]; d < s->lev_diag_ptr[l + 1]; ++d) { const int p = cpart[diag_colnew[d]]; if (p == me) { s->tasks_a.push_back(kTaskFwd2); s->tasks_a.push_back(d); } else if (p < 0) { s->tasks_b.push_back(kTaskFwd2); s->tasks_b.push_back(d); } }
       for (int t = s->lev_sub_ptr[l]; t < s->lev_sub_ptr[l + 1]; ++t) { const int p = cpart[sub_colnew[t]]; if (p == me) { s->tasks_a.push_back(kTaskSub); s->tasks_a.push_back(t); } else if (p < 0) { s->tasks_b.push_back(kTaskSub); s->tasks_b.push_back(t); } }
+    }
+    if (two_rhs) {
+      // launch A ends with what travels: this rank's part's share of every separator column's second right-hand side, and of the two dots;
+      // launch B's ETA task sits between its forward and its backward phase
+      for (int d = 0; d < (int)diag_colnew.size(); ++d) if (cpart[diag_colnew[d]] < 0) { s->tasks_a.push_back(kTaskFwd2P); s->tasks_a.push_back(d); }
+      s->tasks_a.push_back(kTaskEta); s->tasks_a.push_back(0);
+      s->tasks_b.push_back(kTaskEta); s->tasks_b.push_back(0);
     }
     for (int l = nlev - 1; l >= 0; --l)
       for (int d = s->lev_diag_ptr[l]; d < s->lev_diag_ptr[l + 1]; ++d) { const int p = cpart[diag_colnew[d]]; if (p == me || p < 0) { s->tasks_b.push_back(kTaskBack); s->tasks_b.push_back(d); } }
@@ -1106,6 +1129,18 @@ int32_t build_solver_impl(rsba_handle* h) {
   up.upload_ref(&s->d_back_info, s->back_info);
   up.upload_ref(&s->d_back_ptr, s->back_ptr);
   up.upload_ref(&s->d_back_list, s->back_list);
+  {
+    // second right-hand side: per DIAG item the index of its column among the separators' tile columns (ascending new order: the order of top_tiles below)
+    s->diag_toprow.assign(diag_colnew.size(), -1);
+    if (sharded) {
+      std::vector<int32_t> trow_of_col((size_t)nt, -1);
+      int32_t cnt = 0;
+      for (int j = 0; j < nt; ++j) if (cpart[j] < 0) trow_of_col[j] = cnt++;
+      for (size_t d = 0; d < diag_colnew.size(); ++d) s->diag_toprow[d] = trow_of_col[diag_colnew[d]];
+    }
+    up.upload_ref(&s->d_fwd_full, s->fwd_full); up.upload_ref(&s->d_diag_toprow, s->diag_toprow);
+    if (sharded) { up.upload_ref(&s->d_fwd_a, s->fwd_a); up.upload_ref(&s->d_fwd_b, s->fwd_b); }
+  }
 
   // ---- sharded factorisation: what the exchange between the two launches needs ----
   std::vector<int32_t> top_slots, top_info, asm_ptr(1, 0), asm_list, top_tiles, top_fill;   // (alive until the uploads have finished)
@@ -1140,11 +1175,14 @@ int32_t build_solver_impl(rsba_handle* h) {
     up.upload(&s->d_top_slots, top_slots); up.upload(&s->d_top_info, top_info); up.upload(&s->d_asm_ptr, asm_ptr); up.upload(&s->d_asm_list, asm_list);
     up.upload(&s->d_top_tiles, top_tiles); up.upload(&s->d_row_mine, row_mine); up.upload(&s->d_top_fill, top_fill);
     { std::vector<uint8_t> row_check((size_t)nt, 0); for (int t = 0; t < nt; ++t) row_check[t] = tord.part_of[t] == h->rank; up.upload(&s->d_row_check, row_check); }
+    { std::vector<uint8_t> row_sep((size_t)nt, 0); for (int t = 0; t < nt; ++t) row_sep[t] = tord.part_of[t] < 0; up.upload(&s->d_row_sep, row_sep); }
     up.upload_const(&sv.frame_lead, frame_lead);
     up.upload_ref(&s->d_tasks_a, s->tasks_a); up.upload_ref(&s->d_tasks_b, s->tasks_b);
     up.upload_ref(&s->d_diag_info_sh, s->diag_info_sh); up.upload_ref(&s->d_sub_info_sh, s->sub_info_sh);
-    if ((rc = s_alloc(s, &s->topx_buf, (size_t)s->ntop_slots * kTile * kTile + (size_t)s->ntop_tiles * kTile))) return rc;
+    // (+ with a second right-hand side: the parts' share of the separators' rows of it, and of the two dots — behind the tiles and the rhs rows)
+    if ((rc = s_alloc(s, &s->topx_buf, (size_t)s->ntop_slots * kTile * kTile + (size_t)s->ntop_tiles * kTile + (two_rhs ? (size_t)s->ntop_tiles * kTile + 8 : 0)))) return rc;
     if ((rc = s_alloc(s, &s->ybuf, (size_t)sv.npad))) return rc;
+    if (two_rhs) HIP_TRY(hipMemsetAsync(s->topx_buf + (size_t)s->ntop_slots * kTile * kTile + (size_t)s->ntop_tiles * kTile, 0, ((size_t)s->ntop_tiles * kTile + 8) * sizeof(double), h->stream));
   }
   HIP_TRY(up.finish());
   tick("uploads");
@@ -1244,9 +1282,15 @@ int32_t build_solver_impl(rsba_handle* h) {
   pl.tasks = s->d_tasks; pl.ntasks = (int)(s->tasks.size() / 2); pl.ndiag = (int)(s->diag_info.size() / 4);
   pl.ticket = s->d_dag_sync;
   pl.nslots = sv.nslots; pl.nparts = parts;
+  pl.fwd_range = s->d_fwd_full; pl.diag_toprow = s->d_diag_toprow; pl.fwd2_minus = nullptr; pl.fwd2_partial = nullptr; pl.eta_tiles = nullptr; pl.eta_extra = nullptr; pl.eta_partial = nullptr;
   if (sharded) {
     s->plan_a = pl; s->plan_a.tasks = s->d_tasks_a; s->plan_a.ntasks = (int)(s->tasks_a.size() / 2);
     s->plan_b = pl; s->plan_b.tasks = s->d_tasks_b; s->plan_b.ntasks = (int)(s->tasks_b.size() / 2);
+    if (two_rhs) {
+      double* tail = s->topx_buf + (size_t)s->ntop_slots * kTile * kTile + (size_t)s->ntop_tiles * kTile;
+      s->plan_a.fwd_range = s->d_fwd_a; s->plan_a.fwd2_partial = tail; s->plan_a.eta_tiles = s->d_row_check; s->plan_a.eta_partial = tail + (size_t)s->ntop_tiles * kTile;
+      s->plan_b.fwd_range = s->d_fwd_b; s->plan_b.fwd2_minus = tail; s->plan_b.eta_tiles = s->d_row_sep; s->plan_b.eta_extra = tail + (size_t)s->ntop_tiles * kTile;
+    }
     s->plan_b.diag_info = s->d_diag_info_sh; s->plan_b.sub_info = s->d_sub_info_sh;   // (the parts' partial tiles have been summed in by the exchange)
   }
   int cus = 0;
@@ -1390,6 +1434,14 @@ int32_t exchange(rsba_handle* h, double* buf, int64_t count, int op, int kind) {
   return RSBA_OK;
 }
 
+// The ratio's column of the normal equations (and its own h, g) is formed by EVERY rank over ALL priors, from replicated poses — also where
+// a sharded plan has shared the priors' blocks out (h->prior_split: dp.prior_of then lists this rank's share).
+DeviceProblem all_priors(const rsba_handle* h) {
+  DeviceProblem d = h->dp;
+  if (h->prior_split) d.prior_of = h->prior_of_all;
+  return d;
+}
+
 // r, J (loss-corrected, masked, scaled) and the normal-equation blocks at the current parameters;
 // exchange (1): per-camera gradient blocks + diag(U) + cost scalars.  Results: sv.gc / sv.udiag global,
 // scalars[kCost, kFixedCost, kEvalFailed].
@@ -1414,7 +1466,7 @@ int32_t linearize(rsba_handle* h, bool have_eval = false, bool want_gradmax = fa
       if (!have_eval) HIP_TRY(launch_prior_cost(h->dp, h->d_cost2, h->prior_invalid, h->stream));
       HIP_TRY(launch_prior_blocks(h->dp, s->sv, s->ucross, h->stream));
     }
-    if (s->border) HIP_TRY(launch_prior_border(h->dp, s->sv, s->border, s->ratio4, h->stream));   // every rank: from replicated poses
+    if (s->border) HIP_TRY(launch_prior_border(all_priors(h), s->sv, s->border, s->ratio4, h->stream));   // every rank: from replicated poses
   }
   if (h->dp.pp_count > 0 || h->dp.pp_spherical >= 0) {   // per-pose priors: replicated terms, contributed by the lead rank;
     PhaseScope ps(h, RSBA_PHASE_PRIORS);                   // the linearisation of the priorPoses coordinates (v0, g0, cross) on every rank: each one steps them itself
@@ -1525,7 +1577,7 @@ int32_t solve_reduced_system(rsba_handle* h, bool rhs_stays = false) {
       // launch A: the columns of this rank's part, from its own partial S — complete for them: every point that sees one of its tiles is here
       HIP_TRY(launch_chol_dag(sv, s->plan_a, s->d_dag_args_a[now], std::min(s->dag_workgroups, std::max(1, s->plan_a.ntasks)), s->dag_one_per_cu, st));
       // exchange (2'): the separators' tiles, each rank's share less what its part subtracts from them, summed over the ranks
-      const int64_t count = (int64_t)s->ntop_slots * kTile * kTile + (int64_t)s->ntop_tiles * kTile;
+      const int64_t count = (int64_t)s->ntop_slots * kTile * kTile + (int64_t)s->ntop_tiles * kTile + (s->two_rhs ? (int64_t)s->ntop_tiles * kTile + 8 : 0);   // (+ the second right-hand side's share: launch A left it behind the rows of the first)
       ps.stop();
       {
         PhaseScope pe(h, RSBA_PHASE_EXCHANGE);
@@ -2112,7 +2164,7 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
       HIP_TRY(launch_linearize_blocks(dp, sv, st, &fused));   // camera blocks, the accepted candidate's copy over x, point blocks: side by side in one launch
       if (!fused) HIP_TRY(launch_camera_blocks(dp, sv, st, /*take_candidate=*/true, /*padding_is_zero=*/true));   // (the initial linearisation zeroed the pseudo frames' padding)
       if (my_priors) HIP_TRY(launch_prior_blocks(dp, sv, s->ucross, st));                             // ... and their blocks of an accepted step's linearisation
-      if (free_ratio) HIP_TRY(launch_prior_border(dp, sv, s->border, s->ratio4, st));                 // (the ratio's column at the accepted point: every rank, from replicated poses)
+      if (free_ratio) HIP_TRY(launch_prior_border(all_priors(h), sv, s->border, s->ratio4, st));      // (the ratio's column at the accepted point: every rank, from replicated poses)
       HIP_TRY(launch_intr_blocks(dp, sv, st));
       if (!fused) HIP_TRY(launch_point_blocks(dp, sv, st));
       s->ctl_seq += 1.0;

@@ -162,9 +162,18 @@ struct CholPlan {
   unsigned int* ticket;
   long long* trace;          // debugging (RSBA_CHOL_TRACE): [ntasks][8] {workgroup, claimed, inputs ready, 4 task-specific stamps, done} in 10 ns ticks
   int nslots, nparts;
+  // second right-hand side (free interFrameRatio), per plan: a sharded factorisation runs its FWD2 / ETA tasks in two launches
+  const int32_t* fwd_range;   // [ndiag][2] contributors (positions in diag_list) a FWD2 / FWD2P task of this plan sums over
+  const int32_t* diag_toprow; // [ndiag] index of the item's column among the separators' tile columns, -1 = a part's column
+  const double* fwd2_minus;   // [separator tile columns][kTile] sum over the ranks of what their parts' columns contribute to z2's right-hand side (exchange (2')); null: nothing to subtract
+  double* fwd2_partial;       // ... and where THIS rank's share of it goes (FWD2P tasks, before the exchange)
+  const uint8_t* eta_tiles;   // [nt] tile columns the ETA task of this plan takes the dots z2.z, z2.z2 over (null: all)
+  const double* eta_extra;    // [2] + the other columns' share, summed by the exchange (null: none)
+  double* eta_partial;        // non-null: the task only leaves its two dots here (launch A of a sharded factorisation)
 };
 
-enum : int { kTaskUpdate = 0, kTaskDiag = 1, kTaskSub = 2, kTaskBack = 3, kTaskFwd2 = 4, kTaskEta = 5 };   // FWD2: item = DIAG item whose column's z2 it forms
+// FWD2: item = DIAG item whose column's z2 it forms; FWD2P: the same item's sum over THIS rank's part only (sharded: what travels)
+enum : int { kTaskUpdate = 0, kTaskDiag = 1, kTaskSub = 2, kTaskBack = 3, kTaskFwd2 = 4, kTaskEta = 5, kTaskFwd2P = 6 };
 
 // per-pose priors (kernels_pose_prior.hip): linearisation of the priorPoses coordinates [pp_count][6] and where the pose
 // entries sit in the packed tiles

@@ -45,6 +45,8 @@ def nd_mode(mode, outdir, rank, world, dist, torch):
     if "priors" in flags:    # a motion prior between every two consecutive frames (CeresHandler.h:147-185), known interFrameRatio: each rank contributes the priors of its part
         full.prior_kind, full.prior_scale, full.inter_frame_ratio = 2, 25.0, 1.2
         full.prior_frames = np.arange(1, full.num_frames, dtype=np.int32)
+        if "freeratio" in flags:   # ... the reference's default: the ratio is a free, lower-bounded block (CeresHandler.h:161,172,175) — its column's forward solve runs part by part
+            full.prior_kind, full.inter_frame_ratio, full.ratio_free = 1, 1.0, True
     if "hostrank" in flags and rank == 1:   # ONE rank cannot run the loop without the host (test hook of the library; in the field: a rank without observations, or with phase timers on): ALL ranks must then take the host form — their collectives pair up or the solve hangs
         os.environ["RSBA_DEVICE_LM_OFF_ON_THIS_RANK"] = "1"
     if "corrupt" in flags:   # the first persistent-driver solve loses an entry of its result (test hook of the library): every rank must notice through exchange (3)
@@ -74,7 +76,7 @@ def nd_mode(mode, outdir, rank, world, dist, torch):
     out = {"rank": rank, "transport": transport, "collective_calls": {k: v["calls"] for k, v in xs["collectives"].items()}, "world": world, "n_full": int(full.num_observations), "n_shard": int(shard.num_observations), "top_tile_columns": ntop,
            "final_cost": s.final_cost, "initial_cost": s.initial_cost, "iters": s.num_iterations, "dag_fallbacks": s.num_dag_fallbacks,
            "reduced": s.num_residual_blocks_reduced, "params": s.num_parameters_reduced, "costs": [t.cost for t in tr], "plan": st,
-           "poses_sum": float(np.abs(shard.poses).sum()), "points_sum": float(np.abs(shard.points).sum())}
+           "poses_sum": float(np.abs(shard.poses).sum()), "points_sum": float(np.abs(shard.points).sum()), "ratio": float(shard.inter_frame_ratio)}
     os.environ.pop("RSBA_CHOL_TEST_CORRUPT", None)
     os.environ.pop("RSBA_DEVICE_LM_OFF_ON_THIS_RANK", None)
     if rank == 0:
@@ -84,7 +86,7 @@ def nd_mode(mode, outdir, rank, world, dist, torch):
             st1 = d1.plan_stats()
         out.update(ref_final=s1.final_cost, ref_initial=s1.initial_cost, ref_iters=s1.num_iterations, ref_reduced=s1.num_residual_blocks_reduced, ref_params=s1.num_parameters_reduced,
                    pose_err=float(np.abs(ref.poses - shard.poses).max()), point_err=float(np.abs(ref.points - shard.points).max()),
-                   traj_err=float(max(abs(a.cost - b.cost) / b.cost for a, b in zip(tr, tr1))), ref_plan=st1,
+                   traj_err=float(max(abs(a.cost - b.cost) / b.cost for a, b in zip(tr, tr1))), ref_plan=st1, ref_ratio=float(ref.inter_frame_ratio),
                    decisions_equal=bool(all(a.step_is_successful == b.step_is_successful for a, b in zip(tr, tr1))))
     with open(os.path.join(outdir, f"rank{rank}.json"), "w") as f:
         json.dump(out, f)

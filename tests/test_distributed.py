@@ -298,14 +298,18 @@ def test_sharded_factorisation_on_three_ranks(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode,world", [("nd:C2:8:priors", 2), ("nd:S300:6:priors", 3), ("nd:S300:6:priors:intr", 4)])
+@pytest.mark.parametrize("mode,world", [("nd:C2:8:priors", 2), ("nd:S300:6:priors", 3), ("nd:S300:6:priors:intr", 4),
+                                        ("nd:C2:8:priors:freeratio", 2), ("nd:S300:6:priors:freeratio", 3), ("nd:S300:6:priors:intr:freeratio", 4), ("nd:C2:6:priors:freeratio:hostrank", 2)])
 def test_sharded_factorisation_with_motion_priors(tmp_path, mode, world):
     """A motion prior between every two consecutive frames with a known interFrameRatio (the reference's usual video configuration,
     CeresHandler.h:147-185).  The prior between frames f and f - 1 goes to the rank whose part holds either frame (rank 0 when both
     sit in separators), so a part's columns are still complete on its rank; every rank adds its own priors' cost, blocks and model
     change.  Same trajectory as one GPU, where all priors are on the one rank."""
     res = run_two_ranks(mode, tmp_path, world)
-    check_nd(res, world)
+    a = check_nd(res, world)
+    if "freeratio" in mode:   # the free ratio (the reference's default): one more unknown, solved for alike on every rank — out of the second right-hand side that
+        assert all(o["ratio"] == a["ratio"] for o in res) and a["ratio"] != 1.0   # rides through both launches of the sharded factorisation (FWD2 / FWD2P / ETA tasks)
+        assert abs(a["ratio"] - a["ref_ratio"]) <= 1e-8 * abs(a["ref_ratio"])
 
 
 @pytest.mark.gpu
@@ -355,8 +359,9 @@ def test_sharded_factorisation_at_c4_size_over_a_stream_ordered_transport(tmp_pa
 
 
 @pytest.mark.gpu
-def test_stream_ordered_transport_with_motion_priors_and_shared_intrinsics(tmp_path):
-    res = run_two_ranks("nd:S300:6:priors:intr:mock", tmp_path, 3, env_extra={"RSBA_RCCL_LIB": MOCK_RCCL})
+@pytest.mark.parametrize("mode", ["nd:S300:6:priors:intr:mock", "nd:S300:6:priors:freeratio:mock"])
+def test_stream_ordered_transport_with_motion_priors_and_shared_intrinsics(tmp_path, mode):
+    res = run_two_ranks(mode, tmp_path, 3, env_extra={"RSBA_RCCL_LIB": MOCK_RCCL})
     check_nd(res, 3)
 
 
