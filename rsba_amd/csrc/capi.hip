@@ -210,7 +210,8 @@ int32_t rsba_create(const rsba_problem_desc* d, int32_t device, rsba_handle** ou
   if ((rc = dev_upload(h, &h->d_mask_intr, h->mask_intr.data(), (size_t)dp.NI * 9))) return bail(rc);
 
   if ((rc = dev_alloc(h, &dp.res, 2 * (size_t)kEvalBlock * dp.ntiles))) return bail(rc);
-  if ((rc = dev_alloc(h, &dp.jac, 2 * (size_t)dp.K * kEvalBlock * dp.ntiles))) return bail(rc);
+  dp.jac = nullptr;   // [2 K x 256 x ntiles] what CostFunction::Evaluate materialises — 480 B per observation (4 GB at 4k cameras): allocated when a raw
+                      // evaluation is first asked for (ensure_jacobians).  BA() never is: the LM iteration forms its blocks without writing the Jacobian.
   const int nb = std::max(eval_num_blocks(N), 1);
   if ((rc = dev_alloc(h, &dp.cost_partial, (size_t)nb))) return bail(rc);
   if ((rc = dev_alloc(h, &dp.fixed_partial, (size_t)nb))) return bail(rc);
@@ -272,8 +273,15 @@ int32_t rsba_download_parameters(rsba_handle* h, double* poses, double* points, 
   return RSBA_OK;
 }
 
+static int32_t ensure_jacobians(rsba_handle* h) {
+  if (h->dp.jac) return RSBA_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  return dev_alloc(h, &h->dp.jac, 2 * (size_t)h->dp.K * kEvalBlock * h->dp.ntiles);
+}
+
 int32_t rsba_evaluate_device(rsba_handle* h, int32_t with_jacobians) {
   if (!h) return fail(RSBA_ERR_INVALID_ARGUMENT, "null handle");
+  if (with_jacobians) { if (int32_t rc = ensure_jacobians(h)) return rc; }
   HIP_TRY(launch_eval(h->dp, with_jacobians ? kRawJacobian : kResidualOnly, h->stream));
   return RSBA_OK;
 }
@@ -281,6 +289,7 @@ int32_t rsba_evaluate_device(rsba_handle* h, int32_t with_jacobians) {
 int32_t rsba_get_device_view(rsba_handle* h, rsba_device_view* v) {
   if (!h || !v) return fail(RSBA_ERR_INVALID_ARGUMENT, "null argument");
   std::memset(v, 0, sizeof *v);
+  if (int32_t rc = ensure_jacobians(h)) return rc;
   v->residuals = h->dp.res; v->jacobians = h->dp.jac; v->tile = kEvalBlock; v->jacobian_cols = h->dp.K;
   ensure_order(h);
   v->order_host = h->order.data(); v->poses = h->dp.poses; v->points = h->dp.points; v->intrinsics = h->dp.intr;
@@ -291,6 +300,7 @@ int32_t rsba_time_evaluate(rsba_handle* h, int32_t with_jacobians, int32_t warmu
   if (!h || !avg_ms || iters <= 0) return fail(RSBA_ERR_INVALID_ARGUMENT, "bad argument");
   HIP_TRY(hipSetDevice(h->device));
   const EvalMode mode = with_jacobians ? kRawJacobian : kResidualOnly;
+  if (with_jacobians) { if (int32_t rc = ensure_jacobians(h)) return rc; }
   for (int i = 0; i < warmup; ++i) HIP_TRY(launch_eval(h->dp, mode, h->stream));
   HIP_TRY(hipEventRecord(h->ev0, h->stream));
   for (int i = 0; i < iters; ++i) HIP_TRY(launch_eval(h->dp, mode, h->stream));
@@ -406,6 +416,7 @@ int32_t rsba_evaluate(rsba_handle* h, double* cost, double* residuals, double* j
   HIP_TRY(hipSetDevice(h->device));
   DeviceProblem& dp = h->dp;
   const int64_t N = dp.N; const int K = dp.K;
+  if (jacobians) { if (int32_t rc = ensure_jacobians(h)) return rc; }
   HIP_TRY(hipMemsetAsync(dp.fail_count, 0, sizeof(int), h->stream));
   HIP_TRY(launch_eval(dp, jacobians ? kRawJacobian : kResidualOnly, h->stream));
   HIP_TRY(launch_cost_reduce(dp, h->d_cost2, h->stream));

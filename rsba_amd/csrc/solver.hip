@@ -26,6 +26,7 @@
 #include "devmem.hpp"
 #include "solver_state.hpp"
 #include "tile_order.hpp"
+#include "plan_device.hpp"
 
 namespace rsba {
 
@@ -304,13 +305,37 @@ int32_t build_solver_impl(rsba_handle* h) {
   const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
   int plan_threads = N >= 400000 ? (int)std::min(16u, hw) : N >= 50000 ? (int)std::min(4u, hw) : 1;
   if (const char* e = std::getenv("RSBA_PLAN_THREADS")) plan_threads = std::max(1, std::min(64, std::atoi(e)));
+  const int nt = sv.nt;
+  // Which frame tiles store their groups FACTORED (solver_state.hpp: kGroupFactored): two-pose frames of a problem whose point-side passes
+  // recompute the records — the 12 camera-side rows of a frame are (1 - tau) q | tau q, so 6 rows and tau say it all (SURVEY §8a row 3) —
+  // except a tile that holds an intrinsics pseudo frame (its virtual records have no such structure).  RSBA_FACTORED=0: none (A/B).
+  bool recompute = dp.calibrated != 0 || NIB == 1;
+  if (const char* e = std::getenv("RSBA_RECORDS")) recompute = recompute && e[0] != '1';
+  bool factored = recompute && dp.P == 2;
+  if (const char* e = std::getenv("RSBA_FACTORED")) factored = factored && e[0] != '0';
+  std::vector<uint8_t> tile_factored((size_t)nt, 0);
+  for (int t = 0; t < nt && factored; ++t) tile_factored[t] = !((int64_t)(t + 1) * FT > FR && (int64_t)t * FT < F && F > FR);   // (no pseudo frame in [t FT, (t + 1) FT))
+  // The passes over observations, points and entries run ON THE DEVICE (plan_device.hip: stable sorts and prefix sums — the lists come
+  // out as from the host passes below, which stay as the path for what the device form leaves out: several intrinsics blocks (their
+  // per-point block lists), more than 8 192 tile columns (a dense pair map), and RSBA_PLAN_DEVICE=0 for A/B runs and the test that
+  // compares the two).  The host keeps the O(tiles) part: ordering, symbolic factorisation, task lists, chunk numbering.
+  bool dev_plan = N > 0 && NIB <= 1 && (int64_t)nt * nt <= ((int64_t)1 << 26) && N < ((int64_t)1 << 31);
+  if (const char* e = std::getenv("RSBA_PLAN_DEVICE")) dev_plan = dev_plan && e[0] != '0';
+  DevicePlanOut dpo;
   std::vector<int64_t> frame_ptr(FR + 1, 0);
-  std::vector<int64_t>& point_ptr = scr.point_ptr; point_ptr.assign((size_t)M + 1, 0);
+  std::vector<int64_t>& point_ptr = scr.point_ptr;
+  if (!dev_plan) point_ptr.assign((size_t)M + 1, 0);
+  else for (int f = 0; f <= FR; ++f) frame_ptr[f] = (int64_t)(std::lower_bound(of.begin(), of.end(), (int32_t)f) - of.begin());   // (the list is frame-major)
+  std::vector<int32_t>& obs_slot = scr.obs_slot; std::vector<int32_t>& real_frame = scr.real_frame;
+  std::vector<int64_t>& vgroup_ptr = scr.vgroup_ptr; std::vector<int32_t>& vgroup_point = scr.vgroup_point; std::vector<int32_t>& vgroup_intr = scr.vgroup_intr;
+  std::vector<int32_t>& slot_frame_host = scr.slot_frame; std::vector<int32_t>& slot_point = scr.slot_point;
+  int64_t NVG = 0, NS = N;
+  if (!dev_plan) {
   // slots: stable counting sort of the frame-major list by point -> ascending frame inside a point.  On several threads: every
   // thread counts the points of ITS range of observations, the counts of the threads before it are where its share of a point's
   // slots starts — the slots come out exactly as from one thread.
-  std::vector<int32_t>& obs_slot = scr.obs_slot; obs_slot.resize((size_t)N);
-  std::vector<int32_t>& real_frame = scr.real_frame; real_frame.resize((size_t)N);
+  obs_slot.resize((size_t)N);
+  real_frame.resize((size_t)N);
   const int nthr_obs = (N >= 200000 && (int64_t)plan_threads * M <= ((int64_t)1 << 26)) ? plan_threads : 1;
   if (nthr_obs > 1) {
     std::vector<std::vector<int32_t>> cnt((size_t)nthr_obs);
@@ -344,8 +369,7 @@ int32_t build_solver_impl(rsba_handle* h) {
   }
   // virtual groups: one per (observed point, intrinsics block it is seen through), blocks ascending; each owns NPF virtual
   // slots behind the real ones
-  std::vector<int64_t>& vgroup_ptr = scr.vgroup_ptr; vgroup_ptr.assign((size_t)M + 1, 0);
-  std::vector<int32_t>& vgroup_point = scr.vgroup_point; std::vector<int32_t>& vgroup_intr = scr.vgroup_intr;
+  vgroup_ptr.assign((size_t)M + 1, 0);
   vgroup_point.clear(); vgroup_intr.clear();
   if (NIB == 1) {   // one shared block (the usual uncalibrated session): every observed point is seen through it — no lists to sort
     vgroup_point.reserve((size_t)M); vgroup_intr.reserve((size_t)M);
@@ -363,14 +387,15 @@ int32_t build_solver_impl(rsba_handle* h) {
       vgroup_ptr[j + 1] = (int64_t)vgroup_point.size();
     }
   }
-  const int64_t NVG = (int64_t)vgroup_point.size();
-  sv.nvgroups = NVG;
-  const int64_t NS = N + NVG * NPF;
-  std::vector<int32_t>& slot_frame = scr.slot_frame; slot_frame.resize((size_t)NS);
-  std::vector<int32_t>& slot_point = scr.slot_point; slot_point.resize((size_t)NS);
-  parallel_ranges(nthr_obs, N, [&](int64_t a, int64_t b, int) { for (int64_t x = a; x < b; ++x) slot_frame[x] = real_frame[x]; });
+  NVG = (int64_t)vgroup_point.size();
+  NS = N + NVG * NPF;
+  slot_frame_host.resize((size_t)NS);
+  slot_point.resize((size_t)NS);
+  parallel_ranges(nthr_obs, N, [&](int64_t a, int64_t b, int) { for (int64_t x = a; x < b; ++x) slot_frame_host[x] = real_frame[x]; });
   parallel_ranges(nthr_obs, M, [&](int64_t a, int64_t b, int) { for (int64_t j = a; j < b; ++j) for (int64_t x = point_ptr[j]; x < point_ptr[j + 1]; ++x) slot_point[x] = (int32_t)j; });
-  for (int64_t g = 0; g < NVG; ++g) for (int v = 0; v < NPF; ++v) { slot_frame[N + g * NPF + v] = FR + vgroup_intr[g] * NPF + v; slot_point[N + g * NPF + v] = vgroup_point[g]; }
+  for (int64_t g = 0; g < NVG; ++g) for (int v = 0; v < NPF; ++v) { slot_frame_host[N + g * NPF + v] = FR + vgroup_intr[g] * NPF + v; slot_point[N + g * NPF + v] = vgroup_point[g]; }
+  }   // (!dev_plan)
+  std::vector<int32_t>& slot_frame = dev_plan ? dpo.slot_frame_h : slot_frame_host;   // (device plan: the real slots only, and only when a later pass asks for them)
   // the slots of point j in ascending frame order (virtual ones last, by intrinsics block; only for points that are observed)
   auto slots_of = [&](int j, std::vector<int64_t>& out) {
     out.clear();
@@ -379,37 +404,32 @@ int32_t build_solver_impl(rsba_handle* h) {
   };
   Uploader up(s, h->device);
   up.upload_const(&sv.frame_ptr, frame_ptr);
-  up.upload_const_ref(&sv.point_ptr, point_ptr);
-  up.upload_const_ref(&sv.slot_frame, slot_frame);
-  up.upload_const_ref(&sv.slot_point, slot_point);
-  up.upload_ref(&s->d_obs_slot, obs_slot);
+  if (!dev_plan) {
+    up.upload_const_ref(&sv.point_ptr, point_ptr);
+    up.upload_const_ref(&sv.slot_frame, slot_frame_host);
+    up.upload_const_ref(&sv.slot_point, slot_point);
+    up.upload_ref(&s->d_obs_slot, obs_slot);
+  }
   tick("slots");
   // ---- work list of the point elimination: one ENTRY per (point, pair of frame tiles I >= J) ----
   // An entry lists the point's observation slot in each of the FT frames of tile I (sa) and of tile J (sb),
   // -1 where it is not observed.  One wave turns an entry into up to FT x FT block products P_a P_b^T with
   // every P record loaded once (frame-pair-major accumulation, no atomics).  A point seen
   // twice in one frame gets a second "layer" of slots and the cross-layer entries.
-  const int nt = sv.nt;
   // Per point, the (tile, layer) groups of its slots — computed once, flat (no per-point allocations: this pass used
   // to be 85 % of the symbolic phase): group g of point j covers one tile and one layer and owns FT slot entries.
-  std::vector<int64_t>& pt_group = scr.pt_group; pt_group.assign((size_t)M + 1, 0);     // groups of point j: [pt_group[j], pt_group[j+1])
+  std::vector<int64_t>& pt_group = scr.pt_group;     // groups of point j: [pt_group[j], pt_group[j+1])
   std::vector<int32_t>& g_tile = scr.g_tile; std::vector<int32_t>& g_rows = scr.g_rows;   // tile of each group; FT slots per group (NS = not observed)
-  std::vector<uint32_t>& slot_gpos = scr.slot_gpos; slot_gpos.resize((size_t)NS);         // where every slot's P record goes: group offset | position << 1 | kind (solver_state.hpp)
+  std::vector<uint32_t>& slot_gpos = scr.slot_gpos;         // where every slot's P record goes: group offset | position << 1 | kind (solver_state.hpp)
+  if (!dev_plan) { pt_group.assign((size_t)M + 1, 0); slot_gpos.resize((size_t)NS); }
   std::vector<uint8_t>& group_mask = scr.group_mask;        // which of the three 16-row blocks of a group's records can be non-zero
   std::vector<uint8_t>& group_present = scr.group_present;  // frames of the group's tile that see the point (plan statistics)
-  // Which frame tiles store their groups FACTORED (solver_state.hpp: kGroupFactored): two-pose frames of a problem whose point-side passes
-  // recompute the records — the 12 camera-side rows of a frame are (1 - tau) q | tau q, so 6 rows and tau say it all (SURVEY §8a row 3) —
-  // except a tile that holds an intrinsics pseudo frame (its virtual records have no such structure).  RSBA_FACTORED=0: none (A/B).
-  bool recompute = dp.calibrated != 0 || NIB == 1;
-  if (const char* e = std::getenv("RSBA_RECORDS")) recompute = recompute && e[0] != '1';
-  bool factored = recompute && dp.P == 2;
-  if (const char* e = std::getenv("RSBA_FACTORED")) factored = factored && e[0] != '0';
-  std::vector<uint8_t> tile_factored((size_t)nt, 0);
-  for (int t = 0; t < nt && factored; ++t) tile_factored[t] = !((int64_t)(t + 1) * FT > FR && (int64_t)t * FT < F && F > FR);   // (no pseudo frame in [t FT, (t + 1) FT))
   std::vector<uint32_t>& g_off = scr.g_off;                 // element offset of every group in Pm
-  std::vector<int64_t>& pt_goff = scr.pt_goff; pt_goff.assign((size_t)M + 1, 0);   // doubles of the groups of the points before j
+  std::vector<int64_t>& pt_goff = scr.pt_goff;   // doubles of the groups of the points before j
   const int nthr_pts = M >= 4096 ? plan_threads : 1;
-  {
+  int64_t pt_total = 0;                          // doubles of all groups
+  if (!dev_plan) {
+    pt_goff.assign((size_t)M + 1, 0);
     // one walk over a point's slots: on_group(g, tile) for every new (tile, layer) group g = 0, 1, .. of the point, on_slot(g, pos, slot)
     auto walk = [&](int j, std::vector<int64_t>& pslots, auto&& on_group, auto&& on_slot) -> int64_t {
       slots_of(j, pslots);
@@ -457,21 +477,24 @@ int32_t build_solver_impl(rsba_handle* h) {
       }
     });
     g_off[(size_t)NG] = (uint32_t)pt_goff[M];
+    pt_total = pt_goff[M];
+    sv.ngroups = (int64_t)g_tile.size();
   }
-  sv.ngroups = (int64_t)g_tile.size();
   // A plan that cannot be built on THIS rank must not leave the other ranks waiting in the vote further down (one all-reduce in the
   // middle of the plan): a rank-local failure is carried into that vote and every rank fails together; a single rank returns here.
   const bool plan_votes = h->allreduce && h->world > 1 && !h->union_mask.empty();
   int32_t local_fail = RSBA_OK; const char* local_why = "";
   if (std::getenv("RSBA_TEST_FAIL_PLAN")) { local_fail = RSBA_ERR_UNSUPPORTED; local_why = "RSBA_TEST_FAIL_PLAN: the plan was made to fail (test hook)"; }   // after the uploader has started
-  else if (pt_goff[M] + kGroupFull >= ((int64_t)1 << 32)) { local_fail = RSBA_ERR_UNSUPPORTED; local_why = "more than 2^32 doubles of P records: the Schur kernel indexes them with 32 bits"; }
+  else if (pt_total + kGroupFull >= ((int64_t)1 << 32)) { local_fail = RSBA_ERR_UNSUPPORTED; local_why = "more than 2^32 doubles of P records: the Schur kernel indexes them with 32 bits"; }
   if (local_fail && !plan_votes) return rsba_set_error(local_fail, local_why);
-  up.upload_const_ref(&sv.slot_gpos, slot_gpos);
+  if (!dev_plan) up.upload_const_ref(&sv.slot_gpos, slot_gpos);
   const bool dense_keys = (int64_t)nt * nt <= (int64_t)1 << 26;
   std::vector<int64_t> dense_cnt; std::unordered_map<int64_t, int64_t> sparse_cnt;
-  if (dense_keys) dense_cnt.assign((size_t)nt * nt, -1);
+  if (dense_keys && !dev_plan) dense_cnt.assign((size_t)nt * nt, -1);
+  std::vector<uint32_t> struct_keys;   // (device plan: the keys of the pairs that exist whatever the points say)
   auto bump = [&](int I, int J, int64_t by) {
     const int64_t key = (int64_t)I * nt + J;
+    if (dev_plan) { struct_keys.push_back((uint32_t)key); return; }
     if (dense_keys) { int64_t& c = dense_cnt[key]; c = (c < 0 ? 0 : c) + by; }
     else sparse_cnt[key] += by;
   };
@@ -512,6 +535,37 @@ int32_t build_solver_impl(rsba_handle* h) {
   const int nthreads = (small_keys || listed_keys) && M >= 4096 ? plan_threads : 1;   // (small_keys: per-thread counters of 4 nt^2 bytes)
   std::vector<std::vector<int32_t>>& thread_cnt = scr.thread_cnt; thread_cnt.resize(nthreads > 1 ? nthreads : 0);
   auto point_range = [&](int t) { return std::pair<int, int>((int)((int64_t)M * t / nthreads), (int)((int64_t)M * (t + 1) / nthreads)); };
+  std::vector<int32_t> tp_I, tp_J; std::vector<int64_t> tp_ptr(1, 0);
+  int64_t nent = 0;
+  std::vector<int32_t>& ent_pt = scr.ent_pt;   // (host passes only; the device plan hands the chunk numbering the entry list's segments instead)
+  if (dev_plan) ent_pt.clear();
+  std::vector<int64_t> products_part(1, 0);   // (plan statistics: block products that are not structurally zero)
+  if (dev_plan) {
+    // ---- the device form of the passes above and below (plan_device.hip) ----
+    uint8_t* d_tf = nullptr;
+    if (factored) { if (int32_t rc_ = s_upload(s, &d_tf, tile_factored)) return rc_; }
+    bool any_const_point = false;
+    for (int j = 0; j < M && !any_const_point; ++j) any_const_point = h->mask_point[(size_t)j * 3] == 0.0;
+    int64_t chunk_block = nt > 500 ? 2048 : 0;   // (the chunk numbering by blocks of points, below: it gets the entry list's segments instead of the list)
+    if (const char* e = std::getenv("RSBA_SCHUR_BLOCK")) chunk_block = std::atoi(e) > 0 ? std::max(16, std::atoi(e)) : 0;
+    if (chunk_block >= M) chunk_block = 0;
+    DevicePlanIn din{dp.obs_frame, dp.obs_point, N, M, FR, NPF, NIB, FT, CD, nt, d_tf, struct_keys.data(), (int64_t)struct_keys.size(), chunk_block, any_const_point, h->stream};
+    const hipError_t pe = device_plan_lists(din, &dpo);
+    s->allocs.insert(s->allocs.end(), dpo.owned.begin(), dpo.owned.end());
+    if (pe != hipSuccess) return rsba_set_error(pe == hipErrorOutOfMemory ? RSBA_ERR_OUT_OF_MEMORY : RSBA_ERR_HIP, (std::string("device plan: ") + hipGetErrorString(pe)).c_str());
+    point_ptr.swap(dpo.point_ptr_h);
+    sv.point_ptr = dpo.point_ptr; sv.slot_frame = dpo.slot_frame; sv.slot_point = dpo.slot_point; s->d_obs_slot = dpo.obs_slot; sv.slot_gpos = dpo.slot_gpos;
+    sv.ent_groups = dpo.ent_groups; sv.ent_pt = dpo.ent_pt; sv.ent_mask = dpo.ent_mask;
+    NVG = dpo.nvgroups; NS = N + NVG * NPF;
+    sv.ngroups = dpo.ngroups; pt_total = dpo.group_doubles;
+    tp_I.swap(dpo.tp_I); tp_J.swap(dpo.tp_J); tp_ptr.swap(dpo.tp_ptr);
+    nent = tp_ptr.back();
+    products_part[0] = dpo.products;
+    if (!local_fail && pt_total + kGroupFull >= ((int64_t)1 << 32)) {
+      local_fail = RSBA_ERR_UNSUPPORTED; local_why = "more than 2^32 doubles of P records: the Schur kernel indexes them with 32 bits";
+      if (!plan_votes) return rsba_set_error(local_fail, local_why);
+    }
+  } else {
   std::vector<int32_t> pair_no;   // listed_keys: key -> number of the pair in (I, J) order (what dense_index will hold further down)
   if (nthreads > 1 && listed_keys) {
     std::vector<uint8_t> seen((size_t)nt * nt, 0);
@@ -565,7 +619,6 @@ int32_t build_solver_impl(rsba_handle* h) {
     }
   } else
   for (int j = 0; j < M; ++j) for_each_entry(j, [&](int64_t gx, int64_t gy) { bump(g_tile[gx], g_tile[gy], 1); });
-  std::vector<int32_t> tp_I, tp_J; std::vector<int64_t> tp_ptr(1, 0);
   std::unordered_map<int64_t, int32_t> tp_index; std::vector<int32_t> dense_index;
   if (dense_keys) {
     dense_index.assign((size_t)nt * nt, -1);
@@ -581,13 +634,13 @@ int32_t build_solver_impl(rsba_handle* h) {
     for (int64_t key : keys) { tp_index[key] = (int32_t)tp_I.size(); tp_I.push_back((int32_t)(key / nt)); tp_J.push_back((int32_t)(key % nt)); tp_ptr.push_back(tp_ptr.back() + sparse_cnt[key]); }
   }
   auto index_of = [&](int I, int J) -> int32_t { return dense_keys ? dense_index[(size_t)I * nt + J] : tp_index[(int64_t)I * nt + J]; };
-  const int64_t nent = tp_ptr.back();
+  nent = tp_ptr.back();
   // an entry is the pair of groups (of tile I, of tile J) plus its point: the kernel looks the slots up in g_rows
   std::vector<uint32_t>& ent_groups = scr.ent_groups; ent_groups.resize((size_t)nent * 2);   // (where the two groups start in Pm | kind: solver_state.hpp)
-  std::vector<int32_t>& ent_pt = scr.ent_pt; ent_pt.resize((size_t)nent);
+  ent_pt.resize((size_t)nent);
   // ... and, per entry, which of the 3 x 3 block products of its two groups can be non-zero
   std::vector<uint16_t>& ent_mask = scr.ent_mask; ent_mask.resize((size_t)nent);
-  std::vector<int64_t> products_part((size_t)std::max(nthreads, 1), 0);   // (plan statistics: block products that are not structurally zero)
+  products_part.assign((size_t)std::max(nthreads, 1), 0);
   auto put_entry = [&](int64_t w, int64_t gx, int64_t gy, int j, int64_t& prod) {
     ent_groups[2 * (size_t)w] = g_off[(size_t)gx] | (tile_factored[g_tile[(size_t)gx]] ? 1u : 0u);
     ent_groups[2 * (size_t)w + 1] = g_off[(size_t)gy] | (tile_factored[g_tile[(size_t)gy]] ? 1u : 0u);
@@ -626,11 +679,13 @@ int32_t build_solver_impl(rsba_handle* h) {
     }
   }
   std::vector<int32_t>().swap(dense_index);
-  const int ntp = (int)tp_I.size();
-  s->num_pairs = nent;
   up.upload_const_ref(&sv.ent_groups, ent_groups);
   up.upload_const_ref(&sv.ent_pt, ent_pt);
   up.upload_const_ref(&sv.ent_mask, ent_mask);
+  }   // (!dev_plan)
+  sv.nvgroups = NVG;
+  const int ntp = (int)tp_I.size();
+  s->num_pairs = nent;
 
   // ---- tile graph of S, fill-reducing / parallelism-exposing ordering, symbolic factorisation ----
   std::vector<std::vector<int32_t>> adj(nt);
@@ -907,13 +962,31 @@ int32_t build_solver_impl(rsba_handle* h) {
   auto number_chunks = [&](int64_t kBlock) {
     chunk_tp.clear(); chunk_n.clear(); chunk_e0.clear();
     for (auto& pc : pair_chunks) pc.clear();
+    if (dev_plan && kBlock < M) {
+      // the device plan's segments — maximal runs of one tile pair's entries inside one block of points, in entry order — in the order of
+      // the walk below: block by block, inside a block the pairs in (I, J) order, every segment cut into chunks
+      const size_t nseg = dpo.seg_pair.size();
+      std::vector<int32_t> order(nseg);
+      for (size_t q = 0; q < nseg; ++q) order[q] = (int32_t)q;
+      std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return dpo.seg_block[a] != dpo.seg_block[b] ? dpo.seg_block[a] < dpo.seg_block[b] : dpo.seg_pair[a] < dpo.seg_pair[b]; });
+      for (int32_t q : order) {
+        const int tp_ = dpo.seg_pair[q];
+        const int64_t q0 = dpo.seg_start[q], q1 = ((size_t)q + 1 < nseg && dpo.seg_pair[q + 1] == tp_) ? dpo.seg_start[q + 1] : tp_ptr[tp_ + 1];
+        for (int64_t a = q0; a < q1; a += kSchurChunk) {
+          pair_chunks[tp_].push_back((int32_t)chunk_tp.size());
+          chunk_tp.push_back(tp_); chunk_e0.push_back(a); chunk_n.push_back((int32_t)std::min<int64_t>(kSchurChunk, q1 - a));
+        }
+      }
+      return;
+    }
     // per tile pair the cursor into its entry list (entries are in point order); pairs that still have entries, in (I, J) order
     std::vector<int64_t> cursor(tp_ptr.begin(), tp_ptr.end() - 1);
     std::vector<int32_t> live; live.reserve(64);
     int next_pair = 0;           // pairs enter `live` when the block reaches their first point
     std::vector<int32_t> by_first(ntp);
     for (int t = 0; t < ntp; ++t) by_first[t] = t;
-    auto first_point = [&](int t) { return tp_ptr[t] < tp_ptr[t + 1] ? (ent_pt[tp_ptr[t]] & 0x7fffffff) : std::numeric_limits<int32_t>::max(); };
+    // (the device plan brings the entries' points to the host only for a numbering by point blocks: without them every pair is live from the first — and only — block)
+    auto first_point = [&](int t) { return tp_ptr[t] < tp_ptr[t + 1] ? (ent_pt.empty() ? 0 : (ent_pt[tp_ptr[t]] & 0x7fffffff)) : std::numeric_limits<int32_t>::max(); };
     std::stable_sort(by_first.begin(), by_first.end(), [&](int a, int b) { return first_point(a) < first_point(b); });
     for (int64_t p0 = 0; p0 < M; p0 += kBlock) {
       const int64_t p1 = std::min<int64_t>(p0 + kBlock, M);
@@ -924,7 +997,8 @@ int32_t build_solver_impl(rsba_handle* h) {
         const int tp_ = live[x];
         int64_t q = cursor[tp_];
         const int64_t qend = tp_ptr[tp_ + 1];
-        if (p1 >= M) q = qend; else while (q < qend && (ent_pt[q] & 0x7fffffff) < p1) ++q;
+        if (p1 >= M) q = qend;
+        else q = std::lower_bound(ent_pt.begin() + q, ent_pt.begin() + qend, (int32_t)p1, [](int32_t e, int32_t p) { return (e & 0x7fffffff) < p; }) - ent_pt.begin();   // (a pair's entries are in point order)
         for (int64_t q0 = cursor[tp_]; q0 < q; q0 += kSchurChunk) {
           pair_chunks[tp_].push_back((int32_t)chunk_tp.size());
           chunk_tp.push_back(tp_); chunk_e0.push_back(q0); chunk_n.push_back((int32_t)std::min<int64_t>(kSchurChunk, q - q0));
@@ -1060,7 +1134,7 @@ int32_t build_solver_impl(rsba_handle* h) {
   up.upload_const_ref(&sv.inprog_point, inprog_point);
   up.upload_const(&sv.inprog_intr, inprog_intr);
   std::vector<int32_t> ifp((size_t)NIB + 1, 0), ifl;       // (alive until the uploads have finished)
-  std::vector<int64_t> point_vgroup(NIB == 1 ? (size_t)M : 0, -1);
+  std::vector<int64_t> point_vgroup((NIB == 1 && !dev_plan) ? (size_t)M : 0, -1);
   {
     for (int f = 0; f < FR && NIB > 0; ++f) ifp[intr_of(f) + 1]++;
     for (int c = 0; c < NIB; ++c) ifp[c + 1] += ifp[c];
@@ -1068,10 +1142,13 @@ int32_t build_solver_impl(rsba_handle* h) {
     { std::vector<int32_t> fill(ifp.begin(), ifp.end() - 1); for (int f = 0; f < FR && NIB > 0; ++f) ifl[fill[intr_of(f)]++] = f; }
     up.upload_const(&sv.intr_frame_ptr, ifp);
     up.upload_const(&sv.intr_frame_list, ifl);
-    up.upload_const_ref(&sv.vgroup_point, vgroup_point);
-    up.upload_const_ref(&sv.vgroup_intr, vgroup_intr);
-    for (int j = 0; j < M && NIB == 1; ++j) if (vgroup_ptr[j + 1] > vgroup_ptr[j]) point_vgroup[j] = vgroup_ptr[j];
-    up.upload_const(&sv.point_vgroup, point_vgroup);
+    if (dev_plan) { sv.vgroup_point = dpo.vgroup_point; sv.vgroup_intr = dpo.vgroup_intr; sv.point_vgroup = dpo.point_vgroup; }
+    else {
+      up.upload_const_ref(&sv.vgroup_point, vgroup_point);
+      up.upload_const_ref(&sv.vgroup_intr, vgroup_intr);
+      for (int j = 0; j < M && NIB == 1; ++j) if (vgroup_ptr[j + 1] > vgroup_ptr[j]) point_vgroup[j] = vgroup_ptr[j];
+      up.upload_const(&sv.point_vgroup, point_vgroup);
+    }
   }
   up.upload_const(&sv.chunk_tp, chunk_tp);
   up.upload_const(&sv.chunk_e0, chunk_e0);
@@ -1235,8 +1312,8 @@ int32_t build_solver_impl(rsba_handle* h) {
   if ((rc = s_alloc(s, &sv.diag_p, (size_t)M * 3))) return rc;
   if ((rc = s_alloc(s, &sv.Linv, (size_t)M * 6))) return rc;
   if ((rc = s_alloc(s, &sv.z, (size_t)M * 3))) return rc;
-  const size_t pm_doubles = (size_t)pt_goff[M] + kGroupFull;   // (+ the all-zero group)
-  sv.zero_off = (uint32_t)pt_goff[M];
+  const size_t pm_doubles = (size_t)pt_total + kGroupFull;   // (+ the all-zero group)
+  sv.zero_off = (uint32_t)pt_total;
   sv.lerp_rot = dp.interp_rotation && dp.shutter != 0;
   if ((rc = s_alloc(s, &sv.Pm, pm_doubles))) return rc;
   HIP_TRY(hipMemsetAsync(sv.Pm, 0, pm_doubles * sizeof(double), h->stream));   // rows of frames that do not see the point stay zero for good: nothing ever writes them
@@ -1366,9 +1443,9 @@ int32_t build_solver_impl(rsba_handle* h) {
                         2 * T3 / 3 * (int64_t)(s->diag_info.size() / 4) + 4 * (int64_t)kTile * kTile * ((int64_t)sv.nslots + nt);
     ps.exchange_doubles = (int64_t)s->exch_tiles * kTile * kTile + sv.npad;   // exchange (2) of a sharded solve: the plan's tile pairs | rhs (the fill-in tiles of the factor's layout stay home)
     ps.schur_groups = sv.ngroups;
-    ps.schur_group_bytes = pt_goff[M] * (int64_t)sizeof(double);
-    ps.schur_factored_groups = 0;
-    for (int64_t g = 0; g < sv.ngroups; ++g) ps.schur_factored_groups += tile_factored[g_tile[(size_t)g]];
+    ps.schur_group_bytes = pt_total * (int64_t)sizeof(double);
+    ps.schur_factored_groups = dev_plan ? dpo.factored_groups : 0;
+    for (int64_t g = 0; g < sv.ngroups && !dev_plan; ++g) ps.schur_factored_groups += tile_factored[g_tile[(size_t)g]];
     ps.sharded_factorisation = sharded ? 1 : 0;
     if (sharded) {   // ... or, when every rank factors its own part: the separators' tiles | their rows of the rhs, and the gather of the step
       ps.exchange_doubles = (int64_t)s->ntop_slots * kTile * kTile + (int64_t)s->ntop_tiles * kTile + sv.npad;

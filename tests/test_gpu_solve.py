@@ -588,3 +588,45 @@ def test_parameter_arrays_assigned_after_create_are_copied_into_the_bound_ones(c
         with pytest.raises(ValueError):
             dp.upload_parameters()
         p.poses = bound
+
+
+@pytest.mark.parametrize("case", ["c2", "layers", "intrinsics", "constant_points", "global_shutter", "priors", "blocked_chunks", "blocked_chunks_intrinsics"])
+def test_the_symbolic_phase_on_the_device_builds_the_same_plan(capi, monkeypatch, case):
+    """The passes of the symbolic phase over observations, points and (point, tile pair) entries run on the device (plan_device.hip:
+    stable radix sorts and prefix sums); RSBA_PLAN_DEVICE=0 keeps them on host threads.  Same lists in the same order: the same plan
+    figures and a solve whose every bit is the same — with a point seen twice in one frame (a second layer of groups), with the shared
+    intrinsics block's virtual slots, with constant points (the reduced program's block count), with one pose per frame."""
+    from rsba_amd.scene import make_config
+    def problem():
+        if case == "c2":
+            return make_config("C2").problem
+        p = small_scene(frames=40, points=2500, seed=31, rolling=case != "global_shutter")
+        if case == "layers":      # some observations twice (another detection of the same point in the same frame): cross-layer entries
+            dup = np.arange(0, p.num_observations, 17)
+            order = np.argsort(np.concatenate([p.obs_frame, p.obs_frame[dup]]), kind="stable")
+            p.obs_xy = np.concatenate([p.obs_xy, p.obs_xy[dup] + 0.25])[order]
+            p.obs_point = np.concatenate([p.obs_point, p.obs_point[dup]])[order]
+            p.obs_frame = np.concatenate([p.obs_frame, p.obs_frame[dup]])[order]
+        if case in ("intrinsics", "blocked_chunks_intrinsics"):
+            p.calibrated = False; p.huber_a = 2.0
+        if case.startswith("blocked_chunks"):   # the chunk numbering of large problems (blocks of points; here: of 64): the device plan hands it the entry list's segments
+            monkeypatch.setenv("RSBA_SCHUR_BLOCK", "64")
+        if case == "constant_points":
+            p.point_constant = np.zeros(p.num_points, dtype=np.uint8); p.point_constant[::7] = 1
+        if case == "priors":
+            p.prior_kind, p.prior_scale, p.inter_frame_ratio, p.ratio_free = 1, 10.0, 1.0, True
+            p.prior_frames = np.arange(1, p.num_frames, dtype=np.int32)
+        return p
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("RSBA_PLAN_DEVICE", mode)
+        p = problem()
+        with capi.DeviceProblem(p) as dp:
+            s, tr = dp.solve(capi.default_options(max_num_iterations=5))
+            st = dp.plan_stats()
+        keys = ("tiles", "factor_tiles", "levels", "tasks", "schur_entries", "schur_chunks", "schur_block_products", "schur_groups", "schur_group_bytes", "schur_factored_groups", "schur_mfma_issued")
+        out[mode] = (s.final_cost, s.num_residual_blocks_reduced, [t.cost for t in tr], p.poses.copy(), p.points.copy(), p.intrinsics.copy(), {k: st[k] for k in keys})
+    a, b = out["0"], out["1"]
+    assert a[6] == b[6], (a[6], b[6])
+    assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2]
+    assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5])
