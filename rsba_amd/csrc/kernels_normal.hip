@@ -1706,8 +1706,8 @@ hipError_t launch_lm_linearize_gradient(const DeviceProblem& dp, const SolverDev
   LAUNCH(lm_linearize_gradient_kernel, nblocks256(sv.n + 3 * (int64_t)dp.M), 256, st, dp, sv, cost2);
   return hipSuccess;
 }
-hipError_t launch_lm_verdict_gradient(const DeviceProblem& dp, const SolverDev& sv, double* ctl, const LmRules& rules, rsba_iteration* trace, int trace_cap, double* snapshot, double seq, hipStream_t st, bool gradmax_done) {
-  LAUNCH(lm_verdict_gradient_kernel, 1, 256, st, sv, gradmax_done ? -1 : nblocks256(sv.n + 3 * (int64_t)dp.M), ctl, rules, trace, trace_cap, snapshot, seq);
+hipError_t launch_lm_verdict_gradient(const DeviceProblem& dp, const SolverDev& sv, double* ctl, const LmRules& rules, rsba_iteration* trace, int trace_cap, double* snapshot, double seq, hipStream_t st, bool gradmax_done, int extra_partials) {
+  LAUNCH(lm_verdict_gradient_kernel, 1, 256, st, sv, gradmax_done ? -1 : nblocks256(sv.n + 3 * (int64_t)dp.M) + extra_partials, ctl, rules, trace, trace_cap, snapshot, seq);
   return hipSuccess;
 }
 hipError_t launch_lm_decide_step(const SolverDev& sv, double* ctl, const LmRules& rules, rsba_iteration* trace, int trace_cap, hipStream_t st) {

@@ -55,6 +55,7 @@ __device__ __forceinline__ Spherical spherical_at(const double* pose) {
 // cost of the blocks at (poses, prior values): cost2[0] += 1/2 sum |r|^2 (cost2[1] for a SphericalPrior on a constant pose),
 // fail_count += blocks whose functor returns false
 __global__ __launch_bounds__(kPPThreads) void pose_prior_cost_kernel(const DeviceProblem dp, double* cost2) {
+  if (lm_stopped(dp.ctl)) return;   // (device-side trust region: iterations enqueued behind a termination fall through)
   __shared__ double s_red[4];
   double c = 0.0, bad = 0.0;
   for (int k = threadIdx.x; k < dp.pp_count; k += kPPThreads) {
@@ -80,6 +81,7 @@ __global__ __launch_bounds__(kPPThreads) void pose_prior_cost_kernel(const Devic
 // linearisation: U_f, g_f += the blocks' J^T J / J^T r over the pose coordinates (lead rank only); per priorPoses coordinate v0, g0, c (every rank)
 __global__ __launch_bounds__(kPPThreads) void pose_prior_blocks_kernel(const DeviceProblem dp, const SolverDev sv, double* __restrict__ v0, double* __restrict__ g0,
                                                                         double* __restrict__ cross) {
+  if (lm_not_accepted(sv.ctl)) return;   // (device-side trust region: a rejected candidate is not linearised)
   const int CD = sv.CD;
   for (int k = threadIdx.x; k < dp.pp_count; k += kPPThreads) {
     const int b = dp.pp_block[k], f = b / dp.P, q = b % dp.P;
@@ -122,18 +124,26 @@ __global__ void pose_prior_clamp_kernel(int n, const double* v0, double* diag, d
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t < n) diag[t] = fmin(fmax(v0[t], lo), hi);
 }
-// max |g_i| of the UNSCALED gradient over the priorPoses coordinates, folded into scalars[kGradMax]
-__global__ __launch_bounds__(kPPThreads) void pose_prior_gradmax_kernel(const DeviceProblem dp, const SolverDev sv, const double* g0) {
+// max |g_i| of the UNSCALED gradient over the priorPoses coordinates, folded into scalars[kGradMax] — or (out != null: the loop that runs
+// without the host) left as one more partial maximum for the kernel that reduces them and decides
+__global__ __launch_bounds__(kPPThreads) void pose_prior_gradmax_kernel(const DeviceProblem dp, const SolverDev sv, const double* g0, double* out) {
   __shared__ double s_red[4];
   double m = 0.0;
   for (int t = threadIdx.x; t < 6 * dp.pp_count; t += kPPThreads) { const double s0 = dp.pp_scale[t]; if (s0 > 0.0) m = fmax(m, fabs(g0[t] / s0)); }
   m = block_max(m, s_red);
-  if (threadIdx.x == 0) sv.scalars[kGradMax] = fmax(sv.scalars[kGradMax], m);
+  if (threadIdx.x == 0) { if (out) *out = m; else sv.scalars[kGradMax] = fmax(sv.scalars[kGradMax], m); }
+}
+// x = x + delta for the priorPoses values, where the device-side loop has accepted the candidate (the host form swaps the two buffers)
+__global__ void pose_prior_take_kernel(const DeviceProblem dp, const SolverDev sv) {
+  if (lm_not_accepted(sv.ctl)) return;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t < 6 * dp.pp_count) dp.pp_value[t] = dp.pp_trial[t];
 }
 
 // elimination of the priorPoses blocks from the reduced camera system (after the Schur merge)
 __global__ void pose_prior_reduce_kernel(const DeviceProblem dp, const SolverDev sv, const double* v0, const double* g0, const double* cross,
                                          const double* diag, double inv_radius, const int32_t* tile_diag_slot) {
+  if (sv.ctl) { if (lm_stopped(sv.ctl)) return; inv_radius = 1.0 / sv.ctl[kCtlRadius]; }   // (device-side trust region: the radius lives in HBM)
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= 6 * dp.pp_count) return;
   const int k = t / 6, i = t % 6;
@@ -149,6 +159,7 @@ __global__ void pose_prior_reduce_kernel(const DeviceProblem dp, const SolverDev
 // |step|^2 and |x|^2 (added to the scalars the point / camera kernels have already written)
 __global__ __launch_bounds__(kPPThreads) void pose_prior_step_kernel(const DeviceProblem dp, const SolverDev sv, const double* v0, const double* g0,
                                                                       const double* cross, const double* diag, double inv_radius) {
+  if (sv.ctl) { if (lm_stopped(sv.ctl)) return; inv_radius = 1.0 / sv.ctl[kCtlRadius]; }
   __shared__ double s_red[4];
   double acc = 0.0, st = 0.0, xx = 0.0;
   for (int k = threadIdx.x; k < dp.pp_count; k += kPPThreads) {
@@ -217,9 +228,14 @@ hipError_t launch_pose_prior_clamp(const DeviceProblem& dp, const PosePriorDev& 
   PP_LAUNCH(pose_prior_clamp_kernel, pp_grid(dp), 256, st, 6 * dp.pp_count, pp.v0, pp.diag, lo, hi);
   return hipSuccess;
 }
-hipError_t launch_pose_prior_gradmax(const DeviceProblem& dp, const SolverDev& sv, const PosePriorDev& pp, hipStream_t st) {
+hipError_t launch_pose_prior_gradmax(const DeviceProblem& dp, const SolverDev& sv, const PosePriorDev& pp, hipStream_t st, double* out) {
   if (dp.pp_count <= 0) return hipSuccess;
-  PP_LAUNCH(pose_prior_gradmax_kernel, 1, kPPThreads, st, dp, sv, pp.g0);
+  PP_LAUNCH(pose_prior_gradmax_kernel, 1, kPPThreads, st, dp, sv, pp.g0, out);
+  return hipSuccess;
+}
+hipError_t launch_pose_prior_take(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {
+  if (dp.pp_count <= 0) return hipSuccess;
+  PP_LAUNCH(pose_prior_take_kernel, pp_grid(dp), 256, st, dp, sv);
   return hipSuccess;
 }
 hipError_t launch_pose_prior_reduce(const DeviceProblem& dp, const SolverDev& sv, const PosePriorDev& pp, double radius, hipStream_t st) {

@@ -2150,7 +2150,7 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
   // Single-GPU problems that keep no records (calibrated, or ONE shared intrinsics block), with or without motion priors of a known
   // interFrameRatio — on one rank or several (every rank takes the same form: settled with the problem-size exchange); everything else (a free
   // ratio, per-pose priors, per-frame intrinsics blocks) — and a suspect factorisation — goes through the host form.
-  bool device_ctl = speculate && dp.pp_count == 0 && dp.pp_spherical < 0 && !s->use_levels &&
+  bool device_ctl = speculate && (dp.pp_count == 0 || !h->allreduce) && dp.pp_spherical < 0 && !s->use_levels &&   // (GoodPosePrior blocks: on one rank; the SphericalPrior — 1e20 on the residual — stays with the host)
                     !any_rank_needs_host && opt->max_num_iterations > 0;
   if (const char* e = std::getenv("RSBA_DEVICE_LM")) device_ctl = device_ctl && e[0] != '0';   // A/B switch: 0 = the host decides
   if (device_ctl) {
@@ -2213,26 +2213,30 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
       // (thirteen launches on this stream; the steps the host form spreads over twenty-two, in its order: kernels_normal.hip, "the same steps in
       // fewer launches".  The diagonal's clamp rides in the point factor's launch — after a rejected step it recomputes what is there.)
       if (free_ratio) HIP_TRY(launch_ratio_prepare_ctl(s->ratio4, s->d_ctl, opt->min_lm_diagonal, opt->max_lm_diagonal, st));   // the ratio's damped pivot and gradient for the ETA task of the factorisation
+      if (dp.pp_count > 0) HIP_TRY(launch_pose_prior_clamp(dp, s->pp, opt->min_lm_diagonal, opt->max_lm_diagonal, st));   // (the priorPoses coordinates' LM diagonal: recomputed from what the last accepted linearisation left — the same numbers after a rejected step)
       if ((rc = factor_and_solve(h, 1.0))) return rc;   // (the radius argument is ignored: the kernels read ctl)
       if (free_ratio) HIP_TRY(launch_ratio_candidate(s->ratio4, s->d_ctl, st));
       HIP_TRY(launch_candidate_and_model_cost(dp, sv, st));
       if (s->ucross && (sv.lead || h->prior_split)) HIP_TRY(launch_prior_model(dp, sv, sv.scalars + kModelCostChange, 0.0, st, free_ratio ? s->ratio4 + kRtC : nullptr));   // motion priors: their share of the model cost change (a free ratio's step included) ...
+      if (dp.pp_count > 0) HIP_TRY(launch_pose_prior_step(dp, sv, s->pp, 1.0, st));   // per-pose priors: the candidate priorPoses values, their share of the three sums
       swap_params();
       HIP_TRY(launch_eval(dp, kLmJacobian, st));
-      if (s->ucross) {                                                                                 // ... their cost at the candidate, behind the observations' ...
+      const bool extra_cost = s->ucross != nullptr || dp.pp_count > 0;   // prior blocks add their cost behind the observations': the cost is reduced by a launch of its own then
+      if (extra_cost) {                                                                                // ... their cost at the candidate, behind the observations' ...
         HIP_TRY(launch_cost_reduce(dp, h->d_cost2, st));
-        if (sv.lead || h->prior_split) {
+        if (s->ucross && (sv.lead || h->prior_split)) {
           DeviceProblem dq = dp;
           if (free_ratio) dq.prior_ratio_ptr = s->ratio4 + kRtRatioEval;   // (... at the candidate's ratio)
           HIP_TRY(launch_prior_cost(dq, h->d_cost2, h->prior_invalid, st));
         }
+        if (dp.pp_count > 0) HIP_TRY(launch_pose_prior_cost(dp, h->d_cost2, st));
       }
       swap_params();
       if ((rc = await_verification(h))) return rc;
       const bool my_priors = s->ucross && (sv.lead || h->prior_split);
-      if (!multi) HIP_TRY(launch_lm_verdict_step(dp, sv, h->d_cost2, s->d_ctl, R, s->d_trace_it, cap, st, /*cost_reduced=*/s->ucross != nullptr));
+      if (!multi) HIP_TRY(launch_lm_verdict_step(dp, sv, h->d_cost2, s->d_ctl, R, s->d_trace_it, cap, st, /*cost_reduced=*/extra_cost));
       else {   // several ranks: the scalars of the step are summed over the ranks between the reduction and the decision — exchange (3), enqueued like a kernel
-        if (!s->ucross) HIP_TRY(launch_cost_reduce(dp, h->d_cost2, st));
+        if (!extra_cost) HIP_TRY(launch_cost_reduce(dp, h->d_cost2, st));
         HIP_TRY(launch_pack_trial(dp, sv, h->d_cost2, st));
         if ((rc = exchange(h, sv.scalars, 12, 0, RSBA_EXCHANGE_SCALARS))) return rc;
         HIP_TRY(launch_lm_decide_step(sv, s->d_ctl, R, s->d_trace_it, cap, st));
@@ -2242,13 +2246,16 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
       if (!fused) HIP_TRY(launch_camera_blocks(dp, sv, st, /*take_candidate=*/true, /*padding_is_zero=*/true));   // (the initial linearisation zeroed the pseudo frames' padding)
       if (my_priors) HIP_TRY(launch_prior_blocks(dp, sv, s->ucross, st));                             // ... and their blocks of an accepted step's linearisation
       if (free_ratio) HIP_TRY(launch_prior_border(all_priors(h), sv, s->border, s->ratio4, st));      // (the ratio's column at the accepted point: every rank, from replicated poses)
+      if (dp.pp_count > 0) { HIP_TRY(launch_pose_prior_take(dp, sv, st)); HIP_TRY(launch_pose_prior_blocks(dp, sv, s->pp, st)); }   // per-pose priors: the accepted values, their blocks
       HIP_TRY(launch_intr_blocks(dp, sv, st));
       if (!fused) HIP_TRY(launch_point_blocks(dp, sv, st));
       s->ctl_seq += 1.0;
       double* const slot = s->h_ctl_dev + (size_t)(enqueued % Solver::kCtlRing) * kCtlSize;
       if (!multi) {
         HIP_TRY(launch_lm_linearize_gradient(dp, sv, h->d_cost2, st));
-        HIP_TRY(launch_lm_verdict_gradient(dp, sv, s->d_ctl, R, s->d_trace_it, cap, slot, s->ctl_seq, st));
+        const int ngm = (int)((sv.n + 3 * (int64_t)dp.M + 255) / 256);
+        if (dp.pp_count > 0) HIP_TRY(launch_pose_prior_gradmax(dp, sv, s->pp, st, sv.partial + ngm));   // (one more partial maximum for the verdict)
+        HIP_TRY(launch_lm_verdict_gradient(dp, sv, s->d_ctl, R, s->d_trace_it, cap, slot, s->ctl_seq, st, false, dp.pp_count > 0 ? 1 : 0));
       } else {   // exchange (1): the camera gradient, diag(U), the cost — and every rank's gradient maximum over its points — whether or not the candidate
                  // was accepted (the host does not know): the unpacking skips itself after a rejected one, the maximum comes out as it was
         const bool ride = h->world <= kMaxRankSlots;

@@ -185,7 +185,8 @@ struct PosePriorDev {
 hipError_t launch_pose_prior_blocks(const DeviceProblem& dp, const SolverDev& sv, const PosePriorDev& pp, hipStream_t st);
 hipError_t launch_pose_prior_scale(const DeviceProblem& dp, const PosePriorDev& pp, hipStream_t st);
 hipError_t launch_pose_prior_clamp(const DeviceProblem& dp, const PosePriorDev& pp, double lo, double hi, hipStream_t st);
-hipError_t launch_pose_prior_gradmax(const DeviceProblem& dp, const SolverDev& sv, const PosePriorDev& pp, hipStream_t st);
+hipError_t launch_pose_prior_gradmax(const DeviceProblem& dp, const SolverDev& sv, const PosePriorDev& pp, hipStream_t st, double* out = nullptr);   // out: one more partial maximum instead of folding into scalars[kGradMax]
+hipError_t launch_pose_prior_take(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);   // device-side trust region: the accepted candidate's priorPoses values
 hipError_t launch_pose_prior_reduce(const DeviceProblem& dp, const SolverDev& sv, const PosePriorDev& pp, double radius, hipStream_t st);
 hipError_t launch_pose_prior_step(const DeviceProblem& dp, const SolverDev& sv, const PosePriorDev& pp, double radius, hipStream_t st);
 
@@ -231,7 +232,7 @@ hipError_t launch_lm_take_candidate(const DeviceProblem& dp, const SolverDev& sv
 hipError_t launch_candidate_and_model_cost(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);   // launch_model_cost_change + launch_candidate: the three sums by one launch
 hipError_t launch_lm_verdict_step(const DeviceProblem& dp, const SolverDev& sv, double* cost2, double* ctl, const LmRules& rules, rsba_iteration* trace, int trace_cap, hipStream_t st, bool cost_reduced = false);   // launch_cost_reduce (unless cost_reduced: done, the priors' cost added) + launch_pack_trial + launch_lm_decide_step
 hipError_t launch_lm_linearize_gradient(const DeviceProblem& dp, const SolverDev& sv, const double* cost2, hipStream_t st);   // launch_local_linearize + the per-workgroup maxima of launch_gradient_max
-hipError_t launch_lm_verdict_gradient(const DeviceProblem& dp, const SolverDev& sv, double* ctl, const LmRules& rules, rsba_iteration* trace, int trace_cap, double* snapshot, double seq, hipStream_t st, bool gradmax_done = false);   // the maxima reduced (unless gradmax_done: scalars[kGradMax] is there) + launch_lm_decide_gradient; ctl copied to `snapshot` (device-visible host memory), stamped `seq` last
+hipError_t launch_lm_verdict_gradient(const DeviceProblem& dp, const SolverDev& sv, double* ctl, const LmRules& rules, rsba_iteration* trace, int trace_cap, double* snapshot, double seq, hipStream_t st, bool gradmax_done = false, int extra_partials = 0);   // extra_partials: maxima behind the coordinates' own in sv.partial (the per-pose priors')   // the maxima reduced (unless gradmax_done: scalars[kGradMax] is there) + launch_lm_decide_gradient; ctl copied to `snapshot` (device-visible host memory), stamped `seq` last
 // motion priors (kernels_prior.hip): U_f, g_f += their J^T J / J^T r, ucross[f] = the (f, f-1) block; model cost change
 hipError_t launch_prior_blocks(const DeviceProblem& dp, const SolverDev& sv, double* ucross, hipStream_t st);
 hipError_t launch_prior_model(const DeviceProblem& dp, const SolverDev& sv, double* model_cost_change, double ratio_step, hipStream_t st, const double* ratio_step_ptr = nullptr);

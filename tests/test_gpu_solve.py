@@ -473,7 +473,7 @@ def test_device_blocks_are_cached_between_handles_and_given_back(capi):
 
 
 @pytest.mark.parametrize("case", ["c2", "rejections", "failure", "tolerances", "max_iterations", "huber", "priors", "priors_rejections", "c2_priors", "intrinsics", "intrinsics_rejections", "intrinsics_priors",
-                                  "free_ratio", "free_ratio_rejections", "free_ratio_acceleration", "c2_free_ratio"])
+                                  "free_ratio", "free_ratio_rejections", "free_ratio_acceleration", "c2_free_ratio", "pose_priors", "pose_priors_rejections", "pose_priors_free_ratio"])
 def test_device_side_trust_region_equals_the_host_form(capi, monkeypatch, case):
     """accept / reject, the radius update and the convergence tests of the LM loop run in a single-thread kernel, the
     iteration's kernels read the radius from HBM and skip themselves where the host form would not have launched them, the host
@@ -500,11 +500,16 @@ def test_device_side_trust_region_equals_the_host_form(capi, monkeypatch, case):
         if case.startswith("priors") or case == "intrinsics_priors":                # motion priors with a known interFrameRatio (CeresHandler.h:147-185): their cost, blocks and model change are part of every decision
             p.prior_kind, p.prior_scale, p.inter_frame_ratio = 1, 1.0 if case == "priors_rejections" else 10.0, 0.8
             p.prior_frames = np.arange(1, p.num_frames, dtype=np.int32)
-        if case.startswith("free_ratio"):   # the reference's default with motion priors (CeresHandler.h:161,172,175): the interFrameRatio is a free, lower-bounded block — one more
+        if case.startswith("pose_priors"):   # GoodPosePrior blocks (CeresHandler.h:188-204): a free priorPoses block per pose, eliminated in closed form beside the points
+            rng = np.random.default_rng(5)
+            p.pose_prior_block = np.arange(2, 2 * p.num_frames, dtype=np.int32)
+            p.pose_prior_values = p.poses.reshape(-1, 6)[p.pose_prior_block] + rng.normal(0, 0.01, (len(p.pose_prior_block), 6))
+            p.pose_prior_rotation, p.pose_prior_position = 3.0, 5.0
+        if case.startswith("free_ratio") or case == "pose_priors_free_ratio":   # the reference's default with motion priors (CeresHandler.h:161,172,175): the interFrameRatio is a free, lower-bounded block — one more
             p.prior_kind = 2 if case == "free_ratio_acceleration" else 1   # unknown of every decision (its step out of the factorisation's second right-hand side, its candidate, its projected gradient)
             p.prior_scale, p.inter_frame_ratio, p.ratio_free = 1.0 if case == "free_ratio_rejections" else 10.0, 1.0, True
             p.prior_frames = np.arange(1, p.num_frames, dtype=np.int32)
-        if case in ("rejections", "failure", "priors_rejections", "intrinsics_rejections", "free_ratio_rejections"):      # a start far from the minimum and a huge first radius: Gauss-Newton steps that overshoot (or never recover)
+        if case in ("rejections", "failure", "priors_rejections", "intrinsics_rejections", "free_ratio_rejections", "pose_priors_rejections"):      # a start far from the minimum and a huge first radius: Gauss-Newton steps that overshoot (or never recover)
             rng = np.random.default_rng(2)
             sc = 3.0 if case == "failure" else 2.0
             p.points += rng.normal(0, 0.6 * sc, p.points.shape); p.poses[1:, :, 3:] += rng.normal(0, 0.25 * sc, p.poses[1:, :, 3:].shape)
@@ -512,7 +517,7 @@ def test_device_side_trust_region_equals_the_host_form(capi, monkeypatch, case):
             return p, dict(max_num_iterations=30, initial_trust_region_radius=1e12)
         if case == "tolerances":
             return p, dict(max_num_iterations=50)
-        if case in ("priors", "intrinsics", "intrinsics_priors", "free_ratio", "free_ratio_acceleration"):
+        if case in ("priors", "intrinsics", "intrinsics_priors", "free_ratio", "free_ratio_acceleration", "pose_priors", "pose_priors_free_ratio"):
             return p, dict(max_num_iterations=15)
         return p, dict(max_num_iterations=3)
     out = {}
@@ -526,17 +531,21 @@ def test_device_side_trust_region_equals_the_host_form(capi, monkeypatch, case):
             s, tr = dp.solve(capi.default_options(**kw))
         rec = [(t.iteration, t.step_is_valid, t.step_is_successful, t.cost, t.cost_change, t.gradient_max_norm, t.step_norm, t.relative_decrease, t.trust_region_radius, t.model_cost_change) for t in tr]
         out[mode] = (rec, (s.termination_type, s.num_successful_steps, s.num_unsuccessful_steps, s.num_iterations, s.initial_cost, s.final_cost, s.is_solution_usable, float(p.inter_frame_ratio)),
-                     p.poses.copy(), p.points.copy(), p.intrinsics.copy())
+                     p.poses.copy(), p.points.copy(), p.intrinsics.copy(), None if p.pose_prior_values is None else p.pose_prior_values.copy())
     ref = out["host"]
     for mode in ("device", "device_ahead_1", "device_ahead_5"):
         got = out[mode]
         assert got[0] == ref[0], mode
         assert got[1] == ref[1], (mode, got[1], ref[1])
         assert np.array_equal(got[2], ref[2]) and np.array_equal(got[3], ref[3]) and np.array_equal(got[4], ref[4]), mode
-    if case in ("rejections", "priors_rejections", "intrinsics_rejections", "free_ratio_rejections"):
+        assert (got[5] is None and ref[5] is None) or np.array_equal(got[5], ref[5]), mode   # the solved priorPoses values
+    if case in ("rejections", "priors_rejections", "intrinsics_rejections", "free_ratio_rejections", "pose_priors_rejections"):
         assert ref[1][1] >= 5 and ref[1][2] >= 3          # the case does accept and reject steps
     if "free_ratio" in case:
         assert ref[1][7] != 1.0                            # the ratio was solved for
+    if case.startswith("pose_priors"):
+        p0, _ = problem()
+        assert np.max(np.abs(ref[5] - p0.pose_prior_values)) > 1e-5   # ... and the priorPoses blocks moved
     if case == "failure":
         assert ref[1][2] >= 3                              # ... and this one only rejects (invalid or unsuccessful steps to the end)
     if case == "max_iterations":
