@@ -90,7 +90,7 @@ __global__ __launch_bounds__(kPPThreads) void pose_prior_blocks_kernel(const Dev
       const double w = pp_weight(dp, i), r = (p0[i] - pose[i]) * w;
       const double s0 = dp.pp_scale[(size_t)k * 6 + i], sp = dp.scale_pose[(size_t)b * 6 + i];
       const int a = 6 * q + i;
-      if (sv.lead) {   // replicated terms of the normal equations: contributed once, by the lead rank of a sharded solve
+      if (sv.frame_lead ? sv.frame_lead[f] != 0.0 : sv.lead != 0) {   // replicated terms of the normal equations: contributed once — by the lead rank, or (sharded factorisation) by the rank whose part holds the frame
         sv.U[((size_t)f * CD + a) * CD + a] += (w * sp) * (w * sp);
         sv.gc[(size_t)f * CD + a] += -(w * sp) * r;
       }
@@ -147,6 +147,7 @@ __global__ void pose_prior_reduce_kernel(const DeviceProblem dp, const SolverDev
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= 6 * dp.pp_count) return;
   const int k = t / 6, i = t % 6;
+  if (!(sv.frame_lead ? sv.frame_lead[dp.pp_block[k] / dp.P] != 0.0 : sv.lead != 0)) return;   // (the rank that added the block's terms takes them out again)
   const int64_t cc = (int64_t)dp.pp_block[k] * 6 + i;               // camera-side coordinate of the pose entry
   const int I = (int)(cc / kTile), r = (int)(cc % kTile);
   const double vp = v0[t] + diag[t] * inv_radius;

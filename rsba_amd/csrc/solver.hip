@@ -730,7 +730,7 @@ int32_t build_solver_impl(rsba_handle* h) {
   // interFrameRatio or several intrinsics blocks (their replicated terms come from rank 0 alone) — those problems keep the
   // replicated factorisation.  Motion priors with a known ratio are shared out like the frames: see below.
   std::vector<int32_t> cpart(nt, -1);
-  bool sharded = want_parts && tord.parts_ok && h->pp_blocks.empty() && dp.pp_spherical < 0 && NIB <= 1;   // (a free interFrameRatio is in: its column's forward solve runs part by part, FWD2P / ETA below)
+  bool sharded = want_parts && tord.parts_ok && dp.pp_spherical < 0 && NIB <= 1;   // (GoodPosePrior blocks are in: their terms go to the rank whose part holds the pose, like the frames' damping)   // (a free interFrameRatio is in: its column's forward solve runs part by part, FWD2P / ETA below)
   if (const char* e = std::getenv("RSBA_SHARDED")) sharded = sharded && e[0] != '0';   // A/B switch
   if (want_parts) {
     double bad = sharded ? 0.0 : 1.0;
@@ -1605,7 +1605,7 @@ int32_t reduce_system(rsba_handle* h, double radius) {
     // plan was built — are never written by anyone: the factorisation keeps its own tiles, the multi-GPU exchange adds zeros)
     HIP_TRY(launch_schur_blocks(h->dp, sv, radius, st));
     ++s->schur_launches;
-    if (sv.lead) HIP_TRY(launch_pose_prior_reduce(h->dp, sv, s->pp, radius, st));   // the priorPoses blocks leave the system like points
+    if (sv.lead || sv.frame_lead) HIP_TRY(launch_pose_prior_reduce(h->dp, sv, s->pp, radius, st));   // the priorPoses blocks leave the system like points (each on the rank that holds its pose's tile)
   }
   // exchange (2): partial reduced camera systems -> the full one on every rank (then factored redundantly) — unless every rank
   // factors its own part: then only the separators travel, between the two launches of the factorisation (solve_reduced_system)

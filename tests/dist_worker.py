@@ -47,6 +47,11 @@ def nd_mode(mode, outdir, rank, world, dist, torch):
         full.prior_frames = np.arange(1, full.num_frames, dtype=np.int32)
         if "freeratio" in flags:   # ... the reference's default: the ratio is a free, lower-bounded block (CeresHandler.h:161,172,175) — its column's forward solve runs part by part
             full.prior_kind, full.inter_frame_ratio, full.ratio_free = 1, 1.0, True
+    if "posepriors" in flags:   # GoodPosePrior blocks (CeresHandler.h:188-204): every rank passes the same blocks; their terms go to the rank whose part holds the pose
+        rng = np.random.default_rng(5)
+        full.pose_prior_block = np.arange(2, 2 * full.num_frames, dtype=np.int32)
+        full.pose_prior_values = full.poses.reshape(-1, 6)[full.pose_prior_block] + rng.normal(0, 0.01, (len(full.pose_prior_block), 6))
+        full.pose_prior_rotation, full.pose_prior_position = 3.0, 5.0
     if "hostrank" in flags and rank == 1:   # ONE rank cannot run the loop without the host (test hook of the library; in the field: a rank without observations, or with phase timers on): ALL ranks must then take the host form — their collectives pair up or the solve hangs
         os.environ["RSBA_DEVICE_LM_OFF_ON_THIS_RANK"] = "1"
     if "corrupt" in flags:   # the first persistent-driver solve loses an entry of its result (test hook of the library): every rank must notice through exchange (3)
@@ -76,7 +81,8 @@ def nd_mode(mode, outdir, rank, world, dist, torch):
     out = {"rank": rank, "transport": transport, "collective_calls": {k: v["calls"] for k, v in xs["collectives"].items()}, "world": world, "n_full": int(full.num_observations), "n_shard": int(shard.num_observations), "top_tile_columns": ntop,
            "final_cost": s.final_cost, "initial_cost": s.initial_cost, "iters": s.num_iterations, "dag_fallbacks": s.num_dag_fallbacks,
            "reduced": s.num_residual_blocks_reduced, "params": s.num_parameters_reduced, "costs": [t.cost for t in tr], "plan": st,
-           "poses_sum": float(np.abs(shard.poses).sum()), "points_sum": float(np.abs(shard.points).sum()), "ratio": float(shard.inter_frame_ratio)}
+           "poses_sum": float(np.abs(shard.poses).sum()), "points_sum": float(np.abs(shard.points).sum()), "ratio": float(shard.inter_frame_ratio),
+           "prior_values_sum": None if shard.pose_prior_values is None else float(np.abs(shard.pose_prior_values).sum())}
     os.environ.pop("RSBA_CHOL_TEST_CORRUPT", None)
     os.environ.pop("RSBA_DEVICE_LM_OFF_ON_THIS_RANK", None)
     if rank == 0:
@@ -87,6 +93,7 @@ def nd_mode(mode, outdir, rank, world, dist, torch):
         out.update(ref_final=s1.final_cost, ref_initial=s1.initial_cost, ref_iters=s1.num_iterations, ref_reduced=s1.num_residual_blocks_reduced, ref_params=s1.num_parameters_reduced,
                    pose_err=float(np.abs(ref.poses - shard.poses).max()), point_err=float(np.abs(ref.points - shard.points).max()),
                    traj_err=float(max(abs(a.cost - b.cost) / b.cost for a, b in zip(tr, tr1))), ref_plan=st1, ref_ratio=float(ref.inter_frame_ratio),
+                   prior_err=None if ref.pose_prior_values is None else float(np.abs(ref.pose_prior_values - shard.pose_prior_values).max()),
                    decisions_equal=bool(all(a.step_is_successful == b.step_is_successful for a, b in zip(tr, tr1))))
     with open(os.path.join(outdir, f"rank{rank}.json"), "w") as f:
         json.dump(out, f)
