@@ -173,9 +173,9 @@ int32_t rsba_time_evaluate(rsba_handle* h, int32_t with_jacobians, int32_t warmu
  * camera system, all on the device; parameters are written back to the arrays given to rsba_create.
  * trace (may be NULL) receives up to trace_capacity iteration records.
  * The trust-region decisions themselves (TrustRegionMinimizer's accept / reject, radius, convergence tests) are taken by a device kernel
- * wherever the problem allows (no records kept: calibrated or one shared intrinsics block; no free interFrameRatio, no per-pose priors;
- * one rank or several) — the host then waits once per iteration for the state, never inside one; the same rules on the host otherwise
- * and with options.profile_phases.  The two forms produce the same iteration records bit for bit. */
+ * wherever the problem allows (no records kept: calibrated or one shared intrinsics block; with or without motion priors — interFrameRatio
+ * known or free — and GoodPosePrior blocks; one rank or several, pose priors on one) — the host then waits once per iteration for the
+ * state, never inside one; the same rules on the host otherwise (per-frame intrinsics blocks, a SphericalPrior) and with options.profile_phases.  The two forms produce the same iteration records bit for bit. */
 void rsba_default_solver_options(rsba_solver_options* opt);
 int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rsba_solver_summary* summary,
                    rsba_iteration* trace, int32_t trace_capacity);

@@ -52,3 +52,20 @@ for k in order[-40:]:
     prev = ends[np.searchsorted(ends, us[k, 2]) - 1] if us[k, 2] > ends[0] else 0.0
     rel = [us[k, 0] - us[k, 2], us[k, 1] - us[k, 2]] + [((tr[k, j] - tr[k, 1]) * 0.01 + us[k, 0] - us[k, 2]) if tr[k, j] > 0 else float('nan') for j in (3, 5, 4, 6)]
     print(f"  {us[k, 2]:8.1f} {us[k, 2] - prev:6.1f} | " + " ".join(f"{x:8.1f}" for x in rel) + f" | {int(tr[k, 0])}")
+# the forward phase level by level: the DIAG tasks of a level sit next to each other in the task list
+runs, start = [], None
+for i in range(n + 1):
+    isd = i < n and tasks[i, 0] == 1
+    if isd and start is None: start = i
+    if not isd and start is not None: runs.append((start, i)); start = None
+print("level: DIAG tasks | first / last completion (us) | pace of the slowest chain (last completion - previous level's) | mean wait claimed->late input | mean late input->done")
+prev = 0.0
+for l, (a, b) in enumerate(runs):
+    done = us[a:b, 2]
+    sub = np.where((tasks[:, 0] == 2))[0]
+    print(f"  {l:3d}: {b - a:3d} | {done.min():7.1f} {done.max():7.1f} | {done.max() - prev:6.1f} | {np.mean(us[a:b, 1] - us[a:b, 0]):6.1f} | {np.mean(us[a:b, 2] - us[a:b, 1]):6.1f}")
+    prev = done.max()
+# how busy the workgroups are: tasks running (claimed .. done) at sample times
+ts = np.linspace(0, us[:, 2].max(), 40)
+busy = [(int(((us[:, 0] <= t) & (us[:, 2] > t)).sum()), int(((us[:, 1] <= t) & (us[:, 2] > t)).sum())) for t in ts]
+print("claimed / working (past their last late input) tasks at 40 sample times:", " ".join(f"{a}/{b}" for a, b in busy))

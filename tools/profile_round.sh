@@ -2,7 +2,7 @@
 # Runs on the GPU box (via gpurun): collects this round's evidence into gpurun_out/$1/ (default r02).
 #   the bench lines (C4 = the metric's workload, C5 = the 4k-camera Huber + shared-intrinsics scene), kernel-trace stats of the
 #   same commands, FETCH_SIZE and WRITE_SIZE in separate --pmc passes (never combined with tracing), the HBM stream calibration.
-R=${1:-r03}
+R=${1:-r05}
 OUT=gpurun_out/$R
 mkdir -p $OUT
 export TMPDIR=/tmp

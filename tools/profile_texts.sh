@@ -2,7 +2,7 @@
 # Runs on the GPU box (via gpurun) after tools/profile_round.sh: the text evidence profiles/rNN/README.md lists — phase times, LM
 # wall times (DAG driver against the level schedule), the task timeline of the Cholesky, the chunk timeline of the Schur kernel,
 # the tile-factorisation and hand-off micro-benchmarks, the cost of a fresh handle, and the -m gpu suite — into gpurun_out/$1/.
-R=${1:-r03}
+R=${1:-r05}
 OUT=gpurun_out/$R
 mkdir -p $OUT
 F='grep -v amdgpu.ids'
@@ -14,6 +14,8 @@ python tools/chol_trace.py C4 2>&1 | $F > $OUT/chol_trace_c4.txt
 python tools/schur_trace.py C4 2>&1 | $F > $OUT/schur_trace_c4.txt
 timeout 120 tools/tile_factor_bench > $OUT/tile_factor.txt 2>&1
 timeout 120 tools/xcd_handoff > $OUT/xcd_handoff.txt 2>&1
-{ RSBA_DEBUG_PLAN=1 python tools/setup_time.py C4 2>&1 | $F; python tools/setup_time.py C2 2>&1 | $F; } > $OUT/setup_time.txt
+{ RSBA_DEBUG_PLAN=1 python tools/setup_time.py C4 2>&1 | $F; python tools/setup_time.py C2 2>&1 | $F; RSBA_DEBUG_PLAN=1 python tools/setup_time.py C5 2>&1 | $F | grep -E "host phases|fresh handle|device lists"; } > $OUT/setup_time.txt
+{ for C in C4 C5; do for FAC in 0 1; do echo "== $C RSBA_FACTORED=$FAC"; RSBA_FACTORED=$FAC python tools/phase_time.py $C 8 2>&1 | $F; done; done; } > $OUT/factored_groups_ab.txt
+python tools/lm_time.py C4 12 priors 2>&1 | $F > $OUT/lm_time_c4_priors.txt
 python tools/filter_time.py 2>&1 | $F > $OUT/filter_time.txt
 python -m pytest tests -m gpu -q 2>&1 | $F | tail -15 > $OUT/pytest_gpu.txt
