@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256) void project_kernel(const DeviceProblem dp, co
 // are found with one wave vote per block and their MFMAs are not issued (a fifth of them at 1k cameras; 0 * x adds nothing,
 // so the result is the same to the bit), and a tile paired with itself only forms the blocks on and below the
 // diagonal (nothing reads the upper triangle of a diagonal tile of S).
-// One workgroup per chunk of kSchurChunk entries; its four waves take every fourth entry and keep all
+// One chunk of kSchurChunk entries at a time per workgroup (resident workgroups take chunk after chunk: schur_tile_kernel); its four waves take every fourth entry and keep all
 // nine 16x16 blocks (loads run kDepth groups ahead of the MFMAs in a register ring), the four partial tiles meet
 // once in LDS.  The fp64 VALU form of this product was bound by LDS operand reads at 2.0 ms per 1k-camera
 // iteration.  Chunks write partial tiles; the merge kernel sums them in chunk order (fixed order, no atomics)
@@ -457,7 +457,7 @@ constexpr unsigned kLowerBlocks = 0x1D9;   // bits 3 I + J with J <= I
 // SQ_VALU_MFMA_BUSY_CYCLES).  Here: entry counts are padded to a multiple of 16 with entries that point at an all-zero group
 // (no tail selects), the table holds ready element offsets (one 64-bit add per operand, the blocks ride on the load's immediate
 // offset), and which of the nine 16 x 16 blocks of a group of four entries have anything to multiply
-// is ONE scalar read of host-computed masks (a full mask — the common case — runs 27 MFMAs without a branch).
+// is ONE scalar read of host-computed masks; every MFMA sits behind a scalar test of its block's bit (untaken for a full mask, the common case).
 //
 // FA / FB: the groups of the I / J side are stored FACTORED (solver_state.hpp: kGroupFactored; round 5).  The 48 camera-side rows of
 // a two-pose frame tile are, frame by frame, (1 - tau) q | tau q with q = Jq^T Jp L^-T (6 x 3): such a group holds the 24 "sources"
@@ -491,8 +491,33 @@ template <bool F> struct SchurSide;
 template <> struct SchurSide<true> { double qm[3], ql[3], tm, tl; };   // [coordinate]
 template <> struct SchurSide<false> { double v[3][3]; };               // [coordinate][block]
 
+// The table cells of a chunk that one thread stages (entries tid and tid + 256), loaded ahead of the chunk: the persistent form of the
+// kernel issues these loads for its NEXT chunk before the epilogue of the current one, so that the dependent chain chunk -> entry list ->
+// operands is not paid chunk by chunk (one workgroup per chunk spent 16 % of a CU slot's time between the end of one chunk and the
+// first MFMA of the next: dispatch, four dependent reads; profiles/r05/schur_persistent.txt).
+struct ChunkStage { uint32_t ga[2], gb[2]; unsigned pm[2]; int32_t pt[2]; };
+static_assert(kSchurChunk == 512, "two table cells per thread");
+__device__ __forceinline__ void stage_chunk(const SolverDev& sv, const int4& info, int tid, ChunkStage& st) {
+  const int64_t e0 = (int64_t)(((uint64_t)(uint32_t)info.y << 32) | (uint32_t)info.x);
+  const int n = info.z;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int k = tid + 256 * u;
+    st.ga[u] = st.gb[u] = sv.zero_off;      // (behind the chunk's last entry: the all-zero group behind the last one)
+    st.pm[u] = 0; st.pt[u] = 0;
+    if (k < n) {
+      const uint2 gg = *reinterpret_cast<const uint2*>(sv.ent_groups + 2 * (e0 + k));
+      st.ga[u] = gg.x & ~15u; st.gb[u] = gg.y & ~15u;   // (the kind bit: the same for every entry of a tile pair — FA, FB)
+      st.pm[u] = sv.ent_mask[e0 + k];     // 16 x 16 blocks of the entry with a frame that sees the point on both sides (host)
+      if (info.w & 1) st.pt[u] = sv.ent_pt[e0 + k];
+    }
+  }
+}
+
+// -> the workgroup's next chunk (-1: none), `info` / `st` then hold that chunk's
 template <bool DIAG, int kDepth, bool FA, bool FB>
-__device__ __forceinline__ void schur_chunk(const SolverDev& sv, const double* __restrict__ Pm, const double* __restrict__ zz, int chunk, double* smem) {
+__device__ __forceinline__ int schur_chunk(const SolverDev& sv, const double* __restrict__ Pm, const double* __restrict__ zz, int chunk, int4& info, ChunkStage& st, double* smem, int* s_next,
+                                           bool persistent, int xcd, int per_xcd) {
   constexpr int TPITCH = kTile + 1;
   constexpr unsigned kFull = DIAG ? kLowerBlocks : 0x1FFu;
   uint32_t* s_off = reinterpret_cast<uint32_t*>(smem);
@@ -500,28 +525,30 @@ __device__ __forceinline__ void schur_chunk(const SolverDev& sv, const double* _
   double* s_z = reinterpret_cast<double*>(reinterpret_cast<char*>(smem) + kSchurOffBytes + kSchurMskBytes);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
-  const int64_t e0 = sv.chunk_e0[chunk];
-  const int n = sv.chunk_n[chunk], n16 = (n + 15) & ~15;
+  const int n = info.z, n16 = (n + 15) & ~15;
   long long* tr = sv.schur_trace ? sv.schur_trace + 8 * (size_t)chunk : nullptr;
   if (tr && tid == 0) { tr[0] = blockIdx.x; tr[1] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); tr[2] = wall_clock64(); tr[6] = n; }   // HW_REG_HW_ID
-  for (int k = tid; k < n16; k += 256) {
-    uint32_t ga = sv.zero_off, gb = ga;       // the all-zero group behind the last one
-    unsigned pm = 0;
-    if (k < n) {
-      ga = sv.ent_groups[2 * (e0 + k)] & ~15u; gb = sv.ent_groups[2 * (e0 + k) + 1] & ~15u;   // (the kind bit: the same for every entry of a tile pair — FA, FB)
-      pm = sv.ent_mask[e0 + k] & kFull;   // 16 x 16 blocks of the entry with a frame that sees the point on both sides (host)
-      if (sv.schur_variant == 5) { ga = (uint32_t)(k & 63) * kGroupFull; gb = (uint32_t)(64 + (k & 63)) * kGroupFull; }   // ablation: operands out of the caches
-    }
-    s_off[2 * k] = ga; s_off[2 * k + 1] = gb;
-    s_msk[(k & 3) * (kSchurChunk / 4) + (k >> 2)] = (uint16_t)pm;
-    if (DIAG) {
-      const int32_t pt = k < n ? sv.ent_pt[e0 + k] : 0;
+  __syncthreads();   // (the previous chunk's epilogue has read its partial tiles: the same LDS)
 #pragma unroll
-      for (int c = 0; c < 3; ++c) s_z[3 * k + c] = pt < 0 ? zz[(size_t)(pt & 0x7fffffff) * 3 + c] : 0.0;   // top bit: diagonal entry of the point -> rhs term P z
+  for (int u = 0; u < 2; ++u) {
+    const int k = tid + 256 * u;
+    if (k < n16) {
+      uint32_t ga = st.ga[u], gb = st.gb[u];
+      if (sv.schur_variant == 5 && k < n) { ga = (uint32_t)(k & 63) * kGroupFull; gb = (uint32_t)(64 + (k & 63)) * kGroupFull; }   // ablation: operands out of the caches
+      s_off[2 * k] = ga; s_off[2 * k + 1] = gb;
+      s_msk[(k & 3) * (kSchurChunk / 4) + (k >> 2)] = (uint16_t)(st.pm[u] & kFull);
+      if (DIAG) {
+        const int32_t pt = st.pt[u];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) s_z[3 * k + c] = pt < 0 ? zz[(size_t)(pt & 0x7fffffff) * 3 + c] : 0.0;   // top bit: diagonal entry of the point -> rhs term P z
+      }
     }
   }
   __syncthreads();
-  if (tr && tid == 0) tr[3] = wall_clock64();
+  if (tr && tid == 0) { tr[3] = wall_clock64(); tr[7] = -clock64(); }
+  // the workgroup's next chunk: the next one of its XCD's eighth of the list that nobody has taken (asked for now, needed behind the loop)
+  unsigned ticket = 0;
+  if (persistent && tid == 0) ticket = __hip_atomic_fetch_add(sv.schur_next + 16 * xcd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // K = 3 per point against 4 per MFMA: four of the wave's entries share three MFMA steps — step t takes coordinate t of the four,
   // lane group g holding entry g of them (one table cell per lane and group of four).  The wave's entries are wave, wave + 4, ..:
   // entry e of its group q is k = wave + 16 q + 4 e.
@@ -584,37 +611,22 @@ __device__ __forceinline__ void schur_chunk(const SolverDev& sv, const double* _
           if constexpr (FA) { wa0 = __builtin_fma(fl.b0, G.a.tm, fl.a0); wa1 = __builtin_fma(fl.b1, G.a.tm, fl.a1); wa2 = __builtin_fma(fl.b2, G.a.tl, fl.a2); }
           if constexpr (FB) { wb0 = __builtin_fma(fl.b0, G.b.tm, fl.a0); wb1 = __builtin_fma(fl.b1, G.b.tm, fl.a1); wb2 = __builtin_fma(fl.b2, G.b.tl, fl.a2); }
           if (sv.schur_variant == 4) pm = 0;   // ablation: loads only
-          if (pm == kFull) {
+          // ONE code path for full and partial masks: every MFMA behind a scalar test of its block's bit (a second, branch-free path for the
+          // full mask made the register allocator keep two homes for the 72 accumulator registers and copy them over around every group:
+          // 3.5 v_mov_b64 per MFMA in the round-5 build, 2 in round 4's)
+          const unsigned pm27 = pm * 0x40201u;   // the nine bits once per coordinate: every MFMA tests a bit of its own (one s_bitcmp1 + branch; the same bit three times made the compiler keep the tests as lane masks and turn them over on the vector unit)
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
-              double a[3], b[3];
-              operands(G.a, t, wa0, wa1, wa2, a); operands(G.b, t, wb0, wb1, wb2, b);
+          for (int t = 0; t < 3; ++t) {
+            double a[3], b[3];
+            operands(G.a, t, wa0, wa1, wa2, a); operands(G.b, t, wb0, wb1, wb2, b);
 #pragma unroll
-              for (int I = 0; I < 3; ++I)
+            for (int I = 0; I < 3; ++I)
 #pragma unroll
-                for (int J = 0; J < 3; ++J)
-                  if (!DIAG || J <= I) acc[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[I], b[J], acc[I][J], 0, 0, 0);
-              if (DIAG) {
+              for (int J = 0; J < 3; ++J)
+                if ((!DIAG || J <= I) && __builtin_expect(((pm27 >> (9 * t + 3 * I + J)) & 1u) != 0u, 1)) acc[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[I], b[J], acc[I][J], 0, 0, 0);
+            if (DIAG) {
 #pragma unroll
-                for (int I = 0; I < 3; ++I) racc[I] += a[I] * G.z[t];
-              }
-            }
-          } else {
-#pragma unroll
-            for (int t = 0; t < 3; ++t) {
-              double a[3], b[3];
-              operands(G.a, t, wa0, wa1, wa2, a); operands(G.b, t, wb0, wb1, wb2, b);
-              if (pm != 0u) {
-#pragma unroll
-                for (int I = 0; I < 3; ++I)
-#pragma unroll
-                  for (int J = 0; J < 3; ++J)
-                    if ((!DIAG || J <= I) && ((pm >> (3 * I + J)) & 1u)) acc[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[I], b[J], acc[I][J], 0, 0, 0);
-              }
-              if (DIAG) {
-#pragma unroll
-                for (int I = 0; I < 3; ++I) racc[I] += a[I] * G.z[t];
-              }
+              for (int I = 0; I < 3; ++I) racc[I] += a[I] * G.z[t];
             }
           }
           issued += 3u * (unsigned)__builtin_popcount(pm);
@@ -624,8 +636,25 @@ __device__ __forceinline__ void schur_chunk(const SolverDev& sv, const double* _
     }
   }
   if (lane == 0 && issued) atomicAdd(sv.schur_mfma_count, (unsigned long long)issued);   // a statistic (bench.py: issued against useful flops), not a result
+  if (tid == 0) {
+    const int64_t slots = (int64_t)(gridDim.x >> 3);      // (the first gridDim.x / 8 of every eighth went to the workgroups as they started)
+    int64_t i = slots + ticket, c = (int64_t)xcd * per_xcd + i;
+    int nx = persistent && i < per_xcd && c < sv.nchunk ? (int)c : -1;
+    // its own eighth is done: the next chunk of another XCD's (the eighths have the same number of chunks, not of entries — without this the
+    // launch ramps down over two chunk times)
+    for (int k = 1; k < 8 && persistent && nx < 0; ++k) {
+      const int y = (xcd + k) & 7;
+      i = slots + __hip_atomic_fetch_add(sv.schur_next + 16 * y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      c = (int64_t)y * per_xcd + i;
+      if (i < per_xcd && c < sv.nchunk) nx = (int)c;
+    }
+    s_next[0] = nx;
+  }
   __syncthreads();   // everyone is done with the tables: the same LDS now takes the four partial tiles
-  if (tr && tid == 0) tr[4] = wall_clock64();
+  if (tr && tid == 0) { tr[4] = wall_clock64(); tr[7] += clock64(); }   // (shader cycles of the loop: the clock under this load)
+  const int next = __builtin_amdgcn_readfirstlane(s_next[0]);
+  info = next >= 0 ? sv.chunk_info[next] : int4{0, 0, 0, 0};
+  stage_chunk(sv, info, tid, st);   // (in flight under the epilogue; nothing to read behind the last chunk)
   double* buf = smem + wave * (kTile * TPITCH);
   // every result to its place in the tile: a factored side's rows were taken in this kernel's own order (factored_row).  A factored tile
   // paired with itself formed the blocks J <= I of that order: each lands twice, as (row, column) and as (column, row) — the tile comes
@@ -661,27 +690,39 @@ __device__ __forceinline__ void schur_chunk(const SolverDev& sv, const double* _
   }
   if (DIAG && tid < kTile) { const double* v = smem + 4 * kTile * TPITCH; part[kTile * kTile + tid] = (v[tid] + v[kTile + tid]) + (v[2 * kTile + tid] + v[3 * kTile + tid]); }
   if (tr && tid == 0) tr[5] = wall_clock64();
+  return next;
 }
 
 // kDepth = groups of four entries in flight per wave (18 loads each in full form, 16 factored: vmcnt counts to 63).  Two waves per SIMD (two workgroups
 // per CU) fit 256 registers with two groups in flight; three need 300.
+// PERSISTENT form (the default): 8 x min(an eighth of the chunk list, the XCD's workgroup slots) workgroups; workgroup b starts with chunk
+// b >> 3 of eighth b & 7 (workgroups go round-robin over the 8 XCDs, so XCD x walks the x-th eighth of the chunk list in order and its L2
+// sees the repeats: consecutive chunks share records — host: chunk numbering) and then takes the eighth's next untaken chunk (a counter per
+// eighth) until there is none.  The last workgroup to leave puts the counters back to zero for the next launch.
+// RSBA_SCHUR_VARIANT=2: one workgroup per chunk (rounds 2 - 4).
 template <int kDepth, int kWavesPerSimd>
-__global__ __launch_bounds__(256, kWavesPerSimd) void schur_tile_kernel(const SolverDev sv, const double* __restrict__ Pm, const double* __restrict__ zz) {
+__global__ __launch_bounds__(256, kWavesPerSimd) void schur_tile_kernel(const SolverDev sv, const double* __restrict__ Pm, const double* __restrict__ zz, int persistent) {
   if (lm_stopped(sv.ctl)) return;
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  // consecutive chunks share records (host: chunk numbering); workgroups go round-robin over the 8 XCDs, so XCD x
-  // walks the x-th eighth of the chunk list in order and its L2 sees the repeats
-  const int per_xcd = (sv.nchunk + 7) / 8;
-  const int chunk = sv.schur_linear ? (int)blockIdx.x : (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
-  if (chunk >= sv.nchunk) return;
-  const int tp = sv.chunk_tp[chunk];
-  const int I = sv.tp_I[tp], J = sv.tp_J[tp];
-  const bool fa = sv.tile_factored && sv.tile_factored[I], fb = sv.tile_factored && sv.tile_factored[J];
-  if (I == J) { if (fa) schur_chunk<true, kDepth, true, true>(sv, Pm, zz, chunk, smem); else schur_chunk<true, kDepth, false, false>(sv, Pm, zz, chunk, smem); }
-  else if (fa && fb) schur_chunk<false, kDepth, true, true>(sv, Pm, zz, chunk, smem);
-  else if (fb) schur_chunk<false, kDepth, false, true>(sv, Pm, zz, chunk, smem);        // an intrinsics pseudo tile (full form) against a frame tile
-  else if (fa) schur_chunk<false, kDepth, true, false>(sv, Pm, zz, chunk, smem);        // (a frame tile against a lower-numbered full-form tile: not produced by the plan today)
-  else schur_chunk<false, kDepth, false, false>(sv, Pm, zz, chunk, smem);
+  __shared__ int s_next[2];
+  const int per_xcd = (sv.nchunk + 7) / 8, xcd = (int)(blockIdx.x & 7);
+  int chunk = sv.schur_linear ? (int)blockIdx.x : xcd * per_xcd + (int)(blockIdx.x >> 3);
+  if (chunk >= sv.nchunk || (!sv.schur_linear && (int)(blockIdx.x >> 3) >= per_xcd)) chunk = -1;
+  int4 info = int4{0, 0, 0, 0};
+  ChunkStage st;
+  if (chunk >= 0) { info = sv.chunk_info[chunk]; stage_chunk(sv, info, (int)threadIdx.x, st); }
+  while (chunk >= 0) {
+    const int f = info.w;
+    if (f & 1) { if (f & 2) chunk = schur_chunk<true, kDepth, true, true>(sv, Pm, zz, chunk, info, st, smem, s_next, persistent != 0, xcd, per_xcd); else chunk = schur_chunk<true, kDepth, false, false>(sv, Pm, zz, chunk, info, st, smem, s_next, persistent != 0, xcd, per_xcd); }
+    else if ((f & 6) == 6) chunk = schur_chunk<false, kDepth, true, true>(sv, Pm, zz, chunk, info, st, smem, s_next, persistent != 0, xcd, per_xcd);
+    else if (f & 4) chunk = schur_chunk<false, kDepth, false, true>(sv, Pm, zz, chunk, info, st, smem, s_next, persistent != 0, xcd, per_xcd);        // an intrinsics pseudo tile (full form) against a frame tile
+    else if (f & 2) chunk = schur_chunk<false, kDepth, true, false>(sv, Pm, zz, chunk, info, st, smem, s_next, persistent != 0, xcd, per_xcd);        // (a frame tile against a lower-numbered full-form tile: not produced by the plan today)
+    else chunk = schur_chunk<false, kDepth, false, false>(sv, Pm, zz, chunk, info, st, smem, s_next, persistent != 0, xcd, per_xcd);
+  }
+  if (persistent && threadIdx.x == 0 && __hip_atomic_fetch_add(sv.schur_next + 128, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+    for (int e = 0; e < 8; ++e) __hip_atomic_store(sv.schur_next + 16 * e, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(sv.schur_next + 128, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // one workgroup per group of a very long chunk list: partial[first] = sum of the group's partials, in list order
@@ -1646,13 +1687,16 @@ hipError_t launch_schur_blocks(const DeviceProblem& dp, const SolverDev& sv, dou
     const size_t table = (size_t)kSchurOffBytes + kSchurMskBytes + (size_t)kSchurChunk * 3 * sizeof(double);
     const size_t tiles = (size_t)(4 * kTile * (kTile + 1) + 4 * kTile) * sizeof(double);
     const size_t lds = table > tiles ? table : tiles;
-    const dim3 grid(8 * ((sv.nchunk + 7) / 8));
-    if (sv.schur_variant == 1) {   // (RSBA_SCHUR_VARIANT=1: three groups in flight, one wave per SIMD; 4 / 5: ablations of variant 0)
+    const int per_xcd = (sv.nchunk + 7) / 8;
+    const int persistent = sv.schur_variant != 2 && !sv.schur_linear;
+    if (sv.schur_variant == 1) {   // (RSBA_SCHUR_VARIANT=1: three groups in flight, one wave per SIMD; 2: one workgroup per chunk; 4 / 5: ablations of variant 0)
+      const dim3 grid(8 * (persistent ? std::min(per_xcd, 32) : per_xcd));
       hipError_t e = allow_dynamic_lds(schur_tile_kernel<3, 1>, lds); if (e != hipSuccess) return e;
-      hipLaunchKernelGGL((schur_tile_kernel<3, 1>), grid, dim3(256), lds, st, sv, sv.Pm, sv.z);
+      hipLaunchKernelGGL((schur_tile_kernel<3, 1>), grid, dim3(256), lds, st, sv, sv.Pm, sv.z, persistent);
     } else {
+      const dim3 grid(8 * (persistent ? std::min(per_xcd, 64) : per_xcd));   // (32 CUs per XCD, two of these workgroups per CU)
       hipError_t e = allow_dynamic_lds(schur_tile_kernel<2, 2>, lds); if (e != hipSuccess) return e;
-      hipLaunchKernelGGL((schur_tile_kernel<2, 2>), grid, dim3(256), lds, st, sv, sv.Pm, sv.z);
+      hipLaunchKernelGGL((schur_tile_kernel<2, 2>), grid, dim3(256), lds, st, sv, sv.Pm, sv.z, persistent);
     }
     { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; }
   }

@@ -1155,6 +1155,12 @@ int32_t build_solver_impl(rsba_handle* h) {
   up.upload_const(&sv.tp_chunk0, tp_chunk0);
   up.upload_const(&sv.tp_chunk_list, tp_chunk_list);
   up.upload_const(&sv.chunk_n, chunk_n);
+  std::vector<int4> chunk_info(chunk_tp.size());
+  for (size_t c = 0; c < chunk_tp.size(); ++c) {
+    const int I_ = tp_I[chunk_tp[c]], J_ = tp_J[chunk_tp[c]];
+    chunk_info[c] = int4{(int)(uint32_t)(chunk_e0[c] & 0xffffffff), (int)(chunk_e0[c] >> 32), chunk_n[c], (I_ == J_ ? 1 : 0) | (tile_factored[I_] ? 2 : 0) | (tile_factored[J_] ? 4 : 0)};
+  }
+  up.upload_const(&sv.chunk_info, chunk_info);
   up.upload_const(&sv.pm_ptr, pm_ptr);
   up.upload_const(&sv.pm_list, pm_list);
   up.upload_const(&sv.tp_dst, tp_dst);
@@ -1317,6 +1323,8 @@ int32_t build_solver_impl(rsba_handle* h) {
   sv.lerp_rot = dp.interp_rotation && dp.shutter != 0;
   if ((rc = s_alloc(s, &sv.Pm, pm_doubles))) return rc;
   HIP_TRY(hipMemsetAsync(sv.Pm, 0, pm_doubles * sizeof(double), h->stream));   // rows of frames that do not see the point stay zero for good: nothing ever writes them
+  if ((rc = s_alloc(s, &sv.schur_next, 9 * 16))) return rc;
+  HIP_TRY(hipMemsetAsync(sv.schur_next, 0, 9 * 16 * sizeof(unsigned), h->stream));   // (every launch leaves the counters at zero: its last workgroup)
   if ((rc = s_alloc(s, &sv.schur_mfma_count, 1))) return rc;
   HIP_TRY(hipMemsetAsync(sv.schur_mfma_count, 0, sizeof(unsigned long long), h->stream));
 

@@ -72,6 +72,8 @@ struct SolverDev {
   const int32_t* chunk_tp;      // [nchunk]
   const int64_t* chunk_e0;      // [nchunk] first entry of the chunk
   const int32_t* chunk_n;       // [nchunk] entries in the chunk (<= kSchurChunk)
+  const int4* chunk_info;       // [nchunk] the same in ONE 16-byte read: {first entry (low, high word), entries, bit 0 = a tile paired with itself | bit 1 / 2 = I / J side stored factored}
+  unsigned* schur_next;         // [8][16] next list position of every XCD's eighth of the chunk list (the persistent form of the kernel: kernels_normal.hip) | [128] workgroups done
   const int32_t* tp_chunk0;     // [ntp+1] range of each tile pair in tp_chunk_list
   const int32_t* tp_chunk_list; // chunk ids of each tile pair, in entry order (heads of pre-merged groups for very long lists)
   int npremerge;                // groups of chunks summed ahead of the merge

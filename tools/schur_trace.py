@@ -26,5 +26,6 @@ for lo, hi in ((0, 64), (64, 128), (128, 256), (256, 384), (384, 513)):
 starts = np.sort(us[:, 0]); ends = np.sort(us[:, 3])
 grid = np.linspace(0, us[:, 3].max(), 21)
 print("resident chunks over time:", [int((starts <= g).sum() - (ends <= g).sum()) for g in grid])
+print(f"shader clock inside the loops: {tr[:, 7].sum() / (loop.sum() * 1e-6) * 1e-6:.0f} MHz (s_memtime cycles / wall time of the loops)")
 hw = tr[:, 1]
 print("distinct (se, cu, simd ...) ids seen:", len(np.unique(hw >> 8)))
