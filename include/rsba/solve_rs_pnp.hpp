@@ -110,6 +110,101 @@ inline void smallest_eigenvector12(double a[12][12], double vec[12], double gap[
     gap[0] = a[best][best]; gap[1] = second; gap[2] = largest;
   }
 }
+// eigen decomposition of a symmetric 3 x 3 matrix (cyclic Jacobi): values ascending, vec[k] = unit eigenvector of val[k]
+inline void eigen3(const double sym[6] /* xx xy xz yy yz zz */, double val[3], double vec[3][3]) {
+  double a[3][3] = {{sym[0], sym[1], sym[2]}, {sym[1], sym[3], sym[4]}, {sym[2], sym[4], sym[5]}}, v[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  for (int sweep = 0; sweep < 40; ++sweep) {
+    const double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
+    if (off < 1e-300) break;
+    for (int p_ = 0; p_ < 3; ++p_) for (int q = p_ + 1; q < 3; ++q) {
+      if (std::fabs(a[p_][q]) < 1e-300) continue;
+      const double theta = (a[q][q] - a[p_][p_]) / (2.0 * a[p_][q]);
+      const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0)), c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+      for (int k = 0; k < 3; ++k) { const double akp = a[k][p_], akq = a[k][q]; a[k][p_] = c * akp - sn * akq; a[k][q] = sn * akp + c * akq; }
+      for (int k = 0; k < 3; ++k) { const double apk = a[p_][k], aqk = a[q][k]; a[p_][k] = c * apk - sn * aqk; a[q][k] = sn * apk + c * aqk; }
+      for (int k = 0; k < 3; ++k) { const double vkp = v[k][p_], vkq = v[k][q]; v[k][p_] = c * vkp - sn * vkq; v[k][q] = sn * vkp + c * vkq; }
+    }
+  }
+  int order[3] = {0, 1, 2};
+  for (int i = 0; i < 3; ++i) for (int j = i + 1; j < 3; ++j) if (a[order[j]][order[j]] < a[order[i]][order[i]]) { const int t = order[i]; order[i] = order[j]; order[j] = t; }
+  for (int k = 0; k < 3; ++k) { val[k] = a[order[k]][order[k]]; for (int r = 0; r < 3; ++r) vec[k][r] = v[r][order[k]]; }
+}
+// nearest rotation to a (nearly orthogonal) 3 x 3 matrix, R <- (R + R^-T) / 2; false: singular or a reflection
+inline bool nearest_rotation(double R[9]) {
+  for (int it = 0; it < 30; ++it) {
+    const double det = R[0] * (R[4] * R[8] - R[5] * R[7]) - R[1] * (R[3] * R[8] - R[5] * R[6]) + R[2] * (R[3] * R[7] - R[4] * R[6]);
+    if (!(std::fabs(det) > 1e-12)) return false;
+    const double it_[9] = {(R[4] * R[8] - R[5] * R[7]) / det, (R[5] * R[6] - R[3] * R[8]) / det, (R[3] * R[7] - R[4] * R[6]) / det,
+                           (R[2] * R[7] - R[1] * R[8]) / det, (R[0] * R[8] - R[2] * R[6]) / det, (R[1] * R[6] - R[0] * R[7]) / det,
+                           (R[1] * R[5] - R[2] * R[4]) / det, (R[2] * R[3] - R[0] * R[5]) / det, (R[0] * R[4] - R[1] * R[3]) / det};   // R^-T
+    for (int k = 0; k < 9; ++k) R[k] = 0.5 * (R[k] + it_[k]);
+  }
+  return R[0] * (R[4] * R[8] - R[5] * R[7]) - R[1] * (R[3] * R[8] - R[5] * R[6]) + R[2] * (R[3] * R[7] - R[4] * R[6]) > 0;
+}
+// (rotation matrix world->camera, tvec) -> rsba's 6-vector
+inline bool pose_from_rt(const double R[9], const double tvec[3], double pose[6]) {
+  double rvec[3];
+  const double tr = R[0] + R[4] + R[8], cs = std::fmin(1.0, std::fmax(-1.0, 0.5 * (tr - 1.0))), th = std::acos(cs);
+  const double ax[3] = {R[7] - R[5], R[2] - R[6], R[3] - R[1]};
+  const double sn = 0.5 * std::sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+  if (sn > 1e-8) for (int k = 0; k < 3; ++k) rvec[k] = ax[k] * (th / (2.0 * sn));
+  else if (cs > 0) for (int k = 0; k < 3; ++k) rvec[k] = 0.5 * ax[k];
+  else {   // a half turn: the axis from the diagonal
+    const double d[3] = {std::sqrt(std::fmax(0.0, 0.5 * (R[0] + 1.0))), std::sqrt(std::fmax(0.0, 0.5 * (R[4] + 1.0))), std::sqrt(std::fmax(0.0, 0.5 * (R[8] + 1.0)))};
+    rvec[0] = th * d[0]; rvec[1] = th * d[1] * (R[1] + R[3] >= 0 ? 1.0 : -1.0); rvec[2] = th * d[2] * (R[2] + R[6] >= 0 ? 1.0 : -1.0);
+  }
+  to_pose(rvec, tvec, pose);
+  for (int k = 0; k < 6; ++k) if (!std::isfinite(pose[k])) return false;
+  return true;
+}
+// A PLANAR target (a wall, a checkerboard): the 12-unknown DLT has a two-dimensional null space there, and cv::solvePnP — what the
+// reference calls, solveRSpnp.cpp:111-117 — starts from the plane's homography instead (its cvFindExtrinsicCameraParams2 takes that branch
+// when the two smallest singular values of the centred points' scatter are in a ratio below 1e-3).  Here: the points in the plane's own
+// frame (e1, e2, n = eigenvectors of the scatter, centred at c, divided by `scale`), the homography (x, y, 1) -> normalised image point
+// from the 9-unknown DLT (image points Hartley-normalised), then [r1 r2 t] ~ H: r1, r2 the normalised first columns, r3 = r1 x r2,
+// t = h3 over the mean of the two column norms, the nearest rotation to [r1 r2 r3] — and back to world coordinates.
+inline bool planar_pose(const float* opoints, const double* normalised, const int32_t* idx, int m, const double c[3], double scale, const double axes[3][3] /* e1 e2 n (ascending eigenvalues reversed) */,
+                        double pose[6]) {
+  if (m < 4) return false;
+  double e1[3] = {axes[0][0], axes[0][1], axes[0][2]}, e2[3] = {axes[1][0], axes[1][1], axes[1][2]};
+  const double nrm[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};   // right-handed whatever the eigenvectors' signs
+  double cu = 0.0, cv = 0.0, su = 0.0;
+  for (int i = 0; i < m; ++i) { cu += normalised[2 * (size_t)idx[i]] / m; cv += normalised[2 * (size_t)idx[i] + 1] / m; }
+  for (int i = 0; i < m; ++i) su += std::hypot(normalised[2 * (size_t)idx[i]] - cu, normalised[2 * (size_t)idx[i] + 1] - cv) / m;
+  if (!(su > 0.0)) return false;
+  su /= 1.4142135623730951;
+  double ata[12][12] = {};
+  for (int i = 0; i < m; ++i) {
+    const double d[3] = {(opoints[3 * (size_t)idx[i]] - c[0]) / scale, (opoints[3 * (size_t)idx[i] + 1] - c[1]) / scale, (opoints[3 * (size_t)idx[i] + 2] - c[2]) / scale};
+    const double x = d[0] * e1[0] + d[1] * e1[1] + d[2] * e1[2], y = d[0] * e2[0] + d[1] * e2[1] + d[2] * e2[2];
+    const double u = (normalised[2 * (size_t)idx[i]] - cu) / su, v = (normalised[2 * (size_t)idx[i] + 1] - cv) / su;
+    const double r0[9] = {x, y, 1, 0, 0, 0, -u * x, -u * y, -u}, r1[9] = {0, 0, 0, x, y, 1, -v * x, -v * y, -v};
+    for (int a = 0; a < 9; ++a) for (int b = 0; b < 9; ++b) ata[a][b] += r0[a] * r0[b] + r1[a] * r1[b];
+  }
+  double big = 0.0;
+  for (int a = 0; a < 9; ++a) big += ata[a][a];
+  if (!(big > 0.0)) return false;
+  for (int a = 9; a < 12; ++a) ata[a][a] = 2.0 * big;   // (the 12 x 12 solver with three idle unknowns far from the null space)
+  double hv[12], gap[3];
+  smallest_eigenvector12(ata, hv, gap);
+  if (!(gap[1] > 1e-9 * gap[2]) || !(gap[0] < 0.05 * gap[1])) return false;   // collinear image or object points: no single homography
+  // undo the image normalisation: H = [[su 0 cu] [0 su cv] [0 0 1]] Hn
+  double H[9];
+  for (int k = 0; k < 3; ++k) { H[k] = su * hv[k] + cu * hv[6 + k]; H[3 + k] = su * hv[3 + k] + cv * hv[6 + k]; H[6 + k] = hv[6 + k]; }
+  if (H[8] < 0) for (double& x : H) x = -x;   // the centroid (x = y = 0) in front of the camera
+  const double n1 = std::sqrt(H[0] * H[0] + H[3] * H[3] + H[6] * H[6]), n2 = std::sqrt(H[1] * H[1] + H[4] * H[4] + H[7] * H[7]);
+  if (!(n1 > 1e-300) || !(n2 > 1e-300) || !std::isfinite(n1 + n2)) return false;
+  const double r1[3] = {H[0] / n1, H[3] / n1, H[6] / n1}, r2[3] = {H[1] / n2, H[4] / n2, H[7] / n2};
+  const double r3[3] = {r1[1] * r2[2] - r1[2] * r2[1], r1[2] * r2[0] - r1[0] * r2[2], r1[0] * r2[1] - r1[1] * r2[0]};
+  const double lam = 0.5 * (n1 + n2), tp[3] = {H[2] / lam, H[5] / lam, H[8] / lam};
+  double Rp[9] = {r1[0], r2[0], r3[0], r1[1], r2[1], r3[1], r1[2], r2[2], r3[2]};
+  if (!nearest_rotation(Rp)) return false;
+  // x_cam ~ Rp [e1 e2 n]^T (X - c) / scale + tp
+  double R[9], tvec[3];
+  for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) R[3 * r + k] = Rp[3 * r] * e1[k] + Rp[3 * r + 1] * e2[k] + Rp[3 * r + 2] * nrm[k];
+  for (int r = 0; r < 3; ++r) tvec[r] = scale * tp[r] - (R[3 * r] * c[0] + R[3 * r + 1] * c[1] + R[3 * r + 2] * c[2]);
+  return pose_from_rt(R, tvec, pose);
+}
 // rsba pose (angle-axis world->camera, camera centre) from >= 6 correspondences idx[0..m): false when the points are degenerate
 inline bool dlt_pose(const float* opoints, const double* normalised, const int32_t* idx, int m, double pose[6]) {
   if (m < 6) return false;
@@ -117,26 +212,19 @@ inline bool dlt_pose(const float* opoints, const double* normalised, const int32
   for (int i = 0; i < m; ++i) for (int k = 0; k < 3; ++k) c[k] += opoints[3 * (size_t)idx[i] + k] / m;
   for (int i = 0; i < m; ++i) { double d2 = 0; for (int k = 0; k < 3; ++k) { const double d = opoints[3 * (size_t)idx[i] + k] - c[k]; d2 += d * d; } scale += std::sqrt(d2) / m; }
   if (!(scale > 0.0)) return false;
-  // Coplanar (or collinear) object points: the DLT's null space then has more than one dimension and the eigenvector picked from it
-  // is arbitrary — OpenCV's solvePnP switches to a homography there; this initialisation simply declines (the caller starts from the
-  // zero pose, as the reference does whenever the GS initialisation fails).  Flatness = smallest over largest eigenvalue of the
-  // points' 3 x 3 scatter matrix (closed form for a symmetric 3 x 3).
+  // The shape of the cloud, from the eigenvalues l0 <= l1 <= l2 of the centred points' 3 x 3 scatter: collinear points determine no pose
+  // (declined: the caller starts from the zero pose, as the reference does whenever the GS initialisation fails); coplanar points —
+  // l0 < 1e-3 l1, cv::solvePnP's own test — go through the plane's homography (planar_pose), everything else through the 12-unknown DLT.
   {
     double sc[6] = {0, 0, 0, 0, 0, 0};   // xx xy xz yy yz zz
     for (int i = 0; i < m; ++i) {
       const double d[3] = {(opoints[3 * (size_t)idx[i]] - c[0]) / scale, (opoints[3 * (size_t)idx[i] + 1] - c[1]) / scale, (opoints[3 * (size_t)idx[i] + 2] - c[2]) / scale};
       sc[0] += d[0] * d[0]; sc[1] += d[0] * d[1]; sc[2] += d[0] * d[2]; sc[3] += d[1] * d[1]; sc[4] += d[1] * d[2]; sc[5] += d[2] * d[2];
     }
-    const double q = (sc[0] + sc[3] + sc[5]) / 3.0, p1 = sc[1] * sc[1] + sc[2] * sc[2] + sc[4] * sc[4];
-    const double p2 = (sc[0] - q) * (sc[0] - q) + (sc[3] - q) * (sc[3] - q) + (sc[5] - q) * (sc[5] - q) + 2.0 * p1, pp = std::sqrt(p2 / 6.0);
-    double lmin = q, lmax = q;
-    if (pp > 0.0) {
-      const double b[6] = {(sc[0] - q) / pp, sc[1] / pp, sc[2] / pp, (sc[3] - q) / pp, sc[4] / pp, (sc[5] - q) / pp};
-      const double detb = b[0] * (b[3] * b[5] - b[4] * b[4]) - b[1] * (b[1] * b[5] - b[4] * b[2]) + b[2] * (b[1] * b[4] - b[3] * b[2]);
-      const double phi = std::acos(std::fmin(1.0, std::fmax(-1.0, 0.5 * detb))) / 3.0;
-      lmax = q + 2.0 * pp * std::cos(phi); lmin = q + 2.0 * pp * std::cos(phi + 2.0943951023931953);
-    }
-    if (!(lmin > 1e-6 * lmax)) return false;
+    double val[3], vec[3][3];
+    eigen3(sc, val, vec);
+    if (!(val[1] > 1e-4 * val[2])) return false;   // (a strip a hundred times longer than wide counts as a line)
+    if (val[0] < 1e-3 * val[1]) { const double axes[3][3] = {{vec[2][0], vec[2][1], vec[2][2]}, {vec[1][0], vec[1][1], vec[1][2]}, {vec[0][0], vec[0][1], vec[0][2]}}; return planar_pose(opoints, normalised, idx, m, c, scale, axes, pose); }
   }
   double ata[12][12] = {};
   for (int i = 0; i < m; ++i) {
@@ -158,32 +246,11 @@ inline bool dlt_pose(const float* opoints, const double* normalised, const int32
   if (!(lambda > 1e-300) || !std::isfinite(lambda)) return false;
   double R[9];
   for (int k = 0; k < 9; ++k) R[k] = M[k] / lambda;
-  for (int it = 0; it < 30; ++it) {   // nearest rotation: R <- (R + R^-T) / 2
-    const double det = R[0] * (R[4] * R[8] - R[5] * R[7]) - R[1] * (R[3] * R[8] - R[5] * R[6]) + R[2] * (R[3] * R[7] - R[4] * R[6]);
-    if (!(std::fabs(det) > 1e-12)) return false;
-    const double it_[9] = {(R[4] * R[8] - R[5] * R[7]) / det, (R[5] * R[6] - R[3] * R[8]) / det, (R[3] * R[7] - R[4] * R[6]) / det,
-                           (R[2] * R[7] - R[1] * R[8]) / det, (R[0] * R[8] - R[2] * R[6]) / det, (R[1] * R[6] - R[0] * R[7]) / det,
-                           (R[1] * R[5] - R[2] * R[4]) / det, (R[2] * R[3] - R[0] * R[5]) / det, (R[0] * R[4] - R[1] * R[3]) / det};   // R^-T
-    for (int k = 0; k < 9; ++k) R[k] = 0.5 * (R[k] + it_[k]);
-  }
-  if (R[0] * (R[4] * R[8] - R[5] * R[7]) - R[1] * (R[3] * R[8] - R[5] * R[6]) + R[2] * (R[3] * R[7] - R[4] * R[6]) < 0) return false;
+  if (!nearest_rotation(R)) return false;
   // x_cam ~ R (X - c) / scale + t / lambda  =>  tvec = scale t / lambda - R c (up to the common factor 1 / scale, which the projection ignores)
   double tvec[3];
   for (int r = 0; r < 3; ++r) tvec[r] = scale * t[r] / lambda - (R[3 * r] * c[0] + R[3 * r + 1] * c[1] + R[3 * r + 2] * c[2]);
-  // rotation matrix -> angle-axis
-  double rvec[3];
-  const double tr = R[0] + R[4] + R[8], cs = std::fmin(1.0, std::fmax(-1.0, 0.5 * (tr - 1.0))), th = std::acos(cs);
-  const double ax[3] = {R[7] - R[5], R[2] - R[6], R[3] - R[1]};
-  const double sn = 0.5 * std::sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
-  if (sn > 1e-8) for (int k = 0; k < 3; ++k) rvec[k] = ax[k] * (th / (2.0 * sn));
-  else if (cs > 0) for (int k = 0; k < 3; ++k) rvec[k] = 0.5 * ax[k];
-  else {   // a half turn: the axis from the diagonal
-    const double d[3] = {std::sqrt(std::fmax(0.0, 0.5 * (R[0] + 1.0))), std::sqrt(std::fmax(0.0, 0.5 * (R[4] + 1.0))), std::sqrt(std::fmax(0.0, 0.5 * (R[8] + 1.0)))};
-    rvec[0] = th * d[0]; rvec[1] = th * d[1] * (R[1] + R[3] >= 0 ? 1.0 : -1.0); rvec[2] = th * d[2] * (R[2] + R[6] >= 0 ? 1.0 : -1.0);
-  }
-  to_pose(rvec, tvec, pose);
-  for (int k = 0; k < 6; ++k) if (!std::isfinite(pose[k])) return false;
-  return true;
+  return pose_from_rt(R, tvec, pose);
 }
 inline std::vector<double> normalised_points(const double cam[NUM_CAM_PARAMS], const float* ipoints, int n) {
   std::vector<double> out(2 * (size_t)n);

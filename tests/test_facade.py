@@ -441,11 +441,11 @@ def test_dlt_of_the_global_shutter_pnp_initialisation_recovers_the_pose(oracle, 
         assert np.max(np.abs(rvec - pose[:3])) <= 2e-3 and np.max(np.abs(centre - pose[3:])) <= 2e-2, (rvec, pose, centre)
 
 
-def test_dlt_declines_planar_targets(oracle, tmp_path):
-    """Coplanar object points (a checkerboard, a wall) leave the DLT's null space two-dimensional: the eigenvector picked from it is
-    arbitrary, and an arbitrary pose must not be handed on as the global-shutter initialisation (OpenCV's solvePnP switches to a
-    homography there).  The host glue declines — exactly planar, nearly planar (1e-4 of the extent), collinear — and still accepts
-    a shallow but genuinely three-dimensional cloud."""
+def test_dlt_takes_planar_targets_through_the_homography(oracle, tmp_path):
+    """Coplanar object points (a checkerboard, a wall) leave the 12-unknown DLT's null space two-dimensional.  cv::solvePnP — what the
+    reference calls at solveRSpnp.cpp:111-117 — starts from the plane's homography there (two smallest singular values of the centred
+    points' scatter in a ratio below 1e-3); so does the host glue: exactly planar and nearly planar (1e-4 of the extent) targets give
+    the pose back, collinear points are declined, a shallow but genuinely three-dimensional cloud takes the 12-unknown DLT."""
     import struct
     import __graft_entry__ as G
     exe = os.path.join(ROOT, "examples", "pnp_ransac")
@@ -476,8 +476,13 @@ def test_dlt_declines_planar_targets(oracle, tmp_path):
     normal, origin = np.array([0.2, -0.1, 1.0]), np.array([0.0, 0.0, 9.0])
     e1 = np.cross(normal, [1.0, 0, 0]); e1 /= np.linalg.norm(e1); e2 = np.cross(normal, e1); e2 /= np.linalg.norm(e2)
     plane = origin + uv[:, :1] * e1 + uv[:, 1:] * e2
-    assert not run(plane)[0]                                                        # exactly planar
-    assert not run(plane + 2e-4 * rng.normal(size=(40, 1)) * normal / np.linalg.norm(normal))[0]   # planar up to 1e-4 of its extent
+    for X in (plane, plane + 2e-4 * rng.normal(size=(40, 1)) * normal / np.linalg.norm(normal)):   # exactly planar; planar up to 1e-4 of its extent
+        ok, v = run(X)
+        assert ok
+        centre = -oracle.angle_axis_rotate(-v[0:3], v[3:6])
+        assert np.max(np.abs(v[0:3] - pose[:3])) <= 5e-3 and np.max(np.abs(centre - pose[3:])) <= 5e-2, (v, pose, centre)
+    ok, v = run(plane[:6])                                                          # a minimal RANSAC subset on the plane
+    assert ok and np.max(np.abs(v[0:3] - pose[:3])) <= 2e-2
     assert not run(origin + uv[:, :1] * e1 + 1e-3 * uv[:, 1:] * e2)[0]              # (almost) collinear
     ok, v = run(plane + 0.3 * rng.normal(size=(40, 1)) * normal / np.linalg.norm(normal))   # shallow, but three-dimensional
     assert ok
