@@ -123,7 +123,7 @@ def roofline_lm(prob, dp, iters, capi):
     cd = 6 * prob.poses_per_frame
     rec = 8 * (2 + 2 * k)                       # the point-major record of one observation
     prec = 8 * cd * 3                           # its P record
-    pgroups = st["schur_groups"] * 3 * 48 * 8   # the P records as the Schur kernel reads them: one [3][48] block per (point, frame tile)
+    pgroups = st.get("schur_group_bytes") or st["schur_groups"] * 3 * 48 * 8   # the P records as the Schur kernel reads them: one block per (point, frame tile) — [3][48] doubles, or the 640-B factored form of a two-pose frame tile
     recompute = prob.calibrated or prob.num_intrinsics == 1
     if recompute:   # the point-side passes recompute the records from the observations (24 B each, slot order) instead of streaming 256-B copies
         obs = n * 24 + prob.num_frames * prob.poses_per_frame * 96 + m * 48

@@ -435,9 +435,10 @@ __device__ __forceinline__ bool factor_invert_tile(double* D, double* Wl, double
 // Result layout of the instruction (measured, tools/mfma_f64_check.hip): lane holds rows g + 4v (v < 4), column r.
 typedef double dbl4 __attribute__((ext_vector_type(4)));
 
+constexpr bool kCachedOperands = true;   // (false: every operand load coherent, as in rounds 1 - 4; A/B by rebuilding)
 struct Frag {
   double v[3][3];   // [row block I][step t]
-  template <bool DAG>
+  template <bool DAG, bool COHERENT>
   __device__ __forceinline__ void load(const double* tile, int wave, int lane);
 };
 
@@ -520,13 +521,19 @@ __device__ __forceinline__ double* factor_ptr(const SolverDev& sv, int slot) { r
 
 
 
-template <bool DAG>
+// COHERENT = false: ordinary loads, served by this XCD's L2 (and the CU's L1) when they hold the line.  A cell is written once, so what
+// such a load returns is either the cell's final value or "empty" — possibly a stale empty (a copy cached before the producer's store, which
+// went to the memory side); the caller checks every double it consumes and reads an incomplete fragment again COHERENTLY (sc1: from the
+// memory side).  A factor tile is an operand of ~12 products in as many tasks (chol_dag_kernel pulled 12 x the factor's size from the
+// fabric when every operand load was coherent): the tasks that come after the first find it in L2.  Lines of an EARLIER solve cannot
+// be met: the cells are re-armed by a launch of their own, and a launch starts with its XCD's L2 invalidated.
+template <bool DAG, bool COHERENT>
 __device__ __forceinline__ void Frag::load(const double* tile, int wave, int lane) {
   const double* p = tile + (lane & 15) * T + 12 * wave + 3 * (lane >> 4);
 #pragma unroll
   for (int I = 0; I < 3; ++I)
 #pragma unroll
-    for (int t = 0; t < 3; ++t) v[I][t] = ld<DAG>(p + 16 * I * T + t);
+    for (int t = 0; t < 3; ++t) v[I][t] = (DAG && COHERENT) ? ld<true>(p + 16 * I * T + t) : gl(p + 16 * I * T + t);
 }
 
 // sum_{p in [p0,p1)} L_a(p) L_b(p)^T into acc (K-split over the waves), and for DIAG lists sum L_jk z_k into
@@ -544,12 +551,13 @@ __device__ __forceinline__ void accumulate(const SolverDev& sv, const CholPlan& 
   constexpr int kGroup = 1;   // (one contributor ahead: with two, the operand registers push the persistent kernel past 256 per lane and a CU holds one workgroup instead of two)
   struct Group { Frag a[kGroup], b[kGroup]; double z[kGroup][3]; };
   Group cur, nxt;
-  auto fetch_group = [&](Group& g, int p) {
+  auto fetch_group = [&](Group& g, int p, auto coherent) {   // (coherent: std::true_type — the second look at a group that came in incomplete; the look ahead goes through the caches)
+    constexpr bool C = decltype(coherent)::value || !kCachedOperands;
 #pragma unroll
     for (int u = 0; u < kGroup; ++u) {
       const int q = min(p + u, p1 - 1);
-      g.a[u].template load<DAG>(factor_ptr(sv, gl(list + 2 * q)), wave, lane);
-      if (!DIAG) g.b[u].template load<DAG>(factor_ptr(sv, gl(list + 2 * q + 1)), wave, lane);
+      g.a[u].template load<DAG, C>(factor_ptr(sv, gl(list + 2 * q)), wave, lane);
+      if (!DIAG) g.b[u].template load<DAG, C>(factor_ptr(sv, gl(list + 2 * q + 1)), wave, lane);
       else {
         const double* zk = sv.zv + (size_t)gl(list + 2 * q + 1) * T + 12 * wave + 3 * (lane >> 4);
         g.z[u][0] = ld<DAG>(zk); g.z[u][1] = ld<DAG>(zk + 1); g.z[u][2] = ld<DAG>(zk + 2);
@@ -584,10 +592,10 @@ __device__ __forceinline__ void accumulate(const SolverDev& sv, const CholPlan& 
       }
     }
   };
-  fetch_group(cur, p0);
+  fetch_group(cur, p0, std::false_type{});
   for (int p = p0; p < p1; p += kGroup) {
     const int pn = p + kGroup;
-    if (pn < p1) fetch_group(nxt, pn);
+    if (pn < p1) fetch_group(nxt, pn, std::false_type{});
     if (DAG) {
       bool late = false;
       while (!complete(cur)) {
@@ -595,7 +603,7 @@ __device__ __forceinline__ void accumulate(const SolverDev& sv, const CholPlan& 
         const int q = min(p + kGroup, p1) - 1;
         watch_cell<DAG>(factor_ptr(sv, gl(list + 2 * q)) + 12 * wave);
         if (!DIAG) watch_cell<DAG>(factor_ptr(sv, gl(list + 2 * q + 1)) + 12 * wave);
-        fetch_group(cur, p);
+        fetch_group(cur, p, std::true_type{});
         late = true;
       }
       if (late) note_late_input();
