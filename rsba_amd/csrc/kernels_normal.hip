@@ -636,19 +636,27 @@ __device__ __forceinline__ int schur_chunk(const SolverDev& sv, const double* __
     }
   }
   if (lane == 0 && issued) atomicAdd(sv.schur_mfma_count, (unsigned long long)issued);   // a statistic (bench.py: issued against useful flops), not a result
-  if (tid == 0) {
+  if (wave == 0) {
     const int64_t slots = (int64_t)(gridDim.x >> 3);      // (the first gridDim.x / 8 of every eighth went to the workgroups as they started)
-    int64_t i = slots + ticket, c = (int64_t)xcd * per_xcd + i;
+    int64_t i = slots + (unsigned)__builtin_amdgcn_readfirstlane((int)ticket), c = (int64_t)xcd * per_xcd + i;
     int nx = persistent && i < per_xcd && c < sv.nchunk ? (int)c : -1;
-    // its own eighth is done: the next chunk of another XCD's (the eighths have the same number of chunks, not of entries — without this the
-    // launch ramps down over two chunk times)
-    for (int k = 1; k < 8 && persistent && nx < 0; ++k) {
-      const int y = (xcd + k) & 7;
-      i = slots + __hip_atomic_fetch_add(sv.schur_next + 16 * y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      c = (int64_t)y * per_xcd + i;
-      if (i < per_xcd && c < sv.nchunk) nx = (int)c;
+    // its own eighth is done: the next chunk of another XCD's (the eighths have the same number of chunks, not of entries).  The other
+    // counters are LOOKED at first, all at once — one round trip — and asked only where the look says there is something left: at the end
+    // of the launch (and in a launch with a workgroup per chunk) nobody queues seven dependent atomics in front of its last epilogue.
+    if (persistent && nx < 0 && per_xcd > slots) {
+      const unsigned seen = lane < 8 ? __hip_atomic_load(sv.schur_next + 16 * ((xcd + lane) & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+      for (int k = 1; k < 8 && nx < 0; ++k) {
+        const int y = (xcd + k) & 7;
+        const int64_t left = (int64_t)slots + (unsigned)__shfl((int)seen, k, 64);
+        if (left >= per_xcd || (int64_t)y * per_xcd + left >= sv.nchunk) continue;
+        unsigned t = 0;
+        if (lane == 0) t = __hip_atomic_fetch_add(sv.schur_next + 16 * y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        i = slots + (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+        c = (int64_t)y * per_xcd + i;
+        if (i < per_xcd && c < sv.nchunk) nx = (int)c;
+      }
     }
-    s_next[0] = nx;
+    if (lane == 0) s_next[0] = nx;
   }
   __syncthreads();   // everyone is done with the tables: the same LDS now takes the four partial tiles
   if (tr && tid == 0) { tr[4] = wall_clock64(); tr[7] += clock64(); }   // (shader cycles of the loop: the clock under this load)

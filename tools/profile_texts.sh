@@ -18,4 +18,4 @@ timeout 120 tools/xcd_handoff > $OUT/xcd_handoff.txt 2>&1
 { for C in C4 C5; do for FAC in 0 1; do echo "== $C RSBA_FACTORED=$FAC"; RSBA_FACTORED=$FAC python tools/phase_time.py $C 8 2>&1 | $F; done; done; } > $OUT/factored_groups_ab.txt
 python tools/lm_time.py C4 12 priors 2>&1 | $F > $OUT/lm_time_c4_priors.txt
 python tools/filter_time.py 2>&1 | $F > $OUT/filter_time.txt
-python -m pytest tests -m gpu -q 2>&1 | $F | tail -15 > $OUT/pytest_gpu.txt
+python -m pytest tests -m gpu -q 2>&1 | $F | grep -E "passed|failed|error|Error" | tail -8 > $OUT/pytest_gpu.txt
