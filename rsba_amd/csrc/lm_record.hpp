@@ -52,7 +52,7 @@ __device__ __forceinline__ void lm_observation(const DeviceProblem& dp, int f, i
   for (int k = 0; k < K; ++k) dropped = dropped && (sc[k] == 0.0);
   // Corrector (Ceres 1.9 corrector.cc) for rho'' <= 0, which always holds for Huber: residual
   // and Jacobian rows are scaled by sqrt(rho').
-  const double sr1 = sqrt(rho[1]);
+  const double sr1 = dp.huber_a > 0.0 ? sqrt(rho[1]) : 1.0;   // (without a loss rho' is exactly 1: the same bits, and no fp64 square root — thirty instructions — per observation)
   o.r[0] *= sr1; o.r[1] *= sr1;
 #pragma unroll
   for (int k = 0; k < K; ++k) { const double c = sr1 * sc[k]; o.J[0][k] *= c; o.J[1][k] *= c; }

@@ -639,3 +639,38 @@ def test_the_symbolic_phase_on_the_device_builds_the_same_plan(capi, monkeypatch
     assert a[6] == b[6], (a[6], b[6])
     assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2]
     assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5])
+
+
+@pytest.mark.parametrize("case", ["c2", "small_intrinsics", "few_chunks"])
+def test_resident_schur_workgroups_leave_the_same_bits_as_a_workgroup_per_chunk(capi, monkeypatch, case):
+    """The Schur kernel's default form keeps 512 workgroups resident; each takes chunk after chunk from per-XCD counters (another XCD's
+    when its own eighth of the list is done) with the next chunk's tables loaded under the epilogue (kernels_normal.hip,
+    schur_tile_kernel).  RSBA_SCHUR_VARIANT=2 launches a workgroup per chunk, as rounds 2 - 4 did.  Which workgroup forms a chunk's
+    partial tile must not show: same partial tiles, same merge order, every bit of the solve the same — with more chunks than resident
+    workgroups (C2's 453 < 512 exercises the start-up map only; the blocked numbering of the second case makes thousands of small
+    chunks, so that the counters and the stealing run), and with fewer chunks than XCDs."""
+    from rsba_amd.scene import make_config
+    def problem():
+        if case == "c2":
+            return make_config("C2").problem
+        if case == "few_chunks":
+            return small_scene(frames=6, points=300, seed=5, rolling=True)
+        p = small_scene(frames=60, points=6000, seed=37, rolling=True)
+        p.calibrated = False; p.huber_a = 2.0
+        monkeypatch.setenv("RSBA_SCHUR_BLOCK", "16")
+        return p
+    out = {}
+    for variant in ("0", "2"):
+        monkeypatch.setenv("RSBA_SCHUR_VARIANT", variant)
+        p = problem()
+        with capi.DeviceProblem(p) as dp:
+            s, tr = dp.solve(capi.default_options(max_num_iterations=6))
+            st = dp.plan_stats()
+            s2, tr2 = dp.solve(capi.default_options(max_num_iterations=2))   # (a second launch sequence on the same counters)
+        out[variant] = (s.final_cost, [t.cost for t in tr], s2.final_cost, p.poses.copy(), p.points.copy(), p.intrinsics.copy(), st["schur_chunks"], st["schur_mfma_issued"])
+    a, b = out["0"], out["2"]
+    if case == "small_intrinsics":
+        assert a[6] > 1024, a[6]
+    assert a[6] == b[6] and a[7] == b[7]
+    assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2]
+    assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5])
