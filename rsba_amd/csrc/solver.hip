@@ -1380,11 +1380,16 @@ int32_t build_solver_impl(rsba_handle* h) {
   }
   int cus = 0;
   HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
-  // One persistent workgroup per CU.  Claimed tasks that wait for their inputs hold a workgroup and the schedule is short of them
-  // (192 instead of 256 workgroups cost 5 % at C4), and the kernel is built so that two fit a CU (78 KB of LDS, <= 256
-  // registers per lane) — but with 384 or 512 resident workgroups the solve slows down by three orders of magnitude (waves
-  // that poll share a SIMD with the waves they wait for); RSBA_CHOL_WGS is there to experiment with, capped at two per CU.
+  // One persistent workgroup per CU — or two, for a WIDE task graph.  Claimed tasks that wait for their inputs hold a workgroup and the
+  // schedule is short of them (192 instead of 256 workgroups cost 5 % at C4); the kernel is built so that two fit a CU (78 KB of LDS,
+  // <= 256 registers per lane).  Through round 4 two per CU slowed the solve down by orders of magnitude: twice the waves polling AND every
+  // operand load going to the memory side.  With the operand tiles looked ahead at through L2 (cholesky.hip, Frag::load) that is gone:
+  // 512 workgroups are stable (C5 7.54 - 7.64 ms per LM iteration in six runs against 7.86 - 7.96 with 256, 384 in between) where a level of
+  // the elimination tree holds more tasks than there are CUs (C5: 380 per level), and change nothing where the chain dominates (C4: 116 per
+  // level, 1.62 ms either way).  RSBA_CHOL_WGS overrides, capped at two per CU.
   s->dag_workgroups = std::max(1, std::min(pl.ntasks, std::max(cus, 1)));
+  const int64_t my_tasks = s->sharded ? (int64_t)s->plan_a.ntasks + s->plan_b.ntasks : (int64_t)pl.ntasks;   // (what THIS rank runs)
+  if (s->nlev > 0 && my_tasks > (int64_t)s->nlev * std::max(cus, 1)) { s->dag_workgroups = std::max(1, std::min(pl.ntasks, 2 * std::max(cus, 1))); s->dag_one_per_cu = false; }
   // A small plan (100 cameras: 267 tasks, ~15 per elimination level) is served better by a quarter as many workgroups as tasks — fewer
   // pollers around the chain: 0.428 -> 0.418 ms per iteration, three runs each — and leaves the rest of the chip to other streams.
   if (pl.ntasks <= 512) s->dag_workgroups = std::max(1, std::min(s->dag_workgroups, std::max(64, pl.ntasks / 4)));
