@@ -67,7 +67,7 @@ struct SolverDev {
   const int32_t* ent_pt;        // [nent] point index; top bit set = the entry carries the rhs term P z
   int schur_linear;             // debugging (RSBA_SCHUR_LINEAR=1): blockIdx -> chunk without the XCD map
   long long* schur_trace;       // debugging (RSBA_SCHUR_TRACE=<file>): [nchunk][8] {workgroup, xcc/cu id, start, tables staged, loop done, end (100 MHz ticks), entries, -} of the last launch
-  int schur_variant;            // tuning aid (RSBA_SCHUR_VARIANT): 0 = two groups in flight, two waves per SIMD; 1 = three groups, one wave
+  int schur_variant;            // tuning aid (RSBA_SCHUR_VARIANT): 0 = two groups in flight, two waves per SIMD, resident workgroups; 1 = three groups, one wave; 2 = a workgroup per chunk; 4 / 5 = ablations
   int nchunk;                   // workgroups of the Schur kernel: kSchurChunk entries each
   const int32_t* chunk_tp;      // [nchunk]
   const int64_t* chunk_e0;      // [nchunk] first entry of the chunk
