@@ -69,3 +69,12 @@ for l, (a, b) in enumerate(runs):
 ts = np.linspace(0, us[:, 2].max(), 40)
 busy = [(int(((us[:, 0] <= t) & (us[:, 2] > t)).sum()), int(((us[:, 1] <= t) & (us[:, 2] > t)).sum())) for t in ts]
 print("claimed / working (past their last late input) tasks at 40 sample times:", " ".join(f"{a}/{b}" for a, b in busy))
+# the slowest DIAG task of each of the first levels, absolute times: where do the leaf levels lose their time?
+print("slowest DIAG task of a level (absolute us): level | claimed  late-input  accumulate-end  W-in-registers  factor-start  factor-end  done | prev level's slowest done")
+prev_done = 0.0
+for li, (a, b) in enumerate(runs[:24]):
+    idx = np.arange(a, b)
+    k = idx[np.argmax(us[idx, 2])]
+    ab = [us[k, 0], us[k, 1]] + [((tr[k, j] - tr[k, 1]) * 0.01 + us[k, 0]) if tr[k, j] > 0 else float('nan') for j in (3, 5, 4, 6)] + [us[k, 2]]
+    print(f"  {li:3d} | " + " ".join(f"{x:8.1f}" for x in ab) + f" | {prev_done:8.1f}   (W-in-registers - prev done {ab[3] - prev_done:5.1f}; done - W-in-registers {ab[6] - ab[3]:5.1f})")
+    prev_done = us[k, 2]
