@@ -932,10 +932,14 @@ __device__ __forceinline__ void slot_record(const DeviceProblem& dp, const Solve
 // tau: the twelve rows (1 - tau) q | tau q are formed by the Schur kernel in registers, the column scales are applied where its partial
 // tiles are merged.  Half the bytes written here (the pass is bound by its stores) and read there.
 //   group layout: [c][16] sources s = 0..15 of coordinate c | [c][8] sources 16..23 | tau[4];  source s = 6 (frame position in the tile) + pose coordinate
-template <bool CAL, int P>
-__global__ __launch_bounds__(256) void project_rc_kernel(const DeviceProblem dp, const SolverDev sv, int nch) {
+// ALLF: every slot's group is factored (SolverDev::all_real_factored — the rule for two-pose problems; a tile that mixes real and pseudo
+// frames is the exception): 19 doubles per slot go through LDS instead of 36 — 40 KB per workgroup instead of 76, and with the register
+// budget of three waves per SIMD the pass, which is bound by its fp64 arithmetic, runs three workgroups per CU instead of two.
+template <bool CAL, int P, bool ALLF>
+__global__ __launch_bounds__(256, ALLF ? 3 : 1) void project_rc_kernel(const DeviceProblem dp, const SolverDev sv, int nch) {
   if (lm_stopped(sv.ctl)) return;   // (device-side trust region: the solve is over, iterations enqueued ahead fall through)
-  constexpr int CD = 6 * P, OUT = CD * 3, PITCH = OUT | 1, kPer = 64 / CD, OP = CAL ? 0 : 9;   // OP: the pose columns follow the 9 intrinsics columns
+  static_assert(!ALLF || P == 2, "factored groups are a two-pose form");
+  constexpr int CD = 6 * P, OUT = CD * 3, PITCH = ALLF ? 19 : (OUT | 1), kPer = 64 / CD, OP = CAL ? 0 : 9;   // OP: the pose columns follow the 9 intrinsics columns
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double* buf = smem + (size_t)wave * (64 * PITCH + 32);
@@ -958,7 +962,7 @@ __global__ __launch_bounds__(256) void project_rc_kernel(const DeviceProblem dp,
       B[r][0] = p0 * i00; B[r][1] = p0 * i10 + p1 * i11; B[r][2] = p0 * i20 + p1 * i21 + p2 * i22;
     }
     const uint32_t gpos = sv.slot_gpos[s];
-    if (P == 2 && gpos_factored(gpos)) {
+    if (ALLF || (P == 2 && gpos_factored(gpos))) {
 #pragma unroll
       for (int a = 0; a < 6; ++a)
 #pragma unroll
@@ -971,7 +975,7 @@ __global__ __launch_bounds__(256) void project_rc_kernel(const DeviceProblem dp,
         for (int k = 0; k < 3; ++k) buf[lane * PITCH + k * CD + a] = o.J[0][OP + a] * B[0][k] + o.J[1][OP + a] * B[1][k];
     }
     s_gpos[lane] = gpos;
-    const bool any_factored = P == 2 && __ballot(gpos_factored(gpos)) != 0ull, any_full = __ballot(!(P == 2 && gpos_factored(gpos))) != 0ull;   // (wave-uniform: a wave's slots are almost always of one kind)
+    const bool any_factored = ALLF || (P == 2 && __ballot(gpos_factored(gpos)) != 0ull), any_full = !ALLF && __ballot(!(P == 2 && gpos_factored(gpos))) != 0ull;   // (wave-uniform: a wave's slots are almost always of one kind)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (any_factored) {
       // factored slots: six lanes per slot (a pose coordinate each), ten slots per pass; the lane of coordinate 0 also stores tau
@@ -983,7 +987,7 @@ __global__ __launch_bounds__(256) void project_rc_kernel(const DeviceProblem dp,
           const int sl = i * kPerF + my;
           if (sl < nslot) {
             const uint32_t gp = s_gpos[sl];
-            if (gpos_factored(gp)) {
+            if (ALLF || gpos_factored(gp)) {
               const int src_no = 6 * gpos_pos(gp) + w;   // source 0..23 of the group
               double* dst = sv.Pm + gpos_group(gp) + (src_no < 16 ? src_no : 48 + (src_no - 16));
               const int stride = src_no < 16 ? 16 : 8;
@@ -1035,12 +1039,16 @@ inline int sweep_points(int64_t M) {
 // numbers over the point's slots in slot order (the same order as ever: same bits) — when only the 16 lanes that own a point did
 // this, the other 48 waited through 20 x NC dependent LDS reads and adds per point: most of the sweep's time (the virtual-record sweep
 // of a shared intrinsics block, NC = 27, took 0.91 ms at 4k cameras against 0.35 for NC = 9 over the same records).
-template <bool CAL, int P, int NC, class PerSlot, class PerPoint>
+// NCP: the slots' numbers go through LDS NCP components at a time (NC / NCP passes per 64 slots, the record computed once): the 27 of the
+// virtual-record sweep in three passes of nine take 18 KB per workgroup instead of 55 — room beside the projection pass, which runs at the
+// same time on its own stream — and the pairs' slot ranges are kept once per pass layout, not per component.
+template <bool CAL, int P, int NC, int NCP = NC, class PerSlot, class PerPoint>
 __device__ __forceinline__ double point_sweep(const DeviceProblem& dp, const SolverDev& sv, double* smem, int sp, int64_t block, PerSlot per_slot, PerPoint per_point) {
-  constexpr int NPAIR = kSweepPoints * NC, PER = (NPAIR + 63) / 64;   // (sized for the most points a wave takes; sp <= kSweepPoints of them this launch)
+  static_assert(NC % NCP == 0 && kSweepPoints * NC <= 64 * NCP, "passes of equal width; the final gather fits the buffer");
+  constexpr int NPART = NC / NCP, NPAIR = kSweepPoints * NCP, PER = (NPAIR + 63) / 64;   // pairs (point, component of a pass): sized for the most points a wave takes; sp <= kSweepPoints of them this launch
   __shared__ double s_red[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double* cbuf = smem + (size_t)wave * (64 * NC);
+  double* cbuf = smem + (size_t)wave * (64 * NCP);
   const int64_t j0 = (block * 4 + wave) * sp;
   double ret = 0.0;
   auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
@@ -1050,48 +1058,55 @@ __device__ __forceinline__ double point_sweep(const DeviceProblem& dp, const Sol
     const int64_t j = j0 + (mine ? lane : 0);
     const int64_t lo = mine ? sv.point_ptr[j] : 0, hi = mine ? sv.point_ptr[j + 1] : 0;
     const int64_t sb = sv.point_ptr[j0], se = sv.point_ptr[j0 + jn];
-    // this lane's pairs: pair = lane + 64 i -> point pair / NC of the wave, component pair % NC; the point's slot range from its owner lane
-    double acc[PER]; int64_t plo[PER], phi[PER]; int pq[PER];
+    // this lane's pairs: pair = lane + 64 i -> point pair / NCP of the wave, component pair % NCP of every pass; the point's slot range from its owner lane
+    double acc[NPART][PER]; int64_t plo[PER], phi[PER]; int pq[PER], pp[PER];
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-      const int pair = lane + 64 * i, pj = pair / NC;
-      acc[i] = 0.0; pq[i] = pair % NC;
+      const int pair = lane + 64 * i, pj = pair / NCP;
+#pragma unroll
+      for (int part = 0; part < NPART; ++part) acc[part][i] = 0.0;
+      pq[i] = pair % NCP; pp[i] = pj;
       const long long l = __shfl((long long)lo, pj < kSweepPoints ? pj : 0, 64), h = __shfl((long long)hi, pj < kSweepPoints ? pj : 0, 64);
-      const bool live = pair < jn * NC;
+      const bool live = pair < jn * NCP;
       plo[i] = live ? l : 0; phi[i] = live ? h : 0;
     }
     for (int64_t c0 = sb; c0 < se; c0 += 64) {
       const int nrec = (int)(se - c0 < 64 ? se - c0 : 64);
+      double c[NC];
       {
         const int64_t s = c0 + lane < se ? c0 + lane : se - 1;
         ObsOut<CAL, P> o;
         int frame, pt;
         slot_record<CAL, P>(dp, sv, s, o, frame, pt);
-        double c[NC];
         per_slot(o, frame, pt, c);
-#pragma unroll
-        for (int q = 0; q < NC; ++q) cbuf[lane * NC + q] = c[q];
       }
-      wave_sync();
-      // (four numbers of a pair are READ before the first of them is added — in slot order, as ever: the same bits — with the rows' offsets
-      // in the instructions: 2.5 instructions per number instead of the 9 of the plain loop, which was 17 - 29 % of these passes)
 #pragma unroll
-      for (int i = 0; i < PER; ++i) {
-        const int lo = (int)((plo[i] > c0 ? plo[i] : c0) - c0), hi = (int)((phi[i] < c0 + nrec ? phi[i] : c0 + nrec) - c0);
-        const double* col = cbuf + pq[i];
-        int k = lo;
-        for (; k + 4 <= hi; k += 4) {
-          const double* p = col + k * NC;
-          const double v0 = p[0], v1 = p[NC], v2 = p[2 * NC], v3 = p[3 * NC];
-          acc[i] += v0; acc[i] += v1; acc[i] += v2; acc[i] += v3;
+      for (int part = 0; part < NPART; ++part) {
+#pragma unroll
+        for (int q = 0; q < NCP; ++q) cbuf[lane * NCP + q] = c[part * NCP + q];
+        wave_sync();
+        // (four numbers of a pair are READ before the first of them is added — in slot order, as ever: the same bits — with the rows' offsets
+        // in the instructions: 2.5 instructions per number instead of the 9 of the plain loop, which was 17 - 29 % of these passes)
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+          const int klo = (int)((plo[i] > c0 ? plo[i] : c0) - c0), khi = (int)((phi[i] < c0 + nrec ? phi[i] : c0 + nrec) - c0);
+          const double* col = cbuf + pq[i];
+          int k = klo;
+          for (; k + 4 <= khi; k += 4) {
+            const double* p = col + k * NCP;
+            const double v0 = p[0], v1 = p[NCP], v2 = p[2 * NCP], v3 = p[3 * NCP];
+            acc[part][i] += v0; acc[part][i] += v1; acc[part][i] += v2; acc[part][i] += v3;
+          }
+          for (; k < khi; ++k) acc[part][i] += col[k * NCP];
         }
-        for (; k < hi; ++k) acc[i] += col[k * NC];
+        wave_sync();
       }
-      wave_sync();
     }
-    // the sums of a point back to the lane that owns it
+    // the sums of a point back to the lane that owns it: [point][NC]
 #pragma unroll
-    for (int i = 0; i < PER; ++i) if (lane + 64 * i < NPAIR) cbuf[lane + 64 * i] = acc[i];
+    for (int i = 0; i < PER; ++i)
+#pragma unroll
+      for (int part = 0; part < NPART; ++part) if (lane + 64 * i < NPAIR) cbuf[pp[i] * NC + part * NCP + pq[i]] = acc[part][i];
     wave_sync();
     if (mine) {
       double a[NC];
@@ -1190,7 +1205,7 @@ __global__ __launch_bounds__(256) void virtual_records_rc_kernel(const DevicePro
   if (lm_stopped(sv.ctl)) return;
   constexpr int CD = 6 * P, OX = 9 + CD;
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  point_sweep<false, P, 27>(dp, sv, smem, sp, blockIdx.x,
+  point_sweep<false, P, 27, 9>(dp, sv, smem, sp, blockIdx.x,
     [&](const ObsOut<false, P>& o, int, int j, double c[27]) {
       const double* li = sv.Linv + (size_t)j * 6;
       const double i00 = li[0], i10 = li[1], i11 = li[2], i20 = li[3], i21 = li[4], i22 = li[5];
@@ -1663,10 +1678,12 @@ hipError_t launch_project(const DeviceProblem& dp, const SolverDev& sv, hipStrea
   const int KC = dp.K - 3;
   if (sv.slot_xy) {
     const int CD = sv.CD;
-    const size_t lds = (size_t)4 * (64 * ((CD * 3) | 1) + 32) * sizeof(double);
+    const bool allf = CD == 12 && sv.all_real_factored != 0;
+    const size_t lds = (size_t)4 * (64 * (allf ? 19 : ((CD * 3) | 1)) + 32) * sizeof(double);
     const int nch = project_chunks(dp.N), grid = (int)((dp.N + 256 * (int64_t)nch - 1) / (256 * (int64_t)nch));
-    if (dp.calibrated) { if (CD == 12) hipLaunchKernelGGL((project_rc_kernel<true, 2>), dim3(grid), dim3(256), lds, st, dp, sv, nch); else hipLaunchKernelGGL((project_rc_kernel<true, 1>), dim3(grid), dim3(256), lds, st, dp, sv, nch); }
-    else { if (CD == 12) hipLaunchKernelGGL((project_rc_kernel<false, 2>), dim3(grid), dim3(256), lds, st, dp, sv, nch); else hipLaunchKernelGGL((project_rc_kernel<false, 1>), dim3(grid), dim3(256), lds, st, dp, sv, nch); }
+    if (allf) { if (dp.calibrated) hipLaunchKernelGGL((project_rc_kernel<true, 2, true>), dim3(grid), dim3(256), lds, st, dp, sv, nch); else hipLaunchKernelGGL((project_rc_kernel<false, 2, true>), dim3(grid), dim3(256), lds, st, dp, sv, nch); }
+    else if (dp.calibrated) { if (CD == 12) hipLaunchKernelGGL((project_rc_kernel<true, 2, false>), dim3(grid), dim3(256), lds, st, dp, sv, nch); else hipLaunchKernelGGL((project_rc_kernel<true, 1, false>), dim3(grid), dim3(256), lds, st, dp, sv, nch); }
+    else { if (CD == 12) hipLaunchKernelGGL((project_rc_kernel<false, 2, false>), dim3(grid), dim3(256), lds, st, dp, sv, nch); else hipLaunchKernelGGL((project_rc_kernel<false, 1, false>), dim3(grid), dim3(256), lds, st, dp, sv, nch); }
     return hipGetLastError();
   }
   if (sv.CD == 12 && KC == 12) return launch_project_as<12, 12>(dp, sv, st);
@@ -1685,7 +1702,7 @@ hipError_t launch_virtual_records(const DeviceProblem& dp, const SolverDev& sv, 
   if (sv.NPF == 0) return hipSuccess;
   if (sv.nvgroups == 0) return hipSuccess;
   if (sv.slot_xy) {   // (one intrinsics block: recomputed like the rest)
-    const size_t lds = (size_t)4 * 64 * 27 * sizeof(double);
+    const size_t lds = (size_t)4 * 64 * 9 * sizeof(double);   // (nine of the 27 components at a time: point_sweep)
     const int sp = sweep_points(dp.M), grid = (int)((dp.M + 4 * sp - 1) / (4 * sp));
     if (sv.CD == 12) hipLaunchKernelGGL(virtual_records_rc_kernel<2>, dim3(grid), dim3(256), lds, st, dp, sv, sp);
     else hipLaunchKernelGGL(virtual_records_rc_kernel<1>, dim3(grid), dim3(256), lds, st, dp, sv, sp);

@@ -1127,6 +1127,8 @@ int32_t build_solver_impl(rsba_handle* h) {
   int32_t rc;
   sv.tile_factored = nullptr;
   if (factored) up.upload_const(&sv.tile_factored, tile_factored);
+  sv.all_real_factored = factored ? 1 : 0;
+  for (int t = 0; t < nt && (int64_t)t * FT < FR; ++t) if (!tile_factored[t]) sv.all_real_factored = 0;
   up.upload_const(&sv.tp_I, tp_I);
   up.upload_const(&sv.tp_J, tp_J);
   up.upload_const(&sv.tp_ptr, tp_ptr);

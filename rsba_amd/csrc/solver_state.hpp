@@ -62,6 +62,7 @@ struct SolverDev {
                                 //   its records, kGroupFactored (the 6-row factor per frame + tau: see kernels_normal.hip) — one more, all zero, sits behind the last: padding entries of the Schur chunks
   uint32_t zero_off;            // element offset of that all-zero group
   const uint8_t* tile_factored; // [nt] 1 = the groups of this frame tile are stored factored (null: none is)
+  int all_real_factored;        // 1 = every tile that holds a real frame is stored factored: the projection pass stages 19 doubles per slot instead of 36 (kernels_normal.hip, project_rc_kernel)
   int lerp_rot;                 // interpolateRotation of a rolling-shutter model: the rotation rows of a factored group carry (1 - tau) / tau like the translation rows (else 1 / 0)
   const uint16_t* ent_mask;     // [nent] bit 3 I + J: block rows 16 I .. of the I-side group and 16 J .. of the J-side group both contain a frame that sees the point
   const int32_t* ent_pt;        // [nent] point index; top bit set = the entry carries the rhs term P z
