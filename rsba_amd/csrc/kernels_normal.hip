@@ -1042,13 +1042,16 @@ inline int sweep_points(int64_t M) {
 // NCP: the slots' numbers go through LDS NCP components at a time (NC / NCP passes per 64 slots, the record computed once): the 27 of the
 // virtual-record sweep in three passes of nine take 18 KB per workgroup instead of 55 — room beside the projection pass, which runs at the
 // same time on its own stream — and the pairs' slot ranges are kept once per pass layout, not per component.
-template <bool CAL, int P, int NC, int NCP = NC, class PerSlot, class PerPoint>
-__device__ __forceinline__ double point_sweep(const DeviceProblem& dp, const SolverDev& sv, double* smem, int sp, int64_t block, PerSlot per_slot, PerPoint per_point) {
-  static_assert(NC % NCP == 0 && kSweepPoints * NC <= 64 * NCP, "passes of equal width; the final gather fits the buffer");
+// WAVE_DOUBLES: a wave's share of the dynamic LDS (>= 64 NCP; the fused sweep below keeps a staging area in the same doubles).  per_slot also
+// gets the slot's index and the wave's LDS; per_batch(wave's LDS, slots of the batch) runs once the 64 slots of a batch have been through
+// per_slot, between two wave barriers, BEFORE the batch's numbers go into the same LDS.
+template <bool CAL, int P, int NC, int NCP, int WAVE_DOUBLES, class PerSlot, class PerBatch, class PerPoint>
+__device__ __forceinline__ double point_sweep_hooked(const DeviceProblem& dp, const SolverDev& sv, double* smem, int sp, int64_t block, PerSlot per_slot, PerBatch per_batch, PerPoint per_point) {
+  static_assert(NC % NCP == 0 && kSweepPoints * NC <= 64 * NCP && WAVE_DOUBLES >= 64 * NCP, "passes of equal width; the final gather fits the buffer");
   constexpr int NPART = NC / NCP, NPAIR = kSweepPoints * NCP, PER = (NPAIR + 63) / 64;   // pairs (point, component of a pass): sized for the most points a wave takes; sp <= kSweepPoints of them this launch
   __shared__ double s_red[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double* cbuf = smem + (size_t)wave * (64 * NCP);
+  double* cbuf = smem + (size_t)wave * WAVE_DOUBLES;
   const int64_t j0 = (block * 4 + wave) * sp;
   double ret = 0.0;
   auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
@@ -1078,8 +1081,9 @@ __device__ __forceinline__ double point_sweep(const DeviceProblem& dp, const Sol
         ObsOut<CAL, P> o;
         int frame, pt;
         slot_record<CAL, P>(dp, sv, s, o, frame, pt);
-        per_slot(o, frame, pt, c);
+        per_slot(o, frame, pt, s, cbuf, c);
       }
+      per_batch(cbuf, nrec, wave_sync);
 #pragma unroll
       for (int part = 0; part < NPART; ++part) {
 #pragma unroll
@@ -1119,6 +1123,12 @@ __device__ __forceinline__ double point_sweep(const DeviceProblem& dp, const Sol
   if (lane == 0) s_red[wave] = ret;
   __syncthreads();
   return s_red[0] + s_red[1] + s_red[2] + s_red[3];
+}
+template <bool CAL, int P, int NC, int NCP = NC, class PerSlot, class PerPoint>
+__device__ __forceinline__ double point_sweep(const DeviceProblem& dp, const SolverDev& sv, double* smem, int sp, int64_t block, PerSlot per_slot, PerPoint per_point) {
+  return point_sweep_hooked<CAL, P, NC, NCP, 64 * NCP>(dp, sv, smem, sp, block,
+    [&](const ObsOut<CAL, P>& o, int frame, int pt, int64_t, double*, double* c) { per_slot(o, frame, pt, c); },
+    [](double*, int, auto&) {}, per_point);
 }
 
 // K2b without records: V_j, g_p,j
@@ -1242,6 +1252,82 @@ __global__ __launch_bounds__(256) void virtual_records_rc_kernel(const DevicePro
     });
 }
 
+// The same sweep writing the slots' (factored) P records as well — project_rc_kernel<false, 2, true> and virtual_records_rc_kernel<2> in ONE
+// pass over the observations of a problem with ONE shared intrinsics block whose real frames' tiles are all factored (C5's class): the two
+// passes evaluate the same observations against the same point factors, and together they are bound by the vector unit they share.
+// A wave's LDS: [64][19] staging of q = Jq^T (Jp L^-T) | tau per slot, then 64 group positions; the sums' nine-component passes reuse its front.
+constexpr int kFusedStage = 19, kFusedWaveDoubles = 64 * kFusedStage + 32;
+__global__ __launch_bounds__(256) void virtual_project_rc_kernel(const DeviceProblem dp, const SolverDev sv, int sp) {
+  if (lm_stopped(sv.ctl)) return;
+  constexpr int P = 2, CD = 12, OX = 9 + CD;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int lane = threadIdx.x & 63;
+  point_sweep_hooked<false, P, 27, 9, kFusedWaveDoubles>(dp, sv, smem, sp, blockIdx.x,
+    [&](const ObsOut<false, P>& o, int, int j, int64_t s, double* wl, double c[27]) {
+      const double* li = sv.Linv + (size_t)j * 6;
+      const double i00 = li[0], i10 = li[1], i11 = li[2], i20 = li[3], i21 = li[4], i22 = li[5];
+      double B[2][3];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const double p0 = o.J[r][OX], p1 = o.J[r][OX + 1], p2 = o.J[r][OX + 2];
+        B[r][0] = p0 * i00; B[r][1] = p0 * i10 + p1 * i11; B[r][2] = p0 * i20 + p1 * i21 + p2 * i22;
+      }
+#pragma unroll
+      for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int m = 0; m < 3; ++m) c[3 * k + m] = o.J[0][k] * B[0][m] + o.J[1][k] * B[1][m];
+      // the slot's factored P record (project_rc_kernel: the same expressions, the same bits)
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) wl[lane * kFusedStage + k * 6 + a] = o.Jq[0][a] * B[0][k] + o.Jq[1][a] * B[1][k];
+      wl[lane * kFusedStage + 18] = o.tau;
+      reinterpret_cast<uint32_t*>(wl + 64 * kFusedStage)[lane] = sv.slot_gpos[s];
+    },
+    [&](double* wl, int nrec, auto& wave_sync) {
+      wave_sync();
+      const uint32_t* s_gpos = reinterpret_cast<const uint32_t*>(wl + 64 * kFusedStage);
+      constexpr int kPerF = 10;   // six lanes per slot (a pose coordinate each), ten slots per pass; the lane of coordinate 0 also stores tau
+      const int my = lane / 6, w = lane % 6;
+      if (my < kPerF) {
+#pragma unroll 2
+        for (int i = 0; i * kPerF < 64; ++i) {
+          const int sl = i * kPerF + my;
+          if (sl < nrec) {
+            const uint32_t gp = s_gpos[sl];
+            const int src_no = 6 * gpos_pos(gp) + w;   // source 0..23 of the group
+            double* dst = sv.Pm + gpos_group(gp) + (src_no < 16 ? src_no : 48 + (src_no - 16));
+            const int stride = src_no < 16 ? 16 : 8;
+            const double* src = wl + sl * kFusedStage + w;
+#pragma unroll
+            for (int comp = 0; comp < 3; ++comp) dst[comp * stride] = src[comp * 6];
+            if (w == 0) sv.Pm[gpos_group(gp) + 72 + gpos_pos(gp)] = wl[sl * kFusedStage + 18];
+          }
+        }
+      }
+      wave_sync();
+    },
+    [&](int64_t j, const double acc[27]) {
+      const int64_t g = sv.point_vgroup[j];
+      if (g < 0) return 0.0;
+      for (int v = 0; v < sv.NPF; ++v) {
+        const uint32_t gpos = sv.slot_gpos[dp.N + g * sv.NPF + v];   // (a pseudo frame's tile: full form)
+        double* out = sv.Pm + gpos_group(gpos) + gpos_pos(gpos) * CD;
+#pragma unroll
+        for (int rl = 0; rl < CD; ++rl) {
+          const int k = v * CD + rl;
+#pragma unroll
+          for (int m = 0; m < 3; ++m) {
+            double q = 0.0;
+#pragma unroll
+            for (int kk = 0; kk < 9; ++kk) if (kk == k) q = acc[3 * kk + m];
+            out[m * kTile + rl] = q;
+          }
+        }
+      }
+      return 0.0;
+    });
+}
 __global__ __launch_bounds__(256) void reduce_sum_kernel(const double* partial, int n, double* out, double sign) {
   __shared__ double s_red[4];
   double v = 0.0;
@@ -1673,8 +1759,17 @@ static hipError_t launch_project_as(const DeviceProblem& dp, const SolverDev& sv
   hipLaunchKernelGGL((project_kernel<CD, KC>), dim3(grid), dim3(256), lds, st, dp, sv);
   return hipGetLastError();
 }
+// does launch_project do the virtual records too?  (decided with the plan, SolverDev::fused_sweep: one shared intrinsics block, recomputed
+// records, two-pose frames all in factored tiles; RSBA_NO_FUSED_SWEEP=1 keeps the two passes apart)
+bool project_covers_virtual_records(const DeviceProblem& dp, const SolverDev& sv) { return sv.fused_sweep != 0 && dp.N > 0; }
 hipError_t launch_project(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {
   if (dp.N == 0) return hipSuccess;
+  if (project_covers_virtual_records(dp, sv)) {
+    const size_t lds = (size_t)4 * kFusedWaveDoubles * sizeof(double);
+    const int sp = sweep_points(dp.M), grid = (int)((dp.M + 4 * sp - 1) / (4 * sp));
+    hipLaunchKernelGGL(virtual_project_rc_kernel, dim3(grid), dim3(256), lds, st, dp, sv, sp);
+    return hipGetLastError();
+  }
   const int KC = dp.K - 3;
   if (sv.slot_xy) {
     const int CD = sv.CD;
@@ -1701,6 +1796,7 @@ hipError_t launch_intr_blocks(const DeviceProblem& dp, const SolverDev& sv, hipS
 hipError_t launch_virtual_records(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st) {
   if (sv.NPF == 0) return hipSuccess;
   if (sv.nvgroups == 0) return hipSuccess;
+  if (project_covers_virtual_records(dp, sv)) return hipSuccess;   // (launch_project's fused sweep wrote them)
   if (sv.slot_xy) {   // (one intrinsics block: recomputed like the rest)
     const size_t lds = (size_t)4 * 64 * 9 * sizeof(double);   // (nine of the 27 components at a time: point_sweep)
     const int sp = sweep_points(dp.M), grid = (int)((dp.M + 4 * sp - 1) / (4 * sp));

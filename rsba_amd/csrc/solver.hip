@@ -1129,6 +1129,7 @@ int32_t build_solver_impl(rsba_handle* h) {
   if (factored) up.upload_const(&sv.tile_factored, tile_factored);
   sv.all_real_factored = factored ? 1 : 0;
   for (int t = 0; t < nt && (int64_t)t * FT < FR; ++t) if (!tile_factored[t]) sv.all_real_factored = 0;
+  sv.fused_sweep = 0;   // (set once the plan knows its virtual groups, below)
   up.upload_const(&sv.tp_I, tp_I);
   up.upload_const(&sv.tp_J, tp_J);
   up.upload_const(&sv.tp_ptr, tp_ptr);
@@ -1282,6 +1283,7 @@ int32_t build_solver_impl(rsba_handle* h) {
     HIP_TRY(launch_slot_xy(h->dp, sxy, h->stream));
     sv.slot_xy = sxy;
   } else if ((rc = s_alloc(s, &h->dp.rec, (size_t)N * REC))) return rc;
+  sv.fused_sweep = sv.slot_xy && !h->dp.calibrated && sv.CD == 12 && sv.all_real_factored != 0 && sv.NPF > 0 && sv.nvgroups > 0 && sv.NIB == 1 && !std::getenv("RSBA_NO_FUSED_SWEEP");
   if (N > 0) {
     // camera (and intrinsics border) blocks inside the evaluation kernel: per (64-observation wave, frame it touches)
     // the 16 x 16 blocks on and below the diagonal of [Ji | Jc | r]^T [Ji | Jc | r]
@@ -1603,7 +1605,7 @@ int32_t reduce_system(rsba_handle* h, double radius) {
     PhaseScope ps(h, RSBA_PHASE_PROJECT);
     // A shared intrinsics block at scale (4k cameras: projection 1.03 ms of stores, virtual-record sweep 0.57 ms of fp64): the two passes
     // read the same point factors and write different records — side by side, the sweep on the arming stream (idle here), two events.
-    const bool beside = sv.NPF > 0 && sv.nvgroups > 0 && s->mstream && s->ev_fork && h->dp.N >= 2000000 && !std::getenv("RSBA_NO_SIDE_SWEEP");
+    const bool beside = sv.NPF > 0 && sv.nvgroups > 0 && s->mstream && s->ev_fork && h->dp.N >= 2000000 && !std::getenv("RSBA_NO_SIDE_SWEEP") && !project_covers_virtual_records(h->dp, sv);   // (round 5: one fused sweep does both where it applies)
     if (beside) {
       HIP_TRY(hipEventRecord(s->ev_fork, st));
       HIP_TRY(hipStreamWaitEvent(s->mstream, s->ev_fork, 0));

@@ -62,6 +62,7 @@ struct SolverDev {
                                 //   its records, kGroupFactored (the 6-row factor per frame + tau: see kernels_normal.hip) — one more, all zero, sits behind the last: padding entries of the Schur chunks
   uint32_t zero_off;            // element offset of that all-zero group
   const uint8_t* tile_factored; // [nt] 1 = the groups of this frame tile are stored factored (null: none is)
+  int fused_sweep;              // 1 = the projection pass and the virtual-record sweep of the shared intrinsics block are ONE launch (kernels_normal.hip, virtual_project_rc_kernel)
   int all_real_factored;        // 1 = every tile that holds a real frame is stored factored: the projection pass stages 19 doubles per slot instead of 36 (kernels_normal.hip, project_rc_kernel)
   int lerp_rot;                 // interpolateRotation of a rolling-shutter model: the rotation rows of a factored group carry (1 - tau) / tau like the translation rows (else 1 / 0)
   const uint16_t* ent_mask;     // [nent] bit 3 I + J: block rows 16 I .. of the I-side group and 16 J .. of the J-side group both contain a frame that sees the point
@@ -214,6 +215,7 @@ hipError_t launch_clamp_diagonal(const DeviceProblem& dp, const SolverDev& sv, d
 hipError_t launch_gradient_max(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);           // -> scalars[kGradMax]
 hipError_t launch_point_factor(const DeviceProblem& dp, const SolverDev& sv, double radius, hipStream_t st, const double* clamp = nullptr);   // clamp = {lo, hi}: launch_clamp_diagonal's job rides along
 hipError_t launch_project(const DeviceProblem& dp, const SolverDev& sv, hipStream_t st);
+bool project_covers_virtual_records(const DeviceProblem& dp, const SolverDev& sv);   // launch_project runs the fused sweep: launch_virtual_records has nothing left to do
 hipError_t launch_clear_system(const SolverDev& sv, hipStream_t st);   // S = 0 (fill tiles start from zero)
 hipError_t launch_schur_blocks(const DeviceProblem& dp, const SolverDev& sv, double radius, hipStream_t st);
 // sharded factorisation: the exchange between its two launches (kernels_normal.hip)

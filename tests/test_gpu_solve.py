@@ -674,3 +674,33 @@ def test_resident_schur_workgroups_leave_the_same_bits_as_a_workgroup_per_chunk(
     assert a[6] == b[6] and a[7] == b[7]
     assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2]
     assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5])
+
+
+@pytest.mark.parametrize("case", ["small", "huber_layers"])
+def test_the_fused_projection_and_virtual_record_sweep_leaves_the_same_bits(capi, monkeypatch, case):
+    """A problem with ONE shared intrinsics block whose two-pose frames all sit in factored tiles evaluates every observation once for
+    the projection pass (the slots' P records) and the virtual-record sweep of the intrinsics pseudo frames together
+    (kernels_normal.hip, virtual_project_rc_kernel); RSBA_NO_FUSED_SWEEP=1 keeps project_rc_kernel and virtual_records_rc_kernel
+    apart.  Same expressions in the same order: every bit of the solve the same."""
+    def problem():
+        p = small_scene(frames=48, points=4000, seed=41, rolling=True)
+        p.calibrated = False
+        if case == "huber_layers":
+            p.huber_a = 2.0
+            dup = np.arange(0, p.num_observations, 23)   # some points seen twice in a frame: a second layer of groups
+            order = np.argsort(np.concatenate([p.obs_frame, p.obs_frame[dup]]), kind="stable")
+            p.obs_xy = np.concatenate([p.obs_xy, p.obs_xy[dup] + 0.25])[order]
+            p.obs_point = np.concatenate([p.obs_point, p.obs_point[dup]])[order]
+            p.obs_frame = np.concatenate([p.obs_frame, p.obs_frame[dup]])[order]
+        return p
+    out = {}
+    for off in ("", "1"):
+        if off: monkeypatch.setenv("RSBA_NO_FUSED_SWEEP", off)
+        else: monkeypatch.delenv("RSBA_NO_FUSED_SWEEP", raising=False)
+        p = problem()
+        with capi.DeviceProblem(p) as dp:
+            s, tr = dp.solve(capi.default_options(max_num_iterations=6))
+        out[off] = (s.final_cost, [t.cost for t in tr], p.poses.copy(), p.points.copy(), p.intrinsics.copy())
+    a, b = out[""], out["1"]
+    assert a[0] == b[0] and a[1] == b[1]
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
