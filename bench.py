@@ -180,27 +180,70 @@ def roofline_lm(prob, dp, iters, capi):
                 r["mfma_busy_source"] = f"profiles/{pr}/pmc_mfma_summary.json (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE per XCD x 1024 SIMDs))"
                 r["mfma_busy_provenance"] = prov
         break
+    # the passes that recompute the observation model are bound by the fp64 VECTOR unit, not by HBM: price them with the fp64 operations the
+    # counters saw (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 per dispatch, a separate rocprofv3 --pmc pass: tools/profile_round.sh,
+    # tools/pmc_valu_summary.py) against the vector unit's fp64 peak (= the MFMA peak: 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz)
+    valu_kernels = {"eval_trial": ("eval_kernel", ", 0>"), "eval_lm": ("eval_kernel", ", 2>"), "point_blocks": ("point_blocks_rc_kernel", ""), "project": ("project_rc_kernel", ""),
+                    "back_substitute": ("point_step_rc_kernel", "")}
+    for pr in sorted((p for p in os.listdir(os.path.join(ROOT, "profiles")) if os.path.exists(os.path.join(ROOT, "profiles", p, "pmc_valu_summary.json"))), reverse=True):
+        with open(os.path.join(ROOT, "profiles", pr, "pmc_valu_summary.json")) as fh:
+            whole = json.load(fh)
+        pv = whole.get(cfg, {})
+        prov = provenance(whole, f"profiles/{pr}/pmc_valu_summary.json")
+        for r in rows:
+            if r["phase"] not in valu_kernels or not recompute:
+                continue
+            sub, tail = valu_kernels[r["phase"]]
+            hits = [v for name, v in pv.items() if sub in name and (not tail or tail in name)]
+            hit = max(hits, key=lambda v: v.get("f64_flops", 0.0), default=None)
+            if not hit or not hit.get("f64_flops"):
+                continue
+            flops = hit["f64_flops"]
+            per_s = flops / (r["ms_per_call"] * 1e-3)
+            r.update(hbm_frac=r.get("frac"), hbm_algorithmic_bytes=r.get("algorithmic_bytes"), bound="valu_f64", algorithmic_flops=flops, flops_per_observation=flops / max(1, n),
+                     achieved=per_s / 1e12, peak=MFMA_F64_PEAK_TFLOPS, unit="TFLOP/s", frac=per_s / 1e12 / MFMA_F64_PEAK_TFLOPS, valu_busy_frac=hit["valu_busy_frac"],
+                     valu_source=f"profiles/{pr}/pmc_valu_summary.json (fp64 wave instructions x 64 lanes, FMA = 2 flop: counted, exec mask not known to the counter; valu_busy_frac = 4 x SQ_ACTIVE_INST_VALU / SIMD cycles)",
+                     valu_provenance=prov)
+            r.pop("algorithmic_bytes", None)
+        break
     return {"phases": rows, "plan": st, "sum_ms_per_lm_iteration": sum(r["ms_per_lm_iteration"] for r in rows),
             "note": "phases are timed with HIP events around each step of the loop's HOST form (rsba_solve with profile_phases: the host decides, a pair of "
                     "events per step, ~10 us each); lm.ms_per_lm_iteration is the unprofiled solve — on one GPU the device-side loop with fewer launches — "
                     "and is therefore below this sum"}
 
 
-def shard_eval(full, world: int, device, capi):
+def shard_eval(full, world: int, device, capi, steps: int = 20):
     """The metric's kernel on ONE rank's shard of an N-rank run, each shard alone on this GPU (rsba_partition_points, BAProblem.shard —
-    what bench.py --gpus N gives rank r): HIP-event kernel time and roofline fraction per shard, and the whole-job rate N GPUs would
-    deliver if each ran its shard as measured here (the evaluation has no collective): scene observations / slowest shard."""
+    what bench.py --gpus N gives rank r).  Two figures per shard: the HIP-event kernel time of back-to-back launches, and the STEP CADENCE
+    — the wall clock around `steps` rsba_evaluate_device calls + a device sync, i.e. exactly the timed region of this script on that
+    rank (launch path, dependent-kernel boundary and the closing sync included; median of 15 repetitions).  The prediction for N GPUs is
+    quoted from the cadence of the slowest shard: the evaluation has no collective, so that is what the driver's N-GPU line measures,
+    stragglers and the other ranks' hosts aside."""
+    import statistics
+    import torch
     owner, _ = capi.partition_points(full, world)
     rows = []
     for r in range(world):
         sh = full.shard(r, world, owner)
         with capi.DeviceProblem(sh, device=device) as d:
             ms = d.time_evaluate(True, warmup=100, iters=200)
+            walls = []
+            for _rep in range(15):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    d.evaluate_device(True)
+                torch.cuda.synchronize()
+                walls.append((time.perf_counter() - t0) / steps * 1e3)
         ab = algorithmic_bytes(sh)
-        rows.append({"rank": r, "observations": int(sh.num_observations), "kernel_ms": ms, "algorithmic_bytes": ab, "frac_of_hbm_peak": ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
+        rows.append({"rank": r, "observations": int(sh.num_observations), "kernel_ms": ms, "step_ms_wall": statistics.median(walls), "step_ms_wall_min": min(walls), "step_ms_wall_max": max(walls),
+                     "algorithmic_bytes": ab, "frac_of_hbm_peak": ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
     worst = max(x["kernel_ms"] for x in rows)
-    return {"world": world, "shards": rows, "slowest_shard_kernel_ms": worst, "predicted_value": full.num_observations / (worst * 1e-3), "unit": "obs evals/s",
-            "note": "kernel time only (HIP events around back-to-back launches on one stream): what each of N GPUs is busy for per step; the driver's N-GPU line adds launch gaps and the clock around K steps"}
+    worst_step = max(x["step_ms_wall"] for x in rows)
+    return {"world": world, "steps_per_repetition": steps, "shards": rows, "slowest_shard_kernel_ms": worst, "slowest_shard_step_ms_wall": worst_step,
+            "predicted_value": full.num_observations / (worst_step * 1e-3), "predicted_value_from_kernel_time": full.num_observations / (worst * 1e-3), "unit": "obs evals/s",
+            "note": "predicted_value = scene observations / the slowest shard's STEP CADENCE (wall clock around K back-to-back rsba_evaluate_device calls + device sync on this GPU: "
+                    "what each rank's timed region is made of); predicted_value_from_kernel_time uses the HIP-event kernel time alone and is the upper bound"}
 
 
 def next_rows(prob, dp, device):
@@ -337,6 +380,10 @@ def main():
     # test hook (one-GPU boxes): RSBA_BENCH_TEST_ONE_GPU=1 runs every rank on device 0 over gloo with the callback exchange
     # (RCCL refuses two ranks on one device), which exercises the whole multi-rank flow of this script without several GPUs
     one_gpu = os.environ.get("RSBA_BENCH_TEST_ONE_GPU") == "1"
+    # ... and RSBA_BENCH_NATIVE=1 with RSBA_RCCL_LIB=tools/libmock_rccl.so (a stream-ordered stand-in for librccl, test infrastructure) sends the
+    # ranks through the branch the driver's node takes — attach_rccl -> rsba_rccl_comm_create -> rsba_set_exchange_rccl, the warm handle on
+    # the same communicator, the LM leg under its watchdog — instead of the gloo callback
+    native_on_one_gpu = one_gpu and os.environ.get("RSBA_BENCH_NATIVE") == "1"
     if one_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -374,7 +421,7 @@ def main():
     transport_error = None
     if world > 1 and not args.no_lm:
         from rsba_amd.distributed import attach, attach_rccl
-        if one_gpu:
+        if one_gpu and not native_on_one_gpu:
             serialize = os.environ.get("RSBA_BENCH_SERIALIZE", "1") == "1"   # ranks sharing the GPU take turns: per-rank device times as on a node
             attach(dp, serialize=serialize)
             transport = "callback: torch.distributed gloo staged through the host (test hook" + ("; ranks take turns on the shared GPU)" if serialize else ")")
@@ -383,9 +430,11 @@ def main():
             # torch's process group) and says why — the evaluation, which needs no collective, is still timed and reported
             try:
                 comm = attach_rccl(dp, local_rank); transport = "native: ncclAllReduce (RCCL over xGMI) issued by librsba_amd on its stream"
+                if native_on_one_gpu:
+                    transport = "native: ncclAllReduce issued by librsba_amd on its stream, served by " + os.path.basename(os.environ.get("RSBA_RCCL_LIB", "?")) + " (test hook: all ranks on one GPU)"
             except Exception as e:  # noqa: BLE001 - reported in the JSON line
                 transport_error = repr(e)
-            ok = torch.tensor([0.0 if transport_error else 1.0], device="cuda")
+            ok = torch.tensor([0.0 if transport_error else 1.0], device="cpu" if one_gpu else "cuda")
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if float(ok.item()) == 0.0:
                 transport_error = transport_error or "another rank could not set up the library's RCCL communicator"
@@ -557,7 +606,7 @@ def main():
             out["next_rows"] = next_rows(prob, dp, local_rank)
         if not args.no_next_rows and world == 1 and not lm_hung and args.config in ("C4", "C5"):
             try:   # what each rank of the 8-GPU run will execute, measured one shard at a time on this GPU
-                out["shard_eval_n8"] = shard_eval(full, 8, local_rank, capi)
+                out["shard_eval_n8"] = shard_eval(full, 8, local_rank, capi, steps=max(1, args.steps))
                 out["shard_eval_n8"]["predicted_speedup_over_this_run"] = out["shard_eval_n8"]["predicted_value"] / out["value"]
             except Exception as e:  # noqa: BLE001
                 out["shard_eval_n8"] = {"error": repr(e)}

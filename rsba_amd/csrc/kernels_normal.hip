@@ -12,6 +12,7 @@
 #include <type_traits>
 
 #include "solver_state.hpp"
+#include "test_hooks.hpp"
 #include <cstdlib>
 
 namespace rsba {
@@ -534,7 +535,7 @@ __device__ __forceinline__ int schur_chunk(const SolverDev& sv, const double* __
     const int k = tid + 256 * u;
     if (k < n16) {
       uint32_t ga = st.ga[u], gb = st.gb[u];
-      if (sv.schur_variant == 5 && k < n) { ga = (uint32_t)(k & 63) * kGroupFull; gb = (uint32_t)(64 + (k & 63)) * kGroupFull; }   // ablation: operands out of the caches
+      if (kTestHooks && sv.schur_variant == 5 && k < n) { ga = (uint32_t)(k & 63) * kGroupFull; gb = (uint32_t)(64 + (k & 63)) * kGroupFull; }   // ablation: operands out of the caches
       s_off[2 * k] = ga; s_off[2 * k + 1] = gb;
       s_msk[(k & 3) * (kSchurChunk / 4) + (k >> 2)] = (uint16_t)(st.pm[u] & kFull);
       if (DIAG) {
@@ -610,7 +611,7 @@ __device__ __forceinline__ int schur_chunk(const SolverDev& sv, const double* __
           double wa0 = 0, wa1 = 0, wa2 = 0, wb0 = 0, wb1 = 0, wb2 = 0;
           if constexpr (FA) { wa0 = __builtin_fma(fl.b0, G.a.tm, fl.a0); wa1 = __builtin_fma(fl.b1, G.a.tm, fl.a1); wa2 = __builtin_fma(fl.b2, G.a.tl, fl.a2); }
           if constexpr (FB) { wb0 = __builtin_fma(fl.b0, G.b.tm, fl.a0); wb1 = __builtin_fma(fl.b1, G.b.tm, fl.a1); wb2 = __builtin_fma(fl.b2, G.b.tl, fl.a2); }
-          if (sv.schur_variant == 4) pm = 0;   // ablation: loads only
+          if (kTestHooks && sv.schur_variant == 4) pm = 0;   // ablation: loads only (instrumented build)
           // ONE code path for full and partial masks: every MFMA behind a scalar test of its block's bit (a second, branch-free path for the
           // full mask made the register allocator keep two homes for the 72 accumulator registers and copy them over around every group:
           // 3.5 v_mov_b64 per MFMA in the round-5 build, 2 in round 4's)

@@ -27,6 +27,7 @@
 #include "solver_state.hpp"
 #include "tile_order.hpp"
 #include "plan_device.hpp"
+#include "test_hooks.hpp"
 
 namespace rsba {
 
@@ -483,8 +484,8 @@ int32_t build_solver_impl(rsba_handle* h) {
   // A plan that cannot be built on THIS rank must not leave the other ranks waiting in the vote further down (one all-reduce in the
   // middle of the plan): a rank-local failure is carried into that vote and every rank fails together; a single rank returns here.
   const bool plan_votes = h->allreduce && h->world > 1 && !h->union_mask.empty();
-  int32_t local_fail = RSBA_OK; const char* local_why = "";
-  if (std::getenv("RSBA_TEST_FAIL_PLAN")) { local_fail = RSBA_ERR_UNSUPPORTED; local_why = "RSBA_TEST_FAIL_PLAN: the plan was made to fail (test hook)"; }   // after the uploader has started
+  int32_t local_fail = RSBA_OK; const char* local_why = ""; std::string dev_why;
+  if (test_hook("RSBA_TEST_FAIL_PLAN")) { local_fail = RSBA_ERR_UNSUPPORTED; local_why = "RSBA_TEST_FAIL_PLAN: the plan was made to fail (test hook)"; }   // after the uploader has started
   else if (pt_total + kGroupFull >= ((int64_t)1 << 32)) { local_fail = RSBA_ERR_UNSUPPORTED; local_why = "more than 2^32 doubles of P records: the Schur kernel indexes them with 32 bits"; }
   if (local_fail && !plan_votes) return rsba_set_error(local_fail, local_why);
   if (!dev_plan) up.upload_const_ref(&sv.slot_gpos, slot_gpos);
@@ -542,17 +543,36 @@ int32_t build_solver_impl(rsba_handle* h) {
   std::vector<int64_t> products_part(1, 0);   // (plan statistics: block products that are not structurally zero)
   if (dev_plan) {
     // ---- the device form of the passes above and below (plan_device.hip) ----
+    // (a failure here — the arena allocations are the likeliest out-of-memory of the symbolic phase — is carried into the vote below
+    // when several ranks plan together, like the two checks above: a rank that returned early would leave the others waiting in it)
     uint8_t* d_tf = nullptr;
-    if (factored) { if (int32_t rc_ = s_upload(s, &d_tf, tile_factored)) return rc_; }
+    if (factored) {
+      if (int32_t rc_ = s_upload(s, &d_tf, tile_factored)) {
+        if (!plan_votes) return rc_;
+        if (!local_fail) { local_fail = rc_; dev_why = std::string("device plan: ") + rsba_last_error(); local_why = dev_why.c_str(); }
+      }
+    }
     bool any_const_point = false;
     for (int j = 0; j < M && !any_const_point; ++j) any_const_point = h->mask_point[(size_t)j * 3] == 0.0;
     int64_t chunk_block = nt > 500 ? 2048 : 0;   // (the chunk numbering by blocks of points, below: it gets the entry list's segments instead of the list)
     if (const char* e = std::getenv("RSBA_SCHUR_BLOCK")) chunk_block = std::atoi(e) > 0 ? std::max(16, std::atoi(e)) : 0;
     if (chunk_block >= M) chunk_block = 0;
     DevicePlanIn din{dp.obs_frame, dp.obs_point, N, M, FR, NPF, NIB, FT, CD, nt, d_tf, struct_keys.data(), (int64_t)struct_keys.size(), chunk_block, any_const_point, h->stream};
-    const hipError_t pe = device_plan_lists(din, &dpo);
+    hipError_t pe = local_fail ? hipSuccess : device_plan_lists(din, &dpo);
+    if (pe == hipSuccess && !local_fail && test_hook("RSBA_TEST_FAIL_DEVICE_PLAN")) pe = hipErrorOutOfMemory;   // (test hook: the lists' allocations fail on this rank)
     s->allocs.insert(s->allocs.end(), dpo.owned.begin(), dpo.owned.end());
-    if (pe != hipSuccess) return rsba_set_error(pe == hipErrorOutOfMemory ? RSBA_ERR_OUT_OF_MEMORY : RSBA_ERR_HIP, (std::string("device plan: ") + hipGetErrorString(pe)).c_str());
+    if (pe != hipSuccess) {
+      (void)hipGetLastError();
+      const int32_t code = pe == hipErrorOutOfMemory ? RSBA_ERR_OUT_OF_MEMORY : RSBA_ERR_HIP;
+      dev_why = std::string("device plan: ") + hipGetErrorString(pe);
+      if (!plan_votes) return rsba_set_error(code, dev_why.c_str());
+      local_fail = code; local_why = dev_why.c_str();
+    }
+    if (local_fail) {
+      // nothing of the lists can be used: an empty plan (no points' entries) walks through the host-side passes up to the vote, where every rank gives up together
+      dpo = DevicePlanOut{};
+      dpo.point_ptr_h.assign((size_t)M + 1, 0); dpo.tp_ptr.assign(1, 0);
+    }
     point_ptr.swap(dpo.point_ptr_h);
     sv.point_ptr = dpo.point_ptr; sv.slot_frame = dpo.slot_frame; sv.slot_point = dpo.slot_point; s->d_obs_slot = dpo.obs_slot; sv.slot_gpos = dpo.slot_gpos;
     sv.ent_groups = dpo.ent_groups; sv.ent_pt = dpo.ent_pt; sv.ent_mask = dpo.ent_mask;
@@ -1036,7 +1056,7 @@ int32_t build_solver_impl(rsba_handle* h) {
   sv.npremerge = (int)pm_ptr.size() - 1;
   sv.nchunk = (int)chunk_tp.size(); sv.ntp = ntp; sv.FT = FT;
   { const char* e = std::getenv("RSBA_SCHUR_LINEAR"); sv.schur_linear = e && e[0] == '1'; }
-  { const char* e = std::getenv("RSBA_SCHUR_VARIANT"); sv.schur_variant = e ? std::atoi(e) : 0; }
+  { const char* e = std::getenv("RSBA_SCHUR_VARIANT"); sv.schur_variant = e ? std::atoi(e) : 0; if (!kTestHooks && sv.schur_variant >= 4) sv.schur_variant = 0; }   // (4 / 5: ablations, instrumented build only)
   sv.schur_trace = nullptr;
   if (std::getenv("RSBA_SCHUR_TRACE")) { if (int32_t rc_ = s_alloc(s, &sv.schur_trace, 8 * (size_t)std::max(sv.nchunk, 1))) return rc_; }
   std::vector<uint8_t> has_prior((size_t)FR + 1, 0);
@@ -1426,7 +1446,7 @@ int32_t build_solver_impl(rsba_handle* h) {
     HIP_TRY(dev_event_acquire(&s->ev_verified, false));
     HIP_TRY(hipMemset(s->d_verify, 0, 2 * (size_t)sv.npad * sizeof(double)));   // the check kernel leaves it zero again
     { const char* v = std::getenv("RSBA_CHOL_VERIFY"); s->verify_dag = !(v && v[0] == '0'); }
-    { const char* v = std::getenv("RSBA_CHOL_TEST_CORRUPT"); s->test_corrupt_once = v && v[0] == '1'; }
+    { const char* v = test_hook("RSBA_CHOL_TEST_CORRUPT"); s->test_corrupt_once = v && v[0] == '1'; }
     for (int b = 0; b < 2; ++b) {   // one device copy of {sv, plan} per set of cells
       double* c = s->cells[b];
       host_args.sv.Lf = c + s->cell_off[0]; host_args.sv.chol_part = c + s->cell_off[1]; host_args.sv.Winv = c + s->cell_off[2];
@@ -2045,7 +2065,7 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
     // problem-size figures of the whole (all-rank) problem
     const double npri = sv.lead ? (double)h->prior_frames.size() + (double)h->pp_blocks.size() + (dp.pp_spherical >= 0 ? 1.0 : 0.0) : 0.0;
     // (+ how many ranks cannot run the loop without the host — no observations, or phase timers on: every rank must take the same form of the loop)
-    const bool host_form_only = dp.N == 0 || s->timer.on || std::getenv("RSBA_DEVICE_LM_OFF_ON_THIS_RANK") != nullptr;
+    const bool host_form_only = dp.N == 0 || s->timer.on || test_hook("RSBA_DEVICE_LM_OFF_ON_THIS_RANK") != nullptr;
     double cnt[4] = {(double)dp.N + npri, (double)(s->num_reduced_blocks + s->num_priors_reduced), (double)s->num_reduced_params, host_form_only ? 1.0 : 0.0};
     if (h->allreduce) {
       HIP_TRY(hipMemcpyAsync(sv.scalars + 8, cnt, sizeof cnt, hipMemcpyHostToDevice, st));

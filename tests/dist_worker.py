@@ -101,6 +101,45 @@ def nd_mode(mode, outdir, rank, world, dist, torch):
     dist.destroy_process_group()
 
 
+def planfail_mode(mode, outdir, rank, world, dist, torch):
+    """"planfail:<hook>": the symbolic phase fails on RANK 1 ONLY (a test hook of the instrumented library: RSBA_TEST_FAIL_PLAN before the lists are
+    built, RSBA_TEST_FAIL_DEVICE_PLAN = the device lists' allocations).  The ranks vote in the middle of the plan: rank 1 must still enter
+    the vote, every rank must come back with an error (nobody waits for ever), and a retry without the fault must solve as a fresh handle does."""
+    from rsba_amd import capi
+    from rsba_amd.distributed import attach
+    from rsba_amd.scene import make_config
+    hook = mode.split(":")[1]
+    full = make_config("C2").problem
+    owner, _ = capi.partition_points(full, world)
+    shard = full.shard(rank, world, owner)
+    torch.cuda.set_device(0)
+    dp = capi.DeviceProblem(shard, device=0)
+    attach(dp)
+    opts = capi.default_options(max_num_iterations=4)
+    if rank == 1:
+        os.environ[hook] = "1"
+    err = None
+    try:
+        dp.solve(opts)
+    except capi.RsbaError as e:
+        err = str(e)
+    os.environ.pop(hook, None)
+    dist.barrier()
+    s, _ = dp.solve(opts)
+    st = dp.plan_stats()
+    dp.close()
+    out = {"rank": rank, "error": err, "final_cost": s.final_cost, "iters": s.num_iterations, "sharded": st["sharded_factorisation"]}
+    if rank == 0:
+        ref = full.copy()
+        with capi.DeviceProblem(ref) as d1:
+            s1, _ = d1.solve(opts)
+        out["ref_final"] = s1.final_cost
+    with open(os.path.join(outdir, f"rank{rank}.json"), "w") as f:
+        json.dump(out, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def mock_timeout_mode(outdir, rank, world, dist, torch):
     """Two ranks over tools/libmock_rccl.so: one all-reduce both enter (checked), then one that ONLY RANK 0 enters — its device-side wait
     must give up after RSBA_MOCK_RCCL_TIMEOUT_S and the communicator must say so when it is destroyed."""
@@ -153,6 +192,8 @@ def main():
         return nd_mode(mode, outdir, rank, world, dist, torch)
     if mode == "mock_timeout":
         return mock_timeout_mode(outdir, rank, world, dist, torch)
+    if mode.startswith("planfail:"):
+        return planfail_mode(mode, outdir, rank, world, dist, torch)
     full = scene()
     if mode in ("gpu_priors", "gpu_free_ratio"):   # motion priors are replicated terms: every rank lists them, rank 0 contributes them
         full.prior_kind, full.prior_scale, full.inter_frame_ratio = 2, 25.0, 1.2

@@ -15,12 +15,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 MOCK_RCCL = os.path.join(ROOT, "tools", "libmock_rccl.so")   # tools/mock_rccl.hip, built by __graft_entry__.build(): test infrastructure
+HOOKS_LIB = os.path.join(ROOT, "rsba_amd", "_lib", "librsba_amd_hooks.so")   # the instrumented build (-DRSBA_TEST_HOOKS): the only one that reads the fault-injection switches
 
 
 def run_two_ranks(mode, outdir, world=2, timeout=900, env_extra=None):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(env_extra or {}))
+    if any(flag in mode.split(":") for flag in ("hostrank", "corrupt")) or mode.startswith("planfail:"):
+        env["RSBA_AMD_LIB"] = HOOKS_LIB   # modes that inject a fault run on the instrumented library
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"), mode, str(outdir)],
                        capture_output=True, text=True, env=env, timeout=timeout)
@@ -107,6 +110,43 @@ def test_native_rccl_transport_one_rank():
     assert s2.final_cost == s.final_cost and s2.num_iterations == s.num_iterations
     assert np.array_equal(p.poses, q.poses) and np.array_equal(p.points, q.points)
     assert t["exchange"][1] > 0 and t["cholesky"][1] == s.num_iterations - 1
+
+
+def run_bench(nproc, config, extra_env=None, lm_iters=6, timeout=1200):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RSBA_BENCH_TEST_ONE_GPU="1", **(extra_env or {}))
+    args = ["--gpus", str(nproc), "--steps", "5", "--warmup", "1", "--config", config, "--no-cpu-baseline", "--no-next-rows", "--lm-iters", str(lm_iters)]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args if nproc == 1 else \
+          [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py")] + args
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,config", [(2, "C2"), (8, "C4")])
+def test_bench_takes_its_native_rccl_branch_with_several_ranks(world, config):
+    """The branch of bench.py the driver's multi-GPU command takes — attach_rccl -> rsba_rccl_comm_create -> rsba_set_exchange_rccl, the warm
+    handle of the LM leg on the SAME communicator, the LM solve on the watchdog thread with comm set — run here with 2 and 8 ranks on one
+    GPU: RSBA_BENCH_NATIVE=1 + RSBA_RCCL_LIB = the stream-ordered stand-in for librccl (tools/mock_rccl.hip; RCCL itself refuses two
+    ranks on one device).  Every rank must report the communicator as the library sees it, the sharded plan, and the one-GPU cost."""
+    one = run_bench(1, config)
+    many = run_bench(world, config, {"RSBA_BENCH_NATIVE": "1", "RSBA_RCCL_LIB": MOCK_RCCL})
+    assert many["n_gpus"] == world and many["scaling"] == "strong"
+    assert many["config"]["observations_total"] == one["config"]["observations_total"]
+    lm = many["lm"]
+    assert "error" not in lm, lm
+    assert "native" in lm["exchange"] and "libmock_rccl.so" in lm["exchange"]
+    assert len(lm["per_rank"]) == world
+    for r, row in enumerate(lm["per_rank"]):
+        assert row["rank"] == r and row["rccl"]["comm_ranks"] == world and row["rccl"]["comm_rank"] == r
+        assert row["plan"]["sharded_factorisation"] == 1
+        assert row["collectives_of_the_profiled_solve"]["(2) reduced system"]["calls"] > 0
+    assert abs(lm["initial_cost"] - one["lm"]["initial_cost"]) <= 1e-12 * one["lm"]["initial_cost"]
+    assert abs(lm["final_cost"] - one["lm"]["final_cost"]) <= 1e-9 * one["lm"]["final_cost"]
+    assert many["lm_headline"]["ms_per_lm_iteration"] > 0
 
 
 @pytest.mark.gpu
@@ -287,6 +327,19 @@ def test_a_suspect_sharded_solve_sends_every_rank_back_to_the_replicated_factori
     single-GPU level-scheduled solve."""
     res = run_two_ranks("nd:C2:6:corrupt", tmp_path, 2)
     check_nd(res, 2, fallbacks=1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hook,message", [("RSBA_TEST_FAIL_PLAN", "RSBA_TEST_FAIL_PLAN"), ("RSBA_TEST_FAIL_DEVICE_PLAN", "device plan")])
+def test_a_plan_that_fails_on_one_rank_fails_on_every_rank(tmp_path, hook, message):
+    """The ranks vote in the middle of the symbolic phase (one all-reduce: do everyone's points respect the cut?).  A rank whose plan fails
+    before that — an unsupported size, or the device lists' allocations running out of memory — must still enter the vote and
+    say so: rank 1 reports its own error, rank 0 that another rank failed, nobody waits; without the fault the same handles solve."""
+    a, b = run_two_ranks("planfail:" + hook, tmp_path, 2, timeout=300)
+    assert b["error"] is not None and message in b["error"], b["error"]
+    assert a["error"] is not None and "another rank" in a["error"], a["error"]
+    assert a["final_cost"] == b["final_cost"] and a["sharded"] == b["sharded"] == 1
+    assert abs(a["final_cost"] - a["ref_final"]) <= 1e-9 * a["ref_final"]
 
 
 @pytest.mark.gpu

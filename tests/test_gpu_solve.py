@@ -267,24 +267,42 @@ def test_shared_intrinsics_with_many_points(capi, oracle):
     assert np.max(np.abs(p_dev.intrinsics - p_cpu.intrinsics) / np.maximum(1.0, np.abs(p_cpu.intrinsics))) <= 1e-6
 
 
-def test_a_wrong_dag_result_is_caught_and_redone_on_the_level_schedule(capi, monkeypatch):
+def run_hook_case(case, tmp_path):
+    """A case of tests/hook_worker.py in a process of its own, on the instrumented library (the release library has no fault-injection switches)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = os.path.join(str(tmp_path), "hook.json")
+    env = dict(os.environ, RSBA_AMD_LIB=os.path.join(root, "rsba_amd", "_lib", "librsba_amd_hooks.so"))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "hook_worker.py"), case, out], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    res = json.load(open(out))
+    assert res["library"].endswith("librsba_amd_hooks.so")
+    return res
+
+
+def test_a_wrong_dag_result_is_caught_and_redone_on_the_level_schedule(capi, tmp_path):
     """The persistent Cholesky driver's solution is verified against the system it was given (res = rhs - S y against
-    |rhs| + |S||y|).  RSBA_CHOL_TEST_CORRUPT=1 makes the first DAG solve lose one entry of y: the check must notice, the
+    |rhs| + |S||y|).  RSBA_CHOL_TEST_CORRUPT=1 (instrumented library) makes the first DAG solve lose one entry of y: the check must notice, the
     iteration is repeated — and the problem finished — on the level schedule, and the result is the level schedule's, bit
     for bit.  Without the hook no solve of this suite trips the check."""
-    from rsba_amd.scene import make_config
-    out = {}
-    for mode in ("corrupt", "levels", "plain"):
-        monkeypatch.delenv("RSBA_CHOL_TEST_CORRUPT", raising=False)
-        if mode == "corrupt":
-            monkeypatch.setenv("RSBA_CHOL_TEST_CORRUPT", "1")
-        p = make_config("C2").problem
-        with capi.DeviceProblem(p) as dp:
-            s, _ = dp.solve(capi.default_options(max_num_iterations=6, level_scheduled_cholesky=int(mode == "levels")))
-        out[mode] = (s.final_cost, s.num_iterations, s.num_dag_fallbacks, p.poses.copy(), p.points.copy())
-    assert out["corrupt"][2] == 1 and out["levels"][2] == 0 and out["plain"][2] == 0
+    out = run_hook_case("corrupt_dag", tmp_path)
+    assert out["corrupt"]["fallbacks"] == 1 and out["levels"]["fallbacks"] == 0 and out["plain"]["fallbacks"] == 0
     for a, b in ((out["corrupt"], out["levels"]), (out["plain"], out["levels"])):
-        assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+        assert a["final_cost"] == b["final_cost"] and a["iters"] == b["iters"] and a["poses"] == b["poses"] and a["points"] == b["points"]
+
+
+def test_the_release_library_has_no_fault_injection(capi, monkeypatch):
+    """The switches above exist in the instrumented build only (rsba_amd/csrc/test_hooks.hpp): the library the product ships neither fails its
+    plan nor loses an entry of a solve because a variable is set."""
+    assert capi.LIB_PATH.endswith("librsba_amd.so")
+    p, q = small_scene(frames=12, points=500), small_scene(frames=12, points=500)
+    with capi.DeviceProblem(q) as dp:
+        s_ref, _ = dp.solve(capi.default_options(max_num_iterations=5))
+    for hook in ("RSBA_TEST_FAIL_PLAN", "RSBA_TEST_FAIL_DEVICE_PLAN", "RSBA_CHOL_TEST_CORRUPT"):
+        monkeypatch.setenv(hook, "1")
+    with capi.DeviceProblem(p) as dp:
+        s, _ = dp.solve(capi.default_options(max_num_iterations=5))
+    assert s.num_dag_fallbacks == 0 and s.final_cost == s_ref.final_cost and np.array_equal(p.poses, q.poses)
 
 
 @pytest.mark.parametrize("shared_intrinsics", [False, True])
@@ -417,25 +435,15 @@ def test_ragged_scenes_and_degenerate_programs(capi, oracle):
     compare_solves(capi, oracle, one, iters=8, final_tol=1e-6, expect_same_path=False)
 
 
-def test_a_failed_plan_is_torn_down_and_a_retry_fails_or_succeeds_afresh(capi, monkeypatch):
-    """A symbolic phase that fails half-way (out of memory, an unsupported size; here RSBA_TEST_FAIL_PLAN) must not leave a half-built
-    solver behind that the next call takes for a finished one (it would launch kernels on null tables): every retry reports the
-    error again, and once the cause is gone the same handle plans and solves as a fresh one does."""
-    p = small_scene(frames=12, points=500)
-    q = p.copy()
-    with capi.DeviceProblem(q) as dp:
-        s_ref, _ = dp.solve(capi.default_options(max_num_iterations=5))
-    with capi.DeviceProblem(p) as dp:
-        monkeypatch.setenv("RSBA_TEST_FAIL_PLAN", "1")
-        for _ in range(2):
-            with pytest.raises(capi.RsbaError, match="RSBA_TEST_FAIL_PLAN"):
-                dp.solve(capi.default_options(max_num_iterations=5))
-        with pytest.raises(capi.RsbaError, match="RSBA_TEST_FAIL_PLAN"):
-            dp.plan_stats()
-        monkeypatch.delenv("RSBA_TEST_FAIL_PLAN")
-        s, _ = dp.solve(capi.default_options(max_num_iterations=5))
-    assert s.final_cost == s_ref.final_cost and s.num_iterations == s_ref.num_iterations
-    assert np.array_equal(p.poses, q.poses) and np.array_equal(p.points, q.points)
+@pytest.mark.parametrize("hook,message", [("RSBA_TEST_FAIL_PLAN", "RSBA_TEST_FAIL_PLAN"), ("RSBA_TEST_FAIL_DEVICE_PLAN", "device plan")])
+def test_a_failed_plan_is_torn_down_and_a_retry_fails_or_succeeds_afresh(capi, tmp_path, hook, message):
+    """A symbolic phase that fails half-way (out of memory, an unsupported size; here a switch of the instrumented library: before the lists
+    are built, or the device lists' allocations) must not leave a half-built solver behind that the next call takes for a finished one (it
+    would launch kernels on null tables): every retry reports the error again, and once the cause is gone the same handle plans and solves
+    as a fresh one does."""
+    out = run_hook_case("failed_plan:" + hook, tmp_path)
+    assert len(out["errors"]) == 3 and all(e is not None and message in e for e in out["errors"]), out["errors"]
+    assert out["same"]
 
 
 def test_device_blocks_are_cached_between_handles_and_given_back(capi):

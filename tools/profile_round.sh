@@ -2,7 +2,7 @@
 # Runs on the GPU box (via gpurun): collects this round's evidence into gpurun_out/$1/ (default r02).
 #   the bench lines (C4 = the metric's workload, C5 = the 4k-camera Huber + shared-intrinsics scene), kernel-trace stats of the
 #   same commands, FETCH_SIZE and WRITE_SIZE in separate --pmc passes (never combined with tracing), the HBM stream calibration.
-R=${1:-r05}
+R=${1:-r06}
 OUT=gpurun_out/$R
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -46,6 +46,15 @@ for cfg in ("C4", "C5"):
     for k, e in summary[cfg].items():
         if e["mfma_busy_frac"] > 0.01: print(cfg, k, {a: (round(b, 4) if isinstance(b, float) else b) for a, b in e.items()})
 PY
+# the vector unit of the passes that RECOMPUTE the observation model (eval_trial / point_blocks / project / back_substitute): issued and
+# active VALU cycles, and the fp64 operations by kind (a wave instruction = 64 lanes; an FMA counts two flops) — counters only, one pass each
+for C in C4 C5; do
+  IT=4; [ $C = C5 ] && IT=3
+  tools/pmc_pass.sh $OUT/pmc_valu_$C "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES GRBM_GUI_ACTIVE" python tools/lm_time.py $C $IT
+  tools/pmc_pass.sh $OUT/pmc_f64_$C "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE" python tools/lm_time.py $C $IT
+  tools/pmc_pass.sh $OUT/pmc_lds_$C "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE" python tools/lm_time.py $C $IT
+done
+python tools/pmc_valu_summary.py $OUT
 python bench.py --config C2 --steps 50 --warmup 5 --lm-iters 12 --no-cpu-baseline --no-next-rows > $OUT/bench_c2.json 2> $OUT/bench_c2.err
 ./tools/hbm_calib > $OUT/hbm_calib.txt 2>&1
 ./tools/mfma_f64_rate > $OUT/mfma_f64_rate.txt 2>&1
@@ -67,7 +76,7 @@ for cfg, k, key in (("C4", "eval_kernel<true, 2, 1>", "hbm_bytes_per_launch"), (
 json.dump(summary, open(f"{out}/pmc_summary.json", "w"), indent=1)
 print(json.dumps(summary))
 PY
-python tools/source_stamp.py --tag $OUT/pmc_summary.json $OUT/pmc_mfma_summary.json   # the code the counters were taken on (bench.py flags a stale summary)
+python tools/source_stamp.py --tag $OUT/pmc_summary.json $OUT/pmc_mfma_summary.json $OUT/pmc_valu_summary.json   # the code the counters were taken on (bench.py flags a stale summary)
 cp $OUT/kernel_stats_C4.csv $OUT/kernel_stats.csv
 cat $OUT/bench.json
 # the rows next to the hot path: motion priors (f1), RS-PnP hypotheses (f3), filters (f2)
