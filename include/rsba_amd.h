@@ -217,6 +217,8 @@ typedef struct rsba_plan_stats {
   int64_t local_levels, separator_levels;           /* the two dependency chains: elimination levels inside this rank's part / levels that hold a separator column */
   int64_t schur_group_bytes, schur_factored_groups; /* bytes of all groups: 3 x 48 doubles each in full form; 80 doubles for the groups stored FACTORED (two-pose frame tiles: the
                                                      * 6-row factor q = Jq^T Jp L^-T per frame + tau instead of the 12 rows (1 - tau) q | tau q), and how many those are */
+  int64_t device_loop_solves, host_loop_solves;     /* rsba_solve calls on this plan whose trust-region loop ran without the host (decisions by device kernels: every problem rsba_solve takes
+                                                     * except several intrinsics blocks, GoodPosePrior blocks on several ranks, phase timing) / with the host deciding */
 } rsba_plan_stats;
 int32_t rsba_get_plan_stats(rsba_handle* h, rsba_plan_stats* out);   /* runs the symbolic phase if it has not run yet */
 

@@ -97,7 +97,7 @@ class PlanStats(C.Structure):
     _fields_ = [(k, C.c_int64) for k in ("tiles", "factor_tiles", "levels", "tasks", "schur_entries", "schur_chunks", "schur_block_products",
                                          "cholesky_flops", "exchange_doubles", "schur_groups", "schur_mfma_issued", "schur_launches",
                                          "sharded_factorisation", "separator_tiles", "separator_factor_tiles", "local_tasks", "separator_tasks",
-                                         "local_levels", "separator_levels", "schur_group_bytes", "schur_factored_groups")]
+                                         "local_levels", "separator_levels", "schur_group_bytes", "schur_factored_groups", "device_loop_solves", "host_loop_solves")]
 
 
 class ExchangeStats(C.Structure):

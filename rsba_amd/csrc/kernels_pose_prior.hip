@@ -100,7 +100,7 @@ __global__ __launch_bounds__(kPPThreads) void pose_prior_blocks_kernel(const Dev
     }
   }
   __syncthreads();   // a SphericalPrior may sit on a pose that also carries a GoodPosePrior: after the loop above
-  if (threadIdx.x == 0 && dp.pp_spherical >= 0 && sv.lead) {
+  if (threadIdx.x == 0 && dp.pp_spherical >= 0 && (sv.frame_lead ? sv.frame_lead[dp.pp_spherical / dp.P] != 0.0 : sv.lead != 0)) {   // (contributed once: the lead rank, or — sharded factorisation — the rank whose part holds the pose, like a GoodPosePrior's terms)
     const int b = dp.pp_spherical, f = b / dp.P, q = b % dp.P;
     const Spherical s = spherical_at(dp.poses + (size_t)b * 6);
     double J[2][6];

@@ -750,7 +750,7 @@ int32_t build_solver_impl(rsba_handle* h) {
   // interFrameRatio or several intrinsics blocks (their replicated terms come from rank 0 alone) — those problems keep the
   // replicated factorisation.  Motion priors with a known ratio are shared out like the frames: see below.
   std::vector<int32_t> cpart(nt, -1);
-  bool sharded = want_parts && tord.parts_ok && dp.pp_spherical < 0 && NIB <= 1;   // (GoodPosePrior blocks are in: their terms go to the rank whose part holds the pose, like the frames' damping)   // (a free interFrameRatio is in: its column's forward solve runs part by part, FWD2P / ETA below)
+  bool sharded = want_parts && tord.parts_ok && NIB <= 1;   // (the SphericalPrior is in as well, round 6: one 2-residual block on one pose — its terms go where that pose's GoodPosePrior terms would)   // (GoodPosePrior blocks are in: their terms go to the rank whose part holds the pose, like the frames' damping)   // (a free interFrameRatio is in: its column's forward solve runs part by part, FWD2P / ETA below)
   if (const char* e = std::getenv("RSBA_SHARDED")) sharded = sharded && e[0] != '0';   // A/B switch
   if (want_parts) {
     double bad = sharded ? 0.0 : 1.0;
@@ -1598,7 +1598,7 @@ int32_t linearize(rsba_handle* h, bool have_eval = false, bool want_gradmax = fa
   // every collective is tens of microseconds of latency on a node: each rank's maximum over ITS points (they are nobody else's) in a
   // slot of its own behind the payload, the other ranks' slots zero, so the SUM delivers all of them; the cameras' maximum is taken
   // from the summed gradient behind the exchange.  (Not with per-pose priors: their blocks' maximum is the lead rank's alone.)
-  const bool ride = want_gradmax && h->world <= kMaxRankSlots && h->dp.pp_count == 0 && h->dp.pp_spherical < 0;
+  const bool ride = want_gradmax && h->world <= kMaxRankSlots && h->dp.pp_count == 0;   // (a SphericalPrior has no coordinates of its own: its gradient is part of the summed camera gradient)
   HIP_TRY(launch_pack_linearize(h->dp, s->sv, h->d_cost2, h->stream, ride ? h->world : 0));
   if (ride) HIP_TRY(launch_gradient_max_points(h->dp, s->sv, h->rank, h->stream));
   int32_t rc = exchange(h, s->sv.xbuf, 2 * s->sv.n + 3 + (ride ? h->world : 0), 0, RSBA_EXCHANGE_CAMERA);
@@ -2187,9 +2187,11 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
   // Single-GPU problems that keep no records (calibrated, or ONE shared intrinsics block), with or without motion priors of a known
   // interFrameRatio — on one rank or several (every rank takes the same form: settled with the problem-size exchange); everything else (a free
   // ratio, per-pose priors, per-frame intrinsics blocks) — and a suspect factorisation — goes through the host form.
-  bool device_ctl = speculate && (dp.pp_count == 0 || !h->allreduce) && dp.pp_spherical < 0 && !s->use_levels &&   // (GoodPosePrior blocks: on one rank; the SphericalPrior — 1e20 on the residual — stays with the host)
+  bool device_ctl = speculate && (dp.pp_count == 0 || !h->allreduce) && !s->use_levels &&   // (GoodPosePrior blocks: on one rank; the SphericalPrior — one block on one pose, no coordinates of its own — on any number, round 6)
                     !any_rank_needs_host && opt->max_num_iterations > 0;
+  const bool has_pp = dp.pp_count > 0 || dp.pp_spherical >= 0;
   if (const char* e = std::getenv("RSBA_DEVICE_LM")) device_ctl = device_ctl && e[0] != '0';   // A/B switch: 0 = the host decides
+  if (device_ctl) ++s->stats.device_loop_solves; else ++s->stats.host_loop_solves;
   if (device_ctl) {
     const int cap = opt->max_num_iterations + 2;
     if (cap > s->trace_it_cap) { if ((rc = s_alloc(s, &s->d_trace_it, (size_t)cap))) return rc; s->trace_it_cap = cap; }
@@ -2255,10 +2257,10 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
       if (free_ratio) HIP_TRY(launch_ratio_candidate(s->ratio4, s->d_ctl, st));
       HIP_TRY(launch_candidate_and_model_cost(dp, sv, st));
       if (s->ucross && (sv.lead || h->prior_split)) HIP_TRY(launch_prior_model(dp, sv, sv.scalars + kModelCostChange, 0.0, st, free_ratio ? s->ratio4 + kRtC : nullptr));   // motion priors: their share of the model cost change (a free ratio's step included) ...
-      if (dp.pp_count > 0) HIP_TRY(launch_pose_prior_step(dp, sv, s->pp, 1.0, st));   // per-pose priors: the candidate priorPoses values, their share of the three sums
+      if (has_pp) HIP_TRY(launch_pose_prior_step(dp, sv, s->pp, 1.0, st));   // per-pose priors: the candidate priorPoses values, their share of the three sums (the lead rank's to add)
       swap_params();
       HIP_TRY(launch_eval(dp, kLmJacobian, st));
-      const bool extra_cost = s->ucross != nullptr || dp.pp_count > 0;   // prior blocks add their cost behind the observations': the cost is reduced by a launch of its own then
+      const bool extra_cost = s->ucross != nullptr || has_pp;   // prior blocks add their cost behind the observations': the cost is reduced by a launch of its own then
       if (extra_cost) {                                                                                // ... their cost at the candidate, behind the observations' ...
         HIP_TRY(launch_cost_reduce(dp, h->d_cost2, st));
         if (s->ucross && (sv.lead || h->prior_split)) {
@@ -2266,7 +2268,7 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
           if (free_ratio) dq.prior_ratio_ptr = s->ratio4 + kRtRatioEval;   // (... at the candidate's ratio)
           HIP_TRY(launch_prior_cost(dq, h->d_cost2, h->prior_invalid, st));
         }
-        if (dp.pp_count > 0) HIP_TRY(launch_pose_prior_cost(dp, h->d_cost2, st));
+        if (has_pp && sv.lead) HIP_TRY(launch_pose_prior_cost(dp, h->d_cost2, st));   // (replicated blocks: the lead rank's share of the summed cost)
       }
       swap_params();
       if ((rc = await_verification(h))) return rc;
@@ -2283,7 +2285,7 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
       if (!fused) HIP_TRY(launch_camera_blocks(dp, sv, st, /*take_candidate=*/true, /*padding_is_zero=*/true));   // (the initial linearisation zeroed the pseudo frames' padding)
       if (my_priors) HIP_TRY(launch_prior_blocks(dp, sv, s->ucross, st));                             // ... and their blocks of an accepted step's linearisation
       if (free_ratio) HIP_TRY(launch_prior_border(all_priors(h), sv, s->border, s->ratio4, st));      // (the ratio's column at the accepted point: every rank, from replicated poses)
-      if (dp.pp_count > 0) { HIP_TRY(launch_pose_prior_take(dp, sv, st)); HIP_TRY(launch_pose_prior_blocks(dp, sv, s->pp, st)); }   // per-pose priors: the accepted values, their blocks
+      if (has_pp) { HIP_TRY(launch_pose_prior_take(dp, sv, st)); HIP_TRY(launch_pose_prior_blocks(dp, sv, s->pp, st)); }   // per-pose priors: the accepted values, their blocks
       HIP_TRY(launch_intr_blocks(dp, sv, st));
       if (!fused) HIP_TRY(launch_point_blocks(dp, sv, st));
       s->ctl_seq += 1.0;

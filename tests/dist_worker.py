@@ -52,6 +52,9 @@ def nd_mode(mode, outdir, rank, world, dist, torch):
         full.pose_prior_block = np.arange(2, 2 * full.num_frames, dtype=np.int32)
         full.pose_prior_values = full.poses.reshape(-1, 6)[full.pose_prior_block] + rng.normal(0, 0.01, (len(full.pose_prior_block), 6))
         full.pose_prior_rotation, full.pose_prior_position = 3.0, 5.0
+    if "spherical" in flags:   # the SphericalPrior of a session that starts at the origin (CeresHandler.h:36-50,127-130): ONE 2-residual block on the first pose of frame 1 — its terms go to the rank whose part holds that pose
+        full.poses[0] = 0.0; full.poses[1] = 0.0; full.poses[1, :, 3:] += 1e-4
+        full.spherical_pose_block = 2
     if "hostrank" in flags and rank == 1:   # ONE rank cannot run the loop without the host (test hook of the library; in the field: a rank without observations, or with phase timers on): ALL ranks must then take the host form — their collectives pair up or the solve hangs
         os.environ["RSBA_DEVICE_LM_OFF_ON_THIS_RANK"] = "1"
     if "corrupt" in flags:   # the first persistent-driver solve loses an entry of its result (test hook of the library): every rank must notice through exchange (3)

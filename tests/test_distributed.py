@@ -353,7 +353,7 @@ def test_sharded_factorisation_on_three_ranks(tmp_path):
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode,world", [("nd:C2:8:priors", 2), ("nd:S300:6:priors", 3), ("nd:S300:6:priors:intr", 4),
                                         ("nd:C2:8:priors:freeratio", 2), ("nd:S300:6:priors:freeratio", 3), ("nd:S300:6:priors:intr:freeratio", 4), ("nd:C2:6:priors:freeratio:hostrank", 2),
-                                        ("nd:C2:8:posepriors", 2), ("nd:S300:6:posepriors:priors:freeratio", 3)])
+                                        ("nd:C2:8:posepriors", 2), ("nd:S300:6:posepriors:priors:freeratio", 3), ("nd:C2:3:spherical", 2), ("nd:S300:3:spherical:priors", 4)])
 def test_sharded_factorisation_with_motion_priors(tmp_path, mode, world):
     """A motion prior between every two consecutive frames with a known interFrameRatio (the reference's usual video configuration,
     CeresHandler.h:147-185).  The prior between frames f and f - 1 goes to the rank whose part holds either frame (rank 0 when both
@@ -364,6 +364,8 @@ def test_sharded_factorisation_with_motion_priors(tmp_path, mode, world):
     if "freeratio" in mode:   # the free ratio (the reference's default): one more unknown, solved for alike on every rank — out of the second right-hand side that
         assert all(o["ratio"] == a["ratio"] for o in res) and a["ratio"] != 1.0   # rides through both launches of the sharded factorisation (FWD2 / FWD2P / ETA tasks)
         assert abs(a["ratio"] - a["ref_ratio"]) <= 1e-8 * abs(a["ref_ratio"])
+    if "spherical" in mode:   # the SphericalPrior keeps the sharded plan and the device-side loop (round 6): three iterations, while its 1e20-weighted residual is still above rounding
+        assert a["initial_cost"] > 1e38
     if "posepriors" in mode:  # GoodPosePrior blocks: every rank leaves with the same solved priorPoses values, the single-GPU ones
         assert all(o["prior_values_sum"] == a["prior_values_sum"] for o in res) and a["prior_err"] <= 1e-7
 

@@ -481,7 +481,8 @@ def test_device_blocks_are_cached_between_handles_and_given_back(capi):
 
 
 @pytest.mark.parametrize("case", ["c2", "rejections", "failure", "tolerances", "max_iterations", "huber", "priors", "priors_rejections", "c2_priors", "intrinsics", "intrinsics_rejections", "intrinsics_priors",
-                                  "free_ratio", "free_ratio_rejections", "free_ratio_acceleration", "c2_free_ratio", "pose_priors", "pose_priors_rejections", "pose_priors_free_ratio"])
+                                  "free_ratio", "free_ratio_rejections", "free_ratio_acceleration", "c2_free_ratio", "pose_priors", "pose_priors_rejections", "pose_priors_free_ratio",
+                                  "spherical", "spherical_pose_priors"])
 def test_device_side_trust_region_equals_the_host_form(capi, monkeypatch, case):
     """accept / reject, the radius update and the convergence tests of the LM loop run in a single-thread kernel, the
     iteration's kernels read the radius from HBM and skip themselves where the host form would not have launched them, the host
@@ -508,7 +509,10 @@ def test_device_side_trust_region_equals_the_host_form(capi, monkeypatch, case):
         if case.startswith("priors") or case == "intrinsics_priors":                # motion priors with a known interFrameRatio (CeresHandler.h:147-185): their cost, blocks and model change are part of every decision
             p.prior_kind, p.prior_scale, p.inter_frame_ratio = 1, 1.0 if case == "priors_rejections" else 10.0, 0.8
             p.prior_frames = np.arange(1, p.num_frames, dtype=np.int32)
-        if case.startswith("pose_priors"):   # GoodPosePrior blocks (CeresHandler.h:188-204): a free priorPoses block per pose, eliminated in closed form beside the points
+        if case.startswith("spherical"):     # the SphericalPrior on the first pose of frame 1 of a session that starts at the origin (CeresHandler.h:36-50,127-130): 1e20 on the residual — the
+            p.poses[0] = 0.0; p.poses[1] = 0.0; p.poses[1, :, 3:] += 1e-4   # two forms must still agree bit for bit, the collapse of the trust region once the constraint is met included
+            p.spherical_pose_block = 2
+        if case.startswith("pose_priors") or case == "spherical_pose_priors":   # GoodPosePrior blocks (CeresHandler.h:188-204): a free priorPoses block per pose, eliminated in closed form beside the points
             rng = np.random.default_rng(5)
             p.pose_prior_block = np.arange(2, 2 * p.num_frames, dtype=np.int32)
             p.pose_prior_values = p.poses.reshape(-1, 6)[p.pose_prior_block] + rng.normal(0, 0.01, (len(p.pose_prior_block), 6))
@@ -525,7 +529,7 @@ def test_device_side_trust_region_equals_the_host_form(capi, monkeypatch, case):
             return p, dict(max_num_iterations=30, initial_trust_region_radius=1e12)
         if case == "tolerances":
             return p, dict(max_num_iterations=50)
-        if case in ("priors", "intrinsics", "intrinsics_priors", "free_ratio", "free_ratio_acceleration", "pose_priors", "pose_priors_free_ratio"):
+        if case in ("priors", "intrinsics", "intrinsics_priors", "free_ratio", "free_ratio_acceleration", "pose_priors", "pose_priors_free_ratio", "spherical", "spherical_pose_priors"):
             return p, dict(max_num_iterations=15)
         return p, dict(max_num_iterations=3)
     out = {}
@@ -537,6 +541,8 @@ def test_device_side_trust_region_equals_the_host_form(capi, monkeypatch, case):
         p, kw = problem()
         with capi.DeviceProblem(p) as dp:
             s, tr = dp.solve(capi.default_options(**kw))
+            st = dp.plan_stats()
+        assert (st["device_loop_solves"], st["host_loop_solves"]) == ((0, 1) if mode == "host" else (1, 0)), (mode, st)   # the form that was asked for is the form that ran
         rec = [(t.iteration, t.step_is_valid, t.step_is_successful, t.cost, t.cost_change, t.gradient_max_norm, t.step_norm, t.relative_decrease, t.trust_region_radius, t.model_cost_change) for t in tr]
         out[mode] = (rec, (s.termination_type, s.num_successful_steps, s.num_unsuccessful_steps, s.num_iterations, s.initial_cost, s.final_cost, s.is_solution_usable, float(p.inter_frame_ratio)),
                      p.poses.copy(), p.points.copy(), p.intrinsics.copy(), None if p.pose_prior_values is None else p.pose_prior_values.copy())
