@@ -9,6 +9,7 @@
 #include <numeric>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "handle.hpp"
@@ -55,6 +56,33 @@ static int32_t grow(rsba_handle* h, T** p, int64_t* cap, int64_t need) {
   if (rc == RSBA_OK) *cap = need;
   return rc;
 }
+
+// The two host copies of the observation indices a handle keeps (h->obs_frame, h->obs_point: 41 MB each at 4k cameras) come out of a small
+// process-wide pool: a fresh 41 MB vector is 10 000 page faults when it is filled (9 ms of a 4k-camera rsba_create for the two) and an
+// munmap when it goes (11 ms of rsba_destroy) — windowedBA builds and destroys a handle per frame (VideoSfMHandler.cc:185-214).
+// rsba_release_host_scratch() empties it.
+namespace {
+struct IndexPool { std::mutex m; std::vector<std::vector<int32_t>> idle; };
+IndexPool& index_pool() { static IndexPool* p = new IndexPool(); return *p; }
+std::vector<int32_t> index_vector_take(size_t n) {
+  IndexPool& p = index_pool();
+  std::lock_guard<std::mutex> lk(p.m);
+  size_t best = p.idle.size();
+  for (size_t i = 0; i < p.idle.size(); ++i)
+    if (p.idle[i].capacity() >= n && (best == p.idle.size() || p.idle[i].capacity() < p.idle[best].capacity())) best = i;
+  if (best == p.idle.size()) return {};
+  std::vector<int32_t> v = std::move(p.idle[best]);
+  p.idle.erase(p.idle.begin() + (std::ptrdiff_t)best);
+  return v;
+}
+void index_vector_give(std::vector<int32_t>&& v) {
+  if (v.capacity() < (size_t)1 << 18) return;   // (small ones are the allocator's business)
+  IndexPool& p = index_pool();
+  std::lock_guard<std::mutex> lk(p.m);
+  if (p.idle.size() < 4) { v.clear(); p.idle.push_back(std::move(v)); }
+}
+void index_pool_release() { IndexPool& p = index_pool(); std::lock_guard<std::mutex> lk(p.m); p.idle.clear(); p.idle.shrink_to_fit(); }
+}  // namespace
 
 namespace rsba {
 hipError_t allow_dynamic_lds_impl(const void* kernel, size_t bytes) {
@@ -124,20 +152,43 @@ int32_t rsba_create(const rsba_problem_desc* d, int32_t device, rsba_handle** ou
     return fail(RSBA_ERR_INVALID_ARGUMENT, "scanlines[0] == scanlines[1]");
   if (d->num_intrinsics > 1 && !d->frame_intrinsics) return fail(RSBA_ERR_INVALID_ARGUMENT, "frame_intrinsics required when num_intrinsics > 1");
   const int64_t N = d->num_observations;
+  const bool dbg = std::getenv("RSBA_DEBUG_PLAN") != nullptr;
+  auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_mark = dbg ? now_ms() : 0.0; char stages[256] = ""; int stages_n = 0;
+  auto stage = [&](const char* name) { if (!dbg) return; const double t = now_ms(); stages_n += std::snprintf(stages + stages_n, sizeof stages - stages_n, " %s %.2f;", name, t - t_mark); t_mark = t; };
   bool frame_major = true;   // (one pass: index ranges and whether the list is already in frame-major order)
+  // ... on a few threads for large lists (10 M observations: 80 MB of indices), and — the list being frame-major as a rule — beside the two
+  // host copies of the indices the plan keeps (h->obs_frame, h->obs_point): two more threads
+  std::vector<int32_t> of = index_vector_take((size_t)N), op = index_vector_take((size_t)N);
+  of.clear(); op.clear();
   {
     const uint32_t nf = (uint32_t)d->num_frames, np = (uint32_t)d->num_points;
-    bool in_range = true; int32_t prev = 0;
-    for (int64_t i = 0; i < N; ++i) {
-      const int32_t f = d->obs_frame[i];
-      in_range = in_range && (uint32_t)f < nf && (uint32_t)d->obs_point[i] < np;
-      frame_major = frame_major && f >= prev; prev = f;
+    const int T = N >= ((int64_t)1 << 20) ? 4 : 1;
+    std::vector<uint8_t> ok((size_t)T, 1), mono((size_t)T, 1);
+    auto check = [&](int t) {
+      const int64_t i0 = N * t / T, i1 = N * (t + 1) / T;
+      bool in_range = true, fm = true; int32_t prev = i0 > 0 ? d->obs_frame[i0 - 1] : 0;
+      for (int64_t i = i0; i < i1; ++i) {
+        const int32_t f = d->obs_frame[i];
+        in_range = in_range && (uint32_t)f < nf && (uint32_t)d->obs_point[i] < np;
+        fm = fm && f >= prev; prev = f;
+      }
+      ok[(size_t)t] = in_range; mono[(size_t)t] = fm;
+    };
+    if (T == 1) check(0);
+    else {
+      std::vector<std::thread> pool;
+      for (int t = 0; t < T; ++t) pool.emplace_back(check, t);
+      pool.emplace_back([&] { of.assign(d->obs_frame, d->obs_frame + N); });
+      pool.emplace_back([&] { op.assign(d->obs_point, d->obs_point + N); });
+      for (auto& th : pool) th.join();
     }
-    if (!in_range) return fail(RSBA_ERR_INVALID_ARGUMENT, "observation index out of range");
+    for (int t = 0; t < T; ++t) { frame_major = frame_major && mono[(size_t)t]; if (!ok[(size_t)t]) { index_vector_give(std::move(of)); index_vector_give(std::move(op)); return fail(RSBA_ERR_INVALID_ARGUMENT, "observation index out of range"); } }
   }
   if (d->frame_intrinsics) for (int f = 0; f < d->num_frames; ++f)
     if (d->frame_intrinsics[f] < 0 || d->frame_intrinsics[f] >= d->num_intrinsics) return fail(RSBA_ERR_INVALID_ARGUMENT, "frame_intrinsics out of range");
 
+  stage("index check + host copies");
   int32_t ndev = 0;
   int32_t rc = rsba_device_count(&ndev);
   if (rc) return rc;
@@ -157,8 +208,7 @@ int32_t rsba_create(const rsba_problem_desc* d, int32_t device, rsba_handle** ou
   // somebody asks for it — a fresh handle per call is windowedBA's pattern, VideoSfMHandler.cc:185-214)
   h->identity_order = frame_major;
   std::vector<double> xy;
-  std::vector<int32_t> of, op;
-  if (frame_major) { of.assign(d->obs_frame, d->obs_frame + N); op.assign(d->obs_point, d->obs_point + N); }
+  if (frame_major) { if ((int64_t)of.size() != N) { of.assign(d->obs_frame, d->obs_frame + N); op.assign(d->obs_point, d->obs_point + N); } }
   else {
     h->order.resize(N);
     std::iota(h->order.begin(), h->order.end(), (int64_t)0);
@@ -182,10 +232,17 @@ int32_t rsba_create(const rsba_problem_desc* d, int32_t device, rsba_handle** ou
   dp.huber_a = d->huber_a;
   const size_t npose = (size_t)dp.F * dp.P * 6;
 
+  stage("handle");
   double2* dxy = nullptr; int32_t *dof = nullptr, *dop = nullptr, *dfi = nullptr;
-  if ((rc = dev_upload(h, reinterpret_cast<double**>(&dxy), frame_major ? d->obs_xy : xy.data(), 2 * (size_t)N))) return bail(rc);
-  if ((rc = dev_upload(h, &dof, of.data(), (size_t)N))) return bail(rc);
-  if ((rc = dev_upload(h, &dop, op.data(), (size_t)N))) return bail(rc);
+  if ((rc = dev_alloc(h, reinterpret_cast<double**>(&dxy), 2 * (size_t)N))) return bail(rc);
+  if ((rc = dev_alloc(h, &dof, (size_t)N))) return bail(rc);
+  if ((rc = dev_alloc(h, &dop, (size_t)N))) return bail(rc);
+  {   // the three observation arrays in ONE staged upload (devmem.hpp: pinned ring, a few copying threads; small lists: hipMemcpy)
+    const rsba::UploadSeg segs[3] = {{dxy, frame_major ? d->obs_xy : xy.data(), 2 * (size_t)N * sizeof(double)}, {dof, of.data(), (size_t)N * sizeof(int32_t)}, {dop, op.data(), (size_t)N * sizeof(int32_t)}};
+    const hipError_t ue = rsba::dev_upload_staged(segs, 3);
+    if (ue != hipSuccess) return bail(fail(ue == hipErrorOutOfMemory ? RSBA_ERR_OUT_OF_MEMORY : RSBA_ERR_HIP, std::string("upload of the observations: ") + hipGetErrorString(ue)));
+  }
+  stage("observations to the device");
   std::vector<int32_t> fi(dp.F, 0);
   if (d->frame_intrinsics) std::copy(d->frame_intrinsics, d->frame_intrinsics + dp.F, fi.begin());
   if ((rc = dev_upload(h, &dfi, fi.data(), (size_t)dp.F))) return bail(rc);
@@ -209,6 +266,7 @@ int32_t rsba_create(const rsba_problem_desc* d, int32_t device, rsba_handle** ou
   if ((rc = dev_upload(h, &h->d_mask_point, h->mask_point.data(), (size_t)dp.M * 3))) return bail(rc);
   if ((rc = dev_upload(h, &h->d_mask_intr, h->mask_intr.data(), (size_t)dp.NI * 9))) return bail(rc);
 
+  stage("parameters + masks");
   if ((rc = dev_alloc(h, &dp.res, 2 * (size_t)kEvalBlock * dp.ntiles))) return bail(rc);
   dp.jac = nullptr;   // [2 K x 256 x ntiles] what CostFunction::Evaluate materialises — 480 B per observation (4 GB at 4k cameras): allocated when a raw
                       // evaluation is first asked for (ensure_jacobians).  BA() never is: the LM iteration forms its blocks without writing the Jacobian.
@@ -220,6 +278,8 @@ int32_t rsba_create(const rsba_problem_desc* d, int32_t device, rsba_handle** ou
   if ((rc = dev_alloc(h, &h->d_cost2, 2))) return bail(rc);
   if (hipMemset(dp.fail_count, 0, sizeof(int)) != hipSuccess) return bail(fail(RSBA_ERR_HIP, "hipMemset"));
   if (rsba::dev_event_acquire(&h->ev0, true) != hipSuccess || rsba::dev_event_acquire(&h->ev1, true) != hipSuccess) return bail(fail(RSBA_ERR_HIP, "hipEventCreate"));
+  stage("outputs");
+  if (dbg) std::fprintf(stderr, "[rsba create] (ms):%s\n", stages);
   *out = h;
   return RSBA_OK;
 }
@@ -240,6 +300,7 @@ void rsba_destroy(rsba_handle* h) {
   rsba::dev_event_release(h->ev1, true);
   if (h->own_stream) { (void)hipStreamSynchronize(h->own_stream); rsba::dev_stream_release(h->own_stream); }
   const double t3 = dbg ? now() : 0.0;
+  index_vector_give(std::move(h->obs_frame)); index_vector_give(std::move(h->obs_point));
   delete h;
   if (dbg) std::fprintf(stderr, "[rsba destroy] handle: plan %.2f ms; blocks to the cache %.2f ms; events + stream to the pool %.2f ms; host state %.2f ms\n", t1 - t0, t2 - t1, t3 - t2, now() - t3);
 }
@@ -373,7 +434,7 @@ int32_t rsba_set_pose_priors(rsba_handle* h, double rotation, double position, c
   return RSBA_OK;
 }
 
-void rsba_release_host_scratch(void) { rsba_release_plan_scratch(); rsba::dev_release_cache(); }
+void rsba_release_host_scratch(void) { rsba_release_plan_scratch(); index_pool_release(); rsba::dev_release_cache(); }
 
 int32_t rsba_set_global_shutter_frames(rsba_handle* h, const uint8_t* is_global) {
   if (!h) return fail(RSBA_ERR_INVALID_ARGUMENT, "null handle");

@@ -1,8 +1,11 @@
 #include "devmem.hpp"
 
 #include <cstdlib>
+#include <cstring>
+#include <thread>
 #include <map>
 #include <mutex>
+#include <algorithm>
 #include <unordered_map>
 #include <vector>
 
@@ -20,7 +23,11 @@ struct Cache {
   std::map<int, std::vector<hipStream_t>> streams;           // idle, per device
   std::map<int, std::vector<hipEvent_t>> events[2];          // [timing]
   std::map<int, std::vector<void*>> pinned;                  // 4 KB blocks
+  std::map<int, void*> staging;                              // the pinned ring of dev_upload_staged (one per device, kStageBytes)
+  std::mutex staging_m;                                      // one staged upload at a time (a second caller takes hipMemcpy)
 };
+constexpr int kStageThreads = 4;
+constexpr size_t kStageChunk = 8u << 20, kStageBytes = (size_t)kStageThreads * 2 * kStageChunk;
 constexpr size_t kMaxStreams = 16, kMaxEvents = 64, kMaxPinned = 8, kPinnedBytes = 4096;
 Cache& cache() { static Cache* c = new Cache(); return *c; }   // (never destroyed: handles may outlive static destructors)
 
@@ -111,11 +118,13 @@ void dev_release_cache() {
   std::map<int, std::vector<hipStream_t>> streams;
   std::map<int, std::vector<hipEvent_t>> events[2];
   std::map<int, std::vector<void*>> pinned;
+  std::map<int, void*> staging;
   {
+    std::lock_guard<std::mutex> sl(c.staging_m);   // (no upload is using the ring)
     std::lock_guard<std::mutex> lk(c.m);
     take.swap(c.free_blocks);
     c.cached_bytes = 0;
-    streams.swap(c.streams); events[0].swap(c.events[0]); events[1].swap(c.events[1]); pinned.swap(c.pinned);
+    streams.swap(c.streams); events[0].swap(c.events[0]); events[1].swap(c.events[1]); pinned.swap(c.pinned); staging.swap(c.staging);
   }
   int cur = 0;
   const bool have = hipGetDevice(&cur) == hipSuccess;
@@ -127,6 +136,7 @@ void dev_release_cache() {
   for (auto& d : streams) { (void)hipSetDevice(d.first); for (hipStream_t s : d.second) (void)hipStreamDestroy(s); }
   for (auto& ev : events) for (auto& d : ev) { (void)hipSetDevice(d.first); for (hipEvent_t e : d.second) (void)hipEventDestroy(e); }
   for (auto& d : pinned) { (void)hipSetDevice(d.first); for (void* p : d.second) (void)hipHostFree(p); }
+  for (auto& d : staging) { (void)hipSetDevice(d.first); if (d.second) (void)hipHostFree(d.second); }
   if (have) (void)hipSetDevice(cur);
 }
 
@@ -199,6 +209,69 @@ void dev_pinned_release(void* p) {
     if (v.size() < kMaxPinned) { v.push_back(p); return; }
   }
   (void)hipHostFree(p);
+}
+
+
+hipError_t dev_upload_staged(const UploadSeg* segs, int nseg) {
+  size_t total = 0;
+  for (int i = 0; i < nseg; ++i) total += segs[i].bytes;
+  auto plain = [&]() -> hipError_t {
+    for (int i = 0; i < nseg; ++i) if (segs[i].bytes) { const hipError_t e = hipMemcpy(segs[i].dst, segs[i].src, segs[i].bytes, hipMemcpyHostToDevice); if (e != hipSuccess) return e; }
+    return hipSuccess;
+  };
+  if (total < kStageChunk) return plain();
+  Cache& c = cache();
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::unique_lock<std::mutex> ring(c.staging_m, std::try_to_lock);
+  if (!ring.owns_lock()) return plain();
+  char* base = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(c.m);
+    auto it = c.staging.find(dev);
+    if (it != c.staging.end()) base = static_cast<char*>(it->second);
+  }
+  if (!base) {
+    void* q = nullptr;
+    if (hipHostMalloc(&q, kStageBytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return plain(); }
+    base = static_cast<char*>(q);
+    std::lock_guard<std::mutex> lk(c.m);
+    c.staging[dev] = q;
+  }
+  struct Piece { int seg; size_t off, len; };
+  std::vector<Piece> pieces;
+  for (int i = 0; i < nseg; ++i) for (size_t off = 0; off < segs[i].bytes; off += kStageChunk) pieces.push_back(Piece{i, off, std::min(kStageChunk, segs[i].bytes - off)});
+  const int T = (int)std::min<size_t>(kStageThreads, pieces.size());
+  std::vector<hipError_t> err((size_t)T, hipSuccess);
+  auto work = [&](int t) {
+    hipError_t& er = err[(size_t)t];
+    if ((er = hipSetDevice(dev)) != hipSuccess) return;
+    hipStream_t st = nullptr; hipEvent_t ev[2] = {nullptr, nullptr};
+    if ((er = dev_stream_acquire(&st)) != hipSuccess) return;
+    if ((er = dev_event_acquire(&ev[0], false)) == hipSuccess) er = dev_event_acquire(&ev[1], false);
+    char* slot[2] = {base + ((size_t)t * 2) * kStageChunk, base + ((size_t)t * 2 + 1) * kStageChunk};
+    int k = 0;
+    for (size_t q = (size_t)t; q < pieces.size() && er == hipSuccess; q += (size_t)T, ++k) {
+      const Piece& pc = pieces[q];
+      const int sl = k & 1;
+      if (k >= 2 && (er = hipEventSynchronize(ev[sl])) != hipSuccess) break;   // (the DMA that last read this slot is done)
+      std::memcpy(slot[sl], static_cast<const char*>(segs[pc.seg].src) + pc.off, pc.len);
+      if ((er = hipMemcpyAsync(static_cast<char*>(segs[pc.seg].dst) + pc.off, slot[sl], pc.len, hipMemcpyHostToDevice, st)) != hipSuccess) break;
+      er = hipEventRecord(ev[sl], st);
+    }
+    const hipError_t es = hipStreamSynchronize(st);   // (whatever happened: nothing of this thread's is in flight when the ring is handed on)
+    if (er == hipSuccess) er = es;
+    if (ev[0]) dev_event_release(ev[0], false);
+    if (ev[1]) dev_event_release(ev[1], false);
+    dev_stream_release(st);
+  };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < T; ++t) pool.emplace_back(work, t);
+  work(0);
+  for (auto& th : pool) th.join();
+  for (hipError_t x : err) if (x != hipSuccess) return x;
+  return hipSuccess;
 }
 
 }  // namespace rsba
