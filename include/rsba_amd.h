@@ -115,7 +115,7 @@ typedef struct rsba_solver_summary {
  * ordered [cam 9]? [pose0 6] [pose1 6]? [point 3]). */
 typedef struct rsba_device_view {
   double* residuals;
-  double* jacobians;
+  double* jacobians;        /* NULL until an evaluation WITH Jacobians has run on the handle (the buffer — 16 K bytes per observation — is allocated then, not by the view) */
   int64_t tile;
   int32_t jacobian_cols;    /* K */
   int32_t reserved;

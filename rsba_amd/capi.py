@@ -257,10 +257,14 @@ class DeviceProblem:
             if cur is bound:
                 continue
             cur = np.asarray(cur, dtype=np.float64)
-            if cur.size != bound.size:
+            # the same SHAPE, or the flat form of it: anything else with as many elements ((F*2, 6), (6, 2, F) ...) would be re-read in another element order
+            if cur.shape != bound.shape and cur.shape != (bound.size,):
                 raise ValueError(f"{name}: {cur.shape} cannot replace the {bound.shape} array this handle was created with")
             if take_values:
                 np.copyto(bound, cur.reshape(bound.shape))
+            else:
+                import warnings
+                warnings.warn(f"{name}: the array assigned to the problem since the handle was created is replaced by the handle's own (results are written there)", stacklevel=3)
             setattr(p, name, bound)
 
     def upload_parameters(self):

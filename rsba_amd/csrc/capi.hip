@@ -350,7 +350,8 @@ int32_t rsba_evaluate_device(rsba_handle* h, int32_t with_jacobians) {
 int32_t rsba_get_device_view(rsba_handle* h, rsba_device_view* v) {
   if (!h || !v) return fail(RSBA_ERR_INVALID_ARGUMENT, "null argument");
   std::memset(v, 0, sizeof *v);
-  if (int32_t rc = ensure_jacobians(h)) return rc;
+  // (jacobians stays NULL until an evaluation WITH Jacobians has run — rsba_evaluate_device(h, 1), rsba_evaluate with a Jacobian output,
+  // rsba_time_evaluate(…, 1): the buffer is 480 B per observation, 4 GB at 4k cameras, and BA() never needs it; a view must not be what allocates it)
   v->residuals = h->dp.res; v->jacobians = h->dp.jac; v->tile = kEvalBlock; v->jacobian_cols = h->dp.K;
   ensure_order(h);
   v->order_host = h->order.data(); v->poses = h->dp.poses; v->points = h->dp.points; v->intrinsics = h->dp.intr;

@@ -527,6 +527,13 @@ __device__ __forceinline__ double* factor_ptr(const SolverDev& sv, int slot) { r
 // memory side).  A factor tile is an operand of ~12 products in as many tasks (chol_dag_kernel pulled 12 x the factor's size from the
 // fabric when every operand load was coherent): the tasks that come after the first find it in L2.  Lines of an EARLIER solve cannot
 // be met: the cells are re-armed by a launch of their own, and a launch starts with its XCD's L2 invalidated.
+// What that last sentence rests on: the two sets of cells alternate from solve to solve; a set is re-armed (hipMemsetAsync on
+// the arming stream) while the OTHER set's kernel runs, and this kernel waits for its own set's re-arming through an event.  A kernel
+// dispatch packet carries an acquire fence of agent scope or wider (HSA AQL header, set by the HIP runtime for every launch): the L2 of
+// every XCD the launch lands on is invalidated before the first wave runs, so a FILLED line of this set from two solves ago cannot be in
+// any L2 when the kernel starts, and inside the kernel a line of this set can only have been cached empty or final.  Should a runtime
+// ever launch without that fence, the result is a wrong factor — which the residual check that follows every DAG solve (verify_dag, on
+// by default: solver.hip) catches and repairs on the level schedule; tools/dag_stress.py alternates both sets for thousands of solves.
 template <bool DAG, bool COHERENT>
 __device__ __forceinline__ void Frag::load(const double* tile, int wave, int lane) {
   const double* p = tile + (lane & 15) * T + 12 * wave + 3 * (lane >> 4);

@@ -44,6 +44,12 @@ struct DeviceProblem {
   //   [r0 r1 | Jp row0 (3) Jp row1 (3) | Jc row0 (K-3) Jc row1 (K-3)]
   // so that everything the point elimination needs about one point is contiguous in HBM.
   double* rec;                   // [N][rec_len]
+  // A CANDIDATE's records go to a second buffer (round 6): a rejected step needs the records of the point it started from, and the loop
+  // whose decisions are taken on the device cannot wait for the decision before it evaluates.  Which of the two holds the records of the
+  // current point: rec, unless the device-side trust region says otherwise (ctl[kCtlRecSel], flipped by the deciding kernel on acceptance;
+  // the host form swaps the two pointers instead).  null = one buffer (the host form evaluates candidates residual-only then).
+  double* rec_alt;               // [N][rec_len] or null
+  int rec_candidate;             // this launch's LM-mode evaluation is a candidate's: its records go to the buffer that is NOT current
   const int32_t* obs_slot;       // [N]
   // LM mode: the per-frame camera (and intrinsics border) blocks are formed inside the evaluation kernel (fp64 MFMA
   // over each wave's 64 observations) instead of from a second pass over the tiled Jacobian, which is then not
@@ -86,11 +92,18 @@ enum LmCtlSlot : int {
   kCtlAccept = 5,                          // 1: the candidate of this iteration became x (its linearisation follows), 0: it did not
   kCtlStatus = 6,                          // 0: running; 1 + termination type: done; -1: the host must take over (a suspect factorisation)
   kCtlIteration = 7, kCtlInvalidStreak = 8, kCtlSuccessful = 9, kCtlUnsuccessful = 10, kCtlFinalCost = 11, kCtlNumTrace = 12,
+  kCtlRecSel = 13,                         // problems that keep records: 1 = the records of the current point are in dp.rec_alt (flipped on every acceptance)
   kCtlPending = 16,                        // [4] relative decrease, cost change, step norm, model cost change of an accepted step whose record waits for its gradient
   kCtlSeq = 23,                            // in a snapshot on the host only: the sequence number of the iteration it was taken behind, written last
   kCtlSize = 24
 };
 __device__ __forceinline__ bool lm_stopped(const double* ctl) { return ctl && ctl[kCtlStatus] != 0.0; }
+// the records of the current point (candidate = false) / where a candidate's evaluation puts its own (true)
+__device__ __forceinline__ double* lm_records(const DeviceProblem& dp, bool candidate) {
+  if (!dp.rec_alt) return dp.rec;
+  const bool sel = dp.ctl && dp.ctl[kCtlRecSel] != 0.0;
+  return (sel != candidate) ? dp.rec_alt : dp.rec;
+}
 __device__ __forceinline__ bool lm_not_accepted(const double* ctl) { return ctl && (ctl[kCtlStatus] != 0.0 || ctl[kCtlAccept] == 0.0); }
 
 constexpr int kEvalBlock = 256;

@@ -123,6 +123,7 @@ __global__ __launch_bounds__(kEvalBlock) void eval_kernel(const DeviceProblem dp
       {
         const int lane = tid & 63, wv = tid >> 6;
         double* st = s_tr + wv * TRW;
+        double* const recw = lm_records(dp, dp.rec_candidate != 0);
         const int my_slot = valid ? dp.obs_slot[ic] : -1;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(kEvalBlock) void eval_kernel(const DeviceProblem dp
             const int rcd = idx / (REC / 2), part = idx % (REC / 2);
             const int slot = __shfl(my_slot, 32 * h + (rcd < 32 ? rcd : 31), 64);
             if (idx < 16 * REC && slot >= 0)
-              *reinterpret_cast<double2*>(dp.rec + (size_t)slot * REC + 2 * part) = make_double2(st[rcd * RPITCH + 2 * part], st[rcd * RPITCH + 2 * part + 1]);
+              *reinterpret_cast<double2*>(recw + (size_t)slot * REC + 2 * part) = make_double2(st[rcd * RPITCH + 2 * part], st[rcd * RPITCH + 2 * part + 1]);
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }

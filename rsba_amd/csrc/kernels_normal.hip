@@ -170,6 +170,7 @@ __device__ __forceinline__ bool gpos_factored(uint32_t gpos) { return (gpos & 1u
 // Q_j,c = sum_{o of j in frames that use c} Ji_o^T (Jp_o L_j^-T)   (9 x 3), cut into the NPF pseudo-frame records of the group
 template <int CD>
 __global__ __launch_bounds__(256) void virtual_records_kernel(const DeviceProblem dp, const SolverDev sv) {
+  if (lm_stopped(sv.ctl)) return;
   const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (g >= sv.nvgroups) return;
   const int j = sv.vgroup_point[g], c = sv.vgroup_intr[g];
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(256) void virtual_records_kernel(const DeviceProble
   for (int k = 0; k < 9; ++k) { Q[k][0] = 0.0; Q[k][1] = 0.0; Q[k][2] = 0.0; }
   for (int64_t s = sv.point_ptr[j]; s < sv.point_ptr[j + 1]; ++s) {
     if (sv.NIB > 1 && dp.frame_intr[sv.slot_frame[s]] != c) continue;
-    const double* rec = dp.rec + (size_t)s * REC;
+    const double* rec = lm_records(dp, false) + (size_t)s * REC;
     double B[2][3];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
@@ -216,12 +217,13 @@ __global__ __launch_bounds__(256) void virtual_records_kernel(const DeviceProble
 // K2b  per-point block  V_j = sum Jp^T Jp (6 unique),  g_p,j = sum Jp^T r   (point-major records)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void point_blocks_kernel(const DeviceProblem dp, const SolverDev sv) {
+  if (lm_not_accepted(sv.ctl)) return;   // (device-side trust region: a rejected candidate is not linearised)
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= dp.M) return;
   const int REC = 2 + 2 * dp.K;
   double v[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
   for (int64_t s = sv.point_ptr[j]; s < sv.point_ptr[j + 1]; ++s) {
-    const double2* rp = reinterpret_cast<const double2*>(dp.rec + (size_t)s * REC);
+    const double2* rp = reinterpret_cast<const double2*>(lm_records(dp, false) + (size_t)s * REC);
     const double2 a = rp[0], b = rp[1], c = rp[2], d = rp[3];   // r0 r1 | p00 p01 | p02 p10 | p11 p12
     const double r0 = a.x, r1 = a.y, p0[3] = {b.x, b.y, c.x}, p1[3] = {c.y, d.x, d.y};
     v[0] += p0[0] * p0[0] + p1[0] * p1[0]; v[1] += p0[0] * p0[1] + p1[0] * p1[1]; v[2] += p0[0] * p0[2] + p1[0] * p1[2];
@@ -348,6 +350,7 @@ inline int project_chunks(int64_t N) {   // ~2 k waves or more
 
 template <int CD, int KC>
 __global__ __launch_bounds__(256) void project_kernel(const DeviceProblem dp, const SolverDev sv) {
+  if (lm_stopped(sv.ctl)) return;
   constexpr int REC = 8 + 2 * KC, OUT = CD * 3;
   constexpr int PITCH = (REC > OUT ? REC : OUT) | 1;          // odd
   constexpr int off = KC - CD;                                  // 9 when intrinsics columns precede the pose
@@ -364,7 +367,7 @@ __global__ __launch_bounds__(256) void project_kernel(const DeviceProblem dp, co
   int pre_point = 0; uint32_t pre_gpos = 0;
   auto issue = [&](int64_t c0) {
     const int64_t last = (se - c0) * REC - 1;
-    const double* src = dp.rec + (size_t)c0 * REC;
+    const double* src = lm_records(dp, false) + (size_t)c0 * REC;
 #pragma unroll
     for (int k = 0; k < REC; ++k) { const int64_t idx = k * 64 + lane; pre[k] = src[idx < last ? idx : last]; }
     const int64_t sl = c0 + lane < se ? c0 + lane : se - 1;
@@ -823,6 +826,7 @@ __global__ __launch_bounds__(256) void schur_merge_kernel(const DeviceProblem dp
 // in slot order (fixed order: deterministic).
 template <int CD, int KC>
 __global__ __launch_bounds__(256) void point_step_kernel(const DeviceProblem dp, const SolverDev sv) {
+  if (lm_stopped(sv.ctl)) return;
   constexpr int REC = 8 + 2 * KC, PITCH = REC | 1, off = KC - CD, NC = 5;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   __shared__ double s_red[4];
@@ -844,7 +848,7 @@ __global__ __launch_bounds__(256) void point_step_kernel(const DeviceProblem dp,
     // clamped lane are never used), so nothing next to the load makes the compiler wait for it
     auto issue = [&](int64_t c0) {
       const int64_t last = (se - c0) * REC - 1;
-      const double* src = dp.rec + (size_t)c0 * REC;
+      const double* src = lm_records(dp, false) + (size_t)c0 * REC;
 #pragma unroll
       for (int k = 0; k < REC; ++k) { const int64_t idx = k * 64 + lane; pre[k] = src[idx < last ? idx : last]; }
       pre_frame = sv.slot_frame[c0 + lane < se ? c0 + lane : se - 1];
@@ -1468,6 +1472,7 @@ __device__ __forceinline__ void lm_decide_step(const SolverDev& sv, double* ctl,
       radius = radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
       radius = fmin(R.max_trust_region_radius, radius); decrease = 2.0;
       ctl[kCtlRadius] = radius; ctl[kCtlDecrease] = decrease; ctl[kCtlAccept] = 1.0;
+      ctl[kCtlRecSel] = 1.0 - ctl[kCtlRecSel];   // (problems that keep records: the candidate's are the current point's from here on — device_state.hpp: lm_records)
       if (sv.rt) sv.rt[kRtRatio] = sv.rt[kRtRatioNew];
       // (the iteration's record is finished by lm_decide_gradient_kernel once the accepted point is linearised)
       ctl[kCtlPending] = it.relative_decrease; ctl[kCtlPending + 1] = it.cost_change; ctl[kCtlPending + 2] = it.step_norm; ctl[kCtlPending + 3] = it.model_cost_change;

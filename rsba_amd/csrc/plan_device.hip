@@ -255,12 +255,19 @@ __device__ __forceinline__ void entries_of(uint32_t g0, uint32_t g1, const int32
   }
 }
 __global__ void entry_count_kernel(int M, int nt, const uint32_t* __restrict__ pt_group, const uint32_t* __restrict__ ng_total, const int32_t* __restrict__ g_tile,
-                                   uint32_t* __restrict__ nent, uint32_t* __restrict__ pair_flag) {
+                                   uint32_t* __restrict__ nent, uint32_t* __restrict__ pair_flag, unsigned long long* __restrict__ total64) {
   const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= M) return;
   uint32_t c = 0;
-  entries_of(pt_group[j], j + 1 < M ? pt_group[j + 1] : *ng_total, g_tile, [&](uint32_t gx, uint32_t gy) { ++c; pair_flag[(size_t)g_tile[gx] * nt + g_tile[gy]] = 1u; });   // (everybody writes the same 1)
-  nent[j] = c;
+  if (j < M) {
+    entries_of(pt_group[j], j + 1 < M ? pt_group[j + 1] : *ng_total, g_tile, [&](uint32_t gx, uint32_t gy) { ++c; pair_flag[(size_t)g_tile[gx] * nt + g_tile[gy]] = 1u; });   // (everybody writes the same 1)
+    nent[j] = c;
+  }
+  // the entries' total in 64 bits beside the 32-bit prefix sums (entries grow with the SQUARE of a point's tiles: a long-track scene can pass
+  // 2^32 of them below the 2^32-doubles limit of the groups — the scan would wrap without a word).  An integer sum: order-free.
+  unsigned long long w = c;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) w += __shfl_down(w, off, 64);
+  if ((threadIdx.x & 63) == 0 && w) atomicAdd(total64, w);
 }
 __global__ void mark_keys_kernel(const uint32_t* __restrict__ keys, int64_t n, uint32_t* __restrict__ flag) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -431,12 +438,18 @@ hipError_t device_plan_lists(const DevicePlanIn& in, DevicePlanOut* out) {
     PD_TRY(hipMemcpyAsync(d_keys, in.struct_keys, (size_t)in.num_struct_keys * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(mark_keys_kernel, dim3(blocks256(in.num_struct_keys)), dim3(256), 0, st, d_keys, in.num_struct_keys, pair_flag);
   }
-  hipLaunchKernelGGL(entry_count_kernel, dim3(blocks256(M)), dim3(256), 0, st, M, nt, pt_group, totals + 2, g_tile, nent_pt, pair_flag);
+  hipLaunchKernelGGL(entry_count_kernel, dim3(blocks256(M)), dim3(256), 0, st, M, nt, pt_group, totals + 2, g_tile, nent_pt, pair_flag, reinterpret_cast<unsigned long long*>(totals + 10));
   PD_TRY(scan_exclusive(nent_pt, ent_off, M, scratch, totals + 4, st));
   PD_TRY(scan_exclusive(pair_flag, pair_idx, nkeys, scratch, totals + 5, st));
   PD_TRY(hipMemcpyAsync(h_tot, totals, sizeof h_tot, hipMemcpyDeviceToHost, st));
   PD_TRY(hipStreamSynchronize(st));
   const int64_t nent = h_tot[4]; const int ntp = (int)h_tot[5];
+  {
+    unsigned long long nent64 = 0;
+    PD_TRY(hipMemcpyAsync(&nent64, totals + 10, sizeof nent64, hipMemcpyDeviceToHost, st));
+    PD_TRY(hipStreamSynchronize(st));
+    if (nent64 != (unsigned long long)nent) return hipErrorInvalidValue;   // more than 2^32 - 1 entries: the 32-bit lists cannot hold them (the caller says so)
+  }
   out->nent = nent;
   int32_t *d_tpI = nullptr, *d_tpJ = nullptr;
   PD_TMP(d_tpI, (size_t)ntp); PD_TMP(d_tpJ, (size_t)ntp);

@@ -563,8 +563,8 @@ int32_t build_solver_impl(rsba_handle* h) {
     s->allocs.insert(s->allocs.end(), dpo.owned.begin(), dpo.owned.end());
     if (pe != hipSuccess) {
       (void)hipGetLastError();
-      const int32_t code = pe == hipErrorOutOfMemory ? RSBA_ERR_OUT_OF_MEMORY : RSBA_ERR_HIP;
-      dev_why = std::string("device plan: ") + hipGetErrorString(pe);
+      const int32_t code = pe == hipErrorOutOfMemory ? RSBA_ERR_OUT_OF_MEMORY : pe == hipErrorInvalidValue ? RSBA_ERR_UNSUPPORTED : RSBA_ERR_HIP;
+      dev_why = pe == hipErrorInvalidValue ? std::string("device plan: 2^32 or more (point, tile pair) entries — the lists are indexed with 32 bits") : std::string("device plan: ") + hipGetErrorString(pe);
       if (!plan_votes) return rsba_set_error(code, dev_why.c_str());
       local_fail = code; local_why = dev_why.c_str();
     }
@@ -1296,13 +1296,20 @@ int32_t build_solver_impl(rsba_handle* h) {
   h->dp.obs_slot = s->d_obs_slot;
   // The point-side passes recompute the records (lm_record.hpp) from the observations in slot order; problems with several
   // intrinsics parameter blocks (per-frame f.cam) keep the point-major copy.  RSBA_RECORDS=1 forces the copy.
-  sv.slot_xy = nullptr; h->dp.rec = nullptr;   // (recompute: settled with the group layout above)
+  sv.slot_xy = nullptr; h->dp.rec = nullptr; h->dp.rec_alt = nullptr; h->dp.rec_candidate = 0;   // (recompute: settled with the group layout above)
   if (recompute) {
     double2* sxy = nullptr;
     if ((rc = s_alloc(s, &sxy, (size_t)N))) return rc;
     HIP_TRY(launch_slot_xy(h->dp, sxy, h->stream));
     sv.slot_xy = sxy;
-  } else if ((rc = s_alloc(s, &h->dp.rec, (size_t)N * REC))) return rc;
+  } else {
+    if ((rc = s_alloc(s, &h->dp.rec, (size_t)N * REC))) return rc;
+    // ... and a second set for a candidate's records (device_state.hpp: rec_alt): with it the candidate is evaluated in LM mode like everybody
+    // else's, and problems that keep records — several intrinsics blocks (per-frame f.cam, CeresHandler.h:260,277) — run the loop whose
+    // decisions are taken on the device.  RSBA_RECORDS_ALT=0: one set, candidates residual-only, the host decides (round 5's form; A/B)
+    const char* e = std::getenv("RSBA_RECORDS_ALT");
+    if (!(e && e[0] == '0')) { if ((rc = s_alloc(s, &h->dp.rec_alt, (size_t)N * REC))) return rc; }
+  }
   sv.fused_sweep = sv.slot_xy && !h->dp.calibrated && sv.CD == 12 && sv.all_real_factored != 0 && sv.NPF > 0 && sv.nvgroups > 0 && sv.NIB == 1 && !std::getenv("RSBA_NO_FUSED_SWEEP");
   if (N > 0) {
     // camera (and intrinsics border) blocks inside the evaluation kernel: per (64-observation wave, frame it touches)
@@ -1821,7 +1828,7 @@ void rsba_destroy_solver(rsba_handle* h) {
   if (dbg) std::fprintf(stderr, "[rsba destroy] plan: streams + events to the pool %.2f ms; stream sync %.2f ms; blocks to the cache %.2f ms; host state %.2f ms\n", 1e3 * (td1 - td0), 1e3 * (td2 - td1), 1e3 * (td3 - td2), 1e3 * (now_s() - td3));
   h->solver = nullptr;
   if (h->prior_split) { h->dp.prior_of = h->prior_of_all; h->prior_invalid = h->prior_invalid_all; h->prior_split = false; }   // the rank's share of the priors was a table of the plan
-  h->dp.rec = nullptr; h->dp.obs_slot = nullptr; h->dp.cam_part = nullptr; h->dp.wave_seg_base = nullptr; h->dp.frame_rank = nullptr;
+  h->dp.rec = nullptr; h->dp.rec_alt = nullptr; h->dp.rec_candidate = 0; h->dp.obs_slot = nullptr; h->dp.cam_part = nullptr; h->dp.wave_seg_base = nullptr; h->dp.frame_rank = nullptr;
 }
 
 // gradient of Problem::Evaluate: loss-corrected J^T r on the masked tangent space, [F*P*6 | M*3 | NI*9]
@@ -2172,7 +2179,7 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
   // A candidate is evaluated in LM mode straight away (residuals, Jacobian, per-wave camera blocks) when the problem keeps no
   // records (they would be overwritten and a rejected step needs the old ones): an accepted step — the rule — then re-uses that
   // evaluation for its linearisation instead of evaluating twice, a rejected one has computed Jacobians for nothing.
-  bool speculate = dp.rec == nullptr;
+  bool speculate = dp.rec == nullptr || dp.rec_alt != nullptr;   // (records: only with a second set for the candidate's)
   if (const char* e = std::getenv("RSBA_SPECULATE")) speculate = speculate && e[0] != '0';
   int invalid_streak = 0, iteration = 0;
   const size_t pose_bytes = (size_t)dp.F * dp.P * 6 * sizeof(double), point_bytes = (size_t)dp.M * 3 * sizeof(double);
@@ -2259,7 +2266,7 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
       if (s->ucross && (sv.lead || h->prior_split)) HIP_TRY(launch_prior_model(dp, sv, sv.scalars + kModelCostChange, 0.0, st, free_ratio ? s->ratio4 + kRtC : nullptr));   // motion priors: their share of the model cost change (a free ratio's step included) ...
       if (has_pp) HIP_TRY(launch_pose_prior_step(dp, sv, s->pp, 1.0, st));   // per-pose priors: the candidate priorPoses values, their share of the three sums (the lead rank's to add)
       swap_params();
-      HIP_TRY(launch_eval(dp, kLmJacobian, st));
+      { DeviceProblem dq = dp; dq.rec_candidate = 1; HIP_TRY(launch_eval(dq, kLmJacobian, st)); }   // (a problem that keeps records: the candidate's go to the other set)
       const bool extra_cost = s->ucross != nullptr || has_pp;   // prior blocks add their cost behind the observations': the cost is reduced by a launch of its own then
       if (extra_cost) {                                                                                // ... their cost at the candidate, behind the observations' ...
         HIP_TRY(launch_cost_reduce(dp, h->d_cost2, st));
@@ -2326,6 +2333,7 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
       dp.prior_ratio = ratio;
     }
     radius = hc[kCtlRadius]; decrease_factor = hc[kCtlDecrease]; cost = hc[kCtlCost]; gmax = hc[kCtlGmax];
+    if (dp.rec_alt && hc[kCtlRecSel] != 0.0) std::swap(dp.rec, dp.rec_alt);   // (the set that holds the current point's records is dp.rec again, as the host form has it)
     iteration = (int)hc[kCtlIteration]; invalid_streak = (int)hc[kCtlInvalidStreak];
     sum->num_successful_steps = (int)hc[kCtlSuccessful]; sum->num_unsuccessful_steps = (int)hc[kCtlUnsuccessful]; sum->final_cost = hc[kCtlFinalCost];
     const double status = hc[kCtlStatus];
@@ -2360,7 +2368,7 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
     swap_params();
     {
       PhaseScope ps(h, RSBA_PHASE_EVAL_TRIAL);
-      HIP_TRY(launch_eval(dp, speculate ? kLmJacobian : kResidualOnly, st));
+      { DeviceProblem dq = dp; dq.rec_candidate = 1; HIP_TRY(launch_eval(dq, speculate ? kLmJacobian : kResidualOnly, st)); }
       HIP_TRY(launch_cost_reduce(dp, h->d_cost2, st));
     }
     if (s->ucross && (sv.lead || h->prior_split)) {
@@ -2415,6 +2423,7 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
         radius = radius / std::max(1.0 / 3.0, 1.0 - t3 * t3 * t3);
         radius = std::min(opt->max_trust_region_radius, radius); decrease_factor = 2.0; reuse_diagonal = false;
         swap_params();   // x = x_plus_delta
+        if (speculate && dp.rec_alt) std::swap(dp.rec, dp.rec_alt);   // ... and its records, where the problem keeps them
         if (free_ratio) { ratio = ratio_new; dp.prior_ratio = ratio; }
         if (sv.NPF > 0) HIP_TRY(hipMemcpyAsync(sv.trial_intr, dp.intr, 9 * (size_t)dp.NI * sizeof(double), hipMemcpyDeviceToDevice, st));   // constant coordinates stay in sync
         t0 = now_s();

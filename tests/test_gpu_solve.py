@@ -482,7 +482,7 @@ def test_device_blocks_are_cached_between_handles_and_given_back(capi):
 
 @pytest.mark.parametrize("case", ["c2", "rejections", "failure", "tolerances", "max_iterations", "huber", "priors", "priors_rejections", "c2_priors", "intrinsics", "intrinsics_rejections", "intrinsics_priors",
                                   "free_ratio", "free_ratio_rejections", "free_ratio_acceleration", "c2_free_ratio", "pose_priors", "pose_priors_rejections", "pose_priors_free_ratio",
-                                  "spherical", "spherical_pose_priors"])
+                                  "spherical", "spherical_pose_priors", "per_frame_intrinsics", "per_frame_intrinsics_rejections", "mixed_intrinsics_priors"])
 def test_device_side_trust_region_equals_the_host_form(capi, monkeypatch, case):
     """accept / reject, the radius update and the convergence tests of the LM loop run in a single-thread kernel, the
     iteration's kernels read the radius from HBM and skip themselves where the host form would not have launched them, the host
@@ -506,7 +506,15 @@ def test_device_side_trust_region_equals_the_host_form(capi, monkeypatch, case):
         if case.startswith("intrinsics"):            # the shared intrinsics as a parameter block (what BASELINE config 5 has): pseudo frames in the reduced system, virtual records
             p.calibrated = False; p.huber_a = 2.0
             p.intrinsics = p.intrinsics * (1.0 + 1e-3 * np.array([[1, -1, 20, -20, 10, 10, -10, 0.5, -0.5]]))
-        if case.startswith("priors") or case == "intrinsics_priors":                # motion priors with a known interFrameRatio (CeresHandler.h:147-185): their cost, blocks and model change are part of every decision
+        if case in ("per_frame_intrinsics", "per_frame_intrinsics_rejections", "mixed_intrinsics_priors"):   # per-frame f.cam blocks (CeresHandler.h:256-264,273-280): several 9-blocks — these problems
+            p.calibrated = False; p.huber_a = 2.0                  # keep their records; a candidate's go to a second set (device_state.hpp: rec_alt), so that this loop can run them too (round 6)
+            rng = np.random.default_rng(3)
+            F = p.num_frames
+            fi = np.arange(F, dtype=np.int32) if case != "mixed_intrinsics_priors" else np.concatenate([np.zeros(F // 2, dtype=np.int32), np.arange(1, F - F // 2 + 1, dtype=np.int32)])
+            ni = int(fi.max()) + 1
+            p.intrinsics = np.tile(p.intrinsics[:1], (ni, 1)) * (1.0 + 1e-3 * rng.normal(size=(ni, 9)) * np.array([[1, 1, 20, 20, 10, 10, 10, 0.5, 0.5]]))
+            p.frame_intrinsics = fi
+        if case.startswith("priors") or case in ("intrinsics_priors", "mixed_intrinsics_priors"):                # motion priors with a known interFrameRatio (CeresHandler.h:147-185): their cost, blocks and model change are part of every decision
             p.prior_kind, p.prior_scale, p.inter_frame_ratio = 1, 1.0 if case == "priors_rejections" else 10.0, 0.8
             p.prior_frames = np.arange(1, p.num_frames, dtype=np.int32)
         if case.startswith("spherical"):     # the SphericalPrior on the first pose of frame 1 of a session that starts at the origin (CeresHandler.h:36-50,127-130): 1e20 on the residual — the
@@ -521,7 +529,7 @@ def test_device_side_trust_region_equals_the_host_form(capi, monkeypatch, case):
             p.prior_kind = 2 if case == "free_ratio_acceleration" else 1   # unknown of every decision (its step out of the factorisation's second right-hand side, its candidate, its projected gradient)
             p.prior_scale, p.inter_frame_ratio, p.ratio_free = 1.0 if case == "free_ratio_rejections" else 10.0, 1.0, True
             p.prior_frames = np.arange(1, p.num_frames, dtype=np.int32)
-        if case in ("rejections", "failure", "priors_rejections", "intrinsics_rejections", "free_ratio_rejections", "pose_priors_rejections"):      # a start far from the minimum and a huge first radius: Gauss-Newton steps that overshoot (or never recover)
+        if case in ("rejections", "failure", "priors_rejections", "intrinsics_rejections", "free_ratio_rejections", "pose_priors_rejections", "per_frame_intrinsics_rejections"):      # a start far from the minimum and a huge first radius: Gauss-Newton steps that overshoot (or never recover)
             rng = np.random.default_rng(2)
             sc = 3.0 if case == "failure" else 2.0
             p.points += rng.normal(0, 0.6 * sc, p.points.shape); p.poses[1:, :, 3:] += rng.normal(0, 0.25 * sc, p.poses[1:, :, 3:].shape)
@@ -529,7 +537,7 @@ def test_device_side_trust_region_equals_the_host_form(capi, monkeypatch, case):
             return p, dict(max_num_iterations=30, initial_trust_region_radius=1e12)
         if case == "tolerances":
             return p, dict(max_num_iterations=50)
-        if case in ("priors", "intrinsics", "intrinsics_priors", "free_ratio", "free_ratio_acceleration", "pose_priors", "pose_priors_free_ratio", "spherical", "spherical_pose_priors"):
+        if case in ("priors", "intrinsics", "intrinsics_priors", "free_ratio", "free_ratio_acceleration", "pose_priors", "pose_priors_free_ratio", "spherical", "spherical_pose_priors", "per_frame_intrinsics", "mixed_intrinsics_priors"):
             return p, dict(max_num_iterations=15)
         return p, dict(max_num_iterations=3)
     out = {}
