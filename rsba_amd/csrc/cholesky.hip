@@ -185,7 +185,7 @@ __device__ __forceinline__ void rearm_pivot_messages(double* smem, int lane, int
   for (int jj = j0; jj < j1; ++jj) smem[msg_off(jj) + lane] = __longlong_as_double(-1ll);
 }
 // first wave: d = symmetric positive definite 16 x 16 block, accumulator layout.  false on a non-positive / non-finite pivot.
-__device__ __forceinline__ bool ldl16_eliminate(dbl4_t d, double* msg, int lane) {
+__device__ __forceinline__ bool ldl16_eliminate(dbl4_t d, double* msg, int lane, long long* estamp = nullptr) {
   const int c = lane & 15, g = lane >> 4;
   typedef __attribute__((address_space(3))) double* lds_ptr;
   lds_ptr lm = (lds_ptr)msg;
@@ -204,6 +204,14 @@ __device__ __forceinline__ bool ldl16_eliminate(dbl4_t d, double* msg, int lane)
     const double row = grp ? dv : 0.0;                  // B: row jj of D   (k = gg slice, zero elsewhere)
     const double mul = (grp && c > jj) ? -q : 0.0;      // A: -D[jj][i] / d for the rows i below the pivot
     lm[msg_off(jj) + lane] = (grp && c == jj) ? dv : mul;  // the message: the multipliers, with the pivot itself in the (otherwise zero) lane of the diagonal
+    // The message must LEAVE here: left alone the compiler pairs the sixteen stores up (ds_write2st64_b64) and sinks them behind the
+    // thirteenth MFMA of the unrolled loop — the following wave then sees its first message 2 800 cycles into a 3 400-cycle block and
+    // ends 2 450 cycles after this one, three times per tile (round 6: read off the ISA; profiles/r06/tile_factor.txt).
+#ifndef RSBA_AB_NO_STORE_PIN   // (A/B builds of tools/_ab*.sh only)
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    if (estamp && lane == 0) estamp[jj] = clock64();       // (tools/tile_factor_bench.hip: when each message is posted)
     if (jj < 15) d = __builtin_amdgcn_mfma_f64_16x16x4f64(mul, row, d, 0, 0, 0);
   }
   return ok;
@@ -256,7 +264,7 @@ __device__ __forceinline__ double rsqrt_cubic(double x) {
   const double e = fma(-x * y0, y0, 1.0);
   return fma(y0 * e, fma(0.375, e, 0.5), y0);
 }
-__device__ __forceinline__ void ldl16_follow_rows(const double* msg, double* Wl, int o, int lane) {
+__device__ __forceinline__ void ldl16_follow_rows(const double* msg, double* Wl, int o, int lane, long long* fstamp = nullptr) {
   typedef const volatile __attribute__((address_space(3))) double* lds_cvptr;
   typedef double dbl2_t __attribute__((ext_vector_type(2)));
   typedef const __attribute__((address_space(3))) dbl2_t* lds_c2ptr;
@@ -287,6 +295,7 @@ __device__ __forceinline__ void ldl16_follow_rows(const double* msg, double* Wl,
       double piv = next;
       if (__builtin_expect(__ballot(!filled(piv)) != 0ull, 0)) { do { piv = vm[cell + jj]; } while (__ballot(!filled(piv)) != 0ull); }
       piv_prev = piv_cur; piv_cur = piv;
+      if (fstamp && lane == 0) fstamp[4 * jj] = clock64();   // (tools/tile_factor_bench.hip: when each message is seen)
       asm volatile("" ::: "memory");
       if (jj < 15) next = vm[msg_off(jj + 1) + 16 * ((jj + 1) & 3) + jj + 1];
 #pragma unroll
@@ -314,6 +323,7 @@ __device__ __forceinline__ void ldl16_follow_rows(const double* msg, double* Wl,
       if (nstep < 6) { q0 = y0 * t0; p0 = fma(0.375, t0, 0.5); }
       const double rs = fma(q0, p0, y0);
       wl[(o + k) * TP + o + c] = rs * e[k];   // row k has been final since pivot k - 1 (exact zeros right of the diagonal: E is lower triangular)
+      if (fstamp && lane == 0) fstamp[4 * k + 3] = clock64();   // (... and when each row has been stored)
     }
   }
 }
@@ -509,10 +519,26 @@ __shared__ long long* s_trace_slot;   // RSBA_CHOL_TRACE: where the running task
 // Waiting costs memory traffic: a task that found a group of cells incomplete does not keep re-reading the whole group
 // (hundreds of claimed-but-waiting tasks doing that saturate the memory system) — it watches ONE cell of the
 // missing input, with a pause between looks, and reads the group again once that cell has landed.
+// Instrumented build only (-DRSBA_TEST_HOOKS, librsba_amd_hooks.so): what the persistent kernel reads COHERENTLY (from the memory side), by
+// kind — tools/chol_poll_split.py sets it beside the fabric-read counter of a rocprofv3 pass.  Wave-level events, one atomic per event by lane 0.
+//   [0] looks at a watched cell (one 64-byte line each)      [1] of them: looks that found the cell still empty
+//   [2] operand fragments read again coherently (9 x 512 B)   [3] W row blocks / tiles read (12 or 24 x 512 B)   [4] of them: reads that came back incomplete
+#ifdef RSBA_TEST_HOOKS
+__device__ unsigned long long g_chol_coherent[8];
+#define CHOL_COUNT(k, n) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_chol_coherent[k], (unsigned long long)(n)); } while (0)
+#else
+#define CHOL_COUNT(k, n) do { } while (0)
+#endif
 template <bool DAG>
 __device__ __forceinline__ void watch_cell(const double* p) {
   if (!DAG) return;
-  while (!filled(ld<true>(p))) __builtin_amdgcn_s_sleep(8);
+  for (;;) {
+    const bool there = filled(ld<true>(p));
+    CHOL_COUNT(0, 1);
+    if (there) break;
+    CHOL_COUNT(1, 1);
+    __builtin_amdgcn_s_sleep(8);
+  }
 }
 // a waiting task marks when its last late input arrived (RSBA_CHOL_TRACE)
 __device__ __forceinline__ void note_late_input() { if (threadIdx.x == 0 && s_trace_slot) s_trace_slot[2] = wall_clock64(); }
@@ -541,6 +567,7 @@ __device__ __forceinline__ void Frag::load(const double* tile, int wave, int lan
   for (int I = 0; I < 3; ++I)
 #pragma unroll
     for (int t = 0; t < 3; ++t) v[I][t] = (DAG && COHERENT) ? ld<true>(p + 16 * I * T + t) : gl(p + 16 * I * T + t);
+  if (DAG && COHERENT) CHOL_COUNT(2, 1);
 }
 
 // sum_{p in [p0,p1)} L_a(p) L_b(p)^T into acc (K-split over the waves), and for DIAG lists sum L_jk z_k into
@@ -761,13 +788,29 @@ __device__ __forceinline__ void times_inverse_transposed(const SolverDev& sv, in
   double wv[3][12];   // B operand: W[16J + r][4kk + g]
   {
     bool late = false;
+    // A SUB task's FIRST look at W_j goes through the caches, like the operand tiles of accumulate() (round 6): a dozen SUB tasks of a column
+    // read the same 18 KB, and every one of them used to fetch it from the memory side (180 MB per C4 launch for a 4.6 MB array of inverses,
+    // tools/chol_poll_split.py).  W_j is written once: what an ordinary load returns is final or empty — possibly a stale empty, which
+    // sends the task down the coherent path below, as before.  The DIAG task of the next column on the chain (EAGER) polls for rows that
+    // are being written: coherent from the start.
+    bool cached_look = DAG && !EAGER && kCachedOperands;
     for (;;) {
       bool ok = true;
+      if (cached_look) {
 #pragma unroll
-      for (int J = 0; J < 3; ++J)
+        for (int J = 0; J < 3; ++J)
 #pragma unroll
-        for (int kk = 0; kk < 4 * (J + 1); ++kk) { wv[J][kk] = ld<DAG>(Wg + (16 * J + r) * T + 4 * kk + g); ok = ok && filled(wv[J][kk]); }
+          for (int kk = 0; kk < 4 * (J + 1); ++kk) { wv[J][kk] = gl(Wg + (16 * J + r) * T + 4 * kk + g); ok = ok && filled(wv[J][kk]); }
+      } else {
+#pragma unroll
+        for (int J = 0; J < 3; ++J)
+#pragma unroll
+          for (int kk = 0; kk < 4 * (J + 1); ++kk) { wv[J][kk] = ld<DAG>(Wg + (16 * J + r) * T + 4 * kk + g); ok = ok && filled(wv[J][kk]); }
+        if (DAG) CHOL_COUNT(3, 24);
+      }
       if (!DAG || __ballot(!ok) == 0ull) break;
+      if (cached_look) { cached_look = false; watch_cell<DAG>(Wg + (T * T - 1) - T * (blockIdx.x & 15)); continue; }   // (not there, or a stale empty: wait for it on the memory side, then read it from there)
+      CHOL_COUNT(4, 24);
       late = true;
       // A SUB task watches one cell and reads again when it has landed (hundreds of them wait at a time).  A DIAG task is the
       // next link of the critical chain and only a handful wait for their W at any moment: it reads everything again straight
@@ -801,7 +844,9 @@ __device__ __forceinline__ dbl4 times_inverse_block(const SolverDev& sv, int til
     bool ok = true;
 #pragma unroll
     for (int kk = 0; kk < 12; ++kk) if (kk < 4 * (Jc + 1)) { wv[kk] = ld<DAG>(Wg + 4 * kk); ok = ok && filled(wv[kk]); }
+    if (DAG) CHOL_COUNT(3, 4 * (Jc + 1));
     if (!DAG || __ballot(!ok) == 0ull) break;
+    CHOL_COUNT(4, 4 * (Jc + 1));
     late = true;
     __builtin_amdgcn_s_sleep(2);
   }
@@ -1453,3 +1498,13 @@ hipError_t launch_chol_dag(const SolverDev& sv, const CholPlan& pl, const DagArg
 }
 
 }  // namespace rsba
+
+#ifdef RSBA_TEST_HOOKS
+// instrumented build only (not part of include/rsba_amd.h): the coherent-read counters of the persistent Cholesky kernel, since the last reset
+extern "C" int32_t rsba_debug_chol_coherent(unsigned long long out[8], int32_t reset) {
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(rsba::g_chol_coherent), 8 * sizeof(unsigned long long)) != hipSuccess) return RSBA_ERR_HIP;
+  if (reset) { const unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(rsba::g_chol_coherent), zero, sizeof zero) != hipSuccess) return RSBA_ERR_HIP; }
+  return RSBA_OK;
+}
+#endif
+

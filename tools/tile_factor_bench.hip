@@ -50,8 +50,50 @@ __global__ __launch_bounds__(256, 2) void tile_kernel(const double* __restrict__
 
 // the two waves of one 16 x 16 diagonal block step on their own: MODE 0 both, 1 the eliminating wave alone, 2 the following wave alone
 // on messages that are already there.  FW = which wave of the workgroup follows.
+// What slows the following wave down when the eliminating wave runs beside it (both: 366 cycles per pivot; alone on ready messages: 204)?
+// A STAND-IN for the eliminating wave posts the same messages (taken from a first, real elimination) at the eliminating wave's pace —
+// with nothing but s_sleep between them (PACER 1), or with the real wave's sixteen dependent rank-1 MFMAs on a dummy block in between
+// (PACER 2): if the follower keeps pace with 1 and not with 2, it is the matrix pipe's traffic that costs it, not the waiting.
+template <int PACER>
+__global__ __launch_bounds__(256) void paced_kernel(const double* __restrict__ Din, double* __restrict__ out, long long* t, int reps, int sleep_units) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  double* D = smem; double* msg = smem;
+  double* saved = smem + 4 * kBuf + 64;   // [16][64] the messages of a real elimination (behind the task's buffers)
+  for (int e = tid; e < T * T; e += 256) { const int r = e / T, c = e % T; D[r * TP + c] = (c <= r) ? Din[e] : 0.0; }
+  __syncthreads();
+  const dbl4_t d0 = load_sym16(D, 0, lane);
+  arm_pivot_messages(smem, tid);
+  __syncthreads();
+  if (wave == 0) ldl16_eliminate(d0, msg, lane);
+  __syncthreads();
+  if (wave == 0) for (int jj = 0; jj < 16; ++jj) saved[jj * 64 + lane] = msg[msg_off(jj) + lane];
+  __syncthreads();
+  dbl4_t acc = {0, 0, 0, 0}, dummy = d0;
+  long long lead = 0, foll = 0, total = 0;
+  for (int it = 0; it < reps; ++it) {
+    arm_pivot_messages(smem, tid);
+    __syncthreads();
+    const long long c0 = clock64();
+    if (wave == 0) {
+      for (int jj = 0; jj < 16; ++jj) {
+        if (PACER == 2) dummy = __builtin_amdgcn_mfma_f64_16x16x4f64(1e-30 * dummy[0], 1e-30, dummy, 0, 0, 0);   // (a dependent chain, like the real wave's)
+        for (int u = 0; u < sleep_units; ++u) __builtin_amdgcn_s_sleep(1);
+        msg[msg_off(jj) + lane] = saved[jj * 64 + lane];
+      }
+      lead += clock64() - c0;
+    }
+    if (wave == 1) { ldl16_follow_rows(msg, smem + kBuf, 0, lane); acc[0] += smem[kBuf + lane]; foll += clock64() - c0; }
+    __syncthreads();
+    total += clock64() - c0;
+  }
+  for (int v = 0; v < 4; ++v) out[tid * 4 + v] = acc[v] + dummy[v];
+  if (tid == 0) { t[0] = lead; t[2] = total; }
+  if (tid == 64) t[1] = foll;
+}
+
 template <int MODE, int FW, bool ROWS = false>
-__global__ __launch_bounds__(256) void pair_kernel(const double* __restrict__ Din, double* __restrict__ out, long long* t, int reps) {
+__global__ __launch_bounds__(256) void pair_kernel(const double* __restrict__ Din, double* __restrict__ out, long long* t, int reps, long long* stamps = nullptr) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   double* D = smem; double* msg = smem;
@@ -65,9 +107,11 @@ __global__ __launch_bounds__(256) void pair_kernel(const double* __restrict__ Di
     __syncthreads();
     if (MODE == 2 && it == 0) { if (wave == 0) ldl16_eliminate(d0, msg, lane); __syncthreads(); }
     const long long c0 = clock64();
-    if (wave == 0 && MODE != 2) { dbl4_t d = d0; asm volatile("" : "+v"(d)); const bool ok = ldl16_eliminate(d, msg, lane); acc[0] += ok; lead += clock64() - c0; }
+    const bool last = stamps && it == reps - 1;
+    if (last && tid == 0) stamps[0] = c0;
+    if (wave == 0 && MODE != 2) { dbl4_t d = d0; asm volatile("" : "+v"(d)); const bool ok = ldl16_eliminate(d, msg, lane, last ? stamps + 1 : nullptr); acc[0] += ok; lead += clock64() - c0; }
     if (wave == FW && MODE != 1) {
-      if (ROWS) { ldl16_follow_rows(msg, smem + kBuf, 0, lane); acc[0] += smem[kBuf + lane]; } else acc += ldl16_follow(msg, lane);
+      if (ROWS) { ldl16_follow_rows(msg, smem + kBuf, 0, lane, last ? stamps + 17 : nullptr); acc[0] += smem[kBuf + lane]; } else acc += ldl16_follow(msg, lane);
       foll += clock64() - c0;
     }
     __syncthreads();
@@ -147,7 +191,7 @@ int main() {
     auto run_pair = [&](auto kern, const char* name) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       long long h[3];
-      for (int pass = 0; pass < 2; ++pass) { hipLaunchKernelGGL(kern, dim3(1), dim3(256), lds, 0, dA, dO, dP, reps); (void)hipDeviceSynchronize(); }
+      for (int pass = 0; pass < 2; ++pass) { hipLaunchKernelGGL(kern, dim3(1), dim3(256), lds, 0, dA, dO, dP, reps, (long long*)nullptr); (void)hipDeviceSynchronize(); }
       (void)hipMemcpy(h, dP, sizeof h, hipMemcpyDeviceToHost);
       std::printf("%-48s eliminating wave %7.1f  following wave %7.1f  both + barrier %7.1f ticks per 16-pivot block\n", name, h[0] / (double)reps, h[1] / (double)reps, h[2] / (double)reps);
     };
@@ -158,6 +202,25 @@ int main() {
     run_pair(pair_kernel<0, 3>, "both, wave 3 follows");
     run_pair(pair_kernel<2, 1, true>, "W by rows: following wave alone (messages there)");
     run_pair(pair_kernel<0, 1, true>, "W by rows: both, wave 1 follows");
+    for (int sl : {0, 1, 2, 3, 4}) {
+      auto run_paced = [&](auto kern, const char* name) {
+        const size_t lds2 = lds + (64 + 16 * 64) * sizeof(double);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        long long h[3];
+        for (int pass = 0; pass < 2; ++pass) { hipLaunchKernelGGL(kern, dim3(1), dim3(256), lds2, 0, dA, dO, dP, reps, sl); (void)hipDeviceSynchronize(); }
+        (void)hipMemcpy(h, dP, sizeof h, hipMemcpyDeviceToHost);
+        std::printf("%-48s posting wave %7.1f  following wave %7.1f  both + barrier %7.1f ticks per 16-pivot block  (%d x s_sleep 1 per pivot)\n", name, h[0] / (double)reps, h[1] / (double)reps, h[2] / (double)reps, sl);
+      };
+      run_paced(paced_kernel<1>, "stand-in posts ready messages, sleeps between");
+      run_paced(paced_kernel<2>, "stand-in posts ready messages + dependent MFMAs");
+    }
+    {   // when each pivot message is posted (eliminating wave), seen, and its row stored (following wave): the last repetition of the pair above
+      long long* dQ; (void)hipMalloc(&dQ, 128 * 8); (void)hipMemset(dQ, 0, 128 * 8);
+      hipLaunchKernelGGL((pair_kernel<0, 1, true>), dim3(1), dim3(256), lds, 0, dA, dO, dP, 50, dQ); (void)hipDeviceSynchronize();
+      long long q[128]; (void)hipMemcpy(q, dQ, sizeof q, hipMemcpyDeviceToHost);
+      std::printf("pivot k: message posted | seen | next look + multipliers requested | updates of pivot k done | row k stored (shader cycles since the block started)\n");
+      for (int k = 0; k < 16; ++k) std::printf("  %2d: %6lld | %6lld | %6lld | %6lld | %6lld\n", k, q[1 + k] - q[0], q[17 + 4 * k] - q[0], q[17 + 4 * k + 1] - q[0], q[17 + 4 * k + 2] - q[0], q[17 + 4 * k + 3] - q[0]);
+    }
   }
   long long hs[64]; hipMemcpy(hs, dS, sizeof hs, hipMemcpyDeviceToHost);
   std::printf("phases of the last MFMA-pivot tile (clock64 ticks since entry; pairs = before / after each barrier):");
