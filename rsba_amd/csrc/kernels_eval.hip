@@ -161,6 +161,11 @@ __global__ __launch_bounds__(kEvalBlock) void eval_kernel(const DeviceProblem dp
       const int64_t wave_id = (base >> 6) + wv;
       int seg = dp.wave_seg_base[wave_id];
       int done = 0;
+      if (NCOL < 16 * NCB) {   // the padding columns of the operand rows are zero and stay zero: written once per wave, not with every half of every frame's pass (20 of a row's 32 cells with rolling shutter + intrinsics)
+        double* row = tr + 2 * (lane & 31) * TP;
+#pragma unroll
+        for (int c = NCOL; c < 16 * NCB; ++c) { row[c] = 0.0; row[TP + c] = 0.0; }
+      }
       while (done < 64) {
         const int fr = __builtin_amdgcn_readlane(my_frame, done);
         if (fr < 0) break;
@@ -177,8 +182,6 @@ __global__ __launch_bounds__(kEvalBlock) void eval_kernel(const DeviceProblem dp
 #pragma unroll
             for (int c = 0; c < K - 3; ++c) { row[c] = keep ? o.J[0][c] : 0.0; row[TP + c] = keep ? o.J[1][c] : 0.0; }
             row[K - 3] = keep ? o.r[0] : 0.0; row[TP + K - 3] = keep ? o.r[1] : 0.0;
-#pragma unroll
-            for (int c = NCOL; c < 16 * NCB; ++c) { row[c] = 0.0; row[TP + c] = 0.0; }
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
           // rows of this half that belong to the segment: observations [max(done, 32h), min(seg_end, 32h + 32))

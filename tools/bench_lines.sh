@@ -1,6 +1,6 @@
 # the three bench lines of a round in a call of their own (after the PMC summaries of the same build are under profiles/$1)
 export TMPDIR=/tmp
-R=${1:-r05}; O=gpurun_out/$R; mkdir -p $O
+R=${1:-r06}; O=gpurun_out/$R; mkdir -p $O
 python bench.py --steps 50 --warmup 5 --lm-iters 12 > $O/bench.json 2> $O/bench.err
 python bench.py --config C5 --steps 20 --warmup 3 --lm-iters 8 > $O/bench_c5.json 2> $O/bench_c5.err
 python bench.py --config C2 --steps 50 --warmup 5 --lm-iters 12 > $O/bench_c2.json 2> $O/bench_c2.err
