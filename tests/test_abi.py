@@ -30,6 +30,15 @@ def test_every_declared_symbol_is_exported(built_lib):
         assert hasattr(built_lib, n), f"{n} declared in include/rsba_amd.h but not exported"
 
 
+def test_the_instrumented_library_is_the_same_abi_plus_its_counters(built_lib):
+    """rsba_amd/_lib/librsba_amd_hooks.so (-DRSBA_TEST_HOOKS: fault-injection switches, ablation branches, the Cholesky's coherent-read counters) is what
+    the fault-injection tests load; the library the product ships has none of it — not even the debug entry point."""
+    hooks = ctypes.CDLL(os.path.join(ROOT, "rsba_amd", "_lib", "librsba_amd_hooks.so"))
+    for n in declared_functions():
+        assert hasattr(hooks, n), n
+    assert hasattr(hooks, "rsba_debug_chol_coherent") and not hasattr(built_lib, "rsba_debug_chol_coherent")
+
+
 def test_python_binding_lists_the_same_symbols():
     from rsba_amd import capi
     assert sorted(capi.EXPORTS) == declared_functions()
