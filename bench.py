@@ -195,6 +195,8 @@ def roofline_lm(prob, dp, iters, capi):
                 continue
             sub, tail = valu_kernels[r["phase"]]
             hits = [v for name, v in pv.items() if sub in name and (not tail or tail in name)]
+            if not hits and r["phase"] == "eval_trial":   # (candidates are evaluated in LM mode straight away: the phase's kernel is the LM-mode one)
+                hits = [v for name, v in pv.items() if sub in name and ", 2>" in name]
             hit = max(hits, key=lambda v: v.get("f64_flops", 0.0), default=None)
             if not hit or not hit.get("f64_flops"):
                 continue
@@ -559,6 +561,8 @@ def main():
             # a first multi-rank run should be diagnosable from its line alone: every rank's device time per phase (HIP events of its
             # own solve), what each kind of collective carried, and the communicator as the library's RCCL sees it
             mine = {"rank": rank, "observations": int(prob.num_observations)}
+            if isinstance(lm, dict) and "error" not in lm:   # every rank must have seen the same sums: a transport that skipped a collective shows here
+                mine["initial_cost"], mine["final_cost"] = lm.get("initial_cost"), lm.get("final_cost")
             roof = box.get("roof")
             if isinstance(roof, dict) and "phases" in roof:
                 mine["phase_ms_per_lm_iteration"] = {r["phase"]: r["ms_per_lm_iteration"] for r in roof["phases"]}
@@ -574,6 +578,7 @@ def main():
             dist.all_gather_object(rows, mine)
             if rank == 0 and isinstance(lm, dict):
                 lm["per_rank"] = rows
+                lm["ranks_agree"] = all(isinstance(r, dict) and r.get("final_cost") == rows[0].get("final_cost") and r.get("initial_cost") == rows[0].get("initial_cost") for r in rows)
                 if serialize:
                     lm["note_one_gpu_hook"] = ("all ranks share ONE GPU and take turns between collectives: per_rank phase times are each rank's own device time "
                                                "(what its GPU would be busy for on a node); ms_per_lm_iteration and the collectives' ms include the waiting for the other ranks' turns")

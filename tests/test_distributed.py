@@ -126,7 +126,7 @@ def run_bench(nproc, config, extra_env=None, lm_iters=6, timeout=1200):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,config", [(2, "C2"), (8, "C4")])
+@pytest.mark.parametrize("world,config", [(2, "C2"), (5, "C2"), (8, "C4")])
 def test_bench_takes_its_native_rccl_branch_with_several_ranks(world, config):
     """The branch of bench.py the driver's multi-GPU command takes — attach_rccl -> rsba_rccl_comm_create -> rsba_set_exchange_rccl, the warm
     handle of the LM leg on the SAME communicator, the LM solve on the watchdog thread with comm set — run here with 2 and 8 ranks on one
@@ -139,7 +139,7 @@ def test_bench_takes_its_native_rccl_branch_with_several_ranks(world, config):
     lm = many["lm"]
     assert "error" not in lm, lm
     assert "native" in lm["exchange"] and "libmock_rccl.so" in lm["exchange"]
-    assert len(lm["per_rank"]) == world
+    assert len(lm["per_rank"]) == world and lm["ranks_agree"]
     for r, row in enumerate(lm["per_rank"]):
         assert row["rank"] == r and row["rccl"]["comm_ranks"] == world and row["rccl"]["comm_rank"] == r
         assert row["plan"]["sharded_factorisation"] == 1
@@ -396,7 +396,7 @@ def test_a_rank_without_observations(tmp_path):
 # the host polls a pinned stamp while kernels and collectives of the iteration are in flight.
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 5, 8])   # (5 and 8: round 6 — the stand-in's waits used to spin in every workgroup of its kernels, and with five or eight ranks on one GPU they starved each other's publish kernels until the bounded waits gave up: tools/mock_rccl.hip, gate_kernel)
 def test_sharded_factorisation_at_c4_size_over_a_stream_ordered_transport(tmp_path, world):
     assert os.path.exists(MOCK_RCCL), "tools/libmock_rccl.so is built by __graft_entry__.build()"
     res = run_two_ranks("nd:C4:4:mock", tmp_path, world, env_extra={"RSBA_RCCL_LIB": MOCK_RCCL})

@@ -3,8 +3,8 @@
 // RCCL refuses two ranks on one device, so on a one-GPU box the multi-rank tests used to run over a BLOCKING transport (a host
 // callback staged through gloo): the loop whose trust-region decisions are taken on the device (solver.hip), its stamp polling and
 // its exchanges "enqueued like kernels" had therefore never run asynchronously with more than one rank.  This library exports the
-// eight nccl* symbols rsba_amd/csrc/exchange_rccl.hip resolves (RSBA_RCCL_LIB=<this .so>); its ncclAllReduce ENQUEUES two kernels on
-// the caller's stream and returns at once:
+// eight nccl* symbols rsba_amd/csrc/exchange_rccl.hip resolves (RSBA_RCCL_LIB=<this .so>); its ncclAllReduce ENQUEUES its kernels on
+// the caller's stream and returns at once (every wait in a one-workgroup gate kernel in front of the kernel it guards):
 //   publish: copy the buffer into this rank's staging block (device memory every rank has opened through hipIpc), then raise
 //            this rank's "arrived" word to the collective's sequence number;
 //   reduce : wait (on the device) until every rank's word has reached the number, then out[i] = the ranks' values combined in RANK
@@ -74,16 +74,27 @@ __device__ __forceinline__ bool wait_for(const unsigned long long* word, unsigne
   }
 }
 
-// publish: my staging block of this parity is free once every rank has finished reading what it held two collectives ago
+// The waits run in ONE-workgroup kernels of their own, in front of the kernels that copy and combine (round 6).  They used to sit in
+// thread 0 of EVERY workgroup of the publish / reduce kernels — up to 512 workgroups per rank spinning while they hold their slots:
+// with five to eight ranks on one GPU the spinning workgroups of the early ranks filled the device, the publish kernels of the late ranks
+// could not start, and everybody waited for everybody until the bound ran out (20 s) and the collective was skipped — each rank then
+// went on with its own, unreduced numbers (five and eight ranks: every time; two, three, four, six: never, by luck of the arrival order).
+// which = 0: wait until every rank has finished reading what this parity's staging block held two collectives ago ("done" >= want);
+// which = 1: until every rank's block of this collective is there ("arrived" >= want).
+__global__ __launch_bounds__(64) void gate_kernel(Peers p, int me, int world, unsigned long long want, int which, unsigned long long seq, long long timeout) {
+  if (threadIdx.x != 0) return;
+  Words* mine = p.words[me];
+  if (__hip_atomic_load(&mine->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return;   // (one wait that gave up poisons the rest: nothing waits twice)
+  for (int r = 0; r < world; ++r)
+    if (!wait_for(which ? &p.words[r]->arrived : &p.words[r]->done, want, timeout)) { __hip_atomic_store(&mine->error, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return; }
+}
+
 __global__ __launch_bounds__(256) void publish_kernel(const double* __restrict__ buf, size_t n, Peers p, int me, int world, unsigned long long seq, long long timeout) {
   __shared__ int ok;
   Words* mine = p.words[me];
-  if (threadIdx.x == 0) {
-    ok = __hip_atomic_load(&mine->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0;   // (one wait that gave up poisons the rest: nothing waits twice)
-    if (seq > 2) for (int r = 0; r < world && ok; ++r) if (!wait_for(&p.words[r]->done, seq - 2, timeout)) ok = 0;
-  }
+  if (threadIdx.x == 0) ok = __hip_atomic_load(&mine->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0;
   __syncthreads();
-  if (!ok) { if (threadIdx.x == 0) __hip_atomic_store(&mine->error, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return; }
+  if (!ok) return;
   double* stage = const_cast<double*>(p.stage[me]) + (seq & 1) * kCap;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) stage[i] = buf[i];
   __threadfence_system();   // my part of the block is in memory before I count myself in
@@ -100,10 +111,7 @@ __global__ __launch_bounds__(256) void publish_kernel(const double* __restrict__
 __global__ __launch_bounds__(256) void reduce_kernel(double* __restrict__ buf, size_t n, Peers p, int me, int world, unsigned long long seq, int op_max, long long timeout) {
   __shared__ int ok;
   Words* mine = p.words[me];
-  if (threadIdx.x == 0) {
-    ok = __hip_atomic_load(&mine->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0;
-    for (int r = 0; r < world && ok; ++r) if (!wait_for(&p.words[r]->arrived, seq, timeout)) ok = 0;
-  }
+  if (threadIdx.x == 0) ok = __hip_atomic_load(&mine->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0;
   __syncthreads();
   if (ok) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // every wave: nothing of the peers' blocks from before their release
@@ -112,13 +120,13 @@ __global__ __launch_bounds__(256) void reduce_kernel(double* __restrict__ buf, s
       for (int r = 1; r < world; ++r) { const double x = p.stage[r][(seq & 1) * kCap + i]; v = op_max ? (x > v ? x : v) : v + x; }
       buf[i] = v;
     }
-  } else if (threadIdx.x == 0) __hip_atomic_store(&mine->error, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned int prev = __hip_atomic_fetch_add(&mine->count_red, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     if (prev + 1 == gridDim.x) {
       __hip_atomic_store(&mine->count_red, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&mine->done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // (also after a timeout: the others must not wait for me twice)
+      __hip_atomic_store(&mine->done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // (also after a wait that gave up: the others must not wait for me twice)
     }
   }
 }
@@ -236,7 +244,9 @@ ncclResult_t ncclAllReduce(const void* sendbuff, void* recvbuff, size_t count, n
     const size_t n = count - at < kCap ? count - at : kCap;
     const unsigned long long seq = ++c->seq;
     const unsigned grid = (unsigned)((n + 256 * 8 - 1) / (256 * 8) < 1 ? 1 : ((n + 256 * 8 - 1) / (256 * 8) > 512 ? 512 : (n + 256 * 8 - 1) / (256 * 8)));
+    if (seq > 2) hipLaunchKernelGGL(gate_kernel, dim3(1), dim3(64), 0, stream, c->peers, c->rank, c->world, seq - 2, 0, seq, c->timeout_ticks);
     hipLaunchKernelGGL(publish_kernel, dim3(grid), dim3(256), 0, stream, buf + at, n, c->peers, c->rank, c->world, seq, c->timeout_ticks);
+    hipLaunchKernelGGL(gate_kernel, dim3(1), dim3(64), 0, stream, c->peers, c->rank, c->world, seq, 1, seq, c->timeout_ticks);
     hipLaunchKernelGGL(reduce_kernel, dim3(grid), dim3(256), 0, stream, buf + at, n, c->peers, c->rank, c->world, seq, op == ncclMax ? 1 : 0, c->timeout_ticks);
     if (hipGetLastError() != hipSuccess) return ncclUnhandledCudaError;
     if (count == 0) break;

@@ -12,6 +12,7 @@ python - <<PY
 import json
 for f in ("bench.json", "bench_c5.json", "bench_c2.json"):
     d = json.load(open("$O/" + f)); r = d["roofline"]
-    print(f, "value %.4g" % d["value"], "frac %.3f" % r["frac"], r["traffic_provenance"]["file"], "stale", r["traffic_provenance"]["stale"], "lm", round(d["lm_headline"]["ms_per_lm_iteration"], 4))
+    tp = r.get("traffic_provenance") or {}
+    print(f, "value %.4g" % d["value"], "frac %.3f" % r["frac"], tp.get("file"), "stale", tp.get("stale"), "lm marginal", round(d["lm_headline"]["marginal_ms_per_lm_iteration"], 4))
 PY
 tail -3 $O/pytest_gpu.txt
