@@ -207,10 +207,8 @@ __device__ __forceinline__ bool ldl16_eliminate(dbl4_t d, double* msg, int lane,
     // The message must LEAVE here: left alone the compiler pairs the sixteen stores up (ds_write2st64_b64) and sinks them behind the
     // thirteenth MFMA of the unrolled loop — the following wave then sees its first message 2 800 cycles into a 3 400-cycle block and
     // ends 2 450 cycles after this one, three times per tile (round 6: read off the ISA; profiles/r06/tile_factor.txt).
-#ifndef RSBA_AB_NO_STORE_PIN   // (A/B builds of tools/_ab*.sh only)
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-#endif
     if (estamp && lane == 0) estamp[jj] = clock64();       // (tools/tile_factor_bench.hip: when each message is posted)
     if (jj < 15) d = __builtin_amdgcn_mfma_f64_16x16x4f64(mul, row, d, 0, 0, 0);
   }

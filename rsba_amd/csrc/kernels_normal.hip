@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void point_factor_kernel(const DeviceProblem d
 // position (frame % FT) * CD.  Consecutive slots of a point are consecutive frames, so the runs of one
 // coordinate line up back to back: the wave stores coordinate by coordinate, each store instruction covering
 // (mostly) whole 128-B lines.
-constexpr int kProjectChunks = 8;   // consecutive 64-slot chunks per wave of the projection kernel (fewer when the scene is small: project_chunks)
+constexpr int kProjectChunks = 2;   // consecutive 64-slot chunks per wave of the projection kernel at most (one when the scene is small: project_chunks).  Round 6: 8 until then — swept again on the slim (all-factored, three workgroups per CU) form: C4 project phase 0.096 / 0.096 / 0.101 / 0.112 / 0.113 / 0.150 ms for 1 / 2 / 4 / 8 / 16 / 32
 inline int project_chunks(int64_t N) {   // ~2 k waves or more
   static const int forced = [] { const char* e = std::getenv("RSBA_PROJECT_CHUNKS"); const int v = e ? std::atoi(e) : 0; return v >= 1 && v <= 64 ? v : 0; }();   // (tuning aid)
   const int64_t c = N / 64 / 2048;
