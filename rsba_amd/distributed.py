@@ -140,21 +140,36 @@ def solve_timed(dp, prob, world: int, iters: int):
     wall_first = time.perf_counter() - t0
     prob.poses[:], prob.points[:], prob.intrinsics[:] = saved
     dp.upload_parameters()
-    t0 = time.perf_counter()
-    s, trace = dp.solve(capi.default_options(max_num_iterations=iters, function_tolerance=0.0, parameter_tolerance=0.0, gradient_tolerance=0.0))
-    wall = time.perf_counter() - t0
-    prob.poses[:], prob.points[:], prob.intrinsics[:] = saved
-    dp.upload_parameters()
+    opt_k = capi.default_options(max_num_iterations=iters, function_tolerance=0.0, parameter_tolerance=0.0, gradient_tolerance=0.0)
+    opt_2k = capi.default_options(max_num_iterations=2 * iters, function_tolerance=0.0, parameter_tolerance=0.0, gradient_tolerance=0.0)
+
+    def restore():
+        prob.poses[:], prob.points[:], prob.intrinsics[:] = saved
+        dp.upload_parameters()
+
+    # three repetitions of (solve of k, solve of 2k) from the same start, the FASTEST of each is quoted: a solve is deterministic, what varies
+    # from one repetition to the next is the box (a clock ramp, another tenant of the host) — one slow 2k solve used to show up as 0.1 - 0.3 ms
+    # on the marginal figure of a 1.7 ms iteration.  (Every rank runs the same sequence: the collectives of a multi-rank solve pair up.)
+    best_k, best_2k, wall = None, None, None
+    for _rep in range(3):
+        t0 = time.perf_counter()
+        s, trace = dp.solve(opt_k)
+        w = time.perf_counter() - t0
+        restore()
+        s2, _ = dp.solve(opt_2k)
+        restore()
+        if best_k is None or s.total_time_s < best_k.total_time_s:
+            best_k, wall = s, w
+        if best_2k is None or s2.total_time_s < best_2k.total_time_s:
+            best_2k = s2
+    s, s2 = best_k, best_2k
     n_it = max(1, s.num_iterations - 1)
     # what ONE MORE iteration costs: a solve of twice as many iterations against this one (the quotient above also carries iteration 0 —
     # the initial evaluation, two linearisations, the Jacobi scales — and the write-back)
-    s2, _ = dp.solve(capi.default_options(max_num_iterations=2 * iters, function_tolerance=0.0, parameter_tolerance=0.0, gradient_tolerance=0.0))
-    prob.poses[:], prob.points[:], prob.intrinsics[:] = saved
-    dp.upload_parameters()
     extra = s2.num_iterations - s.num_iterations
     marginal = (s2.total_time_s - s.total_time_s) / extra * 1e3 if extra > 0 else None
     return {"iterations": n_it, "ms_per_lm_iteration": s.total_time_s / n_it * 1e3, "marginal_ms_per_lm_iteration": marginal,
-            "marginal_note": "(time of a solve of twice as many iterations - time of this one) / the extra iterations: the steady-state cost of an iteration",
+            "marginal_note": "(time of a solve of twice as many iterations - time of this one) / the extra iterations: the steady-state cost of an iteration; the fastest of three repetitions of each solve",
             "wall_s": wall, "first_solve_wall_s": wall_first,
             "initial_cost": s.initial_cost, "final_cost": s.final_cost,
             "residual_jacobian_s": s.residual_jacobian_time_s, "linear_solver_s": s.linear_solver_time_s,
