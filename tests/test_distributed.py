@@ -371,6 +371,17 @@ def test_sharded_factorisation_with_motion_priors(tmp_path, mode, world):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode,world", [("nd:S60:5:perframe", 2), ("nd:S60:5:perframe:priors", 3)])
+def test_per_frame_intrinsics_blocks_on_several_ranks(tmp_path, mode, world):
+    """Several intrinsics blocks (a 9-block per frame) keep the REPLICATED factorisation on several ranks — and since round 6 they
+    run the loop whose decisions are taken on the device (a candidate's records go to a second set) there too, its exchanges enqueued between
+    its kernels: the single-GPU trajectory, every rank with the same parameters."""
+    res = run_two_ranks(mode, tmp_path, world)
+    check_nd(res, world, sharded=False)
+    assert all(o["plan"]["device_loop_solves"] >= 1 for o in res)
+
+
+@pytest.mark.gpu
 def test_every_rank_takes_the_same_form_of_the_trust_region_loop(tmp_path):
     """On several ranks the loop whose decisions are taken on the device (the exchanges of an iteration enqueued between its kernels,
     no host wait: solver.hip) is the default where it applies — the sharded tests above run it.  A rank that cannot run it says so in the
