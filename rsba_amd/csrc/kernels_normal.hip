@@ -756,60 +756,70 @@ __global__ __launch_bounds__(256) void schur_premerge_kernel(const SolverDev sv)
 
 // kMergeSplit workgroups per tile pair (an element per thread: with few tile pairs — 100 cameras have 140 — a workgroup walking its
 // tile in nine dependent rounds of loads was 25 us of latency): sum the chunk partials in order, add U / D_c^2 / g_c, identity
-// padding, and store into the packed tile slot (transposed when the tile ordering swapped the pair)
+// padding, and store into the packed tile slot (transposed when the tile ordering swapped the pair).
+// The kernel moves 150 MB at 1k cameras and took 57 us: not bandwidth but a CHAIN of dependent reads per thread — pair -> (I, J, chunk range) ->
+// chunk ids -> partials -> [is the side factored -> column scale], [U offset -> U], damping -> store: five round trips, hidden only by
+// occupancy (profiles/r06/schur_inline_merge.txt: the same chain inside the Schur kernel, where nothing hides it, cost more than this
+// launch).  Round 6: ONE 64-byte descriptor per pair (host: solver.hip, tp_desc) holds everything the first two links used to fetch —
+// I, J, the packed slot, the flags AND the first eight chunk ids — and whatever depends on the descriptor alone is requested before the
+// partials are summed: descriptor -> {partials, U, scales, damping} -> store.  The sums are formed in the order they always were (eight
+// interleaved running sums over the chunk list, chunk index mod 8), to the bit.
 constexpr int kMergeSplit = kTile * kTile / 256;
 static_assert(kMergeSplit * 256 == kTile * kTile, "an element per thread");
+struct PairDesc { int32_t I, J, dst, flags, c0, c1, pad0, pad1, head[8]; };   // flags: bit 0 = store transposed, bit 1 / 2 = I / J side factored; [c0, c1) = the pair's range in tp_chunk_list, head = its first eight ids (-1: none)
+static_assert(sizeof(PairDesc) == 64, "one 64-byte line per pair");
+// sum over the pair's chunk list of element `off` of the partials (tile elements, then the kTile rhs rows)
+__device__ __forceinline__ double merge_sum(const SolverDev& sv, const PairDesc& d, int off) {
+  constexpr size_t pstride = kTile * kTile + kTile;
+  double ps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int u = 0; u < 8; ++u) if (d.head[u] >= 0) ps[u] += sv.schur_part[(size_t)d.head[u] * pstride + off];
+  for (int ch = d.c0 + 8; ch < d.c1; ch += 8) {   // (a pair with more than eight chunks: up to kMergeGroup heads of pre-reduced groups)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) if (ch + u < d.c1) ps[u] += sv.schur_part[(size_t)sv.tp_chunk_list[ch + u] * pstride + off];
+  }
+  return ((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7]));
+}
 __global__ __launch_bounds__(256) void schur_merge_kernel(const DeviceProblem dp, const SolverDev sv, double inv_radius) {
-  if (sv.ctl) inv_radius = 1.0 / sv.ctl[kCtlRadius];
   const int tp = blockIdx.x, tid = threadIdx.x;
-  const int I = sv.tp_I[tp], J = sv.tp_J[tp], CD = sv.CD, FT = sv.FT;
-  const int c0 = sv.tp_chunk0[tp], c1 = sv.tp_chunk0[tp + 1];
-  double* dst = sv.S + (size_t)sv.tp_dst[tp] * (kTile * kTile);
-  const bool trans = sv.tp_trans[tp] != 0;
-  const size_t pstride = kTile * kTile + kTile;
+  const PairDesc d = *reinterpret_cast<const PairDesc*>(sv.tp_desc + 16 * (size_t)tp);
+  const int I = d.I, J = d.J, CD = sv.CD, FT = sv.FT;
   {
     const int e = blockIdx.y * 256 + tid;
     const int rt = e / kTile, ct = e % kTile;
     const int x = rt / CD, y = ct / CD, r = rt % CD, c = ct % CD;
     const int a = I * FT + x, b = J * FT + y;
-    // eight interleaved running sums (chunk index mod 8) keep eight loads in flight; the diagonal pair of the
-    // intrinsics pseudo tile has one chunk per 512 points of the whole problem
-    double ps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int ch = c0;
-    for (; ch + 8 <= c1; ch += 8) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) ps[u] += sv.schur_part[(size_t)sv.tp_chunk_list[ch + u] * pstride + e];
-    }
-    for (int u = 0; ch < c1; ++ch, ++u) ps[u] += sv.schur_part[(size_t)sv.tp_chunk_list[ch] * pstride + e];
-    double sum = ((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7]));
+    const bool real = a < sv.Fx && b < sv.Fx, on_diag = a == b && r == c;
+    // everything that hangs on the descriptor alone, requested BEFORE the partials are waited for (clamped addresses where the value is not used)
+    const int64_t add = sv.tp_add[((size_t)tp * FT + x) * FT + y];
+    const double sa = (d.flags & 2) ? (a < sv.F ? dp.scale_pose[(size_t)a * CD + r] : 0.0) : 1.0;
+    const double sb = (d.flags & 4) ? (b < sv.F ? dp.scale_pose[(size_t)b * CD + c] : 0.0) : 1.0;
+    const double lead_a = sv.frame_lead ? sv.frame_lead[a] : (sv.lead != 0 ? 1.0 : 0.0);   // does this rank add the frame's replicated terms (sharded factorisation: the owner of its part)
+    const double damp = (real && on_diag) ? sv.diag_c[(size_t)a * CD + r] : 0.0;
+    const double u = (real && add >= 0) ? sv.U[add + (size_t)r * CD + c] : 0.0;
+    if (sv.ctl) inv_radius = 1.0 / sv.ctl[kCtlRadius];
+    double sum = merge_sum(sv, d, e);
     // a factored side left its column scales out of the products (they do not depend on the point): applied here, once per element
-    if (sv.tile_factored) {
-      if (sv.tile_factored[I]) sum *= a < sv.F ? dp.scale_pose[(size_t)a * CD + r] : 0.0;
-      if (sv.tile_factored[J]) sum *= b < sv.F ? dp.scale_pose[(size_t)b * CD + c] : 0.0;
-    }
+    if (d.flags & 2) sum *= sa;
+    if (d.flags & 4) sum *= sb;
+    const bool lead = lead_a != 0.0;
     double val;
-    const bool lead = sv.frame_lead ? sv.frame_lead[a] != 0.0 : sv.lead != 0;   // does this rank add the frame's replicated terms (sharded factorisation: the owner of its part)
-    if (a >= sv.Fx || b >= sv.Fx) val = (a == b && r == c && lead) ? 1.0 : 0.0;     // padding frames of the last tile
+    if (!real) val = (on_diag && lead) ? 1.0 : 0.0;     // padding frames of the last tile
     else {
-      const int64_t add = sv.tp_add[((size_t)tp * FT + x) * FT + y];
-      val = (add >= 0 ? sv.U[add + (size_t)r * CD + c] : 0.0) - sum;
-      if (a == b && r == c && lead) val += sv.diag_c[(size_t)a * CD + r] * inv_radius;
+      val = u - sum;
+      if (on_diag && lead) val += damp * inv_radius;
     }
-    if (trans) dst[(size_t)ct * kTile + rt] = val; else dst[e] = val;
+    double* dst = sv.S + (size_t)d.dst * (kTile * kTile);
+    if (d.flags & 1) dst[(size_t)ct * kTile + rt] = val; else dst[e] = val;
   }
   if (I == J && blockIdx.y == 0 && tid < kTile) {
     const int a = I * FT + tid / CD;
-    double ps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int ch = c0;
-    for (; ch + 8 <= c1; ch += 8) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) ps[u] += sv.schur_part[(size_t)sv.tp_chunk_list[ch + u] * pstride + kTile * kTile + tid];
-    }
-    for (int u = 0; ch < c1; ++ch, ++u) ps[u] += sv.schur_part[(size_t)sv.tp_chunk_list[ch] * pstride + kTile * kTile + tid];
-    double sum = ((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7]));
-    if (sv.tile_factored && sv.tile_factored[I]) sum *= a < sv.F ? dp.scale_pose[(size_t)I * kTile + tid] : 0.0;
-    const bool lead = sv.frame_lead ? sv.frame_lead[a] != 0.0 : sv.lead != 0;
-    sv.rhs[(size_t)I * kTile + tid] = (a < sv.Fx) ? (lead ? sv.gc[(size_t)I * kTile + tid] : 0.0) - sum : 0.0;
+    const double sa = (d.flags & 2) ? (a < sv.F ? dp.scale_pose[(size_t)I * kTile + tid] : 0.0) : 1.0;
+    const double lead_a = sv.frame_lead ? sv.frame_lead[a] : (sv.lead != 0 ? 1.0 : 0.0);
+    const double g = a < sv.Fx ? sv.gc[(size_t)I * kTile + tid] : 0.0;
+    double sum = merge_sum(sv, d, kTile * kTile + tid);
+    if (d.flags & 2) sum *= sa;
+    sv.rhs[(size_t)I * kTile + tid] = (a < sv.Fx) ? (lead_a != 0.0 ? g : 0.0) - sum : 0.0;
   }
 }
 

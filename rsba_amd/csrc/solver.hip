@@ -1196,6 +1196,18 @@ int32_t build_solver_impl(rsba_handle* h) {
   }
   up.upload_const(&sv.tp_trans, tp_trans);
   up.upload_const(&sv.tp_add, tp_add);
+  {
+    // one 64-byte line per pair for the merge kernel (kernels_normal.hip, PairDesc): what it used to collect from five arrays in two dependent rounds
+    std::vector<int32_t> tp_desc((size_t)ntp * 16, 0);
+    for (int t = 0; t < ntp; ++t) {
+      int32_t* d = tp_desc.data() + (size_t)t * 16;
+      d[0] = tp_I[t]; d[1] = tp_J[t]; d[2] = tp_dst[t];
+      d[3] = (tp_trans[t] ? 1 : 0) | (tile_factored[tp_I[t]] ? 2 : 0) | (tile_factored[tp_J[t]] ? 4 : 0);
+      d[4] = tp_chunk0[t]; d[5] = tp_chunk0[t + 1];
+      for (int u = 0; u < 8; ++u) d[8 + u] = tp_chunk0[t] + u < tp_chunk0[t + 1] ? tp_chunk_list[(size_t)tp_chunk0[t] + u] : -1;
+    }
+    up.upload_const(&sv.tp_desc, tp_desc);
+  }
   if ((rc = s_alloc(s, &sv.schur_part, (size_t)std::max(sv.nchunk, 1) * (kTile * kTile + kTile)))) return rc;
   up.upload_ref(&s->d_upd, s->upd);
   // the write-once cells of the persistent Cholesky driver — factor tiles | partial tiles | W | z, y | published X — live in ONE

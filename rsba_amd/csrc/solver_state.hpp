@@ -84,6 +84,7 @@ struct SolverDev {
   const int32_t* tp_dst;        // [ntp] packed tile slot that receives the pair
   const uint8_t* tp_trans;      // [ntp] 1 = the tile ordering swapped I and J: store transposed
   const int64_t* tp_add;        // [ntp][FT][FT] offset into U of the J^T J block to add, -1 none
+  const int32_t* tp_desc;       // [ntp][16] the pair's line for the merge kernel: I, J, packed slot, flags (transposed | I side factored | J side factored), its range in tp_chunk_list, -, -, the first eight chunk ids
   double* schur_part;           // [nchunk][kTile*kTile + kTile] partial tiles (+ rhs partials) of the chunks
   // numeric
   double* U;                    // [F][CD][CD] frame blocks | [NPF][F][CD][CD] (pseudo v of the frame's intrinsics block) x frame | [NIB][NPF][NPF][CD][CD]
