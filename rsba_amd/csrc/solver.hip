@@ -746,11 +746,15 @@ int32_t build_solver_impl(rsba_handle* h) {
   s->last_diag_slot = slot_base[iperm[nt - 1]];      // the (possibly padded) last tile of the natural order
   tick("symbolic");
   // ---- sharded factorisation: does every rank's share of the points respect the cut? ----
-  // (part of a column = the rank whose subtree it belongs to, -1 = a separator the ranks share.)  Not with pose priors, a free
-  // interFrameRatio or several intrinsics blocks (their replicated terms come from rank 0 alone) — those problems keep the
-  // replicated factorisation.  Motion priors with a known ratio are shared out like the frames: see below.
+  // (part of a column = the rank whose subtree it belongs to, -1 = a separator the ranks share.)  Every kind of block the solver takes
+  // is in (rounds 4 - 6): motion priors are shared out like the frames (below), GoodPosePrior / SphericalPrior terms go to the rank whose
+  // part holds the pose, a free interFrameRatio has its column's forward solve run part by part — and SEVERAL intrinsics blocks (a 9-block
+  // per frame, CeresHandler.h:256-264,273-280; round 6) need nothing of their own: a block's pseudo frames sit in a tile that is adjacent to the
+  // tiles of exactly the frames seen through it, so the dissection puts it in those frames' part or in a separator, every point seen through
+  // the block is owned by that part's rank (rsba_partition_points builds the same graph), and the tile's replicated terms — damping, identity
+  // padding, the gradient after exchange (1) — follow frame_lead like any frame tile's.
   std::vector<int32_t> cpart(nt, -1);
-  bool sharded = want_parts && tord.parts_ok && NIB <= 1;   // (the SphericalPrior is in as well, round 6: one 2-residual block on one pose — its terms go where that pose's GoodPosePrior terms would)   // (GoodPosePrior blocks are in: their terms go to the rank whose part holds the pose, like the frames' damping)   // (a free interFrameRatio is in: its column's forward solve runs part by part, FWD2P / ETA below)
+  bool sharded = want_parts && tord.parts_ok;
   if (const char* e = std::getenv("RSBA_SHARDED")) sharded = sharded && e[0] != '0';   // A/B switch
   if (want_parts) {
     double bad = sharded ? 0.0 : 1.0;

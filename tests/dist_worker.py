@@ -42,11 +42,15 @@ def nd_mode(mode, outdir, rank, world, dist, torch):
     if "intr" in flags:      # shared intrinsics as a parameter block + Huber, as BASELINE config 5 has them: a dense border of the reduced system
         full.calibrated = False; full.huber_a = 2.0
         full.intrinsics = full.intrinsics * (1.0 + 1e-3 * np.array([[1, -1, 20, -20, 10, 10, -10, 0.5, -0.5]]))
-    if "perframe" in flags:  # a 9-block of intrinsics PER FRAME (f.cam, CeresHandler.h:256-264,273-280): several intrinsics blocks keep the replicated factorisation — and, since round 6, run the device-side loop (a candidate's records in a second set) on several ranks too
+    if "perframe" in flags:  # a 9-block of intrinsics PER FRAME (f.cam, CeresHandler.h:256-264,273-280): since round 6 in the sharded plan (a block's pseudo frames sit in its frame's part or in a separator) and in the device-side loop (a candidate's records in a second set)
         full.calibrated = False; full.huber_a = 2.0
         rng = np.random.default_rng(3)
         full.intrinsics = np.tile(full.intrinsics[:1], (full.num_frames, 1)) * (1.0 + 1e-3 * rng.normal(size=(full.num_frames, 9)) * np.array([[1, 1, 20, 20, 10, 10, 10, 0.5, 0.5]]))
         full.frame_intrinsics = np.arange(full.num_frames, dtype=np.int32)
+        if "mixedintr" in flags:   # ... and the frames WITHOUT f.cam fall back on the session's block (sess.cam): every third frame keeps its own, the rest share block 0 — a dense border again, beside the blocks inside the parts
+            own = np.arange(full.num_frames) % 3 == 1
+            full.frame_intrinsics = np.where(own, np.cumsum(own), 0).astype(np.int32)
+            full.intrinsics = np.ascontiguousarray(full.intrinsics[: int(own.sum()) + 1])
     if "priors" in flags:    # a motion prior between every two consecutive frames (CeresHandler.h:147-185), known interFrameRatio: each rank contributes the priors of its part
         full.prior_kind, full.prior_scale, full.inter_frame_ratio = 2, 25.0, 1.2
         full.prior_frames = np.arange(1, full.num_frames, dtype=np.int32)

@@ -254,6 +254,28 @@ def test_partition_points_on_graphs_that_are_not_a_plain_band(kind):
             assert ntop == base[world][1]
 
 
+def test_partition_points_with_an_intrinsics_block_per_frame():
+    """A 9-block of intrinsics per frame (CeresHandler.h:256-264,273-280) adds pseudo frames to the reduced system — one per block behind the
+    real frames, in tiles of their own: the cut takes them along (a block's tile is adjacent to the tiles of the frames seen through it, so it
+    lands in their part or in a separator) — every tile, real or pseudo, that more than one rank's points reach is a separator tile."""
+    from rsba_amd import capi
+    from rsba_amd.scene import make_scene
+    p = make_scene(300, 21000, seed=3).problem
+    p.calibrated = False
+    p.intrinsics = np.tile(p.intrinsics[:1], (p.num_frames, 1))
+    p.frame_intrinsics = np.arange(p.num_frames, dtype=np.int32)
+    FT, FR = 4, p.num_frames
+    nt = (2 * FR + FT - 1) // FT          # two-pose frames: 12 unknowns per frame, one pseudo frame per intrinsics block
+    for world in (2, 4):
+        owner, ntop = capi.partition_points(p, world)
+        load = np.bincount(owner[p.obs_point], minlength=world)
+        touched = np.zeros((world, nt), dtype=bool)
+        touched[owner[p.obs_point], p.obs_frame // FT] = True
+        touched[owner[p.obs_point], (FR + p.frame_intrinsics[p.obs_frame]) // FT] = True
+        assert load.min() > 0 and load.max() <= 1.25 * load.mean()
+        assert 0 < int((touched.sum(0) > 1).sum()) <= ntop <= 0.4 * nt
+
+
 def test_partition_points_refuses_what_cannot_be_cut():
     from rsba_amd import capi
     from rsba_amd.scene import make_scene
@@ -371,14 +393,27 @@ def test_sharded_factorisation_with_motion_priors(tmp_path, mode, world):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode,world", [("nd:S300:5:perframe", 2), ("nd:S300:5:perframe:priors", 3)])
+@pytest.mark.parametrize("mode,world", [("nd:S300:5:perframe", 2), ("nd:S300:5:perframe", 4), ("nd:S300:5:perframe:priors", 3), ("nd:S300:5:perframe:mixedintr", 2),
+                                        ("nd:S300:5:perframe:mixedintr:priors:freeratio", 4)])
 def test_per_frame_intrinsics_blocks_on_several_ranks(tmp_path, mode, world):
-    """Several intrinsics blocks (a 9-block per frame) keep the REPLICATED factorisation on several ranks — and since round 6 they
-    run the loop whose decisions are taken on the device (a candidate's records go to a second set) there too, its exchanges enqueued between
-    its kernels: the single-GPU trajectory, every rank with the same parameters."""
+    """Several intrinsics blocks (a 9-block per frame, CeresHandler.h:256-264,273-280; "mixedintr": two frames in three fall back on the session's
+    block) in BOTH fast paths on several ranks (round 6): the SHARDED factorisation — a block's pseudo frames sit in a tile adjacent to the
+    tiles of the frames seen through it, so the dissection puts it in their part or in a separator, and only the separators' tiles travel — and
+    the loop whose decisions are taken on the device (a candidate's records go to a second set), its exchanges enqueued between its kernels:
+    the single-GPU trajectory to 1e-9, every rank with the same parameters."""
     res = run_two_ranks(mode, tmp_path, world)
-    check_nd(res, world, sharded=False)
+    a = check_nd(res, world)
+    assert a["plan"]["exchange_doubles"] < a["ref_plan"]["exchange_doubles"]
     assert all(o["plan"]["device_loop_solves"] >= 1 for o in res)
+
+
+@pytest.mark.gpu
+def test_per_frame_intrinsics_blocks_with_the_replicated_factorisation(tmp_path, monkeypatch):
+    """... and the same problem with the sharded plan switched off (RSBA_SHARDED=0: what any by-point partition that does not follow the
+    separators gets): every structurally non-zero tile is all-reduced, every rank factors the whole system — the same trajectory."""
+    monkeypatch.setenv("RSBA_SHARDED", "0")
+    res = run_two_ranks("nd:S300:5:perframe", tmp_path, 2)
+    check_nd(res, 2, sharded=False)
 
 
 @pytest.mark.gpu
