@@ -173,9 +173,10 @@ int32_t rsba_time_evaluate(rsba_handle* h, int32_t with_jacobians, int32_t warmu
  * camera system, all on the device; parameters are written back to the arrays given to rsba_create.
  * trace (may be NULL) receives up to trace_capacity iteration records.
  * The trust-region decisions themselves (TrustRegionMinimizer's accept / reject, radius, convergence tests) are taken by a device kernel
- * wherever the problem allows (no records kept: calibrated or one shared intrinsics block; with or without motion priors — interFrameRatio
- * known or free — and GoodPosePrior blocks; one rank or several, pose priors on one) — the host then waits once per iteration for the
- * state, never inside one; the same rules on the host otherwise (per-frame intrinsics blocks, a SphericalPrior) and with options.profile_phases.  The two forms produce the same iteration records bit for bit. */
+ * for every problem this call takes (calibrated, one shared or several intrinsics blocks; with or without motion priors — interFrameRatio
+ * known or free —, GoodPosePrior blocks and the SphericalPrior; one rank or several) — the host then waits once per iteration for the
+ * state, never inside one; the same rules on the host with options.profile_phases, when a rank of a sharded solve asks for it (no
+ * observations) and under RSBA_DEVICE_LM=0.  The two forms produce the same iteration records bit for bit. */
 void rsba_default_solver_options(rsba_solver_options* opt);
 int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rsba_solver_summary* summary,
                    rsba_iteration* trace, int32_t trace_capacity);
@@ -217,8 +218,8 @@ typedef struct rsba_plan_stats {
   int64_t local_levels, separator_levels;           /* the two dependency chains: elimination levels inside this rank's part / levels that hold a separator column */
   int64_t schur_group_bytes, schur_factored_groups; /* bytes of all groups: 3 x 48 doubles each in full form; 80 doubles for the groups stored FACTORED (two-pose frame tiles: the
                                                      * 6-row factor q = Jq^T Jp L^-T per frame + tau instead of the 12 rows (1 - tau) q | tau q), and how many those are */
-  int64_t device_loop_solves, host_loop_solves;     /* rsba_solve calls on this plan whose trust-region loop ran without the host (decisions by device kernels: every problem rsba_solve takes
-                                                     * except several intrinsics blocks, GoodPosePrior blocks on several ranks, phase timing) / with the host deciding */
+  int64_t device_loop_solves, host_loop_solves;     /* rsba_solve calls on this plan whose trust-region loop ran without the host (decisions by device kernels: every problem rsba_solve takes,
+                                                     * phase timing excepted) / with the host deciding */
 } rsba_plan_stats;
 int32_t rsba_get_plan_stats(rsba_handle* h, rsba_plan_stats* out);   /* runs the symbolic phase if it has not run yet */
 

@@ -2207,10 +2207,11 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
   // candidate is not linearised).  What the reference calls per frame — windowedBA over ~100 cameras (VideoSfMClient.cc:241-246) —
   // is where this counts: an iteration there is 0.5 ms, and the host form's 22 dependent launches, two read-backs and their gaps were
   // 0.09 ms of it.  Here an iteration is 13 launches on this stream (the small steps share launches: kernels_normal.hip) and no wait.
-  // Single-GPU problems that keep no records (calibrated, or ONE shared intrinsics block), with or without motion priors of a known
-  // interFrameRatio — on one rank or several (every rank takes the same form: settled with the problem-size exchange); everything else (a free
-  // ratio, per-pose priors, per-frame intrinsics blocks) — and a suspect factorisation — goes through the host form.
-  bool device_ctl = speculate && (dp.pp_count == 0 || !h->allreduce) && !s->use_levels &&   // (GoodPosePrior blocks: on one rank; the SphericalPrior — one block on one pose, no coordinates of its own — on any number, round 6)
+  // Every problem this call takes, on one rank or several (every rank takes the same form: settled with the problem-size exchange) — rounds 3 - 6
+  // added them kind by kind: motion priors, a free interFrameRatio, GoodPosePrior blocks, the SphericalPrior, several intrinsics blocks (their
+  // candidates' records go to a second set), GoodPosePrior blocks on several ranks.  What goes through the host form: phase timing, a rank that
+  // asks for it (no observations), RSBA_DEVICE_LM=0 / RSBA_RECORDS_ALT=0, and a suspect factorisation (the level schedule repeats the iteration).
+  bool device_ctl = speculate && !s->use_levels &&
                     !any_rank_needs_host && opt->max_num_iterations > 0;
   const bool has_pp = dp.pp_count > 0 || dp.pp_spherical >= 0;
   if (const char* e = std::getenv("RSBA_DEVICE_LM")) device_ctl = device_ctl && e[0] != '0';   // A/B switch: 0 = the host decides
@@ -2320,13 +2321,17 @@ extern "C" int32_t rsba_solve(rsba_handle* h, const rsba_solver_options* opt, rs
         HIP_TRY(launch_lm_verdict_gradient(dp, sv, s->d_ctl, R, s->d_trace_it, cap, slot, s->ctl_seq, st, false, dp.pp_count > 0 ? 1 : 0));
       } else {   // exchange (1): the camera gradient, diag(U), the cost — and every rank's gradient maximum over its points — whether or not the candidate
                  // was accepted (the host does not know): the unpacking skips itself after a rejected one, the maximum comes out as it was
-        const bool ride = h->world <= kMaxRankSlots;
+        const bool ride = h->world <= kMaxRankSlots && dp.pp_count == 0;   // (the priorPoses blocks' maximum is the lead rank's alone: a MAX exchange of its own then, as in the host form)
         HIP_TRY(launch_pack_linearize(dp, sv, h->d_cost2, st, ride ? h->world : 0));
         if (ride) HIP_TRY(launch_gradient_max_points(dp, sv, h->rank, st));
         if ((rc = exchange(h, sv.xbuf, 2 * sv.n + 3 + (ride ? h->world : 0), 0, RSBA_EXCHANGE_CAMERA))) return rc;
         HIP_TRY(launch_unpack_linearize(dp, sv, st));
         if (ride) HIP_TRY(launch_gradient_max_cameras(dp, sv, h->world, st));
-        else { HIP_TRY(launch_gradient_max(dp, sv, st)); if ((rc = exchange(h, sv.scalars + kGradMax, 1, 1, RSBA_EXCHANGE_SCALARS))) return rc; }
+        else {
+          HIP_TRY(launch_gradient_max(dp, sv, st));
+          if (sv.lead) HIP_TRY(launch_pose_prior_gradmax(dp, sv, s->pp, st));
+          if ((rc = exchange(h, sv.scalars + kGradMax, 1, 1, RSBA_EXCHANGE_SCALARS))) return rc;
+        }
         HIP_TRY(launch_lm_verdict_gradient(dp, sv, s->d_ctl, R, s->d_trace_it, cap, slot, s->ctl_seq, st, /*gradmax_done=*/true));
       }
       ++enqueued;

@@ -375,7 +375,8 @@ def test_sharded_factorisation_on_three_ranks(tmp_path):
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode,world", [("nd:C2:8:priors", 2), ("nd:S300:6:priors", 3), ("nd:S300:6:priors:intr", 4),
                                         ("nd:C2:8:priors:freeratio", 2), ("nd:S300:6:priors:freeratio", 3), ("nd:S300:6:priors:intr:freeratio", 4), ("nd:C2:6:priors:freeratio:hostrank", 2),
-                                        ("nd:C2:8:posepriors", 2), ("nd:S300:6:posepriors:priors:freeratio", 3), ("nd:C2:3:spherical", 2), ("nd:S300:3:spherical:priors", 4)])
+                                        ("nd:C2:8:posepriors", 2), ("nd:S300:6:posepriors:priors:freeratio", 3), ("nd:C2:3:spherical", 2), ("nd:S300:3:spherical:priors", 4),
+                                        ("nd:S300:5:posepriors:perframe:spherical", 3)])
 def test_sharded_factorisation_with_motion_priors(tmp_path, mode, world):
     """A motion prior between every two consecutive frames with a known interFrameRatio (the reference's usual video configuration,
     CeresHandler.h:147-185).  The prior between frames f and f - 1 goes to the rank whose part holds either frame (rank 0 when both
@@ -390,6 +391,8 @@ def test_sharded_factorisation_with_motion_priors(tmp_path, mode, world):
         assert a["initial_cost"] > 1e38
     if "posepriors" in mode:  # GoodPosePrior blocks: every rank leaves with the same solved priorPoses values, the single-GPU ones
         assert all(o["prior_values_sum"] == a["prior_values_sum"] for o in res) and a["prior_err"] <= 1e-7
+    if "hostrank" not in mode:   # every one of these runs the loop whose decisions are taken on the device (GoodPosePrior blocks on several ranks: since round 6 —
+        assert all(o["plan"]["device_loop_solves"] >= 1 and o["plan"]["host_loop_solves"] == 0 for o in res)   # their blocks' gradient maximum is the lead rank's, one MAX exchange of its own)
 
 
 @pytest.mark.gpu
