@@ -737,21 +737,21 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void schur_tile_kernel(const So
   }
 }
 
-// one workgroup per group of a very long chunk list: partial[first] = sum of the group's partials, in list order
+// a group of a very long chunk list: partial[first] = sum of the group's partials, in list order (four running sums, chunk index mod 4).  An element
+// per thread, kPremergeSplit workgroups per group (round 6; one workgroup per group walked its 2 352 elements in ten rounds of eight dependent
+// loads each: 47 us at 4k cameras for 630 groups)
+constexpr int kPremergeSplit = (kTile * kTile + kTile + 255) / 256;
 __global__ __launch_bounds__(256) void schur_premerge_kernel(const SolverDev sv) {
-  const int g0 = sv.pm_ptr[blockIdx.x], g1 = sv.pm_ptr[blockIdx.x + 1], tid = threadIdx.x;
-  const size_t pstride = kTile * kTile + kTile;
-  double* dst = sv.schur_part + (size_t)sv.pm_list[g0] * pstride;
-  for (int e = tid; e < (int)pstride; e += 256) {
-    double ps[4] = {0, 0, 0, 0};
-    int c = g0;
-    for (; c + 4 <= g1; c += 4) {
+  const int g0 = sv.pm_ptr[blockIdx.x], g1 = sv.pm_ptr[blockIdx.x + 1];
+  constexpr size_t pstride = kTile * kTile + kTile;
+  const int e = blockIdx.y * 256 + threadIdx.x;
+  if (e >= (int)pstride) return;
+  double ps[4] = {0, 0, 0, 0};
+  for (int c = g0; c < g1; c += 8) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) ps[u] += sv.schur_part[(size_t)sv.pm_list[c + u] * pstride + e];
-    }
-    for (int u = 0; c < g1; ++c, ++u) ps[u] += sv.schur_part[(size_t)sv.pm_list[c] * pstride + e];
-    dst[e] = (ps[0] + ps[1]) + (ps[2] + ps[3]);
+    for (int u = 0; u < 8; ++u) if (c + u < g1) ps[u & 3] += sv.schur_part[(size_t)sv.pm_list[c + u] * pstride + e];
   }
+  sv.schur_part[(size_t)sv.pm_list[g0] * pstride + e] = (ps[0] + ps[1]) + (ps[2] + ps[3]);   // (this thread's own element of the group's first partial: read above, nobody else's)
 }
 
 // kMergeSplit workgroups per tile pair (an element per thread: with few tile pairs — 100 cameras have 140 — a workgroup walking its
@@ -1846,7 +1846,7 @@ hipError_t launch_schur_blocks(const DeviceProblem& dp, const SolverDev& sv, dou
     }
     { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; }
   }
-  if (sv.npremerge > 0) LAUNCH(schur_premerge_kernel, sv.npremerge, 256, st, sv);
+  if (sv.npremerge > 0) LAUNCH(schur_premerge_kernel, dim3(sv.npremerge, kPremergeSplit), 256, st, sv);
   LAUNCH(schur_merge_kernel, dim3(sv.ntp, kMergeSplit), 256, st, dp, sv, 1.0 / radius);
   return hipSuccess;
 }

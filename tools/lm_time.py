@@ -1,7 +1,7 @@
 """LM iteration wall time of one configuration with the DAG Cholesky and with the per-level schedule (same task
 bodies), and the difference of the two solves.  usage: python tools/lm_time.py [C4] [iters] [priors]
 ("per_frame_intrinsics": every frame its own intrinsics block; "priors": constant-velocity motion priors between all consecutive frames, scale 10, interFrameRatio 0.8;
- "free_ratio": the same with the ratio a free, lower-bounded parameter starting at 1)"""
+ "free_ratio": the same with the ratio a free, lower-bounded parameter starting at 1; "-" for none of them)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -11,7 +11,7 @@ from rsba_amd.scene import make_config
 name = sys.argv[1] if len(sys.argv) > 1 else "C4"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 res = {}
-for mode in ("dag", "levels"):
+for mode in (("dag",) if "dagonly" in sys.argv else ("dag", "levels")):   # ("dagonly" as a last argument: skip the level schedule and the comparison)
     os.environ["RSBA_CHOL_LEVELS"] = "1" if mode == "levels" else "0"
     prob = make_config(name).problem
     if len(sys.argv) > 3 and sys.argv[3] in ("priors", "free_ratio"):
@@ -49,5 +49,5 @@ for mode in ("dag", "levels"):
               f"whole solve / {n} iterations {1e3 * dt / n:.3f} ms (wall {dt * 1e3:.1f} ms: incl. iteration 0 and the write-back), "
               f"cost {summ.initial_cost:.6e} -> {summ.final_cost:.9e}" + (f", interFrameRatio {prob.inter_frame_ratio:.9f}" if prob.prior_kind else ""), flush=True)
         res[mode] = (summ.final_cost, prob.poses.copy(), prob.points.copy())
-print("final cost rel diff", abs(res["dag"][0] - res["levels"][0]) / res["levels"][0],
+if "levels" in res: print("final cost rel diff", abs(res["dag"][0] - res["levels"][0]) / res["levels"][0],
       "max pose diff", np.abs(res["dag"][1] - res["levels"][1]).max(), "max point diff", np.abs(res["dag"][2] - res["levels"][2]).max())
