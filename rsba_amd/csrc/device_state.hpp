@@ -108,6 +108,9 @@ __device__ __forceinline__ bool lm_not_accepted(const double* ctl) { return ctl 
 
 constexpr int kEvalBlock = 256;
 constexpr int kStageFrames = 16;   // camera blocks staged through LDS per workgroup
+// rows of the blocks (1, 0) and (1, 1) of a wave's partial G = [Ji | Jc | r]^T [Ji | Jc | r] (dp.cam_part) that are written and read: the columns of
+// the second 16-column block that exist, rounded up to the four rows a lane group stores at a time (ncol = columns of the operand, 17 .. 32)
+__host__ __device__ constexpr int cam_part_rows(int ncol) { return ncol <= 16 ? 16 : ((ncol - 16 + 3) / 4) * 4; }
 
 enum EvalMode : int {
   kResidualOnly = 0,   // T=double path: residuals + cost (trial point of the trust-region loop)

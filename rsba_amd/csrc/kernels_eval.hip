@@ -200,11 +200,15 @@ __global__ __launch_bounds__(kEvalBlock) void eval_kernel(const DeviceProblem dp
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
+        // (rows of a block = columns 16 qa + row of the operand: the second column block holds NCOL - 16 of them — six with rolling shutter +
+        // intrinsics — and nothing reads the rows behind them (camera_reduce_frame, kernels_normal.hip: kCamPartRows): a third of the
+        // partials' bytes, written here and read there, at 4k cameras 0.33 GB each way)
         double* part = dp.cam_part + (size_t)seg * (NBLK * 256);
 #pragma unroll
         for (int q = 0; q < NBLK; ++q)
 #pragma unroll
-          for (int v = 0; v < 4; ++v) part[q * 256 + (cg + 4 * v) * 16 + ci] = d[q][v];
+          for (int v = 0; v < 4; ++v)
+            if (q == 0 || 4 * v < cam_part_rows(NCOL)) part[q * 256 + (cg + 4 * v) * 16 + ci] = d[q][v];
         ++seg;
         done = seg_end;
       }

@@ -98,7 +98,7 @@ __device__ __forceinline__ void camera_reduce_frame(const DeviceProblem& dp, con
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
-          for (int q = 0; q < NBLK; ++q) v[u][q] = dp.cam_part[((size_t)s_seg[i + u] * NBLK + q) * 256 + e];
+          for (int q = 0; q < NBLK; ++q) v[u][q] = (q == 0 || e < 16 * cam_part_rows(NCOL)) ? dp.cam_part[((size_t)s_seg[i + u] * NBLK + q) * 256 + e] : 0.0;   // (the rows of the second column block that exist: the evaluation kernel writes no others)
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -106,7 +106,7 @@ __device__ __forceinline__ void camera_reduce_frame(const DeviceProblem& dp, con
       }
       for (; i < nw; ++i)
 #pragma unroll
-        for (int q = 0; q < NBLK; ++q) sum[q] += dp.cam_part[((size_t)s_seg[i] * NBLK + q) * 256 + e];
+        for (int q = 0; q < NBLK; ++q) sum[q] += (q == 0 || e < 16 * cam_part_rows(NCOL)) ? dp.cam_part[((size_t)s_seg[i] * NBLK + q) * 256 + e] : 0.0;
     }
   }
 #pragma unroll
