@@ -108,9 +108,17 @@ __device__ __forceinline__ bool lm_not_accepted(const double* ctl) { return ctl 
 
 constexpr int kEvalBlock = 256;
 constexpr int kStageFrames = 16;   // camera blocks staged through LDS per workgroup
-// rows of the blocks (1, 0) and (1, 1) of a wave's partial G = [Ji | Jc | r]^T [Ji | Jc | r] (dp.cam_part) that are written and read: the columns of
-// the second 16-column block that exist, rounded up to the four rows a lane group stores at a time (ncol = columns of the operand, 17 .. 32)
-__host__ __device__ constexpr int cam_part_rows(int ncol) { return ncol <= 16 ? 16 : ((ncol - 16 + 3) / 4) * 4; }
+// A wave's partial G = X^T X, X = [Ji | Jc | r] (ncol columns), as 16 x 16 blocks of v_mfma_f64_16x16x4_f64 in dp.cam_part ([segments][blocks][256]).
+//   ncol <= 16: ONE block, rows and columns = the operand's columns.
+//   16 < ncol <= 24 (rolling shutter + intrinsics: 22) — TWO products cover everything on and below the diagonal of a 22 x 22 Gram matrix, because a
+//   product's two operands may select DIFFERENT columns and the upper triangle of a block is not needed (round 6; three blocks (0,0) (1,0) (1,1) until then):
+//     block 0: rows = columns 0 .. 15,       columns = columns 0 .. 7 and 16 .. ncol-1   ->  G(i, j < 8) for i < 16, and G(i >= 16, j < 16) transposed
+//     block 1: rows = columns 8 .. ncol-1,   columns = the same                          ->  G(i >= 8, j >= 8)
+//   (selected columns behind the operand's last are a zero column.)  cam_part_entry() says where entry (a, b), a >= b, is.
+__host__ __device__ constexpr int cam_part_blocks(int ncol) { return ncol <= 16 ? 1 : (ncol <= 24 ? 2 : (((ncol + 15) / 16) * ((ncol + 15) / 16 + 1)) / 2); }
+__host__ __device__ constexpr int cam_part_entry(int ncol, int a, int b) {   // -> block * 256 + row * 16 + column (two-block form)
+  return (a >= 16 && b < 16) ? b * 16 + (a - 8) : (b < 8 ? a * 16 + b : 256 + (a - 8) * 16 + (b - 8));
+}
 
 enum EvalMode : int {
   kResidualOnly = 0,   // T=double path: residuals + cost (trial point of the trust-region loop)

@@ -151,11 +151,17 @@ __global__ __launch_bounds__(kEvalBlock) void eval_kernel(const DeviceProblem dp
       // and, with intrinsics as a parameter block, the border blocks Ji^T Jc, Ji^T Ji, Ji^T r of the same frame.
       // MFMA wants lane (i = lane & 15, g = lane >> 4) to hold column i of Jacobian row k = 4 step + g, while the rows
       // live one observation per lane: they change lanes through LDS, half a wave (64 rows) at a time.  A wave
-      // that straddles frames does one pass per frame, rows of the other frames masked to zero.  Only the blocks
-      // on and below the diagonal of G are formed (NCB (NCB + 1) / 2 of 16 x 16).
+      // that straddles frames does one pass per frame, rows of the other frames masked to zero.  One 16 x 16 product per four rows
+      // for up to 16 columns; TWO for the 22 columns of rolling shutter + intrinsics (device_state.hpp: cam_part_blocks — the two operands
+      // of a product select different columns, so that two blocks hold everything on and below the diagonal of G; three products
+      // (0,0) (1,0) (1,1) until round 6: 47 % of their work multiplied padding).
       typedef double dbl4 __attribute__((ext_vector_type(4)));
-      constexpr int NBLK = NCB * (NCB + 1) / 2;
+      constexpr int NBLK = cam_part_blocks(NCOL);
+      constexpr bool TWO = NCB == 2;
+      static_assert(NCB <= 2, "operands of up to 24 columns");
       const int lane = tid & 63, wv = tid >> 6, ci = lane & 15, cg = lane >> 4;
+      // (two-product form) the columns this lane supplies: block 0 = columns 0 .. 15 against columns 0 .. 7, 16 .. ; block 1 = columns 8 .. against themselves; NCOL = a zero column
+      const int col_b0 = ci < 8 ? ci : (ci + 8 < NCOL ? ci + 8 : NCOL), col_a1 = ci + 8 < NCOL ? ci + 8 : NCOL;
       double* tr = s_tr + wv * TRW;
       const int my_frame = valid ? f : -1;
       const int64_t wave_id = (base >> 6) + wv;
@@ -189,26 +195,24 @@ __global__ __launch_bounds__(kEvalBlock) void eval_kernel(const DeviceProblem dp
           if (o_lo < o_hi) {
             const int s_lo = (2 * (o_lo - 32 * h)) >> 2, s_hi = (2 * (o_hi - 32 * h) + 3) >> 2;
             for (int step = s_lo; step < s_hi; ++step) {
-              double a[NCB];
-#pragma unroll
-              for (int q = 0; q < NCB; ++q) a[q] = tr[(4 * step + cg) * TP + 16 * q + ci];
-#pragma unroll
-              for (int qa = 0; qa < NCB; ++qa)
-#pragma unroll
-                for (int qb = 0; qb <= qa; ++qb) d[qa * (qa + 1) / 2 + qb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[qa], a[qb], d[qa * (qa + 1) / 2 + qb], 0, 0, 0);
+              const double* xr = tr + (4 * step + cg) * TP;
+              if constexpr (TWO) {
+                const double x0 = xr[ci], xb = xr[col_b0], x1 = xr[col_a1];
+                d[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, xb, d[0], 0, 0, 0);
+                d[NBLK - 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, d[NBLK - 1], 0, 0, 0);
+              } else {
+                const double x0 = xr[ci];
+                d[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, d[0], 0, 0, 0);
+              }
             }
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        // (rows of a block = columns 16 qa + row of the operand: the second column block holds NCOL - 16 of them — six with rolling shutter +
-        // intrinsics — and nothing reads the rows behind them (camera_reduce_frame, kernels_normal.hip: kCamPartRows): a third of the
-        // partials' bytes, written here and read there, at 4k cameras 0.33 GB each way)
         double* part = dp.cam_part + (size_t)seg * (NBLK * 256);
 #pragma unroll
         for (int q = 0; q < NBLK; ++q)
 #pragma unroll
-          for (int v = 0; v < 4; ++v)
-            if (q == 0 || 4 * v < cam_part_rows(NCOL)) part[q * 256 + (cg + 4 * v) * 16 + ci] = d[q][v];
+          for (int v = 0; v < 4; ++v) part[q * 256 + (cg + 4 * v) * 16 + ci] = d[q][v];
         ++seg;
         done = seg_end;
       }

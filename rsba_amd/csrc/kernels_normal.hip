@@ -74,7 +74,7 @@ __device__ __forceinline__ void take_candidate_block(const DeviceProblem& dp, co
 }
 template <int CD, bool CAL>
 __device__ __forceinline__ void camera_reduce_frame(const DeviceProblem& dp, const SolverDev& sv, const int f) {
-  constexpr int NI = CAL ? 0 : 9, NCOL = NI + CD + 1, NCB = (NCOL + 15) / 16, NBLK = NCB * (NCB + 1) / 2;
+  constexpr int NI = CAL ? 0 : 9, NCOL = NI + CD + 1, NBLK = cam_part_blocks(NCOL);   // (device_state.hpp: where the evaluation kernel leaves which entry of G)
   __shared__ double G[NBLK][256];
   const int e = threadIdx.x;
   const int64_t s0 = sv.frame_ptr[f], s1 = sv.frame_ptr[f + 1];
@@ -98,7 +98,7 @@ __device__ __forceinline__ void camera_reduce_frame(const DeviceProblem& dp, con
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
-          for (int q = 0; q < NBLK; ++q) v[u][q] = (q == 0 || e < 16 * cam_part_rows(NCOL)) ? dp.cam_part[((size_t)s_seg[i + u] * NBLK + q) * 256 + e] : 0.0;   // (the rows of the second column block that exist: the evaluation kernel writes no others)
+          for (int q = 0; q < NBLK; ++q) v[u][q] = dp.cam_part[((size_t)s_seg[i + u] * NBLK + q) * 256 + e];
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -106,7 +106,7 @@ __device__ __forceinline__ void camera_reduce_frame(const DeviceProblem& dp, con
       }
       for (; i < nw; ++i)
 #pragma unroll
-        for (int q = 0; q < NBLK; ++q) sum[q] += (q == 0 || e < 16 * cam_part_rows(NCOL)) ? dp.cam_part[((size_t)s_seg[i] * NBLK + q) * 256 + e] : 0.0;
+        for (int q = 0; q < NBLK; ++q) sum[q] += dp.cam_part[((size_t)s_seg[i] * NBLK + q) * 256 + e];
     }
   }
 #pragma unroll
@@ -114,8 +114,7 @@ __device__ __forceinline__ void camera_reduce_frame(const DeviceProblem& dp, con
   __syncthreads();
   auto g = [&](int a, int b) {   // entry (a, b) of the symmetric G
     if (a < b) { const int t = a; a = b; b = t; }
-    const int qa = a >> 4, qb = b >> 4;
-    return G[qa * (qa + 1) / 2 + qb][(a & 15) * 16 + (b & 15)];
+    return NBLK == 1 ? G[0][a * 16 + b] : (&G[0][0])[cam_part_entry(NCOL, a, b)];
   };
   for (int idx = e; idx < CD * CD; idx += 256) sv.U[(size_t)f * CD * CD + idx] = g(NI + idx / CD, NI + idx % CD);
   if (e < CD) sv.gc[(size_t)f * CD + e] = g(NI + CD, NI + e);

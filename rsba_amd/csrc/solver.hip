@@ -1340,7 +1340,7 @@ int32_t build_solver_impl(rsba_handle* h) {
     int32_t *d_base = nullptr, *d_rank = nullptr;
     if ((rc = s_upload(s, &d_base, wave_seg_base))) return rc;
     if ((rc = s_upload(s, &d_rank, frame_rank))) return rc;
-    const int ncb = ((dp.K - 3) + 1 + 15) / 16, nblk = ncb * (ncb + 1) / 2;
+    const int nblk = cam_part_blocks((dp.K - 3) + 1);   // (device_state.hpp)
     if ((rc = s_alloc(s, &h->dp.cam_part, (size_t)std::max(wave_seg_base[nwaves], 1) * nblk * 256))) return rc;
     h->dp.wave_seg_base = d_base; h->dp.frame_rank = d_rank;
   }
