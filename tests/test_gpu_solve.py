@@ -142,6 +142,22 @@ def test_shared_intrinsics_as_parameter_block(capi, oracle, rolling, huber):
     p.huber_a = huber
     p.intrinsics = p.intrinsics * (1.0 + 1e-3 * np.array([[1, -1, 20, -20, 10, 10, -10, 0.5, -0.5]]))   # start off the true calibration
     check_normal_equations_uncalibrated(capi, oracle, p)
+    # the pose blocks U_f = Jc^T Jc, g_f and the point blocks directly: with rolling shutter the operand [Ji | Jc | r] has 22 columns and the pose
+    # columns 9 .. 20 straddle the two 16 x 16 products the evaluation kernel leaves per wave (device_state.hpp: cam_part_entry — block 0, block 0
+    # transposed and block 1 all hold entries of U_f)
+    if huber == 0.0:   # (no loss: the corrected Jacobian is the oracle's raw one)
+        r, J, ok = oracle.evaluate_blocks(p)
+        cd = 6 * p.poses_per_frame
+        Jc = np.where(ok[:, None, None], J[:, :, 9:9 + cd], 0.0); Jp = np.where(ok[:, None, None], J[:, :, 9 + cd:], 0.0); rr = np.where(ok[:, None], r, 0.0)
+        if p.pose_fixed_mask is not None:   # the columns of fixed coordinates are zero in what the solver linearises (gauge: the first camera)
+            free = ((p.pose_fixed_mask.reshape(p.num_frames, -1)[:, :, None] >> np.arange(6)) & 1) == 0          # [F, P, 6]
+            Jc = Jc * free.reshape(p.num_frames, cd)[p.obs_frame][:, None, :]
+        U_ref = np.zeros((p.num_frames, cd, cd)); gc_ref = np.zeros((p.num_frames, cd)); V_ref = np.zeros((p.num_points, 3, 3)); gp_ref = np.zeros((p.num_points, 3))
+        np.add.at(U_ref, p.obs_frame, np.einsum("nrk,nrl->nkl", Jc, Jc)); np.add.at(gc_ref, p.obs_frame, np.einsum("nrk,nr->nk", Jc, rr))
+        np.add.at(V_ref, p.obs_point, np.einsum("nrk,nrl->nkl", Jp, Jp)); np.add.at(gp_ref, p.obs_point, np.einsum("nrk,nr->nk", Jp, rr))
+        with capi.DeviceProblem(p) as dp:
+            U, gc, V, gp = dp.normal_equations()
+        assert scaled_err(U, U_ref) <= 1e-11 and scaled_err(gc, gc_ref) <= 1e-11 and scaled_err(V, V_ref) <= 1e-11 and scaled_err(gp, gp_ref) <= 1e-11
     s, s_ref, p_dev, p_cpu = compare_solves(capi, oracle, p, iters=40)
     assert np.max(np.abs(p_dev.intrinsics - p_cpu.intrinsics) / np.maximum(1.0, np.abs(p_cpu.intrinsics))) <= 1e-6
     assert not np.array_equal(p_dev.intrinsics, p.intrinsics)
