@@ -116,7 +116,7 @@ constexpr int kStageFrames = 16;   // camera blocks staged through LDS per workg
 //     block 1: rows = columns 8 .. ncol-1,   columns = the same                          ->  G(i >= 8, j >= 8)
 //   (selected columns behind the operand's last are a zero column.)  cam_part_entry() says where entry (a, b), a >= b, is.
 __host__ __device__ constexpr int cam_part_blocks(int ncol) { return ncol <= 16 ? 1 : (ncol <= 24 ? 2 : (((ncol + 15) / 16) * ((ncol + 15) / 16 + 1)) / 2); }
-__host__ __device__ constexpr int cam_part_entry(int ncol, int a, int b) {   // -> block * 256 + row * 16 + column (two-block form)
+__host__ __device__ constexpr int cam_part_entry(int a, int b) {   // entry (a, b), a >= b, of the two-block form -> block * 256 + row * 16 + column
   return (a >= 16 && b < 16) ? b * 16 + (a - 8) : (b < 8 ? a * 16 + b : 256 + (a - 8) * 16 + (b - 8));
 }
 

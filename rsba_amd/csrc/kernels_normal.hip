@@ -61,9 +61,9 @@ __device__ __forceinline__ double u_diag(const SolverDev& sv, int64_t t) {
 // (opt.model.calibrated == false, shared sess.cam), the blocks of J^T J that are NOT block-diagonal:
 //   cross: U[F+v][f] rows = intrinsics coordinates of pseudo frame v, cols = pose coordinates of frame f
 //   self : per-frame partials of Ji^T Ji (45 unique) and Ji^T r (9), summed over frames by intr_reduce_kernel.
-// The products themselves are formed by the evaluation kernel (kernels_eval.hip): every wave leaves the 16 x 16
-// blocks on and below the diagonal of G = [Ji | Jc | r]^T [Ji | Jc | r] per frame it touches.  Here one workgroup
-// per frame sums its waves' partials in wave order (fixed order: deterministic) and files the entries of G.
+// The products themselves are formed by the evaluation kernel (kernels_eval.hip): every wave leaves, per frame it touches, the one or two
+// 16 x 16 blocks that hold everything on and below the diagonal of G = [Ji | Jc | r]^T [Ji | Jc | r] (device_state.hpp: cam_part_blocks /
+// cam_part_entry).  Here one workgroup per frame sums its waves' partials in wave order (fixed order: deterministic) and files the entries of G.
 // ---------------------------------------------------------------------------------------------
 // lm_take_candidate_kernel's copy, by workgroup `block` of a launch that carries it along
 __device__ __forceinline__ void take_candidate_block(const DeviceProblem& dp, const SolverDev& sv, int64_t block) {
@@ -114,7 +114,7 @@ __device__ __forceinline__ void camera_reduce_frame(const DeviceProblem& dp, con
   __syncthreads();
   auto g = [&](int a, int b) {   // entry (a, b) of the symmetric G
     if (a < b) { const int t = a; a = b; b = t; }
-    return NBLK == 1 ? G[0][a * 16 + b] : (&G[0][0])[cam_part_entry(NCOL, a, b)];
+    return NBLK == 1 ? G[0][a * 16 + b] : (&G[0][0])[cam_part_entry(a, b)];
   };
   for (int idx = e; idx < CD * CD; idx += 256) sv.U[(size_t)f * CD * CD + idx] = g(NI + idx / CD, NI + idx % CD);
   if (e < CD) sv.gc[(size_t)f * CD + e] = g(NI + CD, NI + e);
