@@ -397,7 +397,7 @@ def test_sharded_factorisation_with_motion_priors(tmp_path, mode, world):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode,world", [("nd:S300:5:perframe", 2), ("nd:S300:5:perframe", 4), ("nd:S300:5:perframe:priors", 3), ("nd:S300:5:perframe:mixedintr", 2),
-                                        ("nd:S300:5:perframe:mixedintr:priors:freeratio", 4)])
+                                        ("nd:S300:5:perframe:mixedintr:priors:freeratio", 4), ("nd:C4:3:perframe", 4)])   # (the last: 1000 blocks at the headline size — exchange (2) 12 MB instead of 131)
 def test_per_frame_intrinsics_blocks_on_several_ranks(tmp_path, mode, world):
     """Several intrinsics blocks (a 9-block per frame, CeresHandler.h:256-264,273-280; "mixedintr": two frames in three fall back on the session's
     block) in BOTH fast paths on several ranks (round 6): the SHARDED factorisation — a block's pseudo frames sit in a tile adjacent to the
